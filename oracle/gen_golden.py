@@ -1,0 +1,454 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (torch CPU) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference python oracle/gen_golden.py
+
+The reference's Python cannot travel to the GPU box, so its outputs are frozen here as small data
+fixtures (inputs + expected outputs) and committed with this script.  Nothing under
+/root/reference is modified; three attributes that transformers 5.x dropped are restored on the
+transformers modules in this process before the import.
+
+Fixtures written (all data, no reference source text):
+  scale_offset_grid.npz   a1/a2  compute_scale_offset_from_min_max / inverse over a grid
+  quantizer_cases.npz     a5     Quantizer.forward outputs + integer indices, all qcfg combos
+  qlinear_cases.npz       a8     QLinear.forward on small shapes (W8A8 / W4A8 / per-channel / bias)
+  calib_stream.npz        a12/a13 real get_act_range / get_act_scales on a toy module stack
+  checksums.json          sha256 of full-size index tensors (inputs re-creatable from numpy seeds)
+  api_surface.json        state_dict keys / export_qcfg / export_act_range of a toy sim model
+"""
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("MQ_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+# --- harness-side shim for transformers drift (nothing in the reference is edited) -------------
+import transformers.activations as ta            # noqa: E402
+import transformers.cache_utils as cu            # noqa: E402
+import transformers.utils.import_utils as iu     # noqa: E402
+
+cu.SinkCache = type("SinkCache", (cu.Cache,), {})
+iu.is_torch_fx_available = lambda: False
+ta.ACT2FN["silu"] = nn.SiLU
+for _n in ("lm_eval", "lm_eval.base", "lm_eval.evaluator", "lm_eval.tasks", "lm_eval.utils", "termcolor"):
+    sys.modules.setdefault(_n, types.ModuleType(_n))
+sys.modules["lm_eval.base"].BaseLM = object
+sys.modules["termcolor"].colored = lambda s, *a, **k: s
+for _k in ("base", "evaluator", "tasks", "utils"):
+    setattr(sys.modules["lm_eval"], _k, sys.modules["lm_eval." + _k])
+
+import mobilellm.quantization.qmodule as Q       # noqa: E402
+from mobilellm.model.ops import FMatMul          # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(1)          # fixed summation order for the fp32 matmuls we freeze
+
+
+def npf(t):
+    return t.detach().cpu().numpy()
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_scale_offset_grid():
+    mins = [-1.0, -3.5, 0.0, 0.25, 1.0, 2.0, -1e-7, -120.0, -0.013, 5.0, -7.25, -1e7, 0.0]
+    maxs = [2.0, 3.5, 1.0, 0.75, 1.0, 3.0, 1e-7, 250.0, 0.021, 5.5, -0.5, 1e7, 0.0]
+    rows = []
+    for mn, mx in zip(mins, maxs):
+        for bits in (4, 8, 16):
+            for sym in (False, True):
+                s, o, _, _, qmin, qmax = Q.compute_scale_offset_from_min_max(mn, mx, bits, sym)
+                imn, imx = Q.compute_min_max_from_scale_offset(s, o, bits, sym)
+                rows.append((mn, mx, bits, int(sym), float(s), float(o), qmin, qmax, float(imn), float(imx)))
+    arr = np.array(rows, dtype=np.float64)
+    # tensor (per-channel) form
+    g = torch.Generator().manual_seed(7)
+    tmn = -torch.rand(37, 1, generator=g) * 3
+    tmx = torch.rand(37, 1, generator=g) * 2 + 0.01
+    out = {"grid": arr, "tmin": npf(tmn), "tmax": npf(tmx)}
+    for bits in (4, 8, 16):
+        for sym in (False, True):
+            s, o, *_ = Q.compute_scale_offset_from_min_max(tmn, tmx, bits, sym)
+            out[f"t_scale_b{bits}_s{int(sym)}"] = npf(s)
+            out[f"t_offset_b{bits}_s{int(sym)}"] = npf(o)
+    np.savez_compressed(os.path.join(OUT, "scale_offset_grid.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def ref_index(qz, x):
+    """Integer index the reference computes inside Quantizer.forward (qmodule.py:286-287),
+    evaluated with the reference's own round_ste and the quantizer's cached state."""
+    xx = x
+    if qz.qcfg.is_per_channel and qz.qcfg.group_size != -1:
+        xx = x.reshape(-1, qz.qcfg.group_size)
+    q = (Q.round_ste(xx / qz.scale) + qz.offset).clamp(qz.qmin, qz.qmax)
+    chk = ((q - qz.offset) * qz.scale).reshape(x.shape).type(x.dtype)
+    return q.reshape(x.shape), chk
+
+
+def special_values(shape, g):
+    x = torch.randn(shape, generator=g) * 1.7
+    flat = x.view(-1)
+    flat[0], flat[1], flat[2], flat[3] = 0.0, -0.0, 1e-9, -1e-9
+    flat[4], flat[5] = 40.0, -40.0            # far out of range
+    return x
+
+
+def gen_quantizer_cases():
+    g = torch.Generator().manual_seed(1337)
+    out, meta = {}, []
+    cid = 0
+
+    def run(x, bits, sym, per_ch, group, dynamic, rng, tag):
+        nonlocal cid
+        qz = Q.Quantizer(Q.QuantConfig(bitwidth=bits, group_size=group, is_symmetric=sym,
+                                       is_per_channel=per_ch, is_dynamic=dynamic))
+        if rng is not None:
+            qz.set_scale_offset_from_minmax(rng[0], rng[1], "buffer", x.device)
+        y = qz(x)
+        if bits > 16:
+            assert y is x
+            return
+        q, chk = ref_index(qz, x)
+        assert torch.equal(chk, y), tag
+        k = f"c{cid}"
+        out[k + "_x"], out[k + "_y"], out[k + "_q"] = npf(x), npf(y), npf(q.float())
+        out[k + "_scale"], out[k + "_offset"] = npf(qz.scale.float()), npf(qz.offset.float())
+        rng_j = None
+        if rng is not None:
+            if torch.is_tensor(rng[0]):
+                out[k + "_rmin"], out[k + "_rmax"] = npf(rng[0]), npf(rng[1])
+                rng_j = "tensor"
+            else:
+                rng_j = list(rng)
+        meta.append(dict(id=k, tag=tag, bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch,
+                         group_size=group, is_dynamic=dynamic, rng=rng_j, qmin=qz.qmin, qmax=qz.qmax,
+                         dtype=str(x.dtype).replace("torch.", "")))
+        cid += 1
+
+    for bits in (4, 8, 16):
+        for sym in (False, True):
+            x = special_values((6, 64), g)
+            run(x, bits, sym, False, -1, False, (-2.5, 3.0), "static_per_tensor")
+            run(x, bits, sym, False, -1, False, None, "first_forward_per_tensor")
+            run(x, bits, sym, False, -1, True, None, "dynamic_per_tensor")
+            run(x, bits, sym, True, -1, False, None, "per_channel")
+            run(x, bits, sym, True, 32, False, None, "per_group32")
+    # exact .5 ties: x = (k + 0.5) * scale with a power-of-two scale so x/scale is exact
+    ties = (torch.arange(-20, 20, dtype=torch.float32) + 0.5) * 0.25
+    run(ties.view(4, 10), 8, False, False, -1, False, (-32.0, 31.75), "ties_pow2_scale")   # scale = 0.25
+    run(ties.view(4, 10), 8, True, False, -1, False, (-31.75, 31.75), "ties_sym")
+    # ranges not containing zero / degenerate (SURVEY 8a' items 2-3)
+    x = torch.rand(5, 16, generator=g) * 4
+    run(x, 8, False, False, -1, False, (2.0, 3.0), "min_gt_zero")
+    run(x, 8, False, False, -1, False, (1.0, 1.0), "degenerate")
+    run(x, 8, False, False, -1, False, (0.0, 1.0), "sigmoid_range")
+    run(x - 6.0, 8, False, False, -1, False, (-5.0, -1.0), "max_lt_zero")
+    run(x, 16, False, False, -1, False, (-3.0, 4.0), "static16")
+    run(x, 32, False, False, -1, False, None, "bypass32")
+    # activation-like 3-D tensor, realistic range
+    x3 = torch.randn(1, 24, 96, generator=g) * 3
+    run(x3, 8, False, False, -1, False, (float(x3.min()), float(x3.max())), "act3d_tensor_range")
+    run(x3, 16, False, False, -1, False, (float(x3.min()), float(x3.max())), "act3d_16bit")
+    # fp16 inputs: 0-dim scale keeps fp16 math, [N,1] scale promotes (SURVEY 8a' item 4)
+    xh = special_values((6, 64), g).half()
+    run(xh, 8, False, False, -1, False, (-2.5, 3.0), "f16_static_per_tensor")
+    run(xh, 8, True, False, -1, False, (-2.5, 3.0), "f16_static_per_tensor_sym")
+    # (fp16 first-forward range computation is impossible in the reference: clamp(max=1e6) overflows
+    #  half, qmodule.py:58 -- so the per-channel fp16 case uses preset fp32 [N,1] ranges, which promote)
+    run(xh, 8, False, True, -1, False, (-torch.rand(6, 1, generator=g) - 1.0, torch.rand(6, 1, generator=g) + 1.5),
+        "f16_per_channel_preset")
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "quantizer_cases.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_qlinear_cases():
+    g = torch.Generator().manual_seed(2024)
+    out, meta = {}, []
+    cid = 0
+
+    def run(M, K, N, wbits, wsym, wpc, in_cfg, out_bits, bias, tag, x_on_grid=None):
+        nonlocal cid
+        lin = nn.Linear(K, N, bias=bias)
+        lin.weight.copy_(torch.randn(N, K, generator=g) * 0.05)
+        if bias:
+            lin.bias.copy_(torch.randn(N, generator=g) * 0.1)
+        x = torch.randn(2, M // 2, K, generator=g) * 1.5
+        wq = Q.QuantConfig(bitwidth=wbits, is_symmetric=wsym, is_per_channel=wpc)
+        iq = Q.QuantConfig(**in_cfg) if in_cfg is not None else None
+        oq = Q.QuantConfig(bitwidth=out_bits)
+        ql = Q.QLinear.from_float(lin, iq if iq is not None else Q.QuantConfig(), wq, oq)
+        if iq is None:
+            ql.input_quantizer = None
+        if x_on_grid is not None:
+            # the producer's output grid: x is a fake-quantised tensor (q/k/v/o/w1/w3 case)
+            pz = Q.Quantizer(Q.QuantConfig(bitwidth=x_on_grid))
+            pz.set_scale_offset_from_minmax(float(x.min()), float(x.max()), "buffer")
+            x = pz(x)
+            out[f"c{cid}_xscale"], out[f"c{cid}_xoffset"] = npf(pz.scale), npf(pz.offset)
+        y_fp = nn.functional.linear(x, ql.weight, ql.bias)
+        act = {"output": [float(y_fp.min()), float(y_fp.max())]}
+        if iq is not None:
+            act["input"] = [float(x.min()), float(x.max())]
+        ql.set_scale_offset(act, "buffer")
+        y = ql(x)
+        k = f"c{cid}"
+        out[k + "_x"], out[k + "_w"], out[k + "_y"] = npf(x), npf(ql.weight), npf(y)
+        if bias:
+            out[k + "_b"] = npf(ql.bias)
+        out[k + "_wscale"], out[k + "_woffset"] = npf(ql.weight_quantizer.scale), npf(ql.weight_quantizer.offset)
+        meta.append(dict(id=k, tag=tag, M=M, K=K, N=N, wbits=wbits, wsym=wsym, wpc=wpc, in_cfg=in_cfg,
+                         out_bits=out_bits, bias=bias, act=act, x_on_grid=x_on_grid))
+        cid += 1
+
+    a8 = dict(bitwidth=8)
+    run(16, 128, 64, 8, False, False, None, 8, False, "w8a8_pt_noinq", x_on_grid=8)
+    run(16, 128, 64, 8, False, False, a8, 8, False, "w8a8_pt_inq")
+    run(16, 256, 96, 8, False, True, a8, 16, False, "w2_like_perch_out16")
+    run(16, 128, 64, 8, False, True, None, 8, True, "stablelm_qkv_bias_perch", x_on_grid=8)
+    run(16, 128, 64, 8, True, True, a8, 8, False, "w8_sym_perch")
+    run(16, 128, 64, 4, True, True, a8, 8, False, "w4a8_sym_perch")
+    run(16, 128, 64, 4, False, True, a8, 8, False, "w4a8_asym_perch")
+    run(16, 128, 64, 4, False, True, None, 16, True, "w4a8_asym_perch_out16_bias", x_on_grid=8)
+    run(8, 64, 32, 8, False, False, dict(bitwidth=8, is_symmetric=True), 8, False, "a8_sym_in")
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "qlinear_cases.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Toy(nn.Module):
+    """Toy module stack whose leaves are the classes the reference's calibration hooks select."""
+
+    def __init__(self):
+        super().__init__()
+        self.emb = nn.Embedding(50, 32)
+        self.fc1 = nn.Linear(32, 48)
+        self.act = nn.SiLU()
+        self.fc2 = nn.Linear(48, 32)
+        self.bmm = FMatMul()
+        self.ln = nn.LayerNorm(32)
+
+    def forward(self, ids):
+        h = self.emb(ids)
+        c = self.fc2(self.act(self.fc1(h)))
+        s = self.bmm(c, c.transpose(-1, -2))
+        return self.ln(c) + s.mean()
+
+
+class _Tok:
+    bos_token_id, vocab_size = 1, 50
+
+    def __call__(self, line, return_tensors="pt", max_length=None, truncation=True):
+        ids = torch.tensor([[int(t) for t in line.split()][:max_length]])
+        return types.SimpleNamespace(input_ids=ids)
+
+
+def _load_script(path, argv):
+    old = sys.argv
+    sys.argv = argv
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_script_" + os.path.basename(path)[:-3], path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = old
+    return mod
+
+
+def gen_calib_stream():
+    torch.manual_seed(11)
+    toy = _Toy().eval()
+    g = torch.Generator().manual_seed(5)
+
+    def make_ds(lens):
+        return [{"text": " ".join(str(int(t)) for t in torch.randint(2, 49, (n,), generator=g))} for n in lens]
+
+    def record(dataset, prefix, out):
+        """What every hooked leaf saw (our own hooks) = the fixture's tensor stream."""
+        names = {m: n for n, m in toy.named_modules()}
+        count = {}
+
+        def rec(m, xx, yy):
+            n = names[m]
+            k = count.get(n, 0)
+            count[n] = k + 1
+            out[f"{prefix}|{n}|input|{k}"] = npf(xx[0])
+            out[f"{prefix}|{n}|output|{k}"] = npf(yy)
+            if isinstance(m, FMatMul):
+                out[f"{prefix}|{n}|input2|{k}"] = npf(xx[1])
+
+        hs = [m.register_forward_hook(rec) for n, m in toy.named_modules()
+              if isinstance(m, (nn.Linear, nn.SiLU, nn.LayerNorm, FMatMul))]
+        for d in dataset:
+            toy(_Tok()(d["text"], max_length=64).input_ids)
+        for h in hs:
+            h.remove()
+
+    out = {}
+    ragged = make_ds([5, 9, 12, 7, 3, 10])     # per-tensor + absmax: ragged sequence lengths
+    fixed = make_ds([8] * 5)                   # per-channel: the reference needs a fixed length
+    record(ragged, "stream_pt", out)           # (S x S matmul outputs change channel count otherwise)
+    record(fixed, "stream_pc", out)
+
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+    pt = rng_mod.get_act_range(toy, _Tok(), ragged, len(ragged), 64)
+    rng_mod.args.per_channel = True
+    pc = rng_mod.get_act_range(toy, _Tok(), fixed, len(fixed), 64)
+    for name, fields in pt.items():
+        for f, v in fields.items():
+            out[f"pt|{name}|{f}"] = np.array(v, dtype=np.float64)
+    for name, fields in pc.items():
+        for f, v in fields.items():
+            out[f"pc|{name}|{f}"] = npf(v)
+    ss_mod = _load_script(os.path.join(REF, "ptq", "generate_act_scale_shift.py"), ["x", "--hf_path", "none"])
+    sc = ss_mod.get_act_scales(toy, _Tok(), ragged, len(ragged), 64)
+    for k, v in sc.items():
+        out[f"absmax|{k}"] = npf(v)
+    for k, v in toy.state_dict().items():
+        out["toy|" + k] = npf(v)
+    out["ids_pt"] = np.array(json.dumps([d["text"] for d in ragged]))
+    out["ids_pc"] = np.array(json.dumps([d["text"] for d in fixed]))
+    np.savez_compressed(os.path.join(OUT, "calib_stream.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_checksums():
+    """Full-size index tensors: inputs come from numpy seeds so the tests can re-create them."""
+    res = {}
+    rng = np.random.default_rng(1337)
+    x = (rng.standard_normal((2048, 2048), dtype=np.float32) * 1.0).astype(np.float32)
+    xt = torch.from_numpy(x)
+    for bits, sym in ((8, False), (8, True), (16, False)):
+        qz = Q.Quantizer(Q.QuantConfig(bitwidth=bits, is_symmetric=sym))
+        qz.set_scale_offset_from_minmax(float(xt.min()), float(xt.max()), "buffer")
+        y = qz(xt)
+        q, _ = ref_index(qz, xt)
+        res[f"act_2048x2048_b{bits}_s{int(sym)}"] = dict(
+            seed=1337, shape=[2048, 2048], rng=[float(xt.min()), float(xt.max())],
+            q_sha256=sha(npf(q).astype(np.int32)), y_sha256=sha(npf(y)))
+    rng = np.random.default_rng(4242)
+    w = (rng.standard_normal((5632, 2048), dtype=np.float32) * 0.02).astype(np.float32)
+    wt = torch.from_numpy(w)
+    for bits, sym, pc in ((8, False, False), (8, False, True), (4, True, True), (4, False, True)):
+        qz = Q.Quantizer(Q.QuantConfig(bitwidth=bits, is_symmetric=sym, is_per_channel=pc))
+        y = qz(wt)
+        q, _ = ref_index(qz, wt)
+        res[f"w_5632x2048_b{bits}_s{int(sym)}_pc{int(pc)}"] = dict(
+            seed=4242, shape=[5632, 2048], std=0.02,
+            q_sha256=sha(npf(q).astype(np.int32)), y_sha256=sha(npf(y)),
+            scale_sha256=sha(npf(qz.scale)), offset_sha256=sha(npf(qz.offset)))
+    with open(os.path.join(OUT, "checksums.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Block(nn.Module):
+    """Leaf-module graph of one llama-style decoder block (names drive the surgery rules)."""
+
+    def __init__(self, d=32, f=48):
+        super().__init__()
+        from mobilellm.model.hf_model import HFRMSNorm
+        self.input_layernorm = HFRMSNorm(d)
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = (nn.Linear(d, d, bias=False) for _ in range(4))
+        self.qk_bmm, self.pv_bmm = FMatMul(), FMatMul()
+        self.post_attention_layernorm = HFRMSNorm(d)
+        self.w1, self.w3, self.w2 = nn.Linear(d, f, bias=False), nn.Linear(d, f, bias=False), nn.Linear(f, d, bias=False)
+        self.act_fn = nn.SiLU()
+
+    def forward(self, x):
+        h = self.input_layernorm(x)
+        q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+        s = self.qk_bmm(q, k.transpose(-1, -2)) / (q.shape[-1] ** 0.5)
+        a = self.pv_bmm(torch.softmax(s, dim=-1), v)
+        x = x + self.o_proj(a)
+        h = self.post_attention_layernorm(x)
+        return x + self.w2(self.act_fn(self.w1(h)) * self.w3(h))
+
+
+class _ToyLM(nn.Module):
+    def __init__(self):
+        super().__init__()
+        from mobilellm.model.hf_model import HFRMSNorm
+        self.layers = nn.ModuleList([_Block(), _Block()])
+        self.norm = HFRMSNorm(32)
+        self.lm_head = nn.Linear(32, 50, bias=False)
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return self.lm_head(self.norm(x))
+
+
+def gen_api_surface():
+    torch.manual_seed(3)
+    m = _ToyLM().eval()
+    x = torch.randn(1, 6, 32, generator=torch.Generator().manual_seed(9))
+    fp = m(x)
+    sd0 = {k: npf(v) for k, v in m.state_dict().items()}
+    # calibrate per-tensor ranges of every leaf with the reference hook set
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+
+    class _M(nn.Module):                      # get_act_range feeds ids; wrap to feed our float input
+        def __init__(s, inner):
+            super().__init__(); s.inner = inner
+        def forward(s, ids):
+            return s.inner(x)
+    act = rng_mod.get_act_range(_M(m), _Tok(), [{"text": "1 2 3"}], 1, 8)
+    act = {k[len("inner."):]: v for k, v in act.items()}
+    wq, aq = Q.QuantConfig(bitwidth=8), Q.QuantConfig(bitwidth=8)
+    Q.create_sim_qmodel(m, wq, aq)
+    # mixed precision rules of ptq/mobilequant.py:175-201
+    for name, mod in m.named_modules():
+        if isinstance(mod, Q.QLinear):
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    qcfg = Q.export_qcfg(m)
+    Q.set_scale_and_offset(m, act, "buffer")
+    yq = m(x)
+    exported = Q.export_act_range(m)
+    surf = dict(qcfg=qcfg, act_dict=act, state_dict_keys=sorted(m.state_dict().keys()),
+                exported_act_range=exported,
+                module_types={n: type(mm).__name__ for n, mm in m.named_modules() if n})
+    with open(os.path.join(OUT, "api_surface.json"), "w") as f:
+        json.dump(surf, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "toy_lm.npz"), x=npf(x), y_fp=npf(fp), y_w8a8=npf(yq),
+                        **{"sd|" + k: v for k, v in sd0.items()})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_scale_offset_grid()
+    gen_quantizer_cases()
+    gen_qlinear_cases()
+    gen_calib_stream()
+    gen_checksums()
+    gen_api_surface()
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden fixtures written to", os.path.normpath(OUT), f"({tot/1024:.0f} KiB)")

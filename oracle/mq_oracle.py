@@ -1,0 +1,310 @@
+"""CPU oracle for the MobileQuant simulated-quant hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference's algorithm for the one hot path this
+repository accelerates: the fake-quant arithmetic of
+``mobilellm/quantization/qmodule.py`` and the running min/max statistics of
+``ptq/generate_act_range.py`` / ``ptq/generate_act_scale_shift.py``.  Every function cites
+the reference ``file:line`` it follows (paths relative to the reference checkout).
+
+Rules (see DESIGN.md "Oracle"):
+  * Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+    ``bench.py`` may import this module.  The product package ``mobilequant_amd`` never does;
+    it fails loudly when the HIP library is missing.
+  * Parity is PINNED: ``tests/test_oracle_golden.py`` checks every function here bit-exactly
+    against ``tests/golden/*.npz``, which ``oracle/gen_golden.py`` produced by importing the
+    real reference (torch CPU) in the build container.
+  * All arithmetic is IEEE fp32 (numpy float32), same operation order as the reference, so the
+    integer indices it yields are the reference's, bit for bit.  The only operation that is NOT
+    bit-reproducible is the fp32 matmul inside ``qlinear_sim`` (BLAS summation order); tests
+    state a tolerance there and use ``qlinear_int_exact`` for the exact integer contraction.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+CLIPMIN = F32(1e-5)   # qmodule.py:11
+CLIPMAX = F32(1e6)    # qmodule.py:12
+
+
+# ----------------------------------------------------------------------------------------------
+# a1  compute_scale_offset_from_min_max            qmodule.py:40-61
+# ----------------------------------------------------------------------------------------------
+def qrange(bitwidth: int, is_symmetric: bool):
+    """(qmin, qmax) integer grid limits.  qmodule.py:48-54."""
+    if is_symmetric:
+        return -(2 ** (bitwidth - 1)), 2 ** (bitwidth - 1) - 1
+    return 0, 2 ** bitwidth - 1
+
+
+def scale_offset_from_min_max(min_val, max_val, bitwidth: int, is_symmetric: bool):
+    """Returns (scale, offset, qmin, qmax); scale/offset are fp32 arrays shaped like min_val.
+
+    qmodule.py:40-61: asymmetric ``alpha = max-min, beta = min``; symmetric
+    ``alpha = max(|min|,|max|), beta = 0``; ``scale = clamp(alpha/qmax, 1e-5, 1e6)``;
+    ``offset = -round(beta/scale)`` (round half to even; symmetric gives -0.0).
+    Python floats enter through ``torch.tensor(v)`` = fp32 (qmodule.py:41-44).
+    """
+    mn = np.asarray(min_val, dtype=F32)
+    mx = np.asarray(max_val, dtype=F32)
+    qmin, qmax = qrange(bitwidth, is_symmetric)
+    if is_symmetric:
+        alpha = np.maximum(np.abs(mn), np.abs(mx))
+        beta = np.zeros_like(alpha)
+    else:
+        alpha = mx - mn
+        beta = mn
+    scale = (alpha / F32(qmax)).astype(F32)
+    scale = np.clip(scale, CLIPMIN, CLIPMAX).astype(F32)
+    offset = (-np.rint((beta / scale).astype(F32))).astype(F32)
+    return scale, offset, qmin, qmax
+
+
+# ----------------------------------------------------------------------------------------------
+# a2  compute_min_max_from_scale_offset            qmodule.py:66-76
+# ----------------------------------------------------------------------------------------------
+def min_max_from_scale_offset(scale, offset, bitwidth: int, is_symmetric: bool):
+    """Inverse map used by export_act_range (qmodule.py:908-937)."""
+    _, qmax = qrange(bitwidth, is_symmetric)
+    s = np.clip(np.asarray(scale, dtype=F32), CLIPMIN, CLIPMAX).astype(F32)
+    o = np.asarray(offset, dtype=F32)
+    alpha = (s * F32(qmax)).astype(F32)
+    beta = ((-o) * s).astype(F32)
+    max_val = (alpha + beta).astype(F32)
+    min_val = (-max_val) if is_symmetric else beta
+    return min_val, max_val
+
+
+# ----------------------------------------------------------------------------------------------
+# a3  compute_min_max_from_tensor                  qmodule.py:26-34
+# ----------------------------------------------------------------------------------------------
+def min_max_from_tensor(x, is_per_channel: bool = False, group_size: int = -1):
+    """Per-tensor amin/amax of the flattened tensor, or per-row (last dim, keepdim) /
+    per-group (reshape(-1, g) first).  qmodule.py:26-34 and :259-268."""
+    x = np.asarray(x)
+    if is_per_channel:
+        if group_size != -1:
+            x = x.reshape(-1, group_size)
+        return x.min(axis=-1, keepdims=True), x.max(axis=-1, keepdims=True)
+    flat = x.reshape(-1)
+    return flat.min(), flat.max()
+
+
+# ----------------------------------------------------------------------------------------------
+# a4/a5  round_ste + Quantizer.forward arithmetic   qmodule.py:17-21, :286-295
+# ----------------------------------------------------------------------------------------------
+def quantize_index(x, scale, offset, qmin: int, qmax: int):
+    """Integer grid index as an fp32 array: ``clamp(round(x/scale) + offset, qmin, qmax)``.
+
+    qmodule.py:286-287.  True IEEE division, round-half-even, fp32 add, clamp.
+    """
+    x = np.asarray(x, dtype=F32)
+    s = np.asarray(scale, dtype=F32)
+    o = np.asarray(offset, dtype=F32)
+    q = (np.rint((x / s).astype(F32)) + o).astype(F32)
+    return np.clip(q, F32(qmin), F32(qmax)).astype(F32)
+
+
+def dequantize_index(q, scale, offset):
+    """``(q - offset) * scale`` in fp32.  qmodule.py:290."""
+    q = np.asarray(q, dtype=F32)
+    s = np.asarray(scale, dtype=F32)
+    o = np.asarray(offset, dtype=F32)
+    return ((q - o).astype(F32) * s).astype(F32)
+
+
+def fake_quant(x, scale, offset, qmin: int, qmax: int):
+    """quantize -> dequantize, fp32.  qmodule.py:286-290."""
+    return dequantize_index(quantize_index(x, scale, offset, qmin, qmax), scale, offset)
+
+
+def fake_quant_f16_per_tensor(x, scale, offset, qmin: int, qmax: int):
+    """fp16 input with 0-dim fp32 scale/offset: the RESULT dtype stays fp16 (SURVEY 8a' item 4).
+
+    Measured against torch CPU (and frozen in quantizer_cases.npz): each op of qmodule.py:286-290
+    is evaluated in float with the half operand widened and the 0-dim fp32 scale/offset used at
+    full fp32 precision, and the result is rounded to half once per op.
+    """
+    H = np.float16
+    x = np.asarray(x, dtype=H)
+    s = F32(scale)
+    o = F32(offset)
+    t = (x.astype(F32) / s).astype(H)
+    r = np.rint(t.astype(F32)).astype(H)
+    q = (r.astype(F32) + o).astype(H)
+    q = np.clip(q, H(qmin), H(qmax)).astype(H)
+    d = (q.astype(F32) - o).astype(H)
+    return (d.astype(F32) * s).astype(H), q
+
+
+class QuantizerOracle:
+    """State machine of ``Quantizer`` (qmodule.py:112-295) without autograd.
+
+    ``forward`` reproduces qmodule.py:251-295: bypass when disabled or bitwidth > 16; optional
+    group reshape; (re)compute scale/offset when dynamic / LWC / not cached; fake-quantise.
+    """
+
+    def __init__(self, bitwidth=32, group_size=-1, is_symmetric=False, is_per_channel=False,
+                 is_dynamic=False):
+        self.bitwidth, self.group_size = bitwidth, group_size
+        self.is_symmetric, self.is_per_channel, self.is_dynamic = is_symmetric, is_per_channel, is_dynamic
+        self.enable = True
+        self.scale = self.offset = None
+        self.qmin = self.qmax = None
+
+    def set_from_minmax(self, mn, mx):                       # qmodule.py:216-245
+        self.scale, self.offset, self.qmin, self.qmax = scale_offset_from_min_max(
+            mn, mx, self.bitwidth, self.is_symmetric)
+
+    def forward(self, x, return_index=False):
+        if (not self.enable) or self.bitwidth > 16:          # qmodule.py:252-253
+            return (x, None) if return_index else x
+        x = np.asarray(x, dtype=F32)
+        shape = x.shape
+        if self.is_per_channel and self.group_size != -1:    # qmodule.py:259-260
+            x = x.reshape(-1, self.group_size)
+        if self.is_dynamic or self.scale is None:            # qmodule.py:262-277
+            mn, mx = min_max_from_tensor(x, self.is_per_channel, -1)
+            self.set_from_minmax(mn, mx)
+        q = quantize_index(x, self.scale, self.offset, self.qmin, self.qmax)
+        y = dequantize_index(q, self.scale, self.offset).reshape(shape)
+        return (y, q.reshape(shape)) if return_index else y
+
+
+# ----------------------------------------------------------------------------------------------
+# a8  QLinear.forward                               qmodule.py:341-358
+# ----------------------------------------------------------------------------------------------
+def qlinear_sim(x, weight, bias, w_q: QuantizerOracle | None, in_q: QuantizerOracle | None,
+                out_q: QuantizerOracle | None):
+    """The reference's simulated path: fake-quant W, (opt) fake-quant x, fp32 linear, fake-quant out.
+
+    qmodule.py:341-358.  The fp32 matmul's summation order is BLAS-defined, so the pre-output-
+    quant values agree with torch only to fp32 round-off (tests state the tolerance).
+    """
+    w = np.asarray(weight, dtype=F32)
+    if w_q is not None:
+        w = w_q.forward(w)
+    x = np.asarray(x, dtype=F32)
+    if in_q is not None:
+        x = in_q.forward(x)
+    out = x.reshape(-1, w.shape[1]) @ w.T
+    if bias is not None:
+        out = out + np.asarray(bias, dtype=F32)
+    out = out.astype(F32).reshape(*x.shape[:-1], w.shape[0])
+    if out_q is not None:
+        out = out_q.forward(out)
+    return out
+
+
+def qlinear_int_exact(qa, za, sa, qw, zw, sw, bias=None):
+    """Integer-GEMM equivalence of QLinear (SURVEY 8a' item 9), exact contraction.
+
+    ``out[m,n] = sa*sw[n] * sum_k (qa[m,k]-za)(qw[n,k]-zw[n]) + bias[n]``.  The contraction is
+    done in int64 (exact); the scaling mirrors the HIP epilogue: one int->fp32 conversion, one
+    multiply by fp32(sa*sw[n]), one add.  Returns (acc_int64, out_fp32).
+    """
+    qa = np.asarray(qa, dtype=np.int64)
+    qw = np.asarray(qw, dtype=np.int64)
+    za_i = np.asarray(za, dtype=np.int64)
+    zw_i = np.asarray(zw, dtype=np.int64).reshape(-1, 1) if np.ndim(zw) else np.int64(zw)
+    acc = (qa - za_i) @ (qw - zw_i).T
+    alpha = (F32(sa) * np.asarray(sw, dtype=F32).reshape(-1)).astype(F32)
+    out = (acc.astype(F32) * alpha).astype(F32)
+    if bias is not None:
+        out = (out + np.asarray(bias, dtype=F32)).astype(F32)
+    return acc, out
+
+
+# ----------------------------------------------------------------------------------------------
+# a12  update_act_range                             ptq/generate_act_range.py:55-69
+# ----------------------------------------------------------------------------------------------
+class ActRangeOracle:
+    """Running min/max per (module name, field) over a stream of tensors.
+
+    per-tensor: Python ``min``/``max`` of ``.min().item()/.max().item()`` (generate_act_range.py:65-69);
+    per-channel: ``reshape(-1, C)``, min/max over dim 0, running ``minimum``/``maximum`` kept as a
+    ``[2, C]`` tensor (generate_act_range.py:57-63).
+    """
+
+    def __init__(self, per_channel: bool = False):
+        self.per_channel = per_channel
+        self.act_dict: dict = {}
+
+    def update(self, name: str, field: str, t):
+        t = np.asarray(t, dtype=F32)
+        entry = self.act_dict.setdefault(name, {})
+        if self.per_channel:
+            t2 = t.reshape(-1, t.shape[-1])
+            cur = np.stack((t2.min(axis=0), t2.max(axis=0)), axis=0)
+            if field in entry:
+                cur[0] = np.minimum(entry[field][0], cur[0])
+                cur[1] = np.maximum(entry[field][1], cur[1])
+            entry[field] = cur
+        else:
+            mn, mx = float(t.min()), float(t.max())
+            if field in entry:
+                mn, mx = min(entry[field][0], mn), max(entry[field][1], mx)
+            entry[field] = [mn, mx]
+
+    @staticmethod
+    def merge(dicts, per_channel: bool):
+        """Min/max merge of several shards' act_dicts: what the all-reduce computes."""
+        out: dict = {}
+        for d in dicts:
+            for name, fields in d.items():
+                for field, v in fields.items():
+                    e = out.setdefault(name, {})
+                    if field not in e:
+                        e[field] = np.array(v, dtype=F32).copy() if per_channel else list(v)
+                    elif per_channel:
+                        e[field][0] = np.minimum(e[field][0], v[0])
+                        e[field][1] = np.maximum(e[field][1], v[1])
+                    else:
+                        e[field] = [min(e[field][0], v[0]), max(e[field][1], v[1])]
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a13  stat_tensor (SmoothQuant absmax)             ptq/generate_act_scale_shift.py:47-55
+# ----------------------------------------------------------------------------------------------
+class ActScaleOracle:
+    """Running per-channel absmax keyed ``"<module>_<field>"`` (generate_act_scale_shift.py:47-55)."""
+
+    def __init__(self):
+        self.act_scales: dict = {}
+
+    def update(self, name: str, field: str, t):
+        t = np.asarray(t, dtype=F32)
+        cur = np.abs(t.reshape(-1, t.shape[-1])).max(axis=0)
+        key = f"{name}_{field}"
+        self.act_scales[key] = np.maximum(self.act_scales[key], cur) if key in self.act_scales else cur
+
+
+# ----------------------------------------------------------------------------------------------
+# Storage formats the integer path adds (no reference counterpart; defined in DESIGN.md).
+# The values they carry are the reference's indices from quantize_index().
+# ----------------------------------------------------------------------------------------------
+def index_to_i8(q, qmin: int):
+    """Signed-byte storage of an 8-bit index: unsigned grids [0,255] are stored as q-128
+    (MFMA i8 is signed), signed grids [-128,127] as is.  Returns (int8 array, shift)."""
+    shift = 128 if qmin == 0 else 0
+    return (np.asarray(q, dtype=np.int32) - shift).astype(np.int8), shift
+
+
+def pack_w4(q, qmin: int):
+    """Pack 4-bit weight indices [N,K] two per byte, K-interleaved in blocks of 32:
+    byte j of a 16-byte group holds element j (low nibble) and element j+16 (high nibble) of the
+    32-element K block.  Nibbles are stored unsigned (q - qmin).  K must be a multiple of 32."""
+    q = np.asarray(q, dtype=np.int32) - qmin
+    n, k = q.shape
+    assert k % 32 == 0 and q.min() >= 0 and q.max() <= 15
+    blk = q.reshape(n, k // 32, 2, 16)
+    return (blk[:, :, 0, :] | (blk[:, :, 1, :] << 4)).astype(np.uint8).reshape(n, k // 2)
+
+
+def unpack_w4(packed, qmin: int):
+    p = np.asarray(packed, dtype=np.uint8)
+    n, kh = p.shape
+    blk = p.reshape(n, kh // 16, 16).astype(np.int32)
+    out = np.stack((blk & 15, blk >> 4), axis=2).reshape(n, kh * 2)
+    return out + qmin
