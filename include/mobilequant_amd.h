@@ -1,0 +1,153 @@
+/*
+ * mobilequant_amd.h -- C ABI of libmobilequant_amd.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary of the MobileQuant hot path.  The reference has no
+ * native boundary for this path: everything happens inside torch ops called from
+ * mobilellm/quantization/qmodule.py and ptq/generate_act_range.py.  Each entry point below names
+ * the reference code (file:line, relative to the reference checkout) whose arithmetic it replaces.
+ * A maintainer binds these with ctypes; mobilequant_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer (HBM) unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Kernels are enqueued
+ *     on it and the call returns without synchronising; no entry point reads results back.
+ *   - Tensors are dense row-major.  "rows x cols" views follow the reference:
+ *       per-tensor  : one (scale, offset) pair            (n_scale == 1)
+ *       per-row     : one pair per row of a [rows, cols] view (weights [N,K]: per output channel,
+ *                     qmodule.py:263-264; per-group: the caller views the tensor as [-1, g], :259-260)
+ *   - Return value: MQ_OK or an mq_status error; mq_last_error() gives the message for the calling
+ *     thread.  Nothing aborts the process.
+ *   - Integer storage of 8-bit indices ("i8 storage"): the reference's index q (qmodule.py:286-287)
+ *     minus `shift`, where shift = 128 for unsigned grids [0,255] and 0 for signed grids, so every
+ *     stored byte is a signed int8 that the MFMA i8 instructions consume directly.
+ */
+#ifndef MOBILEQUANT_AMD_H
+#define MOBILEQUANT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQ_VERSION 100 /* 0.1.0 */
+
+typedef void* mq_stream_t;
+
+typedef enum mq_status {
+  MQ_OK = 0,
+  MQ_EINVAL = 1,       /* bad argument: null pointer, misaligned pointer, bad shape/dtype */
+  MQ_EHIP = 2,         /* a HIP runtime call or kernel launch failed */
+  MQ_EUNSUPPORTED = 3  /* valid request this build has no kernel for */
+} mq_status;
+
+typedef enum mq_dtype {
+  MQ_F32 = 0,
+  MQ_F16 = 1,
+  MQ_I8 = 2,
+  MQ_U8 = 3,
+  MQ_I16 = 4,
+  MQ_U16 = 5,
+  MQ_I32 = 6
+} mq_dtype;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int mq_version(void);
+const char* mq_last_error(void);
+/* Device facts used by launch heuristics and by bench.py's roofline (compute units, clock). */
+int mq_device_info(int* cu_count, int* max_clock_khz, char* arch_name, size_t arch_name_len);
+
+/* ---- a1: compute_scale_offset_from_min_max  (qmodule.py:40-61) ------------------------------ */
+/* scale[i] = clamp(alpha/qmax, 1e-5, 1e6), offset[i] = -rint(beta/scale) for i < n; asymmetric:
+ * alpha = max-min, beta = min; symmetric: alpha = max(|min|,|max|), beta = 0 (offset = -0.0f). */
+int mq_scale_offset_from_minmax(const float* min_val, const float* max_val, int64_t n, int bitwidth,
+                                int is_symmetric, float* scale, float* offset, mq_stream_t stream);
+
+/* ---- a3 / a12 / a13: min/max reductions ----------------------------------------------------- */
+/* All reductions ACCUMULATE into their outputs (running min / running max), which is the update
+ * rule of update_act_range (ptq/generate_act_range.py:55-69).  Call mq_minmax_init first to start a
+ * fresh statistic (min = +inf, max = -inf).  Results are exact (min/max are order independent);
+ * -0.0 and +0.0 compare equal and either may be returned. */
+int mq_minmax_init(float* min_out, float* max_out, int64_t n, mq_stream_t stream);
+/* per-tensor: compute_min_max_from_tensor (qmodule.py:31-33); generate_act_range.py:65 */
+int mq_minmax_tensor(const void* x, int dtype, int64_t numel, float* min_out, float* max_out,
+                     mq_stream_t stream);
+/* per-row of a [rows, cols] view -> min_out[rows], max_out[rows] (qmodule.py:27-30, :263-264) */
+int mq_minmax_rows(const void* x, int dtype, int64_t rows, int64_t cols, float* min_out,
+                   float* max_out, mq_stream_t stream);
+/* per-column of a [rows, cols] view -> min_out[cols], max_out[cols]: per-channel activation
+ * statistics (generate_act_range.py:57-63).  SmoothQuant's absmax (generate_act_scale_shift.py:47-53)
+ * is max(|min|, |max|) of the same statistic. */
+int mq_minmax_cols(const void* x, int dtype, int64_t rows, int64_t cols, float* min_out,
+                   float* max_out, mq_stream_t stream);
+
+/* ---- a5: Quantizer.forward (qmodule.py:286-295) --------------------------------------------- */
+/* y = (clamp(rint(x / scale) + offset, qmin, qmax) - offset) * scale, IEEE fp32, bit-exact with the
+ * reference's CPU path.  x, y: [rows, cols] of `dtype` (MQ_F32 or MQ_F16), may alias.
+ * n_scale == 1: per-tensor; n_scale == rows: per-row.  For MQ_F16 the arithmetic follows torch's
+ * promotion rule (SURVEY 8a' item 4): per-tensor math rounds to half after every op, per-row math
+ * runs in fp32 and rounds once at the end. */
+int mq_fake_quant(const void* x, void* y, int dtype, int64_t rows, int64_t cols, const float* scale,
+                  const float* offset, int64_t n_scale, float qmin, float qmax, mq_stream_t stream);
+
+/* The integer index itself (qmodule.py:286-287) written as integers instead of being dequantised.
+ * q_dtype MQ_I8: i8 storage (index - shift, see top);  MQ_U8 / MQ_I16 / MQ_U16 / MQ_I32: the plain
+ * index.  row_sum (nullable, [rows] int32): sum over the row of the STORED values -- the
+ * zero-point correction term of the integer GEMM (SURVEY 8a' item 9), produced in the same pass. */
+int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale,
+                const float* offset, int64_t n_scale, float qmin, float qmax, int shift, void* q,
+                int q_dtype, int32_t* row_sum, mq_stream_t stream);
+
+/* ---- a8: QLinear.forward as a real-int8 GEMM (qmodule.py:341-358; SURVEY 8a' item 9) --------- */
+/* Epilogue vectors of one QLinear, computed on device from quantizer state (no host sync):
+ *   alpha[n]    = a_scale * w_scale[n]
+ *   w_zp[n]     = (int)w_offset[n] - w_shift                    stored-domain weight zero point
+ *   col_term[n] = -za * w_colsum[n] + K * za * w_zp[n],  za = (int)a_offset - a_shift
+ * a_scale/a_offset: 1 element.  w_scale/w_offset: n_wscale == 1 or N.  w_colsum[N] = row_sum
+ * output of mq_quantize on the weight.  */
+int mq_linear_epilogue_prepare(const float* a_scale, const float* a_offset, int a_shift,
+                               const float* w_scale, const float* w_offset, int64_t n_wscale,
+                               int w_shift, const int32_t* w_colsum, int64_t N, int64_t K,
+                               float* alpha, int32_t* w_zp, int32_t* col_term, mq_stream_t stream);
+
+/* out[m,n] = alpha[n] * (sum_k a[m,k]*w[n,k] - w_zp[n]*a_rowsum[m] + col_term[n]) + bias[n]
+ * optionally followed by the output quantizer (qmodule.py:356-357).
+ *   a [M,K] int8, w [N,K] int8 (i8 storage), K % 64 == 0, pointers 16-byte aligned.
+ *   a_rowsum [M] may be NULL when every w_zp is 0 (symmetric weights); bias may be NULL.
+ *   out_scale/out_offset (1 element each) NULL -> no output quantizer; out_dtype MQ_F32 / MQ_F16.
+ *   With an output quantizer: MQ_F32 / MQ_F16 store the fake-quantised value (what the reference
+ *   returns); MQ_U8 / MQ_I8 / MQ_U16 / MQ_I16 store the output index itself (MQ_I8 = index - 128 for an
+ *   unsigned grid) so the next integer GEMM can consume it.
+ * The int32 contraction is exact.  The output quantizer divides by multiplying with 1/out_scale
+ * (<= 1.5 ulp): DESIGN.md states the resulting tolerance against the reference. */
+int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K,
+                   const int32_t* a_rowsum, const float* alpha, const int32_t* w_zp,
+                   const int32_t* col_term, const float* bias, const float* out_scale,
+                   const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
+                   mq_stream_t stream);
+
+/* W4A8: weights as packed 4-bit indices.  mq_pack_w4 packs an [N,K] tensor of UNSIGNED nibbles
+ * (index - qmin, 0..15, one per byte) two per byte, K-interleaved in blocks of 32: byte j (0..15)
+ * of each 16-byte group holds element j in its low nibble and element j+16 in its high nibble.
+ * K % 64 == 0.  mq_w4a8_linear unpacks in registers and runs the same int8 MFMA contraction; its
+ * w_zp / col_term are in the unsigned-nibble domain (w_shift = qmin). */
+int mq_pack_w4(const uint8_t* nibbles, int64_t N, int64_t K, uint8_t* packed, mq_stream_t stream);
+int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K,
+                   const int32_t* a_rowsum, const float* alpha, const int32_t* w_zp,
+                   const int32_t* col_term, const float* bias, const float* out_scale,
+                   const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
+                   mq_stream_t stream);
+
+/* Tuning/diagnostic knob: force a GEMM tile configuration (see DESIGN.md "GEMM variants").
+ * variant < 0 restores the built-in heuristic.  Returns the number of variants. */
+int mq_gemm_set_variant(int variant);
+const char* mq_gemm_variant_name(int variant);
+/* Ablation switches for profiling (results are WRONG when non-zero): 1 = no LDS-DMA after the first
+ * stage, 2 = no MFMA loop, 4 = no epilogue.  0 = normal operation. */
+int mq_gemm_set_debug(int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBILEQUANT_AMD_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of libmobilequant_amd.so (the C ABI in include/mobilequant_amd.h).
+
+This is the binding a MobileQuant maintainer would add (INTEGRATION.md shows it in isolation).  There is
+deliberately NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+`import torch` must precede loading so the library binds to the HIP runtime torch already loaded
+(both carry the soname libamdhip64.so.7), which makes torch's streams and device pointers valid here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must be imported before the shared library is loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmobilequant_amd.so")
+
+# dtype codes of enum mq_dtype
+MQ_F32, MQ_F16, MQ_I8, MQ_U8, MQ_I16, MQ_U16, MQ_I32 = range(7)
+MQ_OK = 0
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "mq_version": (c_int, []),
+    "mq_last_error": (c_char_p, []),
+    "mq_device_info": (c_int, [POINTER(c_int), POINTER(c_int), ctypes.c_char_p, c_size_t]),
+    "mq_scale_offset_from_minmax": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "mq_minmax_init": (c_int, [_P, _P, c_int64, _P]),
+    "mq_minmax_tensor": (c_int, [_P, c_int, c_int64, _P, _P, _P]),
+    "mq_minmax_rows": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
+    "mq_minmax_cols": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
+    "mq_fake_quant": (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, _P]),
+    "mq_quantize": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, c_int, _P, c_int, _P, _P]),
+    "mq_linear_epilogue_prepare": (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int64, _P, _P, _P, _P]),
+    "mq_w8a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
+    "mq_pack_w4": (c_int, [_P, c_int64, c_int64, _P, _P]),
+    "mq_w4a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
+    "mq_gemm_set_variant": (c_int, [c_int]),
+    "mq_gemm_variant_name": (c_char_p, [c_int]),
+    "mq_gemm_set_debug": (c_int, [c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class MobileQuantLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library.  Raises loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MobileQuantLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m mobilequant_amd.build` (hipcc, gfx950). "
+            "mobilequant_amd has no CPU or PyTorch fallback for its kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+        fn.restype, fn.argtypes = res, args
+    if lib.mq_version() < 100:
+        raise MobileQuantLibraryError("libmobilequant_amd.so is older than this Python package")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an entry point that returns mq_status; raise with the library's message on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != MQ_OK:
+        msg = lib.mq_last_error().decode("utf-8", "replace")
+        raise MobileQuantLibraryError(f"{name} failed (status {rc}): {msg}")
+
+
+def device_info():
+    lib = load()
+    cu, khz = c_int(0), c_int(0)
+    buf = ctypes.create_string_buffer(64)
+    rc = lib.mq_device_info(ctypes.byref(cu), ctypes.byref(khz), buf, 64)
+    if rc != MQ_OK:
+        raise MobileQuantLibraryError("mq_device_info: " + lib.mq_last_error().decode())
+    return {"cu_count": cu.value, "max_clock_khz": khz.value, "arch": buf.value.decode()}

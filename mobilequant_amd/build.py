@@ -1,0 +1,72 @@
+"""Build recipe for libmobilequant_amd.so (HIP, gfx950 only): plain hipcc, in-tree output.
+
+    python -m mobilequant_amd.build          # build if sources are newer than the library
+    python -m mobilequant_amd.build --force
+
+The library has a C ABI (include/mobilequant_amd.h) and no torch dependency; it is built in-tree at
+mobilequant_amd/lib/ so it travels to the GPU box with the source snapshot.  hipcc cross-compiles
+gfx950 without a GPU.  Flags that matter for bit-exact parity with the reference's fp32 arithmetic:
+no fast-math, -ffp-contract=off, correctly rounded fp32 divide.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libmobilequant_amd.so")
+SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ABLATE = ["-DMQ_GEMM_ABLATE"] if os.environ.get("MQ_GEMM_ABLATE") else []
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-Wall", "-Wno-unused-function",
+    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *ABLATE,
+]
+
+
+def _newest_source() -> float:
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "mobilequant_amd.h"),
+                                                               os.path.abspath(__file__)]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def needs_build() -> bool:
+    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print("built", path)

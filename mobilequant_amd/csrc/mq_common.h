@@ -1,0 +1,64 @@
+// Shared helpers for the libmobilequant_amd translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "mobilequant_amd.h"
+
+namespace mq {
+
+// Thread-local error text behind mq_last_error(); defined in mq_elementwise.hip.
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(mq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+#define MQ_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      mq::set_error(__VA_ARGS__);  \
+      return MQ_EINVAL;            \
+    }                              \
+  } while (0)
+
+#define MQ_LAUNCH_CHECK(name)                                                        \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      mq::set_error("%s: kernel launch failed: %s", name, hipGetErrorString(e__));   \
+      return MQ_EHIP;                                                                \
+    }                                                                                \
+  } while (0)
+
+// 64-lane wave reductions (DPP/permute based via __shfl_xor; wave = 64 on gfx950).
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Exact float atomic min/max on the IEEE bit pattern (no CAS loop): non-negative floats order as
+// signed ints, negative floats order reversed as unsigned ints.
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (v >= 0.0f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+}  // namespace mq

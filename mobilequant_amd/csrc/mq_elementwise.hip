@@ -1,0 +1,397 @@
+// Elementwise kernels of the simulated-quant forward (HBM-bound): scale/offset from min/max,
+// fake-quant, quantize-to-integer (+ row sums), GEMM epilogue-vector preparation, W4 packing.
+//
+// Bit-exactness contract (DESIGN.md "Numerics"): every kernel here evaluates the reference's fp32
+// expression tree op for op -- IEEE division (never reciprocal-multiply), round-half-even
+// (v_rndne_f32), separate add / clamp / subtract / multiply, no FMA contraction -- so the integer
+// indices equal the reference CPU path's bit for bit.  Build flags: -ffp-contract=off, no fast-math,
+// -fhip-fp32-correctly-rounded-divide-sqrt (hipcc default, stated explicitly in build.py).
+#include <hip/hip_fp16.h>
+
+#include "mq_common.h"
+
+#pragma clang fp contract(off)
+
+namespace mq {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- the reference's scalar expression tree ---------------------------------------------------
+// qmodule.py:286-287
+__device__ __forceinline__ float q_index(float x, float s, float o, float qmin, float qmax) {
+  float t = __fdiv_rn(x, s);
+  float r = rintf(t);
+  float q = __fadd_rn(r, o);
+  return fminf(fmaxf(q, qmin), qmax);
+}
+// qmodule.py:290
+__device__ __forceinline__ float q_dequant(float q, float s, float o) { return __fmul_rn(__fsub_rn(q, o), s); }
+
+// fp16 tensor with 0-dim fp32 scale/offset: result rounded to half after every op (SURVEY 8a' item 4)
+__device__ __forceinline__ float h_round(float v) { return __half2float(__float2half_rn(v)); }
+__device__ __forceinline__ float q_index_hmath(float x, float s, float o, float qmin, float qmax) {
+  float t = h_round(__fdiv_rn(x, s));
+  float r = h_round(rintf(t));
+  float q = h_round(__fadd_rn(r, o));
+  return fminf(fmaxf(q, qmin), qmax);   // qmin/qmax are exactly representable in half for <= 8 bits
+}
+__device__ __forceinline__ float q_dequant_hmath(float q, float s, float o) {
+  return h_round(__fmul_rn(h_round(__fsub_rn(q, o)), s));
+}
+
+// ---- a1 -----------------------------------------------------------------------------------------
+__global__ void scale_offset_kernel(const float* __restrict__ mn, const float* __restrict__ mx, int64_t n,
+                                    float qmax, int symmetric, float* __restrict__ scale,
+                                    float* __restrict__ offset) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float lo = mn[i], hi = mx[i];
+  float alpha, beta;
+  if (symmetric) {
+    alpha = fmaxf(fabsf(lo), fabsf(hi));
+    beta = 0.0f;
+  } else {
+    alpha = __fsub_rn(hi, lo);
+    beta = lo;
+  }
+  float s = __fdiv_rn(alpha, qmax);
+  s = fminf(fmaxf(s, 1e-5f), 1e6f);            // qmodule.py:58 (CLIPMIN / CLIPMAX)
+  scale[i] = s;
+  offset[i] = -rintf(__fdiv_rn(beta, s));      // qmodule.py:60 ; symmetric -> -0.0f
+}
+
+// ---- a5: fake-quant, vectorised 16 B per lane ---------------------------------------------------
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  float v[4];
+  __device__ static float get(const Vec16& a, int i) { return a.v[i]; }
+  __device__ static void set(Vec16& a, int i, float f) { a.v[i] = f; }
+};
+template <>
+struct Vec16<__half> {
+  static constexpr int N = 8;
+  __half v[8];
+  __device__ static float get(const Vec16& a, int i) { return __half2float(a.v[i]); }
+  __device__ static void set(Vec16& a, int i, float f) { a.v[i] = __float2half_rn(f); }
+};
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, int64_t i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, int64_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld<__half>(const __half* p, int64_t i) { return __half2float(p[i]); }
+template <typename T>
+__device__ __forceinline__ void st(T* p, int64_t i, float v);
+template <>
+__device__ __forceinline__ void st<float>(float* p, int64_t i, float v) { p[i] = v; }
+template <>
+__device__ __forceinline__ void st<__half>(__half* p, int64_t i, float v) { p[i] = __float2half_rn(v); }
+
+template <typename T, bool PER_ROW, bool HMATH>
+__global__ void __launch_bounds__(256) fake_quant_vec_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                             int64_t nvec, uint32_t cols,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, float qmin,
+                                                             float qmax) {
+  using V = Vec16<T>;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f, o = 0.f;
+  if (!PER_ROW) {
+    s = scale[0];
+    o = offset[0];
+  }
+  const V* xv = reinterpret_cast<const V*>(x);
+  V* yv = reinterpret_cast<V*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    V a = xv[i];
+    if (PER_ROW) {
+      int64_t row = (i * V::N) / cols;          // cols % V::N == 0: a vector never straddles rows
+      s = scale[row];
+      o = offset[row];
+    }
+    V r;
+#pragma unroll
+    for (int j = 0; j < V::N; ++j) {
+      float f = V::get(a, j);
+      float q = HMATH ? q_index_hmath(f, s, o, qmin, qmax) : q_index(f, s, o, qmin, qmax);
+      V::set(r, j, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
+    }
+    yv[i] = r;
+  }
+}
+
+template <typename T, bool PER_ROW, bool HMATH>
+__global__ void __launch_bounds__(256) fake_quant_scalar_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                int64_t numel, int64_t cols,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ offset, float qmin,
+                                                                float qmax) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    int64_t row = PER_ROW ? i / cols : 0;
+    float s = scale[row], o = offset[row];
+    float f = ld<T>(x, i);
+    float q = HMATH ? q_index_hmath(f, s, o, qmin, qmax) : q_index(f, s, o, qmin, qmax);
+    st<T>(y, i, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
+  }
+}
+
+// ---- quantize to integers, one workgroup per row, optional row sum ------------------------------
+template <typename QT>
+__device__ __forceinline__ QT to_store(float q, int shift) {
+  return static_cast<QT>(static_cast<int>(q) - shift);
+}
+
+template <typename T, typename QT, bool PER_ROW>
+__global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict__ x, QT* __restrict__ q,
+                                                            int64_t cols, const float* __restrict__ scale,
+                                                            const float* __restrict__ offset, float qmin,
+                                                            float qmax, int shift, int32_t* __restrict__ row_sum,
+                                                            int vec_ok) {
+  using V = Vec16<T>;
+  const int64_t row = blockIdx.x;
+  const float s = scale[PER_ROW ? row : 0];
+  const float o = offset[PER_ROW ? row : 0];
+  const T* xr = x + row * cols;
+  QT* qr = q + row * cols;
+  int acc = 0;
+  if (vec_ok) {
+    const int64_t nvec = cols / V::N;
+    const V* xv = reinterpret_cast<const V*>(xr);
+    for (int64_t i = threadIdx.x; i < nvec; i += 256) {
+      V a = xv[i];
+      QT out[V::N];
+#pragma unroll
+      for (int j = 0; j < V::N; ++j) {
+        float qi = q_index(V::get(a, j), s, o, qmin, qmax);
+        int st_v = static_cast<int>(qi) - shift;
+        acc += st_v;
+        out[j] = static_cast<QT>(st_v);
+      }
+      // V::N elements of QT: 4 B (f32->i8) .. 16 B; a single naturally aligned store
+      struct alignas(sizeof(QT) * V::N) Pack { QT e[V::N]; };
+      Pack p;
+#pragma unroll
+      for (int j = 0; j < V::N; ++j) p.e[j] = out[j];
+      reinterpret_cast<Pack*>(qr)[i] = p;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < cols; i += 256) {
+      float qi = q_index(ld<T>(xr, i), s, o, qmin, qmax);
+      int st_v = static_cast<int>(qi) - shift;
+      acc += st_v;
+      qr[i] = static_cast<QT>(st_v);
+    }
+  }
+  if (row_sum != nullptr) {
+    __shared__ int part[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) row_sum[row] = part[0] + part[1] + part[2] + part[3];
+  }
+}
+
+// ---- epilogue vectors of one QLinear ------------------------------------------------------------
+__global__ void linear_epilogue_prepare_kernel(const float* __restrict__ a_scale, const float* __restrict__ a_offset,
+                                               int a_shift, const float* __restrict__ w_scale,
+                                               const float* __restrict__ w_offset, int per_row, int w_shift,
+                                               const int32_t* __restrict__ w_colsum, int64_t N, int K,
+                                               float* __restrict__ alpha, int32_t* __restrict__ w_zp,
+                                               int32_t* __restrict__ col_term) {
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float sa = a_scale[0];
+  const int za = static_cast<int>(a_offset[0]) - a_shift;
+  const float sw = w_scale[per_row ? n : 0];
+  const int zw = static_cast<int>(w_offset[per_row ? n : 0]) - w_shift;
+  alpha[n] = __fmul_rn(sa, sw);
+  w_zp[n] = zw;
+  // two's-complement wrap-around is fine: the GEMM's final sum is exact when it fits int32
+  col_term[n] = (int32_t)((uint32_t)(-za) * (uint32_t)w_colsum[n] + (uint32_t)K * (uint32_t)za * (uint32_t)zw);
+}
+
+// ---- W4 packing ---------------------------------------------------------------------------------
+// out byte (n, kb*16 + j) = nib(n, kb*32 + j) | nib(n, kb*32 + 16 + j) << 4
+__global__ void pack_w4_kernel(const uint8_t* __restrict__ nib, int64_t total_out, uint8_t* __restrict__ packed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total_out) return;
+  int64_t grp = i >> 4;      // 16-byte output group == 32-element input block
+  int j = (int)(i & 15);
+  const uint8_t* src = nib + grp * 32;
+  packed[i] = (uint8_t)((src[j] & 15) | ((src[j + 16] & 15) << 4));
+}
+
+static int grid_for(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  const int64_t cap = 256 * 8;   // 256 CUs x 8 blocks, grid-stride beyond that
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <typename T>
+static int launch_fake_quant(const T* x, T* y, int64_t rows, int64_t cols, const float* scale, const float* offset,
+                             bool per_row, bool hmath, float qmin, float qmax, hipStream_t st) {
+  const int64_t numel = rows * cols;
+  constexpr int VN = Vec16<T>::N;
+  const bool vec = aligned(x, 16) && aligned(y, 16) && (per_row ? (cols % VN == 0) : (numel % VN == 0)) &&
+                   cols < (int64_t)0xffffffffu;
+#define MQ_FQ(PR, HM)                                                                                            \
+  if (vec)                                                                                                       \
+    fake_quant_vec_kernel<T, PR, HM><<<grid_for(numel / VN, 256), 256, 0, st>>>(x, y, numel / VN, (uint32_t)cols, \
+                                                                               scale, offset, qmin, qmax);       \
+  else                                                                                                           \
+    fake_quant_scalar_kernel<T, PR, HM><<<grid_for(numel, 256), 256, 0, st>>>(x, y, numel, cols, scale, offset,  \
+                                                                             qmin, qmax);
+  if (per_row) {
+    if (hmath) { MQ_FQ(true, true) } else { MQ_FQ(true, false) }
+  } else {
+    if (hmath) { MQ_FQ(false, true) } else { MQ_FQ(false, false) }
+  }
+#undef MQ_FQ
+  MQ_LAUNCH_CHECK("mq_fake_quant");
+  return MQ_OK;
+}
+
+template <typename T, typename QT>
+static int launch_quantize(const T* x, QT* q, int64_t rows, int64_t cols, const float* scale, const float* offset,
+                           bool per_row, float qmin, float qmax, int shift, int32_t* row_sum, hipStream_t st) {
+  constexpr int VN = Vec16<T>::N;
+  const int vec_ok = aligned(x, 16) && aligned(q, sizeof(QT) * VN) && (cols % VN == 0);
+  if (per_row)
+    quantize_rows_kernel<T, QT, true><<<(unsigned)rows, 256, 0, st>>>(x, q, cols, scale, offset, qmin, qmax, shift,
+                                                                    row_sum, vec_ok);
+  else
+    quantize_rows_kernel<T, QT, false><<<(unsigned)rows, 256, 0, st>>>(x, q, cols, scale, offset, qmin, qmax, shift,
+                                                                     row_sum, vec_ok);
+  MQ_LAUNCH_CHECK("mq_quantize");
+  return MQ_OK;
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" {
+
+int mq_version(void) { return MQ_VERSION; }
+
+const char* mq_last_error(void) { return g_err; }
+
+int mq_device_info(int* cu_count, int* max_clock_khz, char* arch_name, size_t arch_name_len) {
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    set_error("mq_device_info: no HIP device");
+    return MQ_EHIP;
+  }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (max_clock_khz) *max_clock_khz = p.clockRate;
+  if (arch_name && arch_name_len) snprintf(arch_name, arch_name_len, "%s", p.gcnArchName);
+  return MQ_OK;
+}
+
+int mq_scale_offset_from_minmax(const float* min_val, const float* max_val, int64_t n, int bitwidth,
+                                int is_symmetric, float* scale, float* offset, mq_stream_t stream) {
+  MQ_REQUIRE(min_val && max_val && scale && offset, "mq_scale_offset_from_minmax: null pointer");
+  MQ_REQUIRE(n >= 0 && bitwidth >= 2 && bitwidth <= 16, "mq_scale_offset_from_minmax: n=%lld bitwidth=%d",
+             (long long)n, bitwidth);
+  if (n == 0) return MQ_OK;
+  const float qmax = is_symmetric ? (float)((1 << (bitwidth - 1)) - 1) : (float)((1 << bitwidth) - 1);
+  scale_offset_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(min_val, max_val, n, qmax,
+                                                                                 is_symmetric, scale, offset);
+  MQ_LAUNCH_CHECK("mq_scale_offset_from_minmax");
+  return MQ_OK;
+}
+
+int mq_fake_quant(const void* x, void* y, int dtype, int64_t rows, int64_t cols, const float* scale,
+                  const float* offset, int64_t n_scale, float qmin, float qmax, mq_stream_t stream) {
+  MQ_REQUIRE(x && y && scale && offset, "mq_fake_quant: null pointer");
+  MQ_REQUIRE(rows >= 0 && cols >= 0, "mq_fake_quant: negative shape");
+  MQ_REQUIRE(n_scale == 1 || n_scale == rows, "mq_fake_quant: n_scale=%lld must be 1 or rows=%lld",
+             (long long)n_scale, (long long)rows);
+  MQ_REQUIRE(qmin <= qmax, "mq_fake_quant: qmin > qmax");
+  if (rows == 0 || cols == 0) return MQ_OK;
+  const bool per_row = (n_scale == rows) && rows > 1;
+  if (dtype == MQ_F32)
+    return launch_fake_quant<float>((const float*)x, (float*)y, rows, cols, scale, offset, per_row, false, qmin, qmax,
+                                    as_stream(stream));
+  if (dtype == MQ_F16)  // per-tensor: half math per op; per-row: fp32 math, one final rounding
+    return launch_fake_quant<__half>((const __half*)x, (__half*)y, rows, cols, scale, offset, per_row, !per_row,
+                                     qmin, qmax, as_stream(stream));
+  set_error("mq_fake_quant: dtype %d not supported (MQ_F32, MQ_F16)", dtype);
+  return MQ_EUNSUPPORTED;
+}
+
+int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
+                int64_t n_scale, float qmin, float qmax, int shift, void* q, int q_dtype, int32_t* row_sum,
+                mq_stream_t stream) {
+  MQ_REQUIRE(x && q && scale && offset, "mq_quantize: null pointer");
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && rows < (int64_t)0x7fffffff, "mq_quantize: bad shape %lld x %lld",
+             (long long)rows, (long long)cols);
+  MQ_REQUIRE(n_scale == 1 || n_scale == rows, "mq_quantize: n_scale=%lld must be 1 or rows=%lld", (long long)n_scale,
+             (long long)rows);
+  if (rows == 0 || cols == 0) return MQ_OK;
+  const bool per_row = (n_scale == rows) && rows > 1;
+  const float lo = qmin - (float)shift, hi = qmax - (float)shift;
+  hipStream_t st = as_stream(stream);
+#define MQ_Q(T, QT, LO, HI)                                                                                          \
+  do {                                                                                                               \
+    MQ_REQUIRE(lo >= (float)(LO) && hi <= (float)(HI), "mq_quantize: [%g,%g]-%d does not fit the storage type", qmin, \
+               qmax, shift);                                                                                         \
+    return launch_quantize<T, QT>((const T*)x, (QT*)q, rows, cols, scale, offset, per_row, qmin, qmax, shift,        \
+                                  row_sum, st);                                                                      \
+  } while (0)
+#define MQ_QD(T)                                          \
+  switch (q_dtype) {                                      \
+    case MQ_I8: MQ_Q(T, int8_t, -128, 127);               \
+    case MQ_U8: MQ_Q(T, uint8_t, 0, 255);                 \
+    case MQ_I16: MQ_Q(T, int16_t, -32768, 32767);         \
+    case MQ_U16: MQ_Q(T, uint16_t, 0, 65535);             \
+    case MQ_I32: MQ_Q(T, int32_t, -2147483648.0, 2147483520.0); \
+    default: break;                                       \
+  }
+  if (dtype == MQ_F32) { MQ_QD(float) }
+  else if (dtype == MQ_F16) { MQ_QD(__half) }
+#undef MQ_QD
+#undef MQ_Q
+  set_error("mq_quantize: dtype %d -> q_dtype %d not supported", dtype, q_dtype);
+  return MQ_EUNSUPPORTED;
+}
+
+int mq_linear_epilogue_prepare(const float* a_scale, const float* a_offset, int a_shift, const float* w_scale,
+                               const float* w_offset, int64_t n_wscale, int w_shift, const int32_t* w_colsum,
+                               int64_t N, int64_t K, float* alpha, int32_t* w_zp, int32_t* col_term,
+                               mq_stream_t stream) {
+  MQ_REQUIRE(a_scale && a_offset && w_scale && w_offset && w_colsum && alpha && w_zp && col_term,
+             "mq_linear_epilogue_prepare: null pointer");
+  MQ_REQUIRE(N > 0 && K > 0 && K < (1 << 24), "mq_linear_epilogue_prepare: N=%lld K=%lld", (long long)N, (long long)K);
+  MQ_REQUIRE(n_wscale == 1 || n_wscale == N, "mq_linear_epilogue_prepare: n_wscale=%lld must be 1 or N",
+             (long long)n_wscale);
+  linear_epilogue_prepare_kernel<<<(unsigned)((N + 255) / 256), 256, 0, as_stream(stream)>>>(
+      a_scale, a_offset, a_shift, w_scale, w_offset, n_wscale == N && N > 1, w_shift, w_colsum, N, (int)K, alpha, w_zp,
+      col_term);
+  MQ_LAUNCH_CHECK("mq_linear_epilogue_prepare");
+  return MQ_OK;
+}
+
+int mq_pack_w4(const uint8_t* nibbles, int64_t N, int64_t K, uint8_t* packed, mq_stream_t stream) {
+  MQ_REQUIRE(nibbles && packed, "mq_pack_w4: null pointer");
+  MQ_REQUIRE(N > 0 && K > 0 && K % 64 == 0, "mq_pack_w4: K=%lld must be a positive multiple of 64", (long long)K);
+  const int64_t total = N * K / 2;
+  pack_w4_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(nibbles, total, packed);
+  MQ_LAUNCH_CHECK("mq_pack_w4");
+  return MQ_OK;
+}
+
+}  // extern "C"

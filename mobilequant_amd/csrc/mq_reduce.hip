@@ -1,0 +1,290 @@
+// Min/max reductions (HBM-bound, one pass yields both): per-tensor, per-row, per-column.
+//
+// Replaces compute_min_max_from_tensor (qmodule.py:26-34) and the calibration statistics of
+// update_act_range (ptq/generate_act_range.py:55-69).  The reference does two reduction passes plus
+// two host syncs per tensor; here one pass keeps a device-resident running [min, max] with no host
+// readback: lane-private min/max over 16-byte loads -> 64-lane wave reduce -> LDS across the
+// workgroup's waves -> one exact float atomic per workgroup (bit-pattern ordered, mq_common.h).
+// min/max are exact and order independent, so any sharding of the data gives identical results.
+#include <hip/hip_fp16.h>
+
+#include "mq_common.h"
+
+namespace mq {
+
+template <typename T>
+struct Ld16;
+template <>
+struct Ld16<float> {
+  static constexpr int N = 4;
+  __device__ static void minmax(const float* p, float& lo, float& hi) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+    hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  __device__ static float one(const float* p) { return *p; }
+};
+template <>
+struct Ld16<__half> {
+  static constexpr int N = 8;
+  __device__ static void minmax(const __half* p, float& lo, float& hi) {
+    struct alignas(16) H8 { __half h[8]; };
+    H8 v = *reinterpret_cast<const H8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = __half2float(v.h[j]);
+      lo = fminf(lo, f);
+      hi = fmaxf(hi, f);
+    }
+  }
+  __device__ static float one(const __half* p) { return __half2float(*p); }
+};
+
+__global__ void minmax_init_kernel(float* mn, float* mx, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    mn[i] = __int_as_float(0x7f800000);   // +inf
+    mx[i] = __int_as_float(0xff800000);   // -inf
+  }
+}
+
+// canonicalise -0.0 -> +0.0 so the bit-pattern atomics treat the two zeros alike
+__device__ __forceinline__ float canon(float v) { return v + 0.0f; }
+
+__device__ __forceinline__ void block_commit(float lo, float hi, float* mn, float* mx) {
+  __shared__ float s_lo[4], s_hi[4];
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[w] = lo;
+    s_hi[w] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    if (lo <= hi) {   // false only when this workgroup saw no element
+      atomic_min_f32(mn, canon(lo));
+      atomic_max_f32(mx, canon(hi));
+    }
+  }
+}
+
+// per-tensor: grid-stride over 16-byte vectors; `head`/`tail` scalars cover unaligned ends
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_tensor_kernel(const T* __restrict__ x, int64_t numel, int64_t head,
+                                                            int64_t nvec, float* mn, float* mx) {
+  using L = Ld16<T>;
+  float lo = __int_as_float(0x7f800000), hi = __int_as_float(0xff800000);
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const T* xv = x + head;
+  for (int64_t i = tid; i < nvec; i += stride) L::minmax(xv + i * L::N, lo, hi);
+  // scalar ends: [0, head) and [head + nvec*N, numel)
+  const int64_t tail0 = head + nvec * L::N;
+  const int64_t nscalar = head + (numel - tail0);
+  for (int64_t i = tid; i < nscalar; i += stride) {
+    float f = L::one(x + (i < head ? i : tail0 + (i - head)));
+    lo = fminf(lo, f);
+    hi = fmaxf(hi, f);
+  }
+  block_commit(lo, hi, mn, mx);
+}
+
+// per-row: one wave per row, 4 rows per workgroup; accumulates into mn[row], mx[row] (plain RMW:
+// each row is owned by exactly one wave of one launch)
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_rows_kernel(const T* __restrict__ x, int64_t rows, int64_t cols,
+                                                          int vec_ok, float* __restrict__ mn,
+                                                          float* __restrict__ mx) {
+  using L = Ld16<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * cols;
+  float lo = __int_as_float(0x7f800000), hi = __int_as_float(0xff800000);
+  if (vec_ok) {
+    const int64_t nvec = cols / L::N;
+    for (int64_t i = lane; i < nvec; i += 64) L::minmax(xr + i * L::N, lo, hi);
+  } else {
+    for (int64_t i = lane; i < cols; i += 64) {
+      float f = L::one(xr + i);
+      lo = fminf(lo, f);
+      hi = fmaxf(hi, f);
+    }
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if (lane == 0) {
+    mn[row] = fminf(mn[row], lo);
+    mx[row] = fmaxf(mx[row], hi);
+  }
+}
+
+// per-column: workgroup = 64 lanes x 4 row-groups; a lane owns Ld16::N adjacent columns, the four
+// waves interleave rows; grid = (column tiles, row chunks); one atomic per column per workgroup.
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_cols_kernel(const T* __restrict__ x, int64_t rows, int64_t cols,
+                                                          int64_t rows_per_block, float* mn, float* mx) {
+  using L = Ld16<T>;
+  constexpr int N = L::N;
+  __shared__ float s_lo[4][64 * N], s_hi[4][64 * N];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * N;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float lo[N], hi[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    lo[j] = __int_as_float(0x7f800000);
+    hi[j] = __int_as_float(0xff800000);
+  }
+  if (c0 < cols) {
+    for (int64_t r = r0 + w; r < r1; r += 4) {
+      const T* p = x + r * cols + c0;
+      struct alignas(16) VV { T e[N]; };
+      VV v = *reinterpret_cast<const VV*>(p);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float f = (float)v.e[j];
+        lo[j] = fminf(lo[j], f);
+        hi[j] = fmaxf(hi[j], f);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    s_lo[w][lane * N + j] = lo[j];
+    s_hi[w][lane * N + j] = hi[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * N; i += 256) {
+    const int64_t c = (int64_t)blockIdx.x * 64 * N + i;
+    if (c < cols) {
+      float l = fminf(fminf(s_lo[0][i], s_lo[1][i]), fminf(s_lo[2][i], s_lo[3][i]));
+      float h = fmaxf(fmaxf(s_hi[0][i], s_hi[1][i]), fmaxf(s_hi[2][i], s_hi[3][i]));
+      if (l <= h) {
+        atomic_min_f32(mn + c, canon(l));
+        atomic_max_f32(mx + c, canon(h));
+      }
+    }
+  }
+}
+
+// generic (unaligned / cols % N != 0) per-column fallback: a thread owns one column
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_cols_scalar_kernel(const T* __restrict__ x, int64_t rows,
+                                                                 int64_t cols, int64_t rows_per_block, float* mn,
+                                                                 float* mx) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float lo = __int_as_float(0x7f800000), hi = __int_as_float(0xff800000);
+  for (int64_t r = r0; r < r1; ++r) {
+    float f = Ld16<T>::one(x + r * cols + c);
+    lo = fminf(lo, f);
+    hi = fmaxf(hi, f);
+  }
+  if (lo <= hi) {
+    atomic_min_f32(mn + c, canon(lo));
+    atomic_max_f32(mx + c, canon(hi));
+  }
+}
+
+template <typename T>
+static int launch_tensor(const T* x, int64_t numel, float* mn, float* mx, hipStream_t st) {
+  constexpr int N = Ld16<T>::N;
+  // leading scalars up to the first 16-byte boundary (tensor views may start anywhere)
+  int64_t head = 0;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(x);
+  if (a % 16) head = (int64_t)((16 - a % 16) / sizeof(T));
+  if (a % sizeof(T)) head = numel;  // cannot happen for real tensors
+  if (head > numel) head = numel;
+  const int64_t nvec = (numel - head) / N;
+  int64_t g = (nvec + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  minmax_tensor_kernel<T><<<(unsigned)g, 256, 0, st>>>(x, numel, head, nvec, mn, mx);
+  MQ_LAUNCH_CHECK("mq_minmax_tensor");
+  return MQ_OK;
+}
+
+template <typename T>
+static int launch_cols(const T* x, int64_t rows, int64_t cols, float* mn, float* mx, hipStream_t st) {
+  constexpr int N = Ld16<T>::N;
+  const bool vec = aligned(x, 16) && cols % N == 0;
+  const int64_t ctiles = vec ? (cols + 64 * N - 1) / (64 * N) : (cols + 255) / 256;
+  // enough row chunks to fill ~8 workgroups per CU, at least 64 rows each
+  int64_t chunks = (2048 + ctiles - 1) / ctiles;
+  int64_t rpb = (rows + chunks - 1) / chunks;
+  if (rpb < 64) rpb = 64;
+  chunks = (rows + rpb - 1) / rpb;
+  MQ_REQUIRE(chunks <= 65535 && ctiles < (int64_t)0x7fffffff, "mq_minmax_cols: shape too large");
+  dim3 grid((unsigned)ctiles, (unsigned)chunks);
+  if (vec)
+    minmax_cols_kernel<T><<<grid, 256, 0, st>>>(x, rows, cols, rpb, mn, mx);
+  else
+    minmax_cols_scalar_kernel<T><<<grid, 256, 0, st>>>(x, rows, cols, rpb, mn, mx);
+  MQ_LAUNCH_CHECK("mq_minmax_cols");
+  return MQ_OK;
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" {
+
+int mq_minmax_init(float* min_out, float* max_out, int64_t n, mq_stream_t stream) {
+  MQ_REQUIRE(min_out && max_out && n >= 0, "mq_minmax_init: bad arguments");
+  if (n == 0) return MQ_OK;
+  minmax_init_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(min_out, max_out, n);
+  MQ_LAUNCH_CHECK("mq_minmax_init");
+  return MQ_OK;
+}
+
+int mq_minmax_tensor(const void* x, int dtype, int64_t numel, float* min_out, float* max_out, mq_stream_t stream) {
+  MQ_REQUIRE(min_out && max_out && numel >= 0, "mq_minmax_tensor: bad arguments");
+  if (numel == 0) return MQ_OK;   // empty input leaves the running statistic untouched
+  MQ_REQUIRE(x, "mq_minmax_tensor: null input");
+  if (dtype == MQ_F32) return launch_tensor<float>((const float*)x, numel, min_out, max_out, as_stream(stream));
+  if (dtype == MQ_F16) return launch_tensor<__half>((const __half*)x, numel, min_out, max_out, as_stream(stream));
+  set_error("mq_minmax_tensor: dtype %d not supported", dtype);
+  return MQ_EUNSUPPORTED;
+}
+
+int mq_minmax_rows(const void* x, int dtype, int64_t rows, int64_t cols, float* min_out, float* max_out,
+                   mq_stream_t stream) {
+  MQ_REQUIRE(min_out && max_out && rows >= 0 && cols >= 0, "mq_minmax_rows: bad arguments");
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(x, "mq_minmax_rows: null input");
+  MQ_REQUIRE((rows + 3) / 4 < (int64_t)0x7fffffff, "mq_minmax_rows: too many rows");
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (dtype == MQ_F32) {
+    const int v = aligned(x, 16) && cols % 4 == 0;
+    minmax_rows_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, rows, cols, v, min_out, max_out);
+  } else if (dtype == MQ_F16) {
+    const int v = aligned(x, 16) && cols % 8 == 0;
+    minmax_rows_kernel<__half><<<grid, 256, 0, as_stream(stream)>>>((const __half*)x, rows, cols, v, min_out, max_out);
+  } else {
+    set_error("mq_minmax_rows: dtype %d not supported", dtype);
+    return MQ_EUNSUPPORTED;
+  }
+  MQ_LAUNCH_CHECK("mq_minmax_rows");
+  return MQ_OK;
+}
+
+int mq_minmax_cols(const void* x, int dtype, int64_t rows, int64_t cols, float* min_out, float* max_out,
+                   mq_stream_t stream) {
+  MQ_REQUIRE(min_out && max_out && rows >= 0 && cols >= 0, "mq_minmax_cols: bad arguments");
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(x, "mq_minmax_cols: null input");
+  if (dtype == MQ_F32) return launch_cols<float>((const float*)x, rows, cols, min_out, max_out, as_stream(stream));
+  if (dtype == MQ_F16) return launch_cols<__half>((const __half*)x, rows, cols, min_out, max_out, as_stream(stream));
+  set_error("mq_minmax_cols: dtype %d not supported", dtype);
+  return MQ_EUNSUPPORTED;
+}
+
+}  // extern "C"

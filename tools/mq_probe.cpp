@@ -1,0 +1,266 @@
+// Standalone probe for libmobilequant_amd.so on a GPU box (no torch): checks the int8 GEMM against a
+// host integer reference and times every tile variant with HIP events.
+//   hipcc --offload-arch=gfx950 -O2 -Iinclude tools/mq_probe.cpp -Lmobilequant_amd/lib -lmobilequant_amd \
+//         -Wl,-rpath,'$ORIGIN/../mobilequant_amd/lib' -o tools/mq_probe
+//   tools/mq_probe [M N K] [iters]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <vector>
+
+#include "mobilequant_amd.h"
+
+#define HIPCHK(x)                                                                   \
+  do {                                                                              \
+    hipError_t e = (x);                                                             \
+    if (e != hipSuccess) {                                                          \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e)); \
+      exit(2);                                                                      \
+    }                                                                               \
+  } while (0)
+#define MQCHK(x)                                                                 \
+  do {                                                                           \
+    int r = (x);                                                                 \
+    if (r != MQ_OK) {                                                            \
+      fprintf(stderr, "%s:%d %s -> %d (%s)\n", __FILE__, __LINE__, #x, r, mq_last_error()); \
+      exit(3);                                                                   \
+    }                                                                            \
+  } while (0)
+
+template <typename T>
+T* dmalloc(size_t n) {
+  T* p;
+  HIPCHK(hipMalloc(&p, n * sizeof(T)));
+  return p;
+}
+template <typename T>
+T* upload(const std::vector<T>& h) {
+  T* p = dmalloc<T>(h.size());
+  HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+
+struct Problem {
+  int M, N, K;
+  std::vector<int8_t> a, w;
+  std::vector<int32_t> rs, zw, ct;
+  std::vector<float> alpha, bias;
+  int8_t *da, *dw;
+  int32_t *drs, *dzw, *dct;
+  float *dalpha, *dbias, *dos, *doo;
+  float os, oo;
+};
+
+static Problem make_problem(int M, int N, int K, unsigned seed, bool per_row) {
+  Problem p;
+  p.M = M; p.N = N; p.K = K;
+  std::mt19937 g(seed);
+  std::uniform_int_distribution<int> d8(-128, 127);
+  p.a.resize((size_t)M * K);
+  p.w.resize((size_t)N * K);
+  for (auto& v : p.a) v = (int8_t)d8(g);
+  for (auto& v : p.w) v = (int8_t)d8(g);
+  p.rs.resize(M);
+  for (int m = 0; m < M; ++m) {
+    int s = 0;
+    for (int k = 0; k < K; ++k) s += p.a[(size_t)m * K + k];
+    p.rs[m] = s;
+  }
+  const int za = 7;   // stored-domain activation zero point
+  p.zw.resize(N); p.ct.resize(N); p.alpha.resize(N); p.bias.resize(N);
+  std::uniform_real_distribution<float> uf(0.5f, 1.5f);
+  for (int n = 0; n < N; ++n) {
+    int cs = 0;
+    for (int k = 0; k < K; ++k) cs += p.w[(size_t)n * K + k];
+    p.zw[n] = per_row ? (n % 31) - 15 : -9;
+    p.ct[n] = -za * cs + K * za * p.zw[n];
+    p.alpha[n] = 1e-4f * (per_row ? uf(g) : 1.0f);
+    p.bias[n] = 0.01f * (float)((n % 13) - 6);
+  }
+  p.da = upload(p.a); p.dw = upload(p.w); p.drs = upload(p.rs); p.dzw = upload(p.zw); p.dct = upload(p.ct);
+  p.dalpha = upload(p.alpha); p.dbias = upload(p.bias);
+  p.os = 0.05f; p.oo = 131.f;
+  std::vector<float> s1{p.os}, o1{p.oo};
+  p.dos = upload(s1); p.doo = upload(o1);
+  return p;
+}
+
+static void free_problem(Problem& p) {
+  hipFree(p.da); hipFree(p.dw); hipFree(p.drs); hipFree(p.dzw); hipFree(p.dct); hipFree(p.dalpha);
+  hipFree(p.dbias); hipFree(p.dos); hipFree(p.doo);
+}
+
+// host reference for row m: returns pre-quant float values
+static void ref_row(const Problem& p, int m, std::vector<float>& out, std::vector<int>& acc_out) {
+  out.resize(p.N); acc_out.resize(p.N);
+  for (int n = 0; n < p.N; ++n) {
+    int64_t acc = 0;
+    const int8_t* ar = &p.a[(size_t)m * p.K];
+    const int8_t* wr = &p.w[(size_t)n * p.K];
+    for (int k = 0; k < p.K; ++k) acc += (int)ar[k] * (int)wr[k];
+    int t = (int)(acc - (int64_t)p.zw[n] * p.rs[m] + p.ct[n]);
+    acc_out[n] = t;
+    out[n] = (float)t * p.alpha[n] + p.bias[n];
+  }
+}
+
+static int check(const Problem& p, int variant, int out_dtype, bool outq) {
+  const size_t esz = out_dtype == MQ_F32 ? 4 : (out_dtype == MQ_F16 || out_dtype == MQ_U16 || out_dtype == MQ_I16) ? 2 : 1;
+  void* dout;
+  HIPCHK(hipMalloc(&dout, (size_t)p.M * p.N * esz));
+  HIPCHK(hipMemset(dout, 0xCD, (size_t)p.M * p.N * esz));
+  mq_gemm_set_variant(variant);
+  MQCHK(mq_w8a8_linear(p.da, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, outq ? p.dos : nullptr,
+                       outq ? p.doo : nullptr, 0.f, out_dtype == MQ_U16 ? 65535.f : 255.f, dout, out_dtype, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<uint8_t> h((size_t)p.M * p.N * esz);
+  HIPCHK(hipMemcpy(h.data(), dout, h.size(), hipMemcpyDeviceToHost));
+  hipFree(dout);
+  // rows to check: all if small, else a spread incl. first/last of tiles
+  std::vector<int> rows;
+  if (p.M <= 64) for (int m = 0; m < p.M; ++m) rows.push_back(m);
+  else for (int i = 0; i < 24; ++i) rows.push_back((int)(((int64_t)i * 2654435761u + 17) % p.M));
+  rows.push_back(0); rows.push_back(p.M - 1);
+  int bad = 0;
+  std::vector<float> ref; std::vector<int> racc;
+  const float qmax = out_dtype == MQ_U16 ? 65535.f : 255.f;
+  for (int m : rows) {
+    ref_row(p, m, ref, racc);
+    for (int n = 0; n < p.N; ++n) {
+      float got, want = ref[n];
+      size_t idx = (size_t)m * p.N + n;
+      if (outq) {
+        float q = rintf(want / p.os) + p.oo;
+        q = std::min(std::max(q, 0.f), qmax);
+        if (out_dtype == MQ_F32) { got = ((float*)h.data())[idx]; want = (q - p.oo) * p.os; }
+        else if (out_dtype == MQ_U8) { got = (float)h[idx]; want = q; }
+        else if (out_dtype == MQ_I8) { got = (float)((int8_t*)h.data())[idx] + 128.f; want = q; }
+        else if (out_dtype == MQ_U16) { got = (float)((uint16_t*)h.data())[idx]; want = q; }
+        else { got = want; }
+        float tol = (out_dtype == MQ_F32) ? p.os * 1.001f : 1.0f;   // <= 1 LSB (recip-multiply rounding)
+        if (fabsf(got - want) > tol) { if (bad < 5) fprintf(stderr, "  mismatch m=%d n=%d got=%g want=%g\n", m, n, got, want); ++bad; }
+      } else {
+        got = out_dtype == MQ_F32 ? ((float*)h.data())[idx] : 0.f;
+        if (out_dtype == MQ_F32 && got != want) { if (bad < 5) fprintf(stderr, "  mismatch m=%d n=%d got=%g want=%g\n", m, n, got, want); ++bad; }
+      }
+    }
+  }
+  return bad;
+}
+
+static float time_variant(const Problem& p, int variant, int out_dtype, bool outq, int iters) {
+  const size_t esz = out_dtype == MQ_F32 ? 4 : (out_dtype == MQ_F16 || out_dtype == MQ_U16) ? 2 : 1;
+  void* dout;
+  HIPCHK(hipMalloc(&dout, (size_t)p.M * p.N * esz));
+  mq_gemm_set_variant(variant);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  auto run = [&]() {
+    MQCHK(mq_w8a8_linear(p.da, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, outq ? p.dos : nullptr,
+                         outq ? p.doo : nullptr, 0.f, 255.f, dout, out_dtype, nullptr));
+  };
+  for (int i = 0; i < 5; ++i) run();
+  HIPCHK(hipDeviceSynchronize());
+  float best = 1e30f, tot = 0;
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) {
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) run();
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    best = std::min(best, ms);
+    tot += ms;
+  }
+  hipFree(dout);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  (void)tot;
+  return best;
+}
+
+int main(int argc, char** argv) {
+  int cu = 0, khz = 0;
+  char arch[64] = "";
+  MQCHK(mq_device_info(&cu, &khz, arch, sizeof(arch)));
+  printf("device: %s, %d CUs, %d kHz; lib version %d\n", arch, cu, khz, mq_version());
+  const int nvar = mq_gemm_set_variant(-1);
+  int iters = 50;
+  if (argc >= 2 && !strcmp(argv[1], "prof")) {
+    // mq_probe prof <variant> <dbg> <launches> [M N K] [out_dtype]: a few launches of one configuration for rocprofv3
+    const int v = argc > 2 ? atoi(argv[2]) : 1, dbg = argc > 3 ? atoi(argv[3]) : 0, n = argc > 4 ? atoi(argv[4]) : 20;
+    const int M = argc > 7 ? atoi(argv[5]) : 2048, N = argc > 7 ? atoi(argv[6]) : 5632, K = argc > 7 ? atoi(argv[7]) : 2048;
+    const int od = argc > 8 ? atoi(argv[8]) : MQ_U8;
+    Problem p = make_problem(M, N, K, 99u, false);
+    mq_gemm_set_debug(dbg);
+    float t = time_variant(p, v, od, od != MQ_F32 && od != MQ_F16, n);
+    printf("prof %s dbg=%d %dx%dx%d od=%d: %.2f us\n", mq_gemm_variant_name(v), dbg, M, N, K, od, t * 1e3);
+    return 0;
+  }
+  // ---- correctness: small odd shapes on every variant, then the headline shape ---------------------
+  int total_bad = 0;
+  {
+    struct S { int M, N, K; } shapes[] = {{64, 64, 128}, {100, 180, 256}, {300, 352, 384}, {257, 260, 128}};
+    for (auto s : shapes) {
+      Problem p = make_problem(s.M, s.N, s.K, 1234u + s.M, true);
+      for (int v = 0; v < nvar; ++v) {
+        int b0 = check(p, v, MQ_F32, false), b1 = check(p, v, MQ_U8, true), b2 = check(p, v, MQ_F32, true);
+        int b3 = check(p, v, MQ_U16, true), b4 = check(p, v, MQ_I8, true);
+        printf("check %4dx%4dx%4d %-16s f32:%d u8q:%d f32q:%d u16q:%d i8q:%d\n", s.M, s.N, s.K, mq_gemm_variant_name(v), b0, b1, b2, b3, b4);
+        total_bad += b0 + b1 + b2 + b3 + b4;
+      }
+      free_problem(p);
+    }
+  }
+  struct S { int M, N, K; };
+  std::vector<S> shapes = {{2048, 5632, 2048}};
+  if (argc >= 4) shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3])}};
+  if (argc >= 5) iters = atoi(argv[4]);
+  for (auto s : shapes) {
+    Problem p = make_problem(s.M, s.N, s.K, 99u, false);
+    const double ops = 2.0 * s.M * (double)s.N * s.K;
+    for (int v = 0; v < nvar; ++v) {
+      int bad = check(p, v, MQ_F32, false) + check(p, v, MQ_U8, true);
+      total_bad += bad;
+      float t32 = time_variant(p, v, MQ_F32, false, iters);
+      float t16 = time_variant(p, v, MQ_F16, false, iters);
+      float tq8 = time_variant(p, v, MQ_U8, true, iters);
+      float tqf = time_variant(p, v, MQ_F32, true, iters);
+      printf("time %4dx%4dx%4d %-16s bad=%d  f32 %.2f us %.0f TOPS | f16 %.2f us %.0f | u8q %.2f us %.0f | f32q %.2f us %.0f\n", s.M, s.N, s.K,
+             mq_gemm_variant_name(v), bad, t32 * 1e3, ops / t32 / 1e9, t16 * 1e3, ops / t16 / 1e9, tq8 * 1e3, ops / tq8 / 1e9, tqf * 1e3,
+             ops / tqf / 1e9);
+      fflush(stdout);
+    }
+    free_problem(p);
+  }
+  // ---- ablations on the headline shape (results invalid, timing only) ---------------------------------
+  {
+    Problem p = make_problem(2048, 5632, 2048, 99u, false);
+    const double ops = 2.0 * 2048 * 5632.0 * 2048;
+    const char* names[] = {"full", "noDMA", "noMFMA", "noDMA+noMFMA", "noEpi", "noDMA+noEpi", "noMFMA+noEpi", "none"};
+    for (int v = 0; v < nvar; ++v)
+      for (int dbg = 0; dbg < 8; ++dbg) {
+        mq_gemm_set_debug(dbg);
+        float t = time_variant(p, v, MQ_U8, true, iters);
+        printf("ablate %-16s %-14s %.2f us (%.0f TOPS-equivalent)\n", mq_gemm_variant_name(v), names[dbg], t * 1e3, ops / t / 1e9);
+      }
+    mq_gemm_set_debug(0);
+    free_problem(p);
+    // fixed overhead: one K step only
+    Problem p1 = make_problem(2048, 5632, 128, 5u, false);
+    for (int v = 0; v < nvar; ++v) {
+      float t = time_variant(p1, v, MQ_U8, true, iters);
+      float t2 = time_variant(p1, v, MQ_F32, false, iters);
+      printf("K=128 only %-16s u8q %.2f us  f32 %.2f us\n", mq_gemm_variant_name(v), t * 1e3, t2 * 1e3);
+    }
+    free_problem(p1);
+  }
+  printf("TOTAL_BAD=%d\n", total_bad);
+  return total_bad ? 1 : 0;
+}
