@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: the W8A8 real-int8 QLinear step at TinyLlama-1.1B's headline shape.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over one batch of synthetic activations already resident in HBM:
+    fp32 x [2048, 2048]  --mq_quantize-->  int8 + row sums  --mq_w8a8_linear (MFMA i8, fused dequant +
+    8-bit output quantizer)-->  output indices [2048, 5632]                     (BASELINE.json configs[1])
+metric = 2*M*K*N int8 ops per step / step time, summed over ranks (replicas: the quantized forward has no
+exchange step -- DESIGN.md "Multi-GPU"; the data-parallel calibration path with its single all-reduce is
+exercised by `--workload calibration`).
+
+The JSON line also carries
+  roofline     : the dominant kernel (the int8 GEMM) against the dense int8 MFMA peak, from HIP-event timing
+                 of that kernel alone on the stream it is launched on;
+  cpu_baseline : the numpy oracle of the reference's simulated QLinear (oracle/mq_oracle.py, "port") timed
+                 on this box's host cores on the same shape -- a reported baseline, not a target;
+  variants     : the same step with fp16 / fp32 outputs, and the drop-in nn.Module forward (fp32 in/out).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, K, N = 2048, 2048, 5632            # bsz*seq, hidden, FFN  (TinyLlama-1.1B w1/w3)
+OPS_PER_STEP = 2.0 * M * K * N
+INT8_MFMA_PEAK_TOPS = 5000.0          # dense int8 = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
+N_BATCHES = 4                         # distinct activation batches rotated through the steps
+GRAPH_STEPS = 10                      # steps captured per hipGraph (launch-bound otherwise)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default="qlinear", choices=["qlinear", "calibration"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true")
+    return p.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(v: float, world) -> float:
+    if world == 1:
+        return v
+    import torch.distributed as dist
+    t = torch.tensor([v], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class Step:
+    """The real-int8 QLinear step on preallocated buffers (no allocation inside the timed region)."""
+
+    def __init__(self, dev, out_dtype_code, seed):
+        from mobilequant_amd import ops
+        from mobilequant_amd._lib import MQ_I8
+        import mobilequant_amd as mq
+        self.ops = ops
+        g = torch.Generator(device="cpu").manual_seed(1337 + seed)      # the reference's seed (mobilequant.py:87)
+        self.x = [torch.randn(M, K, generator=g).to(dev) for _ in range(N_BATCHES)]
+        w = (torch.randn(N, K, generator=g) * 0.02).to(dev)
+        lo = min(float(x.min()) for x in self.x)
+        hi = max(float(x.max()) for x in self.x)
+        self.aq = mq.Quantizer(mq.QuantConfig(bitwidth=8))              # per-tensor asymmetric, static
+        self.aq.set_scale_offset_from_minmax(lo, hi, "buffer", dev)
+        wq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+        wq(w)                                                           # first forward: range from the weight
+        self.w8, colsum, wshift = wq.quantize_to_int(w, MQ_I8, want_row_sum=True, rows=N)
+        self.alpha, self.wzp, self.ct = ops.linear_epilogue_prepare(self.aq.scale, self.aq.offset, 128, wq.scale.detach(),
+                                                                    wq.offset.detach(), wshift, colsum, K)
+        y = torch.nn.functional.linear(self.x[0], w)
+        self.oq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+        self.oq.set_scale_offset_from_minmax(float(y.min()), float(y.max()), "buffer", dev)
+        del y
+        from mobilequant_amd.ops import _OUT_TORCH
+        self.code = out_dtype_code
+        self.a8 = torch.empty(M, K, dtype=torch.int8, device=dev)
+        self.rs = torch.empty(M, dtype=torch.int32, device=dev)
+        self.out = torch.empty(M, N, dtype=_OUT_TORCH[out_dtype_code], device=dev)
+        self.w_fp = w
+
+    def quantize(self, i):
+        from mobilequant_amd import _lib
+        from mobilequant_amd._lib import MQ_F32, MQ_I8
+        x = self.x[i % N_BATCHES]
+        _lib.call("mq_quantize", x.data_ptr(), MQ_F32, M, K, self.aq.scale.data_ptr(), self.aq.offset.data_ptr(), 1,
+                  0.0, 255.0, 128, self.a8.data_ptr(), MQ_I8, self.rs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+    def gemm(self):
+        self.ops.int8_linear(self.a8, self.w8, self.rs, self.alpha, self.wzp, self.ct, None, out_scale=self.oq.scale,
+                             out_offset=self.oq.offset, out_qmin=0.0, out_qmax=255.0, out_dtype=self.code, out=self.out)
+
+    def __call__(self, i):
+        self.quantize(i)
+        self.gemm()
+
+
+def run_steps(fn, steps, warmup, world, use_graph=True):
+    """W untimed warmup steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize.
+    Steps are replayed from hipGraphs of GRAPH_STEPS steps each (the step is ~30 us: launch-bound from
+    Python otherwise); a remainder runs eagerly inside the same timed region."""
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    graph = None
+    if use_graph and steps >= GRAPH_STEPS:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for i in range(3):
+                fn(i)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(GRAPH_STEPS):
+                fn(i)
+        graph.replay()
+        torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    done = 0
+    if graph is not None:
+        for _ in range(steps // GRAPH_STEPS):
+            graph.replay()
+        done = (steps // GRAPH_STEPS) * GRAPH_STEPS
+    for i in range(done, steps):
+        fn(i)
+    barrier(world)
+    return (time.perf_counter() - t0) / steps
+
+
+def event_time(fn, iters):
+    """Average duration of `fn` launches via HIP events on the current stream (where the kernels run)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(3):
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return best * 1e-3
+
+
+def cpu_baseline():
+    """The oracle's restatement of the reference's simulated QLinear.forward (weight re-quantised on
+    every call, as qmodule.py:346-347 does), on this box's host cores, bounded to ~10-30 s."""
+    from oracle import mq_oracle as O
+    rng = np.random.default_rng(1337)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) * np.float32(0.02)).astype(np.float32)
+    wq, iq, oq = O.QuantizerOracle(8), O.QuantizerOracle(8), O.QuantizerOracle(8)
+    iq.set_from_minmax(float(x.min()), float(x.max()))
+    y = x @ w.T
+    oq.set_from_minmax(float(y.min()), float(y.max()))
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    O.qlinear_sim(x, w, None, wq, iq, oq)              # warm-up; also caches the weight grid like the reference
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 40):
+        O.qlinear_sim(x, w, None, wq, iq, oq)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(OPS_PER_STEP / dt / 1e12, 4), "unit": "TOPS", "cores": int(blas_threads), "kind": "port",
+            "seconds_per_step": round(dt, 4),
+            "sample": f"{reps} calls of oracle.qlinear_sim (weight fake-quant + input fake-quant + fp32 GEMM + output "
+                      f"fake-quant) at M={M},K={K},N={N}; numpy elementwise on 1 thread, OpenBLAS GEMM on {blas_threads}"}
+
+
+def bench_calibration(args, rank, world, dev):
+    """Data-parallel activation-range calibration over a TinyLlama-shaped MLP block stack (synthetic)."""
+    import torch.nn as nn
+    from mobilequant_amd.calibration import ActRangeCollector
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm1 = HFRMSNorm(2048)
+            self.w1, self.w3, self.w2 = nn.Linear(2048, 5632, bias=False), nn.Linear(2048, 5632, bias=False), nn.Linear(5632, 2048, bias=False)
+            self.act_fn = nn.SiLU()
+
+        def forward(self, x):
+            h = self.norm1(x)
+            return x + self.w2(self.act_fn(self.w1(h)) * self.w3(h))
+
+    torch.manual_seed(1337)
+    model = nn.Sequential(*[MLP() for _ in range(2)]).to(dev).eval()
+    n_samples = 64
+    xs = [torch.randn(1, 2048, 2048, device=dev) for _ in range(4)]
+    col = ActRangeCollector(model).attach()
+    with torch.no_grad():
+        for i in range(2):
+            model(xs[i % 4])
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(rank, n_samples, world):
+            model(xs[i % 4])
+        col.all_reduce()
+        barrier(world)
+    dt = time.perf_counter() - t0
+    col.detach()
+    dt = max_over_ranks(dt, world)
+    if rank == 0:
+        print(json.dumps({"metric": "activation-range calibration samples/s (2 TinyLlama MLP blocks, S=2048, per-tensor)",
+                          "value": round(n_samples / dt, 2), "unit": "samples/s", "n_gpus": world, "scaling": "strong",
+                          "collectives": 1, "data": "synthetic"}))
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    rank, world, local = dist_setup(args)
+    dev = torch.device("cuda", local)
+    import mobilequant_amd._lib as L
+    from mobilequant_amd._lib import MQ_F16, MQ_F32, MQ_U8
+    info = L.device_info()
+    if args.workload == "calibration":
+        return bench_calibration(args, rank, world, dev)
+
+    with torch.no_grad():
+        step = Step(dev, MQ_U8, seed=rank)
+        sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph)
+        sec = max_over_ranks(sec, world)
+        value = world * OPS_PER_STEP / sec / 1e12
+
+        extras = {}
+        roof = cpu = None
+        if rank == 0:
+            # dominant kernel alone, HIP events on its stream
+            t_gemm = event_time(step.gemm, 50)
+            t_quant = event_time(lambda: step.quantize(0), 50)
+            achieved = OPS_PER_STEP / t_gemm / 1e12
+            roof = {"bound": "mfma", "kernel": "mq::gemm_i8_kernel (mq_w8a8_linear)", "achieved": round(achieved, 1),
+                    "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOPS", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
+                    "avg_launch_us": round(t_gemm * 1e6, 2), "traffic": None,
+                    "algorithmic_ops_per_launch": OPS_PER_STEP,
+                    "quantize_kernel": {"bound": "hbm", "avg_launch_us": round(t_quant * 1e6, 2),
+                                        "achieved_GBps": round((M * K * 5 + M * 4) / t_quant / 1e9, 1), "peak_GBps": 8000.0}}
+            for name, code in (("out_f16", MQ_F16), ("out_f32", MQ_F32)):
+                s2 = Step(dev, code, seed=rank)
+                t2 = run_steps(s2, min(args.steps, 100), 5, 1, use_graph=not args.no_graph)
+                extras[name] = {"ms_per_step": round(t2 * 1e3, 5), "value": round(OPS_PER_STEP / t2 / 1e12, 1)}
+                del s2
+            # drop-in nn.Module forward: fp32 in -> fp32 out, weight cached as int8 after the first call
+            import mobilequant_amd as mq
+            lin = torch.nn.Linear(K, N, bias=False, device=dev)
+            with torch.no_grad():
+                lin.weight.copy_(step.w_fp)
+            a8 = mq.QuantConfig(bitwidth=8)
+            ql = mq.QLinear.from_float(lin, a8, a8, a8).requires_grad_(False)
+            ql.input_quantizer.set_scale_offset_from_minmax(float(step.x[0].min()), float(step.x[0].max()), "buffer", dev)
+            ql.output_quantizer.set_scale_offset_from_minmax(-3.0, 3.0, "buffer", dev)
+            x3 = step.x[0].view(1, M, K)
+            ql(x3)
+            tm = event_time(lambda: ql(x3), 30)
+            extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
+                                            "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "W8A8 QuantLinear GEMM TOPS (% int8 MFMA peak) + TinyLlama-1.1B decode tok/s",
+            "value": round(value, 1), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i8", "data": "synthetic",
+            "config": {"workload": "TinyLlama-1.1B W8A8 real-int8 QLinear step (BASELINE.json configs[1]): fp32 x[2048,2048] "
+                                   "-> int8 quantize(+row sums) -> MFMA i8 GEMM 2048->5632 with fused dequant + 8-bit output "
+                                   "quantizer -> u8 indices; per-tensor asymmetric activation ranges, per-tensor asymmetric weights",
+                       "M": M, "K": K, "N": N, "parallelism": f"replicas x{world}", "graph_steps": 0 if args.no_graph else GRAPH_STEPS,
+                       "pct_int8_mfma_peak": round(100 * value / world / INT8_MFMA_PEAK_TOPS, 2),
+                       "decode_tok_s": None, "device": info},
+            "roofline": roof, "cpu_baseline": cpu, "variants": extras,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

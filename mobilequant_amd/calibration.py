@@ -1,0 +1,212 @@
+"""Activation-range calibration: MI355X-native counterpart of ``ptq/generate_act_range.py`` and of the
+absmax half of ``ptq/generate_act_scale_shift.py``.
+
+The reference (generate_act_range.py:49-122) runs the model sample by sample and, in a forward hook
+on every Linear / Norm / SiLU / GELU / Softmax / MatMul leaf, computes ``x.min().item()`` and
+``x.max().item()``: two reduction passes and two host syncs per tensor, ~576 tensors per sample,
+one process.  Here:
+
+  * each hooked tensor is reduced by ONE single-pass HIP kernel (``mq_minmax_tensor`` /
+    ``mq_minmax_cols``) straight into a device-resident running statistic -- no host sync in the loop;
+  * samples are sharded round-robin over the ranks of a ``torch.distributed`` group (one process per
+    GPU); min/max are exact and order independent, so any sharding gives bit-identical statistics;
+  * at the end every rank packs ``[-min..., max...]`` of all tensors into one flat fp32 buffer and
+    the group performs ONE all-reduce(MAX) (RCCL over xGMI on GPUs; payload is KBs for per-tensor
+    mode, ~10 MB for per-channel mode: latency bound, so one collective, not one per tensor);
+  * artefacts keep the reference formats: ``act_dict.json`` (indent 4, sorted keys;
+    mobilellm/utils/io.py:34-36), ``act_dict_per_channel.pth``, ``act_scales.pth`` keys
+    ``"<module>_<input|output>"``.
+"""
+from __future__ import annotations
+
+import json
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .quantization.fp_ops import FMatMul, HFRMSNorm
+
+_HOOKED_TYPE_NAMES = ("GELUActivation", "NewGELUActivation", "PytorchGELUTanh", "HFRMSNorm", "FMatMul")
+
+
+def is_calibrated_leaf(name: str, m: nn.Module) -> bool:
+    """The reference's hook set (generate_act_range.py:93-95)."""
+    if isinstance(m, (nn.Linear, nn.SiLU, nn.Softmax, nn.LayerNorm, HFRMSNorm, FMatMul)):
+        return True
+    if any(c.__name__ in _HOOKED_TYPE_NAMES for c in type(m).__mro__):
+        return True
+    return "attn_quantizer" in name or "softmax_quantizer" in name
+
+
+def _is_matmul(m: nn.Module) -> bool:
+    return isinstance(m, FMatMul) or any(c.__name__ == "FMatMul" for c in type(m).__mro__)
+
+
+class ActRangeCollector:
+    """Running min/max of the input / output (/ input2) of every calibrated leaf of ``model``.
+
+    Slots are laid out from ``model.named_modules()`` order, not from the order tensors happen to be
+    seen, so every rank has the same layout even if it processed no sample.
+    """
+
+    def __init__(self, model: nn.Module, per_channel: bool = False, device=None):
+        self.model = model
+        self.per_channel = per_channel
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        self.slots: "OrderedDict[tuple, int]" = OrderedDict()
+        for name, m in model.named_modules():
+            if is_calibrated_leaf(name, m):
+                for field in (("input", "output", "input2") if _is_matmul(m) else ("input", "output")):
+                    self.slots[(name, field)] = len(self.slots)
+        n = len(self.slots)
+        if per_channel:
+            self._pc: List[Optional[tuple]] = [None] * n      # lazily sized (min[C], max[C]) per slot
+        else:
+            self._mn = torch.full((n,), float("inf"), dtype=torch.float32, device=self.device)
+            self._mx = torch.full((n,), float("-inf"), dtype=torch.float32, device=self.device)
+        self._hooks = []
+
+    # -- hooks -------------------------------------------------------------------------------------
+    def _update(self, name: str, field: str, t: torch.Tensor) -> None:
+        i = self.slots[(name, field)]
+        t = t.detach()
+        if self.per_channel:
+            t2 = t.reshape(-1, t.shape[-1])
+            if self._pc[i] is None:
+                self._pc[i] = ops.minmax_new(t2.shape[1], t.device)
+            mn, mx = self._pc[i]
+            if mn.numel() != t2.shape[1]:
+                raise RuntimeError(f"per-channel calibration of {name}.{field}: channel count changed from "
+                                   f"{mn.numel()} to {t2.shape[1]} (the reference has the same restriction: "
+                                   "use a fixed sequence length)")
+            ops.minmax_cols_(t2, mn, mx)
+        else:
+            # layout does not matter for a per-tensor statistic: reduce the dense storage in place
+            if not t.is_contiguous():
+                p = t.permute(sorted(range(t.dim()), key=lambda d: -t.stride(d)))
+                t = p if p.is_contiguous() else t.contiguous()      # transposed views (k^T in qk_bmm): no copy
+            ops.minmax_tensor_(t, self._mn[i:i + 1], self._mx[i:i + 1])
+
+    def _hook(self, name: str, matmul: bool):
+        def fn(m, xx, yy):
+            x = xx[0] if isinstance(xx, tuple) else xx
+            y = yy[0] if isinstance(yy, tuple) else yy
+            self._update(name, "input", x)
+            self._update(name, "output", y)
+            if matmul:
+                self._update(name, "input2", xx[1])
+        return fn
+
+    def attach(self) -> "ActRangeCollector":
+        for name, m in self.model.named_modules():
+            if is_calibrated_leaf(name, m):
+                self._hooks.append(m.register_forward_hook(self._hook(name, _is_matmul(m))))
+        return self
+
+    def detach(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # -- merge -------------------------------------------------------------------------------------
+    def _packed(self) -> torch.Tensor:
+        if not self.per_channel:
+            return torch.cat((-self._mn, self._mx))
+        parts = []
+        for s in self._pc:
+            parts += [-s[0], s[1]]
+        return torch.cat(parts) if parts else torch.empty(0, device=self.device)
+
+    def _unpack(self, buf: torch.Tensor) -> None:
+        if not self.per_channel:
+            n = len(self.slots)
+            self._mn, self._mx = -buf[:n], buf[n:]
+            return
+        off = 0
+        for i, s in enumerate(self._pc):
+            c = s[0].numel()
+            self._pc[i] = (-buf[off:off + c], buf[off + c:off + 2 * c])
+            off += 2 * c
+
+    def all_reduce(self, group=None) -> None:
+        """ONE all-reduce(MAX) over the packed [-min, max] buffer of every tensor."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        if self.per_channel:
+            # ranks that saw no sample must still contribute correctly sized (+inf, -inf) entries
+            shapes = [None if s is None else s[0].numel() for s in self._pc]
+            gathered = [None] * dist.get_world_size(group)
+            dist.all_gather_object(gathered, shapes, group=group)
+            for i in range(len(shapes)):
+                c = next((g[i] for g in gathered if g[i] is not None), None)
+                if c is None:
+                    raise RuntimeError("a calibrated tensor was never observed on any rank")
+                if self._pc[i] is None:
+                    self._pc[i] = (torch.full((c,), float("inf"), device=self.device),
+                                   torch.full((c,), float("-inf"), device=self.device))
+        buf = self._packed()
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+        self._unpack(buf)
+
+    # -- results -----------------------------------------------------------------------------------
+    def act_dict(self) -> Dict[str, dict]:
+        """``{module: {field: [min, max]}}`` (per-tensor, Python floats -- the only host readback of the
+        whole run) or ``{module: {field: Tensor[2, C]}}`` on the CPU (per-channel)."""
+        out: Dict[str, dict] = {}
+        if self.per_channel:
+            for (name, field), i in self.slots.items():
+                if self._pc[i] is not None:
+                    out.setdefault(name, {})[field] = torch.stack(self._pc[i], dim=0).cpu()
+            return out
+        mn, mx = self._mn.tolist(), self._mx.tolist()
+        for (name, field), i in self.slots.items():
+            if mn[i] <= mx[i]:
+                out.setdefault(name, {})[field] = [mn[i], mx[i]]
+        return out
+
+    def act_scales(self) -> Dict[str, torch.Tensor]:
+        """SmoothQuant statistics: per-channel absmax keyed ``"<module>_<field>"`` for Linear / Norm
+        leaves (generate_act_scale_shift.py:47-71); absmax = max(|min|, |max|) of the same running stats."""
+        assert self.per_channel, "act_scales needs per-channel statistics"
+        out = {}
+        mods = dict(self.model.named_modules())
+        for (name, field), i in self.slots.items():
+            m = mods[name]
+            is_norm = isinstance(m, (nn.LayerNorm, HFRMSNorm)) or any(c.__name__ == "HFRMSNorm" for c in type(m).__mro__)
+            if field in ("input", "output") and (isinstance(m, nn.Linear) or is_norm) and self._pc[i] is not None:
+                mn, mx = self._pc[i]
+                out[f"{name}_{field}"] = torch.maximum(mn.abs(), mx.abs()).float().cpu()
+        return out
+
+
+@torch.no_grad()
+def get_act_range(model: nn.Module, samples: Sequence[torch.Tensor], per_channel: bool = False, group=None,
+                  forward=None) -> Dict[str, dict]:
+    """Data-parallel counterpart of ``get_act_range`` (generate_act_range.py:49-122).
+
+    ``samples``: the full list of calibration inputs (token-id tensors), identical on every rank; rank r
+    processes samples r, r + world, ...  Returns the merged act_dict on every rank.
+    """
+    model.eval()
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    col = ActRangeCollector(model, per_channel).attach()
+    dev = col.device
+    run = forward if forward is not None else (lambda s: model(s))
+    try:
+        for i in range(rank, len(samples), world):
+            run(samples[i].to(dev))
+    finally:
+        col.detach()
+    col.all_reduce(group)
+    return col.act_dict()
+
+
+def save_act_dict(path: str, act_dict: Dict[str, dict]) -> None:
+    """Same bytes as the reference's json_save (io.py:34-36)."""
+    with open(path, "w") as f:
+        json.dump(act_dict, f, indent=4, sort_keys=True)

@@ -1,0 +1,186 @@
+"""Tensor-level wrappers over the C ABI (include/mobilequant_amd.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every computation is a
+hand-written HIP kernel in libmobilequant_amd.so.  All functions require ROCm device tensors and raise
+otherwise -- there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MQ_F16, MQ_F32, MQ_I8, MQ_I16, MQ_I32, MQ_U8, MQ_U16
+
+_DT = {torch.float32: MQ_F32, torch.float16: MQ_F16}
+_QDT = {MQ_I8: torch.int8, MQ_U8: torch.uint8, MQ_I16: torch.int16, MQ_U16: torch.uint16, MQ_I32: torch.int32}
+
+
+def _dev(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"mobilequant_amd: {what} must be a ROCm device tensor (got "
+                           f"{getattr(t, 'device', type(t))}); there is no CPU path")
+    return t
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _fdt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"mobilequant_amd: dtype {t.dtype} not supported (float32, float16)") from None
+
+
+def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    _dev(t, what)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+# ---- a1 --------------------------------------------------------------------------------------------
+def scale_offset_from_minmax(min_val: torch.Tensor, max_val: torch.Tensor, bitwidth: int, is_symmetric: bool):
+    """Device version of compute_scale_offset_from_min_max (qmodule.py:40-61); shapes follow min_val."""
+    mn, mx = _f32(min_val, "min_val"), _f32(max_val, "max_val")
+    scale, offset = torch.empty_like(mn), torch.empty_like(mn)
+    _lib.call("mq_scale_offset_from_minmax", mn.data_ptr(), mx.data_ptr(), mn.numel(), int(bitwidth),
+              int(bool(is_symmetric)), scale.data_ptr(), offset.data_ptr(), _stream())
+    return scale, offset
+
+
+# ---- a3 / a12 --------------------------------------------------------------------------------------
+def minmax_new(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fresh running statistics (min = +inf, max = -inf)."""
+    mn = torch.empty(n, dtype=torch.float32, device=device)
+    mx = torch.empty(n, dtype=torch.float32, device=device)
+    _lib.call("mq_minmax_init", mn.data_ptr(), mx.data_ptr(), n, _stream())
+    return mn, mx
+
+
+def minmax_tensor_(x: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
+    """Running per-tensor update: mn[0] = min(mn[0], x.min()), mx[0] = max(mx[0], x.max())."""
+    x = _dev(x, "x").contiguous()
+    _lib.call("mq_minmax_tensor", x.data_ptr(), _fdt(x), x.numel(), mn.data_ptr(), mx.data_ptr(), _stream())
+
+
+def minmax_rows_(x2d: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
+    x2d = _dev(x2d, "x").contiguous()
+    rows, cols = x2d.shape
+    _lib.call("mq_minmax_rows", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
+
+
+def minmax_cols_(x2d: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
+    x2d = _dev(x2d, "x").contiguous()
+    rows, cols = x2d.shape
+    _lib.call("mq_minmax_cols", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
+
+
+def minmax_tensor(x: torch.Tensor):
+    mn, mx = minmax_new(1, x.device)
+    minmax_tensor_(x, mn, mx)
+    return mn, mx
+
+
+def minmax_rows(x2d: torch.Tensor):
+    mn, mx = minmax_new(x2d.shape[0], x2d.device)
+    minmax_rows_(x2d, mn, mx)
+    return mn, mx
+
+
+def minmax_cols(x2d: torch.Tensor):
+    mn, mx = minmax_new(x2d.shape[1], x2d.device)
+    minmax_cols_(x2d, mn, mx)
+    return mn, mx
+
+
+# ---- a5 --------------------------------------------------------------------------------------------
+def _rows_cols(x: torch.Tensor, n_scale: int) -> Tuple[int, int]:
+    if n_scale == 1:
+        return 1, x.numel()
+    if x.numel() % n_scale:
+        raise RuntimeError(f"mobilequant_amd: {n_scale} scales do not divide a tensor of {x.numel()} elements")
+    return n_scale, x.numel() // n_scale
+
+
+def fake_quant(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Quantizer.forward arithmetic (qmodule.py:286-295).  `scale`/`offset` hold 1 element (per-tensor)
+    or one per row of x viewed as [n_scale, -1] (per-channel / per-group)."""
+    x = _dev(x, "x").contiguous()
+    s, o = _f32(scale, "scale"), _f32(offset, "offset")
+    rows, cols = _rows_cols(x, s.numel())
+    y = torch.empty_like(x) if out is None else out
+    _lib.call("mq_fake_quant", x.data_ptr(), y.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(),
+              s.numel(), float(qmin), float(qmax), _stream())
+    return y
+
+
+def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, *,
+             q_dtype: int = MQ_I8, shift: int = 0, rows: Optional[int] = None, want_row_sum: bool = False):
+    """Integer indices (qmodule.py:286-287) as integers; optional per-row sums of the stored values.
+    x is viewed as [rows, -1]; rows defaults to the number of scales (per-row) or all leading dims."""
+    x = _dev(x, "x").contiguous()
+    s, o = _f32(scale, "scale"), _f32(offset, "offset")
+    if rows is None:
+        rows = s.numel() if s.numel() > 1 else (x.numel() // x.shape[-1] if x.dim() > 0 else 1)
+    cols = x.numel() // max(rows, 1)
+    q = torch.empty(x.shape, dtype=_QDT[q_dtype], device=x.device)
+    rs = torch.empty(rows, dtype=torch.int32, device=x.device) if want_row_sum else None
+    _lib.call("mq_quantize", x.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(), float(qmin),
+              float(qmax), int(shift), q.data_ptr(), q_dtype, rs.data_ptr() if rs is not None else None, _stream())
+    return (q, rs) if want_row_sum else q
+
+
+# ---- a8 --------------------------------------------------------------------------------------------
+def linear_epilogue_prepare(a_scale, a_offset, a_shift: int, w_scale, w_offset, w_shift: int, w_colsum, K: int):
+    sa, oa = _f32(a_scale, "a_scale"), _f32(a_offset, "a_offset")
+    sw, ow = _f32(w_scale, "w_scale"), _f32(w_offset, "w_offset")
+    N = w_colsum.numel()
+    dev = w_colsum.device
+    alpha = torch.empty(N, dtype=torch.float32, device=dev)
+    w_zp = torch.empty(N, dtype=torch.int32, device=dev)
+    col_term = torch.empty(N, dtype=torch.int32, device=dev)
+    _lib.call("mq_linear_epilogue_prepare", sa.data_ptr(), oa.data_ptr(), int(a_shift), sw.data_ptr(), ow.data_ptr(),
+              sw.numel(), int(w_shift), w_colsum.data_ptr(), N, int(K), alpha.data_ptr(), w_zp.data_ptr(),
+              col_term.data_ptr(), _stream())
+    return alpha, w_zp, col_term
+
+
+_OUT_TORCH = {MQ_F32: torch.float32, MQ_F16: torch.float16, MQ_U8: torch.uint8, MQ_I8: torch.int8,
+              MQ_U16: torch.uint16, MQ_I16: torch.int16}
+
+
+def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.Tensor], alpha: torch.Tensor,
+                w_zp: torch.Tensor, col_term: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+                out_scale: Optional[torch.Tensor] = None, out_offset: Optional[torch.Tensor] = None,
+                out_qmin: float = 0.0, out_qmax: float = 255.0, out_dtype: int = MQ_F32, w4: bool = False,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """QLinear as an int8 MFMA GEMM with fused dequant (+ output quantizer).  a_q [M,K] int8, w_q [N,K]
+    int8 (or [N,K/2] packed nibbles when w4)."""
+    _dev(a_q, "a_q"); _dev(w_q, "w_q")
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=_OUT_TORCH[out_dtype], device=a_q.device)
+    b = _f32(bias, "bias") if bias is not None else None
+    os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
+    oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
+    _lib.call("mq_w4a8_linear" if w4 else "mq_w8a8_linear", a_q.data_ptr(), w_q.data_ptr(), M, N, K,
+              a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(),
+              col_term.data_ptr(), b.data_ptr() if b is not None else None,
+              os_.data_ptr() if os_ is not None else None, oo_.data_ptr() if oo_ is not None else None,
+              float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype, _stream())
+    return out
+
+
+def pack_w4(nibbles: torch.Tensor) -> torch.Tensor:
+    """[N,K] uint8 nibbles (0..15) -> [N,K/2] packed (layout: include/mobilequant_amd.h, mq_pack_w4)."""
+    nibbles = _dev(nibbles, "nibbles").contiguous()
+    N, K = nibbles.shape
+    packed = torch.empty((N, K // 2), dtype=torch.uint8, device=nibbles.device)
+    _lib.call("mq_pack_w4", nibbles.data_ptr(), N, K, packed.data_ptr(), _stream())
+    return packed

@@ -1,0 +1,702 @@
+"""MI355X-native mirror of MobileQuant's ``mobilellm.quantization.qmodule`` API.
+
+Same public names, constructor signatures, attribute names, ``state_dict`` keys and JSON formats as
+the reference, so ``ptq/mobilequant.py`` / ``eval/harness_eval.py`` style
+callers work against this module unchanged -- but every tensor-sized computation is a hand-written
+HIP kernel reached through the C ABI (``mobilequant_amd.ops``):
+
+  * ``Quantizer.forward``  -> fused fake-quant kernel (reference: ~8 torch elementwise ops,
+    qmodule.py:286-295); first-forward / dynamic ranges -> single-pass min/max kernels + a
+    scale/offset kernel, no host sync (reference: qmodule.py:262-277).
+  * ``QLinear.forward``    -> real int8 path when the configuration allows it: quantize-to-int8 (+row
+    sums) -> ``v_mfma_i32_16x16x64_i8`` GEMM -> zero-point-corrected dequant + fused output quantizer
+    (reference: fp32 simulation, qmodule.py:341-358).  Otherwise the simulated path with HIP fake-quant
+    kernels around the library fp GEMM.
+
+Tensors must live on a ROCm device; CPU tensors raise (no fallback).  Host-side scalar set-up
+(ranges read from ``act_dict.json`` -> scale/offset) is plain fp32 arithmetic with the reference's
+operation order.
+"""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import MQ_F16, MQ_F32, MQ_I8, MQ_U8
+from .fp_ops import FMatMul, HFRMSNorm
+
+CLIPMIN = 1e-5
+CLIPMAX = 1e6
+
+
+# ------------------------------------------------------------------------------------------------
+# scalar / small-tensor range math (reference: qmodule.py:17-76)
+# ------------------------------------------------------------------------------------------------
+def round_ste(x: torch.Tensor) -> torch.Tensor:
+    """Round half to even with an identity gradient (reference: qmodule.py:17-21)."""
+    return x + (torch.round(x) - x).detach()
+
+
+def _grid_limits(bitwidth: int, is_symmetric: bool):
+    if is_symmetric:
+        half = 2 ** (bitwidth - 1)
+        return -half, half - 1
+    return 0, 2 ** bitwidth - 1
+
+
+def _as_f32(v, device=None) -> torch.Tensor:
+    if torch.is_tensor(v):
+        return v
+    return torch.tensor(v, dtype=torch.float32, device=device)
+
+
+def compute_min_max_from_tensor(x: torch.Tensor, is_per_channel: bool = False, group_size: int = -1):
+    """amin/amax per tensor, per last-dim row (keepdim) or per group (reference: qmodule.py:26-34).
+    Runs the single-pass HIP min/max kernels; results stay on the device."""
+    if is_per_channel:
+        if group_size != -1:
+            x = x.reshape(-1, group_size)
+        lead = x.shape[:-1]
+        mn, mx = ops.minmax_rows(x.reshape(-1, x.shape[-1]))
+        return mn.reshape(*lead, 1), mx.reshape(*lead, 1)
+    mn, mx = ops.minmax_tensor(x)
+    return mn.reshape(()), mx.reshape(())
+
+
+def compute_scale_offset_from_min_max(min_val, max_val, bitwidth: int, is_symmetric: bool):
+    """(scale, offset, alpha, beta, q_min, q_max) exactly as the reference returns them
+    (qmodule.py:40-61).  Device tensors use the HIP kernel; host scalars / CPU tensors are tiny
+    configuration values and use the same fp32 expression on the host."""
+    q_min, q_max = _grid_limits(bitwidth, is_symmetric)
+    mn, mx = _as_f32(min_val), _as_f32(max_val)
+    if mn.is_cuda:
+        scale, offset = ops.scale_offset_from_minmax(mn, mx.to(mn.device), bitwidth, is_symmetric)
+        alpha = torch.maximum(mn.abs(), mx.abs()) if is_symmetric else mx - mn
+        beta = 0 if is_symmetric else mn
+        return scale, offset, alpha, beta, q_min, q_max
+    if is_symmetric:
+        alpha, beta = torch.maximum(mn.abs(), mx.abs()), 0
+    else:
+        alpha, beta = mx - mn, mn
+    scale = (alpha / q_max).clamp(min=CLIPMIN, max=CLIPMAX)
+    offset = -(beta / scale).round()
+    return scale, offset, alpha, beta, q_min, q_max
+
+
+def compute_min_max_from_scale_offset(scale, offset, bitwidth: int, is_symmetric: bool):
+    """Inverse of the above (reference: qmodule.py:66-76); used by export_act_range."""
+    _, q_max = _grid_limits(bitwidth, is_symmetric)
+    s = scale.clamp(min=CLIPMIN, max=CLIPMAX)
+    hi = s * q_max + (-offset) * s
+    lo = -hi if is_symmetric else (-offset) * s
+    return lo, hi
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class QuantConfig:
+    """Five-field quantizer description, serialised with string values (reference: qmodule.py:82-107)."""
+    bitwidth: int = 32
+    group_size: int = -1
+    is_symmetric: bool = False
+    is_per_channel: bool = False
+    is_dynamic: bool = False
+
+    @classmethod
+    def from_dict(cls, cfg: dict) -> "QuantConfig":
+        flag = lambda k: cfg[k] in ("True", "true")   # noqa: E731
+        return cls(bitwidth=int(cfg["bitwidth"]), group_size=int(cfg["group_size"]), is_symmetric=flag("is_symmetric"),
+                   is_per_channel=flag("is_per_channel"), is_dynamic=flag("is_dynamic"))
+
+    def to_dict(self) -> dict:
+        return {k: str(getattr(self, k)) for k in ("bitwidth", "group_size", "is_symmetric", "is_per_channel", "is_dynamic")}
+
+
+# ------------------------------------------------------------------------------------------------
+class _FakeQuantFn(torch.autograd.Function):
+    """HIP fake-quant with a straight-through backward.
+
+    Forward is the fused kernel.  Backward (needed by the reference's PTQ training loops,
+    algorithm.py:381/:587) passes the gradient where the index was not clamped and accumulates the
+    LSQ-style gradients of scale and offset; it is evaluated by a HIP kernel as well
+    (``mq_fake_quant_backward``) once that row of SURVEY 8f lands -- until then it raises.
+    """
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, qmin, qmax):
+        ctx.save_for_backward(x, scale, offset)
+        ctx.limits = (qmin, qmax)
+        return ops.fake_quant(x, scale.detach(), offset.detach(), qmin, qmax)
+
+    @staticmethod
+    def backward(ctx, grad_out):  # pragma: no cover - exercised on GPU only
+        raise NotImplementedError(
+            "mobilequant_amd: backward through the HIP fake-quant kernel is not built yet (SURVEY 8f rank 3); "
+            "run the quantized forward under torch.no_grad()")
+
+
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class Quantizer(nn.Module):
+    """Fake-quantizer with cached or on-the-fly (scale, offset) (reference: qmodule.py:112-295)."""
+
+    def __init__(self, qcfg):
+        super().__init__()
+        self.qcfg = deepcopy(qcfg)
+        self.lwc = False
+        self.enable = True
+
+    # -- configuration ---------------------------------------------------------------------------
+    def update_qcfg(self, qcfg):
+        if not isinstance(qcfg, QuantConfig):
+            assert isinstance(qcfg, dict)
+            qcfg = QuantConfig.from_dict(qcfg)
+        self.qcfg = deepcopy(qcfg)
+        for name in ("scale", "offset"):          # a new config invalidates the cached grid
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def export_qcfg(self):
+        return self.qcfg.to_dict()
+
+    def _has_grid(self) -> bool:
+        return hasattr(self, "scale") and hasattr(self, "offset")
+
+    # -- learnable weight clipping (training-time; reference: qmodule.py:133-185) ------------------
+    def enable_lwc(self, w):
+        self.lwc = True
+        if self.qcfg.group_size != -1:
+            rows = int(w.shape[0] * math.ceil(w.shape[1] / self.qcfg.group_size))
+        else:
+            rows = w.shape[0]
+        shape = (rows, 1) if self.qcfg.is_per_channel else (1,)
+        init = torch.full(shape, 4.0, dtype=w.dtype, device=w.device)
+        self.upbound_factor = nn.Parameter(init.clone())
+        self.lowbound_factor = nn.Parameter(init.clone())
+
+    def disable_lwc(self):
+        self.lwc = False
+        for name in ("upbound_factor", "lowbound_factor"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def _tensor_range(self, x2):
+        """min/max of the (already group-reshaped) tensor, with the LWC factors applied if enabled."""
+        if self.qcfg.is_per_channel:
+            lead = x2.shape[:-1]
+            mn, mx = ops.minmax_rows(x2.reshape(-1, x2.shape[-1]))
+            mn, mx = mn.reshape(*lead, 1), mx.reshape(*lead, 1)
+        else:
+            mn, mx = ops.minmax_tensor(x2)
+            mn, mx = mn.reshape(()), mx.reshape(())
+        if self.lwc:
+            mx = torch.sigmoid(self.upbound_factor) * mx
+            mn = torch.sigmoid(self.lowbound_factor) * mn
+        return mn, mx
+
+    def run_lwc(self, input_):
+        """Clamp a weight to its (learned) clipping range and drop the LWC state (qmodule.py:159-185)."""
+        grouped = self.qcfg.is_per_channel and self.qcfg.group_size != -1
+        x = input_.reshape(-1, self.qcfg.group_size) if grouped else input_
+        mn, mx = self._tensor_range(x)
+        if self.lwc:
+            for name in ("scale", "offset"):
+                if hasattr(self, name):
+                    delattr(self, name)
+            self.disable_lwc()
+        x = torch.maximum(torch.minimum(x, mx.to(x.dtype)), mn.to(x.dtype))
+        return x.reshape(input_.shape).type(input_.dtype)
+
+    # -- grid -----------------------------------------------------------------------------------
+    def set_scale_offset_from_minmax(self, min_val, max_val, cache_mode=None, device=None):
+        scale, offset, _, _, q_min, q_max = compute_scale_offset_from_min_max(
+            min_val, max_val, self.qcfg.bitwidth, self.qcfg.is_symmetric)
+        self.qmin, self.qmax = q_min, q_max
+        scale, offset = scale.to(device), offset.to(device)
+        for name in ("scale", "offset"):
+            if hasattr(self, name):
+                delattr(self, name)
+        if cache_mode == "parameter":
+            self.register_parameter("scale", nn.Parameter(scale))
+            self.register_parameter("offset", nn.Parameter(offset))
+        elif cache_mode == "buffer":
+            self.register_buffer("scale", scale)
+            self.register_buffer("offset", offset)
+        else:
+            self.scale, self.offset = scale, offset
+
+    def set_scale_offset_from_tensor(self, x, cache_mode=None):
+        mn, mx = compute_min_max_from_tensor(x, self.qcfg.is_per_channel, self.qcfg.group_size)
+        self.set_scale_offset_from_minmax(mn, mx, cache_mode, x.device)
+
+    def _prepare(self, x2, use_scale_offset_as):
+        """Make sure (scale, offset) exist for this call and sit on x's device (qmodule.py:262-283)."""
+        if self.qcfg.is_dynamic or self.lwc or not self._has_grid():
+            mn, mx = self._tensor_range(x2)
+            transient = self.qcfg.is_dynamic or self.lwc
+            self.set_scale_offset_from_minmax(mn, mx, None if transient else use_scale_offset_as, x2.device)
+        if self.scale.device != x2.device:
+            self.scale.data = self.scale.to(x2.device)
+        if self.offset.device != x2.device:
+            self.offset.data = self.offset.to(x2.device)
+
+    def bypassed(self) -> bool:
+        return (not self.enable) or self.qcfg.bitwidth > 16
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, input_, use_scale_offset_as="parameter"):
+        if self.bypassed():
+            return input_
+        grouped = self.qcfg.is_per_channel and self.qcfg.group_size != -1
+        x = input_.reshape(-1, self.qcfg.group_size) if grouped else input_
+        self._prepare(x, use_scale_offset_as)
+        if _needs_grad(x, self.scale, self.offset):
+            y = _FakeQuantFn.apply(x, self.scale, self.offset, self.qmin, self.qmax)
+        else:
+            y = ops.fake_quant(x, self.scale.detach(), self.offset.detach(), self.qmin, self.qmax)
+        return y.reshape(input_.shape) if grouped else y
+
+    def quantize_to_int(self, x, q_dtype=MQ_I8, want_row_sum=False, rows=None):
+        """Integer indices of x on this quantizer's grid (static per-tensor or per-row grids).
+        Returns (q, row_sum or None, shift): int8 storage subtracts shift = 128 from unsigned grids."""
+        shift = 128 if (q_dtype == MQ_I8 and self.qmax > 127) else 0
+        out = ops.quantize(x, self.scale.detach(), self.offset.detach(), self.qmin, self.qmax, q_dtype=q_dtype,
+                           shift=shift, rows=rows, want_row_sum=want_row_sum)
+        q, rs = out if want_row_sum else (out, None)
+        return q, rs, shift
+
+
+# ------------------------------------------------------------------------------------------------
+class _QuantizedOp:
+    """Shared config/range plumbing of the Q* modules.  ``_slots`` lists (role, attribute) pairs in
+    the order the reference's update_qcfg signatures take them."""
+
+    _slots = ()
+    _optional_update = ()      # roles whose config may be None in update_qcfg (QSiLU / QGELU input)
+
+    def _init_quantizers(self, **cfgs):
+        for role, attr in self._slots:
+            cfg = cfgs.get(role)
+            setattr(self, attr, Quantizer(cfg) if cfg is not None else None)
+
+    def update_qcfg(self, *cfgs):
+        for (role, attr), cfg in zip(self._slots, cfgs):
+            q = getattr(self, attr)
+            if q is None or (cfg is None and role in self._optional_update):
+                continue
+            q.update_qcfg(cfg)
+
+    def export_qcfg(self):
+        return {role: getattr(self, attr).export_qcfg() for role, attr in self._slots if getattr(self, attr) is not None}
+
+    def _range_device(self):
+        w = getattr(self, "weight", None)
+        return w.device if torch.is_tensor(w) else None
+
+    def set_scale_offset(self, act_scale, use_scale_offset_as="parameter"):
+        # weights get no preset range: their statistics are computed on the first forward
+        self._act_range = {k: act_scale[k] for k in ("input", "input2", "output") if k in act_scale}
+        for role, attr in self._slots:
+            q = getattr(self, attr)
+            if q is None or role == "weight":
+                continue
+            if role == "input2" and "input2" not in act_scale and isinstance(self, QSiLU):
+                lo, hi = 0.0, 1.0                      # sigmoid range (reference: qmodule.py:731-734)
+            else:
+                lo, hi = act_scale[role][0], act_scale[role][1]
+            q.set_scale_offset_from_minmax(lo, hi, use_scale_offset_as, self._range_device())
+
+
+def _apply(q: Optional[Quantizer], x):
+    return x if q is None else q(x)
+
+
+def _static_per_tensor(q: Optional[Quantizer], max_bits: int) -> bool:
+    return (q is not None and not q.bypassed() and q.qcfg.bitwidth <= max_bits and not q.qcfg.is_dynamic
+            and not q.lwc and not q.qcfg.is_per_channel and q._has_grid() and q.scale.numel() == 1)
+
+
+class QLinear(nn.Linear, _QuantizedOp):
+    """``nn.Linear`` with weight / input / output quantizers (reference: qmodule.py:298-405)."""
+
+    _slots = (("input", "input_quantizer"), ("weight", "weight_quantizer"), ("output", "output_quantizer"))
+
+    def __init__(self, kargs, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
+        super().__init__(**kargs)
+        self.use_temporary_parameter = False
+        self._init_quantizers(input=input_quant_cfg, weight=weight_quant_cfg, output=output_quant_cfg)
+        self.int8_mode = "auto"        # "auto" | "off": real-int8 MFMA path when the config allows it
+        self._input_grid = None        # producer's output grid for linears without an input quantizer
+        self._plan = None
+
+    # -- integer path ------------------------------------------------------------------------------
+    def set_input_grid(self, min_val, max_val, bitwidth=8, is_symmetric=False):
+        """Declare the grid the incoming activation already sits on (the producer's output quantizer).
+        q/k/v/o/w1/w3 have no input quantizer in the reference (qmodule.py:848-850): their inputs are
+        fake-quantised by the previous module, so re-quantising on that same grid is the identity."""
+        q = Quantizer(QuantConfig(bitwidth=bitwidth, is_symmetric=is_symmetric))
+        q.set_scale_offset_from_minmax(min_val, max_val, None, self.weight.device)
+        self._input_grid = q
+
+    def _activation_grid(self) -> Optional[Quantizer]:
+        iq = self.input_quantizer
+        if iq is not None and not iq.bypassed():
+            return iq if _static_per_tensor(iq, 8) else None
+        return self._input_grid
+
+    def _int8_ready(self, x, weight) -> bool:
+        if self.int8_mode == "off" or not x.is_cuda or x.dtype not in (torch.float32, torch.float16):
+            return False
+        wq = self.weight_quantizer
+        if wq is None or wq.bypassed() or wq.qcfg.bitwidth > 8 or wq.qcfg.is_dynamic or wq.lwc:
+            return False
+        if wq.qcfg.is_per_channel and wq.qcfg.group_size != -1:
+            return False
+        if weight.shape[1] % 128 or weight.shape[0] % 4 or self._activation_grid() is None:
+            return False
+        oq = self.output_quantizer
+        if oq is not None and not oq.bypassed() and not _static_per_tensor(oq, 16):
+            return False
+        params = [x, weight, self.bias, getattr(wq, "scale", None)]
+        return not _needs_grad(*params)
+
+    def _weight_plan(self, weight):
+        """Integer weights + column sums, cached until the weight or its quantizer changes (SURVEY 8a' item 5)."""
+        wq = self.weight_quantizer
+        if not wq._has_grid():
+            wq._prepare(weight, "parameter")           # first forward: range from the weight itself
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), wq.scale.data_ptr(), wq.scale._version,
+               wq.offset._version, wq.qcfg.bitwidth, wq.qcfg.is_symmetric, wq.qcfg.is_per_channel)
+        plan = self._plan
+        if plan is not None and plan["key"] == key:
+            return plan
+        w4 = wq.qcfg.bitwidth == 4
+        w32 = weight.detach().to(torch.float32)
+        if w4:   # unsigned nibbles (index - qmin), packed two per byte
+            q, colsum = ops.quantize(w32, wq.scale.detach(), wq.offset.detach(), wq.qmin, wq.qmax, q_dtype=MQ_U8,
+                                     shift=wq.qmin, rows=weight.shape[0], want_row_sum=True)
+            wint, shift = ops.pack_w4(q), wq.qmin
+        else:
+            wint, colsum, shift = wq.quantize_to_int(w32, MQ_I8, want_row_sum=True, rows=weight.shape[0])
+        plan = {"key": key, "w": wint, "colsum": colsum, "shift": shift, "w4": w4, "epi_key": None}
+        self._plan = plan
+        return plan
+
+    def _forward_int8(self, x, weight, bias):
+        wq, oq, grid = self.weight_quantizer, self.output_quantizer, self._activation_grid()
+        plan = self._weight_plan(weight)
+        K, N = weight.shape[1], weight.shape[0]
+        if grid.scale.device != x.device:
+            grid.scale.data, grid.offset.data = grid.scale.to(x.device), grid.offset.to(x.device)
+        a_q, a_rs, a_shift = grid.quantize_to_int(x.reshape(-1, K), MQ_I8, want_row_sum=True)
+        epi_key = (grid.scale.data_ptr(), grid.scale._version, grid.offset._version, a_shift)
+        if plan["epi_key"] != epi_key:
+            plan["alpha"], plan["w_zp"], plan["col_term"] = ops.linear_epilogue_prepare(
+                grid.scale.detach(), grid.offset.detach(), a_shift, wq.scale.detach(), wq.offset.detach(),
+                plan["shift"], plan["colsum"], K)
+            plan["epi_key"] = epi_key
+        fused = oq is not None and not oq.bypassed()
+        if fused and oq.scale.device != x.device:
+            oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
+        out = ops.int8_linear(
+            a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
+            out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
+            out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0,
+            out_dtype=MQ_F16 if x.dtype == torch.float16 else MQ_F32, w4=plan["w4"])
+        return out.reshape(*x.shape[:-1], N)
+
+    # -- forward -----------------------------------------------------------------------------------
+    def forward(self, input_):
+        weight = self.temp_weight if self.use_temporary_parameter else self.weight
+        bias = self.temp_bias if self.use_temporary_parameter else self.bias
+        if self._int8_ready(input_, weight):
+            return self._forward_int8(input_, weight, bias)
+        # simulated path: HIP fake-quant kernels around the library GEMM
+        weight = _apply(self.weight_quantizer, weight)
+        input_ = _apply(self.input_quantizer, input_)
+        out = F.linear(input_, weight, bias=bias)
+        return _apply(self.output_quantizer, out)
+
+    @staticmethod
+    def from_float(module, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
+        kargs = dict(in_features=module.in_features, out_features=module.out_features, bias=module.bias is not None,
+                     device=module.weight.device, dtype=module.weight.dtype)
+        out = QLinear(kargs, input_quant_cfg, weight_quant_cfg, output_quant_cfg)
+        with torch.no_grad():
+            out.weight.copy_(module.weight)
+            if out.bias is not None:
+                out.bias.copy_(module.bias)
+        return out
+
+    @staticmethod
+    def to_float(module):
+        out = nn.Linear(module.in_features, module.out_features, bias=module.bias is not None,
+                        device=module.weight.device, dtype=module.weight.dtype)
+        with torch.no_grad():
+            out.weight.copy_(module.weight)
+            if module.bias is not None:
+                out.bias.copy_(module.bias)
+        return out
+
+
+class QMatMul(nn.Module, _QuantizedOp):
+    """Quantized ``torch.matmul`` of two activations (reference: qmodule.py:408-466)."""
+
+    _slots = (("input", "input_quantizer"), ("input2", "input2_quantizer"), ("output", "output_quantizer"))
+
+    def __init__(self, input_quant_cfg, input2_quant_cfg, output_quant_cfg):
+        super().__init__()
+        self._init_quantizers(input=input_quant_cfg, input2=input2_quant_cfg, output=output_quant_cfg)
+
+    def forward(self, x1, x2):
+        out = torch.matmul(_apply(self.input_quantizer, x1), _apply(self.input2_quantizer, x2))
+        return _apply(self.output_quantizer, out)
+
+
+class QRMSNorm(HFRMSNorm, _QuantizedOp):
+    """RMSNorm with quantized weight / input / output (reference: qmodule.py:469-576)."""
+
+    _slots = (("input", "input_quantizer"), ("weight", "weight_quantizer"), ("output", "output_quantizer"))
+
+    def __init__(self, kargs, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
+        super().__init__(**kargs)
+        self.use_temporary_parameter = False
+        self._init_quantizers(input=input_quant_cfg, weight=weight_quant_cfg, output=output_quant_cfg)
+
+    def forward(self, input_):
+        weight = self.temp_weight if self.use_temporary_parameter else self.weight
+        weight = _apply(self.weight_quantizer, weight)
+        out = self.forward_impl(_apply(self.input_quantizer, input_), weight, self.bias)
+        return _apply(self.output_quantizer, out)
+
+    @staticmethod
+    def _kargs(module):
+        return dict(dim=len(module.weight), eps=module.eps, device=module.weight.device, dtype=module.weight.dtype,
+                    l2norm_as_rmsnorm=module.l2norm_as_rmsnorm)
+
+    @staticmethod
+    def from_float(module, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
+        out = QRMSNorm(QRMSNorm._kargs(module), input_quant_cfg, weight_quant_cfg, output_quant_cfg)
+        with torch.no_grad():
+            out.weight.copy_(module.weight)
+        return out
+
+    @staticmethod
+    def to_float(module):
+        out = HFRMSNorm(**QRMSNorm._kargs(module))
+        with torch.no_grad():
+            out.weight.copy_(module.weight)
+        return out
+
+
+class QLayerNorm(nn.LayerNorm, _QuantizedOp):
+    """LayerNorm with quantized weight / input / output (reference: qmodule.py:579-688)."""
+
+    _slots = (("input", "input_quantizer"), ("weight", "weight_quantizer"), ("output", "output_quantizer"))
+
+    def __init__(self, kargs, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
+        super().__init__(**kargs)
+        self.use_temporary_parameter = False
+        self._init_quantizers(input=input_quant_cfg, weight=weight_quant_cfg, output=output_quant_cfg)
+
+    def forward(self, input_):
+        weight = self.temp_weight if self.use_temporary_parameter else self.weight
+        bias = self.temp_bias if self.use_temporary_parameter else self.bias
+        weight = _apply(self.weight_quantizer, weight)
+        input_ = _apply(self.input_quantizer, input_)
+        out = F.layer_norm(input_, input_.shape[-1:], weight=weight, bias=bias, eps=self.eps)
+        return _apply(self.output_quantizer, out)
+
+    @staticmethod
+    def from_float(module, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
+        kargs = dict(normalized_shape=len(module.weight), eps=module.eps, elementwise_affine=module.elementwise_affine,
+                     device=module.weight.device, dtype=module.weight.dtype)
+        out = QLayerNorm(kargs, input_quant_cfg, weight_quant_cfg, output_quant_cfg)
+        with torch.no_grad():
+            out.weight.copy_(module.weight)
+            if out.bias is not None:
+                out.bias.copy_(module.bias)
+        return out
+
+    @staticmethod
+    def to_float(module):
+        out = nn.LayerNorm(len(module.weight), eps=module.eps, elementwise_affine=module.elementwise_affine,
+                           bias=module.bias is not None, device=module.weight.device, dtype=module.weight.dtype)
+        with torch.no_grad():
+            out.weight.copy_(module.weight)
+            if module.bias is not None:
+                out.bias.copy_(module.bias)
+        return out
+
+
+class QSiLU(nn.Module, _QuantizedOp):
+    """x * quant(sigmoid(x)) with quantized output (reference: qmodule.py:691-753)."""
+
+    _slots = (("input", "input_quantizer"), ("input2", "input2_quantizer"), ("output", "output_quantizer"))
+    _optional_update = ("input",)
+
+    def __init__(self, input_quant_cfg, input2_quant_cfg, output_quant_cfg):
+        super().__init__()
+        self._init_quantizers(input=input_quant_cfg, input2=input2_quant_cfg, output=output_quant_cfg)
+
+    def forward(self, x):
+        x = _apply(self.input_quantizer, x)
+        gate = _apply(self.input2_quantizer, torch.sigmoid(x))
+        return _apply(self.output_quantizer, x * gate)
+
+
+class QGELU(nn.Module, _QuantizedOp):
+    """GELU with quantized input / output (reference: qmodule.py:756-798)."""
+
+    _slots = (("input", "input_quantizer"), ("output", "output_quantizer"))
+    _optional_update = ("input",)
+
+    def __init__(self, input_quant_cfg, output_quant_cfg):
+        super().__init__()
+        self._init_quantizers(input=input_quant_cfg, output=output_quant_cfg)
+
+    def forward(self, x):
+        return _apply(self.output_quantizer, F.gelu(_apply(self.input_quantizer, x)))
+
+
+QuantLinear = QLinear   # the north star's name for the same class
+
+
+# ------------------------------------------------------------------------------------------------
+# model surgery and artefact IO (reference: qmodule.py:835-970)
+# ------------------------------------------------------------------------------------------------
+_Q_TYPES = (QLinear, QRMSNorm, QLayerNorm, QMatMul, QSiLU, QGELU)
+_NO_INPUT_QUANT = ("q_proj", "k_proj", "v_proj", "o_proj", "w1", "w3")
+
+
+def _type_named(module, *names) -> bool:
+    """isinstance by class name too, so the reference's own model classes are recognised when they are
+    importable (mobilellm.model.ops.FMatMul, hf_model.HFRMSNorm, transformers' GELU variants)."""
+    return any(c.__name__ in names for c in type(module).__mro__)
+
+
+def create_sim_qmodel(model, default_weight_qcfg=None, default_act_qcfg=None):
+    """Swap float leaves for Q-modules by the reference's name rules (qmodule.py:835-865)."""
+    wcfg = default_weight_qcfg if default_weight_qcfg is not None else QuantConfig()
+    acfg = default_act_qcfg if default_act_qcfg is not None else QuantConfig()
+    for name, module in reversed(list(model._modules.items())):
+        if "lm_head" in name or ("norm" in name and "layernorm" not in name):
+            continue                                   # final norm and predictor stay in floating point
+        if isinstance(module, nn.Linear):
+            q = QLinear.from_float(module, acfg, wcfg, acfg)
+            if any(tag in name for tag in _NO_INPUT_QUANT):
+                q.input_quantizer = None               # already quantized by the producing module
+            model._modules[name] = q
+        elif isinstance(module, FMatMul) or _type_named(module, "FMatMul"):
+            model._modules[name] = QMatMul(acfg, acfg, acfg)
+        elif isinstance(module, nn.SiLU):
+            q = QSiLU(acfg, acfg, acfg)
+            q.input_quantizer = None
+            model._modules[name] = q
+        elif isinstance(module, nn.GELU) or _type_named(module, "GELUActivation", "PytorchGELUTanh"):
+            q = QGELU(acfg, acfg)
+            q.input_quantizer = None
+            model._modules[name] = q
+        elif isinstance(module, HFRMSNorm) or _type_named(module, "HFRMSNorm"):
+            model._modules[name] = QRMSNorm.from_float(module, acfg, wcfg, acfg)
+        elif isinstance(module, nn.LayerNorm):
+            model._modules[name] = QLayerNorm.from_float(module, acfg, wcfg, acfg)
+        elif len(list(module.children())) > 0:
+            create_sim_qmodel(module, wcfg, acfg)
+    return model
+
+
+def create_fp_model(model):
+    """Inverse surgery (reference: qmodule.py:889-905)."""
+    for name, module in reversed(list(model._modules.items())):
+        if isinstance(module, (QLinear, QRMSNorm, QLayerNorm)):
+            model._modules[name] = type(module).to_float(module)
+        elif isinstance(module, QMatMul):
+            model._modules[name] = FMatMul()
+        elif isinstance(module, QSiLU):
+            model._modules[name] = nn.SiLU()
+        elif isinstance(module, QGELU):
+            model._modules[name] = nn.GELU()
+        elif len(list(module.children())) > 1:
+            create_fp_model(module)
+    return model
+
+
+def create_weight_only_qmodel(model, w_qcfg=None):
+    """W4A16 packing is the third-party auto_gptq path of the reference (qmodule.py:803-886), which is
+    outside the W8A8 / W4A8 hot path this package implements."""
+    raise NotImplementedError("weight-only (W4A16) packing relies on auto_gptq in the reference and is out of scope "
+                              "here; use the W4A8 path (QLinear with a 4-bit weight quantizer)")
+
+
+def _minmax_entry(q: Quantizer):
+    lo, hi = compute_min_max_from_scale_offset(q.scale, q.offset, q.qcfg.bitwidth, q.qcfg.is_symmetric)
+    return [lo.item(), hi.item()]
+
+
+def export_act_range(model):
+    """Ranges implied by the current activation grids (reference: qmodule.py:908-937)."""
+    act_dict = {}
+    for name, m in model.named_modules():
+        if not isinstance(m, _Q_TYPES):
+            continue
+        roles = ("input", "input2", "output") if isinstance(m, (QMatMul, QSiLU)) else ("input", "output")
+        entry = act_dict.get(name, {})
+        for role in roles:
+            q = getattr(m, role + "_quantizer", None)
+            if q is not None:
+                entry[role] = _minmax_entry(q)
+        act_dict[name] = entry
+    return act_dict
+
+
+def update_qcfg(model, override_qcfg):
+    for name, module in model.named_modules():
+        if not isinstance(module, _Q_TYPES):
+            continue
+        assert name in override_qcfg
+        cfg = override_qcfg[name]
+        if isinstance(module, (QLinear, QRMSNorm, QLayerNorm)):
+            module.update_qcfg(cfg.get("input", None), cfg["weight"], cfg["output"])
+        elif isinstance(module, QMatMul):
+            module.update_qcfg(cfg["input"], cfg["input2"], cfg["output"])
+        elif isinstance(module, QSiLU):
+            module.update_qcfg(cfg.get("input", None), cfg["input2"], cfg["output"])
+        else:
+            module.update_qcfg(cfg.get("input", None), cfg["output"])
+    return model
+
+
+def export_qcfg(model):
+    return {name: m.export_qcfg() for name, m in model.named_modules() if isinstance(m, _Q_TYPES)}
+
+
+def set_scale_and_offset(model, act_dict, use_scale_offset_as="buffer"):
+    for name, module in model.named_modules():
+        if isinstance(module, _Q_TYPES):
+            assert name in act_dict
+            module.set_scale_offset(act_dict[name], use_scale_offset_as)
+    return model
+
+
+def wire_integer_inputs(model, act_bitwidth=8, act_is_symmetric=False):
+    """Graph pass the integer path needs and the reference never did (hard parts):
+    every QLinear without an input quantizer is told the grid its producer quantized to, which is the
+    calibrated range of its own input (``act_dict[name]['input']``, kept by set_scale_offset) on the
+    activation bitwidth.  Returns the number of linears wired."""
+    n = 0
+    for _, m in model.named_modules():
+        if isinstance(m, QLinear) and m.input_quantizer is None and "input" in getattr(m, "_act_range", {}):
+            lo, hi = m._act_range["input"]
+            m.set_input_grid(lo, hi, act_bitwidth, act_is_symmetric)
+            n += 1
+    return n

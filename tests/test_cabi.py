@@ -1,0 +1,64 @@
+"""The C-ABI library builds for gfx950 (cross-compiled, no GPU needed), loads, and exports exactly the
+entry points include/mobilequant_amd.h declares.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mobilequant_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from mobilequant_amd import build
+    return build.build()          # no-op when the in-tree library is newer than its sources
+
+
+def test_header_and_binding_agree():
+    from mobilequant_amd import _lib
+    assert declared_functions() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (mq_[a-z0-9_]+)$", out, flags=re.M))
+    assert exported == set(declared_functions())       # nothing undeclared leaks out either
+
+
+def test_library_contains_gfx950_code_only(lib_path):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", lib_path], capture_output=True, text=True).stdout
+    blob = open(lib_path, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob, out[:200]
+
+
+def test_binding_loads_and_reports_errors_without_a_gpu(lib_path):
+    from mobilequant_amd import _lib
+    lib = _lib.load()
+    assert lib.mq_version() >= 100
+    nvar = lib.mq_gemm_set_variant(-1)
+    assert nvar >= 4 and lib.mq_gemm_variant_name(0).decode().startswith("t")
+    # argument validation happens before any HIP call: null pointers -> MQ_EINVAL + a message, no crash
+    rc = lib.mq_fake_quant(None, None, 0, 4, 4, None, None, 1, 0.0, 255.0, None)
+    assert rc == 1 and b"null pointer" in lib.mq_last_error()
+    with pytest.raises(_lib.MobileQuantLibraryError, match="K=100"):
+        _lib.call("mq_w8a8_linear", 16, 16, 4, 8, 100, None, 16, 16, 16, None, None, None, 0.0, 0.0, 16, 0, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mobilequant_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MobileQuantLibraryError, match="no CPU or PyTorch fallback"):
+        _lib.load()

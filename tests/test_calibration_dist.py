@@ -1,0 +1,105 @@
+"""The N>1 calibration path on CPU: two gloo ranks shard a sample stream round-robin, keep running
+[min, max] per tensor, and merge with ONE packed all-reduce(MAX) -- identical to the unsharded oracle.
+(The per-tensor reductions themselves are HIP kernels and are covered by the gpu tests; here each rank's
+running statistics are produced by the oracle so the collective, packing and layout logic run without a GPU.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_npz
+from oracle import mq_oracle as O
+from toy_models import CalibToy
+
+
+def _stream(z, prefix):
+    items = {}
+    for key in z.files:
+        if key.startswith(prefix + "|"):
+            _, name, field, idx = key.split("|")
+            items.setdefault(int(idx), []).append((name, field, z[key]))
+    return [items[i] for i in sorted(items)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, per_channel, empty_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mobilequant_amd.calibration import ActRangeCollector
+        z = load_npz("calib_stream.npz")
+        samples = _stream(z, "stream_pc" if per_channel else "stream_pt")
+        if empty_rank:
+            samples = samples[:1]              # fewer samples than ranks: rank 1 sees nothing
+        col = ActRangeCollector(CalibToy(), per_channel=per_channel, device="cpu")
+        calls = {"n": 0}
+        real = dist.all_reduce
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+        dist.all_reduce = counting
+        mine = O.ActRangeOracle(per_channel)
+        for s in samples[rank::world]:
+            for name, field, t in s:
+                mine.update(name, field, t)
+        for (name, field), i in col.slots.items():          # inject this rank's running statistics
+            v = mine.act_dict.get(name, {}).get(field)
+            if v is None:
+                continue
+            if per_channel:
+                col._pc[i] = (torch.from_numpy(v[0].copy()), torch.from_numpy(v[1].copy()))
+            else:
+                col._mn[i], col._mx[i] = float(v[0]), float(v[1])
+        col.all_reduce()
+        dist.all_reduce = real
+        got = col.act_dict()
+        full = O.ActRangeOracle(per_channel)
+        for s in samples:
+            for name, field, t in s:
+                full.update(name, field, t)
+        ok = calls["n"] == 1 and got.keys() == full.act_dict.keys()
+        for name, fields in full.act_dict.items():
+            for f, v in fields.items():
+                if per_channel:
+                    ok &= bool(np.array_equal(got[name][f].numpy(), v))
+                else:
+                    ok &= got[name][f] == [np.float32(v[0]), np.float32(v[1])]
+        q.put((rank, bool(ok), calls["n"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("per_channel,empty_rank", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_rank_calibration_merge(per_channel, empty_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, per_channel, empty_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, 1), (1, True, 1)], res
+
+
+def test_collector_slot_layout_is_data_independent():
+    from mobilequant_amd.calibration import ActRangeCollector
+    a = ActRangeCollector(CalibToy(), device="cpu")
+    assert list(a.slots) == [("fc1", "input"), ("fc1", "output"), ("act", "input"), ("act", "output"), ("fc2", "input"),
+                             ("fc2", "output"), ("bmm", "input"), ("bmm", "output"), ("bmm", "input2"),
+                             ("ln", "input"), ("ln", "output")]
+    assert a.act_dict() == {}          # nothing observed yet -> nothing reported
