@@ -160,15 +160,26 @@ def run_steps(fn, steps, warmup, world, use_graph=True):
 
 
 def event_time(fn, iters):
-    """Average duration of `fn` launches via HIP events on the current stream (where the kernels run)."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    """Average duration of one `fn` launch: `iters` launches captured in a hipGraph (so the host cannot be
+    the bottleneck) and bracketed by HIP events on the stream the kernels run on."""
     fn()
     torch.cuda.synchronize()
-    best = float("inf")
-    for _ in range(3):
-        e0.record()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
         for _ in range(iters):
             fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(5):
+        e0.record()
+        g.replay()
         e1.record()
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1) / iters)

@@ -420,20 +420,17 @@ static int launch_cfg(const GemmArgs& a, bool outq, hipStream_t st) {
 
 static int pick_variant(int M, int N) {
   if (g_forced_variant >= 0) return g_forced_variant;
-  // choose the largest tile that still yields >= ~256 workgroups (one per CU), preferring an exact
-  // one-wave fit; small problems fall through to the small tiles.
-  const int order[] = {0, 2, 4, 5, 3, 6};
-  for (int v : order) {
-    const long gm = (M + kVariants[v].bm - 1) / kVariants[v].bm, gn = (N + kVariants[v].bn - 1) / kVariants[v].bn;
-    const long nblk = gm * gn;
-    if (v == 0 && (N % 176 != 0)) continue;
-    if (nblk >= 224 && (nblk <= 256 || nblk >= 704)) return v;
-  }
-  for (int v : {3, 6}) {
-    const long gm = (M + kVariants[v].bm - 1) / kVariants[v].bm, gn = (N + kVariants[v].bn - 1) / kVariants[v].bn;
-    if (gm * gn >= 128) return v;
-  }
-  return 6;
+  auto blocks = [&](int v) {
+    return (long)((M + kVariants[v].bm - 1) / kVariants[v].bm) * ((N + kVariants[v].bn - 1) / kVariants[v].bn);
+  };
+  // Measured on MI355X (tools/mq_probe, profiles/): the 8-wave 256x176 tile is the fastest whenever it
+  // tiles N exactly and fills the chip in one round (TinyLlama / StableLM FFN: N = 5632 = 32 x 176);
+  // otherwise pick the largest tile that still gives every CU a workgroup, else the small tiles.
+  if (N % 176 == 0 && blocks(1) >= 192) return 1;
+  const int order[] = {2, 5, 3, 6};
+  for (int v : order)
+    if (blocks(v) >= 224) return v;
+  return blocks(3) >= 96 ? 3 : 6;
 }
 
 template <bool W4>
