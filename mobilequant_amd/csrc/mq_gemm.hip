@@ -49,6 +49,7 @@ struct GemmArgs {
   void* out;
   int out_dtype;
   int grid_m, grid_n;
+  unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
 };
 
 constexpr int BK = 128;   // bytes of K per LDS stage (two MFMA k-steps of 64)
@@ -77,33 +78,18 @@ template <> struct OutT<MQ_I8> { using type = int8_t; };
 template <> struct OutT<MQ_U16> { using type = uint16_t; };
 template <> struct OutT<MQ_I16> { using type = int16_t; };
 
-// Store 4 consecutive-n results of one lane.
-template <int OUT>
-__device__ __forceinline__ void store4(void* out, size_t idx, const float (&v)[4], int shift) {
-  if constexpr (OUT == MQ_F32) {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + idx) = make_float4(v[0], v[1], v[2], v[3]);
-  } else if constexpr (OUT == MQ_F16) {
-    struct alignas(8) H4 { __half h[4]; };
-    H4 p;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p.h[j] = __float2half_rn(v[j]);
-    *reinterpret_cast<H4*>(reinterpret_cast<__half*>(out) + idx) = p;
-  } else if constexpr (OUT == MQ_U8 || OUT == MQ_I8) {
-    uint32_t p = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p |= (uint32_t)((int)v[j] - shift & 0xff) << (8 * j);
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + idx) = p;
-  } else {
-    uint2 p;
-    p.x = (uint32_t)((int)v[0] & 0xffff) | ((uint32_t)((int)v[1] & 0xffff) << 16);
-    p.y = (uint32_t)((int)v[2] & 0xffff) | ((uint32_t)((int)v[3] & 0xffff) << 16);
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + idx) = p;
-  }
+// Bytes of LDS in front of the per-n epilogue vectors: the stage buffers, or the epilogue's staging tiles
+// (NW waves x 16 rows x padded fp32 row) if those are larger.
+constexpr int lds_main_bytes(int BM, int BN, int WM, int WN, bool W4, bool PP) {
+  const int wrow = W4 ? BK / 2 : BK;
+  const int stages = PP ? 2 * BM * BK + 3 * BN * wrow : 2 * (BM * BK + BN * wrow);
+  const int staging = WM * WN * 16 * ((BN / WN) * 4 + 16);
+  return stages > staging ? stages : staging;
 }
 
 // ABL: compile-time ablation for profiling builds (-DMQ_GEMM_ABLATE): bit0 = no LDS-DMA after the
 // first stage, bit1 = no MFMA loop body, bit2 = no epilogue.  Production instantiates ABL = 0 only.
-template <int BM, int BN, int WM, int WN, int OUT, bool OUTQ, bool W4, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int OUT, bool OUTQ, bool W4, int ABL = 0, bool PP = false>
 __global__ void __launch_bounds__(64 * WM * WN)
     gemm_i8_kernel(const GemmArgs args) {
   constexpr int NW = WM * WN;
@@ -124,7 +110,10 @@ __global__ void __launch_bounds__(64 * WM * WN)
   constexpr bool W_TAIL = (W_INSTR % NW) != 0;      // last round: only some waves have an instruction
   constexpr int N_DMA = A_ROUNDS + W_ROUNDS;        // DMA instructions per wave per stage (max)
   constexpr int DMA_PER_GROUP = (N_DMA + FN - 1) / FN;
-  constexpr int PAR = 2 * STAGE;                    // LDS offset of the per-n epilogue vectors
+  // LDS map.  classic: [stage 0: A|W][stage 1: A|W][params].  ping-pong: [A0][A1][W0][W1][W2][params] --
+  // three W buffers give the shared weight rows five phases of flight time (A rows are private per wave).
+  constexpr int W_BASE = PP ? 2 * A_BYTES : A_BYTES;
+  constexpr int PAR = lds_main_bytes(BM, BN, WM, WN, W4, PP);       // LDS offset of the per-n epilogue vectors
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -132,6 +121,8 @@ __global__ void __launch_bounds__(64 * WM * WN)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave_m = wave / WN, wave_n = wave % WN;
 
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -143,10 +134,12 @@ __global__ void __launch_bounds__(64 * WM * WN)
   // A / W8 instruction: lane -> row (lane>>3), stored chunk (lane&7) holds logical chunk (lane&7)^(row&7).
   // W4 instruction (64-byte rows): lane -> row (lane>>2), stored chunk (lane&3) holds logical chunk
   // (lane&3) ^ g(row), g = {0,3,2,1}[(row>>2)&3]  (conflict-free for ds_read_b128 at a 64-byte pitch).
-  int src_a[A_ROUNDS], src_w[W_ROUNDS];
+  unsigned src_a[A_ROUNDS], src_w[W_ROUNDS];   // byte offsets < 2^31 (checked by the host wrapper)
 #pragma unroll
   for (int i = 0; i < A_ROUNDS; ++i) {
-    int row = m0 + (wave + i * NW) * 8 + (lane >> 3);
+    // classic loop: instruction j = wave + i*NW (strided);  ping-pong: j = wave*A_ROUNDS + i, i.e. exactly the
+    // rows this wave's own MFMAs consume (WN == 1), so its A slice of a stage buffer is private to it
+    int row = m0 + (PP ? wave * A_ROUNDS + i : wave + i * NW) * 8 + (lane >> 3);
     row = row < M ? row : M - 1;
     src_a[i] = row * K + (((lane & 7) ^ (lane >> 3)) << 4);
   }
@@ -168,44 +161,54 @@ __global__ void __launch_bounds__(64 * WM * WN)
   const int8_t* a_ptr = args.a;
   const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
 
-  // one DMA instruction: index d in [0, N_DMA) = A rounds first, then W rounds
-  auto issue_one = [&](int d, int buf, int kt) {
-    char* base = smem + buf * STAGE + wave * 1024;
+  // one DMA instruction: index d in [0, N_DMA) = A rounds first, then W rounds.  `buf` selects the stage
+  // buffer (classic) or the A buffer (ping-pong); `wbuf` the W buffer of the ping-pong layout.
+  auto issue_one = [&](int d, int buf, int kt, int wbuf = 0) {
     if (d < A_ROUNDS) {
-      __builtin_amdgcn_global_load_lds(MQ_GLOBAL_PTR(a_ptr + src_a[d] + kt * BK), MQ_LDS_PTR(base + d * NW * 1024), 16, 0, 0);
+      char* dst = PP ? smem + buf * A_BYTES + (wave * A_ROUNDS + d) * 1024
+                     : smem + buf * STAGE + (wave + d * NW) * 1024;
+      __builtin_amdgcn_global_load_lds(MQ_GLOBAL_PTR(a_ptr + (size_t)(src_a[d] + (unsigned)(kt * BK))), MQ_LDS_PTR(dst), 16, 0, 0);
     } else {
       const int i = d - A_ROUNDS;
+      char* dst = PP ? smem + W_BASE + wbuf * W_BYTES + (wave + i * NW) * 1024
+                     : smem + buf * STAGE + A_BYTES + (wave + i * NW) * 1024;
       if (!W_TAIL || i < W_ROUNDS - 1 || wave + i * NW < W_INSTR)
-        __builtin_amdgcn_global_load_lds(MQ_GLOBAL_PTR(w_ptr + src_w[i] + kt * WROW),
-                                         MQ_LDS_PTR(base + A_BYTES + i * NW * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(MQ_GLOBAL_PTR(w_ptr + (size_t)(src_w[i] + (unsigned)(kt * WROW))), MQ_LDS_PTR(dst), 16, 0, 0);
     }
   };
 
-  // stage 0 first: its latency overlaps the parameter staging below
-#pragma unroll
-  for (int d = 0; d < N_DMA; ++d) issue_one(d, 0, 0);
-
-  // ---- per-n epilogue vectors -> LDS (read back as 16-byte vectors in the epilogue) --------------
-  {
-    float* p_alpha = reinterpret_cast<float*>(smem + PAR);
-    float* p_bias = p_alpha + BN;
-    int* p_zw = reinterpret_cast<int*>(p_bias + BN);
-    int* p_ct = p_zw + BN;
-    for (int t = threadIdx.x; t < BN; t += 64 * NW) {
-      const int n = n0 + t;
-      const bool ok = n < N;
-      p_alpha[t] = ok ? args.alpha[n] : 0.f;
-      p_bias[t] = (ok && args.bias != nullptr) ? args.bias[n] : 0.f;
-      p_zw[t] = ok ? args.w_zp[n] : 0;
-      p_ct[t] = ok ? args.col_term[n] : 0;
-    }
-  }
+  // ---- prologue ----------------------------------------------------------------------------------
+  // Ordinary global loads first (per-n epilogue vectors, row sums), THEN the LDS-DMA of the first
+  // stage(s): vmcnt retires in issue order, so waiting for the parameter loads does not drain the DMA.
   const int frow = lane & 15, kq = lane >> 4;
   int rs[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wave_m * TM + i * 16 + frow;
     rs[i] = (args.a_rowsum != nullptr && m < M) ? args.a_rowsum[m] : 0;
+  }
+  // per-n epilogue vectors: fetched now into registers, parked in LDS only AFTER the main loop (a ds_write
+  // issued while LDS-DMA is in flight makes the compiler drain every outstanding DMA first)
+  constexpr int PR = (BN + 64 * NW - 1) / (64 * NW);
+  float pa[PR], pb[PR];
+  int pz[PR], pc[PR];
+#pragma unroll
+  for (int r = 0; r < PR; ++r) {
+    const int tt = (int)threadIdx.x + r * 64 * NW;
+    const int n = n0 + tt;
+    const bool ok = tt < BN && n < N;
+    pa[r] = ok ? args.alpha[n] : 0.f;
+    pb[r] = (ok && args.bias != nullptr) ? args.bias[n] : 0.f;
+    pz[r] = ok ? args.w_zp[n] : 0;
+    pc[r] = ok ? args.col_term[n] : 0;
+  }
+#pragma unroll
+  for (int d = 0; d < N_DMA; ++d) issue_one(d, 0, 0, 0);
+  if constexpr (PP) {
+    if (KT > 1) {
+#pragma unroll
+      for (int d = 0; d < N_DMA; ++d) issue_one(d, 1, 1, 1);
+    }
   }
 
   // ---- ds_read offsets (per lane) -----------------------------------------------------------------
@@ -215,8 +218,11 @@ __global__ void __launch_bounds__(64 * WM * WN)
   if constexpr (W4) {
     w_off = A_BYTES + (wave_n * TN + frow) * WROW;   // group index added per use (depends on kq/ks)
   } else {
-    w_off = A_BYTES + (wave_n * TN + frow) * BK + ((kq ^ (lane & 7)) << 4);
+    w_off = W_BASE + (wave_n * TN + frow) * BK + ((kq ^ (lane & 7)) << 4);
   }
+
+  const int x_off1 = x_off ^ 64, w_off1 = w_off ^ 64;
+  (void)x_off1; (void)w_off1;
 
   v4i acc[FM][FN];
 #pragma unroll
@@ -224,12 +230,145 @@ __global__ void __launch_bounds__(64 * WM * WN)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
+  if constexpr (PP) {
+    // ---- ping-pong main loop (8 waves = two groups of four, one wave of each group per SIMD) --------
+    // Unit of work u = (stage t, k-step ks) = one MFMA k-step of 64 over the wave's whole tile.
+    //   phase E_u : group 0 issues the MFMAs of unit u from registers | group 1 ds_reads unit u
+    //   phase O_u : group 0 ds_reads unit u+1                         | group 1 issues the MFMAs of unit u
+    // The matrix pipe of every SIMD alternates between its group-0 and its group-1 wave and never waits for
+    // LDS latency; MFMA phases contain nothing but MFMAs; one s_barrier ends every phase.
+    // LDS-DMA rides in the READ phases only, A_ROUNDS or W_ROUNDS pieces per phase and wave:
+    //   A(t+2): a wave's A rows are private (WN == 1); it refills them right after its own read of (t,1)
+    //           -- group 0 in O_(t,0), group 1 in E_(t,1) -- no barrier involved, two A buffers.
+    //   W(t+2): shared rows in a ring of THREE buffers; buffer (t+2)%3 held stage t-1 and is free after the
+    //           barrier ending E_(t-1,1): group 0 issues its share in O_(t-1,1), group 1 in E_(t,0).
+    // Retirement: before the barrier ending E_(t,1) every wave waits until only its W(t+2) and A(t+2) pieces
+    // (the youngest W share + A_ROUNDS) are outstanding, i.e. its pieces of stage t+1 have landed; stage t+1
+    // is first read in O_(t,1).  Every piece gets >= 5 phases of flight time.
+    static_assert(NW == 8 && WN == 1 && !W4, "ping-pong schedule: 8 waves stacked along M, int8 weights");
+    const int grp = wave >> 2;
+    v4i xf[FM], wf[FN];
+    bool skip_reads = false;
+    (void)skip_reads;
+    auto read_unit = [&](int abuf, int wbuf, auto ks_tag) {
+      constexpr int ks = decltype(ks_tag)::value;
+      if constexpr (ABL & 8) {   // ablation: no fragment reads (only the first unit is read so registers are defined)
+        if (skip_reads) return;
+        skip_reads = true;
+      }
+      // (off + i*2048) ^ 64 == (off ^ 64) + i*2048: one base VGPR per operand and k-step, the fragment
+      // index goes into the ds_read immediate offset
+      const char* xb = smem + abuf * A_BYTES + (ks ? x_off1 : x_off);
+      const char* wb = smem + wbuf * W_BYTES + (ks ? w_off1 : w_off);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) xf[i] = *reinterpret_cast<const v4i*>(xb + i * 16 * BK);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const v4i*>(wb + j * 16 * BK);
+    };
+    auto all_frags_read = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto mfma_unit = [&]() {
+      if constexpr (ABL & 2) return;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], xf[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto issue_a = [&](int abuf, int kt) {
+      if constexpr (ABL & 1) return;
+#pragma unroll
+      for (int d = 0; d < A_ROUNDS; ++d) issue_one(d, abuf, kt, 0);
+    };
+    auto issue_w = [&](int wbuf, int kt) {
+      if constexpr (ABL & 1) return;
+#pragma unroll
+      for (int d = A_ROUNDS; d < N_DMA; ++d) issue_one(d, 0, kt, wbuf);
+    };
+    bool tail_owner = true;                                     // does this wave own a piece in the last W round?
+    if constexpr (W_TAIL) tail_owner = wave + (W_ROUNDS - 1) * NW < W_INSTR;
+    // wait until at most (a ? A_ROUNDS : 0) + (w ? this wave's W share : 0) DMA pieces are outstanding
+    auto leave_in_flight = [&](bool a, bool w) {
+      if constexpr (ABL & 1) return;
+      if (a && w) {
+        if (tail_owner) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROUNDS + W_ROUNDS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROUNDS + W_ROUNDS - 1) : "memory");
+      } else if (a) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROUNDS) : "memory");
+      } else if (w) {
+        if (tail_owner) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_ROUNDS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_ROUNDS - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    auto phase_end = []() { asm volatile("s_barrier" ::: "memory"); };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+
+    // LDS-DMA schedule (pieces ride at the END of READ phases, after the phase's ds_reads are issued, with
+    // no dependency wait in front of them; MFMA phases hold nothing but MFMAs):
+    //   group 0:  O_(t,0): reads (t,1)   then W(t+2) -> W buffer (t+2)%3  [held stage t-1, consumed at E_(t-1,1)]
+    //             O_(t,1): reads (t+1,0) then A(t+2) -> A buffer t&1      [own rows, read back in O_(t,0)]
+    //   group 1:  E_(t,0): reads (t,0)   then A(t+1) -> A buffer (t+1)&1  [own rows, read back in E_(t-1,1)]
+    //             E_(t,1): reads (t,1)   then W(t+2) -> W buffer (t+2)%3
+    // Shared rows (W) must be retired before the barrier ending E_(t,1) (stage t+1 is first read in O_(t,1));
+    // private rows (A) only before the owner's own read.  Every piece has >= 4 phases of flight time.
+    leave_in_flight(KT > 1, KT > 1);                           // stage 0 landed; stage 1 may be in flight
+    phase_end();
+    if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
+    if (grp == 0) {
+      read_unit(0, 0, K0{});
+      all_frags_read();
+      phase_end();                                             // O_(-1)
+      int w3 = 0;                                              // t % 3
+      for (int t = 0; t < KT; ++t) {
+        const int w3n = w3 == 2 ? 0 : w3 + 1;                  // (t+1) % 3
+        const int w3p = w3 == 0 ? 2 : w3 - 1;                  // (t+2) % 3
+        mfma_unit();                                           // E_(t,0)
+        phase_end();
+        read_unit(t & 1, w3, K1{});                            // O_(t,0)
+        if (t + 2 < KT) issue_w(w3p, t + 2);
+        all_frags_read();
+        phase_end();
+        mfma_unit();                                           // E_(t,1)
+        leave_in_flight(false, t + 2 < KT);                    //   W(t+1) and A(t+1) of this wave have landed
+        phase_end();
+        if (t + 1 < KT) read_unit((t + 1) & 1, w3n, K0{});     // O_(t,1)
+        if (t + 2 < KT) issue_a(t & 1, t + 2);
+        all_frags_read();
+        phase_end();
+        w3 = w3n;
+      }
+    } else {
+      phase_end();                                             // O_(-1): nothing to do yet
+      int w3 = 0;
+      for (int t = 0; t < KT; ++t) {
+        const int w3n = w3 == 2 ? 0 : w3 + 1;
+        const int w3p = w3 == 0 ? 2 : w3 - 1;
+        if (t > 0) leave_in_flight(false, t + 1 < KT);         // E_(t,0): own A(t) has landed (W(t+1) may fly)
+        read_unit(t & 1, w3, K0{});
+        if (t > 0 && t + 1 < KT) issue_a((t + 1) & 1, t + 1);
+        all_frags_read();
+        phase_end();
+        mfma_unit();                                           // O_(t,0)
+        phase_end();
+        read_unit(t & 1, w3, K1{});                            // E_(t,1)
+        if (t + 2 < KT) issue_w(w3p, t + 2);
+        all_frags_read();
+        leave_in_flight(t > 0 && t + 1 < KT, t + 2 < KT);      //   this wave's W(t+1) pieces have landed
+        phase_end();
+        mfma_unit();                                           // O_(t,1)
+        phase_end();
+        w3 = w3n;
+      }
+    }
+  } else {
   auto k_step = [&](int kt, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value && !(ABL & 1);
     const int cur = kt & 1;
     // own DMA of stage kt retired, then everyone's; also: every wave has finished reading buf cur^1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     const char* sb = smem + cur * STAGE;
     if constexpr (ABL & 2) {
       if constexpr (more) {
@@ -285,56 +424,136 @@ __global__ void __launch_bounds__(64 * WM * WN)
   };
   for (int kt = 0; kt < KT - 1; ++kt) k_step(kt, std::true_type{});
   k_step(KT - 1, std::false_type{});
-
-  // ---- epilogue -----------------------------------------------------------------------------------
-  // lane holds, for fragment (i, j): m = frow, n = 4*kq + {0..3}
-  if constexpr (ABL & 4) {
-    if (acc[0][0][0] == 0x7fffffff) reinterpret_cast<int*>(args.out)[0] = 1;
-    return;
   }
-  float inv_so = 0.f, so = 0.f, oo = 0.f;
-  int oshift = 0;
+
+  if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
+  // ---- epilogue -----------------------------------------------------------------------------------
+  // (1) park the per-n vectors in LDS (with the output quantizer folded in: q = rint(t*A' + B'),
+  //     A' = alpha/so, B' = bias/so + oo);  (2) per 16-row block: dequant (+quantize) in registers,
+  //     transpose through a wave-private LDS tile so that (3) every lane stores 16 contiguous bytes and
+  //     a wave instruction writes whole rows -- instead of 16-byte fragments of 16 different rows.
+  constexpr bool FOLD_OO = OUTQ && (OUT == MQ_U8 || OUT == MQ_I8);
+  float so = 1.f, oo = 0.f, inv_so = 1.f;
   if constexpr (OUTQ) {
     so = args.out_scale[0];
     oo = args.out_offset[0];
     inv_so = __fdiv_rn(1.0f, so);
-    if constexpr (OUT == MQ_I8) oshift = (args.out_qmin == 0.0f) ? 128 : 0;
   }
+  {
+    float* p_alpha_w = reinterpret_cast<float*>(smem + PAR);
+    float* p_bias_w = p_alpha_w + BN;
+    int* p_zw_w = reinterpret_cast<int*>(p_bias_w + BN);
+    int* p_ct_w = p_zw_w + BN;
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+      const int tt = (int)threadIdx.x + r * 64 * NW;
+      if (tt < BN) {
+        p_alpha_w[tt] = OUTQ ? pa[r] * inv_so : pa[r];
+        // 8-bit storage: the offset (<= 255) rides in the bias; 16-bit grids keep it out of the rounding
+        p_bias_w[tt] = OUTQ ? (FOLD_OO ? pb[r] * inv_so + oo : pb[r] * inv_so) : pb[r];
+        p_zw_w[tt] = pz[r];
+        p_ct_w[tt] = pc[r];
+      }
+    }
+    __syncthreads();     // also: every wave is done with the stage buffers, which become staging tiles
+  }
+  if constexpr (ABL & 4) {
+    if (acc[0][0][0] == 0x7fffffff) reinterpret_cast<int*>(args.out)[0] = 1;
+    return;
+  }
+  using OT = typename OutT<OUT>::type;
+  constexpr int ESZ = sizeof(OT);
+  constexpr int ROWB = TN * ESZ;                                   // bytes of one output row of the wave tile
+  constexpr int ROWP = ROWB + (((ROWB / 4) % 8 == 0) ? 16 : 0);    // padded pitch: keeps the LDS writes <= 2-way
+  constexpr int CH = ROWB / 16;                                    // 16-byte chunks per row
+  constexpr int EPC = 16 / ESZ;                                    // elements per chunk
+  static_assert(NW * 16 * ROWP <= PAR, "staging tiles must fit in front of the epilogue vectors");
+  char* stg = smem + wave * (16 * ROWP);
   const float qmin = args.out_qmin, qmax = args.out_qmax;
+  const bool i8_unsigned_grid = (OUT == MQ_I8) && (args.out_qmin == 0.0f);
   const v4f* p_alpha = reinterpret_cast<const v4f*>(smem + PAR);
   const v4f* p_bias = reinterpret_cast<const v4f*>(smem + PAR + BN * 4);
   const v4i* p_zw = reinterpret_cast<const v4i*>(smem + PAR + BN * 8);
   const v4i* p_ct = reinterpret_cast<const v4i*>(smem + PAR + BN * 12);
+  const bool rows_vec = (N % EPC) == 0;        // 16-byte row stores need N*ESZ % 16 == 0 (always true for LLM shapes)
+  OT* outp = reinterpret_cast<OT*>(args.out);
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int nl = wave_n * TN + j * 16 + kq * 4;   // column within the tile
-    const int n = n0 + nl;
-    if (n + 3 < N) {
+  for (int i = 0; i < FM; ++i) {
+    const int mrow0 = m0 + wave_m * TM + i * 16;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nl = wave_n * TN + j * 16 + kq * 4;   // column within the block tile
       const v4f al = p_alpha[nl >> 2];
       const v4f bs = p_bias[nl >> 2];
       const v4i zw = p_zw[nl >> 2];
       const v4i ct = p_ct[nl >> 2];
+      float v[4];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wave_m * TM + i * 16 + frow;
-        if (m < M) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int t = (int)((unsigned)acc[i][j][e] - (unsigned)zw[e] * (unsigned)rs[i] + (unsigned)ct[e]);
-            float f = __fmul_rn((float)t, al[e]);
-            f = __fadd_rn(f, bs[e]);
-            if constexpr (OUTQ) {
-              float q = rintf(f * inv_so) + oo;
-              q = fminf(fmaxf(q, qmin), qmax);
-              if constexpr (OUT == MQ_F32 || OUT == MQ_F16) f = __fmul_rn(__fsub_rn(q, oo), so);
-              else f = q;
-            }
-            v[e] = f;
-          }
-          store4<OUT>(args.out, (size_t)m * N + n, v, oshift);
+      for (int e = 0; e < 4; ++e) {
+        // |w_zp| < 2^23 and |row sum| < 2^23 (K <= 65536): 24-bit multiply-add is exact and full rate
+        const int t = (int)((unsigned)__mul24(-zw[e], rs[i]) + (unsigned)acc[i][j][e] + (unsigned)ct[e]);
+        if constexpr (OUTQ) {
+          float q = rintf(__builtin_fmaf((float)t, al[e], bs[e]));
+          if constexpr (!FOLD_OO) q += oo;
+          q = __builtin_amdgcn_fmed3f(q, qmin, qmax);
+          if constexpr (OUT == MQ_F32 || OUT == MQ_F16) v[e] = __fmul_rn(__fsub_rn(q, oo), so);
+          else v[e] = q;
+        } else {
+          v[e] = __fadd_rn(__fmul_rn((float)t, al[e]), bs[e]);
         }
       }
+      char* dst = stg + frow * ROWP + (j * 16 + kq * 4) * ESZ;
+      if constexpr (OUT == MQ_F32) {
+        *reinterpret_cast<v4f*>(dst) = v4f{v[0], v[1], v[2], v[3]};
+      } else if constexpr (OUT == MQ_F16) {
+        struct alignas(8) H4 { __half h[4]; };
+        H4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h.h[e] = __float2half_rn(v[e]);
+        *reinterpret_cast<H4*>(dst) = h;
+      } else if constexpr (OUT == MQ_U8 || OUT == MQ_I8) {
+        unsigned pk = 0;
+        if (OUT == MQ_U8 || i8_unsigned_grid) {      // values in [0,255]; i8 storage = value - 128 = byte ^ 0x80
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(v[e], e, pk);
+          if (OUT == MQ_I8) pk ^= 0x80808080u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk |= ((unsigned)(int)v[e] & 0xffu) << (8 * e);
+        }
+        *reinterpret_cast<unsigned*>(dst) = pk;
+      } else {
+        uint2 pk;
+        pk.x = ((unsigned)(int)v[0] & 0xffffu) | (((unsigned)(int)v[1] & 0xffffu) << 16);
+        pk.y = ((unsigned)(int)v[2] & 0xffffu) | (((unsigned)(int)v[3] & 0xffffu) << 16);
+        *reinterpret_cast<uint2*>(dst) = pk;
+      }
+    }
+    // the wave's own LDS accesses execute in order: its writes above are visible to its reads below
+    if (rows_vec) {
+#pragma unroll
+      for (int c0 = 0; c0 < 16 * CH; c0 += 64) {
+        const int c = c0 + lane;
+        if (16 * CH % 64 == 0 || c < 16 * CH) {
+          const int row = c / CH, ch = c - row * CH;
+          const int m = mrow0 + row, n = n0 + wave_n * TN + ch * EPC;
+          const v4i val = *reinterpret_cast<const v4i*>(stg + row * ROWP + ch * 16);
+          if (m < M && n < N) *reinterpret_cast<v4i*>(outp + (size_t)m * N + n) = val;
+        }
+      }
+    } else {
+      for (int c = lane; c < 16 * TN; c += 64) {        // ragged N: element-wise
+        const int row = c / TN, col = c - row * TN;
+        const int m = mrow0 + row, n = n0 + wave_n * TN + col;
+        if (m < M && n < N) outp[(size_t)m * N + n] = *reinterpret_cast<const OT*>(stg + row * ROWP + col * ESZ);
+      }
+    }
+  }
+  if constexpr (ABL & 16) {
+    if (args.dbg_ts != nullptr && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long* d = args.dbg_ts + ((size_t)blockIdx.x * NW + wave) * 4;
+      d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
     }
   }
 }
@@ -353,14 +572,16 @@ static const Variant kVariants[] = {
     {"t128x256_w2x2", 128, 256, 256},
     {"t256x128_w4x2", 256, 128, 512},
     {"t64x64_w2x2", 64, 64, 256},
+    {"t256x176_w8x1_pp", 256, 176, 512},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static int g_forced_variant = -1;
 static int g_debug = 0;
+static unsigned long long* g_dbg_ts = nullptr;
 
-template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, int ABL>
+template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, int ABL, bool PP>
 static int launch_one(const GemmArgs& a, int lds, hipStream_t st) {
-  auto kfn = gemm_i8_kernel<BM, BN, WM, WN, OUT, OQ, W4, ABL>;
+  auto kfn = gemm_i8_kernel<BM, BN, WM, WN, OUT, OQ, W4, ABL, PP>;
   static bool attr_set = false;   // per instantiation; one device per process
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -375,43 +596,50 @@ static int launch_one(const GemmArgs& a, int lds, hipStream_t st) {
   return MQ_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4>
+template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, bool PP>
 static int launch_typed(const GemmArgs& a, hipStream_t st) {
   constexpr int WROW = W4 ? BK / 2 : BK;
-  constexpr int LDS = 2 * (BM * BK + BN * WROW) + 16 * BN;
+  constexpr int LDS = lds_main_bytes(BM, BN, WM, WN, W4, PP) + 16 * BN;
 #ifdef MQ_GEMM_ABLATE
   if constexpr (OUT == MQ_U8 && OQ && !W4 && BM == 256) {
     switch (g_debug) {
-      case 1: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 1>(a, LDS, st);
-      case 2: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 2>(a, LDS, st);
-      case 3: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 3>(a, LDS, st);
-      case 4: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 4>(a, LDS, st);
-      case 5: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 5>(a, LDS, st);
-      case 6: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 6>(a, LDS, st);
-      case 7: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 7>(a, LDS, st);
+      case 1: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 1, PP>(a, LDS, st);
+      case 2: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 2, PP>(a, LDS, st);
+      case 3: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 3, PP>(a, LDS, st);
+      case 4: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 4, PP>(a, LDS, st);
+      case 5: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 5, PP>(a, LDS, st);
+      case 6: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 6, PP>(a, LDS, st);
+      case 7: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 7, PP>(a, LDS, st);
+      case 8: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 8, PP>(a, LDS, st); else break;
+      case 9: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 9, PP>(a, LDS, st); else break;
+      case 16: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 16, PP>(a, LDS, st); else break;
+      case 17: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 17, PP>(a, LDS, st); else break;
+      case 18: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 18, PP>(a, LDS, st); else break;
+      case 24: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 24, PP>(a, LDS, st); else break;
+      case 25: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 25, PP>(a, LDS, st); else break;
       default: break;
     }
   }
 #endif
-  return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 0>(a, LDS, st);
+  return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 0, PP>(a, LDS, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool W4>
+template <int BM, int BN, int WM, int WN, bool W4, bool PP = false>
 static int launch_cfg(const GemmArgs& a, bool outq, hipStream_t st) {
   if (outq) {
     switch (a.out_dtype) {
-      case MQ_F32: return launch_typed<BM, BN, WM, WN, MQ_F32, true, W4>(a, st);
-      case MQ_F16: return launch_typed<BM, BN, WM, WN, MQ_F16, true, W4>(a, st);
-      case MQ_U8: return launch_typed<BM, BN, WM, WN, MQ_U8, true, W4>(a, st);
-      case MQ_I8: return launch_typed<BM, BN, WM, WN, MQ_I8, true, W4>(a, st);
-      case MQ_U16: return launch_typed<BM, BN, WM, WN, MQ_U16, true, W4>(a, st);
-      case MQ_I16: return launch_typed<BM, BN, WM, WN, MQ_I16, true, W4>(a, st);
+      case MQ_F32: return launch_typed<BM, BN, WM, WN, MQ_F32, true, W4, PP>(a, st);
+      case MQ_F16: return launch_typed<BM, BN, WM, WN, MQ_F16, true, W4, PP>(a, st);
+      case MQ_U8: return launch_typed<BM, BN, WM, WN, MQ_U8, true, W4, PP>(a, st);
+      case MQ_I8: return launch_typed<BM, BN, WM, WN, MQ_I8, true, W4, PP>(a, st);
+      case MQ_U16: return launch_typed<BM, BN, WM, WN, MQ_U16, true, W4, PP>(a, st);
+      case MQ_I16: return launch_typed<BM, BN, WM, WN, MQ_I16, true, W4, PP>(a, st);
       default: set_error("mq_gemm: out_dtype %d not supported", a.out_dtype); return MQ_EUNSUPPORTED;
     }
   }
   switch (a.out_dtype) {
-    case MQ_F32: return launch_typed<BM, BN, WM, WN, MQ_F32, false, W4>(a, st);
-    case MQ_F16: return launch_typed<BM, BN, WM, WN, MQ_F16, false, W4>(a, st);
+    case MQ_F32: return launch_typed<BM, BN, WM, WN, MQ_F32, false, W4, PP>(a, st);
+    case MQ_F16: return launch_typed<BM, BN, WM, WN, MQ_F16, false, W4, PP>(a, st);
     default:
       set_error("mq_gemm: integer out_dtype %d needs an output quantizer", a.out_dtype);
       return MQ_EINVAL;
@@ -426,7 +654,7 @@ static int pick_variant(int M, int N) {
   // Measured on MI355X (tools/mq_probe, profiles/): the 8-wave 256x176 tile is the fastest whenever it
   // tiles N exactly and fills the chip in one round (TinyLlama / StableLM FFN: N = 5632 = 32 x 176);
   // otherwise pick the largest tile that still gives every CU a workgroup, else the small tiles.
-  if (N % 176 == 0 && blocks(1) >= 192) return 1;
+  if (N % 176 == 0 && blocks(1) >= 192) return 7;   // ping-pong schedule (variant 1 = same tile, simple 2-stage loop)
   const int order[] = {2, 5, 3, 6};
   for (int v : order)
     if (blocks(v) >= 224) return v;
@@ -447,6 +675,9 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
     case 4: return launch_cfg<128, 256, 2, 2, W4>(a, outq, st);
     case 5: return launch_cfg<256, 128, 4, 2, W4>(a, outq, st);
     case 6: return launch_cfg<64, 64, 2, 2, W4>(a, outq, st);
+    case 7:
+      if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, true>(a, outq, st);
+      else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
     default: set_error("mq_gemm: bad variant %d", v); return MQ_EINVAL;
   }
 }
@@ -456,7 +687,7 @@ static int check_common(const char* fn, const void* a, const void* w, int64_t M,
                         const float* bias, const float* out_scale, const float* out_offset, void* out, int kdiv) {
   MQ_REQUIRE(a && w && alpha && w_zp && col_term && out, "%s: null pointer", fn);
   MQ_REQUIRE(M > 0 && N > 0 && K > 0, "%s: bad shape M=%lld N=%lld K=%lld", fn, (long long)M, (long long)N, (long long)K);
-  MQ_REQUIRE(K % 128 == 0, "%s: K=%lld must be a multiple of 128", fn, (long long)K);
+  MQ_REQUIRE(K % 128 == 0 && K <= 65536, "%s: K=%lld must be a multiple of 128, at most 65536", fn, (long long)K);
   MQ_REQUIRE(N % 4 == 0, "%s: N=%lld must be a multiple of 4", fn, (long long)N);
   MQ_REQUIRE(M * K < (1ll << 31) && N * K / kdiv < (1ll << 31) && M * N < (1ll << 40), "%s: operand too large", fn);
   MQ_REQUIRE(aligned(a, 16) && aligned(w, 16) && aligned(out, 16) && aligned(alpha, 16) && aligned(w_zp, 16) &&
@@ -483,6 +714,14 @@ int mq_gemm_set_debug(int flags) {
   return 0;
 }
 
+#ifdef MQ_GEMM_ABLATE
+// not part of the public header: probe-only hook for the s_memtime stamps of ablation builds
+extern "C" int mq_gemm_set_debug_buffer_(void* p) {
+  g_dbg_ts = reinterpret_cast<unsigned long long*>(p);
+  return 0;
+}
+#endif
+
 const char* mq_gemm_variant_name(int variant) {
   return (variant >= 0 && variant < kNumVariants) ? kVariants[variant].name : "";
 }
@@ -495,7 +734,7 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
                         out, 1);
   if (rc != MQ_OK) return rc;
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
 }
 
@@ -507,7 +746,7 @@ int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t 
                         out_offset, out, 2);
   if (rc != MQ_OK) return rc;
   GemmArgs g{a, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, g_dbg_ts};
   return run_gemm<true>(g, as_stream(stream));
 }
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "mobilequant_amd.h"
+extern "C" int mq_gemm_set_debug_buffer_(void*) __attribute__((weak));   // ablation builds of the library only
 
 #define HIPCHK(x)                                                                   \
   do {                                                                              \
@@ -201,6 +202,27 @@ int main(int argc, char** argv) {
     mq_gemm_set_debug(dbg);
     float t = time_variant(p, v, od, od != MQ_F32 && od != MQ_F16, n);
     printf("prof %s dbg=%d %dx%dx%d od=%d: %.2f us\n", mq_gemm_variant_name(v), dbg, M, N, K, od, t * 1e3);
+    if ((dbg & 16) && mq_gemm_set_debug_buffer_) {   // s_memtime stamps: [block][wave][t0, loop start, loop end, end]
+      const int nb = ((M + 255) / 256) * ((N + 175) / 176), nw = 8;
+      unsigned long long* d = dmalloc<unsigned long long>((size_t)nb * nw * 4);
+      HIPCHK(hipMemset(d, 0, (size_t)nb * nw * 4 * 8));
+      mq_gemm_set_debug_buffer_(d);
+      time_variant(p, v, od, true, 3);
+      std::vector<unsigned long long> h((size_t)nb * nw * 4);
+      HIPCHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+      double pro = 0, loop = 0, epi = 0, tot = 0; unsigned long long gmin = ~0ull, gmax = 0;
+      for (int i = 0; i < nb * nw; ++i) {
+        const unsigned long long* q = &h[(size_t)i * 4];
+        pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); tot += (double)(q[3] - q[0]);
+        gmin = std::min(gmin, q[0]); gmax = std::max(gmax, q[3]);
+      }
+      const double n2 = nb * nw;
+      printf("stamps (cycles, mean over %d waves): prologue %.0f  loop %.0f (%.0f per K=128 stage)  epilogue %.0f  total %.0f; first start -> last end %llu\n",
+             nb * nw, pro / n2, loop / n2, loop / n2 / (K / 128), epi / n2, tot / n2, gmax - gmin);
+      // per-group breakdown for block 0
+      for (int w = 0; w < nw; ++w) { const unsigned long long* q = &h[(size_t)w * 4]; printf("  blk0 wave%d: pro %llu loop %llu epi %llu\n", w, q[1]-q[0], q[2]-q[1], q[3]-q[2]); }
+      mq_gemm_set_debug_buffer_(nullptr);
+    }
     return 0;
   }
   // ---- correctness: small odd shapes on every variant, then the headline shape ---------------------
@@ -243,9 +265,10 @@ int main(int argc, char** argv) {
   {
     Problem p = make_problem(2048, 5632, 2048, 99u, false);
     const double ops = 2.0 * 2048 * 5632.0 * 2048;
-    const char* names[] = {"full", "noDMA", "noMFMA", "noDMA+noMFMA", "noEpi", "noDMA+noEpi", "noMFMA+noEpi", "none"};
+    const char* names[] = {"full", "noDMA", "noMFMA", "noDMA+noMFMA", "noEpi", "noDMA+noEpi", "noMFMA+noEpi", "none", "noREAD", "noREAD+noDMA"};
     for (int v = 0; v < nvar; ++v)
-      for (int dbg = 0; dbg < 8; ++dbg) {
+      for (int dbg = 0; dbg < 10; ++dbg) {
+        if (dbg >= 8 && v != 7) continue;
         mq_gemm_set_debug(dbg);
         float t = time_variant(p, v, MQ_U8, true, iters);
         printf("ablate %-16s %-14s %.2f us (%.0f TOPS-equivalent)\n", mq_gemm_variant_name(v), names[dbg], t * 1e3, ops / t / 1e9);
