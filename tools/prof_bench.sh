@@ -1,12 +1,21 @@
 #!/bin/bash
-# rocprofv3 kernel trace (+ optional PMC passes) of bench.py on the GPU box.  usage: prof_bench.sh <tag> [pmc]
+# rocprofv3 kernel trace (+ PMC passes) of bench.py on the GPU box; keeps only text summaries (the rocpd
+# databases are tens of MB).  usage: prof_bench.sh <tag> [pmc]     (run through gpurun)
 TAG=${1:-r01}; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_bench_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+pass() {  # name, rocprofv3 args...
+  local name=$1; shift
+  timeout 300 rocprofv3 "$@" -d /tmp/prof_$name -o p -- $CMD > $OUT/$name.log 2>&1
+  python $R/tools/pmc_summary.py /tmp/prof_$name/p_results.db > $OUT/$name.summary.txt 2>&1
+  grep -E '^\{"metric"' $OUT/$name.log > $OUT/$name.bench.json
+  rm -rf /tmp/prof_$name; tail -c 2000 $OUT/$name.log > $OUT/$name.log.tail; rm -f $OUT/$name.log
+}
+pass trace --kernel-trace --stats
 if [ "$2" = "pmc" ]; then
-  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_I8 --kernel-trace -d $OUT/pmc1 -o p -- $CMD > $OUT/pmc1.log 2>&1
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p -- $CMD > $OUT/pmc_fetch.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o p -- $CMD > $OUT/pmc_write.log 2>&1
+  pass pmc_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_I8 --kernel-trace
+  pass pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace
+  pass pmc_fetch --pmc FETCH_SIZE --kernel-trace
+  pass pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace
 fi
-tail -n 2 $OUT/trace.log
+cat $OUT/trace.summary.txt | head -40
