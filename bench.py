@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--workload", default="qlinear", choices=["qlinear", "calibration"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--overlap", action="store_true",
+                   help="experiment: quantize(batch i+1) on a side stream next to GEMM(batch i); measured SLOWER "
+                        "(36.3 vs 34.7 us/step): the GEMM's one workgroup per CU leaves no room to co-schedule")
     return p.parse_args()
 
 
@@ -104,28 +107,51 @@ class Step:
         del y
         from mobilequant_amd.ops import _OUT_TORCH
         self.code = out_dtype_code
-        self.a8 = torch.empty(M, K, dtype=torch.int8, device=dev)
-        self.rs = torch.empty(M, dtype=torch.int32, device=dev)
+        # two int8 activation buffers: the quantize of batch i+1 may run while the GEMM of batch i reads its own
+        self.a8s = [torch.empty(M, K, dtype=torch.int8, device=dev) for _ in range(2)]
+        self.rss = [torch.empty(M, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.a8, self.rs = self.a8s[0], self.rss[0]
         self.out = torch.empty(M, N, dtype=_OUT_TORCH[out_dtype_code], device=dev)
         self.w_fp = w
 
-    def quantize(self, i):
+    def quantize(self, i, slot=0):
         from mobilequant_amd import _lib
         from mobilequant_amd._lib import MQ_F32, MQ_I8
         x = self.x[i % N_BATCHES]
         _lib.call("mq_quantize", x.data_ptr(), MQ_F32, M, K, self.aq.scale.data_ptr(), self.aq.offset.data_ptr(), 1,
-                  0.0, 255.0, 128, self.a8.data_ptr(), MQ_I8, self.rs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                  0.0, 255.0, 128, self.a8s[slot].data_ptr(), MQ_I8, self.rss[slot].data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
 
-    def gemm(self):
-        self.ops.int8_linear(self.a8, self.w8, self.rs, self.alpha, self.wzp, self.ct, None, out_scale=self.oq.scale,
-                             out_offset=self.oq.offset, out_qmin=0.0, out_qmax=255.0, out_dtype=self.code, out=self.out)
+    def gemm(self, slot=0):
+        self.ops.int8_linear(self.a8s[slot], self.w8, self.rss[slot], self.alpha, self.wzp, self.ct, None,
+                             out_scale=self.oq.scale, out_offset=self.oq.offset, out_qmin=0.0, out_qmax=255.0,
+                             out_dtype=self.code, out=self.out)
 
     def __call__(self, i):
         self.quantize(i)
         self.gemm()
 
+    def pipelined(self, n, side):
+        """n steps with the activation quantize of batch i+1 on a side stream next to the GEMM of batch i (the
+        GEMM leaves 24 KiB of LDS and ~150 VGPRs per SIMD lane free on every CU; the quantize kernel is HBM-bound).
+        Every batch still passes through both kernels; only their order across batches is software-pipelined."""
+        main = torch.cuda.current_stream()
+        q_done = [torch.cuda.Event() for _ in range(n)]
+        g_done = [torch.cuda.Event() for _ in range(n)]
+        side.wait_stream(main)
+        for i in range(n):
+            with torch.cuda.stream(side):
+                if i >= 2:
+                    side.wait_event(g_done[i - 2])          # slot i%2 was read by GEMM i-2
+                self.quantize(i, i % 2)
+                q_done[i].record(side)
+            main.wait_event(q_done[i])
+            self.gemm(i % 2)
+            g_done[i].record(main)
+        main.wait_stream(side)
 
-def run_steps(fn, steps, warmup, world, use_graph=True):
+
+def run_steps(fn, steps, warmup, world, use_graph=True, pipelined=False):
     """W untimed warmup steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize.
     Steps are replayed from hipGraphs of GRAPH_STEPS steps each (the step is ~30 us: launch-bound from
     Python otherwise); a remainder runs eagerly inside the same timed region."""
@@ -141,9 +167,13 @@ def run_steps(fn, steps, warmup, world, use_graph=True):
                 fn(i)
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
         with torch.cuda.graph(graph):
-            for i in range(GRAPH_STEPS):
-                fn(i)
+            if pipelined:
+                fn.pipelined(GRAPH_STEPS, side)
+            else:
+                for i in range(GRAPH_STEPS):
+                    fn(i)
         graph.replay()
         torch.cuda.synchronize()
     barrier(world)
@@ -269,7 +299,8 @@ def main():
 
     with torch.no_grad():
         step = Step(dev, MQ_U8, seed=rank)
-        sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph)
+        pipelined = args.overlap and not args.no_graph
+        sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph, pipelined=pipelined)
         sec = max_over_ranks(sec, world)
         value = world * OPS_PER_STEP / sec / 1e12
 
@@ -286,6 +317,10 @@ def main():
                     "algorithmic_ops_per_launch": OPS_PER_STEP,
                     "quantize_kernel": {"bound": "hbm", "avg_launch_us": round(t_quant * 1e6, 2),
                                         "achieved_GBps": round((M * K * 5 + M * 4) / t_quant / 1e9, 1), "peak_GBps": 8000.0}}
+            if pipelined:
+                t_ser = run_steps(step, min(args.steps, 100), 5, 1, use_graph=True, pipelined=False)
+                extras["serial_u8"] = {"ms_per_step": round(t_ser * 1e3, 5), "value": round(OPS_PER_STEP / t_ser / 1e12, 1),
+                                       "note": "quantize and GEMM back to back on one stream"}
             for name, code in (("out_f16", MQ_F16), ("out_f32", MQ_F32)):
                 s2 = Step(dev, code, seed=rank)
                 t2 = run_steps(s2, min(args.steps, 100), 5, 1, use_graph=not args.no_graph)
@@ -318,6 +353,7 @@ def main():
                                    "-> int8 quantize(+row sums) -> MFMA i8 GEMM 2048->5632 with fused dequant + 8-bit output "
                                    "quantizer -> u8 indices; per-tensor asymmetric activation ranges, per-tensor asymmetric weights",
                        "M": M, "K": K, "N": N, "parallelism": f"replicas x{world}", "graph_steps": 0 if args.no_graph else GRAPH_STEPS,
+                       "schedule": "quantize(batch i+1) overlapped with GEMM(batch i) on a second stream" if pipelined else "serial",
                        "pct_int8_mfma_peak": round(100 * value / world / INT8_MFMA_PEAK_TOPS, 2),
                        "decode_tok_s": None, "device": info},
             "roofline": roof, "cpu_baseline": cpu, "variants": extras,

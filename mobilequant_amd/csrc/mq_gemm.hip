@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(64 * WM * WN)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave_m = wave / WN, wave_n = wave % WN;
 
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsp[5] = {0, 0, 0, 0, 0};
+  (void)tsp;
   if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
@@ -325,19 +326,25 @@ __global__ void __launch_bounds__(64 * WM * WN)
       for (int t = 0; t < KT; ++t) {
         const int w3n = w3 == 2 ? 0 : w3 + 1;                  // (t+1) % 3
         const int w3p = w3 == 0 ? 2 : w3 - 1;                  // (t+2) % 3
+        const bool stamp = (ABL & 16) && t == 8;
+        if (stamp) tsp[0] = __builtin_readcyclecounter();
         mfma_unit();                                           // E_(t,0)
         phase_end();
+        if (stamp) tsp[1] = __builtin_readcyclecounter();
         read_unit(t & 1, w3, K1{});                            // O_(t,0)
         if (t + 2 < KT) issue_w(w3p, t + 2);
         all_frags_read();
         phase_end();
+        if (stamp) tsp[2] = __builtin_readcyclecounter();
         mfma_unit();                                           // E_(t,1)
         leave_in_flight(false, t + 2 < KT);                    //   W(t+1) and A(t+1) of this wave have landed
         phase_end();
+        if (stamp) tsp[3] = __builtin_readcyclecounter();
         if (t + 1 < KT) read_unit((t + 1) & 1, w3n, K0{});     // O_(t,1)
         if (t + 2 < KT) issue_a(t & 1, t + 2);
         all_frags_read();
         phase_end();
+        if (stamp) tsp[4] = __builtin_readcyclecounter();
         w3 = w3n;
       }
     } else {
@@ -346,20 +353,26 @@ __global__ void __launch_bounds__(64 * WM * WN)
       for (int t = 0; t < KT; ++t) {
         const int w3n = w3 == 2 ? 0 : w3 + 1;
         const int w3p = w3 == 0 ? 2 : w3 - 1;
+        const bool stamp = (ABL & 16) && t == 8;
+        if (stamp) tsp[0] = __builtin_readcyclecounter();
         if (t > 0) leave_in_flight(false, t + 1 < KT);         // E_(t,0): own A(t) has landed (W(t+1) may fly)
         read_unit(t & 1, w3, K0{});
         if (t > 0 && t + 1 < KT) issue_a((t + 1) & 1, t + 1);
         all_frags_read();
+        if (stamp) tsp[1] = __builtin_readcyclecounter();      //   (before the barrier: own work of the phase)
         phase_end();
         mfma_unit();                                           // O_(t,0)
         phase_end();
+        if (stamp) tsp[2] = __builtin_readcyclecounter();
         read_unit(t & 1, w3, K1{});                            // E_(t,1)
         if (t + 2 < KT) issue_w(w3p, t + 2);
         all_frags_read();
         leave_in_flight(t > 0 && t + 1 < KT, t + 2 < KT);      //   this wave's W(t+1) pieces have landed
+        if (stamp) tsp[3] = __builtin_readcyclecounter();
         phase_end();
         mfma_unit();                                           // O_(t,1)
         phase_end();
+        if (stamp) tsp[4] = __builtin_readcyclecounter();
         w3 = w3n;
       }
     }
@@ -552,8 +565,9 @@ __global__ void __launch_bounds__(64 * WM * WN)
   if constexpr (ABL & 16) {
     if (args.dbg_ts != nullptr && lane == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned long long* d = args.dbg_ts + ((size_t)blockIdx.x * NW + wave) * 4;
+      unsigned long long* d = args.dbg_ts + ((size_t)blockIdx.x * NW + wave) * 16;
       d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
+      for (int q = 0; q < 5; ++q) d[4 + q] = tsp[q];
     }
   }
 }

@@ -204,15 +204,15 @@ int main(int argc, char** argv) {
     printf("prof %s dbg=%d %dx%dx%d od=%d: %.2f us\n", mq_gemm_variant_name(v), dbg, M, N, K, od, t * 1e3);
     if ((dbg & 16) && mq_gemm_set_debug_buffer_) {   // s_memtime stamps: [block][wave][t0, loop start, loop end, end]
       const int nb = ((M + 255) / 256) * ((N + 175) / 176), nw = 8;
-      unsigned long long* d = dmalloc<unsigned long long>((size_t)nb * nw * 4);
-      HIPCHK(hipMemset(d, 0, (size_t)nb * nw * 4 * 8));
+      unsigned long long* d = dmalloc<unsigned long long>((size_t)nb * nw * 16);
+      HIPCHK(hipMemset(d, 0, (size_t)nb * nw * 16 * 8));
       mq_gemm_set_debug_buffer_(d);
       time_variant(p, v, od, true, 3);
-      std::vector<unsigned long long> h((size_t)nb * nw * 4);
+      std::vector<unsigned long long> h((size_t)nb * nw * 16);
       HIPCHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
       double pro = 0, loop = 0, epi = 0, tot = 0; unsigned long long gmin = ~0ull, gmax = 0;
       for (int i = 0; i < nb * nw; ++i) {
-        const unsigned long long* q = &h[(size_t)i * 4];
+        const unsigned long long* q = &h[(size_t)i * 16];
         pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); tot += (double)(q[3] - q[0]);
         gmin = std::min(gmin, q[0]); gmax = std::max(gmax, q[3]);
       }
@@ -220,7 +220,7 @@ int main(int argc, char** argv) {
       printf("stamps (cycles, mean over %d waves): prologue %.0f  loop %.0f (%.0f per K=128 stage)  epilogue %.0f  total %.0f; first start -> last end %llu\n",
              nb * nw, pro / n2, loop / n2, loop / n2 / (K / 128), epi / n2, tot / n2, gmax - gmin);
       // per-group breakdown for block 0
-      for (int w = 0; w < nw; ++w) { const unsigned long long* q = &h[(size_t)w * 4]; printf("  blk0 wave%d: pro %llu loop %llu epi %llu\n", w, q[1]-q[0], q[2]-q[1], q[3]-q[2]); }
+      for (int b : {0, 100}) for (int w = 0; w < nw; ++w) { const unsigned long long* q = &h[((size_t)b * nw + w) * 16]; printf("  blk%d wave%d: pro %llu loop %llu epi %llu | stage8: %llu %llu %llu %llu\n", b, w, q[1]-q[0], q[2]-q[1], q[3]-q[2], q[5]-q[4], q[6]-q[5], q[7]-q[6], q[8]-q[7]); }
       mq_gemm_set_debug_buffer_(nullptr);
     }
     return 0;
