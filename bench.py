@@ -245,6 +245,46 @@ def cpu_baseline():
                       f"fake-quant) at M={M},K={K},N={N}; numpy elementwise on 1 thread, OpenBLAS GEMM on {blas_threads}"}
 
 
+def bench_decode(dev, tokens=20):
+    """TinyLlama-1.1B decode, linears only: per layer quantize(x) -> GEMV qkv (2048->2560) -> quantize -> GEMV o
+    (2048->2048) -> quantize -> GEMV w1|w3 (2048->11264) -> quantize -> GEMV w2 (5632->2048), 22 layers with their own
+    int8 weights (0.97 GB streamed per token), one hipGraph per token.  Attention, norms and sampling are outside the
+    hot path of this repository and are not included."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_F32, MQ_I8
+    g = torch.Generator(device="cpu").manual_seed(7)
+    shapes = [(2048, 2560), (2048, 2048), (2048, 11264), (5632, 2048)]      # (K, N) per layer
+    layers = []
+    aq = mq.Quantizer(mq.QuantConfig(bitwidth=8)); aq.set_scale_offset_from_minmax(-4.0, 4.0, "buffer", dev)
+    oq = mq.Quantizer(mq.QuantConfig(bitwidth=8)); oq.set_scale_offset_from_minmax(-4.0, 4.0, "buffer", dev)
+    for _ in range(22):
+        lw = []
+        for Kk, Nn in shapes:
+            w8 = torch.randint(-128, 128, (Nn, Kk), dtype=torch.int8, generator=g).to(dev)
+            colsum = w8.to(torch.int32).sum(1).to(torch.int32)
+            wscale = torch.full((1,), 2e-4, device=dev); woff = torch.full((1,), 128.0, device=dev)
+            alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, 128, wscale, woff, 128, colsum, Kk)
+            lw.append((w8, alpha, wzp, ct, torch.empty(1, Nn, device=dev)))
+        layers.append(lw)
+    xs = {2048: torch.randn(1, 2048, device=dev), 5632: torch.randn(1, 5632, device=dev)}
+    a8 = {k: torch.empty(1, k, dtype=torch.int8, device=dev) for k in xs}
+    rs = {k: torch.empty(1, dtype=torch.int32, device=dev) for k in xs}
+    from mobilequant_amd import _lib
+    st = lambda: torch.cuda.current_stream().cuda_stream
+
+    def token():
+        for lw in layers:
+            for (Kk, Nn), (w8, alpha, wzp, ct, out) in zip(shapes, lw):
+                ops.int8_linear_f32in(xs[Kk], aq.scale, aq.offset, 0.0, 255.0, 128, w8, alpha, wzp, ct, None, out_scale=oq.scale,
+                                      out_offset=oq.offset, out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_F32, out=out)
+    t = event_time(token, 1)      # graph of one token, best of 5 replays
+    wbytes = 22 * sum(Kk * Nn for Kk, Nn in shapes)
+    return {"decode_tok_s": round(1.0 / t, 1), "ms_per_token": round(t * 1e3, 4), "weight_GB_per_token": round(wbytes / 1e9, 4),
+            "achieved_GBps": round(wbytes / t / 1e9, 1), "peak_GBps": 8000.0, "kernels_per_token": 22 * 4,
+            "scope": "linears only (22 layers x [qkv, o, w1|w3, w2] W8A8 GEMV with the activation quantize fused in), batch 1, hipGraph"}
+
+
 def bench_calibration(args, rank, world, dev):
     """Data-parallel activation-range calibration over a TinyLlama-shaped MLP block stack (synthetic)."""
     import torch.nn as nn
@@ -305,7 +345,7 @@ def main():
         value = world * OPS_PER_STEP / sec / 1e12
 
         extras = {}
-        roof = cpu = None
+        roof = cpu = decode = None
         if rank == 0:
             # dominant kernel alone, HIP events on its stream
             t_gemm = event_time(step.gemm, 50)
@@ -340,6 +380,7 @@ def main():
             tm = event_time(lambda: ql(x3), 30)
             extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
                                             "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
+            decode = bench_decode(dev)
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline()
 
@@ -355,8 +396,8 @@ def main():
                        "M": M, "K": K, "N": N, "parallelism": f"replicas x{world}", "graph_steps": 0 if args.no_graph else GRAPH_STEPS,
                        "schedule": "quantize(batch i+1) overlapped with GEMM(batch i) on a second stream" if pipelined else "serial",
                        "pct_int8_mfma_peak": round(100 * value / world / INT8_MFMA_PEAK_TOPS, 2),
-                       "decode_tok_s": None, "device": info},
-            "roofline": roof, "cpu_baseline": cpu, "variants": extras,
+                       "decode_tok_s": decode["decode_tok_s"] if decode else None, "device": info},
+            "roofline": roof, "cpu_baseline": cpu, "decode": decode, "variants": extras,
         }
         print(json.dumps(line))
     if world > 1:

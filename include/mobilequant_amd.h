@@ -127,6 +127,17 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
                    const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
                    mq_stream_t stream);
 
+/* Decode shapes (M <= 8 tokens, M*K < 64 KiB, K % 256 == 0): the activation quantizer (qmodule.py:349-351) fused
+ * into the weight-streaming GEMV -- x is the fp32 [M,K] activation, quantised on the fly to its grid
+ * (a_scale/a_offset: 1 element; a_shift as in mq_quantize) with the row sums reduced in LDS; alpha / w_zp /
+ * col_term are the vectors mq_linear_epilogue_prepare made for that same grid.  Other shapes: MQ_EUNSUPPORTED
+ * (use mq_quantize + mq_w8a8_linear; mq_w8a8_linear itself switches to the GEMV kernel for M <= 8). */
+int mq_w8a8_linear_f32in(const float* x, const float* a_scale, const float* a_offset, float a_qmin,
+                         float a_qmax, int a_shift, const int8_t* w, int64_t M, int64_t N, int64_t K,
+                         const float* alpha, const int32_t* w_zp, const int32_t* col_term,
+                         const float* bias, const float* out_scale, const float* out_offset,
+                         float out_qmin, float out_qmax, void* out, int out_dtype, mq_stream_t stream);
+
 /* W4A8: weights as packed 4-bit indices.  mq_pack_w4 packs an [N,K] tensor of UNSIGNED nibbles
  * (index - qmin, 0..15, one per byte) two per byte, K-interleaved in blocks of 32: byte j (0..15)
  * of each 16-byte group holds element j in its low nibble and element j+16 in its high nibble.

@@ -8,6 +8,8 @@
 // -fhip-fp32-correctly-rounded-divide-sqrt (hipcc default, stated explicitly in build.py).
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "mq_common.h"
 
 #pragma clang fp contract(off)
@@ -203,6 +205,50 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
   }
 }
 
+// fp32 -> 1-byte indices, wave-per-row: a lane converts 16 consecutive elements (four independent 16-byte
+// loads in flight, one 16-byte store), so a wave instruction stores 1 KiB contiguous; the row sum is a
+// wave reduction (no LDS, no barrier).  Needs cols % 16 == 0 and 16-byte aligned rows.
+template <typename QT, bool PER_ROW>
+__global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float* __restrict__ x, QT* __restrict__ q,
+                                                                    int64_t rows, int64_t cols,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ offset, float qmin,
+                                                                    float qmax, int shift, int32_t* __restrict__ row_sum) {
+  static_assert(sizeof(QT) == 1, "one byte per index");
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < rows; row += nwaves) {
+    const float s = scale[PER_ROW ? row : 0];
+    const float o = offset[PER_ROW ? row : 0];
+    const float* xr = x + row * cols;
+    QT* qr = q + row * cols;
+    int acc = 0;
+    for (int64_t c = (int64_t)lane * 16; c < cols; c += 1024) {
+      const float4* p = reinterpret_cast<const float4*>(xr + c);
+      const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+      const float f[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+      uint32_t w[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int st_v = static_cast<int>(q_index(f[d * 4 + e], s, o, qmin, qmax)) - shift;
+          acc += st_v;
+          pk |= (static_cast<uint32_t>(st_v) & 0xffu) << (8 * e);
+        }
+        w[d] = pk;
+      }
+      *reinterpret_cast<uint4*>(qr + c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (row_sum != nullptr) {
+      acc = wave_sum(acc);
+      if (lane == 0) row_sum[row] = acc;
+    }
+  }
+}
+
 // ---- epilogue vectors of one QLinear ------------------------------------------------------------
 __global__ void linear_epilogue_prepare_kernel(const float* __restrict__ a_scale, const float* __restrict__ a_offset,
                                                int a_shift, const float* __restrict__ w_scale,
@@ -268,6 +314,20 @@ static int launch_quantize(const T* x, QT* q, int64_t rows, int64_t cols, const 
                            bool per_row, float qmin, float qmax, int shift, int32_t* row_sum, hipStream_t st) {
   constexpr int VN = Vec16<T>::N;
   const int vec_ok = aligned(x, 16) && aligned(q, sizeof(QT) * VN) && (cols % VN == 0);
+  if constexpr (std::is_same<T, float>::value && sizeof(QT) == 1) {
+    if (aligned(x, 16) && aligned(q, 16) && cols % 16 == 0 && cols >= 256) {
+      int64_t blocks = (rows + 3) / 4;
+      if (blocks > 256 * 16) blocks = 256 * 16;           // 16 workgroups per CU, wave-stride over the rest
+      if (per_row)
+        quantize_rows_f32_b16_kernel<QT, true><<<(unsigned)blocks, 256, 0, st>>>(x, q, rows, cols, scale, offset, qmin,
+                                                                                 qmax, shift, row_sum);
+      else
+        quantize_rows_f32_b16_kernel<QT, false><<<(unsigned)blocks, 256, 0, st>>>(x, q, rows, cols, scale, offset, qmin,
+                                                                                  qmax, shift, row_sum);
+      MQ_LAUNCH_CHECK("mq_quantize");
+      return MQ_OK;
+    }
+  }
   if (per_row)
     quantize_rows_kernel<T, QT, true><<<(unsigned)rows, 256, 0, st>>>(x, q, cols, scale, offset, qmin, qmax, shift,
                                                                     row_sum, vec_ok);

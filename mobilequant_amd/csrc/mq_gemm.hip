@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "mq_common.h"
+#include "mq_gemv.h"
 
 namespace mq {
 
@@ -747,9 +748,40 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
   int rc = check_common("mq_w8a8_linear", a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
                         out, 1);
   if (rc != MQ_OK) return rc;
+  if (M <= 8 && M * K <= 64 * 1024 && g_forced_variant < 0) {   // decode shapes: weight-streaming GEMV (mq_gemv.hip)
+    if (out_scale == nullptr && out_dtype != MQ_F32 && out_dtype != MQ_F16) {
+      set_error("mq_w8a8_linear: integer out_dtype %d needs an output quantizer", out_dtype);
+      return MQ_EINVAL;
+    }
+    GemvArgs v{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
+               out_qmin, out_qmax, out, out_dtype, nullptr, nullptr, nullptr, 0.f, 0.f, 0};
+    return run_gemv(v, as_stream(stream));
+  }
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
              out_qmin, out_qmax, out, out_dtype, 0, 0, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_f32in(const float* x, const float* a_scale, const float* a_offset, float a_qmin, float a_qmax,
+                         int a_shift, const int8_t* w, int64_t M, int64_t N, int64_t K, const float* alpha,
+                         const int32_t* w_zp, const int32_t* col_term, const float* bias, const float* out_scale,
+                         const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
+                         mq_stream_t stream) {
+  int rc = check_common("mq_w8a8_linear_f32in", x, w, M, N, K, nullptr, alpha, w_zp, col_term, bias, out_scale,
+                        out_offset, out, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(a_scale && a_offset, "mq_w8a8_linear_f32in: null activation grid");
+  if (!(M <= 8 && M * K <= 64 * 1024 - 64 && K % 256 == 0)) {
+    set_error("mq_w8a8_linear_f32in: decode shapes only (M <= 8, M*K < 64 KiB, K %% 256 == 0); use mq_quantize + mq_w8a8_linear");
+    return MQ_EUNSUPPORTED;
+  }
+  if (out_scale == nullptr && out_dtype != MQ_F32 && out_dtype != MQ_F16) {
+    set_error("mq_w8a8_linear_f32in: integer out_dtype %d needs an output quantizer", out_dtype);
+    return MQ_EINVAL;
+  }
+  GemvArgs v{nullptr, w, (int)M, (int)N, (int)K, nullptr, alpha, w_zp, col_term, bias, out_scale, out_offset,
+             out_qmin, out_qmax, out, out_dtype, x, a_scale, a_offset, a_qmin, a_qmax, a_shift};
+  return run_gemv(v, as_stream(stream));
 }
 
 int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,

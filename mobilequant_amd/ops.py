@@ -177,6 +177,32 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     return out
 
 
+def decode_shape(M: int, K: int) -> bool:
+    """Shapes mq_w8a8_linear_f32in accepts (activation quantize fused into the weight-streaming GEMV)."""
+    return M <= 8 and M * K <= 64 * 1024 - 64 and K % 256 == 0
+
+
+def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qmax: float, a_shift: int, w_q: torch.Tensor,
+                      alpha, w_zp, col_term, bias=None, *, out_scale=None, out_offset=None, out_qmin: float = 0.0,
+                      out_qmax: float = 255.0, out_dtype: int = MQ_F32, out: Optional[torch.Tensor] = None):
+    """Decode-shape QLinear in ONE kernel: fp32 activations are quantised inside the GEMV (M <= 8)."""
+    x2d = _f32(_dev(x2d, "x"), "x")
+    M, K = x2d.shape
+    N = w_q.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=_OUT_TORCH[out_dtype], device=x2d.device)
+    sa, oa = _f32(a_scale, "a_scale"), _f32(a_offset, "a_offset")
+    b = _f32(bias, "bias") if bias is not None else None
+    os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
+    oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
+    _lib.call("mq_w8a8_linear_f32in", x2d.data_ptr(), sa.data_ptr(), oa.data_ptr(), float(a_qmin), float(a_qmax), int(a_shift),
+              w_q.data_ptr(), M, N, K, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
+              b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
+              oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype,
+              _stream())
+    return out
+
+
 def pack_w4(nibbles: torch.Tensor) -> torch.Tensor:
     """[N,K] uint8 nibbles (0..15) -> [N,K/2] packed (layout: include/mobilequant_amd.h, mq_pack_w4)."""
     nibbles = _dev(nibbles, "nibbles").contiguous()

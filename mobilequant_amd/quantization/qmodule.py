@@ -397,7 +397,11 @@ class QLinear(nn.Linear, _QuantizedOp):
         K, N = weight.shape[1], weight.shape[0]
         if grid.scale.device != x.device:
             grid.scale.data, grid.offset.data = grid.scale.to(x.device), grid.offset.to(x.device)
-        a_q, a_rs, a_shift = grid.quantize_to_int(x.reshape(-1, K), MQ_I8, want_row_sum=True)
+        x2d = x.reshape(-1, K)
+        decode = (not plan["w4"]) and x.dtype == torch.float32 and ops.decode_shape(x2d.shape[0], K)
+        a_shift = 128 if grid.qmax > 127 else 0
+        if not decode:
+            a_q, a_rs, a_shift = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
         epi_key = (grid.scale.data_ptr(), grid.scale._version, grid.offset._version, a_shift)
         if plan["epi_key"] != epi_key:
             plan["alpha"], plan["w_zp"], plan["col_term"] = ops.linear_epilogue_prepare(
@@ -407,6 +411,13 @@ class QLinear(nn.Linear, _QuantizedOp):
         fused = oq is not None and not oq.bypassed()
         if fused and oq.scale.device != x.device:
             oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
+        if decode:   # M <= 8: activation quantize fused into the weight-streaming GEMV (one launch)
+            out = ops.int8_linear_f32in(
+                x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift, plan["w"], plan["alpha"],
+                plan["w_zp"], plan["col_term"], bias, out_scale=oq.scale.detach() if fused else None,
+                out_offset=oq.offset.detach() if fused else None, out_qmin=oq.qmin if fused else 0.0,
+                out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32)
+            return out.reshape(*x.shape[:-1], N)
         out = ops.int8_linear(
             a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
             out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,

@@ -385,6 +385,54 @@ def test_int8_gemm_fused_output_quantizer(dev):
             assert np.array_equal(gh, gf.astype(np.float16))
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+def test_decode_gemv_path_exact(dev, M):
+    """M <= 8 takes the weight-streaming GEMV kernel (mq_gemv.hip): same exact contraction and epilogue."""
+    from mobilequant_amd._lib import MQ_U8
+    rng = np.random.default_rng(100 + M)
+    for N, K in ((2048, 2048), (256, 2048), (2048, 5632), (180, 256)):
+        qa, qw, za, zw, sa, sw, bias = _int_problem(rng, M, N, K, per_row=(N != 256))
+        _, want = O.qlinear_int_exact(qa, za, sa, qw, zw, sw, bias)
+        got = _run_int8(dev, qa, qw, za, zw, sa, sw, bias, 128).detach().cpu().numpy()
+        assert np.array_equal(bits(got), bits(want)), (M, N, K)
+        so, oo, qmin, qmax = O.scale_offset_from_min_max(float(want.min()), float(want.max()), 8, False)
+        kw = dict(out_scale=T(np.array([so], F32), dev), out_offset=T(np.array([oo], F32), dev), out_qmin=qmin, out_qmax=qmax)
+        gq = _run_int8(dev, qa, qw, za, zw, sa, sw, bias, 128, out_dtype=MQ_U8, **kw).detach().cpu().numpy().astype(F32)
+        d = np.abs(gq - O.quantize_index(want, so, oo, qmin, qmax))
+        assert d.max() <= 1 and (d == 0).mean() > 0.995, (M, N, K, d.max())
+
+
+def test_decode_fused_quantize_gemv(dev):
+    """mq_w8a8_linear_f32in == mq_quantize + mq_w8a8_linear, bit for bit (same indices, same row sums, same epilogue)."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_I8
+    rng = np.random.default_rng(77)
+    for M, N, K in ((1, 2048, 2048), (4, 256, 2048), (8, 2048, 5632), (3, 180, 256)):
+        x = T(rng.standard_normal((M, K), dtype=F32) * 2, dev)
+        w8 = T(rng.integers(-128, 128, size=(N, K)).astype(np.int8), dev)
+        aq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+        aq.set_scale_offset_from_minmax(-5.0, 6.0, "buffer", dev)
+        colsum = w8.to(torch.int32).sum(1).to(torch.int32)
+        wsc, wof = T(rng.random(N, dtype=F32) * F32(1e-3) + F32(1e-4), dev), T(rng.integers(0, 256, N).astype(F32), dev)
+        alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, 128, wsc, wof, 128, colsum, K)
+        bias = T(rng.standard_normal(N, dtype=F32), dev)
+        a8, rs, shift = aq.quantize_to_int(x, MQ_I8, want_row_sum=True)
+        ref = ops.int8_linear(a8, w8, rs, alpha, wzp, ct, bias)
+        got = ops.int8_linear_f32in(x, aq.scale, aq.offset, 0.0, 255.0, 128, w8, alpha, wzp, ct, bias)
+        assert torch.equal(ref, got), (M, N, K)
+    # and through the module: a [1, 1, K] decode input takes the fused path and matches the prefill path's row
+    lin = torch.nn.Linear(2048, 512, bias=False).to(dev)
+    a8c = mq.QuantConfig(bitwidth=8)
+    ql = mq.QLinear.from_float(lin, a8c, a8c, a8c).requires_grad_(False)
+    xs = torch.randn(1, 64, 2048, device=dev)
+    ql.set_scale_offset({"input": [float(xs.min()), float(xs.max())], "output": [-3.0, 3.0]}, "buffer")
+    with torch.no_grad():
+        full = ql(xs)
+        one = ql(xs[:, 5:6, :])
+    assert torch.equal(one, full[:, 5:6, :])
+
+
 def test_w4a8_gemm_and_packing(dev):
     from mobilequant_amd import ops
     rng = np.random.default_rng(11)
