@@ -51,6 +51,18 @@ __global__ void minmax_init_kernel(float* mn, float* mx, int64_t n) {
 // canonicalise -0.0 -> +0.0 so the bit-pattern atomics treat the two zeros alike
 __device__ __forceinline__ float canon(float v) { return v + 0.0f; }
 
+// Same-address atomics serialise at the L2 (~12 ns each): with 1-2 k workgroups committing to ONE running
+// [min, max] the atomics alone took longer than the streaming pass.  A relaxed agent-scope read filters them:
+// only a workgroup that would actually improve the statistic issues the atomic (expected O(log #workgroups)
+// per launch, and none at all once a calibration statistic has settled).  A stale read can only cause a
+// redundant atomic, never a wrong result.
+__device__ __forceinline__ void commit_min(float* addr, float v) {
+  if (v < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_min_f32(addr, v);
+}
+__device__ __forceinline__ void commit_max(float* addr, float v) {
+  if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_f32(addr, v);
+}
+
 __device__ __forceinline__ void block_commit(float lo, float hi, float* mn, float* mx) {
   __shared__ float s_lo[4], s_hi[4];
   lo = wave_min(lo);
@@ -65,8 +77,8 @@ __device__ __forceinline__ void block_commit(float lo, float hi, float* mn, floa
     lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
     hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
     if (lo <= hi) {   // false only when this workgroup saw no element
-      atomic_min_f32(mn, canon(lo));
-      atomic_max_f32(mx, canon(hi));
+      commit_min(mn, canon(lo));
+      commit_max(mx, canon(hi));
     }
   }
 }
@@ -177,8 +189,8 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(const T* __restrict__ 
       float l = fminf(fminf(s_lo[0][i], s_lo[1][i]), fminf(s_lo[2][i], s_lo[3][i]));
       float h = fmaxf(fmaxf(s_hi[0][i], s_hi[1][i]), fmaxf(s_hi[2][i], s_hi[3][i]));
       if (l <= h) {
-        atomic_min_f32(mn + c, canon(l));
-        atomic_max_f32(mx + c, canon(h));
+        commit_min(mn + c, canon(l));
+        commit_max(mx + c, canon(h));
       }
     }
   }
@@ -200,8 +212,8 @@ __global__ void __launch_bounds__(256) minmax_cols_scalar_kernel(const T* __rest
     hi = fmaxf(hi, f);
   }
   if (lo <= hi) {
-    atomic_min_f32(mn + c, canon(lo));
-    atomic_max_f32(mx + c, canon(hi));
+    commit_min(mn + c, canon(lo));
+    commit_max(mx + c, canon(hi));
   }
 }
 
