@@ -91,6 +91,18 @@ int mq_minmax_cols(const void* x, int dtype, int64_t rows, int64_t cols, float* 
 int mq_fake_quant(const void* x, void* y, int dtype, int64_t rows, int64_t cols, const float* scale,
                   const float* offset, int64_t n_scale, float qmin, float qmax, mq_stream_t stream);
 
+/* Backward of the above for the PTQ training loops (mobilellm/quantization/algorithm.py:381, :587), fp32:
+ * the gradients torch autograd derives for qmodule.py:286-290 with round_ste (qmodule.py:17-21) -- identity
+ * through the rounding, clamp passes the gradient where qmin <= q <= qmax:
+ *   grad_x = (g*s)/s inside, 0 clamped;  grad_scale += g*(r - x/s) inside, g*(clamp(q) - o) clamped;
+ *   grad_offset += 0 inside, -g*s clamped     (r = rint(x/s), q = r + o)
+ * grad_scale / grad_offset ([n_scale]) must be ZERO-INITIALISED by the caller; they are accumulated with float
+ * atomics (summation order is not deterministic; tolerance 1e-5 relative). */
+int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, int64_t cols,
+                           const float* scale, const float* offset, int64_t n_scale, float qmin,
+                           float qmax, float* grad_x, float* grad_scale, float* grad_offset,
+                           mq_stream_t stream);
+
 /* The integer index itself (qmodule.py:286-287) written as integers instead of being dequantised.
  * q_dtype MQ_I8: i8 storage (index - shift, see top);  MQ_U8 / MQ_I16 / MQ_U16 / MQ_I32: the plain
  * index.  row_sum (nullable, [rows] int32): sum over the row of the STORED values -- the

@@ -249,6 +249,64 @@ __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float*
   }
 }
 
+// ---- a5 backward: straight-through gradients of the fake-quant (training loops, algorithm.py:381/:587) ----
+// One workgroup per row (per-row grids) or a grid-stride slab (per-tensor); grad_scale / grad_offset are
+// accumulated with float atomics into zero-initialised outputs (one pair of atomics per workgroup).
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <bool PER_ROW>
+__global__ void __launch_bounds__(256) fake_quant_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                             int64_t rows, int64_t cols, const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, float qmin, float qmax,
+                                                             float* __restrict__ gx, float* __restrict__ gscale,
+                                                             float* __restrict__ goffset) {
+  __shared__ float s_gs[4], s_go[4];
+  float acc_s = 0.f, acc_o = 0.f;
+  int64_t begin, end, step;
+  float s, o;
+  if (PER_ROW) {             // blockIdx.x = row
+    begin = (int64_t)blockIdx.x * cols + threadIdx.x;
+    end = (int64_t)(blockIdx.x + 1) * cols;
+    step = 256;
+    s = scale[blockIdx.x];
+    o = offset[blockIdx.x];
+  } else {
+    begin = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    end = rows * cols;
+    step = (int64_t)gridDim.x * 256;
+    s = scale[0];
+    o = offset[0];
+  }
+  for (int64_t i = begin; i < end; i += step) {
+    const float xv = x[i], g = gy[i];
+    const float t = __fdiv_rn(xv, s);
+    const float r = rintf(t);
+    const float q = __fadd_rn(r, o);
+    const bool inside = q >= qmin && q <= qmax;
+    const float qc = fminf(fmaxf(q, qmin), qmax);
+    gx[i] = inside ? __fdiv_rn(__fmul_rn(g, s), s) : 0.f;          // (g*s) * mask / s, as autograd chains it
+    acc_s += inside ? g * (r - t) : g * (qc - o);
+    acc_o += inside ? 0.f : -g * s;
+  }
+  acc_s = wave_sum_f(acc_s);
+  acc_o = wave_sum_f(acc_o);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_gs[w] = acc_s;
+    s_go[w] = acc_o;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int slot = PER_ROW ? blockIdx.x : 0;
+    atomicAdd(gscale + slot, (s_gs[0] + s_gs[1]) + (s_gs[2] + s_gs[3]));
+    atomicAdd(goffset + slot, (s_go[0] + s_go[1]) + (s_go[2] + s_go[3]));
+  }
+}
+
 // ---- epilogue vectors of one QLinear ------------------------------------------------------------
 __global__ void linear_epilogue_prepare_kernel(const float* __restrict__ a_scale, const float* __restrict__ a_offset,
                                                int a_shift, const float* __restrict__ w_scale,
@@ -391,6 +449,27 @@ int mq_fake_quant(const void* x, void* y, int dtype, int64_t rows, int64_t cols,
                                      qmin, qmax, as_stream(stream));
   set_error("mq_fake_quant: dtype %d not supported (MQ_F32, MQ_F16)", dtype);
   return MQ_EUNSUPPORTED;
+}
+
+int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, int64_t cols, const float* scale,
+                           const float* offset, int64_t n_scale, float qmin, float qmax, float* grad_x,
+                           float* grad_scale, float* grad_offset, mq_stream_t stream) {
+  MQ_REQUIRE(x && grad_y && scale && offset && grad_x && grad_scale && grad_offset, "mq_fake_quant_backward: null pointer");
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && (n_scale == 1 || n_scale == rows), "mq_fake_quant_backward: bad shape");
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(rows < (int64_t)0x7fffffff, "mq_fake_quant_backward: too many rows");
+  if (n_scale == rows && rows > 1) {
+    fake_quant_bwd_kernel<true><<<(unsigned)rows, 256, 0, as_stream(stream)>>>(x, grad_y, rows, cols, scale, offset, qmin,
+                                                                             qmax, grad_x, grad_scale, grad_offset);
+  } else {
+    int64_t g = (rows * cols + 1023) / 1024;
+    if (g < 1) g = 1;
+    if (g > 512) g = 512;     // 512 pairs of same-address atomics at most
+    fake_quant_bwd_kernel<false><<<(unsigned)g, 256, 0, as_stream(stream)>>>(x, grad_y, rows, cols, scale, offset, qmin,
+                                                                           qmax, grad_x, grad_scale, grad_offset);
+  }
+  MQ_LAUNCH_CHECK("mq_fake_quant_backward");
+  return MQ_OK;
 }
 
 int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,

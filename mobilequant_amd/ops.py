@@ -119,6 +119,20 @@ def fake_quant(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin:
     return y
 
 
+def fake_quant_backward(x: torch.Tensor, grad_y: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float,
+                        qmax: float):
+    """Straight-through gradients of fake_quant: (grad_x, grad_scale, grad_offset), fp32."""
+    x = _f32(x, "x")
+    g = _f32(grad_y, "grad_y")
+    s, o = _f32(scale, "scale"), _f32(offset, "offset")
+    rows, cols = _rows_cols(x, s.numel())
+    gx = torch.empty_like(x)
+    gs, go = torch.zeros_like(s), torch.zeros_like(o)
+    _lib.call("mq_fake_quant_backward", x.data_ptr(), g.data_ptr(), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(),
+              float(qmin), float(qmax), gx.data_ptr(), gs.data_ptr(), go.data_ptr(), _stream())
+    return gx, gs, go
+
+
 def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, *,
              q_dtype: int = MQ_I8, shift: int = 0, rows: Optional[int] = None, want_row_sum: bool = False):
     """Integer indices (qmodule.py:286-287) as integers; optional per-row sums of the stored values.

@@ -121,12 +121,12 @@ class QuantConfig:
 
 # ------------------------------------------------------------------------------------------------
 class _FakeQuantFn(torch.autograd.Function):
-    """HIP fake-quant with a straight-through backward.
+    """HIP fake-quant with the reference's straight-through backward.
 
-    Forward is the fused kernel.  Backward (needed by the reference's PTQ training loops,
-    algorithm.py:381/:587) passes the gradient where the index was not clamped and accumulates the
-    LSQ-style gradients of scale and offset; it is evaluated by a HIP kernel as well
-    (``mq_fake_quant_backward``) once that row of SURVEY 8f lands -- until then it raises.
+    The reference trains through ``Quantizer.forward`` (algorithm.py:381 / :587): ``round_ste`` passes the
+    gradient through the rounding, the clamp masks it, and ``scale`` / ``offset`` are learnable.  Both
+    directions are HIP kernels (``mq_fake_quant`` / ``mq_fake_quant_backward``); gradients match torch
+    autograd of qmodule.py:286-290 (tests: golden ``quantizer_grads.npz``).  fp32 only.
     """
 
     @staticmethod
@@ -136,10 +136,14 @@ class _FakeQuantFn(torch.autograd.Function):
         return ops.fake_quant(x, scale.detach(), offset.detach(), qmin, qmax)
 
     @staticmethod
-    def backward(ctx, grad_out):  # pragma: no cover - exercised on GPU only
-        raise NotImplementedError(
-            "mobilequant_amd: backward through the HIP fake-quant kernel is not built yet (SURVEY 8f rank 3); "
-            "run the quantized forward under torch.no_grad()")
+    def backward(ctx, grad_out):
+        x, scale, offset = ctx.saved_tensors
+        if x.dtype != torch.float32:
+            raise NotImplementedError("mobilequant_amd: fake-quant backward is implemented for float32 tensors")
+        gx, gs, go = ops.fake_quant_backward(x, grad_out, scale.detach(), offset.detach(), *ctx.limits)
+        gs = gs.reshape(scale.shape) if ctx.needs_input_grad[1] else None
+        go = go.reshape(offset.shape) if ctx.needs_input_grad[2] else None
+        return (gx if ctx.needs_input_grad[0] else None), gs, go, None, None
 
 
 def _needs_grad(*tensors) -> bool:

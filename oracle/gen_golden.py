@@ -11,6 +11,7 @@ transformers modules in this process before the import.
 Fixtures written (all data, no reference source text):
   scale_offset_grid.npz   a1/a2  compute_scale_offset_from_min_max / inverse over a grid
   quantizer_cases.npz     a5     Quantizer.forward outputs + integer indices, all qcfg combos
+  quantizer_grads.npz     a5     autograd of Quantizer.forward: grad x / scale / offset (STE + clamp mask)
   qlinear_cases.npz       a8     QLinear.forward on small shapes (W8A8 / W4A8 / per-channel / bias)
   calib_stream.npz        a12/a13 real get_act_range / get_act_scales on a toy module stack
   checksums.json          sha256 of full-size index tensors (inputs re-creatable from numpy seeds)
@@ -173,6 +174,35 @@ def gen_quantizer_cases():
         "f16_per_channel_preset")
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "quantizer_cases.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_quantizer_grads():
+    """Gradients the reference's autograd produces through Quantizer.forward (STE round, clamp mask,
+    learnable scale / offset): what algorithm.py's LRL / LWC training consumes."""
+    g = torch.Generator().manual_seed(99)
+    out, meta = {}, []
+    with torch.enable_grad():
+        for cid, (bits, sym, per_ch, rng) in enumerate([(8, False, False, (-2.0, 2.5)), (8, True, False, (-2.0, 2.5)),
+                                                        (4, False, False, (-1.0, 1.5)), (8, False, True, None),
+                                                        (4, True, True, None), (16, False, False, (-3.0, 3.0))]):
+            x = (torch.randn(12, 96, generator=g) * 1.5).requires_grad_(True)
+            gy = torch.randn(12, 96, generator=g)
+            qz = Q.Quantizer(Q.QuantConfig(bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch))
+            if rng is not None:
+                qz.set_scale_offset_from_minmax(rng[0], rng[1], "parameter")
+            else:
+                with torch.no_grad():
+                    qz(x.detach())                      # first forward caches the per-row grid as Parameters
+            y = qz(x)
+            (y * gy).sum().backward()
+            k = f"g{cid}"
+            out[k + "_x"], out[k + "_gy"], out[k + "_gx"] = npf(x), npf(gy), npf(x.grad)
+            out[k + "_scale"], out[k + "_offset"] = npf(qz.scale), npf(qz.offset)
+            out[k + "_gscale"], out[k + "_goffset"] = npf(qz.scale.grad), npf(qz.offset.grad)
+            meta.append(dict(id=k, bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch, qmin=qz.qmin, qmax=qz.qmax))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "quantizer_grads.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -446,6 +476,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_scale_offset_grid()
     gen_quantizer_cases()
+    gen_quantizer_grads()
     gen_qlinear_cases()
     gen_calib_stream()
     gen_checksums()

@@ -118,6 +118,35 @@ def fake_quant(x, scale, offset, qmin: int, qmax: int):
     return dequantize_index(quantize_index(x, scale, offset, qmin, qmax), scale, offset)
 
 
+def fake_quant_backward(x, grad_y, scale, offset, qmin: int, qmax: int):
+    """Gradients of ``y = (clamp(round_ste(x/s) + o, qmin, qmax) - o) * s`` (qmodule.py:17-21, :286-290) as
+    torch autograd derives them: round is a straight-through identity, clamp passes the gradient where
+    qmin <= q <= qmax.  With t = x/s, r = round(t), q = r + o:
+        dL/dx = (g*s)/s      inside | 0                 clamped
+        dL/ds = g * (r - t)  inside | g * (clamp(q)-o)  clamped
+        dL/do = 0            inside | -g * s            clamped
+    scale/offset gradients are summed over the elements that share them (all, or one row).
+    Returns (grad_x, grad_scale, grad_offset) with the shapes of x / scale / offset."""
+    x = np.asarray(x, dtype=F32)
+    g = np.asarray(grad_y, dtype=F32)
+    s = np.asarray(scale, dtype=F32)
+    o = np.asarray(offset, dtype=F32)
+    t = (x / s).astype(F32)
+    r = np.rint(t)
+    q = (r + o).astype(F32)
+    inside = (q >= F32(qmin)) & (q <= F32(qmax))
+    qc = np.clip(q, F32(qmin), F32(qmax))
+    # autograd chain for x: (g * s) through the clamp mask, then the division's grad / s  -- reproduced
+    # op for op so grad_x is bit-identical to torch's (it is g only up to one rounding)
+    gx = (np.where(inside, (g * s).astype(F32), F32(0)) / s).astype(F32)
+    gs_e = np.where(inside, g * (r - t), g * (qc - o)).astype(np.float64)
+    go_e = np.where(inside, 0.0, -g * s).astype(np.float64)
+    if s.size == 1:
+        return gx, np.asarray(gs_e.sum(), dtype=F32).reshape(s.shape), np.asarray(go_e.sum(), dtype=F32).reshape(o.shape)
+    axes = tuple(range(1, x.ndim))
+    return gx, gs_e.sum(axis=axes).astype(F32).reshape(s.shape), go_e.sum(axis=axes).astype(F32).reshape(o.shape)
+
+
 def fake_quant_f16_per_tensor(x, scale, offset, qmin: int, qmax: int):
     """fp16 input with 0-dim fp32 scale/offset: the RESULT dtype stays fp16 (SURVEY 8a' item 4).
 

@@ -80,6 +80,18 @@ def test_quantizer_cases_fp16():
     assert len(seen) == 3
 
 
+def test_quantizer_backward_matches_reference_autograd():
+    """fp32 sums in a different order than torch: tolerance 1e-5 relative on the scale/offset gradients;
+    grad_x is a masked copy and must be bit-exact."""
+    z = load_npz("quantizer_grads.npz")
+    for m in load_meta(z):
+        k = m["id"]
+        gx, gs, go = O.fake_quant_backward(z[k + "_x"], z[k + "_gy"], z[k + "_scale"], z[k + "_offset"], m["qmin"], m["qmax"])
+        assert np.array_equal(gx, z[k + "_gx"]), k
+        assert np.allclose(gs, z[k + "_gscale"], rtol=1e-5, atol=1e-4), (k, np.abs(gs - z[k + "_gscale"]).max())
+        assert np.allclose(go, z[k + "_goffset"], rtol=1e-5, atol=1e-5), k
+
+
 def _qlinear_oracle(m, z):
     k = m["id"]
     wq = O.QuantizerOracle(m["wbits"], -1, m["wsym"], m["wpc"])
