@@ -57,6 +57,10 @@ def _as_f32(v, device=None) -> torch.Tensor:
     return torch.tensor(v, dtype=torch.float32, device=device)
 
 
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def compute_min_max_from_tensor(x: torch.Tensor, is_per_channel: bool = False, group_size: int = -1):
     """amin/amax per tensor, per last-dim row (keepdim) or per group (reference: qmodule.py:26-34).
     Runs the single-pass HIP min/max kernels; results stay on the device."""
@@ -73,10 +77,12 @@ def compute_min_max_from_tensor(x: torch.Tensor, is_per_channel: bool = False, g
 def compute_scale_offset_from_min_max(min_val, max_val, bitwidth: int, is_symmetric: bool):
     """(scale, offset, alpha, beta, q_min, q_max) exactly as the reference returns them
     (qmodule.py:40-61).  Device tensors use the HIP kernel; host scalars / CPU tensors are tiny
-    configuration values and use the same fp32 expression on the host."""
+    configuration values and use the same fp32 expression on the host.  Ranges that carry a gradient
+    (learnable weight clipping: ``sigmoid(bound_factor) * max``, qmodule.py:271-273) are [N,1]-sized and keep
+    the differentiable torch expression so the factors train."""
     q_min, q_max = _grid_limits(bitwidth, is_symmetric)
     mn, mx = _as_f32(min_val), _as_f32(max_val)
-    if mn.is_cuda:
+    if mn.is_cuda and not _needs_grad(mn, mx):
         scale, offset = ops.scale_offset_from_minmax(mn, mx.to(mn.device), bitwidth, is_symmetric)
         alpha = torch.maximum(mn.abs(), mx.abs()) if is_symmetric else mx - mn
         beta = 0 if is_symmetric else mn
@@ -144,10 +150,6 @@ class _FakeQuantFn(torch.autograd.Function):
         gs = gs.reshape(scale.shape) if ctx.needs_input_grad[1] else None
         go = go.reshape(offset.shape) if ctx.needs_input_grad[2] else None
         return (gx if ctx.needs_input_grad[0] else None), gs, go, None, None
-
-
-def _needs_grad(*tensors) -> bool:
-    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 class Quantizer(nn.Module):

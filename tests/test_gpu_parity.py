@@ -126,6 +126,14 @@ def test_quantizer_backward_golden(dev):
         gs, go = qz.scale.grad.cpu().numpy(), qz.offset.grad.cpu().numpy()
         assert gs.shape == z[k + "_gscale"].shape and np.allclose(gs, z[k + "_gscale"], rtol=1e-5, atol=1e-4), k
         assert np.allclose(go, z[k + "_goffset"], rtol=1e-5, atol=1e-5), k
+    # learnable weight clipping: the bound factors receive gradients (qmodule.py:133-185)
+    w = torch.randn(16, 64, device=dev)
+    lq = mq.Quantizer(mq.QuantConfig(bitwidth=4, is_per_channel=True))
+    lq.enable_lwc(w)
+    yq = lq(w)
+    (yq - w).square().sum().backward()
+    assert lq.upbound_factor.grad is not None and lq.upbound_factor.grad.shape == (16, 1)
+    assert float(lq.upbound_factor.grad.abs().sum()) > 0 and float(lq.lowbound_factor.grad.abs().sum()) > 0
     # a QLinear with gradients required takes the simulated (differentiable) path end to end
     lin = torch.nn.Linear(256, 128).to(dev)
     a8 = mq.QuantConfig(bitwidth=8)
