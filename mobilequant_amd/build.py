@@ -21,7 +21,8 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmobilequant_amd.so")
 SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ABLATE = ["-DMQ_GEMM_ABLATE"] if os.environ.get("MQ_GEMM_ABLATE") else []
+ABLATE = (["-DMQ_GEMM_ABLATE"] if os.environ.get("MQ_GEMM_ABLATE") else []) + \
+    ([f"-DMQ_PP_PRIO={os.environ['MQ_PP_PRIO']}"] if os.environ.get("MQ_PP_PRIO") else [])
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -53,6 +53,10 @@ struct GemmArgs {
   unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
 };
 
+#ifndef MQ_PP_PRIO
+#define MQ_PP_PRIO 1   // 1: raise the MFMA-phase wave's priority; 0: none; 2: raise the READ/DMA-phase wave instead
+#endif
+
 constexpr int BK = 128;   // bytes of K per LDS stage (two MFMA k-steps of 64)
 
 // Bijective XCD-aware remap of the linear block id, then grouped (GROUP_M tall) tile order.
@@ -254,6 +258,9 @@ __global__ void __launch_bounds__(64 * WM * WN)
     (void)skip_reads;
     auto read_unit = [&](int abuf, int wbuf, auto ks_tag) {
       constexpr int ks = decltype(ks_tag)::value;
+#if MQ_PP_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
       if constexpr (ABL & 8) {   // ablation: no fragment reads (only the first unit is read so registers are defined)
         if (skip_reads) return;
         skip_reads = true;
@@ -270,12 +277,16 @@ __global__ void __launch_bounds__(64 * WM * WN)
     auto all_frags_read = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     auto mfma_unit = [&]() {
       if constexpr (ABL & 2) return;
+#if MQ_PP_PRIO == 1
       __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], xf[i], acc[i][j], 0, 0, 0);
+#if MQ_PP_PRIO == 1
       __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto issue_a = [&](int abuf, int kt) {
       if constexpr (ABL & 1) return;
@@ -304,7 +315,12 @@ __global__ void __launch_bounds__(64 * WM * WN)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     };
-    auto phase_end = []() { asm volatile("s_barrier" ::: "memory"); };
+    auto phase_end = []() {
+#if MQ_PP_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      asm volatile("s_barrier" ::: "memory");
+    };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
 
@@ -670,9 +686,9 @@ static int pick_variant(int M, int N) {
   // tiles N exactly and fills the chip in one round (TinyLlama / StableLM FFN: N = 5632 = 32 x 176);
   // otherwise pick the largest tile that still gives every CU a workgroup, else the small tiles.
   if (N % 176 == 0 && blocks(1) >= 192) return 7;   // ping-pong schedule (variant 1 = same tile, simple 2-stage loop)
-  const int order[] = {2, 5, 3, 6};
+  const int order[] = {2, 5, 3, 6};   // 256x256, 256x128, 128x128, 64x64
   for (int v : order)
-    if (blocks(v) >= 224) return v;
+    if (blocks(v) >= (v == 5 ? 160 : 224)) return v;   // 256x128 already wins at 160 workgroups (fused q|k|v, N = 2560)
   return blocks(3) >= 96 ? 3 : 6;
 }
 

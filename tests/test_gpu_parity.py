@@ -394,6 +394,22 @@ def test_int8_gemm_tinyllama_shapes_full_m(dev, N, K):
     assert np.array_equal(acc.sum(1), want_rowsum)
 
 
+def test_int8_gemm_extreme_k_and_zero_points(dev):
+    """Gemma's w2 depth (K = 16384) with worst-case operands: every index at an end of the grid and extreme zero
+    points, so the int32 accumulator and the correction terms reach their largest magnitudes -- still exact."""
+    M, N, K = 64, 352, 16384
+    rng = np.random.default_rng(1)
+    qa = rng.choice([0, 255], size=(M, K))
+    qw = rng.choice([0, 255], size=(N, K))
+    qa[0, :] = 255; qw[0, :] = 255; qa[1, :] = 0; qw[1, :] = 255
+    for za, zwv in ((0, 0), (255, 0), (0, 255), (128, 127)):
+        zw = np.full(N, zwv)
+        sa, sw = F32(0.01), np.full(N, F32(1e-4), F32)
+        _, want = O.qlinear_int_exact(qa, za, sa, qw, zw, sw, None)
+        got = _run_int8(dev, qa, qw, za, zw, sa, sw, None, 128).detach().cpu().numpy()
+        assert np.array_equal(bits(got), bits(want)), (za, zwv)
+
+
 def test_int8_gemm_fused_output_quantizer(dev):
     """Output-quantizer epilogue: indices within 1 LSB of the exact quantization of the exact pre-quant
     value (reciprocal-multiply instead of divide), > 99.9 % identical; all storage types agree."""
