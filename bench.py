@@ -402,6 +402,7 @@ def main():
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()            # ranks > 0 wait for rank 0's untimed extras before tearing RCCL down
         dist.destroy_process_group()
 
 
