@@ -50,6 +50,7 @@ struct GemmArgs {
   void* out;
   int out_dtype;
   int grid_m, grid_n;
+  int has_bias;                 // bias == NULL is replaced by a valid dummy pointer on the host
   unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
 };
 
@@ -187,27 +188,59 @@ __global__ void __launch_bounds__(64 * WM * WN)
   // Ordinary global loads first (per-n epilogue vectors, row sums), THEN the LDS-DMA of the first
   // stage(s): vmcnt retires in issue order, so waiting for the parameter loads does not drain the DMA.
   const int frow = lane & 15, kq = lane >> 4;
+  // Straight-line, unpredicated loads (indices clamped; the host passes valid dummy pointers for absent
+  // row sums / bias): with no control flow around them hipcc counts vmcnt exactly and the LDS-DMA issued
+  // right after is not drained when their values are first used.
   int rs[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wave_m * TM + i * 16 + frow;
-    rs[i] = (args.a_rowsum != nullptr && m < M) ? args.a_rowsum[m] : 0;
+    int m = m0 + wave_m * TM + i * 16 + frow;
+    m = m < M ? m : M - 1;
+    rs[i] = args.a_rowsum[m];
   }
-  // per-n epilogue vectors: fetched now into registers, parked in LDS only AFTER the main loop (a ds_write
-  // issued while LDS-DMA is in flight makes the compiler drain every outstanding DMA first)
+  // per-n epilogue vectors: global loads first, then the LDS-DMA of the first stage(s); the vectors are parked
+  // in LDS with inline-asm ds_writes (a compiler-visible ds_write behind an in-flight LDS-DMA makes hipcc drain
+  // every outstanding DMA first) so the accumulators can be INITIALISED with the integer zero-point
+  // correction while the first stage is still in flight -- the epilogue then needs no integer arithmetic.
   constexpr int PR = (BN + 64 * NW - 1) / (64 * NW);
   float pa[PR], pb[PR];
   int pz[PR], pc[PR];
 #pragma unroll
   for (int r = 0; r < PR; ++r) {
-    const int tt = (int)threadIdx.x + r * 64 * NW;
-    const int n = n0 + tt;
-    const bool ok = tt < BN && n < N;
-    pa[r] = ok ? args.alpha[n] : 0.f;
-    pb[r] = (ok && args.bias != nullptr) ? args.bias[n] : 0.f;
-    pz[r] = ok ? args.w_zp[n] : 0;
-    pc[r] = ok ? args.col_term[n] : 0;
+    int n = n0 + (int)threadIdx.x + r * 64 * NW;
+    n = n < N ? n : N - 1;
+    pa[r] = args.alpha[n];
+    pb[r] = args.bias[n];
+    pz[r] = args.w_zp[n];
+    pc[r] = args.col_term[n];
   }
+  constexpr bool FOLD_OO = OUTQ && (OUT == MQ_U8 || OUT == MQ_I8);
+  float so = 1.f, oo = 0.f, inv_so = 1.f;
+  if constexpr (OUTQ) {
+    so = args.out_scale[0];
+    oo = args.out_offset[0];
+    inv_so = __fdiv_rn(1.0f, so);
+  }
+  {
+    // layout at PAR: alpha'[BN] | bias'[BN] | w_zp[BN] | col_term[BN]; with an output quantizer alpha' = alpha/so,
+    // bias' = bias/so (+ oo for 8-bit storage: the offset <= 255 rides in the bias; 16-bit grids keep it out)
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+      const int tt = (int)threadIdx.x + r * 64 * NW;
+      if (tt < BN) {
+        const float a_v = OUTQ ? pa[r] * inv_so : pa[r];
+        const float bias_v = args.has_bias ? pb[r] : 0.f;
+        const float b_v = OUTQ ? (FOLD_OO ? bias_v * inv_so + oo : bias_v * inv_so) : bias_v;
+        const unsigned base = (unsigned)(size_t)MQ_LDS_PTR(smem + PAR) + tt * 4;     // LDS byte address
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%5\n\tds_write_b32 %0, %3 offset:%6\n\t"
+                     "ds_write_b32 %0, %4 offset:%7"
+                     :: "v"(base), "v"(a_v), "v"(b_v), "v"(pz[r]), "v"(pc[r]), "n"(BN * 4), "n"(BN * 8), "n"(BN * 12)
+                     : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // first stage(s) go out now; the barrier that publishes the parked vectors follows the issue
 #pragma unroll
   for (int d = 0; d < N_DMA; ++d) issue_one(d, 0, 0, 0);
   if constexpr (PP) {
@@ -216,6 +249,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
       for (int d = 0; d < N_DMA; ++d) issue_one(d, 1, 1, 1);
     }
   }
+  asm volatile("s_barrier" ::: "memory");
 
   // ---- ds_read offsets (per lane) -----------------------------------------------------------------
   // 128-byte rows: chunk (kq + 4*ks) ^ (row & 7); ks toggles bit 2 -> XOR 64 on the byte address
@@ -230,11 +264,23 @@ __global__ void __launch_bounds__(64 * WM * WN)
   const int x_off1 = x_off ^ 64, w_off1 = w_off ^ 64;
   (void)x_off1; (void)w_off1;
 
+  // accumulators start at the zero-point correction  col_term[n] - w_zp[n] * a_rowsum[m]  (exact in int32
+  // wrap-around arithmetic; |w_zp|, |row sum| < 2^23 so the 24-bit multiply is exact); the MFMAs add the
+  // contraction on top.  Runs while the first LDS-DMA stage is in flight.
   v4i acc[FM][FN];
+  {
+    const v4i* p_zw0 = reinterpret_cast<const v4i*>(smem + PAR + BN * 8);
+    const v4i* p_ct0 = reinterpret_cast<const v4i*>(smem + PAR + BN * 12);
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j) {
+      const int nl = wave_n * TN + j * 16 + kq * 4;
+      const v4i zw = p_zw0[nl >> 2], ct = p_ct0[nl >> 2];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = (int)((unsigned)__mul24(-zw[e], rs[i]) + (unsigned)ct[e]);
+    }
+  }
 
   if constexpr (PP) {
     // ---- ping-pong main loop (8 waves = two groups of four, one wave of each group per SIMD) --------
@@ -462,31 +508,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
   //     A' = alpha/so, B' = bias/so + oo);  (2) per 16-row block: dequant (+quantize) in registers,
   //     transpose through a wave-private LDS tile so that (3) every lane stores 16 contiguous bytes and
   //     a wave instruction writes whole rows -- instead of 16-byte fragments of 16 different rows.
-  constexpr bool FOLD_OO = OUTQ && (OUT == MQ_U8 || OUT == MQ_I8);
-  float so = 1.f, oo = 0.f, inv_so = 1.f;
-  if constexpr (OUTQ) {
-    so = args.out_scale[0];
-    oo = args.out_offset[0];
-    inv_so = __fdiv_rn(1.0f, so);
-  }
-  {
-    float* p_alpha_w = reinterpret_cast<float*>(smem + PAR);
-    float* p_bias_w = p_alpha_w + BN;
-    int* p_zw_w = reinterpret_cast<int*>(p_bias_w + BN);
-    int* p_ct_w = p_zw_w + BN;
-#pragma unroll
-    for (int r = 0; r < PR; ++r) {
-      const int tt = (int)threadIdx.x + r * 64 * NW;
-      if (tt < BN) {
-        p_alpha_w[tt] = OUTQ ? pa[r] * inv_so : pa[r];
-        // 8-bit storage: the offset (<= 255) rides in the bias; 16-bit grids keep it out of the rounding
-        p_bias_w[tt] = OUTQ ? (FOLD_OO ? pb[r] * inv_so + oo : pb[r] * inv_so) : pb[r];
-        p_zw_w[tt] = pz[r];
-        p_ct_w[tt] = pc[r];
-      }
-    }
-    __syncthreads();     // also: every wave is done with the stage buffers, which become staging tiles
-  }
+  __syncthreads();       // every wave is done with the stage buffers, which become staging tiles
   if constexpr (ABL & 4) {
     if (acc[0][0][0] == 0x7fffffff) reinterpret_cast<int*>(args.out)[0] = 1;
     return;
@@ -503,8 +525,9 @@ __global__ void __launch_bounds__(64 * WM * WN)
   const bool i8_unsigned_grid = (OUT == MQ_I8) && (args.out_qmin == 0.0f);
   const v4f* p_alpha = reinterpret_cast<const v4f*>(smem + PAR);
   const v4f* p_bias = reinterpret_cast<const v4f*>(smem + PAR + BN * 4);
-  const v4i* p_zw = reinterpret_cast<const v4i*>(smem + PAR + BN * 8);
-  const v4i* p_ct = reinterpret_cast<const v4i*>(smem + PAR + BN * 12);
+  // unsigned 8-bit grid: v_cvt_pk_u8_f32 rounds to nearest even and saturates to [0,255] (measured:
+  // tools/cvt_probe.cpp), i.e. it IS clamp(rint(v), qmin, qmax) -- no separate rint / med3
+  const bool u8_grid = (OUT == MQ_U8 || OUT == MQ_I8) && args.out_qmin == 0.0f && args.out_qmax == 255.0f;
   const bool rows_vec = (N % EPC) == 0;        // 16-byte row stores need N*ESZ % 16 == 0 (always true for LLM shapes)
   OT* outp = reinterpret_cast<OT*>(args.out);
 #pragma unroll
@@ -515,17 +538,17 @@ __global__ void __launch_bounds__(64 * WM * WN)
       const int nl = wave_n * TN + j * 16 + kq * 4;   // column within the block tile
       const v4f al = p_alpha[nl >> 2];
       const v4f bs = p_bias[nl >> 2];
-      const v4i zw = p_zw[nl >> 2];
-      const v4i ct = p_ct[nl >> 2];
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        // |w_zp| < 2^23 and |row sum| < 2^23 (K <= 65536): 24-bit multiply-add is exact and full rate
-        const int t = (int)((unsigned)__mul24(-zw[e], rs[i]) + (unsigned)acc[i][j][e] + (unsigned)ct[e]);
+        const int t = acc[i][j][e];              // contraction + zero-point correction (accumulator init)
         if constexpr (OUTQ) {
-          float q = rintf(__builtin_fmaf((float)t, al[e], bs[e]));
-          if constexpr (!FOLD_OO) q += oo;
-          q = __builtin_amdgcn_fmed3f(q, qmin, qmax);
+          float q = __builtin_fmaf((float)t, al[e], bs[e]);
+          if (!(FOLD_OO && u8_grid)) {           // wave-uniform; the u8 fast path leaves both to cvt_pk_u8
+            q = rintf(q);
+            if constexpr (!FOLD_OO) q += oo;
+            q = __builtin_amdgcn_fmed3f(q, qmin, qmax);
+          }
           if constexpr (OUT == MQ_F32 || OUT == MQ_F16) v[e] = __fmul_rn(__fsub_rn(q, oo), so);
           else v[e] = q;
         } else {
@@ -695,6 +718,8 @@ static int pick_variant(int M, int N) {
 template <bool W4>
 static int run_gemm(GemmArgs a, hipStream_t st) {
   const bool outq = a.out_scale != nullptr;
+  if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;                 // only multiplied by w_zp == 0
+  if (a.bias == nullptr) a.bias = a.alpha;                            // masked by has_bias
   const int v = pick_variant(a.M, a.N);
   a.grid_m = (a.M + kVariants[v].bm - 1) / kVariants[v].bm;
   a.grid_n = (a.N + kVariants[v].bn - 1) / kVariants[v].bn;
@@ -774,7 +799,7 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
     return run_gemv(v, as_stream(stream));
   }
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0, g_dbg_ts};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
 }
 
@@ -808,7 +833,7 @@ int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t 
                         out_offset, out, 2);
   if (rc != MQ_OK) return rc;
   GemmArgs g{a, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0, g_dbg_ts};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, g_dbg_ts};
   return run_gemm<true>(g, as_stream(stream));
 }
 
