@@ -216,6 +216,25 @@ def event_time(fn, iters):
     return best * 1e-3
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01/pmc_fetch + pmc_write; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
+    streams on gfx950).  Counters cannot be read from inside the bench, so this is the last profiled value."""
+    import re
+    d = os.path.join(ROOT, "profiles", "r01")
+    vals = {}
+    for fn, key in (("pmc_fetch.summary.txt", "FETCH_SIZE"), ("pmc_write.summary.txt", "WRITE_SIZE")):
+        try:
+            txt = open(os.path.join(d, fn)).read()
+        except OSError:
+            return None, None
+        m = re.search(r"gemm_i8_kernel<256, 176, 8, 1, 3,[^\n]*\n(?:\s+\S+\s+[\d.]+[^\n]*\n)*?\s+" + key + r"\s+([\d.]+)", txt)
+        if not m:
+            return None, None
+        vals[key] = float(m.group(1)) * 1024.0
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "profiles/r01/pmc_fetch.summary.txt + pmc_write.summary.txt"
+
+
 def cpu_baseline():
     """The oracle's restatement of the reference's simulated QLinear.forward (weight re-quantised on
     every call, as qmodule.py:346-347 does), on this box's host cores, bounded to ~10-30 s."""
@@ -351,9 +370,11 @@ def main():
             t_gemm = event_time(step.gemm, 50)
             t_quant = event_time(lambda: step.quantize(0), 50)
             achieved = OPS_PER_STEP / t_gemm / 1e12
+            traffic, traffic_src = pmc_traffic()
             roof = {"bound": "mfma", "kernel": "mq::gemm_i8_kernel (mq_w8a8_linear)", "achieved": round(achieved, 1),
                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOPS", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
-                    "avg_launch_us": round(t_gemm * 1e6, 2), "traffic": None,
+                    "avg_launch_us": round(t_gemm * 1e6, 2), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": M * K + N * K + M * N,
                     "algorithmic_ops_per_launch": OPS_PER_STEP,
                     "quantize_kernel": {"bound": "hbm", "avg_launch_us": round(t_quant * 1e6, 2),
                                         "achieved_GBps": round((M * K * 5 + M * 4) / t_quant / 1e9, 1), "peak_GBps": 8000.0}}

@@ -229,7 +229,7 @@ static int launch_tensor(const T* x, int64_t numel, float* mn, float* mx, hipStr
   const int64_t nvec = (numel - head) / N;
   int64_t g = (nvec + 1023) / 1024;   // >= 4 vectors per lane before the grid-stride loop wraps
   if (g < 1) g = 1;
-  if (g > 2048) g = 2048;
+  if (g > 512) g = 512;               // 2 workgroups per CU keep 8 MB in flight; a fresh statistic sees <= 1024 atomics
   minmax_tensor_kernel<T><<<(unsigned)g, 256, 0, st>>>(x, numel, head, nvec, mn, mx);
   MQ_LAUNCH_CHECK("mq_minmax_tensor");
   return MQ_OK;
