@@ -31,7 +31,17 @@ __device__ __forceinline__ float q_index(float x, float s, float o, float qmin, 
   float t = __fdiv_rn(x, s);
   float r = rintf(t);
   float q = __fadd_rn(r, o);
-  return fminf(fmaxf(q, qmin), qmax);
+  return fminf(fmaxf(q, qmin), qmax);          // NaN saturates to qmin: integer storage has no NaN
+}
+// torch.clamp propagates NaN (v_min/v_max drop it): the float-valued kernels follow the reference there
+__device__ __forceinline__ float clamp_nan(float q, float lo, float hi) {
+  const float c = fminf(fmaxf(q, lo), hi);
+  return q != q ? q : c;
+}
+// round_ste (qmodule.py:17-21) is (round(t) - t) + t: exact for finite t, NaN for t = +-inf (inf - inf)
+__device__ __forceinline__ float round_ste(float t) { return __fadd_rn(__fsub_rn(rintf(t), t), t); }
+__device__ __forceinline__ float q_index_fq(float x, float s, float o, float qmin, float qmax) {
+  return clamp_nan(__fadd_rn(round_ste(__fdiv_rn(x, s)), o), qmin, qmax);
 }
 // qmodule.py:290
 __device__ __forceinline__ float q_dequant(float q, float s, float o) { return __fmul_rn(__fsub_rn(q, o), s); }
@@ -40,9 +50,9 @@ __device__ __forceinline__ float q_dequant(float q, float s, float o) { return _
 __device__ __forceinline__ float h_round(float v) { return __half2float(__float2half_rn(v)); }
 __device__ __forceinline__ float q_index_hmath(float x, float s, float o, float qmin, float qmax) {
   float t = h_round(__fdiv_rn(x, s));
-  float r = h_round(rintf(t));
+  float r = h_round(__fadd_rn(h_round(__fsub_rn(h_round(rintf(t)), t)), t));   // round_ste, one half rounding per op
   float q = h_round(__fadd_rn(r, o));
-  return fminf(fmaxf(q, qmin), qmax);   // qmin/qmax are exactly representable in half for <= 8 bits
+  return clamp_nan(q, qmin, qmax);      // qmin/qmax are exactly representable in half for <= 8 bits
 }
 __device__ __forceinline__ float q_dequant_hmath(float q, float s, float o) {
   return h_round(__fmul_rn(h_round(__fsub_rn(q, o)), s));
@@ -57,14 +67,14 @@ __global__ void scale_offset_kernel(const float* __restrict__ mn, const float* _
   float lo = mn[i], hi = mx[i];
   float alpha, beta;
   if (symmetric) {
-    alpha = fmaxf(fabsf(lo), fabsf(hi));
+    alpha = (lo != lo || hi != hi) ? __fadd_rn(lo, hi) : fmaxf(fabsf(lo), fabsf(hi));   // torch.max propagates NaN
     beta = 0.0f;
   } else {
     alpha = __fsub_rn(hi, lo);
     beta = lo;
   }
   float s = __fdiv_rn(alpha, qmax);
-  s = fminf(fmaxf(s, 1e-5f), 1e6f);            // qmodule.py:58 (CLIPMIN / CLIPMAX)
+  s = clamp_nan(s, 1e-5f, 1e6f);               // qmodule.py:58 (CLIPMIN / CLIPMAX)
   scale[i] = s;
   offset[i] = -rintf(__fdiv_rn(beta, s));      // qmodule.py:60 ; symmetric -> -0.0f
 }
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(256) fake_quant_vec_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < V::N; ++j) {
       float f = V::get(a, j);
-      float q = HMATH ? q_index_hmath(f, s, o, qmin, qmax) : q_index(f, s, o, qmin, qmax);
+      float q = HMATH ? q_index_hmath(f, s, o, qmin, qmax) : q_index_fq(f, s, o, qmin, qmax);
       V::set(r, j, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
     }
     yv[i] = r;
@@ -144,7 +154,7 @@ __global__ void __launch_bounds__(256) fake_quant_scalar_kernel(const T* __restr
     int64_t row = PER_ROW ? i / cols : 0;
     float s = scale[row], o = offset[row];
     float f = ld<T>(x, i);
-    float q = HMATH ? q_index_hmath(f, s, o, qmin, qmax) : q_index(f, s, o, qmin, qmax);
+    float q = HMATH ? q_index_hmath(f, s, o, qmin, qmax) : q_index_fq(f, s, o, qmin, qmax);
     st<T>(y, i, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
   }
 }
@@ -284,10 +294,10 @@ __global__ void __launch_bounds__(256) fake_quant_bwd_kernel(const float* __rest
   for (int64_t i = begin; i < end; i += step) {
     const float xv = x[i], g = gy[i];
     const float t = __fdiv_rn(xv, s);
-    const float r = rintf(t);
+    const float r = round_ste(t);
     const float q = __fadd_rn(r, o);
     const bool inside = q >= qmin && q <= qmax;
-    const float qc = fminf(fmaxf(q, qmin), qmax);
+    const float qc = clamp_nan(q, qmin, qmax);
     gx[i] = inside ? __fdiv_rn(__fmul_rn(g, s), s) : 0.f;          // (g*s) * mask / s, as autograd chains it
     acc_s += inside ? g * (r - t) : g * (qc - o);
     acc_o += inside ? 0.f : -g * s;

@@ -652,7 +652,6 @@ static int launch_one(const GemmArgs& a, int lds, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, bool PP>
 static int launch_typed(const GemmArgs& a, hipStream_t st) {
-  constexpr int WROW = W4 ? BK / 2 : BK;
   constexpr int LDS = lds_main_bytes(BM, BN, WM, WN, W4, PP) + 16 * BN;
 #ifdef MQ_GEMM_ABLATE
   if constexpr (OUT == MQ_U8 && OQ && !W4 && BM == 256) {

@@ -12,6 +12,21 @@
 
 namespace mq {
 
+// torch.min / torch.max / aminmax return NaN when the tensor holds one (v_min_f32 / v_max_f32 would drop it):
+// v_minimum3_f32 / v_maximum3_f32 (new on gfx950) propagate NaN at no cost.
+__device__ __forceinline__ float min_p(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ float max_p(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float wave_min_p(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min_p(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_p(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max_p(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 template <typename T>
 struct Ld16;
 template <>
@@ -19,8 +34,8 @@ struct Ld16<float> {
   static constexpr int N = 4;
   __device__ static void minmax(const float* p, float& lo, float& hi) {
     float4 v = *reinterpret_cast<const float4*>(p);
-    lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
-    hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    lo = min_p(min_p(lo, v.x), min_p(v.y, min_p(v.z, v.w)));
+    hi = max_p(max_p(hi, v.x), max_p(v.y, max_p(v.z, v.w)));
   }
   __device__ static float one(const float* p) { return *p; }
 };
@@ -33,8 +48,8 @@ struct Ld16<__half> {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = __half2float(v.h[j]);
-      lo = fminf(lo, f);
-      hi = fmaxf(hi, f);
+      lo = min_p(lo, f);
+      hi = max_p(hi, f);
     }
   }
   __device__ static float one(const __half* p) { return __half2float(*p); }
@@ -63,10 +78,25 @@ __device__ __forceinline__ void commit_max(float* addr, float v) {
   if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_f32(addr, v);
 }
 
+// NaN is sticky under the bit-pattern atomics: 0xffffffff is the largest unsigned and the smallest-but-one
+// signed pattern, so neither branch of atomic_min_f32 can replace it; 0x7fffffff likewise for atomic_max_f32.
+__device__ __forceinline__ void commit_nan(float* mn, float* mx) {
+  atomicMax(reinterpret_cast<unsigned int*>(mn), 0xffffffffu);
+  atomicMax(reinterpret_cast<int*>(mx), 0x7fffffff);
+}
+__device__ __forceinline__ void commit_pair(float lo, float hi, float* mn, float* mx) {
+  if (lo != lo || hi != hi) {
+    commit_nan(mn, mx);
+  } else if (lo <= hi) {   // false only when nothing was seen
+    commit_min(mn, canon(lo));
+    commit_max(mx, canon(hi));
+  }
+}
+
 __device__ __forceinline__ void block_commit(float lo, float hi, float* mn, float* mx) {
   __shared__ float s_lo[4], s_hi[4];
-  lo = wave_min(lo);
-  hi = wave_max(hi);
+  lo = wave_min_p(lo);
+  hi = wave_max_p(hi);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     s_lo[w] = lo;
@@ -74,12 +104,9 @@ __device__ __forceinline__ void block_commit(float lo, float hi, float* mn, floa
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
-    hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
-    if (lo <= hi) {   // false only when this workgroup saw no element
-      commit_min(mn, canon(lo));
-      commit_max(mx, canon(hi));
-    }
+    lo = min_p(min_p(s_lo[0], s_lo[1]), min_p(s_lo[2], s_lo[3]));
+    hi = max_p(max_p(s_hi[0], s_hi[1]), max_p(s_hi[2], s_hi[3]));
+    commit_pair(lo, hi, mn, mx);
   }
 }
 
@@ -103,15 +130,15 @@ __global__ void __launch_bounds__(256) minmax_tensor_kernel(const T* __restrict_
     L::minmax(xv + (i + 3 * stride) * L::N, lo3, hi3);
   }
   for (; i < nvec; i += stride) L::minmax(xv + i * L::N, lo, hi);
-  lo = fminf(fminf(lo, lo1), fminf(lo2, lo3));
-  hi = fmaxf(fmaxf(hi, hi1), fmaxf(hi2, hi3));
+  lo = min_p(min_p(lo, lo1), min_p(lo2, lo3));
+  hi = max_p(max_p(hi, hi1), max_p(hi2, hi3));
   // scalar ends: [0, head) and [head + nvec*N, numel)
   const int64_t tail0 = head + nvec * L::N;
   const int64_t nscalar = head + (numel - tail0);
   for (int64_t i2 = tid; i2 < nscalar; i2 += stride) {
     float f = L::one(x + (i2 < head ? i2 : tail0 + (i2 - head)));
-    lo = fminf(lo, f);
-    hi = fmaxf(hi, f);
+    lo = min_p(lo, f);
+    hi = max_p(hi, f);
   }
   block_commit(lo, hi, mn, mx);
 }
@@ -134,15 +161,15 @@ __global__ void __launch_bounds__(256) minmax_rows_kernel(const T* __restrict__ 
   } else {
     for (int64_t i = lane; i < cols; i += 64) {
       float f = L::one(xr + i);
-      lo = fminf(lo, f);
-      hi = fmaxf(hi, f);
+      lo = min_p(lo, f);
+      hi = max_p(hi, f);
     }
   }
-  lo = wave_min(lo);
-  hi = wave_max(hi);
+  lo = wave_min_p(lo);
+  hi = wave_max_p(hi);
   if (lane == 0) {
-    mn[row] = fminf(mn[row], lo);
-    mx[row] = fmaxf(mx[row], hi);
+    mn[row] = min_p(mn[row], lo);
+    mx[row] = max_p(mx[row], hi);
   }
 }
 
@@ -172,8 +199,8 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(const T* __restrict__ 
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         float f = (float)v.e[j];
-        lo[j] = fminf(lo[j], f);
-        hi[j] = fmaxf(hi[j], f);
+        lo[j] = min_p(lo[j], f);
+        hi[j] = max_p(hi[j], f);
       }
     }
   }
@@ -186,12 +213,9 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(const T* __restrict__ 
   for (int i = threadIdx.x; i < 64 * N; i += 256) {
     const int64_t c = (int64_t)blockIdx.x * 64 * N + i;
     if (c < cols) {
-      float l = fminf(fminf(s_lo[0][i], s_lo[1][i]), fminf(s_lo[2][i], s_lo[3][i]));
-      float h = fmaxf(fmaxf(s_hi[0][i], s_hi[1][i]), fmaxf(s_hi[2][i], s_hi[3][i]));
-      if (l <= h) {
-        commit_min(mn + c, canon(l));
-        commit_max(mx + c, canon(h));
-      }
+      float l = min_p(min_p(s_lo[0][i], s_lo[1][i]), min_p(s_lo[2][i], s_lo[3][i]));
+      float h = max_p(max_p(s_hi[0][i], s_hi[1][i]), max_p(s_hi[2][i], s_hi[3][i]));
+      commit_pair(l, h, mn + c, mx + c);
     }
   }
 }
@@ -208,13 +232,10 @@ __global__ void __launch_bounds__(256) minmax_cols_scalar_kernel(const T* __rest
   float lo = __int_as_float(0x7f800000), hi = __int_as_float(0xff800000);
   for (int64_t r = r0; r < r1; ++r) {
     float f = Ld16<T>::one(x + r * cols + c);
-    lo = fminf(lo, f);
-    hi = fmaxf(hi, f);
+    lo = min_p(lo, f);
+    hi = max_p(hi, f);
   }
-  if (lo <= hi) {
-    commit_min(mn + c, canon(lo));
-    commit_max(mx + c, canon(hi));
-  }
+  commit_pair(lo, hi, mn + c, mx + c);
 }
 
 template <typename T>

@@ -15,6 +15,7 @@ Fixtures written (all data, no reference source text):
   qlinear_cases.npz       a8     QLinear.forward on small shapes (W8A8 / W4A8 / per-channel / bias)
   calib_stream.npz        a12/a13 real get_act_range / get_act_scales on a toy module stack
   checksums.json          sha256 of full-size index tensors (inputs re-creatable from numpy seeds)
+  nonfinite_cases.npz     a1/a3/a5 NaN and +-inf inputs: torch.clamp / amin / amax propagate NaN
   api_surface.json        state_dict keys / export_qcfg / export_act_range of a toy sim model
 """
 import hashlib
@@ -174,6 +175,54 @@ def gen_quantizer_cases():
         "f16_per_channel_preset")
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "quantizer_cases.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_nonfinite():
+    """NaN / +-inf inputs through the reference: Quantizer.forward with a preset grid (torch.clamp keeps
+    NaN, saturates inf), compute_min_max_from_tensor (amin/amax return NaN if any element is NaN) and
+    compute_scale_offset_from_min_max on a NaN range."""
+    g = torch.Generator().manual_seed(4242)
+    out, meta = {}, []
+    x = torch.randn(8, 64, generator=g) * 2
+    x[0, 3], x[2, 0], x[7, 63] = float("nan"), float("nan"), float("nan")
+    x[1, 5], x[3, 9], x[4, 4] = float("inf"), float("-inf"), float("inf")
+    for i, (bits, sym, per_ch) in enumerate(((8, False, False), (8, True, False), (16, False, False), (8, False, True))):
+        qz = Q.Quantizer(Q.QuantConfig(bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch))
+        if per_ch:
+            rng = (-torch.rand(8, 1, generator=g) - 1.0, torch.rand(8, 1, generator=g) + 1.5)
+            out[f"q{i}_rmin"], out[f"q{i}_rmax"] = npf(rng[0]), npf(rng[1])
+        else:
+            rng = (-2.5, 3.0)
+        qz.set_scale_offset_from_minmax(rng[0], rng[1], "buffer", x.device)
+        out[f"q{i}_y"] = npf(qz(x))
+        meta.append(dict(id=f"q{i}", bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch,
+                         rng=None if per_ch else list(rng)))
+    out["x"] = npf(x)
+    # statistics: NaN rows / columns, inf-only rows, per-tensor
+    xs = torch.randn(6, 40, generator=g)
+    xs[1, 7] = float("nan")
+    xs[3, 0], xs[4, 39] = float("inf"), float("-inf")
+    out["xs"] = npf(xs)
+    mn, mx = Q.compute_min_max_from_tensor(xs)
+    out["xs_t_min"], out["xs_t_max"] = npf(mn), npf(mx)
+    mn, mx = Q.compute_min_max_from_tensor(xs, is_per_channel=True)
+    out["xs_r_min"], out["xs_r_max"] = npf(mn), npf(mx)
+    out["xs_c_min"], out["xs_c_max"] = npf(torch.amin(xs, 0)), npf(torch.amax(xs, 0))       # generate_act_range.py:62-63
+    xi = xs.clone()
+    xi[1, 7] = 0.25                      # infinities only
+    out["xi"] = npf(xi)
+    mn, mx = Q.compute_min_max_from_tensor(xi)
+    out["xi_t_min"], out["xi_t_max"] = npf(mn), npf(mx)
+    # NaN / inf ranges -> scale, offset
+    rmin = torch.tensor([float("nan"), -1.0, -1.0, float("-inf"), -2.0])
+    rmax = torch.tensor([1.0, float("nan"), float("inf"), 1.0, 3.0])
+    for sym in (False, True):
+        sc, of, *_ = Q.compute_scale_offset_from_min_max(rmin, rmax, 8, sym)
+        out[f"so_scale_s{int(sym)}"], out[f"so_offset_s{int(sym)}"] = npf(sc), npf(of)
+    out["so_min"], out["so_max"] = npf(rmin), npf(rmax)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "nonfinite_cases.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -476,6 +525,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_scale_offset_grid()
     gen_quantizer_cases()
+    gen_nonfinite()
     gen_quantizer_grads()
     gen_qlinear_cases()
     gen_calib_stream()

@@ -96,12 +96,18 @@ def min_max_from_tensor(x, is_per_channel: bool = False, group_size: int = -1):
 def quantize_index(x, scale, offset, qmin: int, qmax: int):
     """Integer grid index as an fp32 array: ``clamp(round(x/scale) + offset, qmin, qmax)``.
 
-    qmodule.py:286-287.  True IEEE division, round-half-even, fp32 add, clamp.
+    qmodule.py:286-287.  True IEEE division, round-half-even, fp32 add, clamp.  round_ste
+    (qmodule.py:17-21) evaluates ``(round(t) - t) + t``: exact for finite t (the difference is exactly
+    representable), NaN for t = +-inf (inf - inf) -- so an infinite input comes out NaN like a NaN one
+    (frozen in tests/golden/nonfinite_cases.npz).  np.clip, like torch.clamp, keeps NaN.
     """
     x = np.asarray(x, dtype=F32)
     s = np.asarray(scale, dtype=F32)
     o = np.asarray(offset, dtype=F32)
-    q = (np.rint((x / s).astype(F32)) + o).astype(F32)
+    with np.errstate(invalid="ignore"):
+        t = (x / s).astype(F32)
+        r = ((np.rint(t) - t).astype(F32) + t).astype(F32)
+        q = (r + o).astype(F32)
     return np.clip(q, F32(qmin), F32(qmax)).astype(F32)
 
 
@@ -131,9 +137,10 @@ def fake_quant_backward(x, grad_y, scale, offset, qmin: int, qmax: int):
     g = np.asarray(grad_y, dtype=F32)
     s = np.asarray(scale, dtype=F32)
     o = np.asarray(offset, dtype=F32)
-    t = (x / s).astype(F32)
-    r = np.rint(t)
-    q = (r + o).astype(F32)
+    with np.errstate(invalid="ignore"):
+        t = (x / s).astype(F32)
+        r = ((np.rint(t) - t).astype(F32) + t).astype(F32)       # round_ste, see quantize_index
+        q = (r + o).astype(F32)
     inside = (q >= F32(qmin)) & (q <= F32(qmax))
     qc = np.clip(q, F32(qmin), F32(qmax))
     # autograd chain for x: (g * s) through the clamp mask, then the division's grad / s  -- reproduced
@@ -159,7 +166,9 @@ def fake_quant_f16_per_tensor(x, scale, offset, qmin: int, qmax: int):
     s = F32(scale)
     o = F32(offset)
     t = (x.astype(F32) / s).astype(H)
-    r = np.rint(t.astype(F32)).astype(H)
+    with np.errstate(invalid="ignore"):
+        r0 = np.rint(t.astype(F32)).astype(H)
+        r = ((r0.astype(F32) - t.astype(F32)).astype(H).astype(F32) + t.astype(F32)).astype(H)   # round_ste in half
     q = (r.astype(F32) + o).astype(H)
     q = np.clip(q, H(qmin), H(qmax)).astype(H)
     d = (q.astype(F32) - o).astype(H)

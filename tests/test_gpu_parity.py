@@ -238,6 +238,61 @@ def test_minmax_kernels_edge_cases(dev):
         assert np.array_equal(mn.detach().cpu().numpy(), a.min(0)) and np.array_equal(mx.detach().cpu().numpy(), a.max(0)), (r, c)
 
 
+def eq_nan(a, b):
+    a, b = np.asarray(a, F32), np.asarray(b, F32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and np.array_equal(a[~na], b[~nb])
+
+
+def test_nonfinite_inputs_follow_reference(dev):
+    """NaN / +-inf through the HIP kernels vs the reference's frozen outputs: torch.clamp, amin and amax keep
+    NaN (v_min/v_max would drop it), round_ste turns +-inf into NaN, NaN statistics are sticky under atomics."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    z = load_npz("nonfinite_cases.npz")
+    x = T(z["x"], dev)
+    for m in load_meta(z):
+        qz = mq.Quantizer(mq.QuantConfig(m["bitwidth"], -1, m["is_symmetric"], m["is_per_channel"], False))
+        if m["is_per_channel"]:
+            qz.set_scale_offset_from_minmax(T(z[m["id"] + "_rmin"], dev), T(z[m["id"] + "_rmax"], dev), "buffer", dev)
+        else:
+            qz.set_scale_offset_from_minmax(m["rng"][0], m["rng"][1], "buffer", dev)
+        assert eq_nan(qz(x).cpu().numpy(), z[m["id"] + "_y"]), m
+    # fp16 per-tensor path against the oracle's half arithmetic
+    xh = z["x"].astype(np.float16)
+    qz = mq.Quantizer(mq.QuantConfig(8))
+    qz.set_scale_offset_from_minmax(-2.5, 3.0, "buffer", dev)
+    want, _ = O.fake_quant_f16_per_tensor(xh, qz.scale.item(), qz.offset.item(), 0, 255)
+    assert eq_nan(qz(T(xh, dev)).float().cpu().numpy(), want.astype(F32))
+    xs, xi = T(z["xs"], dev), T(z["xi"], dev)
+    mn, mx = ops.minmax_tensor(xs)
+    assert eq_nan(mn.cpu().numpy().reshape(()), z["xs_t_min"]) and eq_nan(mx.cpu().numpy().reshape(()), z["xs_t_max"])
+    mn, mx = ops.minmax_rows(xs)
+    assert eq_nan(mn.cpu().numpy().reshape(-1, 1), z["xs_r_min"]) and eq_nan(mx.cpu().numpy().reshape(-1, 1), z["xs_r_max"])
+    mn, mx = ops.minmax_cols(xs)
+    assert eq_nan(mn.cpu().numpy(), z["xs_c_min"]) and eq_nan(mx.cpu().numpy(), z["xs_c_max"])
+    mn, mx = ops.minmax_tensor(xi)
+    assert mn.item() == float("-inf") and mx.item() == float("inf")
+    # NaN stays in a running statistic whatever arrives later, and wherever in a large tensor it sits
+    mn, mx = ops.minmax_tensor(xs)
+    for later in (xi, T(np.array([-1e30, 1e30], F32), dev), T(np.zeros(5, F32), dev)):
+        ops.minmax_tensor_(later, mn, mx)
+        assert np.isnan(mn.item()) and np.isnan(mx.item())
+    big = torch.randn(1 << 22, device=dev)
+    for pos in (0, 12345, (1 << 22) - 1):
+        b = big.clone()
+        b[pos] = float("nan")
+        mn, mx = ops.minmax_tensor(b)
+        assert np.isnan(mn.item()) and np.isnan(mx.item()), pos
+        mn, mx = ops.minmax_cols(b.view(2048, 2048))
+        want = np.zeros(2048, bool)
+        want[pos % 2048] = True
+        assert np.array_equal(np.isnan(mn.cpu().numpy()), want) and np.array_equal(np.isnan(mx.cpu().numpy()), want)
+    for sym in (0, 1):
+        s, o = ops.scale_offset_from_minmax(T(z["so_min"], dev), T(z["so_max"], dev), 8, bool(sym))
+        assert eq_nan(s.cpu().numpy(), z[f"so_scale_s{sym}"]) and eq_nan(o.cpu().numpy(), z[f"so_offset_s{sym}"]), sym
+
+
 def _stream(z, prefix):
     items = {}
     for key in z.files:

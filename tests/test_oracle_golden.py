@@ -252,3 +252,37 @@ def test_w4_pack_roundtrip():
         p = O.pack_w4(q, qmin)
         assert p.shape == (24, 48) and p.dtype == np.uint8
         assert np.array_equal(O.unpack_w4(p, qmin), q)
+
+
+def eq_nan(a, b):
+    """Equal where finite / infinite (bit-exact), NaN exactly where the reference has NaN."""
+    a, b = np.asarray(a, F32), np.asarray(b, F32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and np.array_equal(a[~na], b[~nb])
+
+
+def test_nonfinite_inputs_follow_reference():
+    """NaN propagates through clamp / amin / amax; +-inf becomes NaN inside round_ste (torch semantics)."""
+    z = load_npz("nonfinite_cases.npz")
+    x = z["x"]
+    assert np.isnan(x).sum() == 3 and np.isinf(x).sum() == 3
+    for m in load_meta(z):
+        qz = O.QuantizerOracle(m["bitwidth"], -1, m["is_symmetric"], m["is_per_channel"], False)
+        if m["is_per_channel"]:
+            qz.set_from_minmax(z[m["id"] + "_rmin"], z[m["id"] + "_rmax"])
+        else:
+            qz.set_from_minmax(*m["rng"])
+        y = qz.forward(x)
+        assert eq_nan(y, z[m["id"] + "_y"]), m
+        assert np.array_equal(np.isnan(y), ~np.isfinite(x))      # round_ste turns +-inf into NaN (inf - inf)
+    xs, xi = z["xs"], z["xi"]
+    mn, mx = O.min_max_from_tensor(xs)
+    assert eq_nan(mn, z["xs_t_min"]) and eq_nan(mx, z["xs_t_max"]) and np.isnan(mn) and np.isnan(mx)
+    mn, mx = O.min_max_from_tensor(xs, True)
+    assert eq_nan(mn, z["xs_r_min"]) and eq_nan(mx, z["xs_r_max"])
+    assert eq_nan(xs.min(0), z["xs_c_min"]) and eq_nan(xs.max(0), z["xs_c_max"])
+    mn, mx = O.min_max_from_tensor(xi)
+    assert mn == z["xi_t_min"] == -np.inf and mx == z["xi_t_max"] == np.inf
+    for sym in (0, 1):
+        s, o, _, _ = O.scale_offset_from_min_max(z["so_min"], z["so_max"], 8, bool(sym))
+        assert eq_nan(s, z[f"so_scale_s{sym}"]) and eq_nan(o, z[f"so_offset_s{sym}"]), sym
