@@ -788,7 +788,7 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
   int rc = check_common("mq_w8a8_linear", a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
                         out, 1);
   if (rc != MQ_OK) return rc;
-  if (M <= 8 && M * K <= 64 * 1024 && g_forced_variant < 0) {   // decode shapes: weight-streaming GEMV (mq_gemv.hip)
+  if (M <= 8 && M * K <= 64 * 1024 - 64 && g_forced_variant < 0) {   // decode shapes: weight-streaming GEMV (mq_gemv.hip)
     if (out_scale == nullptr && out_dtype != MQ_F32 && out_dtype != MQ_F16) {
       set_error("mq_w8a8_linear: integer out_dtype %d needs an output quantizer", out_dtype);
       return MQ_EINVAL;

@@ -1,4 +1,4 @@
-// Decode-shape QLinear (M <= 16 tokens): int8 GEMV, weight-streaming, HBM-bound.
+// Decode-shape QLinear (M <= 8 tokens): int8 GEMV, weight-streaming.
 //
 // Same arithmetic and epilogue as the MFMA GEMM (mq_gemm.hip):
 //   out[m,n] = alpha[n] * ( sum_k a[m,k]*w[n,k] - w_zp[n]*a_rowsum[m] + col_term[n] ) + bias[n]  (+ output quantizer)
@@ -7,10 +7,17 @@
 // for W: it is not shared between waves) feeding v_dot4_i32_i8.  Algorithmic bytes per token: N*K weight
 // bytes (+ K activation bytes, L2 resident).  TinyLlama-1.1B W8: 22 x 44.04 MB = 0.969 GB per token.
 //
-// Mapping: one wave owns ROWS_PER_WAVE consecutive output rows; its 64 lanes split K into 16-byte
-// chunks (lane l takes chunks l, l+64, ...), so a wave instruction reads 1 KiB contiguous per row;
-// ROWS_PER_WAVE loads are in flight per lane before the first dot product is needed.  Activations
-// ([M,K] int8, a few KiB) are staged in LDS once per workgroup and re-read from there.
+// Structure: one fat workgroup (16 waves) per CU.  A wave owns whole output rows (row_base + wave + 16 t); its
+// 64 lanes split K into 16-byte chunks (lane l takes chunks l, l + 64, ...: a wave instruction reads 1 KiB
+// contiguous) and it issues ALL its weight loads (<= 8 per lane per pass; one pass covers every TinyLlama matrix)
+// plus the per-row epilogue parameters before anything else.  The activations are quantized ONCE per CU
+// (K / 1024 elements per thread) into LDS while those loads fly; reductions are DPP adds; the epilogue runs from
+// registers.  Why: the first version (256-1408 small workgroups, 2 rows per wave, several load trips, bpermute
+// reductions, parameter loads after the dot products) cost the same whether its weights came from L2, the Infinity
+// Cache or HBM -- it was bound by its dependent chain, not by bytes.  Measured (tools/bench_gemv_cache.py, HBM-resident
+// 1 GB weight sets, hipGraph): launch time = 3.7 us + bytes / 5.5 TB/s for all four TinyLlama shapes
+// (4.2 / 4.6 / 5.8 / 7.9 us for 4.2 / 5.2 / 11.5 / 23 MB; v1: 4.5 / 5.0 / 8.5 / 9.7 us); a trivial kernel in the same
+// graph costs 1.76 us per launch.
 #include <hip/hip_fp16.h>
 
 #include "mq_gemv.h"
@@ -32,51 +39,57 @@ __device__ __forceinline__ int q_index_i(float x, float s, float o, float qmin, 
   return (int)fminf(fmaxf(q, qmin), qmax);
 }
 
-template <int MT, int ROWS, bool FUSEQ>   // MT: tokens per pass; ROWS: output rows per wave; FUSEQ: fp32 activations in
-__global__ void __launch_bounds__(256) gemv_i8_kernel(const GemvArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [M][K] int8 activations (+ M row sums when FUSEQ)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// 64-lane integer sum with DPP row operations (6 VALU adds instead of 6 LDS-crossbar bpermutes); all lanes active
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror: every lane = its row-of-16 total
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+constexpr int GV2_THREADS = 1024, GV2_WAVES = 16, GV2_INFLIGHT = 8;
+
+template <int MT, bool FUSEQ>
+__global__ void __launch_bounds__(GV2_THREADS) gemv_i8_fat_kernel(const GemvArgs g, const int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [M][K] int8 activations, then M row sums
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = g.K, N = g.N, M = g.M;
   const int kchunks = K >> 4;
+  const int cpl = (kchunks + 63) >> 6;                            // 16-byte chunks per lane per row
   int* s_rs = reinterpret_cast<int*>(smem + (size_t)M * K);
-  // First trip of this wave's weight rows goes out BEFORE the activation staging: the kernel is one HBM
-  // round trip long for the small decode matrices, so the weight latency must overlap the staging.
-  const int n0 = (blockIdx.x * 4 + wave) * ROWS;
-  v4i pw[ROWS], pw2[ROWS];
-  {
-    const int c = lane, c2 = lane + 64;
+  const int row0 = blockIdx.x * rows_per_wg + wave;               // this wave's rows: row0 + 16 t
+  const int row_end = (blockIdx.x + 1) * rows_per_wg < N ? (blockIdx.x + 1) * rows_per_wg : N;
+
+  // ---- pass 0 weight loads + per-row parameters go out first ------------------------------------------
+  v4i buf[GV2_INFLIGHT];
+  auto issue_pass = [&](int t, int j) {                            // (t, j) = first (row slot, chunk slot) of the pass
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int n = (n0 + r < N) ? n0 + r : N - 1;
-      const v4i* wr = reinterpret_cast<const v4i*>(g.w + (size_t)n * K);
-      pw[r] = (c < kchunks) ? __builtin_nontemporal_load(wr + c) : v4i{0, 0, 0, 0};
-      pw2[r] = (c2 < kchunks) ? __builtin_nontemporal_load(wr + c2) : v4i{0, 0, 0, 0};
+    for (int u = 0; u < GV2_INFLIGHT; ++u) {
+      const int row = row0 + GV2_WAVES * t;
+      const int c = lane + 64 * j;
+      if (row < row_end && c < kchunks)
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * K) + c);
+      else
+        buf[u] = v4i{0, 0, 0, 0};
+      if (++j == cpl) { j = 0; ++t; }
+    }
+  };
+  issue_pass(0, 0);
+  float p_alpha = 0.f, p_bias = 0.f;
+  int p_zp = 0, p_ct = 0;
+  {
+    const int row = row0 + GV2_WAVES * lane;                       // lane t keeps the parameters of row slot t
+    if (row < row_end) {
+      p_alpha = g.alpha[row];
+      p_zp = g.w_zp[row];
+      p_ct = g.col_term[row];
+      if (g.bias) p_bias = g.bias[row];
     }
   }
-  if constexpr (FUSEQ) {
-    // quantize the fp32 activations straight into LDS (every workgroup repeats it: M*K*4 bytes from L2)
-    // and reduce the row sums of the stored values with LDS atomics
-    if (threadIdx.x < M) s_rs[threadIdx.x] = 0;
-    __syncthreads();
-    const float s = g.xq_scale[0], o = g.xq_offset[0];
-    for (int i = threadIdx.x; i < M * (K >> 2); i += 256) {
-      const float4 v = reinterpret_cast<const float4*>(g.x_f32)[i];
-      const int q0 = q_index_i(v.x, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q1 = q_index_i(v.y, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
-      const int q2 = q_index_i(v.z, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q3 = q_index_i(v.w, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
-      reinterpret_cast<unsigned*>(smem)[i] = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
-      int part = q0 + q1 + q2 + q3;
-      // lanes of a wave may straddle rows only if K < 256; K % 128 == 0 and a wave covers 256 elements per trip
-      const int row = (i << 2) / K;
-      part = wave_sum(part);          // K >= 256 here (checked on the host): the whole wave is in one row
-      if (lane == 0) atomicAdd(&s_rs[row], part);
-    }
-  } else {
-    const v4i* src = reinterpret_cast<const v4i*>(g.a);
-    v4i* dst = reinterpret_cast<v4i*>(smem);
-    for (int i = threadIdx.x; i < M * kchunks; i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
-  if (n0 >= N) return;
   float so = 1.f, oo = 0.f, inv_so = 1.f;
   const bool outq = g.out_scale != nullptr;
   if (outq) {
@@ -84,73 +97,91 @@ __global__ void __launch_bounds__(256) gemv_i8_kernel(const GemvArgs g) {
     oo = g.out_offset[0];
     inv_so = __fdiv_rn(1.0f, so);
   }
-  for (int mb = 0; mb < M; mb += MT) {
-    int acc[MT][ROWS];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) acc[m][r] = 0;
-    // two K chunks per trip: 2*ROWS independent 16-byte weight loads in flight per lane
-    for (int c = lane; c < kchunks; c += 128) {
-      const int c2 = c + 64;
-      const bool has2 = c2 < kchunks;
-      v4i wv[ROWS], wv2[ROWS];
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        const int n = (n0 + r < N) ? n0 + r : N - 1;
-        const v4i* wr = reinterpret_cast<const v4i*>(g.w + (size_t)n * K);
-        if (c == lane) {                                            // first trip: already in registers
-          wv[r] = pw[r];
-          wv2[r] = pw2[r];
-        } else {
-          wv[r] = __builtin_nontemporal_load(wr + c);               // streamed once: bypass-friendly
-          wv2[r] = has2 ? __builtin_nontemporal_load(wr + c2) : v4i{0, 0, 0, 0};
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (mb + m < M) {
-          const v4i av = *reinterpret_cast<const v4i*>(smem + (size_t)(mb + m) * K + c * 16);
-          const v4i av2 = has2 ? *reinterpret_cast<const v4i*>(smem + (size_t)(mb + m) * K + c2 * 16) : v4i{0, 0, 0, 0};
-#pragma unroll
-          for (int r = 0; r < ROWS; ++r) acc[m][r] = dot16(wv2[r], av2, dot16(wv[r], av, acc[m][r]));
-        }
-      }
+
+  // ---- activations -> LDS, once per CU ---------------------------------------------------------------
+  if constexpr (FUSEQ) {
+    if (threadIdx.x < M) s_rs[threadIdx.x] = 0;
+    __syncthreads();
+    const float s = g.xq_scale[0], o = g.xq_offset[0];
+    for (int i = threadIdx.x; i < M * (K >> 2); i += GV2_THREADS) {
+      const float4 v = reinterpret_cast<const float4*>(g.x_f32)[i];
+      const int q0 = q_index_i(v.x, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q1 = q_index_i(v.y, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
+      const int q2 = q_index_i(v.z, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q3 = q_index_i(v.w, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
+      reinterpret_cast<unsigned*>(smem)[i] = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+      // K % 256 == 0 (host check): a wave's 64 float4s never straddle a row and the trip count is a multiple of
+      // 64, so every wave is fully active here
+      const int part = wave_sum_dpp(q0 + q1 + q2 + q3);
+      if (lane == 0) atomicAdd(&s_rs[(i << 2) / K], part);
     }
+  } else {
+    const v4i* src = reinterpret_cast<const v4i*>(g.a);
+    v4i* dst = reinterpret_cast<v4i*>(smem);
+    for (int i = threadIdx.x; i < M * kchunks; i += GV2_THREADS) dst[i] = src[i];
+    if (threadIdx.x < M) s_rs[threadIdx.x] = g.a_rowsum ? g.a_rowsum[threadIdx.x] : 0;
+  }
+  __syncthreads();
+  if (row0 >= row_end) return;
+
+  // ---- dot products, DPP reduction and epilogue per completed row ---------------------------------------
+  const int nslots = (row_end - row0 + GV2_WAVES - 1) / GV2_WAVES;   // rows of this wave
+  for (int mb = 0; mb < M; mb += MT) {
+    int acc[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) acc[m] = 0;
+    int t = 0, j = 0;
+    if (mb > 0) issue_pass(0, 0);                                  // M > MT: weights are re-streamed (L2) per token group
+    while (t < nslots) {
+      int t2 = t, j2 = j;
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) acc[m][r] = wave_sum(acc[m][r]);
-    if (lane == 0) {
+      for (int u = 0; u < GV2_INFLIGHT; ++u) {
+        if (t2 < nslots) {                                         // wave-uniform
+          int c = lane + 64 * j2;
+          c = c < kchunks ? c : kchunks - 1;                       // buf[u] is zero there
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (mb + m >= M) break;
-        const int rs = FUSEQ ? s_rs[mb + m] : (g.a_rowsum ? g.a_rowsum[mb + m] : 0);
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const int n = n0 + r;
-          if (n >= N) break;
-          const int t = (int)((unsigned)acc[m][r] - (unsigned)g.w_zp[n] * (unsigned)rs + (unsigned)g.col_term[n]);
-          float f = __fadd_rn(__fmul_rn((float)t, g.alpha[n]), g.bias ? g.bias[n] : 0.f);
-          const size_t idx = (size_t)(mb + m) * N + n;
-          if (outq) {
-            float q = rintf(f * inv_so) + oo;
-            q = fminf(fmaxf(q, g.out_qmin), g.out_qmax);
-            switch (g.out_dtype) {
-              case MQ_F32: reinterpret_cast<float*>(g.out)[idx] = __fmul_rn(__fsub_rn(q, oo), so); break;
-              case MQ_F16: reinterpret_cast<__half*>(g.out)[idx] = __float2half_rn(__fmul_rn(__fsub_rn(q, oo), so)); break;
-              case MQ_U8: reinterpret_cast<uint8_t*>(g.out)[idx] = (uint8_t)(int)q; break;
-              case MQ_I8: reinterpret_cast<int8_t*>(g.out)[idx] = (int8_t)((int)q - (g.out_qmin == 0.f ? 128 : 0)); break;
-              case MQ_U16: reinterpret_cast<uint16_t*>(g.out)[idx] = (uint16_t)(int)q; break;
-              default: reinterpret_cast<int16_t*>(g.out)[idx] = (int16_t)(int)q; break;
+          for (int m = 0; m < MT; ++m) {
+            if (mb + m < M) {
+              const v4i av = *reinterpret_cast<const v4i*>(smem + (size_t)(mb + m) * K + c * 16);
+              acc[m] = dot16(buf[u], av, acc[m]);
             }
-          } else if (g.out_dtype == MQ_F32) {
-            reinterpret_cast<float*>(g.out)[idx] = f;
-          } else {
-            reinterpret_cast<__half*>(g.out)[idx] = __float2half_rn(f);
           }
+          if (j2 == cpl - 1) {                                     // row slot t2 complete
+            const int row = row0 + GV2_WAVES * t2;
+            const float alpha = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p_alpha), t2));
+            const float bias = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p_bias), t2));
+            const int zp = __builtin_amdgcn_readlane(p_zp, t2), ct = __builtin_amdgcn_readlane(p_ct, t2);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const int sum = wave_sum_dpp(acc[m]);
+              acc[m] = 0;
+              if (mb + m < M && lane == 0) {
+                const int tt = (int)((unsigned)sum - (unsigned)zp * (unsigned)s_rs[mb + m] + (unsigned)ct);
+                const float f = __fadd_rn(__fmul_rn((float)tt, alpha), bias);
+                const size_t idx = (size_t)(mb + m) * N + row;
+                if (outq) {
+                  float q = rintf(f * inv_so) + oo;
+                  q = fminf(fmaxf(q, g.out_qmin), g.out_qmax);
+                  switch (g.out_dtype) {
+                    case MQ_F32: reinterpret_cast<float*>(g.out)[idx] = __fmul_rn(__fsub_rn(q, oo), so); break;
+                    case MQ_F16: reinterpret_cast<__half*>(g.out)[idx] = __float2half_rn(__fmul_rn(__fsub_rn(q, oo), so)); break;
+                    case MQ_U8: reinterpret_cast<uint8_t*>(g.out)[idx] = (uint8_t)(int)q; break;
+                    case MQ_I8: reinterpret_cast<int8_t*>(g.out)[idx] = (int8_t)((int)q - (g.out_qmin == 0.f ? 128 : 0)); break;
+                    case MQ_U16: reinterpret_cast<uint16_t*>(g.out)[idx] = (uint16_t)(int)q; break;
+                    default: reinterpret_cast<int16_t*>(g.out)[idx] = (int16_t)(int)q; break;
+                  }
+                } else if (g.out_dtype == MQ_F32) {
+                  reinterpret_cast<float*>(g.out)[idx] = f;
+                } else {
+                  reinterpret_cast<__half*>(g.out)[idx] = __float2half_rn(f);
+                }
+              }
+            }
+          }
+          if (++j2 == cpl) { j2 = 0; ++t2; }
         }
       }
+      t = t2;
+      j = j2;
+      if (t < nslots) issue_pass(t, j);                            // next pass (matrices beyond 8 loads per lane)
     }
   }
 }
@@ -158,17 +189,27 @@ __global__ void __launch_bounds__(256) gemv_i8_kernel(const GemvArgs g) {
 // Called by mq_w8a8_linear / mq_w8a8_linear_f32in for decode shapes (argument checks already done there).
 int run_gemv(const GemvArgs& g, hipStream_t st) {
   const bool fuse = g.x_f32 != nullptr;
-  const size_t lds = (size_t)g.M * g.K + (fuse ? 64 : 0);
+  const size_t lds = (size_t)g.M * g.K + 64;
   if (lds > 64 * 1024 || (fuse && g.K < 256)) {
     set_error("mq_w8a8_linear (decode path): M*K = %zu bytes of activations exceed the 64 KiB staging buffer", lds);
     return MQ_EUNSUPPORTED;
   }
-  constexpr int ROWS = 2;
-  const unsigned grid = (unsigned)((g.N + 4 * ROWS - 1) / (4 * ROWS));
-#define MQ_GV(MT)                                                            \
-  do {                                                                       \
-    if (fuse) gemv_i8_kernel<MT, ROWS, true><<<grid, 256, lds, st>>>(g);    \
-    else gemv_i8_kernel<MT, ROWS, false><<<grid, 256, lds, st>>>(g);        \
+  // one fat workgroup per CU; a wave keeps at most 64 row slots (their parameters live one per lane)
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  int rows_per_wg = (g.N + cus - 1) / cus;
+  if (rows_per_wg > GV2_WAVES * 64) rows_per_wg = GV2_WAVES * 64;
+  const unsigned grid = (unsigned)((g.N + rows_per_wg - 1) / rows_per_wg);
+  const size_t lds_bytes = (size_t)g.M * g.K + 64;
+#define MQ_GV(MT)                                                                                      \
+  do {                                                                                                 \
+    if (fuse) gemv_i8_fat_kernel<MT, true><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);     \
+    else gemv_i8_fat_kernel<MT, false><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);         \
   } while (0)
   if (g.M == 1) MQ_GV(1);
   else if (g.M == 2) MQ_GV(2);

@@ -499,7 +499,11 @@ def test_decode_gemv_path_exact(dev, M):
     """M <= 8 takes the weight-streaming GEMV kernel (mq_gemv.hip): same exact contraction and epilogue."""
     from mobilequant_amd._lib import MQ_U8
     rng = np.random.default_rng(100 + M)
-    for N, K in ((2048, 2048), (256, 2048), (2048, 5632), (180, 256)):
+    # incl. several load passes per wave (32772 rows: 9 row slots x 2 chunks; K = 8192: 8 chunks per lane), a partially
+    # filled last chunk slot (K = 1152 = 72 chunks) and row counts that do not divide over the workgroups
+    for N, K in ((2048, 2048), (256, 2048), (2048, 5632), (180, 256), (32772, 2048), (512, 8192), (4100, 1152)):
+        if M in (2, 5) and N == 32772:
+            continue
         qa, qw, za, zw, sa, sw, bias = _int_problem(rng, M, N, K, per_row=(N != 256))
         _, want = O.qlinear_int_exact(qa, za, sa, qw, zw, sw, bias)
         got = _run_int8(dev, qa, qw, za, zw, sa, sw, bias, 128).detach().cpu().numpy()
@@ -517,7 +521,7 @@ def test_decode_fused_quantize_gemv(dev):
     from mobilequant_amd import ops
     from mobilequant_amd._lib import MQ_I8
     rng = np.random.default_rng(77)
-    for M, N, K in ((1, 2048, 2048), (4, 256, 2048), (8, 2048, 5632), (3, 180, 256)):
+    for M, N, K in ((1, 2048, 2048), (4, 256, 2048), (8, 2048, 5632), (3, 180, 256), (2, 4100, 1280), (1, 32772, 2048), (5, 512, 8192)):
         x = T(rng.standard_normal((M, K), dtype=F32) * 2, dev)
         w8 = T(rng.integers(-128, 128, size=(N, K)).astype(np.int8), dev)
         aq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
