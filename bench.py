@@ -264,7 +264,7 @@ def cpu_baseline():
                       f"fake-quant) at M={M},K={K},N={N}; numpy elementwise on 1 thread, OpenBLAS GEMM on {blas_threads}"}
 
 
-def bench_decode(dev, tokens=20):
+def bench_decode(dev, w4=False):
     """TinyLlama-1.1B decode, linears only: per layer quantize(x) -> GEMV qkv (2048->2560) -> quantize -> GEMV o
     (2048->2048) -> quantize -> GEMV w1|w3 (2048->11264) -> quantize -> GEMV w2 (5632->2048), 22 layers with their own
     int8 weights (0.97 GB streamed per token), one hipGraph per token.  Attention, norms and sampling are outside the
@@ -280,10 +280,17 @@ def bench_decode(dev, tokens=20):
     for _ in range(22):
         lw = []
         for Kk, Nn in shapes:
-            w8 = torch.randint(-128, 128, (Nn, Kk), dtype=torch.int8, generator=g).to(dev)
-            colsum = w8.to(torch.int32).sum(1).to(torch.int32)
-            wscale = torch.full((1,), 2e-4, device=dev); woff = torch.full((1,), 128.0, device=dev)
-            alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, 128, wscale, woff, 128, colsum, Kk)
+            if w4:      # packed unsigned nibbles, zero point 8
+                nib = torch.randint(0, 16, (Nn, Kk), dtype=torch.uint8, generator=g).to(dev)
+                colsum = nib.to(torch.int32).sum(1).to(torch.int32)
+                w8 = ops.pack_w4(nib)
+                wscale = torch.full((1,), 3e-3, device=dev); woff = torch.full((1,), 8.0, device=dev)
+                alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, 128, wscale, woff, 0, colsum, Kk)
+            else:
+                w8 = torch.randint(-128, 128, (Nn, Kk), dtype=torch.int8, generator=g).to(dev)
+                colsum = w8.to(torch.int32).sum(1).to(torch.int32)
+                wscale = torch.full((1,), 2e-4, device=dev); woff = torch.full((1,), 128.0, device=dev)
+                alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, 128, wscale, woff, 128, colsum, Kk)
             lw.append((w8, alpha, wzp, ct, torch.empty(1, Nn, device=dev)))
         layers.append(lw)
     xs = {2048: torch.randn(1, 2048, device=dev), 5632: torch.randn(1, 5632, device=dev)}
@@ -296,12 +303,12 @@ def bench_decode(dev, tokens=20):
         for lw in layers:
             for (Kk, Nn), (w8, alpha, wzp, ct, out) in zip(shapes, lw):
                 ops.int8_linear_f32in(xs[Kk], aq.scale, aq.offset, 0.0, 255.0, 128, w8, alpha, wzp, ct, None, out_scale=oq.scale,
-                                      out_offset=oq.offset, out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_F32, out=out)
+                                      out_offset=oq.offset, out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_F32, out=out, w4=w4)
     t = event_time(token, 1)      # graph of one token, best of 5 replays
-    wbytes = 22 * sum(Kk * Nn for Kk, Nn in shapes)
+    wbytes = 22 * sum(Kk * Nn for Kk, Nn in shapes) // (2 if w4 else 1)
     return {"decode_tok_s": round(1.0 / t, 1), "ms_per_token": round(t * 1e3, 4), "weight_GB_per_token": round(wbytes / 1e9, 4),
             "achieved_GBps": round(wbytes / t / 1e9, 1), "peak_GBps": 8000.0, "kernels_per_token": 22 * 4,
-            "scope": "linears only (22 layers x [qkv, o, w1|w3, w2] W8A8 GEMV with the activation quantize fused in), batch 1, hipGraph"}
+            "scope": "linears only (22 layers x [qkv, o, w1|w3, w2] %s GEMV with the activation quantize fused in), batch 1, hipGraph" % ("W4A8" if w4 else "W8A8")}
 
 
 def bench_calibration(args, rank, world, dev):
@@ -402,6 +409,8 @@ def main():
             extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
                                             "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
             decode = bench_decode(dev)
+            torch.cuda.empty_cache()
+            extras["decode_w4a8"] = bench_decode(dev, w4=True)      # the reference's deployment mode: 4-bit weights
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline()
 

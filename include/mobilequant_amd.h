@@ -162,6 +162,15 @@ int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t 
                    const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
                    mq_stream_t stream);
 
+/* W4A8 decode shapes: mq_w4a8_linear itself streams the packed nibbles through the GEMV kernel for M <= 8 (half the
+ * weight bytes of W8 per token); mq_w4a8_linear_f32in is mq_w8a8_linear_f32in for packed 4-bit weights (same shape
+ * limits, K % 256 == 0).  This is the reference's deployment mode (W4A8 LLaMA-1.1B) at decode time. */
+int mq_w4a8_linear_f32in(const float* x, const float* a_scale, const float* a_offset, float a_qmin,
+                         float a_qmax, int a_shift, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K,
+                         const float* alpha, const int32_t* w_zp, const int32_t* col_term,
+                         const float* bias, const float* out_scale, const float* out_offset,
+                         float out_qmin, float out_qmax, void* out, int out_dtype, mq_stream_t stream);
+
 /* Tuning/diagnostic knob: force a GEMM tile configuration (see DESIGN.md "GEMM variants").
  * variant < 0 restores the built-in heuristic.  Returns the number of variants. */
 int mq_gemm_set_variant(int variant);

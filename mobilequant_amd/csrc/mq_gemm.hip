@@ -794,7 +794,7 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
       return MQ_EINVAL;
     }
     GemvArgs v{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-               out_qmin, out_qmax, out, out_dtype, nullptr, nullptr, nullptr, 0.f, 0.f, 0};
+               out_qmin, out_qmax, out, out_dtype, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0};
     return run_gemv(v, as_stream(stream));
   }
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
@@ -802,26 +802,43 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
   return run_gemm<false>(g, as_stream(stream));
 }
 
+static int linear_f32in(const char* fn, int w4, const float* x, const float* a_scale, const float* a_offset, float a_qmin,
+                        float a_qmax, int a_shift, const void* w, int64_t M, int64_t N, int64_t K, const float* alpha,
+                        const int32_t* w_zp, const int32_t* col_term, const float* bias, const float* out_scale,
+                        const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
+                        mq_stream_t stream) {
+  int rc = check_common(fn, x, w, M, N, K, nullptr, alpha, w_zp, col_term, bias, out_scale, out_offset, out, w4 ? 2 : 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(a_scale && a_offset, "%s: null activation grid", fn);
+  if (!(M <= 8 && M * K <= 64 * 1024 - 64 && K % 256 == 0)) {
+    set_error("%s: decode shapes only (M <= 8, M*K < 64 KiB, K %% 256 == 0); use mq_quantize + the int8-input entry point", fn);
+    return MQ_EUNSUPPORTED;
+  }
+  if (out_scale == nullptr && out_dtype != MQ_F32 && out_dtype != MQ_F16) {
+    set_error("%s: integer out_dtype %d needs an output quantizer", fn, out_dtype);
+    return MQ_EINVAL;
+  }
+  GemvArgs v{nullptr, (const int8_t*)w, (int)M, (int)N, (int)K, nullptr, alpha, w_zp, col_term, bias, out_scale, out_offset,
+             out_qmin, out_qmax, out, out_dtype, x, a_scale, a_offset, a_qmin, a_qmax, a_shift, w4};
+  return run_gemv(v, as_stream(stream));
+}
+
 int mq_w8a8_linear_f32in(const float* x, const float* a_scale, const float* a_offset, float a_qmin, float a_qmax,
                          int a_shift, const int8_t* w, int64_t M, int64_t N, int64_t K, const float* alpha,
                          const int32_t* w_zp, const int32_t* col_term, const float* bias, const float* out_scale,
                          const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
                          mq_stream_t stream) {
-  int rc = check_common("mq_w8a8_linear_f32in", x, w, M, N, K, nullptr, alpha, w_zp, col_term, bias, out_scale,
-                        out_offset, out, 1);
-  if (rc != MQ_OK) return rc;
-  MQ_REQUIRE(a_scale && a_offset, "mq_w8a8_linear_f32in: null activation grid");
-  if (!(M <= 8 && M * K <= 64 * 1024 - 64 && K % 256 == 0)) {
-    set_error("mq_w8a8_linear_f32in: decode shapes only (M <= 8, M*K < 64 KiB, K %% 256 == 0); use mq_quantize + mq_w8a8_linear");
-    return MQ_EUNSUPPORTED;
-  }
-  if (out_scale == nullptr && out_dtype != MQ_F32 && out_dtype != MQ_F16) {
-    set_error("mq_w8a8_linear_f32in: integer out_dtype %d needs an output quantizer", out_dtype);
-    return MQ_EINVAL;
-  }
-  GemvArgs v{nullptr, w, (int)M, (int)N, (int)K, nullptr, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, x, a_scale, a_offset, a_qmin, a_qmax, a_shift};
-  return run_gemv(v, as_stream(stream));
+  return linear_f32in("mq_w8a8_linear_f32in", 0, x, a_scale, a_offset, a_qmin, a_qmax, a_shift, w, M, N, K, alpha, w_zp,
+                      col_term, bias, out_scale, out_offset, out_qmin, out_qmax, out, out_dtype, stream);
+}
+
+int mq_w4a8_linear_f32in(const float* x, const float* a_scale, const float* a_offset, float a_qmin, float a_qmax,
+                         int a_shift, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const float* alpha,
+                         const int32_t* w_zp, const int32_t* col_term, const float* bias, const float* out_scale,
+                         const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
+                         mq_stream_t stream) {
+  return linear_f32in("mq_w4a8_linear_f32in", 1, x, a_scale, a_offset, a_qmin, a_qmax, a_shift, w_packed, M, N, K, alpha,
+                      w_zp, col_term, bias, out_scale, out_offset, out_qmin, out_qmax, out, out_dtype, stream);
 }
 
 int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
@@ -831,6 +848,15 @@ int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t 
   int rc = check_common("mq_w4a8_linear", a, w_packed, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale,
                         out_offset, out, 2);
   if (rc != MQ_OK) return rc;
+  if (M <= 8 && M * K <= 64 * 1024 - 64 && g_forced_variant < 0) {   // decode shapes: nibble-streaming GEMV (mq_gemv.hip)
+    if (out_scale == nullptr && out_dtype != MQ_F32 && out_dtype != MQ_F16) {
+      set_error("mq_w4a8_linear: integer out_dtype %d needs an output quantizer", out_dtype);
+      return MQ_EINVAL;
+    }
+    GemvArgs v{a, (const int8_t*)w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale,
+               out_offset, out_qmin, out_qmax, out, out_dtype, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 1};
+    return run_gemv(v, as_stream(stream));
+  }
   GemmArgs g{a, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
              out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, g_dbg_ts};
   return run_gemm<true>(g, as_stream(stream));

@@ -24,6 +24,7 @@ struct GemvArgs {
   const float* xq_offset;
   float xq_qmin, xq_qmax;
   int xq_shift;
+  int w4;   // weights are packed unsigned nibbles (mq_pack_w4 layout), row stride K/2 bytes
 };
 
 int run_gemv(const GemvArgs& g, hipStream_t st);

@@ -52,14 +52,16 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
 
 constexpr int GV2_THREADS = 1024, GV2_WAVES = 16, GV2_INFLIGHT = 8;
 
-template <int MT, bool FUSEQ>
+template <int MT, bool FUSEQ, bool W4>
 __global__ void __launch_bounds__(GV2_THREADS) gemv_i8_fat_kernel(const GemvArgs g, const int rows_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [M][K] int8 activations, then M row sums
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = g.K, N = g.N, M = g.M;
-  const int kchunks = K >> 4;
-  const int cpl = (kchunks + 63) >> 6;                            // 16-byte chunks per lane per row
+  // a 16-byte weight chunk covers 16 k (int8) or 32 k (packed nibbles: low = k 0..15, high = k 16..31 of the block)
+  const int kchunks = W4 ? K >> 5 : K >> 4;
+  const int wrow = W4 ? K >> 1 : K;                               // weight row stride in bytes
+  const int cpl = (kchunks + 63) >> 6;                            // chunks per lane per row
   int* s_rs = reinterpret_cast<int*>(smem + (size_t)M * K);
   const int row0 = blockIdx.x * rows_per_wg + wave;               // this wave's rows: row0 + 16 t
   const int row_end = (blockIdx.x + 1) * rows_per_wg < N ? (blockIdx.x + 1) * rows_per_wg : N;
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(GV2_THREADS) gemv_i8_fat_kernel(const GemvArgs
       const int row = row0 + GV2_WAVES * t;
       const int c = lane + 64 * j;
       if (row < row_end && c < kchunks)
-        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * K) + c);
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * wrow) + c);
       else
         buf[u] = v4i{0, 0, 0, 0};
       if (++j == cpl) { j = 0; ++t; }
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(GV2_THREADS) gemv_i8_fat_kernel(const GemvArgs
   } else {
     const v4i* src = reinterpret_cast<const v4i*>(g.a);
     v4i* dst = reinterpret_cast<v4i*>(smem);
-    for (int i = threadIdx.x; i < M * kchunks; i += GV2_THREADS) dst[i] = src[i];
+    for (int i = threadIdx.x; i < M * (K >> 4); i += GV2_THREADS) dst[i] = src[i];
     if (threadIdx.x < M) s_rs[threadIdx.x] = g.a_rowsum ? g.a_rowsum[threadIdx.x] : 0;
   }
   __syncthreads();
@@ -140,8 +142,14 @@ __global__ void __launch_bounds__(GV2_THREADS) gemv_i8_fat_kernel(const GemvArgs
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             if (mb + m < M) {
-              const v4i av = *reinterpret_cast<const v4i*>(smem + (size_t)(mb + m) * K + c * 16);
-              acc[m] = dot16(buf[u], av, acc[m]);
+              if constexpr (W4) {
+                const v4i* ap = reinterpret_cast<const v4i*>(smem + (size_t)(mb + m) * K + c * 32);
+                const v4i lo = buf[u] & 0x0f0f0f0f, hi = (buf[u] >> 4) & 0x0f0f0f0f;
+                acc[m] = dot16(hi, ap[1], dot16(lo, ap[0], acc[m]));
+              } else {
+                const v4i av = *reinterpret_cast<const v4i*>(smem + (size_t)(mb + m) * K + c * 16);
+                acc[m] = dot16(buf[u], av, acc[m]);
+              }
             }
           }
           if (j2 == cpl - 1) {                                     // row slot t2 complete
@@ -206,10 +214,15 @@ int run_gemv(const GemvArgs& g, hipStream_t st) {
   if (rows_per_wg > GV2_WAVES * 64) rows_per_wg = GV2_WAVES * 64;
   const unsigned grid = (unsigned)((g.N + rows_per_wg - 1) / rows_per_wg);
   const size_t lds_bytes = (size_t)g.M * g.K + 64;
-#define MQ_GV(MT)                                                                                      \
-  do {                                                                                                 \
-    if (fuse) gemv_i8_fat_kernel<MT, true><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);     \
-    else gemv_i8_fat_kernel<MT, false><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);         \
+#define MQ_GV(MT)                                                                                              \
+  do {                                                                                                         \
+    if (g.w4) {                                                                                                \
+      if (fuse) gemv_i8_fat_kernel<MT, true, true><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);     \
+      else gemv_i8_fat_kernel<MT, false, true><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);         \
+    } else {                                                                                                   \
+      if (fuse) gemv_i8_fat_kernel<MT, true, false><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);    \
+      else gemv_i8_fat_kernel<MT, false, false><<<grid, GV2_THREADS, lds_bytes, st>>>(g, rows_per_wg);        \
+    }                                                                                                          \
   } while (0)
   if (g.M == 1) MQ_GV(1);
   else if (g.M == 2) MQ_GV(2);

@@ -198,8 +198,9 @@ def decode_shape(M: int, K: int) -> bool:
 
 def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qmax: float, a_shift: int, w_q: torch.Tensor,
                       alpha, w_zp, col_term, bias=None, *, out_scale=None, out_offset=None, out_qmin: float = 0.0,
-                      out_qmax: float = 255.0, out_dtype: int = MQ_F32, out: Optional[torch.Tensor] = None):
-    """Decode-shape QLinear in ONE kernel: fp32 activations are quantised inside the GEMV (M <= 8)."""
+                      out_qmax: float = 255.0, out_dtype: int = MQ_F32, out: Optional[torch.Tensor] = None, w4: bool = False):
+    """Decode-shape QLinear in ONE kernel: fp32 activations are quantised inside the GEMV (M <= 8).
+    w4: w_q holds packed nibbles ([N, K/2], pack_w4)."""
     x2d = _f32(_dev(x2d, "x"), "x")
     M, K = x2d.shape
     N = w_q.shape[0]
@@ -209,7 +210,7 @@ def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qma
     b = _f32(bias, "bias") if bias is not None else None
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
-    _lib.call("mq_w8a8_linear_f32in", x2d.data_ptr(), sa.data_ptr(), oa.data_ptr(), float(a_qmin), float(a_qmax), int(a_shift),
+    _lib.call("mq_w4a8_linear_f32in" if w4 else "mq_w8a8_linear_f32in", x2d.data_ptr(), sa.data_ptr(), oa.data_ptr(), float(a_qmin), float(a_qmax), int(a_shift),
               w_q.data_ptr(), M, N, K, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
               b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
               oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype,

@@ -404,7 +404,7 @@ class QLinear(nn.Linear, _QuantizedOp):
         if grid.scale.device != x.device:
             grid.scale.data, grid.offset.data = grid.scale.to(x.device), grid.offset.to(x.device)
         x2d = x.reshape(-1, K)
-        decode = (not plan["w4"]) and x.dtype == torch.float32 and ops.decode_shape(x2d.shape[0], K)
+        decode = x.dtype == torch.float32 and ops.decode_shape(x2d.shape[0], K)
         a_shift = 128 if grid.qmax > 127 else 0
         if not decode:
             a_q, a_rs, a_shift = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
@@ -422,7 +422,7 @@ class QLinear(nn.Linear, _QuantizedOp):
                 x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift, plan["w"], plan["alpha"],
                 plan["w_zp"], plan["col_term"], bias, out_scale=oq.scale.detach() if fused else None,
                 out_offset=oq.offset.detach() if fused else None, out_qmin=oq.qmin if fused else 0.0,
-                out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32)
+                out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, w4=plan["w4"])
             return out.reshape(*x.shape[:-1], N)
         out = ops.int8_linear(
             a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,

@@ -569,6 +569,46 @@ def test_w4a8_gemm_and_packing(dev):
         assert np.array_equal(bits(got), bits(want)), (M, N, K, qmin)
 
 
+def test_w4a8_decode_gemv(dev):
+    """M <= 8 with packed 4-bit weights: nibble-streaming GEMV == exact integer oracle; the fused-quantize entry point ==
+    mq_quantize + mq_w4a8_linear bit for bit; a W4A8 QLinear decode row == the same row of its prefill (MFMA) forward."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_I8
+    rng = np.random.default_rng(12)
+    for (M, N, K), qmin in (((1, 2048, 2048), 0), ((3, 180, 256), -8), ((8, 2048, 5632), 0), ((2, 4100, 1280), 0), ((1, 32772, 2048), -8)):
+        qa = rng.integers(0, 256, size=(M, K))
+        qw = rng.integers(qmin, qmin + 16, size=(N, K))
+        za = int(rng.integers(0, 256))
+        zw = np.zeros(N, np.int64) if qmin < 0 else rng.integers(0, 16, size=N)
+        sa, sw = F32(0.03), (rng.random(N, dtype=F32) * F32(1e-2) + F32(1e-3))
+        bias = rng.standard_normal(N, dtype=F32)
+        _, want = O.qlinear_int_exact(qa, za, sa, qw, zw, sw, bias)
+        packed = ops.pack_w4(T((qw - qmin).astype(np.uint8), dev))
+        a8 = T((qa - 128).astype(np.int8), dev)
+        rs = T((qa - 128).sum(1).astype(np.int32), dev)
+        colsum = T((qw - qmin).sum(1).astype(np.int32), dev)
+        a_s, a_o = T(np.array([sa], F32), dev), T(np.array([za], F32), dev)
+        alpha, wzp, ct = ops.linear_epilogue_prepare(a_s, a_o, 128, T(sw, dev), T(zw.astype(F32), dev), qmin, colsum, K)
+        got = ops.int8_linear(a8, packed, rs, alpha, wzp, ct, T(bias, dev), w4=True)
+        assert np.array_equal(bits(got.detach().cpu().numpy()), bits(want)), (M, N, K, qmin)
+        if K % 256 == 0:
+            x = T(((qa - za) * sa).astype(F32), dev)              # dequantised grid points: re-quantise to qa exactly
+            fused = ops.int8_linear_f32in(x, a_s, a_o, 0.0, 255.0, 128, packed, alpha, wzp, ct, T(bias, dev), w4=True)
+            assert torch.equal(fused, got), (M, N, K, qmin)
+    # module: W4A8 QLinear, decode row vs prefill row
+    lin = torch.nn.Linear(2048, 512, bias=True).to(dev)
+    a8c = mq.QuantConfig(bitwidth=8)
+    ql = mq.QLinear.from_float(lin, a8c, mq.QuantConfig(bitwidth=4, is_per_channel=True, is_symmetric=True), a8c).requires_grad_(False)
+    xs = torch.randn(1, 64, 2048, device=dev)
+    ql.set_scale_offset({"input": [float(xs.min()), float(xs.max())], "output": [-3.0, 3.0]}, "buffer")
+    with torch.no_grad():
+        full = ql(xs)
+        one = ql(xs[:, 9:10, :])
+    assert ql._plan is not None and ql._plan["w4"]
+    assert torch.equal(one, full[:, 9:10, :])
+
+
 # ---- QLinear module: the reference's frozen outputs ------------------------------------------------------
 def _build_qlinear(m, z, dev, int8):
     import mobilequant_amd as mq
