@@ -449,6 +449,39 @@ def test_int8_gemm_tinyllama_shapes_full_m(dev, N, K):
     assert np.array_equal(acc.sum(1), want_rowsum)
 
 
+@pytest.mark.parametrize("N,K,wbits,sym", [
+    (2048, 2048, 8, False), (5632, 2048, 8, False), (2048, 5632, 8, False),           # StableLM-2 (BASELINE configs[2])
+    (16384, 2048, 4, True), (2048, 16384, 4, True), (2048, 2048, 4, False), (256, 2048, 4, False)])   # Gemma W4A8 (configs[3])
+def test_per_channel_and_w4_configs_full_m(dev, N, K, wbits, sym):
+    """BASELINE.json configs[2] (per-channel W8 + bias) and configs[3] (packed per-channel W4, symmetric and
+    asymmetric) at M = 2048: sampled rows bit-exact against the integer oracle."""
+    from mobilequant_amd import ops
+    M = 2048
+    rng = np.random.default_rng(N * 3 + K + wbits)
+    qa = rng.integers(0, 256, size=(M, K))
+    za = int(rng.integers(0, 256))
+    sa = F32(0.02)
+    bias = rng.standard_normal(N, dtype=F32)
+    sw = rng.random(N, dtype=F32) * F32(1e-3) + F32(1e-4)
+    rows = np.unique(np.concatenate(([0, 255, 256, 2047], rng.integers(0, M, 8))))
+    if wbits == 8:
+        qw = rng.integers(0, 256, size=(N, K))
+        zw = rng.integers(0, 256, size=N)
+        got = _run_int8(dev, qa, qw, za, zw, sa, sw, bias, 128)
+    else:
+        qmin = -8 if sym else 0
+        qw = rng.integers(qmin, qmin + 16, size=(N, K))
+        zw = np.zeros(N, np.int64) if sym else rng.integers(0, 16, size=N)
+        packed = ops.pack_w4(T((qw - qmin).astype(np.uint8), dev))
+        colsum = T((qw - qmin).sum(1).astype(np.int32), dev)
+        alpha, wzp, ct = ops.linear_epilogue_prepare(T(np.array([sa], F32), dev), T(np.array([za], F32), dev), 128,
+                                                     T(sw, dev), T(zw.astype(F32), dev), qmin, colsum, K)
+        got = ops.int8_linear(T((qa - 128).astype(np.int8), dev), packed, T((qa - 128).sum(1).astype(np.int32), dev),
+                              alpha, wzp, ct, T(bias, dev), w4=True)
+    _, want = O.qlinear_int_exact(qa[rows], za, sa, qw, zw, sw, bias)
+    assert np.array_equal(bits(got[torch.from_numpy(rows).to(dev)].detach().cpu().numpy()), bits(want))
+
+
 def test_int8_gemm_extreme_k_and_zero_points(dev):
     """Gemma's w2 depth (K = 16384) with worst-case operands: every index at an end of the grid and extreme zero
     points, so the int32 accumulator and the correction terms reach their largest magnitudes -- still exact."""
