@@ -51,6 +51,7 @@ struct GemmArgs {
   int out_dtype;
   int grid_m, grid_n;
   int has_bias;                 // bias == NULL is replaced by a valid dummy pointer on the host
+  int has_rowsum;               // a_rowsum == NULL (caller guarantees w_zp == 0): dummy pointer, element 0 only
   unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
 };
 
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     int m = m0 + wave_m * TM + i * 16 + frow;
-    m = m < M ? m : M - 1;
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
     rs[i] = args.a_rowsum[m];
   }
   // per-n epilogue vectors: global loads first, then the LDS-DMA of the first stage(s); the vectors are parked
@@ -717,7 +718,8 @@ static int pick_variant(int M, int N) {
 template <bool W4>
 static int run_gemm(GemmArgs a, hipStream_t st) {
   const bool outq = a.out_scale != nullptr;
-  if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;                 // only multiplied by w_zp == 0
+  a.has_rowsum = a.a_rowsum != nullptr;
+  if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;                 // element 0 only (M may exceed N); multiplied by w_zp == 0
   if (a.bias == nullptr) a.bias = a.alpha;                            // masked by has_bias
   const int v = pick_variant(a.M, a.N);
   a.grid_m = (a.M + kVariants[v].bm - 1) / kVariants[v].bm;
@@ -798,7 +800,7 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
     return run_gemv(v, as_stream(stream));
   }
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, g_dbg_ts};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
 }
 
@@ -858,7 +860,7 @@ int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t 
     return run_gemv(v, as_stream(stream));
   }
   GemmArgs g{a, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, g_dbg_ts};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, g_dbg_ts};
   return run_gemm<true>(g, as_stream(stream));
 }
 

@@ -8,6 +8,8 @@ from mobilequant_amd import ops, _lib
 from mobilequant_amd._lib import MQ_U8, MQ_F32
 
 dev = torch.device("cuda:0")
+if "--lib" in sys.argv:                      # A/B against another build of the library
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 lib = _lib.load()
 nvar = lib.mq_gemm_set_variant(-1)
 
