@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_
 import torch  # noqa: F401  (must be imported before the shared library is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmobilequant_amd.so")
+# MQ_LIB_PATH: another build of the SAME library (A/B timing of kernel changes); never a fallback implementation
+LIB_PATH = os.environ.get("MQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmobilequant_amd.so")
 
 # dtype codes of enum mq_dtype
 MQ_F32, MQ_F16, MQ_I8, MQ_U8, MQ_I16, MQ_U16, MQ_I32 = range(7)

@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
           const int row = c / CH, ch = c - row * CH;
           const int m = mrow0 + row, n = n0 + wave_n * TN + ch * EPC;
           const v4i val = *reinterpret_cast<const v4i*>(stg + row * ROWP + ch * 16);
-          if (m < M && n < N) *reinterpret_cast<v4i*>(outp + (size_t)m * N + n) = val;
+          if (m < M && n < N) __builtin_nontemporal_store(val, reinterpret_cast<v4i*>(outp + (size_t)m * N + n));
         }
       }
     } else {
