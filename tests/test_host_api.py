@@ -119,3 +119,22 @@ def test_wire_integer_inputs_uses_calibrated_input_range():
     # the producer (input_layernorm) quantizes its output to exactly this grid
     p = m.layers[0].input_layernorm.output_quantizer
     assert p.scale.item() == g.scale.item() and p.offset.item() == g.offset.item()
+
+
+def test_reference_import_path_alias():
+    """the names the reference's callers import from mobilellm.quantization.qmodule resolve to this package."""
+    import sys
+    import mobilequant_amd as mq
+    saved = {k: v for k, v in sys.modules.items() if k == "mobilellm" or k.startswith("mobilellm.")}
+    try:
+        mq.install_reference_alias()
+        from mobilellm.quantization.qmodule import (QuantConfig, Quantizer, QLinear, QRMSNorm, QLayerNorm, QMatMul, QSiLU,  # noqa: F401
+                                                    QGELU, create_fp_model, export_act_range, create_sim_qmodel,
+                                                    create_weight_only_qmodel, set_scale_and_offset, update_qcfg, export_qcfg)
+        import mobilellm.quantization.qmodule as alias
+        assert alias is mq.quantization.qmodule and QLinear is mq.QLinear
+        assert QuantConfig(bitwidth=8).to_dict()["bitwidth"] == "8"
+    finally:
+        for k in [k for k in sys.modules if k == "mobilellm" or k.startswith("mobilellm.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
