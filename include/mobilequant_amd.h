@@ -73,6 +73,12 @@ int mq_minmax_init(float* min_out, float* max_out, int64_t n, mq_stream_t stream
 /* per-tensor: compute_min_max_from_tensor (qmodule.py:31-33); generate_act_range.py:65 */
 int mq_minmax_tensor(const void* x, int dtype, int64_t numel, float* min_out, float* max_out,
                      mq_stream_t stream);
+/* per-tensor, FRESH statistic: min_out[0] / max_out[0] are OVERWRITTEN with the tensor's min / max (what a dynamic
+ * quantizer or a first-forward weight range needs, qmodule.py:262-277).  Two launches without atomics (per-workgroup
+ * partials into `scratch`, >= 1024 floats of device memory the caller owns for the duration of the call on `stream`,
+ * then a fold) instead of init + up to 1024 contended atomics.  numel == 0 gives (+inf, -inf). */
+int mq_minmax_tensor_fresh(const void* x, int dtype, int64_t numel, float* min_out, float* max_out,
+                           float* scratch, int64_t scratch_floats, mq_stream_t stream);
 /* per-row of a [rows, cols] view -> min_out[rows], max_out[rows] (qmodule.py:27-30, :263-264) */
 int mq_minmax_rows(const void* x, int dtype, int64_t rows, int64_t cols, float* min_out,
                    float* max_out, mq_stream_t stream);

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "mq_scale_offset_from_minmax": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "mq_minmax_init": (c_int, [_P, _P, c_int64, _P]),
     "mq_minmax_tensor": (c_int, [_P, c_int, c_int64, _P, _P, _P]),
+    "mq_minmax_tensor_fresh": (c_int, [_P, c_int, c_int64, _P, _P, _P, c_int64, _P]),
     "mq_minmax_rows": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "mq_minmax_cols": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "mq_fake_quant": (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, _P]),

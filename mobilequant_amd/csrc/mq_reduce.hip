@@ -112,10 +112,11 @@ __device__ __forceinline__ void block_commit(float lo, float hi, float* mn, floa
 
 // per-tensor: grid-stride over 16-byte vectors; `head`/`tail` scalars cover unaligned ends
 template <typename T>
-__global__ void __launch_bounds__(256) minmax_tensor_kernel(const T* __restrict__ x, int64_t numel, int64_t head,
-                                                            int64_t nvec, float* mn, float* mx) {
+__device__ __forceinline__ void stream_minmax(const T* __restrict__ x, int64_t numel, int64_t head, int64_t nvec,
+                                              float& lo, float& hi) {
   using L = Ld16<T>;
-  float lo = __int_as_float(0x7f800000), hi = __int_as_float(0xff800000);
+  lo = __int_as_float(0x7f800000);
+  hi = __int_as_float(0xff800000);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const T* xv = x + head;
@@ -140,7 +141,61 @@ __global__ void __launch_bounds__(256) minmax_tensor_kernel(const T* __restrict_
     lo = min_p(lo, f);
     hi = max_p(hi, f);
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_tensor_kernel(const T* __restrict__ x, int64_t numel, int64_t head,
+                                                            int64_t nvec, float* mn, float* mx) {
+  float lo, hi;
+  stream_minmax<T>(x, numel, head, nvec, lo, hi);
   block_commit(lo, hi, mn, mx);
+}
+
+// Fresh statistic (dynamic quantizers, first-forward weight ranges): every workgroup would improve a statistic that
+// starts at +-inf, i.e. up to 1024 same-address atomics (~12 ns each) behind a 3 us streaming pass.  Two launches
+// without atomics instead: per-workgroup partials into caller scratch, then one workgroup folds them and WRITES the
+// result (no init kernel either).
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_partials_kernel(const T* __restrict__ x, int64_t numel, int64_t head,
+                                                              int64_t nvec, float* __restrict__ partials) {
+  __shared__ float s_lo[4], s_hi[4];
+  float lo, hi;
+  stream_minmax<T>(x, numel, head, nvec, lo, hi);
+  lo = wave_min_p(lo);
+  hi = wave_max_p(hi);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[w] = lo;
+    s_hi[w] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = min_p(min_p(s_lo[0], s_lo[1]), min_p(s_lo[2], s_lo[3]));
+    partials[2 * blockIdx.x + 1] = max_p(max_p(s_hi[0], s_hi[1]), max_p(s_hi[2], s_hi[3]));
+  }
+}
+
+__global__ void __launch_bounds__(256) minmax_fold_kernel(const float* __restrict__ partials, int n, float* mn, float* mx) {
+  __shared__ float s_lo[4], s_hi[4];
+  float lo = __int_as_float(0x7f800000), hi = __int_as_float(0xff800000);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    lo = min_p(lo, partials[2 * i]);
+    hi = max_p(hi, partials[2 * i + 1]);
+  }
+  lo = wave_min_p(lo);
+  hi = wave_max_p(hi);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[w] = lo;
+    s_hi[w] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = min_p(min_p(s_lo[0], s_lo[1]), min_p(s_lo[2], s_lo[3]));
+    hi = max_p(max_p(s_hi[0], s_hi[1]), max_p(s_hi[2], s_hi[3]));
+    mn[0] = (lo != lo) ? __int_as_float(0xffffffff) : (lo <= hi ? canon(lo) : lo);   // same NaN patterns as the atomics
+    mx[0] = (hi != hi) ? __int_as_float(0x7fffffff) : (lo <= hi ? canon(hi) : hi);
+  }
 }
 
 // per-row: one wave per row, 4 rows per workgroup; accumulates into mn[row], mx[row] (plain RMW:
@@ -256,6 +311,26 @@ static int launch_tensor(const T* x, int64_t numel, float* mn, float* mx, hipStr
   return MQ_OK;
 }
 
+constexpr int kFreshMaxBlocks = 512;
+
+template <typename T>
+static int launch_tensor_fresh(const T* x, int64_t numel, float* mn, float* mx, float* scratch, hipStream_t st) {
+  constexpr int N = Ld16<T>::N;
+  int64_t head = 0;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(x);
+  if (a % 16) head = (int64_t)((16 - a % 16) / sizeof(T));
+  if (head > numel) head = numel;
+  const int64_t nvec = (numel - head) / N;
+  int64_t g = (nvec + 1023) / 1024;
+  if (g < 1) g = 1;
+  if (g > kFreshMaxBlocks) g = kFreshMaxBlocks;
+  minmax_partials_kernel<T><<<(unsigned)g, 256, 0, st>>>(x, numel, head, nvec, scratch);
+  MQ_LAUNCH_CHECK("mq_minmax_tensor_fresh");
+  minmax_fold_kernel<<<1, 256, 0, st>>>(scratch, (int)g, mn, mx);
+  MQ_LAUNCH_CHECK("mq_minmax_tensor_fresh(fold)");
+  return MQ_OK;
+}
+
 template <typename T>
 static int launch_cols(const T* x, int64_t rows, int64_t cols, float* mn, float* mx, hipStream_t st) {
   constexpr int N = Ld16<T>::N;
@@ -297,6 +372,18 @@ int mq_minmax_tensor(const void* x, int dtype, int64_t numel, float* min_out, fl
   if (dtype == MQ_F32) return launch_tensor<float>((const float*)x, numel, min_out, max_out, as_stream(stream));
   if (dtype == MQ_F16) return launch_tensor<__half>((const __half*)x, numel, min_out, max_out, as_stream(stream));
   set_error("mq_minmax_tensor: dtype %d not supported", dtype);
+  return MQ_EUNSUPPORTED;
+}
+
+int mq_minmax_tensor_fresh(const void* x, int dtype, int64_t numel, float* min_out, float* max_out, float* scratch,
+                           int64_t scratch_floats, mq_stream_t stream) {
+  MQ_REQUIRE(min_out && max_out && numel >= 0, "mq_minmax_tensor_fresh: bad arguments");
+  if (numel == 0) return mq_minmax_init(min_out, max_out, 1, stream);   // empty tensor: the identity statistic
+  MQ_REQUIRE(x && scratch && scratch_floats >= 2 * kFreshMaxBlocks, "mq_minmax_tensor_fresh: needs %d floats of scratch",
+             2 * kFreshMaxBlocks);
+  if (dtype == MQ_F32) return launch_tensor_fresh<float>((const float*)x, numel, min_out, max_out, scratch, as_stream(stream));
+  if (dtype == MQ_F16) return launch_tensor_fresh<__half>((const __half*)x, numel, min_out, max_out, scratch, as_stream(stream));
+  set_error("mq_minmax_tensor_fresh: dtype %d not supported", dtype);
   return MQ_EUNSUPPORTED;
 }
 

@@ -80,8 +80,12 @@ def minmax_cols_(x2d: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
 
 
 def minmax_tensor(x: torch.Tensor):
-    mn, mx = minmax_new(1, x.device)
-    minmax_tensor_(x, mn, mx)
+    """(min, max) of one tensor as 1-element device tensors: partials + fold, no atomics, no init launch."""
+    x = _dev(x, "x").contiguous()
+    buf = torch.empty(2 + 1024, dtype=torch.float32, device=x.device)     # [min | max | scratch]
+    mn, mx, scratch = buf[0:1], buf[1:2], buf[2:]
+    _lib.call("mq_minmax_tensor_fresh", x.data_ptr(), _fdt(x), x.numel(), mn.data_ptr(), mx.data_ptr(), scratch.data_ptr(),
+              scratch.numel(), _stream())
     return mn, mx
 
 

@@ -38,14 +38,14 @@ for shape in ((2048, 2048), (5632, 2048), (2048, 5632), (16384, 2048)):
     y = torch.empty_like(x)
     sc, of = torch.full((1,), 0.03, device=dev), torch.full((1,), 128.0, device=dev)
 
-    def fresh():
+    def fresh_atomics():
         a, b = ops.minmax_new(1, dev); ops.minmax_tensor_(x, a, b)
-    cases = (("tensor fresh", fresh), ("tensor running", lambda: ops.minmax_tensor_(x, mn, mx)),
+    cases = (("tensor fresh (init+atomics)", fresh_atomics), ("tensor fresh (partials+fold)", lambda: ops.minmax_tensor(x)), ("tensor running", lambda: ops.minmax_tensor_(x, mn, mx)),
              ("rows", lambda: ops.minmax_rows_(x, rmn, rmx)), ("cols", lambda: ops.minmax_cols_(x, cmn, cmx)),
              ("fake_quant (2x bytes)", lambda: ops.fake_quant(x, sc, of, 0, 255, out=y)))
     for name, fn in cases:
         t = timeit(fn)
         b = nbytes * (2 if name.startswith("fake") else 1)
-        print(f"{str(shape):14s} {name:22s} {t:7.2f} us  {b / t / 1e6:5.2f} TB/s")
+        print(f"{str(shape):14s} {name:30s} {t:7.2f} us  {b / t / 1e6:5.2f} TB/s")
     assert mn.item() == x.min().item() and mx.item() == x.max().item()
     assert torch.equal(rmn, x.min(1).values) and torch.equal(cmx, x.max(0).values)
