@@ -301,8 +301,8 @@ __global__ void __launch_bounds__(64 * WM * WN)
     static_assert(NW == 8 && WN == 1 && !W4, "ping-pong schedule: 8 waves stacked along M, int8 weights");
     const int grp = wave >> 2;
     v4i xf[FM], wf[FN];
-    bool skip_reads = false;
-    (void)skip_reads;
+    bool skip_reads = false, skip_a = false;
+    (void)skip_reads; (void)skip_a;
     auto read_unit = [&](int abuf, int wbuf, auto ks_tag) {
       constexpr int ks = decltype(ks_tag)::value;
 #if MQ_PP_PRIO == 2
@@ -316,8 +316,11 @@ __global__ void __launch_bounds__(64 * WM * WN)
       // index goes into the ds_read immediate offset
       const char* xb = smem + abuf * A_BYTES + (ks ? x_off1 : x_off);
       const char* wb = smem + wbuf * W_BYTES + (ks ? w_off1 : w_off);
+      if (!((ABL & 32) && skip_a)) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) xf[i] = *reinterpret_cast<const v4i*>(xb + i * 16 * BK);
+        for (int i = 0; i < FM; ++i) xf[i] = *reinterpret_cast<const v4i*>(xb + i * 16 * BK);
+      }
+      if constexpr (ABL & 32) skip_a = true;
 #pragma unroll
       for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const v4i*>(wb + j * 16 * BK);
     };
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
 #endif
     };
     auto issue_a = [&](int abuf, int kt) {
-      if constexpr (ABL & 1) return;
+      if constexpr (ABL & (1 | 32)) return;        // 32: "A operand leaves the LDS" what-if (no A DMA, no A reads)
 #pragma unroll
       for (int d = 0; d < A_ROUNDS; ++d) issue_one(d, abuf, kt, 0);
     };
@@ -350,6 +353,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
     // wait until at most (a ? A_ROUNDS : 0) + (w ? this wave's W share : 0) DMA pieces are outstanding
     auto leave_in_flight = [&](bool a, bool w) {
       if constexpr (ABL & 1) return;
+      if constexpr (ABL & 32) a = false;           // no A pieces are in flight in that what-if
       if (a && w) {
         if (tail_owner) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROUNDS + W_ROUNDS) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROUNDS + W_ROUNDS - 1) : "memory");
@@ -671,6 +675,7 @@ static int launch_typed(const GemmArgs& a, hipStream_t st) {
       case 18: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 18, PP>(a, LDS, st); else break;
       case 24: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 24, PP>(a, LDS, st); else break;
       case 25: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 25, PP>(a, LDS, st); else break;
+      case 48: if constexpr (PP) return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 48, PP>(a, LDS, st); else break;
       default: break;
     }
   }
