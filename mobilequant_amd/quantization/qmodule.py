@@ -20,6 +20,7 @@ operation order.
 from __future__ import annotations
 
 import math
+import weakref
 from copy import deepcopy
 from dataclasses import dataclass
 from typing import Optional
@@ -331,6 +332,46 @@ def _static_per_tensor(q: Optional[Quantizer], max_bits: int) -> bool:
             and not q.lwc and not q.qcfg.is_per_channel and q._has_grid() and q.scale.numel() == 1)
 
 
+class _SharedActivation:
+    """One-entry memo of the last activation tensor quantised for an int8 linear.  q_proj / k_proj / v_proj (and w1 /
+    w3) are called with the SAME tensor object and the same input grid, so the reference's three (two) identical
+    fake-quant passes collapse into one mq_quantize launch.  The entry is keyed on the tensor OBJECT (weak reference),
+    its version counter and the grid tensors' storage + versions: a different tensor that happens to reuse the
+    address can never hit."""
+
+    def __init__(self):
+        self._ref = None
+        self._key = None
+        self._val = None
+
+    def get(self, x, grid, a_shift_hint):
+        if self._ref is None or self._ref() is not x:
+            return None
+        if self._key != self._make_key(x, grid, a_shift_hint):
+            return None
+        return self._val
+
+    def put(self, x, grid, a_shift_hint, val):
+        try:
+            self._ref = weakref.ref(x)
+        except TypeError:
+            self._ref = None
+            return
+        self._key = self._make_key(x, grid, a_shift_hint)
+        self._val = val
+
+    @staticmethod
+    def _make_key(x, grid, a_shift_hint):
+        return (x._version, x.data_ptr(), tuple(x.shape), x.dtype, grid.scale.data_ptr(), grid.scale._version,
+                grid.offset.data_ptr(), grid.offset._version, grid.qmin, grid.qmax, a_shift_hint)
+
+    def clear(self):
+        self._ref = self._key = self._val = None
+
+
+_shared_activation = _SharedActivation()
+
+
 class QLinear(nn.Linear, _QuantizedOp):
     """``nn.Linear`` with weight / input / output quantizers (reference: qmodule.py:298-405)."""
 
@@ -407,7 +448,11 @@ class QLinear(nn.Linear, _QuantizedOp):
         decode = x.dtype == torch.float32 and ops.decode_shape(x2d.shape[0], K)
         a_shift = 128 if grid.qmax > 127 else 0
         if not decode:
-            a_q, a_rs, a_shift = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
+            hit = _shared_activation.get(x, grid, a_shift)
+            if hit is None:
+                hit = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
+                _shared_activation.put(x, grid, a_shift, hit)
+            a_q, a_rs, a_shift = hit
         epi_key = (grid.scale.data_ptr(), grid.scale._version, grid.offset._version, a_shift)
         if plan["epi_key"] != epi_key:
             plan["alpha"], plan["w_zp"], plan["col_term"] = ops.linear_epilogue_prepare(

@@ -722,6 +722,51 @@ def test_qlinear_int8_cache_invalidation_and_grad_mode(dev):
         assert not odd._int8_ready(xo, odd.weight) and odd(xo).shape == (5, 64)
 
 
+def test_shared_activation_quantised_once(dev):
+    """q_proj / k_proj / v_proj get the same tensor object: one mq_quantize launch serves all three, results identical
+    to three independent forwards; an in-place edit or another tensor at the same address never hits the memo."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd.quantization import qmodule as Q
+    a8 = mq.QuantConfig(bitwidth=8)
+    torch.manual_seed(5)
+    lins = [mq.QLinear.from_float(torch.nn.Linear(256, n, bias=False).to(dev), a8, a8, a8).requires_grad_(False) for n in (256, 64, 64)]
+    x = torch.randn(1, 48, 256, device=dev)
+    for ql in lins:
+        ql.set_scale_offset({"input": [float(x.min()), float(x.max())], "output": [-3.0, 3.0]}, "buffer")
+    grid = lins[0].input_quantizer
+    for ql in lins[1:]:
+        ql.input_quantizer = grid            # one shared input grid, as wire_integer_inputs sets up for q/k/v
+    calls = []
+    real = ops.quantize
+    ops.quantize = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            for ql in lins:                  # weight plans first (they call ops.quantize for the weights)
+                ql(x)
+            Q._shared_activation.clear()
+            calls.clear()
+            outs = [ql(x) for ql in lins]
+            assert len(calls) == 1, calls
+            refs = []
+            for ql in lins:
+                Q._shared_activation.clear()
+                refs.append(ql(x))
+            assert all(torch.equal(a, b) for a, b in zip(outs, refs))
+            calls.clear()
+            x.mul_(0.5)                      # in-place edit: version counter moves, the memo must miss
+            y1 = lins[0](x)
+            assert len(calls) == 1
+            Q._shared_activation.clear()
+            assert torch.equal(y1, lins[0](x))
+            calls.clear()
+            x2 = x.clone()                   # equal content, different object
+            lins[0](x2)
+            assert len(calls) == 1
+    finally:
+        ops.quantize = real
+
+
 def test_toy_lm_w8a8_logits_vs_reference(dev):
     """Two-block toy LM through create_sim_qmodel -> mixed precision -> set_scale_and_offset -> forward,
     simulated path and integer path, against the reference's logits.  Error budget: a handful of
