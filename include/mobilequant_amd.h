@@ -177,6 +177,21 @@ int mq_w4a8_linear_f32in(const float* x, const float* a_scale, const float* a_of
                          const float* bias, const float* out_scale, const float* out_offset,
                          float out_qmin, float out_qmax, void* out, int out_dtype, mq_stream_t stream);
 
+/* ---- a10: QRMSNorm.forward in one pass (qmodule.py:469-530 around hf_model.py:184-195) ---------------------- */
+/* out = Qout( weight * (xi * 1/sqrt(mean(xi^2) + eps)) (+ bias) ),  xi = Qin(x); x, y [rows, cols] fp32, cols % 4 == 0.
+ *   weight [cols] (+ bias [cols], nullable): ALREADY fake-quantised by the caller (weight quantizer, once per weight).
+ *   in_scale/in_offset, out_scale/out_offset: 1 element each, NULL -> that quantizer is absent.
+ *   y (nullable): the fp32 result the reference returns.  q_out (nullable, needs the output quantizer): the same
+ *   result as int8 storage (index - q_shift) plus row_sum (nullable, [rows]) = sum of the stored values per row, i.e.
+ *   exactly what mq_quantize(want row sums) would produce from y -- the consumer linears skip their quantize launch.
+ * Elementwise arithmetic is the reference's op for op; the sum of squares is reduced in another order than torch's,
+ * so an output within ~1e-7 relative of a rounding boundary may land on the neighbouring grid point. */
+int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
+                     float eps, const float* in_scale, const float* in_offset, float in_qmin,
+                     float in_qmax, const float* out_scale, const float* out_offset, float out_qmin,
+                     float out_qmax, float* y, int8_t* q_out, int q_shift, int32_t* row_sum,
+                     mq_stream_t stream);
+
 /* Tuning/diagnostic knob: force a GEMM tile configuration (see DESIGN.md "GEMM variants").
  * variant < 0 restores the built-in heuristic.  Returns the number of variants. */
 int mq_gemm_set_variant(int variant);

@@ -1,0 +1,189 @@
+// QRMSNorm.forward (qmodule.py:469-530 around hf_model.py:184-195) in ONE pass over the activations.
+//
+// Reference op sequence on x [rows, cols] (fp32):
+//   xi  = Qin(x)                                 input quantizer (16-bit per-tensor in every recipe), optional
+//   r   = rsqrt(mean(xi^2, -1) + eps)            x.pow(2).mean(-1, keepdim=True); torch.rsqrt
+//   y   = weight' * (xi * r) (+ bias)            weight' = Qw(weight), fake-quantised once by the caller
+//   out = Qout(y)                                8-bit per-tensor activation grid, optional
+// = 6 elementwise / reduction launches and ~9 passes over the tensor as composite torch ops.  Here a wave owns a
+// row, keeps it in registers (cols <= 4096) or re-reads it (larger), and writes out -- and, when the output grid is
+// an 8-bit one, the int8 indices + row sums the consumer linears (q/k/v, w1/w3) feed to the integer GEMM, so their
+// activation quantize launches disappear (norm -> int8 -> GEMM chaining).
+//
+// Numerics: every elementwise op is the reference's (IEEE divide, round-half-even, separate mul/add; 1/sqrt with
+// correctly rounded sqrt and divide, which is what the CPU reference computes).  The sum of squares is reduced in
+// a different order than torch's (lane-strided partial sums, then a butterfly), so r can differ in the last bit
+// and an output that sits within ~1e-7 relative of a rounding boundary can land on the neighbouring grid point:
+// tests allow 1 LSB on < 0.1 % of the elements.
+#include <hip/hip_fp16.h>
+
+#include "mq_common.h"
+
+namespace mq {
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float nq_clamp_nan(float q, float lo, float hi) {
+  const float c = fminf(fmaxf(q, lo), hi);
+  return q != q ? q : c;
+}
+// qmodule.py:286-290 with round_ste = (round(t) - t) + t, as in mq_elementwise.hip
+__device__ __forceinline__ float nq_index(float x, float s, float o, float qmin, float qmax) {
+  const float t = __fdiv_rn(x, s);
+  const float r = __fadd_rn(__fsub_rn(rintf(t), t), t);
+  return nq_clamp_nan(__fadd_rn(r, o), qmin, qmax);
+}
+__device__ __forceinline__ float nq_dequant(float q, float s, float o) { return __fmul_rn(__fsub_rn(q, o), s); }
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct NormArgs {
+  const float* x;
+  const float* weight;
+  const float* bias;
+  float eps;
+  const float* in_scale;
+  const float* in_offset;
+  float in_qmin, in_qmax;
+  const float* out_scale;
+  const float* out_offset;
+  float out_qmin, out_qmax;
+  float* y;
+  int8_t* q_out;
+  int q_shift;
+  int32_t* row_sum;
+  int64_t rows;
+  int cols;
+};
+
+// V = float4 vectors held per lane (cols <= 256 * V); V == 0: two passes over the row
+template <int V>
+__global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int cols = a.cols, nvec = cols >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(a.x + row * cols);
+  const float4* wv = reinterpret_cast<const float4*>(a.weight);
+  const float4* bv = reinterpret_cast<const float4*>(a.bias);
+  const bool has_in = a.in_scale != nullptr, has_out = a.out_scale != nullptr;
+  float si = 1.f, oi = 0.f, so = 1.f, oo = 0.f;
+  if (has_in) {
+    si = a.in_scale[0];
+    oi = a.in_offset[0];
+  }
+  if (has_out) {
+    so = a.out_scale[0];
+    oo = a.out_offset[0];
+  }
+  auto qin = [&](float v) { return has_in ? nq_dequant(nq_index(v, si, oi, a.in_qmin, a.in_qmax), si, oi) : v; };
+
+  constexpr int VV = V > 0 ? V : 1;
+  float4 xs[VV];
+  float ss = 0.f;
+  if constexpr (V > 0) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int i = lane + 64 * k;
+      if (i < nvec) {
+        float4 v = xr[i];
+        v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
+        xs[k] = v;
+        ss += v.x * v.x;
+        ss += v.y * v.y;
+        ss += v.z * v.z;
+        ss += v.w * v.w;
+      }
+    }
+  } else {
+    for (int i = lane; i < nvec; i += 64) {
+      float4 v = xr[i];
+      v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
+      ss += v.x * v.x;
+      ss += v.y * v.y;
+      ss += v.z * v.z;
+      ss += v.w * v.w;
+    }
+  }
+  ss = wave_sum_f32(ss);
+  const float mean = __fdiv_rn(ss, (float)cols);
+  const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, a.eps)));
+
+  int acc = 0;
+  auto emit = [&](int i, float4 v) {
+    const float4 w = wv[i];
+    float y0 = __fmul_rn(w.x, __fmul_rn(v.x, r)), y1 = __fmul_rn(w.y, __fmul_rn(v.y, r));
+    float y2 = __fmul_rn(w.z, __fmul_rn(v.z, r)), y3 = __fmul_rn(w.w, __fmul_rn(v.w, r));
+    if (bv) {
+      const float4 b = bv[i];
+      y0 = __fadd_rn(y0, b.x); y1 = __fadd_rn(y1, b.y); y2 = __fadd_rn(y2, b.z); y3 = __fadd_rn(y3, b.w);
+    }
+    if (has_out) {
+      const float q0 = nq_index(y0, so, oo, a.out_qmin, a.out_qmax), q1 = nq_index(y1, so, oo, a.out_qmin, a.out_qmax);
+      const float q2 = nq_index(y2, so, oo, a.out_qmin, a.out_qmax), q3 = nq_index(y3, so, oo, a.out_qmin, a.out_qmax);
+      y0 = nq_dequant(q0, so, oo); y1 = nq_dequant(q1, so, oo); y2 = nq_dequant(q2, so, oo); y3 = nq_dequant(q3, so, oo);
+      if (a.q_out) {   // NaN has no integer image: saturate to the grid's low end like mq_quantize
+        const int s0 = (int)fmaxf(q0, a.out_qmin) - a.q_shift, s1 = (int)fmaxf(q1, a.out_qmin) - a.q_shift;
+        const int s2 = (int)fmaxf(q2, a.out_qmin) - a.q_shift, s3 = (int)fmaxf(q3, a.out_qmin) - a.q_shift;
+        acc += (s0 + s1) + (s2 + s3);
+        reinterpret_cast<unsigned*>(a.q_out + row * cols)[i] =
+            (unsigned)(s0 & 0xff) | ((unsigned)(s1 & 0xff) << 8) | ((unsigned)(s2 & 0xff) << 16) | ((unsigned)(s3 & 0xff) << 24);
+      }
+    }
+    if (a.y) reinterpret_cast<float4*>(a.y + row * cols)[i] = make_float4(y0, y1, y2, y3);
+  };
+  if constexpr (V > 0) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int i = lane + 64 * k;
+      if (i < nvec) emit(i, xs[k]);
+    }
+  } else {
+    for (int i = lane; i < nvec; i += 64) {
+      float4 v = xr[i];
+      v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
+      emit(i, v);
+    }
+  }
+  if (a.row_sum) {
+    acc = wave_sum(acc);
+    if (lane == 0) a.row_sum[row] = acc;
+  }
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
+                                const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
+                                const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
+                                int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+  MQ_REQUIRE(x && weight && (y || q_out), "mq_rmsnorm_quant: null pointer");
+  MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= (1 << 20) && (rows + 3) / 4 < (int64_t)0x7fffffff,
+             "mq_rmsnorm_quant: bad shape %lld x %lld (cols must be a multiple of 4)", (long long)rows, (long long)cols);
+  MQ_REQUIRE((in_scale == nullptr) == (in_offset == nullptr) && (out_scale == nullptr) == (out_offset == nullptr),
+             "mq_rmsnorm_quant: scale/offset must both be set or NULL");
+  MQ_REQUIRE(!q_out || out_scale, "mq_rmsnorm_quant: integer output needs an output quantizer");
+  MQ_REQUIRE(!row_sum || q_out, "mq_rmsnorm_quant: row sums are those of the integer output");
+  MQ_REQUIRE(!q_out || (out_qmin - (float)q_shift >= -128.f && out_qmax - (float)q_shift <= 127.f),
+             "mq_rmsnorm_quant: [%g,%g]-%d does not fit int8", out_qmin, out_qmax, q_shift);
+  MQ_REQUIRE(aligned(x, 16) && aligned(weight, 16) && (!bias || aligned(bias, 16)) && (!y || aligned(y, 16)) &&
+                 (!q_out || aligned(q_out, 4)),
+             "mq_rmsnorm_quant: pointers must be 16-byte aligned");
+  if (rows == 0) return MQ_OK;
+  NormArgs a{x, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale, out_offset, out_qmin, out_qmax,
+             y, q_out, q_shift, row_sum, rows, (int)cols};
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  hipStream_t st = as_stream(stream);
+  if (cols <= 256 * 4) rmsnorm_quant_kernel<4><<<grid, 256, 0, st>>>(a);
+  else if (cols <= 256 * 8) rmsnorm_quant_kernel<8><<<grid, 256, 0, st>>>(a);
+  else if (cols <= 256 * 16) rmsnorm_quant_kernel<16><<<grid, 256, 0, st>>>(a);
+  else rmsnorm_quant_kernel<0><<<grid, 256, 0, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_rmsnorm_quant");
+  return MQ_OK;
+}

@@ -240,6 +240,24 @@ class Quantizer(nn.Module):
             self.register_buffer("offset", offset)
         else:
             self.scale, self.offset = scale, offset
+        # Host-side identity of a grid that was set from Python numbers (calibrated ranges out of act_dict.json):
+        # two quantizers built from the same (min, max, bitwidth, symmetry) ARE the same grid even though their
+        # scale tensors are different objects -- what lets a producer hand its integer output to a consumer
+        # (grid_token).  Dropped as soon as scale / offset are touched again.
+        if isinstance(min_val, (int, float)) and isinstance(max_val, (int, float)):
+            self._host_range = (float(min_val), float(max_val), int(self.qcfg.bitwidth), bool(self.qcfg.is_symmetric),
+                                self.scale._version, self.offset._version)
+        else:
+            self._host_range = None
+
+    def grid_token(self):
+        """Hashable identity of the current per-tensor grid: value based when the range came from host numbers and
+        the tensors were not modified since, storage based otherwise."""
+        hr = getattr(self, "_host_range", None)
+        if hr is not None and self._has_grid() and hr[4:] == (self.scale._version, self.offset._version):
+            return ("host",) + hr[:4]
+        return ("dev", self.scale.data_ptr(), self.scale._version, self.offset.data_ptr(), self.offset._version,
+                self.qmin, self.qmax)
 
     def set_scale_offset_from_tensor(self, x, cache_mode=None):
         mn, mx = compute_min_max_from_tensor(x, self.qcfg.is_per_channel, self.qcfg.group_size)
@@ -336,8 +354,8 @@ class _SharedActivation:
     """One-entry memo of the last activation tensor quantised for an int8 linear.  q_proj / k_proj / v_proj (and w1 /
     w3) are called with the SAME tensor object and the same input grid, so the reference's three (two) identical
     fake-quant passes collapse into one mq_quantize launch.  The entry is keyed on the tensor OBJECT (weak reference),
-    its version counter and the grid tensors' storage + versions: a different tensor that happens to reuse the
-    address can never hit."""
+    its version counter and the grid's identity (Quantizer.grid_token): a different tensor that happens to reuse the
+    address can never hit.  QRMSNorm's fused kernel files its int8 output here too, so its consumers find it."""
 
     def __init__(self):
         self._ref = None
@@ -362,8 +380,7 @@ class _SharedActivation:
 
     @staticmethod
     def _make_key(x, grid, a_shift_hint):
-        return (x._version, x.data_ptr(), tuple(x.shape), x.dtype, grid.scale.data_ptr(), grid.scale._version,
-                grid.offset.data_ptr(), grid.offset._version, grid.qmin, grid.qmax, a_shift_hint)
+        return (x._version, x.data_ptr(), tuple(x.shape), x.dtype, grid.grid_token(), a_shift_hint)
 
     def clear(self):
         self._ref = self._key = self._val = None
@@ -534,8 +551,60 @@ class QRMSNorm(HFRMSNorm, _QuantizedOp):
         self.use_temporary_parameter = False
         self._init_quantizers(input=input_quant_cfg, weight=weight_quant_cfg, output=output_quant_cfg)
 
+    fused_mode = "auto"        # "off": always the composite torch ops around the HIP quantizers
+
+    @staticmethod
+    def _grid_or_none(q):
+        """(scale, offset, qmin, qmax) of a static per-tensor quantizer, None for an absent / bypassed one,
+        False when the quantizer cannot be folded into the fused kernel (dynamic, per-channel, LWC, no range yet)."""
+        if q is None or q.bypassed():
+            return None
+        if not _static_per_tensor(q, 16):
+            return False
+        return (q.scale.detach(), q.offset.detach(), q.qmin, q.qmax)
+
+    def _forward_fused(self, input_, weight):
+        """One launch (mq_rmsnorm_quant) instead of six; with an 8-bit output grid the int8 indices + row sums are
+        handed to the consumer linears through the shared-activation memo, so q/k/v (w1/w3) launch no quantize."""
+        if (self.fused_mode == "off" or self.l2norm_as_rmsnorm or not input_.is_cuda or input_.dtype != torch.float32
+                or weight.dtype != torch.float32 or input_.shape[-1] % 4 or input_.numel() == 0
+                or _needs_grad(input_, weight, self.bias)):
+            return None
+        gi, go = self._grid_or_none(self.input_quantizer), self._grid_or_none(self.output_quantizer)
+        if gi is False or go is False:
+            return None
+        for g in (gi, go):
+            if g is not None and g[0].device != input_.device:
+                return None                      # first call after a device move: the composite path migrates the grids
+        wq = self.weight_quantizer
+        if wq is not None and _needs_grad(getattr(wq, "scale", None), getattr(wq, "offset", None)):
+            return None
+        # the fake-quantised [dim] weight vector is cached until the weight or its grid changes (the first call
+        # also fixes the weight range from the weight itself, qmodule.py:262-277)
+        key = (weight.data_ptr(), weight._version, None if wq is None or not wq._has_grid() else wq.grid_token(),
+               None if wq is None else (wq.enable, wq.lwc, wq.qcfg.bitwidth, wq.qcfg.is_dynamic))
+        cached = getattr(self, "_wfq", None)
+        if cached is not None and cached[0] == key and key[2] is not None:
+            wfq = cached[1]
+        else:
+            with torch.no_grad():
+                wfq = _apply(wq, weight)
+            if wq is not None and wq._has_grid() and not wq.lwc and not wq.qcfg.is_dynamic:
+                key = (key[0], key[1], wq.grid_token(), key[3])
+                self._wfq = (key, wfq)
+        emit = go is not None and self.output_quantizer.qcfg.bitwidth <= 8
+        res = ops.rmsnorm_quant(input_, wfq, self.bias, self.eps, gi, go, emit_int8=emit)
+        if not emit:
+            return res
+        y, q, rs, shift = res
+        _shared_activation.put(y, self.output_quantizer, shift, (q, rs, shift))
+        return y
+
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
+        out = self._forward_fused(input_, weight)
+        if out is not None:
+            return out
         weight = _apply(self.weight_quantizer, weight)
         out = self.forward_impl(_apply(self.input_quantizer, input_), weight, self.bias)
         return _apply(self.output_quantizer, out)

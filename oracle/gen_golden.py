@@ -15,6 +15,7 @@ Fixtures written (all data, no reference source text):
   qlinear_cases.npz       a8     QLinear.forward on small shapes (W8A8 / W4A8 / per-channel / bias)
   calib_stream.npz        a12/a13 real get_act_range / get_act_scales on a toy module stack
   checksums.json          sha256 of full-size index tensors (inputs re-creatable from numpy seeds)
+  qrmsnorm_cases.npz      a10    QRMSNorm.forward (16-bit input / weight grids, 8- or 16-bit output, mixed-precision rules)
   nonfinite_cases.npz     a1/a3/a5 NaN and +-inf inputs: torch.clamp / amin / amax propagate NaN
   api_surface.json        state_dict keys / export_qcfg / export_act_range of a toy sim model
 """
@@ -252,6 +253,37 @@ def gen_quantizer_grads():
             meta.append(dict(id=k, bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch, qmin=qz.qmin, qmax=qz.qmax))
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "quantizer_grads.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_qrmsnorm_cases():
+    """QRMSNorm.forward of the reference (qmodule.py:469-530) on small shapes, configured the way
+    ptq/mobilequant.py:184-188 does (16-bit input and weight grids, asymmetric per-tensor weight), plus the
+    variants without an input / output quantizer and with a 16-bit output."""
+    from mobilellm.model.hf_model import HFRMSNorm
+    g = torch.Generator().manual_seed(2024)
+    out, meta = {}, []
+    for cid, (rows, cols, in_bits, out_bits) in enumerate(((24, 256, 16, 8), (7, 2048, 16, 8), (24, 256, None, 8),
+                                                           (24, 256, 16, 16), (24, 256, 16, None), (5, 5632, 16, 8))):
+        fp = HFRMSNorm(cols, eps=1e-5)
+        with torch.no_grad():
+            fp.weight.copy_(torch.randn(cols, generator=g) * 0.3 + 1.0)
+        a16 = Q.QuantConfig(bitwidth=16)
+        qn = Q.QRMSNorm.from_float(fp, Q.QuantConfig(bitwidth=in_bits) if in_bits else None, a16,
+                                   Q.QuantConfig(bitwidth=out_bits) if out_bits else None)
+        x = torch.randn(1, rows, cols, generator=g) * 2.5
+        x[0, 0, :8] = torch.tensor([0.0, -0.0, 1e-9, -1e-9, 30.0, -30.0, 0.5, -0.5])
+        act = {"input": [float(x.min()) * 0.9, float(x.max()) * 0.9]}      # clips a little on purpose
+        y_fp = fp(x)
+        act["output"] = [float(y_fp.min()) * 0.95, float(y_fp.max()) * 0.95]
+        qn.set_scale_offset(act, "buffer")
+        y = qn(x)
+        k = f"n{cid}"
+        out[k + "_x"], out[k + "_w"], out[k + "_y"] = npf(x), npf(fp.weight), npf(y)
+        out[k + "_wscale"], out[k + "_woffset"] = npf(qn.weight_quantizer.scale.float()), npf(qn.weight_quantizer.offset.float())
+        meta.append(dict(id=k, rows=rows, cols=cols, in_bits=in_bits, out_bits=out_bits, eps=1e-5, act=act))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "qrmsnorm_cases.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -526,6 +558,7 @@ if __name__ == "__main__":
     gen_scale_offset_grid()
     gen_quantizer_cases()
     gen_nonfinite()
+    gen_qrmsnorm_cases()
     gen_quantizer_grads()
     gen_qlinear_cases()
     gen_calib_stream()

@@ -322,6 +322,24 @@ class ActScaleOracle:
 # Storage formats the integer path adds (no reference counterpart; defined in DESIGN.md).
 # The values they carry are the reference's indices from quantize_index().
 # ----------------------------------------------------------------------------------------------
+def qrmsnorm(x, weight, bias, eps, in_q, w_q, out_q):
+    """QRMSNorm.forward (qmodule.py:518-530 around HFRMSNorm.forward_impl, hf_model.py:184-195), fp32:
+    ``Qout( Qw(weight) * (xi * rsqrt(mean(xi^2, -1) + eps)) (+ bias) )`` with ``xi = Qin(x)``; any quantizer may be
+    None.  rsqrt is 1/sqrt with both operations correctly rounded (what torch's CPU kernel computes); the mean is
+    numpy's pairwise sum / n, which is not torch's summation order: agreement with the frozen reference outputs
+    is within one output LSB on a vanishing fraction of elements (tests state the bound)."""
+    x = np.asarray(x, dtype=F32)
+    w = np.asarray(weight, dtype=F32)
+    xi = in_q.forward(x) if in_q is not None else x
+    wq = w_q.forward(w) if w_q is not None else w
+    ms = (xi * xi).astype(F32).mean(axis=-1, keepdims=True, dtype=F32)
+    r = (F32(1.0) / np.sqrt((ms + F32(eps)).astype(F32)).astype(F32)).astype(F32)
+    y = (wq * (xi * r).astype(F32)).astype(F32)
+    if bias is not None:
+        y = (y + np.asarray(bias, dtype=F32)).astype(F32)
+    return out_q.forward(y) if out_q is not None else y
+
+
 def index_to_i8(q, qmin: int):
     """Signed-byte storage of an 8-bit index: unsigned grids [0,255] are stored as q-128
     (MFMA i8 is signed), signed grids [-128,127] as is.  Returns (int8 array, shift)."""

@@ -767,6 +767,120 @@ def test_shared_activation_quantised_once(dev):
         ops.quantize = real
 
 
+def _norm_close(got, want, m):
+    got, want = np.asarray(got, F32), np.asarray(want, F32)
+    if m["out_bits"]:
+        lo, hi = m["act"]["output"]
+        lsb = F32((hi - lo) / (2 ** m["out_bits"] - 1))
+        d = np.abs(got - want)
+        return d.max() <= lsb * F32(1.01) and (d == 0).mean() > 0.999
+    return np.allclose(got, want, rtol=2e-6, atol=1e-7)
+
+
+def test_qrmsnorm_fused_kernel_vs_reference(dev):
+    """mq_rmsnorm_quant (one launch) against the reference's frozen QRMSNorm outputs, against the composite path of
+    this package, and its int8 side output against mq_quantize of its own fp32 output (bit-exact)."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    from mobilequant_amd._lib import MQ_I8
+    z = load_npz("qrmsnorm_cases.npz")
+    for m in load_meta(z):
+        k = m["id"]
+        fp = HFRMSNorm(m["cols"], eps=m["eps"])
+        with torch.no_grad():
+            fp.weight.copy_(torch.from_numpy(z[k + "_w"]))
+        fp = fp.to(dev)
+        a16 = mq.QuantConfig(bitwidth=16)
+        qn = mq.QRMSNorm.from_float(fp, mq.QuantConfig(bitwidth=m["in_bits"]) if m["in_bits"] else None, a16,
+                                    mq.QuantConfig(bitwidth=m["out_bits"]) if m["out_bits"] else None).requires_grad_(False)
+        qn.set_scale_offset(m["act"], "buffer")
+        x = T(z[k + "_x"], dev)
+        with torch.no_grad():
+            qn.fused_mode = "off"
+            y_comp = qn(x)
+            qn.fused_mode = "auto"
+            launches = []
+            real = ops.rmsnorm_quant
+            ops.rmsnorm_quant = lambda *a, **kw: (launches.append(1), real(*a, **kw))[1]
+            try:
+                y = qn(x)
+            finally:
+                ops.rmsnorm_quant = real
+        assert len(launches) == 1, "fused path not taken"
+        assert np.array_equal(bits(qn.weight_quantizer.scale.detach().cpu().numpy().reshape(z[k + "_wscale"].shape)), bits(z[k + "_wscale"]))
+        assert y.shape == x.shape and _norm_close(y.cpu().numpy(), z[k + "_y"], m), m
+        assert _norm_close(y.cpu().numpy(), y_comp.cpu().numpy(), m), m
+        if m["out_bits"] == 8:
+            oq = qn.output_quantizer
+            _, q, rs, shift = ops.rmsnorm_quant(x, qn.weight_quantizer(fp.weight), None, m["eps"],
+                                                (qn.input_quantizer.scale, qn.input_quantizer.offset, qn.input_quantizer.qmin, qn.input_quantizer.qmax) if m["in_bits"] else None,
+                                                (oq.scale, oq.offset, oq.qmin, oq.qmax), emit_int8=True)
+            q2, rs2, shift2 = oq.quantize_to_int(y.reshape(-1, m["cols"]), MQ_I8, want_row_sum=True)
+            assert shift == shift2 and torch.equal(q, q2) and torch.equal(rs, rs2)
+
+
+def test_norm_to_linear_integer_chain(dev):
+    """QRMSNorm (8-bit output) -> q/k/v QLinear without input quantizers.  The norm's fused kernel
+    hands its int8 output to the consumers: no activation quantize launch at all, outputs identical to the unchained
+    execution (each linear re-quantising the norm's fp32 output)."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd.quantization import qmodule as Q
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    torch.manual_seed(11)
+    a8, a16 = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16)
+    fp = HFRMSNorm(256, eps=1e-5).to(dev)
+    norm = mq.QRMSNorm.from_float(fp, a16, a16, a8).requires_grad_(False)
+    x = torch.randn(1, 40, 256, device=dev) * 2
+    with torch.no_grad():
+        y_fp = fp(x)
+    out_rng = [float(y_fp.min()), float(y_fp.max())]
+    norm.set_scale_offset({"input": [float(x.min()), float(x.max())], "output": out_rng}, "buffer")
+    lins = []
+    for n in (256, 64, 64):
+        ql = mq.QLinear.from_float(torch.nn.Linear(256, n, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+        ql.input_quantizer = None                                   # q/k/v rule (qmodule.py:848-850)
+        ql.set_scale_offset({"input": out_rng, "output": [-3.0, 3.0]}, "buffer")
+        lins.append(ql)
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm, self.q_proj, self.k_proj, self.v_proj = norm, *lins
+
+        def forward(self, t):
+            h = self.norm(t)
+            return self.q_proj(h), self.k_proj(h), self.v_proj(h)
+    blk = Block()
+    assert mq.wire_integer_inputs(blk) == 3
+    calls = []
+    real = ops.quantize
+    ops.quantize = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            blk(x)                                                   # weight plans (they quantize the weights)
+            calls.clear()
+            chained = blk(x)
+            assert calls == [], "consumer linears must reuse the norm's int8 output"
+            norm.fused_mode = "off"
+            Q._shared_activation.clear()
+            plain = blk(x)
+            assert len(calls) == 1                                   # one shared quantize of the composite norm output
+    finally:
+        ops.quantize = real
+        norm.fused_mode = "auto"
+    # the composite norm may differ from the fused one by an LSB on a vanishing fraction of elements (summation order);
+    # given the SAME norm output the linears are exact, so compare through the fused norm's own fp32 output
+    with torch.no_grad():
+        h = norm(x)
+        Q._shared_activation.clear()
+        again = [ql(h) for ql in lins]
+    assert all(torch.equal(a, b) for a, b in zip(chained, again))
+    d = [(a - b).abs().max().item() for a, b in zip(chained, plain)]
+    assert max(d) <= 2 * (6.0 / 255) + 1e-6, d
+
+
 def test_toy_lm_w8a8_logits_vs_reference(dev):
     """Two-block toy LM through create_sim_qmodel -> mixed precision -> set_scale_and_offset -> forward,
     simulated path and integer path, against the reference's logits.  Error budget: a handful of

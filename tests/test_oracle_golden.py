@@ -286,3 +286,36 @@ def test_nonfinite_inputs_follow_reference():
     for sym in (0, 1):
         s, o, _, _ = O.scale_offset_from_min_max(z["so_min"], z["so_max"], 8, bool(sym))
         assert eq_nan(s, z[f"so_scale_s{sym}"]) and eq_nan(o, z[f"so_offset_s{sym}"]), sym
+
+
+def _norm_quantizers(m, z):
+    k = m["id"]
+    in_q = out_q = None
+    if m["in_bits"]:
+        in_q = O.QuantizerOracle(m["in_bits"]); in_q.set_from_minmax(*m["act"]["input"])
+    if m["out_bits"]:
+        out_q = O.QuantizerOracle(m["out_bits"]); out_q.set_from_minmax(*m["act"]["output"])
+    w_q = O.QuantizerOracle(16)           # first forward: range from the weight itself (qmodule.py:262-277)
+    return in_q, w_q, out_q
+
+
+def norm_close(got, want, m):
+    """Bound for QRMSNorm against the reference's frozen output: identical up to the summation order of mean(x^2).
+    Quantised output: at most 1 LSB apart, > 99.9 % identical; float output: 2e-6 relative."""
+    got, want = np.asarray(got, F32), np.asarray(want, F32)
+    if m["out_bits"]:
+        lo, hi = m["act"]["output"]
+        lsb = F32((hi - lo) / (2 ** m["out_bits"] - 1))
+        d = np.abs(got - want)
+        return d.max() <= lsb * F32(1.01) and (d == 0).mean() > 0.999
+    return np.allclose(got, want, rtol=2e-6, atol=1e-7)
+
+
+def test_qrmsnorm_cases():
+    z = load_npz("qrmsnorm_cases.npz")
+    for m in load_meta(z):
+        k = m["id"]
+        in_q, w_q, out_q = _norm_quantizers(m, z)
+        y = O.qrmsnorm(z[k + "_x"], z[k + "_w"], None, m["eps"], in_q, w_q, out_q)
+        assert np.array_equal(np.asarray(w_q.scale, F32).reshape(z[k + "_wscale"].shape), z[k + "_wscale"])
+        assert y.shape == z[k + "_y"].shape and norm_close(y, z[k + "_y"], m), m
