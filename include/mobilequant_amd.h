@@ -192,6 +192,16 @@ int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* we
                      float out_qmax, float* y, int8_t* q_out, int q_shift, int32_t* row_sum,
                      mq_stream_t stream);
 
+/* ---- a10: QSiLU / QGELU.forward in one pass (qmodule.py:739-754, :790-798) ------------------------------------ */
+/* act 0 (SiLU): y = Qout( xi * Qmid(sigmoid(xi)) ), act 1 (GELU, erf form): y = Qout( gelu(xi) ), xi = Qin(x); fp32,
+ * per-tensor grids (1 element each; NULL pair = quantizer absent; mid is ignored for GELU).  exp / erf come from the
+ * device math library: after the output quantizer at most one LSB from the CPU reference on a vanishing fraction of
+ * the elements. */
+int mq_act_quant(const float* x, int64_t numel, int act, const float* in_scale, const float* in_offset,
+                 float in_qmin, float in_qmax, const float* mid_scale, const float* mid_offset,
+                 float mid_qmin, float mid_qmax, const float* out_scale, const float* out_offset,
+                 float out_qmin, float out_qmax, float* y, mq_stream_t stream);
+
 /* Tuning/diagnostic knob: force a GEMM tile configuration (see DESIGN.md "GEMM variants").
  * variant < 0 restores the built-in heuristic.  Returns the number of variants. */
 int mq_gemm_set_variant(int variant);

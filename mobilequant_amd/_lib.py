@@ -43,6 +43,7 @@ _SIGNATURES = {
     "mq_w4a8_linear_f32in": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P,
                                      c_float, c_float, _P, c_int, _P]),
     "mq_pack_w4": (c_int, [_P, c_int64, c_int64, _P, _P]),
+    "mq_act_quant": (c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P]),
     "mq_rmsnorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
                                  _P, c_int, _P, _P]),
     "mq_w4a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),

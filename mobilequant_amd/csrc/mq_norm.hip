@@ -187,3 +187,74 @@ extern "C" int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, cons
   MQ_LAUNCH_CHECK("mq_rmsnorm_quant");
   return MQ_OK;
 }
+
+// ---- QSiLU / QGELU.forward in one pass (qmodule.py:739-754, :790-798) -------------------------------------------
+// SiLU:  xi = Qin(x);  g = Qmid(sigmoid(xi));  out = Qout(xi * g)       (Qmid: the [0,1] sigmoid grid, qmodule.py:731-734)
+// GELU:  xi = Qin(x);  out = Qout(0.5 * xi * (1 + erf(xi / sqrt 2)))
+// = 4 (2) launches and 9 (5) passes as composite ops.  exp / erf are the device library's (<= 1-2 ulp), the divide of the
+// sigmoid is IEEE: results equal torch's GPU sigmoid / gelu bit for bit and the CPU reference's up to those ulps, i.e.
+// after the output quantizer at most one LSB apart on a vanishing fraction of elements.
+namespace mq {
+
+struct ActArgs {
+  const float* x;
+  float* y;
+  int64_t numel;
+  int act;   // 0 = SiLU, 1 = GELU (erf)
+  const float* s[3];   // in / mid / out scale (nullable)
+  const float* o[3];
+  float qmin[3], qmax[3];
+};
+
+__global__ void __launch_bounds__(256) act_quant_kernel(const ActArgs a) {
+  float sc[3], of[3];
+  bool has[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    has[k] = a.s[k] != nullptr;
+    sc[k] = has[k] ? a.s[k][0] : 1.f;
+    of[k] = has[k] ? a.o[k][0] : 0.f;
+  }
+  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], a.qmin[k], a.qmax[k]), sc[k], of[k]) : v; };
+  auto f = [&](float v) {
+    const float xi = fq(0, v);
+    float r;
+    if (a.act == 0) {
+      const float g = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-xi)));
+      r = __fmul_rn(xi, fq(1, g));
+    } else {
+      r = __fmul_rn(__fmul_rn(0.5f, xi), __fadd_rn(1.0f, erff(__fmul_rn(xi, 0.70710678118654752440f))));
+    }
+    return fq(2, r);
+  };
+  const int64_t nvec = a.numel >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+    reinterpret_cast<float4*>(a.y)[i] = v;
+  }
+  for (int64_t i = (nvec << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.numel; i += stride) a.y[i] = f(a.x[i]);
+}
+
+}  // namespace mq
+
+extern "C" int mq_act_quant(const float* x, int64_t numel, int act, const float* in_scale, const float* in_offset, float in_qmin,
+                            float in_qmax, const float* mid_scale, const float* mid_offset, float mid_qmin, float mid_qmax,
+                            const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
+                            mq_stream_t stream) {
+  MQ_REQUIRE(numel >= 0 && (act == 0 || act == 1), "mq_act_quant: bad arguments (act = 0 SiLU, 1 GELU)");
+  if (numel == 0) return MQ_OK;
+  MQ_REQUIRE(x && y && aligned(x, 16) && aligned(y, 16), "mq_act_quant: x / y must be non-null and 16-byte aligned");
+  MQ_REQUIRE((in_scale == nullptr) == (in_offset == nullptr) && (mid_scale == nullptr) == (mid_offset == nullptr) &&
+                 (out_scale == nullptr) == (out_offset == nullptr),
+             "mq_act_quant: scale/offset must both be set or NULL");
+  ActArgs a{x, y, numel, act, {in_scale, mid_scale, out_scale}, {in_offset, mid_offset, out_offset},
+            {in_qmin, mid_qmin, out_qmin}, {in_qmax, mid_qmax, out_qmax}};
+  int64_t g = ((numel >> 2) + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;
+  act_quant_kernel<<<(unsigned)g, 256, 0, as_stream(stream)>>>(a);
+  MQ_LAUNCH_CHECK("mq_act_quant");
+  return MQ_OK;
+}

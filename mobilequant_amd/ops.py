@@ -250,6 +250,20 @@ def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_gr
     return (y, q, rs, shift) if emit_int8 else y
 
 
+def act_quant(x: torch.Tensor, act: str, in_grid=None, mid_grid=None, out_grid=None):
+    """QSiLU ("silu") / QGELU ("gelu") forward in one launch; grids: None or (scale, offset, qmin, qmax) per-tensor."""
+    x = _f32(_dev(x, "x"), "x").contiguous()
+    y = torch.empty_like(x)
+    ptrs = []
+    for g in (in_grid, mid_grid, out_grid):
+        if g is None:
+            ptrs += [None, None, 0.0, 0.0]
+        else:
+            ptrs += [_f32(g[0], "scale").data_ptr(), _f32(g[1], "offset").data_ptr(), float(g[2]), float(g[3])]
+    _lib.call("mq_act_quant", x.data_ptr(), x.numel(), {"silu": 0, "gelu": 1}[act], *ptrs, y.data_ptr(), _stream())
+    return y
+
+
 def pack_w4(nibbles: torch.Tensor) -> torch.Tensor:
     """[N,K] uint8 nibbles (0..15) -> [N,K/2] packed (layout: include/mobilequant_amd.h, mq_pack_w4)."""
     nibbles = _dev(nibbles, "nibbles").contiguous()

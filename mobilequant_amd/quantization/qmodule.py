@@ -669,6 +669,20 @@ class QLayerNorm(nn.LayerNorm, _QuantizedOp):
         return out
 
 
+def _fused_activation(module, x, act, quantizers):
+    """QSiLU / QGELU.forward as ONE launch (mq_act_quant) when every quantizer involved is absent or a static
+    per-tensor grid already on x's device; None -> the caller runs the composite ops."""
+    if module.fused_mode == "off" or not x.is_cuda or x.dtype != torch.float32 or x.numel() == 0 or _needs_grad(x):
+        return None
+    grids = []
+    for q in quantizers:
+        g = QRMSNorm._grid_or_none(q)
+        if g is False or (g is not None and (g[0].device != x.device or _needs_grad(q.scale, q.offset))):
+            return None
+        grids.append(g)
+    return ops.act_quant(x, act, *grids)
+
+
 class QSiLU(nn.Module, _QuantizedOp):
     """x * quant(sigmoid(x)) with quantized output (reference: qmodule.py:691-753)."""
 
@@ -679,7 +693,12 @@ class QSiLU(nn.Module, _QuantizedOp):
         super().__init__()
         self._init_quantizers(input=input_quant_cfg, input2=input2_quant_cfg, output=output_quant_cfg)
 
+    fused_mode = "auto"        # "off": composite torch ops around the HIP quantizers
+
     def forward(self, x):
+        y = _fused_activation(self, x, "silu", (self.input_quantizer, self.input2_quantizer, self.output_quantizer))
+        if y is not None:
+            return y
         x = _apply(self.input_quantizer, x)
         gate = _apply(self.input2_quantizer, torch.sigmoid(x))
         return _apply(self.output_quantizer, x * gate)
@@ -695,7 +714,12 @@ class QGELU(nn.Module, _QuantizedOp):
         super().__init__()
         self._init_quantizers(input=input_quant_cfg, output=output_quant_cfg)
 
+    fused_mode = "auto"
+
     def forward(self, x):
+        y = _fused_activation(self, x, "gelu", (self.input_quantizer, None, self.output_quantizer))
+        if y is not None:
+            return y
         return _apply(self.output_quantizer, F.gelu(_apply(self.input_quantizer, x)))
 
 

@@ -16,6 +16,7 @@ Fixtures written (all data, no reference source text):
   calib_stream.npz        a12/a13 real get_act_range / get_act_scales on a toy module stack
   checksums.json          sha256 of full-size index tensors (inputs re-creatable from numpy seeds)
   qrmsnorm_cases.npz      a10    QRMSNorm.forward (16-bit input / weight grids, 8- or 16-bit output, mixed-precision rules)
+  qact_cases.npz          a10    QSiLU / QGELU.forward (sigmoid grid [0,1], 8- and 16-bit outputs)
   nonfinite_cases.npz     a1/a3/a5 NaN and +-inf inputs: torch.clamp / amin / amax propagate NaN
   api_surface.json        state_dict keys / export_qcfg / export_act_range of a toy sim model
 """
@@ -284,6 +285,37 @@ def gen_qrmsnorm_cases():
         meta.append(dict(id=k, rows=rows, cols=cols, in_bits=in_bits, out_bits=out_bits, eps=1e-5, act=act))
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "qrmsnorm_cases.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_qact_cases():
+    """QSiLU.forward / QGELU.forward of the reference (qmodule.py:739-754, :790-798): no input quantizer (the surgery
+    rule, mobilequant.py:196-199) and a 16-bit one; sigmoid grid = the [0,1] default or a calibrated input2 range."""
+    g = torch.Generator().manual_seed(77)
+    out, meta = {}, []
+    x = torch.randn(1, 40, 352, generator=g) * 3
+    x.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-9, -1e-9, 25.0, -25.0, 0.5, -0.5])
+    out["x"] = npf(x)
+    cid = 0
+    for kind in ("silu", "gelu"):
+        for in_bits, out_bits, mid in ((None, 8, None), (16, 8, [0.0, 0.98]), (None, 16, None), (None, None, None)):
+            a = lambda b: Q.QuantConfig(bitwidth=b) if b else None      # noqa: E731
+            if kind == "silu":
+                m = Q.QSiLU(a(in_bits), Q.QuantConfig(bitwidth=8), a(out_bits))
+                y_fp = torch.nn.functional.silu(x)
+            else:
+                m = Q.QGELU(a(in_bits), a(out_bits))
+                y_fp = torch.nn.functional.gelu(x)
+            act = {"input": [float(x.min()) * 0.9, float(x.max()) * 0.9], "output": [float(y_fp.min()), float(y_fp.max()) * 0.95]}
+            if mid is not None and kind == "silu":
+                act["input2"] = mid
+            m.set_scale_offset(act, "buffer")
+            k = f"a{cid}"
+            out[k + "_y"] = npf(m(x))
+            meta.append(dict(id=k, kind=kind, in_bits=in_bits, out_bits=out_bits, act=act))
+            cid += 1
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "qact_cases.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -559,6 +591,7 @@ if __name__ == "__main__":
     gen_quantizer_cases()
     gen_nonfinite()
     gen_qrmsnorm_cases()
+    gen_qact_cases()
     gen_quantizer_grads()
     gen_qlinear_cases()
     gen_calib_stream()

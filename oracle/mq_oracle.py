@@ -340,6 +340,29 @@ def qrmsnorm(x, weight, bias, eps, in_q, w_q, out_q):
     return out_q.forward(y) if out_q is not None else y
 
 
+def qsilu(x, in_q, mid_q, out_q):
+    """QSiLU.forward (qmodule.py:739-754): ``Qout( xi * Qmid(sigmoid(xi)) )``, ``xi = Qin(x)``; fp32, sigmoid =
+    1 / (1 + exp(-x)).  exp is the platform's (<= 1 ulp), so agreement with the frozen reference output is up to
+    one output LSB on a vanishing fraction of elements."""
+    x = np.asarray(x, dtype=F32)
+    xi = in_q.forward(x) if in_q is not None else x
+    with np.errstate(over="ignore"):
+        g = (F32(1.0) / (F32(1.0) + np.exp(-xi).astype(F32)).astype(F32)).astype(F32)
+    g = mid_q.forward(g) if mid_q is not None else g
+    y = (xi * g).astype(F32)
+    return out_q.forward(y) if out_q is not None else y
+
+
+def qgelu(x, in_q, out_q):
+    """QGELU.forward (qmodule.py:790-798): ``Qout( 0.5 * xi * (1 + erf(xi / sqrt 2)) )``, fp32."""
+    from scipy.special import erf
+    x = np.asarray(x, dtype=F32)
+    xi = in_q.forward(x) if in_q is not None else x
+    e = erf((xi * F32(0.7071067811865476)).astype(F32).astype(np.float64)).astype(F32)
+    y = ((F32(0.5) * xi).astype(F32) * (F32(1.0) + e).astype(F32)).astype(F32)
+    return out_q.forward(y) if out_q is not None else y
+
+
 def index_to_i8(q, qmin: int):
     """Signed-byte storage of an 8-bit index: unsigned grids [0,255] are stored as q-128
     (MFMA i8 is signed), signed grids [-128,127] as is.  Returns (int8 array, shift)."""

@@ -820,6 +820,43 @@ def test_qrmsnorm_fused_kernel_vs_reference(dev):
             assert shift == shift2 and torch.equal(q, q2) and torch.equal(rs, rs2)
 
 
+def test_qsilu_qgelu_fused_kernels_vs_reference(dev):
+    """mq_act_quant (one launch) against the reference's frozen QSiLU / QGELU outputs and against this package's
+    composite path (torch sigmoid / gelu on the GPU around the HIP quantizers: same math library, so bit-identical)."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    z = load_npz("qact_cases.npz")
+    x = T(z["x"], dev)
+    for m in load_meta(z):
+        a = lambda b: mq.QuantConfig(bitwidth=b) if b else None      # noqa: E731
+        mod = (mq.QSiLU(a(m["in_bits"]), mq.QuantConfig(bitwidth=8), a(m["out_bits"])) if m["kind"] == "silu"
+               else mq.QGELU(a(m["in_bits"]), a(m["out_bits"])))
+        mod.set_scale_offset(m["act"], "buffer")
+        mod = mod.to(dev)
+        with torch.no_grad():
+            mod.fused_mode = "off"
+            y_comp = mod(x)
+            mod.fused_mode = "auto"
+            launches = []
+            real = ops.act_quant
+            ops.act_quant = lambda *aa, **kw: (launches.append(1), real(*aa, **kw))[1]
+            try:
+                y = mod(x)
+            finally:
+                ops.act_quant = real
+        assert len(launches) == 1, "fused path not taken"
+        lo, hi = m["act"]["output"]
+        got, want = y.cpu().numpy(), z[m["id"] + "_y"]
+        if m["out_bits"]:
+            lsb = F32((hi - lo) / (2 ** m["out_bits"] - 1))
+            d = np.abs(got - want)
+            assert d.max() <= lsb * F32(1.01) and (d == 0).mean() > (0.999 if m["out_bits"] <= 8 else 0.99), (m, d.max(), (d == 0).mean())
+        else:
+            assert np.allclose(got, want, rtol=3e-6, atol=2e-6), m      # 1 + erf cancels in the negative tail
+        dc = (y - y_comp).abs()
+        assert dc.max().item() <= (float(lsb) * 1.01 if m["out_bits"] else 1e-5) and (dc == 0).float().mean().item() > 0.99, m
+
+
 def test_norm_to_linear_integer_chain(dev):
     """QRMSNorm (8-bit output) -> q/k/v QLinear without input quantizers.  The norm's fused kernel
     hands its int8 output to the consumers: no activation quantize launch at all, outputs identical to the unchained
