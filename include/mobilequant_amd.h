@@ -192,6 +192,15 @@ int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* we
                      float out_qmax, float* y, int8_t* q_out, int q_shift, int32_t* row_sum,
                      mq_stream_t stream);
 
+/* QLayerNorm.forward (qmodule.py:624-640 around F.layer_norm): same contract as mq_rmsnorm_quant with the row's mean and
+ * biased variance, y = (xi * rstd + (-rstd * mean)) * weight + bias (torch's CPU kernel expression); bias is the raw
+ * (unquantised) LayerNorm bias, nullable. */
+int mq_layernorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
+                       float eps, const float* in_scale, const float* in_offset, float in_qmin,
+                       float in_qmax, const float* out_scale, const float* out_offset, float out_qmin,
+                       float out_qmax, float* y, int8_t* q_out, int q_shift, int32_t* row_sum,
+                       mq_stream_t stream);
+
 /* ---- a10: QSiLU / QGELU.forward in one pass (qmodule.py:739-754, :790-798) ------------------------------------ */
 /* act 0 (SiLU): y = Qout( xi * Qmid(sigmoid(xi)) ), act 1 (GELU, erf form): y = Qout( gelu(xi) ), xi = Qin(x); fp32,
  * per-tensor grids (1 element each; NULL pair = quantizer absent; mid is ignored for GELU).  exp / erf come from the

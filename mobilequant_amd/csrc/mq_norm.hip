@@ -60,8 +60,10 @@ struct NormArgs {
   int cols;
 };
 
-// V = float4 vectors held per lane (cols <= 256 * V); V == 0: two passes over the row
-template <int V>
+// V = float4 vectors held per lane (cols <= 256 * V); V == 0: the row is re-read instead of kept.
+// LN: LayerNorm (QLayerNorm.forward, qmodule.py:624-640 around F.layer_norm) instead of RMSNorm: mean and biased
+// variance of the row, y = (xi * rstd + (-rstd * mean)) * gamma + beta -- the expression of torch's CPU kernel.
+template <int V, bool LN>
 __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,15 +111,60 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
       ss += v.w * v.w;
     }
   }
-  ss = wave_sum_f32(ss);
-  const float mean = __fdiv_rn(ss, (float)cols);
-  const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, a.eps)));
+  float r, shiftv = 0.f;
+  if constexpr (LN) {
+    // ss holds sum(xi^2) so far; LayerNorm wants sum(xi) and then sum((xi - mean)^2): redo the (register) pass
+    float s1 = 0.f;
+    if constexpr (V > 0) {
+#pragma unroll
+      for (int k = 0; k < V; ++k)
+        if (lane + 64 * k < nvec) s1 += (xs[k].x + xs[k].y) + (xs[k].z + xs[k].w);
+    } else {
+      for (int i = lane; i < nvec; i += 64) {
+        float4 v = xr[i];
+        s1 += (qin(v.x) + qin(v.y)) + (qin(v.z) + qin(v.w));
+      }
+    }
+    const float mu = __fdiv_rn(wave_sum_f32(s1), (float)cols);
+    float s2 = 0.f;
+    auto dev2 = [&](float4 v) {
+      const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+      s2 += d0 * d0;
+      s2 += d1 * d1;
+      s2 += d2 * d2;
+      s2 += d3 * d3;
+    };
+    if constexpr (V > 0) {
+#pragma unroll
+      for (int k = 0; k < V; ++k)
+        if (lane + 64 * k < nvec) dev2(xs[k]);
+    } else {
+      for (int i = lane; i < nvec; i += 64) {
+        float4 v = xr[i];
+        v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
+        dev2(v);
+      }
+    }
+    const float var = __fdiv_rn(wave_sum_f32(s2), (float)cols);
+    r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, a.eps)));
+    shiftv = __fmul_rn(-r, mu);
+  } else {
+    ss = wave_sum_f32(ss);
+    const float mean = __fdiv_rn(ss, (float)cols);
+    r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, a.eps)));
+  }
 
   int acc = 0;
   auto emit = [&](int i, float4 v) {
     const float4 w = wv[i];
-    float y0 = __fmul_rn(w.x, __fmul_rn(v.x, r)), y1 = __fmul_rn(w.y, __fmul_rn(v.y, r));
-    float y2 = __fmul_rn(w.z, __fmul_rn(v.z, r)), y3 = __fmul_rn(w.w, __fmul_rn(v.w, r));
+    float y0, y1, y2, y3;
+    if constexpr (LN) {
+      y0 = __fmul_rn(__fadd_rn(__fmul_rn(v.x, r), shiftv), w.x); y1 = __fmul_rn(__fadd_rn(__fmul_rn(v.y, r), shiftv), w.y);
+      y2 = __fmul_rn(__fadd_rn(__fmul_rn(v.z, r), shiftv), w.z); y3 = __fmul_rn(__fadd_rn(__fmul_rn(v.w, r), shiftv), w.w);
+    } else {
+      y0 = __fmul_rn(w.x, __fmul_rn(v.x, r)); y1 = __fmul_rn(w.y, __fmul_rn(v.y, r));
+      y2 = __fmul_rn(w.z, __fmul_rn(v.z, r)); y3 = __fmul_rn(w.w, __fmul_rn(v.w, r));
+    }
     if (bv) {
       const float4 b = bv[i];
       y0 = __fadd_rn(y0, b.x); y1 = __fadd_rn(y1, b.y); y2 = __fadd_rn(y2, b.z); y3 = __fadd_rn(y3, b.w);
@@ -159,33 +206,55 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
 
 using namespace mq;
 
-extern "C" int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
-                                const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
-                                const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
-                                int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
-  MQ_REQUIRE(x && weight && (y || q_out), "mq_rmsnorm_quant: null pointer");
+static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
+                       float eps, const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
+                       const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
+                       int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+  MQ_REQUIRE(x && weight && (y || q_out), "%s: null pointer", fn);
   MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= (1 << 20) && (rows + 3) / 4 < (int64_t)0x7fffffff,
-             "mq_rmsnorm_quant: bad shape %lld x %lld (cols must be a multiple of 4)", (long long)rows, (long long)cols);
+             "%s: bad shape %lld x %lld (cols must be a multiple of 4)", fn, (long long)rows, (long long)cols);
   MQ_REQUIRE((in_scale == nullptr) == (in_offset == nullptr) && (out_scale == nullptr) == (out_offset == nullptr),
-             "mq_rmsnorm_quant: scale/offset must both be set or NULL");
-  MQ_REQUIRE(!q_out || out_scale, "mq_rmsnorm_quant: integer output needs an output quantizer");
-  MQ_REQUIRE(!row_sum || q_out, "mq_rmsnorm_quant: row sums are those of the integer output");
+             "%s: scale/offset must both be set or NULL", fn);
+  MQ_REQUIRE(!q_out || out_scale, "%s: integer output needs an output quantizer", fn);
+  MQ_REQUIRE(!row_sum || q_out, "%s: row sums are those of the integer output", fn);
   MQ_REQUIRE(!q_out || (out_qmin - (float)q_shift >= -128.f && out_qmax - (float)q_shift <= 127.f),
-             "mq_rmsnorm_quant: [%g,%g]-%d does not fit int8", out_qmin, out_qmax, q_shift);
+             "%s: [%g,%g]-%d does not fit int8", fn, out_qmin, out_qmax, q_shift);
   MQ_REQUIRE(aligned(x, 16) && aligned(weight, 16) && (!bias || aligned(bias, 16)) && (!y || aligned(y, 16)) &&
                  (!q_out || aligned(q_out, 4)),
-             "mq_rmsnorm_quant: pointers must be 16-byte aligned");
+             "%s: pointers must be 16-byte aligned", fn);
   if (rows == 0) return MQ_OK;
   NormArgs a{x, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale, out_offset, out_qmin, out_qmax,
              y, q_out, q_shift, row_sum, rows, (int)cols};
   const unsigned grid = (unsigned)((rows + 3) / 4);
   hipStream_t st = as_stream(stream);
-  if (cols <= 256 * 4) rmsnorm_quant_kernel<4><<<grid, 256, 0, st>>>(a);
-  else if (cols <= 256 * 8) rmsnorm_quant_kernel<8><<<grid, 256, 0, st>>>(a);
-  else if (cols <= 256 * 16) rmsnorm_quant_kernel<16><<<grid, 256, 0, st>>>(a);
-  else rmsnorm_quant_kernel<0><<<grid, 256, 0, st>>>(a);
-  MQ_LAUNCH_CHECK("mq_rmsnorm_quant");
+#define MQ_NORM(V)                                                     \
+  do {                                                                 \
+    if (ln) rmsnorm_quant_kernel<V, true><<<grid, 256, 0, st>>>(a);    \
+    else rmsnorm_quant_kernel<V, false><<<grid, 256, 0, st>>>(a);      \
+  } while (0)
+  if (cols <= 256 * 4) MQ_NORM(4);
+  else if (cols <= 256 * 8) MQ_NORM(8);
+  else if (cols <= 256 * 16) MQ_NORM(16);
+  else MQ_NORM(0);
+#undef MQ_NORM
+  MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
+}
+
+extern "C" int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
+                                const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
+                                const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
+                                int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+  return launch_norm("mq_rmsnorm_quant", false, x, rows, cols, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale,
+                     out_offset, out_qmin, out_qmax, y, q_out, q_shift, row_sum, stream);
+}
+
+extern "C" int mq_layernorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
+                                  const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
+                                  const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
+                                  int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+  return launch_norm("mq_layernorm_quant", true, x, rows, cols, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale,
+                     out_offset, out_qmin, out_qmax, y, q_out, q_shift, row_sum, stream);
 }
 
 // ---- QSiLU / QGELU.forward in one pass (qmodule.py:739-754, :790-798) -------------------------------------------

@@ -222,8 +222,9 @@ def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qma
     return out
 
 
-def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_grid=None, out_grid=None, emit_int8: bool = False):
-    """QRMSNorm.forward in one launch.  in_grid / out_grid: None or (scale, offset, qmin, qmax) per-tensor.
+def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_grid=None, out_grid=None, emit_int8: bool = False,
+                  layernorm: bool = False):
+    """QRMSNorm.forward (layernorm=True: QLayerNorm.forward) in one launch.  in_grid / out_grid: None or (scale, offset, qmin, qmax) per-tensor.
     Returns y, or (y, q_int8, row_sum, shift) with emit_int8 (8-bit output grids only)."""
     x = _f32(_dev(x, "x"), "x").contiguous()
     cols = x.shape[-1]
@@ -243,7 +244,7 @@ def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_gr
         shift = 128 if oqmax > 127 else 0
         q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
         rs = torch.empty(rows, dtype=torch.int32, device=x.device)
-    _lib.call("mq_rmsnorm_quant", x.data_ptr(), rows, cols, w.data_ptr(), b.data_ptr() if b is not None else None, float(eps),
+    _lib.call("mq_layernorm_quant" if layernorm else "mq_rmsnorm_quant", x.data_ptr(), rows, cols, w.data_ptr(), b.data_ptr() if b is not None else None, float(eps),
               si.data_ptr() if si is not None else None, oi.data_ptr() if oi is not None else None, iqmin, iqmax,
               so.data_ptr() if so is not None else None, oo.data_ptr() if oo is not None else None, oqmin, oqmax,
               y.data_ptr(), q.data_ptr() if q is not None else None, shift, rs.data_ptr() if rs is not None else None, _stream())

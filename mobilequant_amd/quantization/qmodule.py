@@ -541,6 +541,45 @@ class QMatMul(nn.Module, _QuantizedOp):
         return _apply(self.output_quantizer, out)
 
 
+def _fused_norm(self, input_, weight, bias, layernorm):
+    """QRMSNorm / QLayerNorm.forward as ONE launch (mq_rmsnorm_quant / mq_layernorm_quant) instead of six; with an
+    8-bit output grid the int8 indices + row sums are handed to the consumer linears through the shared-activation
+    memo, so q/k/v (w1/w3) launch no quantize.  None -> the caller runs the composite ops."""
+    if (self.fused_mode == "off" or weight is None or not input_.is_cuda or input_.dtype != torch.float32
+            or weight.dtype != torch.float32 or input_.shape[-1] % 4 or input_.numel() == 0
+            or _needs_grad(input_, weight, bias)):
+        return None
+    gi, go = QRMSNorm._grid_or_none(self.input_quantizer), QRMSNorm._grid_or_none(self.output_quantizer)
+    if gi is False or go is False:
+        return None
+    for g in (gi, go):
+        if g is not None and g[0].device != input_.device:
+            return None                      # first call after a device move: the composite path migrates the grids
+    wq = self.weight_quantizer
+    if wq is not None and _needs_grad(getattr(wq, "scale", None), getattr(wq, "offset", None)):
+        return None
+    # the fake-quantised [dim] weight vector is cached until the weight or its grid changes (the first call
+    # also fixes the weight range from the weight itself, qmodule.py:262-277)
+    key = (weight.data_ptr(), weight._version, None if wq is None or not wq._has_grid() else wq.grid_token(),
+           None if wq is None else (wq.enable, wq.lwc, wq.qcfg.bitwidth, wq.qcfg.is_dynamic))
+    cached = getattr(self, "_wfq", None)
+    if cached is not None and cached[0] == key and key[2] is not None:
+        wfq = cached[1]
+    else:
+        with torch.no_grad():
+            wfq = _apply(wq, weight)
+        if wq is not None and wq._has_grid() and not wq.lwc and not wq.qcfg.is_dynamic:
+            key = (key[0], key[1], wq.grid_token(), key[3])
+            self._wfq = (key, wfq)
+    emit = go is not None and self.output_quantizer.qcfg.bitwidth <= 8
+    res = ops.rmsnorm_quant(input_, wfq, bias, self.eps, gi, go, emit_int8=emit, layernorm=layernorm)
+    if not emit:
+        return res
+    y, q, rs, shift = res
+    _shared_activation.put(y, self.output_quantizer, shift, (q, rs, shift))
+    return y
+
+
 class QRMSNorm(HFRMSNorm, _QuantizedOp):
     """RMSNorm with quantized weight / input / output (reference: qmodule.py:469-576)."""
 
@@ -564,41 +603,9 @@ class QRMSNorm(HFRMSNorm, _QuantizedOp):
         return (q.scale.detach(), q.offset.detach(), q.qmin, q.qmax)
 
     def _forward_fused(self, input_, weight):
-        """One launch (mq_rmsnorm_quant) instead of six; with an 8-bit output grid the int8 indices + row sums are
-        handed to the consumer linears through the shared-activation memo, so q/k/v (w1/w3) launch no quantize."""
-        if (self.fused_mode == "off" or self.l2norm_as_rmsnorm or not input_.is_cuda or input_.dtype != torch.float32
-                or weight.dtype != torch.float32 or input_.shape[-1] % 4 or input_.numel() == 0
-                or _needs_grad(input_, weight, self.bias)):
+        if self.l2norm_as_rmsnorm:
             return None
-        gi, go = self._grid_or_none(self.input_quantizer), self._grid_or_none(self.output_quantizer)
-        if gi is False or go is False:
-            return None
-        for g in (gi, go):
-            if g is not None and g[0].device != input_.device:
-                return None                      # first call after a device move: the composite path migrates the grids
-        wq = self.weight_quantizer
-        if wq is not None and _needs_grad(getattr(wq, "scale", None), getattr(wq, "offset", None)):
-            return None
-        # the fake-quantised [dim] weight vector is cached until the weight or its grid changes (the first call
-        # also fixes the weight range from the weight itself, qmodule.py:262-277)
-        key = (weight.data_ptr(), weight._version, None if wq is None or not wq._has_grid() else wq.grid_token(),
-               None if wq is None else (wq.enable, wq.lwc, wq.qcfg.bitwidth, wq.qcfg.is_dynamic))
-        cached = getattr(self, "_wfq", None)
-        if cached is not None and cached[0] == key and key[2] is not None:
-            wfq = cached[1]
-        else:
-            with torch.no_grad():
-                wfq = _apply(wq, weight)
-            if wq is not None and wq._has_grid() and not wq.lwc and not wq.qcfg.is_dynamic:
-                key = (key[0], key[1], wq.grid_token(), key[3])
-                self._wfq = (key, wfq)
-        emit = go is not None and self.output_quantizer.qcfg.bitwidth <= 8
-        res = ops.rmsnorm_quant(input_, wfq, self.bias, self.eps, gi, go, emit_int8=emit)
-        if not emit:
-            return res
-        y, q, rs, shift = res
-        _shared_activation.put(y, self.output_quantizer, shift, (q, rs, shift))
-        return y
+        return _fused_norm(self, input_, weight, self.bias, layernorm=False)
 
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
@@ -632,6 +639,8 @@ class QRMSNorm(HFRMSNorm, _QuantizedOp):
 class QLayerNorm(nn.LayerNorm, _QuantizedOp):
     """LayerNorm with quantized weight / input / output (reference: qmodule.py:579-688)."""
 
+    fused_mode = "auto"
+
     _slots = (("input", "input_quantizer"), ("weight", "weight_quantizer"), ("output", "output_quantizer"))
 
     def __init__(self, kargs, input_quant_cfg, weight_quant_cfg, output_quant_cfg):
@@ -642,6 +651,9 @@ class QLayerNorm(nn.LayerNorm, _QuantizedOp):
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
         bias = self.temp_bias if self.use_temporary_parameter else self.bias
+        out = _fused_norm(self, input_, weight, bias, layernorm=True)
+        if out is not None:
+            return out
         weight = _apply(self.weight_quantizer, weight)
         input_ = _apply(self.input_quantizer, input_)
         out = F.layer_norm(input_, input_.shape[-1:], weight=weight, bias=bias, eps=self.eps)

@@ -283,6 +283,25 @@ def gen_qrmsnorm_cases():
         out[k + "_x"], out[k + "_w"], out[k + "_y"] = npf(x), npf(fp.weight), npf(y)
         out[k + "_wscale"], out[k + "_woffset"] = npf(qn.weight_quantizer.scale.float()), npf(qn.weight_quantizer.offset.float())
         meta.append(dict(id=k, rows=rows, cols=cols, in_bits=in_bits, out_bits=out_bits, eps=1e-5, act=act))
+    # QLayerNorm (StableLM-2: LayerNorm with bias), same mixed-precision rules
+    for rows, cols, in_bits, out_bits in ((24, 256, 16, 8), (6, 2048, 16, 8), (24, 256, None, 16), (24, 256, 16, None)):
+        fp = nn.LayerNorm(cols, eps=1e-5)
+        with torch.no_grad():
+            fp.weight.copy_(torch.randn(cols, generator=g) * 0.3 + 1.0)
+            fp.bias.copy_(torch.randn(cols, generator=g) * 0.1)
+        a16 = Q.QuantConfig(bitwidth=16)
+        qn = Q.QLayerNorm.from_float(fp, Q.QuantConfig(bitwidth=in_bits) if in_bits else None, a16,
+                                     Q.QuantConfig(bitwidth=out_bits) if out_bits else None)
+        x = torch.randn(1, rows, cols, generator=g) * 2.5 + 0.7
+        act = {"input": [float(x.min()) * 0.9, float(x.max()) * 0.9]}
+        y_fp = fp(x)
+        act["output"] = [float(y_fp.min()) * 0.95, float(y_fp.max()) * 0.95]
+        qn.set_scale_offset(act, "buffer")
+        y = qn(x)
+        k = f"n{len(meta)}"
+        out[k + "_x"], out[k + "_w"], out[k + "_b"], out[k + "_y"] = npf(x), npf(fp.weight), npf(fp.bias), npf(y)
+        out[k + "_wscale"], out[k + "_woffset"] = npf(qn.weight_quantizer.scale.float()), npf(qn.weight_quantizer.offset.float())
+        meta.append(dict(id=k, rows=rows, cols=cols, in_bits=in_bits, out_bits=out_bits, eps=1e-5, act=act, layernorm=True))
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "qrmsnorm_cases.npz"), **out)
 

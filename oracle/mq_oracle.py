@@ -340,6 +340,23 @@ def qrmsnorm(x, weight, bias, eps, in_q, w_q, out_q):
     return out_q.forward(y) if out_q is not None else y
 
 
+def qlayernorm(x, weight, bias, eps, in_q, w_q, out_q):
+    """QLayerNorm.forward (qmodule.py:624-640 around F.layer_norm), fp32: mean and biased variance over the last dim,
+    ``y = (xi * rstd + (-rstd * mean)) * Qw(weight) + bias`` (the expression of torch's CPU kernel; bias is not
+    quantised), then the output quantizer.  Same summation-order caveat as qrmsnorm."""
+    x = np.asarray(x, dtype=F32)
+    xi = in_q.forward(x) if in_q is not None else x
+    wq = w_q.forward(np.asarray(weight, dtype=F32)) if w_q is not None else np.asarray(weight, dtype=F32)
+    mu = xi.mean(axis=-1, keepdims=True, dtype=F32)
+    d = (xi - mu).astype(F32)
+    var = (d * d).astype(F32).mean(axis=-1, keepdims=True, dtype=F32)
+    rstd = (F32(1.0) / np.sqrt((var + F32(eps)).astype(F32)).astype(F32)).astype(F32)
+    y = (((xi * rstd).astype(F32) + (-rstd * mu).astype(F32)).astype(F32) * wq).astype(F32)
+    if bias is not None:
+        y = (y + np.asarray(bias, dtype=F32)).astype(F32)
+    return out_q.forward(y) if out_q is not None else y
+
+
 def qsilu(x, in_q, mid_q, out_q):
     """QSiLU.forward (qmodule.py:739-754): ``Qout( xi * Qmid(sigmoid(xi)) )``, ``xi = Qin(x)``; fp32, sigmoid =
     1 / (1 + exp(-x)).  exp is the platform's (<= 1 ulp), so agreement with the frozen reference output is up to

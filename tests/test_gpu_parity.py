@@ -787,13 +787,17 @@ def test_qrmsnorm_fused_kernel_vs_reference(dev):
     z = load_npz("qrmsnorm_cases.npz")
     for m in load_meta(z):
         k = m["id"]
-        fp = HFRMSNorm(m["cols"], eps=m["eps"])
+        ln = bool(m.get("layernorm"))
+        fp = torch.nn.LayerNorm(m["cols"], eps=m["eps"]) if ln else HFRMSNorm(m["cols"], eps=m["eps"])
         with torch.no_grad():
             fp.weight.copy_(torch.from_numpy(z[k + "_w"]))
+            if ln:
+                fp.bias.copy_(torch.from_numpy(z[k + "_b"]))
         fp = fp.to(dev)
         a16 = mq.QuantConfig(bitwidth=16)
-        qn = mq.QRMSNorm.from_float(fp, mq.QuantConfig(bitwidth=m["in_bits"]) if m["in_bits"] else None, a16,
-                                    mq.QuantConfig(bitwidth=m["out_bits"]) if m["out_bits"] else None).requires_grad_(False)
+        qn = (mq.QLayerNorm if ln else mq.QRMSNorm).from_float(
+            fp, mq.QuantConfig(bitwidth=m["in_bits"]) if m["in_bits"] else None, a16,
+            mq.QuantConfig(bitwidth=m["out_bits"]) if m["out_bits"] else None).requires_grad_(False)
         qn.set_scale_offset(m["act"], "buffer")
         x = T(z[k + "_x"], dev)
         with torch.no_grad():
@@ -813,9 +817,9 @@ def test_qrmsnorm_fused_kernel_vs_reference(dev):
         assert _norm_close(y.cpu().numpy(), y_comp.cpu().numpy(), m), m
         if m["out_bits"] == 8:
             oq = qn.output_quantizer
-            _, q, rs, shift = ops.rmsnorm_quant(x, qn.weight_quantizer(fp.weight), None, m["eps"],
+            _, q, rs, shift = ops.rmsnorm_quant(x, qn.weight_quantizer(fp.weight), fp.bias if ln else None, m["eps"],
                                                 (qn.input_quantizer.scale, qn.input_quantizer.offset, qn.input_quantizer.qmin, qn.input_quantizer.qmax) if m["in_bits"] else None,
-                                                (oq.scale, oq.offset, oq.qmin, oq.qmax), emit_int8=True)
+                                                (oq.scale, oq.offset, oq.qmin, oq.qmax), emit_int8=True, layernorm=ln)
             q2, rs2, shift2 = oq.quantize_to_int(y.reshape(-1, m["cols"]), MQ_I8, want_row_sum=True)
             assert shift == shift2 and torch.equal(q, q2) and torch.equal(rs, rs2)
 

@@ -316,7 +316,10 @@ def test_qrmsnorm_cases():
     for m in load_meta(z):
         k = m["id"]
         in_q, w_q, out_q = _norm_quantizers(m, z)
-        y = O.qrmsnorm(z[k + "_x"], z[k + "_w"], None, m["eps"], in_q, w_q, out_q)
+        if m.get("layernorm"):
+            y = O.qlayernorm(z[k + "_x"], z[k + "_w"], z[k + "_b"], m["eps"], in_q, w_q, out_q)
+        else:
+            y = O.qrmsnorm(z[k + "_x"], z[k + "_w"], None, m["eps"], in_q, w_q, out_q)
         assert np.array_equal(np.asarray(w_q.scale, F32).reshape(z[k + "_wscale"].shape), z[k + "_wscale"])
         assert y.shape == z[k + "_y"].shape and norm_close(y, z[k + "_y"], m), m
 
