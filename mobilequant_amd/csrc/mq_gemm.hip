@@ -632,6 +632,7 @@ static const Variant kVariants[] = {
     {"t256x128_w4x2", 256, 128, 512},
     {"t64x64_w2x2", 64, 64, 256},
     {"t256x176_w8x1_pp", 256, 176, 512},
+    {"t64x32_w2x2", 64, 32, 256},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static int g_forced_variant = -1;
@@ -705,19 +706,29 @@ static int launch_cfg(const GemmArgs& a, bool outq, hipStream_t st) {
   }
 }
 
-static int pick_variant(int M, int N) {
+static int pick_variant(int M, int N, bool w4) {
   if (g_forced_variant >= 0) return g_forced_variant;
   auto blocks = [&](int v) {
     return (long)((M + kVariants[v].bm - 1) / kVariants[v].bm) * ((N + kVariants[v].bn - 1) / kVariants[v].bn);
   };
-  // Measured on MI355X (tools/mq_probe, profiles/): the 8-wave 256x176 tile is the fastest whenever it
-  // tiles N exactly and fills the chip in one round (TinyLlama / StableLM FFN: N = 5632 = 32 x 176);
-  // otherwise pick the largest tile that still gives every CU a workgroup, else the small tiles.
-  if (N % 176 == 0 && blocks(1) >= 192) return 7;   // ping-pong schedule (variant 1 = same tile, simple 2-stage loop)
-  const int order[] = {2, 5, 3, 6};   // 256x256, 256x128, 128x128, 64x64
-  for (int v : order)
-    if (blocks(v) >= (v == 5 ? 160 : 224)) return v;   // 256x128 already wins at 160 workgroups (fused q|k|v, N = 2560)
-  return blocks(3) >= 96 ? 3 : 6;
+  // Measured on MI355X (tools/bench_shapes.py --sweep, profiles/r01/linear_shapes_all_variants.txt):
+  //  * the 8-wave 256x176 ping-pong tile is the fastest whenever it tiles N exactly and fills the chip in one
+  //    round (TinyLlama / StableLM FFN: N = 5632 = 32 x 176); int8 weights only;
+  //  * otherwise the largest tile that still gives (nearly) every CU a workgroup: 256x256 (Gemma FFN), 256x128
+  //    (fused q|k|v, N = 2560: wins from 160 workgroups);
+  //  * N = 2048 outputs (q/o, w2): four co-resident 64x64 workgroups per CU overlap each other's fill, drain and
+  //    epilogue and beat one 128x128 tile per CU by 3-8 % (W4: 17-21 %, fewer waves unpack the same nibbles);
+  //  * packed 4-bit weights: 256x256 from 160 workgroups, else 64x64 from one workgroup per CU, else 64x32.
+  if (w4) {
+    if (blocks(2) >= 160) return 2;
+    return blocks(6) >= 256 ? 6 : 8;
+  }
+  if (N % 176 == 0 && blocks(1) >= 192) return 7;
+  if (blocks(2) >= 224) return 2;
+  if (blocks(5) >= 160) return 5;
+  if (blocks(6) >= 512) return 6;
+  if (blocks(3) >= 96) return 3;
+  return blocks(6) >= 256 ? 6 : 8;
 }
 
 template <bool W4>
@@ -726,7 +737,7 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
   a.has_rowsum = a.a_rowsum != nullptr;
   if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;                 // element 0 only (M may exceed N); multiplied by w_zp == 0
   if (a.bias == nullptr) a.bias = a.alpha;                            // masked by has_bias
-  const int v = pick_variant(a.M, a.N);
+  const int v = pick_variant(a.M, a.N, W4);
   a.grid_m = (a.M + kVariants[v].bm - 1) / kVariants[v].bm;
   a.grid_n = (a.N + kVariants[v].bn - 1) / kVariants[v].bn;
   switch (v) {
@@ -740,6 +751,7 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
     case 7:
       if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, true>(a, outq, st);
       else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
+    case 8: return launch_cfg<64, 32, 2, 2, W4>(a, outq, st);
     default: set_error("mq_gemm: bad variant %d", v); return MQ_EINVAL;
   }
 }
