@@ -60,14 +60,27 @@ struct NormArgs {
   int cols;
 };
 
-// V = float4 vectors held per lane (cols <= 256 * V); V == 0: the row is re-read instead of kept.
+// TPR = threads per row: 64 (a wave owns a row, 4 rows per workgroup) for short rows, 256 (a workgroup owns a row,
+// reductions through LDS) for cols >= 1024 -- at M = 2048 rows the wave-per-row mapping leaves only 2 waves per SIMD,
+// all in the same phase (load, then ~55 VALU ops per element, then store), so nothing overlaps.
+// V = float4 vectors held per thread (cols <= 4 * TPR * V); V == 0: the row is re-read instead of kept.
 // LN: LayerNorm (QLayerNorm.forward, qmodule.py:624-640 around F.layer_norm) instead of RMSNorm: mean and biased
 // variance of the row, y = (xi * rstd + (-rstd * mean)) * gamma + beta -- the expression of torch's CPU kernel.
-template <int V, bool LN>
+template <int V, bool LN, int TPR>
 __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
+  __shared__ float s_red[3][4];
+  __shared__ int s_redi[4];
+  const int lane = TPR == 64 ? (threadIdx.x & 63) : threadIdx.x;   // index of this thread inside its row
+  const int wv_id = threadIdx.x >> 6;
+  const int64_t row = TPR == 64 ? (int64_t)blockIdx.x * 4 + wv_id : (int64_t)blockIdx.x;
+  if (TPR == 64 && row >= a.rows) return;      // TPR == 256: grid == rows, and the block-wide reductions need everyone
+  auto row_sum_f = [&](float v, int slot) {
+    v = wave_sum_f32(v);
+    if constexpr (TPR == 64) return v;
+    if ((threadIdx.x & 63) == 0) s_red[slot][wv_id] = v;
+    __syncthreads();
+    return (s_red[slot][0] + s_red[slot][1]) + (s_red[slot][2] + s_red[slot][3]);
+  };
   const int cols = a.cols, nvec = cols >> 2;
   const float4* xr = reinterpret_cast<const float4*>(a.x + row * cols);
   const float4* wv = reinterpret_cast<const float4*>(a.weight);
@@ -90,7 +103,7 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
   if constexpr (V > 0) {
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      const int i = lane + 64 * k;
+      const int i = lane + TPR * k;
       if (i < nvec) {
         float4 v = xr[i];
         v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
@@ -102,7 +115,7 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
       }
     }
   } else {
-    for (int i = lane; i < nvec; i += 64) {
+    for (int i = lane; i < nvec; i += TPR) {
       float4 v = xr[i];
       v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
       ss += v.x * v.x;
@@ -118,14 +131,14 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
     if constexpr (V > 0) {
 #pragma unroll
       for (int k = 0; k < V; ++k)
-        if (lane + 64 * k < nvec) s1 += (xs[k].x + xs[k].y) + (xs[k].z + xs[k].w);
+        if (lane + TPR * k < nvec) s1 += (xs[k].x + xs[k].y) + (xs[k].z + xs[k].w);
     } else {
-      for (int i = lane; i < nvec; i += 64) {
+      for (int i = lane; i < nvec; i += TPR) {
         float4 v = xr[i];
         s1 += (qin(v.x) + qin(v.y)) + (qin(v.z) + qin(v.w));
       }
     }
-    const float mu = __fdiv_rn(wave_sum_f32(s1), (float)cols);
+    const float mu = __fdiv_rn(row_sum_f(s1, 0), (float)cols);
     float s2 = 0.f;
     auto dev2 = [&](float4 v) {
       const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
@@ -137,19 +150,19 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
     if constexpr (V > 0) {
 #pragma unroll
       for (int k = 0; k < V; ++k)
-        if (lane + 64 * k < nvec) dev2(xs[k]);
+        if (lane + TPR * k < nvec) dev2(xs[k]);
     } else {
-      for (int i = lane; i < nvec; i += 64) {
+      for (int i = lane; i < nvec; i += TPR) {
         float4 v = xr[i];
         v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
         dev2(v);
       }
     }
-    const float var = __fdiv_rn(wave_sum_f32(s2), (float)cols);
+    const float var = __fdiv_rn(row_sum_f(s2, 1), (float)cols);
     r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, a.eps)));
     shiftv = __fmul_rn(-r, mu);
   } else {
-    ss = wave_sum_f32(ss);
+    ss = row_sum_f(ss, 2);
     const float mean = __fdiv_rn(ss, (float)cols);
     r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, a.eps)));
   }
@@ -186,11 +199,11 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
   if constexpr (V > 0) {
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      const int i = lane + 64 * k;
+      const int i = lane + TPR * k;
       if (i < nvec) emit(i, xs[k]);
     }
   } else {
-    for (int i = lane; i < nvec; i += 64) {
+    for (int i = lane; i < nvec; i += TPR) {
       float4 v = xr[i];
       v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
       emit(i, v);
@@ -198,7 +211,13 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
   }
   if (a.row_sum) {
     acc = wave_sum(acc);
-    if (lane == 0) a.row_sum[row] = acc;
+    if constexpr (TPR == 64) {
+      if (lane == 0) a.row_sum[row] = acc;
+    } else {
+      if ((threadIdx.x & 63) == 0) s_redi[wv_id] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) a.row_sum[row] = (s_redi[0] + s_redi[1]) + (s_redi[2] + s_redi[3]);
+    }
   }
 }
 
@@ -211,7 +230,7 @@ static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, in
                        const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
                        int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
   MQ_REQUIRE(x && weight && (y || q_out), "%s: null pointer", fn);
-  MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= (1 << 20) && (rows + 3) / 4 < (int64_t)0x7fffffff,
+  MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= (1 << 20) && rows < (int64_t)0x7fffffff,
              "%s: bad shape %lld x %lld (cols must be a multiple of 4)", fn, (long long)rows, (long long)cols);
   MQ_REQUIRE((in_scale == nullptr) == (in_offset == nullptr) && (out_scale == nullptr) == (out_offset == nullptr),
              "%s: scale/offset must both be set or NULL", fn);
@@ -225,17 +244,19 @@ static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, in
   if (rows == 0) return MQ_OK;
   NormArgs a{x, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale, out_offset, out_qmin, out_qmax,
              y, q_out, q_shift, row_sum, rows, (int)cols};
-  const unsigned grid = (unsigned)((rows + 3) / 4);
   hipStream_t st = as_stream(stream);
-#define MQ_NORM(V)                                                     \
-  do {                                                                 \
-    if (ln) rmsnorm_quant_kernel<V, true><<<grid, 256, 0, st>>>(a);    \
-    else rmsnorm_quant_kernel<V, false><<<grid, 256, 0, st>>>(a);      \
+#define MQ_NORM(V, TPR)                                                                                   \
+  do {                                                                                                    \
+    const unsigned grid = (TPR) == 64 ? (unsigned)((rows + 3) / 4) : (unsigned)rows;                      \
+    if (ln) rmsnorm_quant_kernel<V, true, TPR><<<grid, 256, 0, st>>>(a);                                  \
+    else rmsnorm_quant_kernel<V, false, TPR><<<grid, 256, 0, st>>>(a);                                    \
   } while (0)
-  if (cols <= 256 * 4) MQ_NORM(4);
-  else if (cols <= 256 * 8) MQ_NORM(8);
-  else if (cols <= 256 * 16) MQ_NORM(16);
-  else MQ_NORM(0);
+  if (cols < 1024) MQ_NORM(4, 64);                      // short rows: a wave per row
+  else if (cols <= 1024) MQ_NORM(1, 256);               // a workgroup per row from here on
+  else if (cols <= 2048) MQ_NORM(2, 256);
+  else if (cols <= 4096) MQ_NORM(4, 256);
+  else if (cols <= 8192) MQ_NORM(8, 256);
+  else MQ_NORM(0, 256);
 #undef MQ_NORM
   MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
