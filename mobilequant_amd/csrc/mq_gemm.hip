@@ -26,6 +26,7 @@
 
 #include "mq_common.h"
 #include "mq_gemv.h"
+#include "mq_gemm_pp_asm.inc"
 
 namespace mq {
 
@@ -96,7 +97,7 @@ constexpr int lds_main_bytes(int BM, int BN, int WM, int WN, bool W4, bool PP) {
 
 // ABL: compile-time ablation for profiling builds (-DMQ_GEMM_ABLATE): bit0 = no LDS-DMA after the
 // first stage, bit1 = no MFMA loop body, bit2 = no epilogue.  Production instantiates ABL = 0 only.
-template <int BM, int BN, int WM, int WN, int OUT, bool OUTQ, bool W4, int ABL = 0, bool PP = false>
+template <int BM, int BN, int WM, int WN, int OUT, bool OUTQ, bool W4, int ABL = 0, int PP = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
     gemm_i8_kernel(const GemmArgs args) {
   constexpr int NW = WM * WN;
@@ -120,7 +121,10 @@ __global__ void __launch_bounds__(64 * WM * WN)
   // LDS map.  classic: [stage 0: A|W][stage 1: A|W][params].  ping-pong: [A0][A1][W0][W1][W2][params] --
   // three W buffers give the shared weight rows five phases of flight time (A rows are private per wave).
   constexpr int W_BASE = PP ? 2 * A_BYTES : A_BYTES;
-  constexpr int PAR = lds_main_bytes(BM, BN, WM, WN, W4, PP);       // LDS offset of the per-n epilogue vectors
+  constexpr int PAR = lds_main_bytes(BM, BN, WM, WN, W4, PP != 0);  // LDS offset of the per-n epilogue vectors
+  // PP == 3: the ping-pong main loop is the generated ISA of mq_gemm_pp_asm.inc (tools/gen_pp_asm.py): A fragments go
+  // HBM/L2 -> AGPRs directly, accumulators live in AGPRs; K % 256 == 0.  Prologue and epilogue are the C++ below.
+  constexpr bool ASMK = PP == 3;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -243,11 +247,11 @@ __global__ void __launch_bounds__(64 * WM * WN)
   }
   // first stage(s) go out now; the barrier that publishes the parked vectors follows the issue
 #pragma unroll
-  for (int d = 0; d < N_DMA; ++d) issue_one(d, 0, 0, 0);
+  for (int d = ASMK ? A_ROUNDS : 0; d < N_DMA; ++d) issue_one(d, 0, 0, 0);     // ASMK: A never passes through the LDS
   if constexpr (PP) {
     if (KT > 1) {
 #pragma unroll
-      for (int d = 0; d < N_DMA; ++d) issue_one(d, 1, 1, 1);
+      for (int d = ASMK ? A_ROUNDS : 0; d < N_DMA; ++d) issue_one(d, 1, 1, 1);
     }
   }
   asm volatile("s_barrier" ::: "memory");
@@ -283,7 +287,52 @@ __global__ void __launch_bounds__(64 * WM * WN)
     }
   }
 
-  if constexpr (PP) {
+  if constexpr (ASMK) {
+    static_assert(!ASMK || (BM == 256 && BN == 176 && NW == 8 && WN == 1 && !W4 && FM == 2 && FN == 11), "generated loop: 256x176, 8x1");
+    // accumulators -> AGPRs (22 per asm statement: operand limit), the generated loop, AGPRs -> accumulators
+    int flat[88];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) flat[(2 * j + i) * 4 + e] = acc[i][j][e];
+#define MQ_OPS22(C, Q) Q(flat[C*22+0]), Q(flat[C*22+1]), Q(flat[C*22+2]), Q(flat[C*22+3]), Q(flat[C*22+4]), Q(flat[C*22+5]), Q(flat[C*22+6]), \
+    Q(flat[C*22+7]), Q(flat[C*22+8]), Q(flat[C*22+9]), Q(flat[C*22+10]), Q(flat[C*22+11]), Q(flat[C*22+12]), Q(flat[C*22+13]),                  \
+    Q(flat[C*22+14]), Q(flat[C*22+15]), Q(flat[C*22+16]), Q(flat[C*22+17]), Q(flat[C*22+18]), Q(flat[C*22+19]), Q(flat[C*22+20]), Q(flat[C*22+21])
+#define MQ_IN(x) "v"(x)
+#define MQ_OUT(x) "=v"(x)
+    asm volatile(MQ_PP_ASM_COPYIN0 ::MQ_OPS22(0, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
+    asm volatile(MQ_PP_ASM_COPYIN1 ::MQ_OPS22(1, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
+    asm volatile(MQ_PP_ASM_COPYIN2 ::MQ_OPS22(2, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
+    asm volatile(MQ_PP_ASM_COPYIN3 ::MQ_OPS22(3, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
+    {
+      int row0 = m0 + wave_m * TM + (lane & 15), row1 = row0 + 16;
+      row0 = row0 < M ? row0 : M - 1;
+      row1 = row1 < M ? row1 : M - 1;
+      const unsigned av0 = (unsigned)row0 * (unsigned)K + ((unsigned)(lane >> 4) << 4);
+      const unsigned av1 = (unsigned)row1 * (unsigned)K + ((unsigned)(lane >> 4) << 4);
+      const unsigned woff0 = (unsigned)w_off, woff1 = (unsigned)w_off1;
+      asm volatile(MQ_PP_ASM_BODY
+                   :
+                   : [kt] "s"(KT), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [woff0] "v"(woff0), [woff1] "v"(woff1),
+                     [av0] "v"(av0), [av1] "v"(av1), [sw0] "v"(src_w[0]), [sw1] "v"(src_w[1]), [sw2] "v"(src_w[2])
+                   : MQ_PP_ASM_CLOBBERS);
+    }
+    asm volatile(MQ_PP_ASM_COPYOUT0 : MQ_OPS22(0, MQ_OUT) : : MQ_PP_ASM_ACLOBBERS);
+    asm volatile(MQ_PP_ASM_COPYOUT1 : MQ_OPS22(1, MQ_OUT) : : MQ_PP_ASM_ACLOBBERS);
+    asm volatile(MQ_PP_ASM_COPYOUT2 : MQ_OPS22(2, MQ_OUT) : : MQ_PP_ASM_ACLOBBERS);
+    asm volatile(MQ_PP_ASM_COPYOUT3 : MQ_OPS22(3, MQ_OUT) : : MQ_PP_ASM_ACLOBBERS);
+#undef MQ_OPS22
+#undef MQ_IN
+#undef MQ_OUT
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = flat[(2 * j + i) * 4 + e];
+  } else if constexpr (PP) {
     // ---- ping-pong main loop (8 waves = two groups of four, one wave of each group per SIMD) --------
     // Unit of work u = (stage t, k-step ks) = one MFMA k-step of 64 over the wave's whole tile.
     //   phase E_u : group 0 issues the MFMAs of unit u from registers | group 1 ds_reads unit u
@@ -633,13 +682,14 @@ static const Variant kVariants[] = {
     {"t64x64_w2x2", 64, 64, 256},
     {"t256x176_w8x1_pp", 256, 176, 512},
     {"t64x32_w2x2", 64, 32, 256},
+    {"t256x176_w8x1_pp_asm", 256, 176, 512},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static int g_forced_variant = -1;
 static int g_debug = 0;
 static unsigned long long* g_dbg_ts = nullptr;
 
-template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, int ABL, bool PP>
+template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, int ABL, int PP>
 static int launch_one(const GemmArgs& a, int lds, hipStream_t st) {
   auto kfn = gemm_i8_kernel<BM, BN, WM, WN, OUT, OQ, W4, ABL, PP>;
   static bool attr_set = false;   // per instantiation; one device per process
@@ -656,9 +706,9 @@ static int launch_one(const GemmArgs& a, int lds, hipStream_t st) {
   return MQ_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, bool PP>
+template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, int PP>
 static int launch_typed(const GemmArgs& a, hipStream_t st) {
-  constexpr int LDS = lds_main_bytes(BM, BN, WM, WN, W4, PP) + 16 * BN;
+  constexpr int LDS = lds_main_bytes(BM, BN, WM, WN, W4, PP != 0) + 16 * BN;
 #ifdef MQ_GEMM_ABLATE
   if constexpr (OUT == MQ_U8 && OQ && !W4 && BM == 256) {
     switch (g_debug) {
@@ -684,7 +734,7 @@ static int launch_typed(const GemmArgs& a, hipStream_t st) {
   return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 0, PP>(a, LDS, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool W4, bool PP = false>
+template <int BM, int BN, int WM, int WN, bool W4, int PP = 0>
 static int launch_cfg(const GemmArgs& a, bool outq, hipStream_t st) {
   if (outq) {
     switch (a.out_dtype) {
@@ -749,8 +799,15 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
     case 5: return launch_cfg<256, 128, 4, 2, W4>(a, outq, st);
     case 6: return launch_cfg<64, 64, 2, 2, W4>(a, outq, st);
     case 7:
-      if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, true>(a, outq, st);
+      if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, 1>(a, outq, st);
       else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
+    case 9:     // generated-ISA main loop: whole pairs of K = 128 stages only
+      if constexpr (!W4) {
+        if (a.K % 256 == 0) return launch_cfg<256, 176, 8, 1, false, 3>(a, outq, st);
+        return launch_cfg<256, 176, 8, 1, false, 1>(a, outq, st);
+      } else {
+        return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
+      }
     case 8: return launch_cfg<64, 32, 2, 2, W4>(a, outq, st);
     default: set_error("mq_gemm: bad variant %d", v); return MQ_EINVAL;
   }
