@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--workload", default="qlinear", choices=["qlinear", "calibration"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--gemm-variant", type=int, default=-1, help="force a GEMM tile variant (experiments)")
     p.add_argument("--overlap", action="store_true",
                    help="experiment: quantize(batch i+1) on a side stream next to GEMM(batch i); measured SLOWER "
                         "(36.3 vs 34.7 us/step): the GEMM's one workgroup per CU leaves no room to co-schedule")
@@ -365,6 +366,9 @@ def main():
 
     with torch.no_grad():
         step = Step(dev, MQ_U8, seed=rank)
+        if args.gemm_variant >= 0:
+            from mobilequant_amd import _lib as _l
+            _l.load().mq_gemm_set_variant(args.gemm_variant)
         pipelined = args.overlap and not args.no_graph
         sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph, pipelined=pipelined)
         sec = max_over_ranks(sec, world)
