@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--gemm-variant", type=int, default=-1, help="force a GEMM tile variant (experiments)")
+    p.add_argument("--row-major-activations", action="store_true",
+                   help="A/B: quantise row-major and run the C++ ping-pong GEMM loop instead of the fragment-blocked layout")
     p.add_argument("--overlap", action="store_true",
                    help="experiment: quantize(batch i+1) on a side stream next to GEMM(batch i); measured SLOWER "
                         "(36.3 vs 34.7 us/step): the GEMM's one workgroup per CU leaves no room to co-schedule")
@@ -85,6 +87,8 @@ def max_over_ranks(v: float, world) -> float:
 class Step:
     """The real-int8 QLinear step on preallocated buffers (no allocation inside the timed region)."""
 
+    tiled_ok = True       # --row-major-activations turns the fragment-blocked layout off (A/B)
+
     def __init__(self, dev, out_dtype_code, seed):
         from mobilequant_amd import ops
         from mobilequant_amd._lib import MQ_I8
@@ -114,11 +118,17 @@ class Step:
         self.a8, self.rs = self.a8s[0], self.rss[0]
         self.out = torch.empty(M, N, dtype=_OUT_TORCH[out_dtype_code], device=dev)
         self.w_fp = w
+        # the layout QLinear._forward_int8 picks for this shape: fragment-blocked activations + generated-ISA GEMM loop
+        self.tiled = Step.tiled_ok and ops.gemm_tiled_supported(M, N, K)
 
     def quantize(self, i, slot=0):
         from mobilequant_amd import _lib
         from mobilequant_amd._lib import MQ_F32, MQ_I8
         x = self.x[i % N_BATCHES]
+        if self.tiled:
+            _lib.call("mq_quantize_tiled", x.data_ptr(), MQ_F32, M, K, self.aq.scale.data_ptr(), self.aq.offset.data_ptr(),
+                      0.0, 255.0, 128, self.a8s[slot].data_ptr(), self.rss[slot].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            return
         _lib.call("mq_quantize", x.data_ptr(), MQ_F32, M, K, self.aq.scale.data_ptr(), self.aq.offset.data_ptr(), 1,
                   0.0, 255.0, 128, self.a8s[slot].data_ptr(), MQ_I8, self.rss[slot].data_ptr(),
                   torch.cuda.current_stream().cuda_stream)
@@ -126,7 +136,7 @@ class Step:
     def gemm(self, slot=0):
         self.ops.int8_linear(self.a8s[slot], self.w8, self.rss[slot], self.alpha, self.wzp, self.ct, None,
                              out_scale=self.oq.scale, out_offset=self.oq.offset, out_qmin=0.0, out_qmax=255.0,
-                             out_dtype=self.code, out=self.out)
+                             out_dtype=self.code, out=self.out, a_tiled_rows=M if self.tiled else None)
 
     def __call__(self, i):
         self.quantize(i)
@@ -365,6 +375,7 @@ def main():
         return bench_calibration(args, rank, world, dev)
 
     with torch.no_grad():
+        Step.tiled_ok = not args.row_major_activations
         step = Step(dev, MQ_U8, seed=rank)
         if args.gemm_variant >= 0:
             from mobilequant_amd import _lib as _l
@@ -382,7 +393,8 @@ def main():
             t_quant = event_time(lambda: step.quantize(0), 50)
             achieved = OPS_PER_STEP / t_gemm / 1e12
             traffic, traffic_src = pmc_traffic()
-            roof = {"bound": "mfma", "kernel": "mq::gemm_i8_kernel (mq_w8a8_linear)", "achieved": round(achieved, 1),
+            roof = {"bound": "mfma", "kernel": "mq::gemm_i8_kernel (%s)" % ("mq_w8a8_linear_tiled: generated-ISA loop, fragment-blocked activations"
+                                                                        if step.tiled else "mq_w8a8_linear"), "achieved": round(achieved, 1),
                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOPS", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
                     "avg_launch_us": round(t_gemm * 1e6, 2), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": M * K + N * K + M * N,

@@ -377,6 +377,84 @@ static int launch_fake_quant(const T* x, T* y, int64_t rows, int64_t cols, const
   return MQ_OK;
 }
 
+// ---- a5 -> int8, fragment-blocked ("tiled") output for the generated-ISA GEMM loop ------------------------------
+// Layout: 1-KiB blocks of 16 rows x 64 k, ordered [row block][k block]; inside a block lane l = (row & 15) + 16 * ((k & 63) >> 4)
+// owns the 16 bytes k & 15 -- the register image of a v_mfma_i32_16x16x64_i8 operand, so the GEMM loads one fragment
+// with ONE fully coalesced global_load_dwordx4 (a row-major fragment is 16 rows x 64 B = 16 half cache lines: measured
+// 4 us slower per launch).  A workgroup owns a row block: its 8 waves split the k blocks, every lane reads 64 B of
+// fp32 per block (four float4; the four lanes of a row cover 256 contiguous bytes) and writes its 16 bytes; row sums
+// of the stored values go through LDS atomics.  Same index arithmetic as quantize_rows_* (bit-exact indices).
+// A workgroup owns 8 rows (half a row block: at M = 2048 that is 256 workgroups, one per CU; the conversion is
+// ~20 VALU ops per element, so leaving half the CUs idle doubles the kernel).  A wave converts 8 rows x 2 k blocks per
+// step: lane = r + 8 * kq + 32 * ksel reads the 64 bytes (16 fp32) of row r, k block kb0 + ksel, quarter kq and stores
+// its 16 bytes at the fragment position; the 8 lanes (kq, ksel) of a row reduce the row sum, LDS atomics across waves.
+template <typename T, bool HAS_SUM, int STEPS>   // STEPS: (k block pairs per wave) held in flight at once (0: generic loop)
+__global__ void __launch_bounds__(512) quantize_tiled_kernel(const T* __restrict__ x, int8_t* __restrict__ q, int64_t rows,
+                                                             int64_t cols, const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, float qmin, float qmax,
+                                                             int shift, int32_t* __restrict__ row_sum) {
+  __shared__ int s_sum[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 7, kq = (lane >> 3) & 3, ksel = lane >> 5;
+  const int64_t row_raw = (int64_t)blockIdx.x * 8 + r;
+  const int64_t row = row_raw < rows ? row_raw : rows - 1;      // rows past the end are padding (written, never used)
+  const int64_t rb = row_raw >> 4;
+  const int r16 = (int)(row_raw & 15);
+  const float s = scale[0], o = offset[0];
+  const int kblocks = (int)(cols >> 6), kpairs = kblocks >> 1;
+  if (HAS_SUM && threadIdx.x < 8) s_sum[threadIdx.x] = 0;
+  if (HAS_SUM) __syncthreads();
+  int acc = 0;
+  const T* xrow = x + row * cols + kq * 16;
+  int8_t* qdst = q + ((rb * kblocks) << 10) + ((r16 + 16 * kq) << 4);
+  auto emit = [&](int kb, const float (&f)[16]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      uint32_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int st_v = static_cast<int>(q_index(f[d * 4 + e], s, o, qmin, qmax)) - shift;
+        acc += st_v;
+        pk |= (static_cast<uint32_t>(st_v) & 0xffu) << (8 * e);
+      }
+      w[d] = pk;
+    }
+    *reinterpret_cast<uint4*>(qdst + ((int64_t)kb << 10)) = make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  if constexpr (STEPS > 0 && std::is_same<T, float>::value) {
+    float4 v[STEPS][4];       // everything this wave converts is requested before the first conversion
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      const float4* p = reinterpret_cast<const float4*>(xrow + (int64_t)(2 * (wave + 8 * i) + ksel) * 64);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) v[i][d] = p[d];
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      const float f[16] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w,
+                           v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w, v[i][3].x, v[i][3].y, v[i][3].z, v[i][3].w};
+      emit(2 * (wave + 8 * i) + ksel, f);
+    }
+  } else {
+    for (int kp = wave; kp < kpairs; kp += 8) {
+      const int kb = 2 * kp + ksel;
+      float f[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) f[e] = ld<T>(xrow + (int64_t)kb * 64, e);
+      emit(kb, f);
+    }
+  }
+  if (HAS_SUM) {
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 8) atomicAdd(&s_sum[r], acc);
+    __syncthreads();
+    if (threadIdx.x < 8 && (int64_t)blockIdx.x * 8 + threadIdx.x < rows) row_sum[(int64_t)blockIdx.x * 8 + threadIdx.x] = s_sum[threadIdx.x];
+  }
+}
+
 template <typename T, typename QT>
 static int launch_quantize(const T* x, QT* q, int64_t rows, int64_t cols, const float* scale, const float* offset,
                            bool per_row, float qmin, float qmax, int shift, int32_t* row_sum, hipStream_t st) {
@@ -516,6 +594,38 @@ int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const floa
 #undef MQ_Q
   set_error("mq_quantize: dtype %d -> q_dtype %d not supported", dtype, q_dtype);
   return MQ_EUNSUPPORTED;
+}
+
+int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
+                      float qmin, float qmax, int shift, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream) {
+  MQ_REQUIRE(x && q_tiled && scale && offset, "mq_quantize_tiled: null pointer");
+  MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 128 == 0 && (rows + 15) / 8 < (int64_t)0x7fffffff,
+             "mq_quantize_tiled: bad shape %lld x %lld (cols must be a multiple of 128)", (long long)rows, (long long)cols);
+  MQ_REQUIRE(qmin - (float)shift >= -128.f && qmax - (float)shift <= 127.f, "mq_quantize_tiled: [%g,%g]-%d does not fit int8",
+             qmin, qmax, shift);
+  MQ_REQUIRE(aligned(x, 16) && aligned(q_tiled, 16), "mq_quantize_tiled: pointers must be 16-byte aligned");
+  if (rows == 0) return MQ_OK;
+  const unsigned grid = (unsigned)(((rows + 15) / 16) * 2);      // 8 rows per workgroup, padding rows included
+  hipStream_t st = as_stream(stream);
+#define MQ_QT(T, KBW)                                                                                                 \
+  do {                                                                                                                \
+    if (row_sum) quantize_tiled_kernel<T, true, KBW><<<grid, 512, 0, st>>>((const T*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum); \
+    else quantize_tiled_kernel<T, false, KBW><<<grid, 512, 0, st>>>((const T*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);       \
+  } while (0)
+  const int64_t kblocks = cols >> 6;
+  if (dtype == MQ_F32) {
+    if (kblocks == 32) MQ_QT(float, 2);            // K = 2048: 2 steps of 2 k blocks per wave, all in flight
+    else if (kblocks == 16) MQ_QT(float, 1);
+    else MQ_QT(float, 0);
+  } else if (dtype == MQ_F16) {
+    MQ_QT(__half, 0);
+  } else {
+    set_error("mq_quantize_tiled: dtype %d not supported", dtype);
+    return MQ_EUNSUPPORTED;
+  }
+#undef MQ_QT
+  MQ_LAUNCH_CHECK("mq_quantize_tiled");
+  return MQ_OK;
 }
 
 int mq_linear_epilogue_prepare(const float* a_scale, const float* a_offset, int a_shift, const float* w_scale,

@@ -52,6 +52,7 @@ struct GemmArgs {
   int out_dtype;
   int grid_m, grid_n;
   int has_bias;                 // bias == NULL is replaced by a valid dummy pointer on the host
+  int a_tiled;                  // A is in the fragment-blocked layout of mq_quantize_tiled (generated-ISA variant only)
   int has_rowsum;               // a_rowsum == NULL (caller guarantees w_zp == 0): dummy pointer, element 0 only
   unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
 };
@@ -307,11 +308,13 @@ __global__ void __launch_bounds__(64 * WM * WN)
     asm volatile(MQ_PP_ASM_COPYIN2 ::MQ_OPS22(2, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
     asm volatile(MQ_PP_ASM_COPYIN3 ::MQ_OPS22(3, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
     {
-      int row0 = m0 + wave_m * TM + (lane & 15), row1 = row0 + 16;
-      row0 = row0 < M ? row0 : M - 1;
-      row1 = row1 < M ? row1 : M - 1;
-      const unsigned av0 = (unsigned)row0 * (unsigned)K + ((unsigned)(lane >> 4) << 4);
-      const unsigned av1 = (unsigned)row1 * (unsigned)K + ((unsigned)(lane >> 4) << 4);
+// fragment-blocked A (mq_quantize_tiled): row block rb, k block kb at ((rb * K/64) + kb) KiB, lane-linear inside
+      const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+      unsigned rb0 = (unsigned)((m0 + wave_m * TM) >> 4), rb1 = rb0 + 1;
+      rb0 = rb0 < rb_max ? rb0 : rb_max;
+      rb1 = rb1 < rb_max ? rb1 : rb_max;
+      const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+      const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
       const unsigned woff0 = (unsigned)w_off, woff1 = (unsigned)w_off1;
       asm volatile(MQ_PP_ASM_BODY
                    :
@@ -756,6 +759,12 @@ static int launch_cfg(const GemmArgs& a, bool outq, hipStream_t st) {
   }
 }
 
+// The generated-ISA loop serves the shapes the 256x176 ping-pong tile serves (N a multiple of 176, at least 192 tiles)
+// with whole pairs of K = 128 stages.
+static bool gemm_tiled_supported(int64_t M, int64_t N, int64_t K) {
+  return M > 0 && N % 176 == 0 && K % 256 == 0 && ((M + 255) / 256) * (N / 176) >= 192;
+}
+
 static int pick_variant(int M, int N, bool w4) {
   if (g_forced_variant >= 0) return g_forced_variant;
   auto blocks = [&](int v) {
@@ -787,7 +796,17 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
   a.has_rowsum = a.a_rowsum != nullptr;
   if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;                 // element 0 only (M may exceed N); multiplied by w_zp == 0
   if (a.bias == nullptr) a.bias = a.alpha;                            // masked by has_bias
-  const int v = pick_variant(a.M, a.N, W4);
+  int v = pick_variant(a.M, a.N, W4);
+  if (a.a_tiled) {
+    if (W4 || !gemm_tiled_supported(a.M, a.N, a.K)) {
+      set_error("mq_w8a8_linear_tiled: shape %dx%dx%d is not served by the fragment-blocked path (see mq_gemm_tiled_supported)", a.M,
+                a.N, a.K);
+      return MQ_EUNSUPPORTED;
+    }
+    v = 9;
+  } else if (v == 9) {
+    v = 7;                                  // variant 9 reads fragment-blocked activations only
+  }
   a.grid_m = (a.M + kVariants[v].bm - 1) / kVariants[v].bm;
   a.grid_n = (a.N + kVariants[v].bn - 1) / kVariants[v].bn;
   switch (v) {
@@ -801,13 +820,9 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
     case 7:
       if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, 1>(a, outq, st);
       else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
-    case 9:     // generated-ISA main loop: whole pairs of K = 128 stages only
-      if constexpr (!W4) {
-        if (a.K % 256 == 0) return launch_cfg<256, 176, 8, 1, false, 3>(a, outq, st);
-        return launch_cfg<256, 176, 8, 1, false, 1>(a, outq, st);
-      } else {
-        return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
-      }
+    case 9:     // generated-ISA main loop on fragment-blocked activations (run_gemm checked the shape)
+      if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, 3>(a, outq, st);
+      else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
     case 8: return launch_cfg<64, 32, 2, 2, W4>(a, outq, st);
     default: set_error("mq_gemm: bad variant %d", v); return MQ_EINVAL;
   }
@@ -874,7 +889,22 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
     return run_gemv(v, as_stream(stream));
   }
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, g_dbg_ts};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, 0, g_dbg_ts};
+  return run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_gemm_tiled_supported(int64_t M, int64_t N, int64_t K) { return gemm_tiled_supported(M, N, K) ? 1 : 0; }
+
+int mq_w8a8_linear_tiled(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                         const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                         const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, void* out,
+                         int out_dtype, mq_stream_t stream) {
+  int rc = check_common("mq_w8a8_linear_tiled", a_tiled, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale,
+                        out_offset, out, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32), "mq_w8a8_linear_tiled: activation too large");
+  GemmArgs g{a_tiled, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 1, 0, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
 }
 
@@ -934,7 +964,7 @@ int mq_w4a8_linear(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t 
     return run_gemv(v, as_stream(stream));
   }
   GemmArgs g{a, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
-             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, g_dbg_ts};
+             out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, 0, g_dbg_ts};
   return run_gemm<true>(g, as_stream(stream));
 }
 

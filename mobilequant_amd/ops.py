@@ -176,23 +176,45 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
                 w_zp: torch.Tensor, col_term: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
                 out_scale: Optional[torch.Tensor] = None, out_offset: Optional[torch.Tensor] = None,
                 out_qmin: float = 0.0, out_qmax: float = 255.0, out_dtype: int = MQ_F32, w4: bool = False,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, a_tiled_rows: Optional[int] = None) -> torch.Tensor:
     """QLinear as an int8 MFMA GEMM with fused dequant (+ output quantizer).  a_q [M,K] int8, w_q [N,K]
-    int8 (or [N,K/2] packed nibbles when w4)."""
+    int8 (or [N,K/2] packed nibbles when w4).  a_tiled_rows = M: a_q is the fragment-blocked buffer of
+    quantize_tiled ([ceil16(M), K] bytes) and the generated-ISA GEMM path runs (gemm_tiled_supported shapes)."""
     _dev(a_q, "a_q"); _dev(w_q, "w_q")
     M, K = a_q.shape
+    if a_tiled_rows is not None:
+        M = int(a_tiled_rows)
     N = w_q.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=_OUT_TORCH[out_dtype], device=a_q.device)
     b = _f32(bias, "bias") if bias is not None else None
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
-    _lib.call("mq_w4a8_linear" if w4 else "mq_w8a8_linear", a_q.data_ptr(), w_q.data_ptr(), M, N, K,
+    fn = "mq_w8a8_linear_tiled" if a_tiled_rows is not None else ("mq_w4a8_linear" if w4 else "mq_w8a8_linear")
+    _lib.call(fn, a_q.data_ptr(), w_q.data_ptr(), M, N, K,
               a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(),
               col_term.data_ptr(), b.data_ptr() if b is not None else None,
               os_.data_ptr() if os_ is not None else None, oo_.data_ptr() if oo_ is not None else None,
               float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype, _stream())
     return out
+
+
+def gemm_tiled_supported(M: int, N: int, K: int) -> bool:
+    """Shapes served by the fragment-blocked activation layout + generated-ISA GEMM loop (TinyLlama / StableLM FFN)."""
+    return bool(_lib.load().mq_gemm_tiled_supported(int(M), int(N), int(K)))
+
+
+def quantize_tiled(x2d: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, shift: int,
+                   want_row_sum: bool = True):
+    """[M,K] activations -> fragment-blocked int8 ([ceil16(M), K] buffer, layout: include/mobilequant_amd.h) + row sums."""
+    x2d = _dev(x2d, "x").contiguous()
+    M, K = x2d.shape
+    q = torch.empty(((M + 15) // 16 * 16, K), dtype=torch.int8, device=x2d.device)
+    rs = torch.empty(M, dtype=torch.int32, device=x2d.device) if want_row_sum else None
+    s, o = _f32(scale, "scale"), _f32(offset, "offset")
+    _lib.call("mq_quantize_tiled", x2d.data_ptr(), _fdt(x2d), M, K, s.data_ptr(), o.data_ptr(), float(qmin), float(qmax),
+              int(shift), q.data_ptr(), rs.data_ptr() if rs is not None else None, _stream())
+    return (q, rs) if want_row_sum else q
 
 
 def decode_shape(M: int, K: int) -> bool:

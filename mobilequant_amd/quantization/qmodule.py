@@ -464,9 +464,19 @@ class QLinear(nn.Linear, _QuantizedOp):
         x2d = x.reshape(-1, K)
         decode = x.dtype == torch.float32 and ops.decode_shape(x2d.shape[0], K)
         a_shift = 128 if grid.qmax > 127 else 0
+        tiled_rows = None
         if not decode:
+            # a producer's int8 copy (fused norm, or a sibling linear) wins: no quantize launch at all.  Otherwise the
+            # large FFN shapes quantise straight into the fragment-blocked layout of the generated-ISA GEMM loop.
             hit = _shared_activation.get(x, grid, a_shift)
-            if hit is None:
+            if hit is None and not plan["w4"] and ops.gemm_tiled_supported(x2d.shape[0], N, K):
+                hit = _shared_activation.get(x, grid, ("tiled", a_shift))
+                if hit is None:
+                    q_t, rs_t = ops.quantize_tiled(x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift)
+                    hit = (q_t, rs_t, a_shift)
+                    _shared_activation.put(x, grid, ("tiled", a_shift), hit)
+                tiled_rows = x2d.shape[0]
+            elif hit is None:
                 hit = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
                 _shared_activation.put(x, grid, a_shift, hit)
             a_q, a_rs, a_shift = hit
@@ -490,7 +500,7 @@ class QLinear(nn.Linear, _QuantizedOp):
             a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
             out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
             out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0,
-            out_dtype=MQ_F16 if x.dtype == torch.float16 else MQ_F32, w4=plan["w4"])
+            out_dtype=MQ_F16 if x.dtype == torch.float16 else MQ_F32, w4=plan["w4"], a_tiled_rows=tiled_rows)
         return out.reshape(*x.shape[:-1], N)
 
     # -- forward -----------------------------------------------------------------------------------

@@ -482,6 +482,68 @@ def test_per_channel_and_w4_configs_full_m(dev, N, K, wbits, sym):
     assert np.array_equal(bits(got[torch.from_numpy(rows).to(dev)].detach().cpu().numpy()), bits(want))
 
 
+def test_fragment_blocked_activations_and_generated_isa_gemm(dev):
+    """mq_quantize_tiled == mq_quantize up to the documented permutation (same indices, same row sums), and
+    mq_w8a8_linear_tiled (generated gfx950 ISA main loop) == mq_w8a8_linear bit for bit, incl. a ragged M, the
+    shortest K (one pair of stages) and every output type; QLinear picks the path by itself for such shapes."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_F16, MQ_F32, MQ_I8, MQ_U8, MQ_U16
+    assert ops.gemm_tiled_supported(2048, 5632, 2048) and ops.gemm_tiled_supported(1536, 5632, 256)
+    assert not ops.gemm_tiled_supported(2048, 2048, 2048) and not ops.gemm_tiled_supported(2048, 5632, 384)
+    assert not ops.gemm_tiled_supported(1024, 5632, 2048)
+    rng = np.random.default_rng(99)
+    one = torch.ones(1, device=dev)
+    for M, N, K in ((2048, 5632, 2048), (2000, 5632, 256), (1530, 5632, 512), (2048, 5632, 5632 - 5632 % 256)):
+        x = T(rng.standard_normal((M, K), dtype=F32) * 2, dev)
+        sc, of = one * 0.031, one * 121.0
+        q_rm, rs_rm = ops.quantize(x, sc, of, 0, 255, q_dtype=MQ_I8, shift=128, rows=M, want_row_sum=True)
+        q_t, rs_t = ops.quantize_tiled(x, sc, of, 0, 255, 128)
+        assert torch.equal(rs_rm, rs_t)
+        Mp = (M + 15) // 16 * 16
+        assert q_t.shape == (Mp, K)
+        # block (rb, kb), lane l = (row & 15) + 16 * kq, 16 bytes  ->  [rb, r, kb, kq, 16]
+        back = q_t.view(Mp // 16, K // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, K)
+        assert torch.equal(back[:M], q_rm), (M, N, K)
+        w8 = T(rng.integers(-128, 128, size=(N, K)).astype(np.int8), dev)
+        colsum = w8.to(torch.int32).sum(1).to(torch.int32)
+        alpha, wzp, ct = ops.linear_epilogue_prepare(sc, of, 128, T(rng.random(N, dtype=F32) * F32(1e-3) + F32(1e-4), dev),
+                                                     T(rng.integers(0, 256, N).astype(F32), dev), 128, colsum, K)
+        bias = T(rng.standard_normal(N, dtype=F32), dev)
+        kw = dict(out_scale=one * 0.05, out_offset=one * 128, out_qmin=0.0, out_qmax=255.0)
+        for od, extra in ((MQ_F32, {}), (MQ_U8, kw), (MQ_F32, kw), (MQ_F16, {}),
+                          (MQ_U16, dict(out_scale=one * 2e-4, out_offset=one * 32768, out_qmin=0.0, out_qmax=65535.0))):
+            ref = ops.int8_linear(q_rm, w8, rs_rm, alpha, wzp, ct, bias, out_dtype=od, **extra)
+            got = ops.int8_linear(q_t, w8, rs_t, alpha, wzp, ct, bias, out_dtype=od, a_tiled_rows=M, **extra)
+            assert torch.equal(ref, got), (M, N, K, od)
+    with pytest.raises(mq._lib.MobileQuantLibraryError):
+        ops.int8_linear(q_t, w8[:2048], rs_t, alpha[:2048], wzp[:2048], ct[:2048], None, a_tiled_rows=M)   # N = 2048: not served
+    # the module: the FFN shape takes the fragment-blocked path, and equals the row-major path
+    lin = torch.nn.Linear(256, 5632, bias=True).to(dev)
+    a8c = mq.QuantConfig(bitwidth=8)
+    ql = mq.QLinear.from_float(lin, a8c, a8c, a8c).requires_grad_(False)
+    xs = torch.randn(1, 1536, 256, device=dev)
+    ql.set_scale_offset({"input": [float(xs.min()), float(xs.max())], "output": [-3.0, 3.0]}, "buffer")
+    calls = []
+    real = ops.quantize_tiled
+    ops.quantize_tiled = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y_t = ql(xs)
+        assert len(calls) == 1
+        ops.gemm_tiled_supported, keep = (lambda *a: False), ops.gemm_tiled_supported
+        try:
+            from mobilequant_amd.quantization import qmodule as Q
+            Q._shared_activation.clear()
+            with torch.no_grad():
+                y_rm = ql(xs)
+        finally:
+            ops.gemm_tiled_supported = keep
+    finally:
+        ops.quantize_tiled = real
+    assert len(calls) == 1 and torch.equal(y_t, y_rm)
+
+
 def test_int8_gemm_extreme_k_and_zero_points(dev):
     """Gemma's w2 depth (K = 16384) with worst-case operands: every index at an end of the grid and extreme zero
     points, so the int32 accumulator and the correction terms reach their largest magnitudes -- still exact."""

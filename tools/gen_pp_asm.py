@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """Generates mobilequant_amd/csrc/mq_gemm_pp_asm.inc: the hand-scheduled gfx950 main loop of the 256x176 ping-pong
-int8 GEMM with the A operand loaded straight into registers (GEMM variant "t256x176_w8x1_pp_asm").
+int8 GEMM on fragment-blocked activations (GEMM variant "t256x176_w8x1_pp_asm", entry point mq_w8a8_linear_tiled).
 
 Why generated ISA: the A rows of the 8x1 wave layout are private to a wave, so staging them through the LDS only costs
-LDS-DMA writes and fragment reads (measured what-if: -10 % kernel time); keeping two register sets of
-A fragments next to 88 accumulator and 44 W-fragment registers is beyond what hipcc allocates without spilling (three
-attempts recorded in DESIGN.md).  Here the registers are fixed by hand:
+LDS-DMA writes and fragment reads (measured what-if: -10 % kernel time).  With the activations
+stored fragment-blocked by mq_quantize_tiled (1-KiB blocks of 16 rows x 64 k = one MFMA operand), a fragment is ONE
+fully coalesced global_load_dwordx4 straight into registers.  Keeping two register sets of A fragments next to 88
+accumulator and 44 W-fragment registers is beyond what hipcc allocates without spilling (attempts recorded in
+DESIGN.md), so the registers are fixed by hand:
 
   AGPR  a[0:87]     accumulators, acc[i][j] = a[(2j+i)*4 : +3]        (i = A fragment 0/1, j = W fragment 0..10)
         a[88:103]   A fragments of even stages  [ks0 i0][ks0 i1][ks1 i0][ks1 i1]
         a[104:119]  A fragments of odd stages
   VGPR  v[76:119]   W fragments of the current k-step (ds_read_b128 x 11)
         v120        LDS read address;  v[121:123] W LDS-DMA source offsets;  v[124:125] A load offsets
-  SGPR  s[84:99]    loop state (below)
+  SGPR  s[84:94]    loop state (below)
 
 Schedule = the one of the C++ ping-pong loop (mq_gemm.hip): phases E/O, one s_barrier each, group 0 (waves 0-3) and
 group 1 (waves 4-7) offset by one phase, W in a ring of three LDS buffers filled by LDS-DMA two stages ahead, counted
-vmcnt waits.  K % 256 == 0 (the loop body covers two K = 128 stages so the A register sets are static).
+vmcnt waits; A(t+2) is requested where the C++ loop issued the A pieces (same count, so the waits carry over).
+K % 256 == 0 (the loop body covers two K = 128 stages so the A register sets are static).
+MQ_ASM_ROWMAJOR=1 regenerates the row-major experiment (a fragment = 16 rows x 64 B = 16 half cache lines: 4 us slower).
 
 Run:  python tools/gen_pp_asm.py   (writes the .inc next to mq_gemm.hip; the file is committed)."""
 import os
@@ -89,6 +93,8 @@ def issue_w(ring_sgpr):
     emit(f"{skip_tail}:")
 
 
+TILED = not os.environ.get("MQ_ASM_ROWMAJOR")     # production: fragment-blocked A (one fragment = 1 KiB contiguous);
+                                                   # MQ_ASM_ROWMAJOR=1 regenerates the row-major experiment (16 rows x 64 B per load)
 NO_A = bool(os.environ.get("MQ_ASM_NO_A"))        # what-if: no A loads after the prologue (results wrong)
 A_ORDER = os.environ.get("MQ_ASM_A_ORDER", "ks")     # "ks": (i0,i1) of k-step 0 then k-step 1;  "row": both halves of a row back to back
 _prologue = [True]
@@ -98,11 +104,19 @@ def load_a(set_):
     """A(kt) with k offset s_k2 -> register set."""
     if NO_A and not _prologue[0]:
         return
-    emit(f"v_add_u32 v{V_A}, s{S_K2}, %[av0]")
-    emit(f"v_add_u32 v{V_A + 1}, s{S_K2}, %[av1]")
+    if TILED:      # k offset of a stage = 2 blocks of 1 KiB = 16 x the row-major k offset
+        emit(f"s_lshl_b32 s{S_TMP}, s{S_K2}, 4")
+        emit(f"v_add_u32 v{V_A}, s{S_TMP}, %[av0]")
+        emit(f"v_add_u32 v{V_A + 1}, s{S_TMP}, %[av1]")
+    else:
+        emit(f"v_add_u32 v{V_A}, s{S_K2}, %[av0]")
+        emit(f"v_add_u32 v{V_A + 1}, s{S_K2}, %[av1]")
     order = [(0, 0), (0, 1), (1, 0), (1, 1)] if A_ORDER == "ks" else [(0, 0), (1, 0), (0, 1), (1, 1)]
     for ks, i in order:
-        emit(f"global_load_dwordx4 {xa(set_, ks, i)}, v{V_A + i}, %[aptr]" + (" offset:64" if ks else ""))
+        if TILED:
+            emit(f"global_load_dwordx4 {xa(set_, ks, i)}, v{V_A + i}, %[aptr]" + (" offset:1024" if ks else ""))
+        else:
+            emit(f"global_load_dwordx4 {xa(set_, ks, i)}, v{V_A + i}, %[aptr]" + (" offset:64" if ks else ""))
 
 
 def wait_vm(base):
