@@ -254,6 +254,14 @@ __global__ void __launch_bounds__(64 * WM * WN)
 #pragma unroll
       for (int d = ASMK ? A_ROUNDS : 0; d < N_DMA; ++d) issue_one(d, 1, 1, 1);
     }
+#if MQ_PP_ASM_STAGE_MODE
+    if constexpr (ASMK) {       // stage-granular loop: the waves of group 0 prefetch W three stages ahead
+      if (KT > 2 && wave < 4) {
+#pragma unroll
+        for (int d = A_ROUNDS; d < N_DMA; ++d) issue_one(d, 0, 2, 2);
+      }
+    }
+#endif
   }
   asm volatile("s_barrier" ::: "memory");
 

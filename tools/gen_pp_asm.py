@@ -240,6 +240,226 @@ def group1_stage(set_, odd):
     rotate()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Stage-granular ping-pong (MQ_ASM_STAGE=1): one phase = one whole K = 128 stage (44 MFMAs | 22 ds_reads + issues), two
+# s_barriers per stage instead of four.  Possible because the accumulators sit in AGPRs: a wave keeps the W fragments of
+# BOTH k-steps (88 VGPRs).  Phases P_2t: G0 MFMA(t) | G1 READ(t);  P_2t+1: G0 READ(t+1) | G1 MFMA(t).
+#   G0 in P_2t+1 issues A(t+2) -> set t&1 and its W(t+3) pieces -> ring slot t%3 (read by everyone by the end of P_2t);
+#   G1 in P_2t   issues A(t+1) -> set (t+1)&1 (t > 0) and its W(t+2) pieces -> slot (t+2)%3 (last read in P_2t-2).
+#   The C++ prologue issues W(0), W(1) for every wave and W(2) for the waves of group 0.
+# Waits (vmcnt is in order; A before W inside a phase so that A can be awaited without its phase's W):
+#   G0 end of P_2t   (after MFMA(t)):  own W(t+1) landed   -> allowed in flight: A(t+1)?? no: see wait tables below.
+STAGE = bool(os.environ.get("MQ_ASM_STAGE"))
+WA0, WB0 = 36, 80              # W fragments of k-step 0 / 1 in stage mode: v[36:79], v[80:123]
+V_T0, V_T1, V_T2, V_T3 = 124, 125, 126, 127
+S_MORE2 = 95
+
+
+def wfs(ks, j):
+    b = (WA0 if ks == 0 else WB0) + 4 * j
+    return f"v[{b}:{b + 3}]"
+
+
+def s_mfma(set_):
+    emit("s_setprio 1")
+    for ks in range(2):
+        for j in range(FN):
+            for i in range(2):
+                emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, {wfs(ks, j)}, {xa(set_, ks, i)}, {acc(i, j)}")
+    emit("s_setprio 0")
+
+
+def s_read(ring_sgpr):
+    for ks in range(2):
+        emit(f"v_add_u32 v{V_T0}, s{ring_sgpr}, %[woff{ks}]")
+        for j in range(FN):
+            emit(f"ds_read_b128 {wfs(ks, j)}, v{V_T0} offset:{j * 16 * BK}")
+
+
+def s_issue_w(ring_sgpr, kdelta):
+    """this wave's W pieces of the stage whose k offset is s_k2 + kdelta -> ring slot ring_sgpr"""
+    skip_tail = label("notail")
+    emit(f"s_add_u32 s{S_TMP2}, s{S_K2}, {kdelta}") if kdelta else emit(f"s_mov_b32 s{S_TMP2}, s{S_K2}")
+    for i in range(3):
+        if i == 2:
+            emit(f"s_cmp_eq_u32 s{S_TAIL}, 0")
+            emit(f"s_cbranch_scc1 {skip_tail}")
+        emit(f"v_add_u32 v{V_T1}, s{S_TMP2}, %[sw{i}]")
+        emit(f"s_add_u32 s{S_TMP}, s{ring_sgpr}, s{S_WAVEK}")
+        emit(f"s_add_u32 m0, s{S_TMP}, {W_BASE + i * 8 * 1024}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 v{V_T1}, %[wptr]")
+    emit(f"{skip_tail}:")
+
+
+def s_load_a(set_, kdelta):
+    """A of the stage whose row-major k offset is s_k2 + kdelta (fragment-blocked: x16) -> register set"""
+    emit(f"s_add_u32 s{S_TMP}, s{S_K2}, {kdelta}") if kdelta else emit(f"s_mov_b32 s{S_TMP}, s{S_K2}")
+    emit(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, 4")
+    emit(f"v_add_u32 v{V_T2}, s{S_TMP}, %[av0]")
+    emit(f"v_add_u32 v{V_T3}, s{S_TMP}, %[av1]")
+    for ks, i in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+        emit(f"global_load_dwordx4 {xa(set_, ks, i)}, v{V_T2 + i}, %[aptr]" + (" offset:1024" if ks else ""))
+
+
+def s_wait(fixed, nw):
+    """s_waitcnt vmcnt(fixed + nw * n_w), n_w = 3 for tail owners (waves 0-5) else 2"""
+    if nw == 0:
+        emit(f"s_waitcnt vmcnt({fixed})")
+        return
+    lt, ld = label("wt"), label("wd")
+    emit(f"s_cmp_eq_u32 s{S_TAIL}, 1")
+    emit(f"s_cbranch_scc1 {lt}")
+    emit(f"s_waitcnt vmcnt({fixed + 2 * nw})")
+    emit(f"s_branch {ld}")
+    emit(f"{lt}:")
+    emit(f"s_waitcnt vmcnt({fixed + 3 * nw})")
+    emit(f"{ld}:")
+
+
+def if_flag(sreg, body, else_body=None):
+    ls, le = label("f0"), label("f1")
+    emit(f"s_cmp_eq_u32 s{sreg}, 0")
+    emit(f"s_cbranch_scc1 {ls}")
+    body()
+    if else_body is not None:
+        emit(f"s_branch {le}")
+    emit(f"{ls}:")
+    if else_body is not None:
+        else_body()
+        emit(f"{le}:")
+
+
+def s_rotate():
+    rotate()
+
+
+def stage_g0(set_, odd):
+    # P_2t: MFMA(t);  then own W(t+1) pieces must have landed (deadline: G1 reads W(t+1) in P_2t+2 ... G0 in P_2t+1):
+    # queue tail at this point: A(t+1), W(t+2) [issued in P_2t-1]  ->  allowed = 4*has1 + n_w*has2
+    emit(f"; ==== G0 {'odd' if odd else 'even'} stage: P_2t  MFMA(t)")
+    s_mfma(set_)
+    if odd:
+        if_flag(S_MORE, lambda: s_wait(4, 1), lambda: emit("s_waitcnt vmcnt(0)"))
+    else:
+        if_flag(S_MORE, lambda: s_wait(4, 1), lambda: emit("s_waitcnt vmcnt(4)"))
+    barrier()
+    emit("; P_2t+1: READ(t+1); A(t+2) -> set t&1; W(t+3) -> slot t%3; then A(t+1) must have landed")
+    if odd:
+        def body():
+            s_read(S_WNXT)
+            s_load_a(set_, 0)                          # A(t+2): k = s_k2
+            if_flag(S_MORE2, lambda: s_issue_w(S_WCUR, BK))   # W(t+3)
+            lgkm0()
+            # allowed: W(t+2) + A(t+2) + W(t+3)
+            if_flag(S_MORE2, lambda: s_wait(4, 2), lambda: s_wait(4, 1))
+        if_flag(S_MORE, body, lambda: emit("s_waitcnt vmcnt(0)"))
+    else:
+        s_read(S_WNXT)
+        def body():
+            s_load_a(set_, 0)
+            s_issue_w(S_WCUR, BK)
+        if_flag(S_MORE, body)
+        lgkm0()
+        # t == 0: W(2) came from the prologue, ahead of A(0) / A(1) in the queue -> only A(2), W(3) may stay in flight
+        l0, l1 = label("p1t0"), label("p1d")
+        emit(f"s_cmp_eq_u32 s{S_T}, 0")
+        emit(f"s_cbranch_scc1 {l0}")
+        if_flag(S_MORE, lambda: s_wait(4, 2), lambda: emit("s_waitcnt vmcnt(0)"))
+        emit(f"s_branch {l1}")
+        emit(f"{l0}:")
+        if_flag(S_MORE, lambda: s_wait(4, 1), lambda: emit("s_waitcnt vmcnt(0)"))
+        emit(f"{l1}:")
+    barrier()
+    s_rotate()
+
+
+def stage_g1(set_, odd):
+    other = 1 - set_
+    emit(f"; ==== G1 {'odd' if odd else 'even'} stage: P_2t  READ(t); A(t+1) -> other set; W(t+2) -> slot (t+2)%3")
+    s_read(S_WCUR)
+    if odd:
+        def body():
+            s_load_a(other, -BK)                       # A(t+1): k = s_k2 - 128
+            s_issue_w(S_WPRV, 0)                       # W(t+2)
+        if_flag(S_MORE, body)
+        lgkm0()
+        if_flag(S_MORE, lambda: s_wait(4, 1), lambda: emit("s_waitcnt vmcnt(0)"))
+    else:
+        l0 = label("t0")
+        emit(f"s_cmp_eq_u32 s{S_T}, 0")
+        emit(f"s_cbranch_scc1 {l0}")
+        s_load_a(other, -BK)
+        emit(f"{l0}:")
+        if_flag(S_MORE, lambda: s_issue_w(S_WPRV, 0))
+        lgkm0()
+        l1, l2 = label("w0"), label("w1")
+        emit(f"s_cmp_eq_u32 s{S_T}, 0")
+        emit(f"s_cbranch_scc1 {l1}")
+        if_flag(S_MORE, lambda: s_wait(4, 1), lambda: emit("s_waitcnt vmcnt(4)"))
+        emit(f"s_branch {l2}")
+        emit(f"{l1}:")
+        if_flag(S_MORE, lambda: s_wait(0, 1), lambda: emit("s_waitcnt vmcnt(0)"))
+        emit(f"{l2}:")
+    barrier()
+    emit("; P_2t+1: MFMA(t)")
+    s_mfma(set_)
+    barrier()
+    s_rotate()
+
+
+def generate_stage():
+    emit("; generated by tools/gen_pp_asm.py (stage-granular ping-pong) -- do not edit")
+    emit("s_nop 4")
+    emit(f"s_mov_b32 s{S_T}, 0")
+    emit(f"s_sub_u32 s{S_LAST}, %[kt], 2")
+    emit(f"s_lshl_b32 s{S_WAVEK}, %[wave], 10")
+    emit(f"s_cmp_lt_u32 %[wave], 6")
+    emit(f"s_cselect_b32 s{S_TAIL}, 1, 0")
+    emit(f"s_mov_b32 s{S_WCUR}, 0")
+    emit(f"s_mov_b32 s{S_WNXT}, {W_BYTES}")
+    emit(f"s_mov_b32 s{S_WPRV}, {2 * W_BYTES}")
+    emit(f"s_mov_b32 s{S_K2}, 0")
+    s_load_a(0, 0)
+    s_load_a(1, BK)
+    emit(f"s_mov_b32 s{S_K2}, {2 * BK}")            # k offset (row-major bytes) of stage t + 2
+    emit("s_waitcnt vmcnt(4)")                        # W(0), W(1), (W(2)), A(0) landed; A(1) may fly
+    barrier()
+    g1, end = label("g1"), label("end")
+    emit("s_cmp_lt_u32 %[wave], 4")
+    emit(f"s_cbranch_scc0 {g1}")
+    # group 0
+    s_read(S_WCUR)
+    lgkm0()
+    barrier()                                          # P_-1
+    loop0 = label("loop0")
+    emit(f"{loop0}:")
+    emit(f"s_cmp_lt_u32 s{S_T}, s{S_LAST}")
+    emit(f"s_cselect_b32 s{S_MORE}, 1, 0")
+    emit(f"s_add_u32 s{S_TMP}, s{S_T}, 4")
+    emit(f"s_cmp_lt_u32 s{S_TMP}, %[kt]")
+    emit(f"s_cselect_b32 s{S_MORE2}, 1, 0")
+    stage_g0(0, False)
+    stage_g0(1, True)
+    emit(f"s_cmp_lt_u32 s{S_T}, %[kt]")
+    emit(f"s_cbranch_scc1 {loop0}")
+    emit(f"s_branch {end}")
+    # group 1
+    emit(f"{g1}:")
+    barrier()                                          # P_-1
+    loop1 = label("loop1")
+    emit(f"{loop1}:")
+    emit(f"s_cmp_lt_u32 s{S_T}, s{S_LAST}")
+    emit(f"s_cselect_b32 s{S_MORE}, 1, 0")
+    stage_g1(0, False)
+    stage_g1(1, True)
+    emit(f"s_cmp_lt_u32 s{S_T}, %[kt]")
+    emit(f"s_cbranch_scc1 {loop1}")
+    emit(f"{end}:")
+    emit("s_nop 15")
+    emit("s_nop 15")
+
+
 def generate():
     emit("; generated by tools/gen_pp_asm.py -- do not edit")
     emit("s_nop 4")
@@ -295,15 +515,16 @@ def generate():
 
 
 def main():
-    generate()
+    generate_stage() if STAGE else generate()
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(here, "..", "mobilequant_amd", "csrc", "mq_gemm_pp_asm.inc")
-    vregs = [f'"v{r}"' for r in range(WF0, V_A + 2)]
+    vregs = [f'"v{r}"' for r in (range(WA0, 128) if STAGE else range(WF0, V_A + 2))]
     aregs = [f'"a{r}"' for r in range(0, 120)]
-    sregs = [f'"s{r}"' for r in range(S_T, S_TMP2 + 1)]
+    sregs = [f'"s{r}"' for r in range(S_T, (S_MORE2 if STAGE else S_TMP2) + 1)]
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_pp_asm.py -- do not edit (see that file for the register map and the schedule).\n")
         f.write("// Operands: kt, wave (SGPR); aptr, wptr (SGPR pairs); woff0, woff1, av0, av1, sw0, sw1, sw2 (VGPR).\n")
+        f.write("#define MQ_PP_ASM_STAGE_MODE %d   // 1: the C++ prologue also issues W(2) for the waves of group 0\n" % (1 if STAGE else 0))
         f.write("#define MQ_PP_ASM_BODY \\\n")
         for line in out:
             f.write('  "%s\\n\\t" \\\n' % line.replace('"', '\\"'))
