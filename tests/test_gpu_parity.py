@@ -505,6 +505,12 @@ def test_fragment_blocked_activations_and_generated_isa_gemm(dev):
         # block (rb, kb), lane l = (row & 15) + 16 * kq, 16 bytes  ->  [rb, r, kb, kq, 16]
         back = q_t.view(Mp // 16, K // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, K)
         assert torch.equal(back[:M], q_rm), (M, N, K)
+        if K <= 512:      # fp16 activations: the generic (loop) form of the kernel
+            xh = x.half()
+            qh_rm, rsh_rm = ops.quantize(xh, sc, of, 0, 255, q_dtype=MQ_I8, shift=128, rows=M, want_row_sum=True)
+            qh_t, rsh_t = ops.quantize_tiled(xh, sc, of, 0, 255, 128)
+            assert torch.equal(rsh_rm, rsh_t)
+            assert torch.equal(qh_t.view(Mp // 16, K // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, K)[:M], qh_rm)
         w8 = T(rng.integers(-128, 128, size=(N, K)).astype(np.int8), dev)
         colsum = w8.to(torch.int32).sum(1).to(torch.int32)
         alpha, wzp, ct = ops.linear_epilogue_prepare(sc, of, 128, T(rng.random(N, dtype=F32) * F32(1e-3) + F32(1e-4), dev),
