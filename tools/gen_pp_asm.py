@@ -20,7 +20,7 @@ Schedule = the one of the C++ ping-pong loop (mq_gemm.hip): phases E/O, one s_ba
 group 1 (waves 4-7) offset by one phase, W in a ring of three LDS buffers filled by LDS-DMA two stages ahead, counted
 vmcnt waits; A(t+2) is requested where the C++ loop issued the A pieces (same count, so the waits carry over).
 K % 256 == 0 (the loop body covers two K = 128 stages so the A register sets are static).
-MQ_ASM_ROWMAJOR=1 regenerates the row-major experiment (a fragment = 16 rows x 64 B = 16 half cache lines: 4 us slower).
+(Row-major activations were tried first: a fragment is then 16 rows x 64 B = 16 half cache lines per load, 4 us slower.)
 
 Run:  python tools/gen_pp_asm.py   (writes the .inc next to mq_gemm.hip; the file is committed)."""
 import os
@@ -93,8 +93,7 @@ def issue_w(ring_sgpr):
     emit(f"{skip_tail}:")
 
 
-TILED = not os.environ.get("MQ_ASM_ROWMAJOR")     # production: fragment-blocked A (one fragment = 1 KiB contiguous);
-                                                   # MQ_ASM_ROWMAJOR=1 regenerates the row-major experiment (16 rows x 64 B per load)
+TILED = True                                       # fragment-blocked A: one fragment = 1 KiB contiguous (mq_quantize_tiled)
 NO_A = bool(os.environ.get("MQ_ASM_NO_A"))        # what-if: no A loads after the prologue (results wrong)
 A_ORDER = os.environ.get("MQ_ASM_A_ORDER", "ks")     # "ks": (i0,i1) of k-step 0 then k-step 1;  "row": both halves of a row back to back
 _prologue = [True]
