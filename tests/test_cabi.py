@@ -79,3 +79,27 @@ def test_generated_isa_is_current(tmp_path):
         assert open(inc).read() == before
     finally:
         open(inc, "w").write(before)
+
+
+def test_argument_checks_fail_before_any_launch():
+    """Bad shapes are rejected by the entry points themselves (MQ_EINVAL / MQ_EUNSUPPORTED + mq_last_error), before any
+    HIP call: checkable without a GPU.  Pointers are fake, aligned and never dereferenced."""
+    import ctypes
+    from mobilequant_amd import _lib as L
+    lib = L.load()
+    p = ctypes.c_void_p(0x10000)
+    # cols must be a multiple of 128 for the fragment-blocked layout
+    assert lib.mq_quantize_tiled(p, L.MQ_F32, 32, 100, p, p, 0.0, 255.0, 128, p, None, None) == 1
+    assert b"multiple of 128" in lib.mq_last_error()
+    # fused norm: cols % 4, integer output without an output grid
+    assert lib.mq_rmsnorm_quant(p, 4, 30, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, p, None, 0, None, None) == 1
+    assert lib.mq_rmsnorm_quant(p, 4, 32, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, None, p, 0, None, None) == 1
+    assert b"output quantizer" in lib.mq_last_error()
+    # activation kernel: unknown activation code
+    assert lib.mq_act_quant(p, 16, 7, None, None, 0.0, 0.0, None, None, 0.0, 0.0, None, None, 0.0, 0.0, p, None) == 1
+    # shapes the fragment-blocked GEMM path does not serve
+    assert lib.mq_gemm_tiled_supported(2048, 5632, 2048) == 1 and lib.mq_gemm_tiled_supported(2048, 2048, 2048) == 0
+    assert lib.mq_w8a8_linear_tiled(p, p, 2048, 2048, 2048, None, p, p, p, None, None, None, 0.0, 0.0, p, L.MQ_F32, None) == 3
+    assert b"mq_gemm_tiled_supported" in lib.mq_last_error()
+    # fresh min/max needs its scratch
+    assert lib.mq_minmax_tensor_fresh(p, L.MQ_F32, 100, p, p, p, 10, None) == 1
