@@ -67,18 +67,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_generated_isa_is_current(tmp_path):
     """csrc/mq_gemm_pp_asm.inc is generated (tools/gen_pp_asm.py) and committed: regenerating must reproduce it."""
     import importlib.util
-    import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     inc = os.path.join(root, "mobilequant_amd", "csrc", "mq_gemm_pp_asm.inc")
-    before = open(inc).read()
     spec = importlib.util.spec_from_file_location("gen_pp_asm", os.path.join(root, "tools", "gen_pp_asm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    try:
-        mod.main()
-        assert open(inc).read() == before
-    finally:
-        open(inc, "w").write(before)
+    fresh = str(tmp_path / "fresh.inc")
+    mod.main(fresh)
+    assert open(fresh).read() == open(inc).read()
 
 
 def test_argument_checks_fail_before_any_launch():

@@ -513,10 +513,10 @@ def generate():
     emit("s_nop 15")
 
 
-def main():
+def main(path=None):
     generate_stage() if STAGE else generate()
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "mobilequant_amd", "csrc", "mq_gemm_pp_asm.inc")
+    path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", "mq_gemm_pp_asm.inc")
     vregs = [f'"v{r}"' for r in (range(WA0, 128) if STAGE else range(WF0, V_A + 2))]
     aregs = [f'"a{r}"' for r in range(0, 120)]
     sregs = [f'"s{r}"' for r in range(S_T, (S_MORE2 if STAGE else S_TMP2) + 1)]
