@@ -548,6 +548,22 @@ def test_fragment_blocked_activations_and_generated_isa_gemm(dev):
     finally:
         ops.quantize_tiled = real
     assert len(calls) == 1 and torch.equal(y_t, y_rm)
+    # w1 / w3 receive the same tensor: ONE fragment-blocked quantize serves both
+    ql2 = mq.QLinear.from_float(torch.nn.Linear(256, 5632, bias=False).to(dev), a8c, a8c, a8c).requires_grad_(False)
+    ql2.set_scale_offset({"input": [float(xs.min()), float(xs.max())], "output": [-3.0, 3.0]}, "buffer")
+    ql2.input_quantizer = ql.input_quantizer
+    from mobilequant_amd.quantization import qmodule as Q2
+    calls.clear()
+    ops.quantize_tiled = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            ql2(xs)                              # weight plan
+            Q2._shared_activation.clear()
+            calls.clear()
+            ql(xs); ql2(xs)
+    finally:
+        ops.quantize_tiled = real
+    assert len(calls) == 1, calls
 
 
 def test_int8_gemm_extreme_k_and_zero_points(dev):
