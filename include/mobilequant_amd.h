@@ -203,13 +203,15 @@ int mq_w4a8_linear_f32in(const float* x, const float* a_scale, const float* a_of
  *   y (nullable): the fp32 result the reference returns.  q_out (nullable, needs the output quantizer): the same
  *   result as int8 storage (index - q_shift) plus row_sum (nullable, [rows]) = sum of the stored values per row, i.e.
  *   exactly what mq_quantize(want row sums) would produce from y -- the consumer linears skip their quantize launch.
+ *   q_tiled (nullable, cols % 64 == 0, ceil(rows/16)*16 * cols bytes): the same integer image in the fragment-blocked
+ *   layout of mq_quantize_tiled, for consumers served by mq_w8a8_linear_tiled (w1 / w3).
  * Elementwise arithmetic is the reference's op for op; the sum of squares is reduced in another order than torch's,
  * so an output within ~1e-7 relative of a rounding boundary may land on the neighbouring grid point. */
 int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
                      float eps, const float* in_scale, const float* in_offset, float in_qmin,
                      float in_qmax, const float* out_scale, const float* out_offset, float out_qmin,
-                     float out_qmax, float* y, int8_t* q_out, int q_shift, int32_t* row_sum,
-                     mq_stream_t stream);
+                     float out_qmax, float* y, int8_t* q_out, int8_t* q_tiled, int q_shift,
+                     int32_t* row_sum, mq_stream_t stream);
 
 /* QLayerNorm.forward (qmodule.py:624-640 around F.layer_norm): same contract as mq_rmsnorm_quant with the row's mean and
  * biased variance, y = (xi * rstd + (-rstd * mean)) * weight + bias (torch's CPU kernel expression); bias is the raw
@@ -217,8 +219,8 @@ int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* we
 int mq_layernorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
                        float eps, const float* in_scale, const float* in_offset, float in_qmin,
                        float in_qmax, const float* out_scale, const float* out_offset, float out_qmin,
-                       float out_qmax, float* y, int8_t* q_out, int q_shift, int32_t* row_sum,
-                       mq_stream_t stream);
+                       float out_qmax, float* y, int8_t* q_out, int8_t* q_tiled, int q_shift,
+                       int32_t* row_sum, mq_stream_t stream);
 
 /* ---- a10: QSiLU / QGELU.forward in one pass (qmodule.py:739-754, :790-798) ------------------------------------ */
 /* act 0 (SiLU): y = Qout( xi * Qmid(sigmoid(xi)) ), act 1 (GELU, erf form): y = Qout( gelu(xi) ), xi = Qin(x); fp32,

@@ -48,9 +48,9 @@ _SIGNATURES = {
     "mq_pack_w4": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "mq_act_quant": (c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P]),
     "mq_rmsnorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
-                                 _P, c_int, _P, _P]),
+                                 _P, _P, c_int, _P, _P]),
     "mq_layernorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
-                                   _P, c_int, _P, _P]),
+                                   _P, _P, c_int, _P, _P]),
     "mq_w4a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
     "mq_gemm_set_variant": (c_int, [c_int]),
     "mq_gemm_variant_name": (c_char_p, [c_int]),

@@ -54,6 +54,7 @@ struct NormArgs {
   float out_qmin, out_qmax;
   float* y;
   int8_t* q_out;
+  int8_t* q_tiled;     // same integer image in the fragment-blocked layout of mq_quantize_tiled (nullable)
   int q_shift;
   int32_t* row_sum;
   int64_t rows;
@@ -186,12 +187,17 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
       const float q0 = nq_index(y0, so, oo, a.out_qmin, a.out_qmax), q1 = nq_index(y1, so, oo, a.out_qmin, a.out_qmax);
       const float q2 = nq_index(y2, so, oo, a.out_qmin, a.out_qmax), q3 = nq_index(y3, so, oo, a.out_qmin, a.out_qmax);
       y0 = nq_dequant(q0, so, oo); y1 = nq_dequant(q1, so, oo); y2 = nq_dequant(q2, so, oo); y3 = nq_dequant(q3, so, oo);
-      if (a.q_out) {   // NaN has no integer image: saturate to the grid's low end like mq_quantize
+      if (a.q_out || a.q_tiled) {   // NaN has no integer image: saturate to the grid's low end like mq_quantize
         const int s0 = (int)fmaxf(q0, a.out_qmin) - a.q_shift, s1 = (int)fmaxf(q1, a.out_qmin) - a.q_shift;
         const int s2 = (int)fmaxf(q2, a.out_qmin) - a.q_shift, s3 = (int)fmaxf(q3, a.out_qmin) - a.q_shift;
         acc += (s0 + s1) + (s2 + s3);
-        reinterpret_cast<unsigned*>(a.q_out + row * cols)[i] =
-            (unsigned)(s0 & 0xff) | ((unsigned)(s1 & 0xff) << 8) | ((unsigned)(s2 & 0xff) << 16) | ((unsigned)(s3 & 0xff) << 24);
+        const unsigned pk = (unsigned)(s0 & 0xff) | ((unsigned)(s1 & 0xff) << 8) | ((unsigned)(s2 & 0xff) << 16) | ((unsigned)(s3 & 0xff) << 24);
+        if (a.q_out) reinterpret_cast<unsigned*>(a.q_out + row * cols)[i] = pk;
+        if (a.q_tiled) {            // block (row >> 4, k >> 6); lane (row & 15) + 16 * ((k >> 4) & 3); byte k & 15;  k = 4 i
+          const int k = i << 2;
+          const int64_t blk = (row >> 4) * (int64_t)(cols >> 6) + (k >> 6);
+          *reinterpret_cast<unsigned*>(a.q_tiled + (blk << 10) + ((((int)row & 15) + 16 * ((k >> 4) & 3)) << 4) + (k & 15)) = pk;
+        }
       }
     }
     if (a.y) reinterpret_cast<float4*>(a.y + row * cols)[i] = make_float4(y0, y1, y2, y3);
@@ -228,22 +234,23 @@ using namespace mq;
 static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
                        float eps, const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
                        const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
-                       int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
-  MQ_REQUIRE(x && weight && (y || q_out), "%s: null pointer", fn);
+                       int8_t* q_out, int8_t* q_tiled, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+  MQ_REQUIRE(x && weight && (y || q_out || q_tiled), "%s: null pointer", fn);
+  MQ_REQUIRE(!q_tiled || (cols % 64 == 0 && aligned(q_tiled, 16)), "%s: the fragment-blocked output needs cols %% 64 == 0 and a 16-byte aligned buffer", fn);
   MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= (1 << 20) && rows < (int64_t)0x7fffffff,
              "%s: bad shape %lld x %lld (cols must be a multiple of 4)", fn, (long long)rows, (long long)cols);
   MQ_REQUIRE((in_scale == nullptr) == (in_offset == nullptr) && (out_scale == nullptr) == (out_offset == nullptr),
              "%s: scale/offset must both be set or NULL", fn);
-  MQ_REQUIRE(!q_out || out_scale, "%s: integer output needs an output quantizer", fn);
-  MQ_REQUIRE(!row_sum || q_out, "%s: row sums are those of the integer output", fn);
-  MQ_REQUIRE(!q_out || (out_qmin - (float)q_shift >= -128.f && out_qmax - (float)q_shift <= 127.f),
+  MQ_REQUIRE(!(q_out || q_tiled) || out_scale, "%s: integer output needs an output quantizer", fn);
+  MQ_REQUIRE(!row_sum || q_out || q_tiled, "%s: row sums are those of the integer output", fn);
+  MQ_REQUIRE(!(q_out || q_tiled) || (out_qmin - (float)q_shift >= -128.f && out_qmax - (float)q_shift <= 127.f),
              "%s: [%g,%g]-%d does not fit int8", fn, out_qmin, out_qmax, q_shift);
   MQ_REQUIRE(aligned(x, 16) && aligned(weight, 16) && (!bias || aligned(bias, 16)) && (!y || aligned(y, 16)) &&
                  (!q_out || aligned(q_out, 4)),
              "%s: pointers must be 16-byte aligned", fn);
   if (rows == 0) return MQ_OK;
   NormArgs a{x, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale, out_offset, out_qmin, out_qmax,
-             y, q_out, q_shift, row_sum, rows, (int)cols};
+             y, q_out, q_tiled, q_shift, row_sum, rows, (int)cols};
   hipStream_t st = as_stream(stream);
 #define MQ_NORM(V, TPR)                                                                                   \
   do {                                                                                                    \
@@ -265,17 +272,17 @@ static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, in
 extern "C" int mq_rmsnorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
                                 const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
                                 const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
-                                int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+                                int8_t* q_out, int8_t* q_tiled, int q_shift, int32_t* row_sum, mq_stream_t stream) {
   return launch_norm("mq_rmsnorm_quant", false, x, rows, cols, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale,
-                     out_offset, out_qmin, out_qmax, y, q_out, q_shift, row_sum, stream);
+                     out_offset, out_qmin, out_qmax, y, q_out, q_tiled, q_shift, row_sum, stream);
 }
 
 extern "C" int mq_layernorm_quant(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
                                   const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
                                   const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
-                                  int8_t* q_out, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+                                  int8_t* q_out, int8_t* q_tiled, int q_shift, int32_t* row_sum, mq_stream_t stream) {
   return launch_norm("mq_layernorm_quant", true, x, rows, cols, weight, bias, eps, in_scale, in_offset, in_qmin, in_qmax, out_scale,
-                     out_offset, out_qmin, out_qmax, y, q_out, q_shift, row_sum, stream);
+                     out_offset, out_qmin, out_qmax, y, q_out, q_tiled, q_shift, row_sum, stream);
 }
 
 // ---- QSiLU / QGELU.forward in one pass (qmodule.py:739-754, :790-798) -------------------------------------------

@@ -245,9 +245,10 @@ def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qma
 
 
 def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_grid=None, out_grid=None, emit_int8: bool = False,
-                  layernorm: bool = False):
-    """QRMSNorm.forward (layernorm=True: QLayerNorm.forward) in one launch.  in_grid / out_grid: None or (scale, offset, qmin, qmax) per-tensor.
-    Returns y, or (y, q_int8, row_sum, shift) with emit_int8 (8-bit output grids only)."""
+                  layernorm: bool = False, emit_tiled: bool = False):
+    """QRMSNorm.forward (layernorm=True: QLayerNorm.forward) in one launch.  in_grid / out_grid: None or
+    (scale, offset, qmin, qmax) per-tensor.  Returns y, or (y, q_int8, row_sum, shift, q_tiled) with emit_int8
+    (8-bit output grids only; q_tiled = the fragment-blocked copy when emit_tiled, else None)."""
     x = _f32(_dev(x, "x"), "x").contiguous()
     cols = x.shape[-1]
     rows = x.numel() // cols
@@ -260,17 +261,21 @@ def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_gr
         si, oi, iqmin, iqmax = _f32(in_grid[0], "in_scale"), _f32(in_grid[1], "in_offset"), float(in_grid[2]), float(in_grid[3])
     if out_grid is not None:
         so, oo, oqmin, oqmax = _f32(out_grid[0], "out_scale"), _f32(out_grid[1], "out_offset"), float(out_grid[2]), float(out_grid[3])
-    q = rs = None
+    q = rs = qt = None
     shift = 0
     if emit_int8:
         shift = 128 if oqmax > 127 else 0
         q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
         rs = torch.empty(rows, dtype=torch.int32, device=x.device)
-    _lib.call("mq_layernorm_quant" if layernorm else "mq_rmsnorm_quant", x.data_ptr(), rows, cols, w.data_ptr(), b.data_ptr() if b is not None else None, float(eps),
+        if emit_tiled:
+            qt = torch.empty(((rows + 15) // 16 * 16, cols), dtype=torch.int8, device=x.device)
+    _lib.call("mq_layernorm_quant" if layernorm else "mq_rmsnorm_quant", x.data_ptr(), rows, cols, w.data_ptr(),
+              b.data_ptr() if b is not None else None, float(eps),
               si.data_ptr() if si is not None else None, oi.data_ptr() if oi is not None else None, iqmin, iqmax,
               so.data_ptr() if so is not None else None, oo.data_ptr() if oo is not None else None, oqmin, oqmax,
-              y.data_ptr(), q.data_ptr() if q is not None else None, shift, rs.data_ptr() if rs is not None else None, _stream())
-    return (y, q, rs, shift) if emit_int8 else y
+              y.data_ptr(), q.data_ptr() if q is not None else None, qt.data_ptr() if qt is not None else None, shift,
+              rs.data_ptr() if rs is not None else None, _stream())
+    return (y, q, rs, shift, qt) if emit_int8 else y
 
 
 def act_quant(x: torch.Tensor, act: str, in_grid=None, mid_grid=None, out_grid=None):

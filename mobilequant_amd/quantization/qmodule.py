@@ -351,39 +351,40 @@ def _static_per_tensor(q: Optional[Quantizer], max_bits: int) -> bool:
 
 
 class _SharedActivation:
-    """One-entry memo of the last activation tensor quantised for an int8 linear.  q_proj / k_proj / v_proj (and w1 /
-    w3) are called with the SAME tensor object and the same input grid, so the reference's three (two) identical
-    fake-quant passes collapse into one mq_quantize launch.  The entry is keyed on the tensor OBJECT (weak reference),
-    its version counter and the grid's identity (Quantizer.grid_token): a different tensor that happens to reuse the
-    address can never hit.  QRMSNorm's fused kernel files its int8 output here too, so its consumers find it."""
+    """Memo of the integer images of the LAST activation tensor quantised for an int8 linear.  q_proj / k_proj / v_proj
+    (and w1 / w3) are called with the SAME tensor object and the same input grid, so the reference's three (two)
+    identical fake-quant passes collapse into one quantize launch.  Keyed on the tensor OBJECT (weak reference) and its
+    version counter -- a different tensor that happens to reuse the address can never hit -- and, per entry, on the
+    grid's identity (Quantizer.grid_token) and the layout tag (a_shift for row-major, ("tiled", a_shift) for the
+    fragment-blocked layout).  The fused norm kernels file their int8 outputs here too, so their consumers find them."""
 
     def __init__(self):
-        self._ref = None
-        self._key = None
-        self._val = None
-
-    def get(self, x, grid, a_shift_hint):
-        if self._ref is None or self._ref() is not x:
-            return None
-        if self._key != self._make_key(x, grid, a_shift_hint):
-            return None
-        return self._val
-
-    def put(self, x, grid, a_shift_hint, val):
-        try:
-            self._ref = weakref.ref(x)
-        except TypeError:
-            self._ref = None
-            return
-        self._key = self._make_key(x, grid, a_shift_hint)
-        self._val = val
-
-    @staticmethod
-    def _make_key(x, grid, a_shift_hint):
-        return (x._version, x.data_ptr(), tuple(x.shape), x.dtype, grid.grid_token(), a_shift_hint)
+        self.clear()
 
     def clear(self):
-        self._ref = self._key = self._val = None
+        self._ref = None
+        self._base = None
+        self._vals = {}
+
+    @staticmethod
+    def _base_key(x):
+        return (x._version, x.data_ptr(), tuple(x.shape), x.dtype)
+
+    def _same(self, x):
+        return self._ref is not None and self._ref() is x and self._base == self._base_key(x)
+
+    def get(self, x, grid, tag):
+        return self._vals.get((grid.grid_token(), tag)) if self._same(x) else None
+
+    def put(self, x, grid, tag, val):
+        if not self._same(x):
+            try:
+                ref = weakref.ref(x)
+            except TypeError:
+                self.clear()
+                return
+            self._ref, self._base, self._vals = ref, self._base_key(x), {}
+        self._vals[(grid.grid_token(), tag)] = val
 
 
 _shared_activation = _SharedActivation()
@@ -466,15 +467,18 @@ class QLinear(nn.Linear, _QuantizedOp):
         a_shift = 128 if grid.qmax > 127 else 0
         tiled_rows = None
         if not decode:
-            # a producer's int8 copy (fused norm, or a sibling linear) wins: no quantize launch at all.  Otherwise the
-            # large FFN shapes quantise straight into the fragment-blocked layout of the generated-ISA GEMM loop.
-            hit = _shared_activation.get(x, grid, a_shift)
-            if hit is None and not plan["w4"] and ops.gemm_tiled_supported(x2d.shape[0], N, K):
-                hit = _shared_activation.get(x, grid, ("tiled", a_shift))
-                if hit is None:
-                    q_t, rs_t = ops.quantize_tiled(x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift)
-                    hit = (q_t, rs_t, a_shift)
-                    _shared_activation.put(x, grid, ("tiled", a_shift), hit)
+            # an integer image left by a producer (fused norm) or a sibling linear wins: no quantize launch at all.
+            # The large FFN shapes want the fragment-blocked layout of the generated-ISA GEMM loop.
+            eligible = (not plan["w4"]) and ops.gemm_tiled_supported(x2d.shape[0], N, K)
+            hit = _shared_activation.get(x, grid, ("tiled", a_shift)) if eligible else None
+            if hit is not None:
+                tiled_rows = x2d.shape[0]
+            else:
+                hit = _shared_activation.get(x, grid, a_shift)
+            if hit is None and eligible:
+                q_t, rs_t = ops.quantize_tiled(x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift)
+                hit = (q_t, rs_t, a_shift)
+                _shared_activation.put(x, grid, ("tiled", a_shift), hit)
                 tiled_rows = x2d.shape[0]
             elif hit is None:
                 hit = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
@@ -582,11 +586,18 @@ def _fused_norm(self, input_, weight, bias, layernorm):
             key = (key[0], key[1], wq.grid_token(), key[3])
             self._wfq = (key, wfq)
     emit = go is not None and self.output_quantizer.qcfg.bitwidth <= 8
-    res = ops.rmsnorm_quant(input_, wfq, bias, self.eps, gi, go, emit_int8=emit, layernorm=layernorm)
+    # the fragment-blocked copy (for w1 / w3, which the generated-ISA GEMM loop serves) costs 1/4 of the fp32 write;
+    # int8_tiled = None decides by shape: prefill-sized inputs whose width fits the layout
+    rows = input_.numel() // input_.shape[-1]
+    tiled = getattr(self, "int8_tiled", None)
+    tiled = emit and (input_.shape[-1] % 128 == 0) and (rows >= 1536 if tiled is None else bool(tiled))
+    res = ops.rmsnorm_quant(input_, wfq, bias, self.eps, gi, go, emit_int8=emit, layernorm=layernorm, emit_tiled=tiled)
     if not emit:
         return res
-    y, q, rs, shift = res
+    y, q, rs, shift, qt = res
     _shared_activation.put(y, self.output_quantizer, shift, (q, rs, shift))
+    if qt is not None:
+        _shared_activation.put(y, self.output_quantizer, ("tiled", shift), (qt, rs, shift))
     return y
 
 

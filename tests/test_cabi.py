@@ -88,8 +88,8 @@ def test_argument_checks_fail_before_any_launch():
     assert lib.mq_quantize_tiled(p, L.MQ_F32, 32, 100, p, p, 0.0, 255.0, 128, p, None, None) == 1
     assert b"multiple of 128" in lib.mq_last_error()
     # fused norm: cols % 4, integer output without an output grid
-    assert lib.mq_rmsnorm_quant(p, 4, 30, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, p, None, 0, None, None) == 1
-    assert lib.mq_rmsnorm_quant(p, 4, 32, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, None, p, 0, None, None) == 1
+    assert lib.mq_rmsnorm_quant(p, 4, 30, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, p, None, None, 0, None, None) == 1
+    assert lib.mq_rmsnorm_quant(p, 4, 32, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, None, p, None, 0, None, None) == 1
     assert b"output quantizer" in lib.mq_last_error()
     # activation kernel: unknown activation code
     assert lib.mq_act_quant(p, 16, 7, None, None, 0.0, 0.0, None, None, 0.0, 0.0, None, None, 0.0, 0.0, p, None) == 1

@@ -901,11 +901,17 @@ def test_qrmsnorm_fused_kernel_vs_reference(dev):
         assert _norm_close(y.cpu().numpy(), y_comp.cpu().numpy(), m), m
         if m["out_bits"] == 8:
             oq = qn.output_quantizer
-            _, q, rs, shift = ops.rmsnorm_quant(x, qn.weight_quantizer(fp.weight), fp.bias if ln else None, m["eps"],
+            _, q, rs, shift, qt = ops.rmsnorm_quant(x, qn.weight_quantizer(fp.weight), fp.bias if ln else None, m["eps"],
                                                 (qn.input_quantizer.scale, qn.input_quantizer.offset, qn.input_quantizer.qmin, qn.input_quantizer.qmax) if m["in_bits"] else None,
-                                                (oq.scale, oq.offset, oq.qmin, oq.qmax), emit_int8=True, layernorm=ln)
+                                                (oq.scale, oq.offset, oq.qmin, oq.qmax), emit_int8=True, layernorm=ln,
+                                                emit_tiled=m["cols"] % 128 == 0)
             q2, rs2, shift2 = oq.quantize_to_int(y.reshape(-1, m["cols"]), MQ_I8, want_row_sum=True)
             assert shift == shift2 and torch.equal(q, q2) and torch.equal(rs, rs2)
+            if qt is not None:        # the fragment-blocked copy == mq_quantize_tiled of the fp32 output (valid rows)
+                qt2, _ = ops.quantize_tiled(y.reshape(-1, m["cols"]), oq.scale, oq.offset, oq.qmin, oq.qmax, shift)
+                R, C = m["rows"], m["cols"]
+                unblock = lambda t: t.view(t.shape[0] // 16, C // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(t.shape[0], C)[:R]   # noqa: E731
+                assert torch.equal(unblock(qt), unblock(qt2)) and torch.equal(unblock(qt), q)
 
 
 def test_qsilu_qgelu_fused_kernels_vs_reference(dev):
@@ -1004,6 +1010,61 @@ def test_norm_to_linear_integer_chain(dev):
     assert all(torch.equal(a, b) for a, b in zip(chained, again))
     d = [(a - b).abs().max().item() for a, b in zip(chained, plain)]
     assert max(d) <= 2 * (6.0 / 255) + 1e-6, d
+
+
+def test_norm_to_ffn_chain_uses_fragment_blocked_layout(dev):
+    """ffn_norm (8-bit output) -> w1 / w3 (N = 5632, no input quantizers): the fused norm also writes the fragment-blocked
+    int8 copy, both linears run the generated-ISA GEMM on it, no quantize launch of any kind, and the outputs equal the
+    unchained execution on the same norm output."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd.quantization import qmodule as Q
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    torch.manual_seed(3)
+    a8, a16 = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16)
+    fp = HFRMSNorm(256, eps=1e-5).to(dev)
+    norm = mq.QRMSNorm.from_float(fp, a16, a16, a8).requires_grad_(False)
+    x = torch.randn(1, 1536, 256, device=dev) * 2
+    with torch.no_grad():
+        y_fp = fp(x)
+    out_rng = [float(y_fp.min()), float(y_fp.max())]
+    norm.set_scale_offset({"input": [float(x.min()), float(x.max())], "output": out_rng}, "buffer")
+    lins = []
+    for _ in range(2):
+        ql = mq.QLinear.from_float(torch.nn.Linear(256, 5632, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+        ql.input_quantizer = None
+        ql.set_scale_offset({"input": out_rng, "output": [-3.0, 3.0]}, "buffer")
+        lins.append(ql)
+
+    class FFN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ffn_norm, self.w1, self.w3 = norm, *lins
+
+        def forward(self, t):
+            h = self.ffn_norm(t)
+            return self.w1(h), self.w3(h)
+    blk = FFN()
+    assert mq.wire_integer_inputs(blk) == 2
+    counts = {"rm": 0, "tiled": 0, "gemm_tiled": 0}
+    real_q, real_t, real_l = ops.quantize, ops.quantize_tiled, ops.int8_linear
+    ops.quantize = lambda *a, **k: (counts.__setitem__("rm", counts["rm"] + 1), real_q(*a, **k))[1]
+    ops.quantize_tiled = lambda *a, **k: (counts.__setitem__("tiled", counts["tiled"] + 1), real_t(*a, **k))[1]
+    ops.int8_linear = lambda *a, **k: (counts.__setitem__("gemm_tiled", counts["gemm_tiled"] + (k.get("a_tiled_rows") is not None)), real_l(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            blk(x)                                                   # weight plans
+            for k in counts:
+                counts[k] = 0
+            chained = blk(x)
+            assert counts == {"rm": 0, "tiled": 0, "gemm_tiled": 2}, counts
+            h = norm(x)
+            Q._shared_activation.clear()
+            plain = [ql(h) for ql in lins]                           # quantises h itself (fragment-blocked, once)
+            assert counts["tiled"] == 1
+    finally:
+        ops.quantize, ops.quantize_tiled, ops.int8_linear = real_q, real_t, real_l
+    assert all(torch.equal(a, b) for a, b in zip(chained, plain))
 
 
 def test_toy_lm_w8a8_logits_vs_reference(dev):

@@ -51,11 +51,29 @@ for S, C in ((2048, 2048),):
         def forward(self, t):
             h = self.norm(t)
             return self.q_proj(h), self.k_proj(h), self.v_proj(h)
+    ffn = []
+    for n in (5632, 5632):
+        ql = mq.QLinear.from_float(torch.nn.Linear(C, n, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+        ql.input_quantizer = None
+        ql.set_scale_offset({"input": [-4.0, 4.0], "output": [-3.0, 3.0]}, "buffer")
+        ffn.append(ql)
+
+    class FFN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm, self.w1, self.w3 = norm, *ffn
+
+        def forward(self, t):
+            h = self.norm(t)
+            return self.w1(h), self.w3(h)
     blk = Block()
+    fblk = FFN()
     mq.wire_integer_inputs(blk)
+    mq.wire_integer_inputs(fblk)
     with torch.no_grad():
         for mode in ("auto", "off"):
             norm.fused_mode = mode
             tn = timeit(lambda: norm(x))
             tb = timeit(lambda: blk(x))
-            print(f"[{S}x{C}] fused_mode={mode:4s}  QRMSNorm.forward {tn:7.2f} us   norm + q/k/v block {tb:7.2f} us")
+            tf = timeit(lambda: fblk(x))
+            print(f"[{S}x{C}] fused_mode={mode:4s}  QRMSNorm.forward {tn:7.2f} us   norm + q/k/v block {tb:7.2f} us   norm + w1/w3 block {tf:7.2f} us")
