@@ -566,6 +566,41 @@ def test_fragment_blocked_activations_and_generated_isa_gemm(dev):
     assert len(calls) == 1, calls
 
 
+def test_int8_gemm_randomised_shapes_vs_oracle(dev):
+    """Differential fuzz: 60 random (M, N, K, per-row / per-tensor, symmetric, bias, W8 / W4) problems through the
+    built-in tile heuristic (GEMM for M > 8, GEMV below), float output bit-exact against the integer oracle."""
+    from mobilequant_amd import ops
+    rng = np.random.default_rng(20260928)
+    for it in range(60):
+        M = int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 255, 256, 257, 384, 600]))
+        N = int(rng.integers(1, 177)) * 4
+        K = int(rng.integers(1, 9)) * 128
+        w4 = bool(rng.integers(0, 2))
+        per_row, sym, has_bias = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        qa = rng.integers(0, 256, size=(M, K))
+        za = int(rng.integers(0, 256))
+        sa = F32(0.02)
+        sw = (rng.random(N, dtype=F32) * F32(1e-3) + F32(1e-4)) if per_row else np.full(N, F32(7e-4), F32)
+        bias = rng.standard_normal(N, dtype=F32) if has_bias else None
+        if w4:
+            qmin = -8 if sym else 0
+            qw = rng.integers(qmin, qmin + 16, size=(N, K))
+            zw = np.zeros(N, np.int64) if sym else (rng.integers(0, 16, size=N) if per_row else np.full(N, int(rng.integers(0, 16))))
+            packed = ops.pack_w4(T((qw - qmin).astype(np.uint8), dev))
+            colsum = T((qw - qmin).sum(1).astype(np.int32), dev)
+            wsc = T(sw if per_row else sw[:1], dev)
+            wof = T((zw if per_row else zw[:1]).astype(F32), dev)
+            alpha, wzp, ct = ops.linear_epilogue_prepare(T(np.array([sa], F32), dev), T(np.array([za], F32), dev), 128, wsc, wof, qmin, colsum, K)
+            got = ops.int8_linear(T((qa - 128).astype(np.int8), dev), packed, T((qa - 128).sum(1).astype(np.int32), dev),
+                                  alpha, wzp, ct, T(bias, dev) if has_bias else None, w4=True)
+        else:
+            qw = rng.integers(-128 if sym else 0, 128 if sym else 256, size=(N, K))
+            zw = np.zeros(N, np.int64) if sym else (rng.integers(0, 256, size=N) if per_row else np.full(N, int(rng.integers(0, 256))))
+            got = _run_int8(dev, qa, qw, za, zw, sa, sw, bias, 0 if sym else 128)
+        _, want = O.qlinear_int_exact(qa, za, sa, qw, zw, sw, bias)
+        assert np.array_equal(bits(got.detach().cpu().numpy()), bits(want)), (it, M, N, K, w4, per_row, sym, has_bias)
+
+
 def test_int8_gemm_extreme_k_and_zero_points(dev):
     """Gemma's w2 depth (K = 16384) with worst-case operands: every index at an end of the grid and extreme zero
     points, so the int32 accumulator and the correction terms reach their largest magnitudes -- still exact."""
