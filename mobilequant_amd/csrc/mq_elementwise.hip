@@ -522,12 +522,12 @@ int mq_scale_offset_from_minmax(const float* min_val, const float* max_val, int6
 
 int mq_fake_quant(const void* x, void* y, int dtype, int64_t rows, int64_t cols, const float* scale,
                   const float* offset, int64_t n_scale, float qmin, float qmax, mq_stream_t stream) {
-  MQ_REQUIRE(x && y && scale && offset, "mq_fake_quant: null pointer");
   MQ_REQUIRE(rows >= 0 && cols >= 0, "mq_fake_quant: negative shape");
   MQ_REQUIRE(n_scale == 1 || n_scale == rows, "mq_fake_quant: n_scale=%lld must be 1 or rows=%lld",
              (long long)n_scale, (long long)rows);
   MQ_REQUIRE(qmin <= qmax, "mq_fake_quant: qmin > qmax");
-  if (rows == 0 || cols == 0) return MQ_OK;
+  if (rows == 0 || cols == 0) return MQ_OK;      // empty tensor (its data pointer may be NULL): nothing to do
+  MQ_REQUIRE(x && y && scale && offset, "mq_fake_quant: null pointer");
   const bool per_row = (n_scale == rows) && rows > 1;
   if (dtype == MQ_F32)
     return launch_fake_quant<float>((const float*)x, (float*)y, rows, cols, scale, offset, per_row, false, qmin, qmax,
@@ -542,9 +542,9 @@ int mq_fake_quant(const void* x, void* y, int dtype, int64_t rows, int64_t cols,
 int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, int64_t cols, const float* scale,
                            const float* offset, int64_t n_scale, float qmin, float qmax, float* grad_x,
                            float* grad_scale, float* grad_offset, mq_stream_t stream) {
-  MQ_REQUIRE(x && grad_y && scale && offset && grad_x && grad_scale && grad_offset, "mq_fake_quant_backward: null pointer");
   MQ_REQUIRE(rows >= 0 && cols >= 0 && (n_scale == 1 || n_scale == rows), "mq_fake_quant_backward: bad shape");
-  if (rows == 0 || cols == 0) return MQ_OK;
+  if (rows == 0 || cols == 0) return MQ_OK;      // empty tensor: the (zero-initialised) scale / offset gradients stay zero
+  MQ_REQUIRE(x && grad_y && scale && offset && grad_x && grad_scale && grad_offset, "mq_fake_quant_backward: null pointer");
   MQ_REQUIRE(rows < (int64_t)0x7fffffff, "mq_fake_quant_backward: too many rows");
   if (n_scale == rows && rows > 1) {
     fake_quant_bwd_kernel<true><<<(unsigned)rows, 256, 0, as_stream(stream)>>>(x, grad_y, rows, cols, scale, offset, qmin,
@@ -563,12 +563,12 @@ int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, in
 int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
                 int64_t n_scale, float qmin, float qmax, int shift, void* q, int q_dtype, int32_t* row_sum,
                 mq_stream_t stream) {
-  MQ_REQUIRE(x && q && scale && offset, "mq_quantize: null pointer");
   MQ_REQUIRE(rows >= 0 && cols >= 0 && rows < (int64_t)0x7fffffff, "mq_quantize: bad shape %lld x %lld",
              (long long)rows, (long long)cols);
   MQ_REQUIRE(n_scale == 1 || n_scale == rows, "mq_quantize: n_scale=%lld must be 1 or rows=%lld", (long long)n_scale,
              (long long)rows);
-  if (rows == 0 || cols == 0) return MQ_OK;
+  if (rows == 0 || cols == 0) return MQ_OK;      // empty tensor (its data pointer may be NULL)
+  MQ_REQUIRE(x && q && scale && offset, "mq_quantize: null pointer");
   const bool per_row = (n_scale == rows) && rows > 1;
   const float lo = qmin - (float)shift, hi = qmax - (float)shift;
   hipStream_t st = as_stream(stream);
@@ -598,13 +598,13 @@ int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const floa
 
 int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
                       float qmin, float qmax, int shift, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream) {
-  MQ_REQUIRE(x && q_tiled && scale && offset, "mq_quantize_tiled: null pointer");
+  MQ_REQUIRE(rows != 0 ? (x && q_tiled && scale && offset) : true, "mq_quantize_tiled: null pointer");
   MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 128 == 0 && (rows + 15) / 8 < (int64_t)0x7fffffff,
              "mq_quantize_tiled: bad shape %lld x %lld (cols must be a multiple of 128)", (long long)rows, (long long)cols);
   MQ_REQUIRE(qmin - (float)shift >= -128.f && qmax - (float)shift <= 127.f, "mq_quantize_tiled: [%g,%g]-%d does not fit int8",
              qmin, qmax, shift);
-  MQ_REQUIRE(aligned(x, 16) && aligned(q_tiled, 16), "mq_quantize_tiled: pointers must be 16-byte aligned");
   if (rows == 0) return MQ_OK;
+  MQ_REQUIRE(aligned(x, 16) && aligned(q_tiled, 16), "mq_quantize_tiled: pointers must be 16-byte aligned");
   const unsigned grid = (unsigned)(((rows + 15) / 16) * 2);      // 8 rows per workgroup, padding rows included
   hipStream_t st = as_stream(stream);
 #define MQ_QT(T, KBW)                                                                                                 \

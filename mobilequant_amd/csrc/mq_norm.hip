@@ -235,6 +235,7 @@ static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, in
                        float eps, const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
                        const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, float* y,
                        int8_t* q_out, int8_t* q_tiled, int q_shift, int32_t* row_sum, mq_stream_t stream) {
+  if (rows == 0) return MQ_OK;                   // empty activation (its data pointers may be NULL)
   MQ_REQUIRE(x && weight && (y || q_out || q_tiled), "%s: null pointer", fn);
   MQ_REQUIRE(!q_tiled || (cols % 64 == 0 && aligned(q_tiled, 16)), "%s: the fragment-blocked output needs cols %% 64 == 0 and a 16-byte aligned buffer", fn);
   MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= (1 << 20) && rows < (int64_t)0x7fffffff,

@@ -419,8 +419,8 @@ class QLinear(nn.Linear, _QuantizedOp):
         return self._input_grid
 
     def _int8_ready(self, x, weight) -> bool:
-        if self.int8_mode == "off" or not x.is_cuda or x.dtype not in (torch.float32, torch.float16):
-            return False
+        if self.int8_mode == "off" or not x.is_cuda or x.dtype not in (torch.float32, torch.float16) or x.numel() == 0:
+            return False                    # (an empty batch takes the simulated path: every op of it handles empties)
         wq = self.weight_quantizer
         if wq is None or wq.bypassed() or wq.qcfg.bitwidth > 8 or wq.qcfg.is_dynamic or wq.lwc:
             return False

@@ -566,6 +566,32 @@ def test_fragment_blocked_activations_and_generated_isa_gemm(dev):
     assert len(calls) == 1, calls
 
 
+def test_empty_inputs_behave_like_torch(dev):
+    """Empty tensors (NULL data pointers) pass through every module with the right shape, as in the reference."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    a8, a16 = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16)
+    q = mq.Quantizer(a8)
+    q.set_scale_offset_from_minmax(-1.0, 2.0, "buffer", dev)
+    for shape in ((0,), (0, 16), (3, 0)):
+        x = torch.empty(*shape, device=dev)
+        assert q(x).shape == x.shape
+    xg = torch.empty(0, 8, device=dev, requires_grad=True)
+    q(xg).sum().backward()
+    assert xg.grad.shape == (0, 8)
+    ql = mq.QLinear.from_float(torch.nn.Linear(256, 64).to(dev), a8, a8, a8).requires_grad_(False)
+    ql.set_scale_offset({"input": [-1.0, 1.0], "output": [-3.0, 3.0]}, "buffer")
+    norm = mq.QRMSNorm.from_float(HFRMSNorm(256).to(dev), a16, a16, a8).requires_grad_(False)
+    norm.set_scale_offset({"input": [-1.0, 1.0], "output": [-3.0, 3.0]}, "buffer")
+    silu = mq.QSiLU(None, a8, a8)
+    silu.set_scale_offset({"output": [-1.0, 3.0]}, "buffer")
+    silu = silu.to(dev)
+    with torch.no_grad():
+        assert ql(torch.empty(1, 0, 256, device=dev)).shape == (1, 0, 64)
+        assert norm(torch.empty(1, 0, 256, device=dev)).shape == (1, 0, 256)
+        assert silu(torch.empty(0, 8, device=dev)).shape == (0, 8)
+
+
 def test_int8_gemm_randomised_shapes_vs_oracle(dev):
     """Differential fuzz: 60 random (M, N, K, per-row / per-tensor, symmetric, bias, W8 / W4) problems through the
     built-in tile heuristic (GEMM for M > 8, GEMV below), float output bit-exact against the integer oracle."""
