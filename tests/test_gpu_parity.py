@@ -566,6 +566,27 @@ def test_fragment_blocked_activations_and_generated_isa_gemm(dev):
     assert len(calls) == 1, calls
 
 
+def test_more_than_2_31_elements(dev):
+    """Maximum sizes: a tensor of 2^31 + 4120 fp16 elements (64-bit indexing in the streaming kernels): min/max finds
+    values planted in the middle and at the very end, fake-quant of head / middle / tail equals the small-tensor result."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    n = (1 << 31) + 4096 + 24
+    x = torch.empty(n, dtype=torch.float16, device=dev)
+    x.uniform_(-3, 3)
+    x[-1] = 7.5
+    x[n // 2] = -9.25
+    mn, mx = ops.minmax_tensor(x)
+    assert (mn.item(), mx.item()) == (-9.25, 7.5)
+    q = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+    q.set_scale_offset_from_minmax(-2.5, 3.0, "buffer", dev)
+    y = q(x)
+    for sl in (slice(0, 4096), slice(n // 2 - 100, n // 2 + 100), slice(n - 4096, n)):
+        assert torch.equal(q(x[sl].clone()), y[sl]), sl
+    del x, y
+    torch.cuda.empty_cache()
+
+
 def test_empty_inputs_behave_like_torch(dev):
     """Empty tensors (NULL data pointers) pass through every module with the right shape, as in the reference."""
     import mobilequant_amd as mq
