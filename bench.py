@@ -322,6 +322,67 @@ def bench_decode(dev, w4=False):
             "scope": "linears only (22 layers x [qkv, o, w1|w3, w2] %s GEMV with the activation quantize fused in), batch 1, hipGraph" % ("W4A8" if w4 else "W8A8")}
 
 
+def bench_layer(dev):
+    """The quantized-linear path of ONE TinyLlama decoder layer at prefill (S = 2048) through the module API:
+    attention_norm -> q/k/v, o_proj, ffn_norm -> w1/w3, w2 (W8A8, 8-bit activations, 16-bit norm inputs; attention,
+    RoPE, SiLU*mul and residuals are not part of the hot path and are left out: every linear gets a ready input).
+    Reports the hipGraph time of the 2 norms + 7 linears with the fused kernels / integer chaining, and with
+    fused_mode = "off" + no chaining (composite norms, every linear quantising its own input)."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.quantization import qmodule as Q
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    a8, a16 = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16)
+    S, H, F_, KV = 2048, 2048, 5632, 256
+    torch.manual_seed(1337)
+
+    def lin(k, n, own_input_quantizer):
+        ql = mq.QLinear.from_float(torch.nn.Linear(k, n, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+        if not own_input_quantizer:
+            ql.input_quantizer = None
+        ql.set_scale_offset({"input": [-4.0, 4.0], "output": [-3.0, 3.0]}, "buffer")
+        return ql
+
+    def norm():
+        n = mq.QRMSNorm.from_float(HFRMSNorm(H, eps=1e-5).to(dev), a16, a16, a8).requires_grad_(False)
+        n.set_scale_offset({"input": [-5.0, 5.0], "output": [-4.0, 4.0]}, "buffer")
+        return n
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attention_norm, self.ffn_norm = norm(), norm()
+            self.q_proj, self.k_proj, self.v_proj = lin(H, H, False), lin(H, KV, False), lin(H, KV, False)
+            self.o_proj, self.w1, self.w3, self.w2 = lin(H, H, True), lin(H, F_, False), lin(H, F_, False), lin(F_, H, True)
+
+        def forward(self, x, attn_out, ffn_mid):
+            h = self.attention_norm(x)
+            q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+            o = self.o_proj(attn_out)
+            g = self.ffn_norm(x)
+            a, b = self.w1(g), self.w3(g)
+            d = self.w2(ffn_mid)
+            return q, k, v, o, a, b, d
+    layer = Layer()
+    mq.wire_integer_inputs(layer)
+    x, attn_out, ffn_mid = torch.randn(1, S, H, device=dev), torch.randn(1, S, H, device=dev), torch.randn(1, S, F_, device=dev)
+    res = {}
+    for mode in ("fused", "composite"):
+        for m in layer.modules():
+            if hasattr(m, "fused_mode"):
+                m.fused_mode = "auto" if mode == "fused" else "off"
+
+        def fwd():
+            if mode == "composite":
+                Q._shared_activation.clear()
+            layer(x, attn_out, ffn_mid)
+        fwd()
+        res[mode + "_us"] = round(event_time(fwd, 5) * 1e6, 1)
+    ops_layer = 2.0 * S * (H * H * 2 + H * KV * 2 + H * F_ * 3)
+    res["tops_fused"] = round(ops_layer / (res["fused_us"] * 1e-6) / 1e12, 1)
+    res["scope"] = "2 QRMSNorm + 7 QLinear of one TinyLlama layer, S = 2048, W8A8, module API, hipGraph"
+    return res
+
+
 def bench_calibration(args, rank, world, dev):
     """Data-parallel activation-range calibration over a TinyLlama-shaped MLP block stack (synthetic)."""
     import torch.nn as nn
@@ -427,6 +488,8 @@ def main():
             decode = bench_decode(dev)
             torch.cuda.empty_cache()
             extras["decode_w4a8"] = bench_decode(dev, w4=True)      # the reference's deployment mode: 4-bit weights
+            torch.cuda.empty_cache()
+            extras["layer_prefill"] = bench_layer(dev)
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline()
 
