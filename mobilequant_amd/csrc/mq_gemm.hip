@@ -694,6 +694,7 @@ static const Variant kVariants[] = {
     {"t256x176_w8x1_pp", 256, 176, 512},
     {"t64x32_w2x2", 64, 32, 256},
     {"t256x176_w8x1_pp_asm", 256, 176, 512},
+    {"t128x128_w2x4", 128, 128, 512},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static int g_forced_variant = -1;
@@ -783,18 +784,20 @@ static int pick_variant(int M, int N, bool w4) {
   //    round (TinyLlama / StableLM FFN: N = 5632 = 32 x 176); int8 weights only;
   //  * otherwise the largest tile that still gives (nearly) every CU a workgroup: 256x256 (Gemma FFN), 256x128
   //    (fused q|k|v, N = 2560: wins from 160 workgroups);
-  //  * N = 2048 outputs (q/o, w2): four co-resident 64x64 workgroups per CU overlap each other's fill, drain and
-  //    epilogue and beat one 128x128 tile per CU by 3-8 % (W4: 17-21 %, fewer waves unpack the same nibbles);
-  //  * packed 4-bit weights: 256x256 from 160 workgroups, else 64x64 from one workgroup per CU, else 64x32.
+  //  * N = 2048 outputs (q/o, w2) and everything mid-sized: 128x128 with EIGHT waves (2 x 4, wave tile 64 x 32): twice
+  //    the waves of the 2 x 2 layout hide the LDS / DMA latency of the simple two-stage loop (4 x 2, 4 x 4 and 16-wave 256x256 / 64x64 / 256x128 layouts measured no better) -- 11.0 vs 15.2 us
+  //    (q/o), 30.7 vs 39.1 us (w2), 75 vs 95 us (Gemma w2);
+  //  * packed 4-bit weights: 256x256 from 224 workgroups (Gemma FFN), else the same 8-wave 128x128 tile (also for
+  //    N = 5632: 26.3 vs 28.1 us), small problems 64x64 / 64x32.
   if (w4) {
-    if (blocks(2) >= 160) return 2;
+    if (blocks(2) >= 224) return 2;
+    if (blocks(10) >= 96) return 10;
     return blocks(6) >= 256 ? 6 : 8;
   }
   if (N % 176 == 0 && blocks(1) >= 192) return 7;
   if (blocks(2) >= 224) return 2;
   if (blocks(5) >= 160) return 5;
-  if (blocks(6) >= 512) return 6;
-  if (blocks(3) >= 96) return 3;
+  if (blocks(10) >= 96) return 10;
   return blocks(6) >= 256 ? 6 : 8;
 }
 
@@ -832,6 +835,7 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
       if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, 3>(a, outq, st);
       else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
     case 8: return launch_cfg<64, 32, 2, 2, W4>(a, outq, st);
+    case 10: return launch_cfg<128, 128, 2, 4, W4>(a, outq, st);
     default: set_error("mq_gemm: bad variant %d", v); return MQ_EINVAL;
   }
 }
