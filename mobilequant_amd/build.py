@@ -41,16 +41,19 @@ def needs_build() -> bool:
     return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, tag: str = "", extra_flags=()) -> str:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
+    tag: build an experiment copy into lib/<tag>/ (A/B timing through MQ_LIB_PATH; never loaded by default)."""
+    libdir = os.path.join(LIBDIR, tag) if tag else LIBDIR
+    lib = os.path.join(libdir, "libmobilequant_amd.so")
+    if not force and not tag and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(libdir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(libdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -61,13 +64,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB
+    return lib
+
+
+def build_probe(tag: str = "") -> str:
+    """tools/mq_probe (standalone C++ checker / timer of the GEMM variants), bound to lib/<tag>/ by rpath."""
+    libdir = os.path.join(LIBDIR, tag) if tag else LIBDIR
+    probe = os.path.join(ROOT, "tools", "mq_probe" + ("_" + tag if tag else ""))
+    rpath = "$ORIGIN/../mobilequant_amd/lib" + ("/" + tag if tag else "")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "-w", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tools", "mq_probe.cpp"), "-L" + libdir, "-lmobilequant_amd", "-Wl,-rpath," + rpath,
+                    "-Wl,--disable-new-dtags", "-o", probe], check=True)
+    return probe
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True)
+    tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")
+    path = build(force="--force" in sys.argv, verbose=True, tag=tag)
     print("built", path)
+    if tag:
+        print("built", build_probe(tag))

@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
     Q(flat[C*22+14]), Q(flat[C*22+15]), Q(flat[C*22+16]), Q(flat[C*22+17]), Q(flat[C*22+18]), Q(flat[C*22+19]), Q(flat[C*22+20]), Q(flat[C*22+21])
 #define MQ_IN(x) "v"(x)
 #define MQ_OUT(x) "=v"(x)
+    if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
     asm volatile(MQ_PP_ASM_COPYIN0 ::MQ_OPS22(0, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
     asm volatile(MQ_PP_ASM_COPYIN1 ::MQ_OPS22(1, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
     asm volatile(MQ_PP_ASM_COPYIN2 ::MQ_OPS22(2, MQ_IN) : MQ_PP_ASM_ACLOBBERS);
@@ -573,7 +574,10 @@ __global__ void __launch_bounds__(64 * WM * WN)
   //     A' = alpha/so, B' = bias/so + oo);  (2) per 16-row block: dequant (+quantize) in registers,
   //     transpose through a wave-private LDS tile so that (3) every lane stores 16 contiguous bytes and
   //     a wave instruction writes whole rows -- instead of 16-byte fragments of 16 different rows.
-  __syncthreads();       // every wave is done with the stage buffers, which become staging tiles
+  // every wave must be done with the stage buffers before they become staging tiles -- except for the generated-ISA
+  // loop, whose A operand never passes through the LDS: the staging tiles (NW x 16 x ROWP bytes from offset 0) lie
+  // inside the unused A region in front of the W ring, so a wave can start its epilogue while others still read W
+  if constexpr (!ASMK) __syncthreads();
   if constexpr (ABL & 4) {
     if (acc[0][0][0] == 0x7fffffff) reinterpret_cast<int*>(args.out)[0] = 1;
     return;
@@ -595,77 +599,88 @@ __global__ void __launch_bounds__(64 * WM * WN)
   const bool u8_grid = (OUT == MQ_U8 || OUT == MQ_I8) && args.out_qmin == 0.0f && args.out_qmax == 255.0f;
   const bool rows_vec = (N % EPC) == 0;        // 16-byte row stores need N*ESZ % 16 == 0 (always true for LLM shapes)
   OT* outp = reinterpret_cast<OT*>(args.out);
+  // the unsigned 8-bit fast path (FOLD_OO && u8_grid, wave-uniform) is a separate instantiation of the block loop so
+  // that it carries no rint / med3 / select per value (88 values per lane)
+  auto store_tile = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int mrow0 = m0 + wave_m * TM + i * 16;
+    for (int i = 0; i < FM; ++i) {
+      const int mrow0 = m0 + wave_m * TM + i * 16;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nl = wave_n * TN + j * 16 + kq * 4;   // column within the block tile
-      const v4f al = p_alpha[nl >> 2];
-      const v4f bs = p_bias[nl >> 2];
-      float v[4];
+      for (int j = 0; j < FN; ++j) {
+        const int nl = wave_n * TN + j * 16 + kq * 4;   // column within the block tile
+        const v4f al = p_alpha[nl >> 2];
+        const v4f bs = p_bias[nl >> 2];
+        float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int t = acc[i][j][e];              // contraction + zero-point correction (accumulator init)
-        if constexpr (OUTQ) {
-          float q = __builtin_fmaf((float)t, al[e], bs[e]);
-          if (!(FOLD_OO && u8_grid)) {           // wave-uniform; the u8 fast path leaves both to cvt_pk_u8
-            q = rintf(q);
-            if constexpr (!FOLD_OO) q += oo;
-            q = __builtin_amdgcn_fmed3f(q, qmin, qmax);
+        for (int e = 0; e < 4; ++e) {
+          const int t = acc[i][j][e];              // contraction + zero-point correction (accumulator init)
+          if constexpr (OUTQ) {
+            float q = __builtin_fmaf((float)t, al[e], bs[e]);
+            if constexpr (!FAST) {                 // the u8 fast path leaves rint and clamp to cvt_pk_u8
+              q = rintf(q);
+              if constexpr (!FOLD_OO) q += oo;
+              q = __builtin_amdgcn_fmed3f(q, qmin, qmax);
+            }
+            if constexpr (OUT == MQ_F32 || OUT == MQ_F16) v[e] = __fmul_rn(__fsub_rn(q, oo), so);
+            else v[e] = q;
+          } else {
+            v[e] = __fadd_rn(__fmul_rn((float)t, al[e]), bs[e]);
           }
-          if constexpr (OUT == MQ_F32 || OUT == MQ_F16) v[e] = __fmul_rn(__fsub_rn(q, oo), so);
-          else v[e] = q;
+        }
+        char* dst = stg + frow * ROWP + (j * 16 + kq * 4) * ESZ;
+        if constexpr (OUT == MQ_F32) {
+          *reinterpret_cast<v4f*>(dst) = v4f{v[0], v[1], v[2], v[3]};
+        } else if constexpr (OUT == MQ_F16) {
+          struct alignas(8) H4 { __half h[4]; };
+          H4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h.h[e] = __float2half_rn(v[e]);
+          *reinterpret_cast<H4*>(dst) = h;
+        } else if constexpr (OUT == MQ_U8 || OUT == MQ_I8) {
+          unsigned pk = 0;
+          if (OUT == MQ_U8 || i8_unsigned_grid) {      // values in [0,255]; i8 storage = value - 128 = byte ^ 0x80
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(v[e], e, pk);
+            if (OUT == MQ_I8) pk ^= 0x80808080u;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= ((unsigned)(int)v[e] & 0xffu) << (8 * e);
+          }
+          *reinterpret_cast<unsigned*>(dst) = pk;
         } else {
-          v[e] = __fadd_rn(__fmul_rn((float)t, al[e]), bs[e]);
+          uint2 pk;
+          pk.x = ((unsigned)(int)v[0] & 0xffffu) | (((unsigned)(int)v[1] & 0xffffu) << 16);
+          pk.y = ((unsigned)(int)v[2] & 0xffffu) | (((unsigned)(int)v[3] & 0xffffu) << 16);
+          *reinterpret_cast<uint2*>(dst) = pk;
         }
       }
-      char* dst = stg + frow * ROWP + (j * 16 + kq * 4) * ESZ;
-      if constexpr (OUT == MQ_F32) {
-        *reinterpret_cast<v4f*>(dst) = v4f{v[0], v[1], v[2], v[3]};
-      } else if constexpr (OUT == MQ_F16) {
-        struct alignas(8) H4 { __half h[4]; };
-        H4 h;
+      // the wave's own LDS accesses execute in order: its writes above are visible to its reads below
+      if (rows_vec) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h.h[e] = __float2half_rn(v[e]);
-        *reinterpret_cast<H4*>(dst) = h;
-      } else if constexpr (OUT == MQ_U8 || OUT == MQ_I8) {
-        unsigned pk = 0;
-        if (OUT == MQ_U8 || i8_unsigned_grid) {      // values in [0,255]; i8 storage = value - 128 = byte ^ 0x80
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(v[e], e, pk);
-          if (OUT == MQ_I8) pk ^= 0x80808080u;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk |= ((unsigned)(int)v[e] & 0xffu) << (8 * e);
+        for (int c0 = 0; c0 < 16 * CH; c0 += 64) {
+          const int c = c0 + lane;
+          if (16 * CH % 64 == 0 || c < 16 * CH) {
+            const int row = c / CH, ch = c - row * CH;
+            const int m = mrow0 + row, n = n0 + wave_n * TN + ch * EPC;
+            const v4i val = *reinterpret_cast<const v4i*>(stg + row * ROWP + ch * 16);
+            if (m < M && n < N) __builtin_nontemporal_store(val, reinterpret_cast<v4i*>(outp + (size_t)m * N + n));
+          }
         }
-        *reinterpret_cast<unsigned*>(dst) = pk;
       } else {
-        uint2 pk;
-        pk.x = ((unsigned)(int)v[0] & 0xffffu) | (((unsigned)(int)v[1] & 0xffffu) << 16);
-        pk.y = ((unsigned)(int)v[2] & 0xffffu) | (((unsigned)(int)v[3] & 0xffffu) << 16);
-        *reinterpret_cast<uint2*>(dst) = pk;
-      }
-    }
-    // the wave's own LDS accesses execute in order: its writes above are visible to its reads below
-    if (rows_vec) {
-#pragma unroll
-      for (int c0 = 0; c0 < 16 * CH; c0 += 64) {
-        const int c = c0 + lane;
-        if (16 * CH % 64 == 0 || c < 16 * CH) {
-          const int row = c / CH, ch = c - row * CH;
-          const int m = mrow0 + row, n = n0 + wave_n * TN + ch * EPC;
-          const v4i val = *reinterpret_cast<const v4i*>(stg + row * ROWP + ch * 16);
-          if (m < M && n < N) __builtin_nontemporal_store(val, reinterpret_cast<v4i*>(outp + (size_t)m * N + n));
+        for (int c = lane; c < 16 * TN; c += 64) {        // ragged N: element-wise
+          const int row = c / TN, col = c - row * TN;
+          const int m = mrow0 + row, n = n0 + wave_n * TN + col;
+          if (m < M && n < N) outp[(size_t)m * N + n] = *reinterpret_cast<const OT*>(stg + row * ROWP + col * ESZ);
         }
       }
-    } else {
-      for (int c = lane; c < 16 * TN; c += 64) {        // ragged N: element-wise
-        const int row = c / TN, col = c - row * TN;
-        const int m = mrow0 + row, n = n0 + wave_n * TN + col;
-        if (m < M && n < N) outp[(size_t)m * N + n] = *reinterpret_cast<const OT*>(stg + row * ROWP + col * ESZ);
-      }
     }
+  };
+  if constexpr (FOLD_OO) {
+    if (u8_grid) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
+  } else {
+    store_tile(std::false_type{});
   }
   if constexpr (ABL & 16) {
     if (args.dbg_ts != nullptr && lane == 0) {

@@ -51,7 +51,7 @@ struct Problem {
   std::vector<int8_t> a, w;
   std::vector<int32_t> rs, zw, ct;
   std::vector<float> alpha, bias;
-  int8_t *da, *dw;
+  int8_t *da, *dw, *dat = nullptr;   // dat: fragment-blocked copy of a (mq_quantize_tiled layout), made on demand
   int32_t *drs, *dzw, *dct;
   float *dalpha, *dbias, *dos, *doo;
   float os, oo;
@@ -91,7 +91,32 @@ static Problem make_problem(int M, int N, int K, unsigned seed, bool per_row) {
   return p;
 }
 
+// fragment-blocked layout of include/mobilequant_amd.h: 1-KiB blocks of 16 rows x 64 k ordered [row block][k block];
+// inside a block byte offset 16 * ((row & 15) + 16 * ((k & 63) >> 4)) + (k & 15)
+static void make_tiled(Problem& p) {
+  if (p.dat) return;
+  const int Mp = (p.M + 15) / 16 * 16, K = p.K;
+  std::vector<int8_t> t((size_t)Mp * K, 0);
+  for (int m = 0; m < p.M; ++m)
+    for (int k = 0; k < K; ++k) {
+      const size_t blk = ((size_t)(m >> 4) * (K >> 6) + (k >> 6)) * 1024;
+      t[blk + 16 * ((m & 15) + 16 * ((k & 63) >> 4)) + (k & 15)] = p.a[(size_t)m * K + k];
+    }
+  p.dat = upload(t);
+}
+
+static int run_linear(Problem& p, int variant, const float* os, const float* oo, float qmax, void* dout, int out_dtype) {
+  if (variant == 9) {       // generated-ISA loop: fragment-blocked activations through the tiled entry point
+    make_tiled(p);
+    return mq_w8a8_linear_tiled(p.dat, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, os, oo, 0.f, qmax, dout,
+                                out_dtype, nullptr);
+  }
+  return mq_w8a8_linear(p.da, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, os, oo, 0.f, qmax, dout, out_dtype,
+                        nullptr);
+}
+
 static void free_problem(Problem& p) {
+  if (p.dat) hipFree(p.dat);
   hipFree(p.da); hipFree(p.dw); hipFree(p.drs); hipFree(p.dzw); hipFree(p.dct); hipFree(p.dalpha);
   hipFree(p.dbias); hipFree(p.dos); hipFree(p.doo);
 }
@@ -110,14 +135,14 @@ static void ref_row(const Problem& p, int m, std::vector<float>& out, std::vecto
   }
 }
 
-static int check(const Problem& p, int variant, int out_dtype, bool outq) {
+static int check(Problem& p, int variant, int out_dtype, bool outq) {
   const size_t esz = out_dtype == MQ_F32 ? 4 : (out_dtype == MQ_F16 || out_dtype == MQ_U16 || out_dtype == MQ_I16) ? 2 : 1;
   void* dout;
   HIPCHK(hipMalloc(&dout, (size_t)p.M * p.N * esz));
   HIPCHK(hipMemset(dout, 0xCD, (size_t)p.M * p.N * esz));
   mq_gemm_set_variant(variant);
-  MQCHK(mq_w8a8_linear(p.da, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, outq ? p.dos : nullptr,
-                       outq ? p.doo : nullptr, 0.f, out_dtype == MQ_U16 ? 65535.f : 255.f, dout, out_dtype, nullptr));
+  if (variant == 9 && !mq_gemm_tiled_supported(p.M, p.N, p.K)) { hipFree(dout); return 0; }   // shape not served
+  MQCHK(run_linear(p, variant, outq ? p.dos : nullptr, outq ? p.doo : nullptr, out_dtype == MQ_U16 ? 65535.f : 255.f, dout, out_dtype));
   HIPCHK(hipDeviceSynchronize());
   std::vector<uint8_t> h((size_t)p.M * p.N * esz);
   HIPCHK(hipMemcpy(h.data(), dout, h.size(), hipMemcpyDeviceToHost));
@@ -154,17 +179,15 @@ static int check(const Problem& p, int variant, int out_dtype, bool outq) {
   return bad;
 }
 
-static float time_variant(const Problem& p, int variant, int out_dtype, bool outq, int iters) {
+static float time_variant(Problem& p, int variant, int out_dtype, bool outq, int iters) {
   const size_t esz = out_dtype == MQ_F32 ? 4 : (out_dtype == MQ_F16 || out_dtype == MQ_U16) ? 2 : 1;
   void* dout;
   HIPCHK(hipMalloc(&dout, (size_t)p.M * p.N * esz));
   mq_gemm_set_variant(variant);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  auto run = [&]() {
-    MQCHK(mq_w8a8_linear(p.da, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, outq ? p.dos : nullptr,
-                         outq ? p.doo : nullptr, 0.f, 255.f, dout, out_dtype, nullptr));
-  };
+  if (variant == 9 && !mq_gemm_tiled_supported(p.M, p.N, p.K)) return 0.f;
+  auto run = [&]() { MQCHK(run_linear(p, variant, outq ? p.dos : nullptr, outq ? p.doo : nullptr, 255.f, dout, out_dtype)); };
   for (int i = 0; i < 5; ++i) run();
   HIPCHK(hipDeviceSynchronize());
   float best = 1e30f, tot = 0;
@@ -199,6 +222,7 @@ int main(int argc, char** argv) {
     const int M = argc > 7 ? atoi(argv[5]) : 2048, N = argc > 7 ? atoi(argv[6]) : 5632, K = argc > 7 ? atoi(argv[7]) : 2048;
     const int od = argc > 8 ? atoi(argv[8]) : MQ_U8;
     Problem p = make_problem(M, N, K, 99u, false);
+    if ((dbg & ~16) == 0) printf("prof check %s: bad=%d\n", mq_gemm_variant_name(v), check(p, v, od, od != MQ_F32 && od != MQ_F16));
     mq_gemm_set_debug(dbg);
     float t = time_variant(p, v, od, od != MQ_F32 && od != MQ_F16, n);
     printf("prof %s dbg=%d %dx%dx%d od=%d: %.2f us\n", mq_gemm_variant_name(v), dbg, M, N, K, od, t * 1e3);
