@@ -46,6 +46,10 @@ def parse():
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="qlinear", choices=["qlinear", "calibration"])
+    p.add_argument("--calib-samples", type=int, default=512, help="--workload calibration: samples (generate_act_range.py:30)")
+    p.add_argument("--calib-layers", type=int, default=22, help="--workload calibration: decoder layers (TinyLlama-1.1B: 22)")
+    p.add_argument("--calib-seq", type=int, default=2048, help="--workload calibration: tokens per sample")
+    p.add_argument("--per-channel", action="store_true", help="--workload calibration: per-channel statistics")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--gemm-variant", type=int, default=-1, help="force a GEMM tile variant (experiments)")
@@ -57,10 +61,36 @@ def parse():
     return p.parse_args()
 
 
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without an outer torchrun: re-launch under torch.distributed.run with N ranks (one process
+    per GPU, RCCL over xGMI) and exit with its status.  Under an outer torchrun WORLD_SIZE must equal --gpus.  Asking for more
+    GPUs than the box has fails loudly -- never a silent 1-rank run."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}")
+        return
+    if args.gpus == 1:
+        return
+    have = torch.cuda.device_count()
+    if args.gpus > have:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible")
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -247,32 +277,50 @@ def pmc_traffic():
 
 
 def cpu_baseline():
-    """The oracle's restatement of the reference's simulated QLinear.forward (weight re-quantised on
-    every call, as qmodule.py:346-347 does), on this box's host cores, bounded to ~10-30 s."""
-    from oracle import mq_oracle as O
-    rng = np.random.default_rng(1337)
-    x = rng.standard_normal((M, K), dtype=np.float32)
-    w = (rng.standard_normal((N, K), dtype=np.float32) * np.float32(0.02)).astype(np.float32)
-    wq, iq, oq = O.QuantizerOracle(8), O.QuantizerOracle(8), O.QuantizerOracle(8)
-    iq.set_from_minmax(float(x.min()), float(x.max()))
-    y = x @ w.T
-    oq.set_from_minmax(float(y.min()), float(y.max()))
+    """The reference's simulated path on this box's host cores: torch CPU kernels with
+    set_num_threads(physical cores), op for op what qmodule.py:251-358 executes -- the weight re-quantised on every
+    QLinear.forward (qmodule.py:346-347), fp32 F.linear, ~8 elementwise ops per Quantizer.forward
+    (oracle/mq_oracle_torch.py, checked bit-exactly against the numpy oracle in tests/).  Two bounded samples: the headline
+    QLinear (2048 x 2048 -> 5632), and one whole TinyLlama-shaped decoder layer at S = 2048.  Baseline only, not a target."""
+    from oracle import mq_oracle_torch as T
+    cores = T.physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
     try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        blas_threads = os.cpu_count() or 1
-    O.qlinear_sim(x, w, None, wq, iq, oq)              # warm-up; also caches the weight grid like the reference
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 40):
-        O.qlinear_sim(x, w, None, wq, iq, oq)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(OPS_PER_STEP / dt / 1e12, 4), "unit": "TOPS", "cores": int(blas_threads), "kind": "port",
-            "seconds_per_step": round(dt, 4),
-            "sample": f"{reps} calls of oracle.qlinear_sim (weight fake-quant + input fake-quant + fp32 GEMM + output "
-                      f"fake-quant) at M={M},K={K},N={N}; numpy elementwise on 1 thread, OpenBLAS GEMM on {blas_threads}"}
+        g = torch.Generator().manual_seed(1337)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * 0.02
+        wq, iq, oq = T.Quantizer(8), T.Quantizer(8).set_range(float(x.min()), float(x.max())), T.Quantizer(8)
+        y = x @ w.T
+        oq.set_range(float(y.min()), float(y.max()))
+        del y
+        with torch.no_grad():
+            T.qlinear(x, w, None, wq, iq, oq)              # warm-up; fixes the weight grid like the reference's first forward
+            t0 = time.perf_counter()
+            reps = 0
+            while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 200):
+                T.qlinear(x, w, None, wq, iq, oq)
+                reps += 1
+            dt = (time.perf_counter() - t0) / reps
+            layer = T.SimLayer()
+            xl = torch.randn(M, K, generator=g)
+            layer.forward(xl)
+            t1 = time.perf_counter()
+            lreps = 0
+            while lreps < 2 or (time.perf_counter() - t1 < 8.0 and lreps < 50):
+                layer.forward(xl)
+                lreps += 1
+            dtl = (time.perf_counter() - t1) / lreps
+    finally:
+        torch.set_num_threads(prev)
+    layer_ops = 2.0 * M * (2048 * 2048 * 2 + 2048 * 256 * 2 + 2048 * 5632 * 3) + 2.0 * 2 * 32 * M * M * 64
+    return {"value": round(OPS_PER_STEP / dt / 1e12, 4), "unit": "TOPS", "cores": int(cores), "kind": "port",
+            "seconds_per_step": round(dt, 4), "threads": int(cores),
+            "sample": f"{reps} calls of the torch-CPU restatement of QLinear.forward (weight fake-quant + input fake-quant + fp32 "
+                      f"F.linear + output fake-quant) at M={M},K={K},N={N}, torch.set_num_threads({cores}) = physical cores",
+            "layer": {"seconds_per_layer": round(dtl, 4), "value": round(layer_ops / dtl / 1e12, 4), "unit": "TOPS-equivalent",
+                      "sample": f"{lreps} forwards of one TinyLlama-shaped W8A8 decoder layer (2 QRMSNorm, 7 QLinear, 2 QMatMul, QSiLU; "
+                                "mixed-precision rules of ptq/mobilequant.py:175-201) at S=2048"}}
 
 
 def bench_decode(dev, w4=False):
@@ -383,57 +431,118 @@ def bench_layer(dev):
     return res
 
 
-def bench_calibration(args, rank, world, dev):
-    """Data-parallel activation-range calibration over a TinyLlama-shaped MLP block stack (synthetic)."""
-    import torch.nn as nn
+def calibration_run(dev, rank, world, layers, n_samples, seq, per_channel):
+    """ptq/generate_act_range.py:49-122 data-parallel: every rank holds the same random-init TinyLlama-shaped fp32 model
+    (mobilequant_amd/llama.py: the reference's leaf-module graph incl. the two FMatMuls), runs samples rank, rank + world, ...
+    through it with the min/max hooks attached (one single-pass HIP reduction per hooked tensor, device-resident running
+    statistics, no host sync), then ONE all-reduce(MAX) of the packed [-min, max] buffer (RCCL over xGMI)."""
     from mobilequant_amd.calibration import ActRangeCollector
-    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
-
-    class MLP(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.norm1 = HFRMSNorm(2048)
-            self.w1, self.w3, self.w2 = nn.Linear(2048, 5632, bias=False), nn.Linear(2048, 5632, bias=False), nn.Linear(5632, 2048, bias=False)
-            self.act_fn = nn.SiLU()
-
-        def forward(self, x):
-            h = self.norm1(x)
-            return x + self.w2(self.act_fn(self.w1(h)) * self.w3(h))
-
-    torch.manual_seed(1337)
-    model = nn.Sequential(*[MLP() for _ in range(2)]).to(dev).eval()
-    n_samples = 64
-    xs = [torch.randn(1, 2048, 2048, device=dev) for _ in range(4)]
-    col = ActRangeCollector(model).attach()
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    shape = LlamaShape.tinyllama(layers=layers, max_pos=seq)
+    model = LlamaForCausalLM(shape)
+    model.reset_parameters(seed=1337)                      # identical weights on every rank
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(1337)
+    pool = min(n_samples, 16)
+    ids = torch.randint(3, shape.vocab, (pool, seq), generator=g).to(dev)      # ids as harness_eval draws them (SURVEY 8d)
+    col = ActRangeCollector(model, per_channel).attach()
     with torch.no_grad():
-        for i in range(2):
-            model(xs[i % 4])
+        model(ids[0:1])                                    # warm-up (sample 0 is part of the stream anyway: min / max are idempotent)
         barrier(world)
         t0 = time.perf_counter()
-        for i in range(rank, n_samples, world):
-            model(xs[i % 4])
+        mine = list(range(rank, n_samples, world)) or [rank % n_samples]
+        for i in mine:
+            model(ids[i % pool][None])
         col.all_reduce()
         barrier(world)
-    dt = time.perf_counter() - t0
-    col.detach()
+        dt = time.perf_counter() - t0
+        col.detach()
+        hooked_bytes = col.bytes_seen / (len(mine) + 1)    # per sample (the warm-up sample was hooked too)
+        # the same samples without hooks: what the model itself costs (fp32 library GEMMs / softmax are not the hot path)
+        k = min(len(mine), 8)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in mine[:k]:
+            model(ids[i % pool][None])
+        torch.cuda.synchronize()
+        t_model = (time.perf_counter() - t1) / k
     dt = max_over_ranks(dt, world)
-    if rank == 0:
-        print(json.dumps({"metric": "activation-range calibration samples/s (2 TinyLlama MLP blocks, S=2048, per-tensor)",
-                          "value": round(n_samples / dt, 2), "unit": "samples/s", "n_gpus": world, "scaling": "strong",
-                          "collectives": 1, "data": "synthetic"}))
+    per_sample = dt / max(len(mine), 1)
+    act = col.act_dict()
+    return {"seconds": dt, "samples_per_s": n_samples / dt, "collectives": getattr(col, "n_collectives", 0), "tensors": len(col.slots),
+            "hooked_bytes_per_sample": hooked_bytes, "model_seconds_per_sample": t_model,
+            "reduction_seconds_per_sample": max(per_sample - t_model, 0.0), "modules": len(act)}
+
+
+def bench_minmax(dev, seq):
+    """HIP-event time of the calibration reductions alone on the dominant hooked tensors of one TinyLlama sample."""
+    from mobilequant_amd import ops
+    res = {}
+    for name, shape in (("qk_bmm.output [1,32,S,S]", (32 * seq, seq)), ("w1.output [1,S,5632]", (seq, 5632)), ("q_proj.input [1,S,2048]", (seq, 2048))):
+        x = torch.randn(shape, device=dev)
+        mn, mx = ops.minmax_new(1, dev)
+        t = event_time(lambda: ops.minmax_tensor_(x, mn, mx), 20)
+        cm, cx = ops.minmax_new(shape[1], dev)
+        tc = event_time(lambda: ops.minmax_cols_(x, cm, cx), 20)
+        nbytes = x.numel() * 4
+        res[name] = {"bytes": nbytes, "minmax_tensor_us": round(t * 1e6, 2), "minmax_tensor_GBps": round(nbytes / t / 1e9, 1),
+                     "minmax_cols_us": round(tc * 1e6, 2), "minmax_cols_GBps": round(nbytes / tc / 1e9, 1)}
+        del x
+    return res
+
+
+def bench_calibration(args, rank, world, dev):
+    """BASELINE.json configs[4]: generate_act_range over 512 calibration samples, data-parallel with one RCCL all-reduce."""
+    r = calibration_run(dev, rank, world, args.calib_layers, args.calib_samples, args.calib_seq, args.per_channel)
+    if rank != 0:
+        return
+    mm = bench_minmax(dev, args.calib_seq)
+    big = mm["qk_bmm.output [1,32,S,S]"]
+    key = "minmax_cols" if args.per_channel else "minmax_tensor"
+    achieved = big["bytes"] / (big[key + "_us"] * 1e-6) / 1e9
+    info = None
+    try:
+        import mobilequant_amd._lib as L
+        info = L.device_info()
+    except Exception:
+        pass
+    print(json.dumps({
+        "metric": "activation-range calibration samples/s (ptq/generate_act_range.py, data-parallel + one RCCL all-reduce)",
+        "value": round(r["samples_per_s"], 3), "unit": "samples/s", "n_gpus": world, "steps": args.calib_samples, "warmup": 1,
+        "ms_per_step": round(1e3 * r["seconds"] / max(args.calib_samples, 1), 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[4]: {args.calib_samples} samples x S={args.calib_seq} through a random-init fp32 "
+                               f"TinyLlama-1.1B-shaped decoder ({args.calib_layers} layers, hidden 2048, 32/4 heads, FFN 5632; hooks on every "
+                               "Linear / HFRMSNorm / SiLU / FMatMul leaf), " + ("per-channel" if args.per_channel else "per-tensor")
+                               + " running [min, max], round-robin shards", "parallelism": f"dp{world}", "collectives": r["collectives"],
+                   "tensors_tracked": r["tensors"], "device": info},
+        "roofline": {"bound": "hbm", "kernel": f"mq::{key}_kernel on the [32*S, S] attention scores (the largest hooked tensor)",
+                     "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                     "algorithmic_bytes_per_launch": big["bytes"], "traffic": None, "per_tensor_shapes": mm},
+        "breakdown": {"hooked_bytes_per_sample": int(r["hooked_bytes_per_sample"]),
+                      "model_ms_per_sample (fp32 library GEMMs, softmax: not the hot path)": round(1e3 * r["model_seconds_per_sample"], 3),
+                      "reduction_ms_per_sample": round(1e3 * r["reduction_seconds_per_sample"], 3),
+                      "reduction_GBps": round(r["hooked_bytes_per_sample"] / max(r["reduction_seconds_per_sample"], 1e-9) / 1e9, 1)},
+        "cpu_baseline": None}))
 
 
 def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    maybe_spawn(args)
     rank, world, local = dist_setup(args)
     dev = torch.device("cuda", local)
     import mobilequant_amd._lib as L
     from mobilequant_amd._lib import MQ_F16, MQ_F32, MQ_U8
     info = L.device_info()
     if args.workload == "calibration":
-        return bench_calibration(args, rank, world, dev)
+        bench_calibration(args, rank, world, dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     with torch.no_grad():
         Step.tiled_ok = not args.row_major_activations
@@ -448,6 +557,12 @@ def main():
 
         extras = {}
         roof = cpu = decode = None
+        # the data-parallel half of the hot path, bounded: 8 samples per rank through 2 TinyLlama-shaped layers + the single
+        # all-reduce -- so every multi-GPU run of this file also drives the RCCL path (full configs[4]: --workload calibration)
+        cal = calibration_run(dev, rank, world, layers=2, n_samples=8 * world, seq=2048, per_channel=False)
+        extras["calibration_dp"] = {"samples_per_s": round(cal["samples_per_s"], 2), "n_gpus": world, "samples": 8 * world, "layers": 2,
+                                    "seq": 2048, "collectives": cal["collectives"], "scaling": "weak (8 samples per rank)"}
+        torch.cuda.empty_cache()
         if rank == 0:
             # dominant kernel alone, HIP events on its stream
             t_gemm = event_time(step.gemm, 50)

@@ -232,14 +232,6 @@ int mq_act_quant(const float* x, int64_t numel, int act, const float* in_scale, 
                  float mid_qmin, float mid_qmax, const float* out_scale, const float* out_offset,
                  float out_qmin, float out_qmax, float* y, mq_stream_t stream);
 
-/* Tuning/diagnostic knob: force a GEMM tile configuration (see DESIGN.md "GEMM variants").
- * variant < 0 restores the built-in heuristic.  Returns the number of variants. */
-int mq_gemm_set_variant(int variant);
-const char* mq_gemm_variant_name(int variant);
-/* Ablation switches for profiling (results are WRONG when non-zero): 1 = no LDS-DMA after the first
- * stage, 2 = no MFMA loop, 4 = no epilogue.  0 = normal operation. */
-int mq_gemm_set_debug(int flags);
-
 #ifdef __cplusplus
 }
 #endif

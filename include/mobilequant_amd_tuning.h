@@ -1,0 +1,25 @@
+/* mobilequant_amd_tuning.h -- tuning / profiling knobs of libmobilequant_amd.so.
+ *
+ * NOT part of the drop-in boundary (include/mobilequant_amd.h): nothing in the reference has a counterpart, and a
+ * maintainer integrating the library never needs them.  They exist for tools/ (mq_probe, bench_shapes, A/B timing) and
+ * for the parity tests that run one problem on every GEMM tile variant.  The settings are process-wide atomics: set them
+ * from one thread while no GEMM call is in flight. */
+#ifndef MOBILEQUANT_AMD_TUNING_H
+#define MOBILEQUANT_AMD_TUNING_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Force a GEMM tile configuration (DESIGN.md "GEMM variants"); variant < 0 restores the built-in heuristic.
+ * Returns the number of variants. */
+int mq_gemm_set_variant(int variant);
+const char* mq_gemm_variant_name(int variant);
+/* Ablation switches of profiling builds (-DMQ_GEMM_ABLATE; results are WRONG when non-zero): 1 = no LDS-DMA after the
+ * first stage, 2 = no MFMA loop, 4 = no epilogue, 16 = s_memtime stamps.  0 = normal operation; ignored by production
+ * builds. */
+int mq_gemm_set_debug(int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBILEQUANT_AMD_TUNING_H */

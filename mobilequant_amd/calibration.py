@@ -20,6 +20,7 @@ one process.  Here:
 from __future__ import annotations
 
 import json
+from contextlib import nullcontext as _nullcontext
 from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -69,11 +70,17 @@ class ActRangeCollector:
             self._mn = torch.full((n,), float("inf"), dtype=torch.float32, device=self.device)
             self._mx = torch.full((n,), float("-inf"), dtype=torch.float32, device=self.device)
         self._hooks = []
+        self.bytes_seen = 0            # bytes of hooked tensors reduced so far (host-side bookkeeping for the benchmark)
+        self.n_collectives = 0
 
     # -- hooks -------------------------------------------------------------------------------------
     def _update(self, name: str, field: str, t: torch.Tensor) -> None:
         i = self.slots[(name, field)]
         t = t.detach()
+        self.bytes_seen += t.numel() * t.element_size()
+        if t.device != self.device:
+            raise RuntimeError(f"calibration of {name}.{field}: tensor on {t.device}, statistics on {self.device} -- run one "
+                               "process per GPU (the data-parallel path) instead of one model sharded over devices")
         if self.per_channel:
             t2 = t.reshape(-1, t.shape[-1])
             if self._pc[i] is None:
@@ -118,7 +125,8 @@ class ActRangeCollector:
             return torch.cat((-self._mn, self._mx))
         parts = []
         for s in self._pc:
-            parts += [-s[0], s[1]]
+            if s is not None:                       # never observed (on any rank: the module is not on the forward path)
+                parts += [-s[0].to(self.device), s[1].to(self.device)]
         return torch.cat(parts) if parts else torch.empty(0, device=self.device)
 
     def _unpack(self, buf: torch.Tensor) -> None:
@@ -128,28 +136,26 @@ class ActRangeCollector:
             return
         off = 0
         for i, s in enumerate(self._pc):
+            if s is None:
+                continue
             c = s[0].numel()
             self._pc[i] = (-buf[off:off + c], buf[off + c:off + 2 * c])
             off += 2 * c
 
-    def all_reduce(self, group=None) -> None:
-        """ONE all-reduce(MAX) over the packed [-min, max] buffer of every tensor."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    def all_reduce(self, group=None, force: bool = False) -> None:
+        """ONE all-reduce(MAX) over the packed [-min, max] buffer of every tensor -- per-tensor and per-channel mode alike.
+        Per-channel slot sizes come from each rank's own observations: get_act_range makes every rank run at least one
+        sample (a duplicate if it owns none; min / max are idempotent), and the reference's per-channel mode already
+        requires equal shapes across samples (generate_act_range.py:57-63), so the packed layout is identical on all ranks
+        without a second (object) collective.  force: also run the pack / reduce / unpack path in a 1-rank group (tests)."""
+        if not (dist.is_available() and dist.is_initialized()):
             return
-        if self.per_channel:
-            # ranks that saw no sample must still contribute correctly sized (+inf, -inf) entries
-            shapes = [None if s is None else s[0].numel() for s in self._pc]
-            gathered = [None] * dist.get_world_size(group)
-            dist.all_gather_object(gathered, shapes, group=group)
-            for i in range(len(shapes)):
-                c = next((g[i] for g in gathered if g[i] is not None), None)
-                if c is None:
-                    raise RuntimeError("a calibrated tensor was never observed on any rank")
-                if self._pc[i] is None:
-                    self._pc[i] = (torch.full((c,), float("inf"), device=self.device),
-                                   torch.full((c,), float("-inf"), device=self.device))
+        if dist.get_world_size(group) == 1 and not force:
+            return
         buf = self._packed()
-        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+        if buf.numel():
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+            self.n_collectives += 1
         self._unpack(buf)
 
     # -- results -----------------------------------------------------------------------------------
@@ -185,7 +191,7 @@ class ActRangeCollector:
 
 @torch.no_grad()
 def get_act_range(model: nn.Module, samples: Sequence[torch.Tensor], per_channel: bool = False, group=None,
-                  forward=None) -> Dict[str, dict]:
+                  forward=None, force_collective: bool = False) -> Dict[str, dict]:
     """Data-parallel counterpart of ``get_act_range`` (generate_act_range.py:49-122).
 
     ``samples``: the full list of calibration inputs (token-id tensors), identical on every rank; rank r
@@ -197,12 +203,16 @@ def get_act_range(model: nn.Module, samples: Sequence[torch.Tensor], per_channel
     col = ActRangeCollector(model, per_channel).attach()
     dev = col.device
     run = forward if forward is not None else (lambda s: model(s))
+    mine = list(range(rank, len(samples), world))
+    if not mine and len(samples):
+        mine = [rank % len(samples)]          # a duplicate: min / max are idempotent, and the rank learns every slot's shape
     try:
-        for i in range(rank, len(samples), world):
-            run(samples[i].to(dev))
+        for i in mine:
+            with torch.cuda.device(dev) if dev.type == "cuda" else _nullcontext():
+                run(samples[i].to(dev))
     finally:
         col.detach()
-    col.all_reduce(group)
+    col.all_reduce(group, force=force_collective)
     return col.act_dict()
 
 

@@ -1,6 +1,7 @@
 // Shared helpers for the libmobilequant_amd translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -15,6 +16,20 @@ void set_error(const char* fmt, ...);
 inline hipStream_t as_stream(mq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// The library may be driven on several devices of one process (a caller that switches devices, one model per GPU in one
+// process): everything cached per kernel or per launch configuration is cached PER DEVICE.
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : 0;
+}
+// once-per-device flag set (one bit per device; setting an attribute twice in a race is harmless)
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool done(int dev) const { return (mask.load(std::memory_order_acquire) >> dev) & 1ull; }
+  void mark(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
 
 #define MQ_REQUIRE(cond, ...)      \
   do {                             \

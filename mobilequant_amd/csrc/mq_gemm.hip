@@ -25,8 +25,10 @@
 #include <type_traits>
 
 #include "mq_common.h"
+#include "mobilequant_amd_tuning.h"
 #include "mq_gemv.h"
 #include "mq_gemm_pp_asm.inc"
+#include "mq_gemm_fr_asm.inc"
 
 namespace mq {
 
@@ -692,6 +694,96 @@ __global__ void __launch_bounds__(64 * WM * WN)
   }
 }
 
+
+// ---- free-running generated kernel (tools/gen_fr_asm.py -> mq_gemm_fr_asm.inc) ---------------------------------------
+// The whole workgroup program (prologue, software-pipelined main loop, epilogue) is generated gfx950 ISA; C++ only forms
+// the per-lane addresses and the scalar arguments.  256 x 176 tile, fragment-blocked activations, int8 weights, 8-bit
+// UNSIGNED output grid (u8 storage, or i8 storage = index - 128), K % 256 == 0, K >= 768.
+__global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 176;
+  const int M = args.M, N = args.N, K = args.K;
+  const int KT = K / BK;
+  // LDS-DMA source offsets of this wave's W pieces (8 rows x 128 B each; piece wave + 8 i), XOR-swizzled like the other variants
+  unsigned sw[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int row = n0 + (wave + i * 8) * 8 + (lane >> 3);
+    row = row < N ? row : N - 1;
+    sw[i] = (unsigned)row * (unsigned)K + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+  }
+  // fragment-blocked A (mq_quantize_tiled): row block rb, k block kb at ((rb * K/64) + kb) KiB, lane-linear inside
+  const int m0w = m0 + wave * 32;
+  const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+  unsigned rb0 = (unsigned)(m0w >> 4), rb1 = rb0 + 1;
+  rb0 = rb0 < rb_max ? rb0 : rb_max;
+  rb1 = rb1 < rb_max ? rb1 : rb_max;
+  const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  unsigned rsofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0w + i * 16 + (lane & 15);
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
+    rsofs[i] = (unsigned)m * 4u;
+  }
+  const float so = args.out_scale[0], oo = args.out_offset[0];
+  const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
+  const int oo_bits = __builtin_amdgcn_readfirstlane(__float_as_int(oo));
+  const int8_t* a_ptr = args.a;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  const float* alpha_p = args.alpha + n0;
+  const float* bias_p = args.bias + n0;
+  const int32_t* wzp_p = args.w_zp + n0;
+  const int32_t* ct_p = args.col_term + n0;
+  const int32_t* rs_p = args.a_rowsum;
+  uint8_t* outw = reinterpret_cast<uint8_t*>(args.out) + (size_t)m0w * N + n0;
+  // (explicit readfirstlane: an "s" constraint alone does not stop hipcc from handing over a VGPR)
+  const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int xorv = __builtin_amdgcn_readfirstlane(args.out_dtype == MQ_I8 ? (int)0x80808080u : 0);
+  const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
+  const unsigned tid = threadIdx.x;
+#if MQ_FR_ASM_STAMP
+  unsigned long long* dbg = args.dbg_ts + ((size_t)blockIdx.x * 8 + wave) * 16;
+#endif
+  asm volatile(MQ_FR_ASM_BODY
+               :
+               : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [alpha] "s"(alpha_p),
+                 [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),
+                 [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [xorv] "s"(xorv),
+#if MQ_FR_ASM_STAMP
+                 [dbg] "s"(dbg),
+#endif
+                 [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [sw2] "v"(sw[2]), [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid),
+                 [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
+               : MQ_FR_ASM_CLOBBERS);
+}
+
+static bool gemm_fr_supported(const GemmArgs& a) {
+  return a.a_tiled && (a.out_dtype == MQ_U8 || a.out_dtype == MQ_I8) && a.out_scale != nullptr && a.out_qmin == 0.0f &&
+         a.out_qmax == 255.0f && a.K % 256 == 0 && a.K >= 768 && a.N % 176 == 0;
+}
+
+static int launch_fr(const GemmArgs& a, hipStream_t st) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_fr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_FR_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", MQ_FR_LDS_BYTES, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  gemm_i8_fr_kernel<<<a.grid_m * a.grid_n, 512, MQ_FR_LDS_BYTES, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
+}
+
 // ---- variants & dispatch --------------------------------------------------------------------------
 struct Variant {
   const char* name;
@@ -710,23 +802,25 @@ static const Variant kVariants[] = {
     {"t64x32_w2x2", 64, 32, 256},
     {"t256x176_w8x1_pp_asm", 256, 176, 512},
     {"t128x128_w2x4", 128, 128, 512},
+    {"t256x176_w8x1_fr_asm", 256, 176, 512},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-static int g_forced_variant = -1;
-static int g_debug = 0;
+static std::atomic<int> g_forced_variant{-1};   // mobilequant_amd_tuning.h: process-wide, atomic
+static std::atomic<int> g_debug{0};
 static unsigned long long* g_dbg_ts = nullptr;
 
 template <int BM, int BN, int WM, int WN, int OUT, bool OQ, bool W4, int ABL, int PP>
 static int launch_one(const GemmArgs& a, int lds, hipStream_t st) {
   auto kfn = gemm_i8_kernel<BM, BN, WM, WN, OUT, OQ, W4, ABL, PP>;
-  static bool attr_set = false;   // per instantiation; one device per process
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;   // per instantiation and per device
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
       return MQ_EHIP;
     }
-    attr_set = true;
+    attr_set.mark(dev);
   }
   kfn<<<a.grid_m * a.grid_n, 64 * WM * WN, lds, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
@@ -738,7 +832,7 @@ static int launch_typed(const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = lds_main_bytes(BM, BN, WM, WN, W4, PP != 0) + 16 * BN;
 #ifdef MQ_GEMM_ABLATE
   if constexpr (OUT == MQ_U8 && OQ && !W4 && BM == 256) {
-    switch (g_debug) {
+    switch (g_debug.load()) {
       case 1: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 1, PP>(a, LDS, st);
       case 2: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 2, PP>(a, LDS, st);
       case 3: return launch_one<BM, BN, WM, WN, OUT, OQ, W4, 3, PP>(a, LDS, st);
@@ -790,7 +884,7 @@ static bool gemm_tiled_supported(int64_t M, int64_t N, int64_t K) {
 }
 
 static int pick_variant(int M, int N, bool w4) {
-  if (g_forced_variant >= 0) return g_forced_variant;
+  if (g_forced_variant.load() >= 0) return g_forced_variant.load();
   auto blocks = [&](int v) {
     return (long)((M + kVariants[v].bm - 1) / kVariants[v].bm) * ((N + kVariants[v].bn - 1) / kVariants[v].bn);
   };
@@ -829,9 +923,11 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
                 a.N, a.K);
       return MQ_EUNSUPPORTED;
     }
-    v = 9;
-  } else if (v == 9) {
-    v = 7;                                  // variant 9 reads fragment-blocked activations only
+    // the free-running generated kernel serves the 8-bit unsigned output grid; every other output type keeps the
+    // ping-pong generated loop with the C++ epilogue (mq_gemm_set_variant(9) forces that one for A/B timing)
+    v = (gemm_fr_supported(a) && g_forced_variant != 9) ? 11 : 9;
+  } else if (v == 9 || v == 11) {
+    v = 7;                                  // variants 9 and 11 read fragment-blocked activations only
   }
   a.grid_m = (a.M + kVariants[v].bm - 1) / kVariants[v].bm;
   a.grid_n = (a.N + kVariants[v].bn - 1) / kVariants[v].bn;
@@ -849,6 +945,7 @@ static int run_gemm(GemmArgs a, hipStream_t st) {
     case 9:     // generated-ISA main loop on fragment-blocked activations (run_gemm checked the shape)
       if constexpr (!W4) return launch_cfg<256, 176, 8, 1, false, 3>(a, outq, st);
       else return launch_cfg<256, 176, 8, 1, W4>(a, outq, st);
+    case 11: return launch_fr(a, st);
     case 8: return launch_cfg<64, 32, 2, 2, W4>(a, outq, st);
     case 10: return launch_cfg<128, 128, 2, 4, W4>(a, outq, st);
     default: set_error("mq_gemm: bad variant %d", v); return MQ_EINVAL;

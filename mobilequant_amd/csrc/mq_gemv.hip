@@ -203,12 +203,13 @@ int run_gemv(const GemvArgs& g, hipStream_t st) {
     return MQ_EUNSUPPORTED;
   }
   // one fat workgroup per CU; a wave keeps at most 64 row slots (their parameters live one per lane)
-  static int cus = 0;
+  static std::atomic<int> cus_of[kMaxDevices];      // CU count per device (0 = not read yet)
+  const int dev = current_device();
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
   if (!cus) {
-    int dev = 0;
     hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 256;
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus_of[dev].store(cus, std::memory_order_relaxed);
   }
   int rows_per_wg = (g.N + cus - 1) / cus;
   if (rows_per_wg > GV2_WAVES * 64) rows_per_wg = GV2_WAVES * 64;

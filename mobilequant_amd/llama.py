@@ -1,0 +1,166 @@
+"""Minimal llama-style decoder with the reference's LEAF-MODULE GRAPH -- nothing else of its model zoo.
+
+MobileQuant's surgery (`create_sim_qmodel`, qmodule.py:835-865), its mixed-precision rules (ptq/mobilequant.py:175-201) and its
+calibration hooks (ptq/generate_act_range.py:93-95) key on module *types* and *names*: `q_proj k_proj v_proj o_proj`, `qk_bmm
+pv_bmm` (FMatMul), `w1 w2 w3`, `act_fn` (nn.SiLU), `input_layernorm post_attention_layernorm` (HFRMSNorm), final `norm`, `lm_head`
+(mobilellm/model/hf_model.py:382-534, :1042-1062, :1165-1260).  This module provides exactly that graph for the shapes of
+BASELINE.json (TinyLlama-1.1B: hidden 2048, 22 layers, 32 heads / 4 KV heads, head_dim 64, FFN 5632, vocab 32000 --
+mobilellm/model/sim_model.py:43-44), so that the calibration benchmark (configs[4]), the layer-level benchmarks and the decode
+step run on the reference's module structure with random-init weights (no checkpoints offline).  RoPE, 1/sqrt(d), mask and
+softmax stay unquantised fp32 ops as in the reference (hf_model.py:486-530); residual adds and the w1*w3 product are plain ops
+(not in the surgery list).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .quantization.fp_ops import FMatMul, HFRMSNorm
+
+
+@dataclass
+class LlamaShape:
+    hidden: int = 2048
+    layers: int = 22
+    heads: int = 32
+    kv_heads: int = 4
+    head_dim: int = 64
+    ffn: int = 5632
+    vocab: int = 32000
+    eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_pos: int = 2048
+
+    @classmethod
+    def tinyllama(cls, **kw) -> "LlamaShape":
+        return cls(**kw)
+
+    @classmethod
+    def toy(cls, **kw) -> "LlamaShape":
+        base = dict(hidden=128, layers=2, heads=4, kv_heads=2, head_dim=32, ffn=256, vocab=97, max_pos=128)
+        base.update(kw)
+        return cls(**base)
+
+
+def rope_tables(shape: LlamaShape, device=None):
+    """cos / sin [max_pos, head_dim] (rotate-half convention, hf_model.py:486-501)."""
+    inv = 1.0 / (shape.rope_theta ** (torch.arange(0, shape.head_dim, 2, dtype=torch.float32, device=device) / shape.head_dim))
+    ang = torch.outer(torch.arange(shape.max_pos, dtype=torch.float32, device=device), inv)
+    ang = torch.cat((ang, ang), dim=-1)
+    return ang.cos(), ang.sin()
+
+
+def apply_rope(x, cos, sin):
+    """x [B, H, S, D]; cos/sin [S, D]."""
+    h = x.shape[-1] // 2
+    rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+    return x * cos + rot * sin
+
+
+class Attention(nn.Module):
+    def __init__(self, s: LlamaShape):
+        super().__init__()
+        self.s = s
+        self.q_proj = nn.Linear(s.hidden, s.heads * s.head_dim, bias=False)
+        self.k_proj = nn.Linear(s.hidden, s.kv_heads * s.head_dim, bias=False)
+        self.v_proj = nn.Linear(s.hidden, s.kv_heads * s.head_dim, bias=False)
+        self.o_proj = nn.Linear(s.heads * s.head_dim, s.hidden, bias=False)
+        self.qk_bmm, self.pv_bmm = FMatMul(), FMatMul()
+
+    def forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
+        """x [B, S, hidden].  cache: optional (k [B, KV, T, D], v [B, KV, T, D]) static buffers; the S new positions are
+        written at pos .. pos+S-1 and attention runs over positions 0 .. pos+S-1 (sim_model.py:160-221's static cache)."""
+        s = self.s
+        B, S, _ = x.shape
+        q = self.q_proj(x).view(B, S, s.heads, s.head_dim).transpose(1, 2)
+        k = self.k_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
+        v = self.v_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
+        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+        if cache is not None:
+            cache[0][:, :, pos:pos + S] = k
+            cache[1][:, :, pos:pos + S] = v
+            k, v = cache[0][:, :, :pos + S], cache[1][:, :, :pos + S]
+        rep = s.heads // s.kv_heads
+        if rep > 1:   # repeat_kv (hf_model.py:509-510)
+            k = k[:, :, None].expand(B, s.kv_heads, rep, k.shape[-2], s.head_dim).reshape(B, s.heads, -1, s.head_dim)
+            v = v[:, :, None].expand(B, s.kv_heads, rep, v.shape[-2], s.head_dim).reshape(B, s.heads, -1, s.head_dim)
+        att = self.qk_bmm(q, k.transpose(2, 3)) / math.sqrt(s.head_dim)
+        if mask is not None:
+            att = att + mask
+        att = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
+        out = self.pv_bmm(att, v)
+        return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
+
+
+class MLP(nn.Module):
+    def __init__(self, s: LlamaShape):
+        super().__init__()
+        self.w1 = nn.Linear(s.hidden, s.ffn, bias=False)
+        self.w2 = nn.Linear(s.ffn, s.hidden, bias=False)
+        self.w3 = nn.Linear(s.hidden, s.ffn, bias=False)
+        self.act_fn = nn.SiLU()
+
+    def forward(self, x):      # hf_model.py:1057
+        return self.w2(self.act_fn(self.w1(x)) * self.w3(x))
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, s: LlamaShape):
+        super().__init__()
+        self.self_attn = Attention(s)
+        self.mlp = MLP(s)
+        self.input_layernorm = HFRMSNorm(s.hidden, eps=s.eps)
+        self.post_attention_layernorm = HFRMSNorm(s.hidden, eps=s.eps)
+
+    def forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
+        x = x + self.self_attn(self.input_layernorm(x), cos, sin, mask, cache, pos)
+        return x + self.mlp(self.post_attention_layernorm(x))
+
+
+class LlamaForCausalLM(nn.Module):
+    """embed -> layers -> norm -> lm_head.  `layers`, final `norm` and `lm_head` carry the names the surgery rules skip
+    (qmodule.py:843)."""
+
+    def __init__(self, shape: LlamaShape, std: float = 0.02):
+        super().__init__()
+        self.shape = shape
+        self.embed_tokens = nn.Embedding(shape.vocab, shape.hidden)
+        self.layers = nn.ModuleList(DecoderLayer(shape) for _ in range(shape.layers))
+        self.norm = HFRMSNorm(shape.hidden, eps=shape.eps)
+        self.lm_head = nn.Linear(shape.hidden, shape.vocab, bias=False)
+        cos, sin = rope_tables(shape)
+        self.register_buffer("cos", cos, persistent=False)
+        self.register_buffer("sin", sin, persistent=False)
+        self.reset_parameters(std)
+
+    @torch.no_grad()
+    def reset_parameters(self, std: float = 0.02, seed: Optional[int] = None):
+        g = None
+        if seed is not None:
+            g = torch.Generator(device="cpu").manual_seed(seed)
+        for p in self.parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * std) if g is not None else p.normal_(0.0, std)
+            else:
+                p.fill_(1.0)
+
+    def forward(self, ids, cache=None, pos: int = 0):
+        """ids [B, S] token ids.  cache: list (one per layer) of (k, v) static buffers [B, KV, T, D], see Attention.forward."""
+        B, S = ids.shape
+        x = self.embed_tokens(ids)
+        cos, sin = self.cos[pos:pos + S], self.sin[pos:pos + S]
+        mask = None
+        if S > 1:
+            mask = torch.full((S, pos + S), float("-inf"), device=x.device, dtype=x.dtype).triu(pos + 1)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, cos, sin, mask, None if cache is None else cache[i], pos)
+        return self.lm_head(self.norm(x))
+
+    def new_cache(self, batch: int, length: int, device=None, dtype=torch.float32):
+        s = self.shape
+        return [(torch.zeros(batch, s.kv_heads, length, s.head_dim, device=device, dtype=dtype),
+                 torch.zeros(batch, s.kv_heads, length, s.head_dim, device=device, dtype=dtype)) for _ in self.layers]

@@ -28,6 +28,34 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _on:
+    """Device guard: every tensor handed to one C-ABI call must live on the same ROCm device, and the call is made with
+    that device current (so the stream is that device's current stream and the kernel launches there) -- a model placed on
+    cuda:1 while cuda:0 is current must not race or fault.  No-op when the device is already current."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, first: torch.Tensor, *rest):
+        dev = first.device
+        for t in rest:
+            if t is not None and t.device != dev:
+                raise RuntimeError(f"mobilequant_amd: tensors on different devices in one call ({dev} vs {t.device}); move the "
+                                   "quantizer grids / statistics to the activation's device")
+        self.idx = dev.index if dev.type == "cuda" else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None and torch.cuda.current_device() != self.idx:
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def _fdt(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]
@@ -47,8 +75,9 @@ def scale_offset_from_minmax(min_val: torch.Tensor, max_val: torch.Tensor, bitwi
     """Device version of compute_scale_offset_from_min_max (qmodule.py:40-61); shapes follow min_val."""
     mn, mx = _f32(min_val, "min_val"), _f32(max_val, "max_val")
     scale, offset = torch.empty_like(mn), torch.empty_like(mn)
-    _lib.call("mq_scale_offset_from_minmax", mn.data_ptr(), mx.data_ptr(), mn.numel(), int(bitwidth),
-              int(bool(is_symmetric)), scale.data_ptr(), offset.data_ptr(), _stream())
+    with _on(mn, mx):
+        _lib.call("mq_scale_offset_from_minmax", mn.data_ptr(), mx.data_ptr(), mn.numel(), int(bitwidth),
+                  int(bool(is_symmetric)), scale.data_ptr(), offset.data_ptr(), _stream())
     return scale, offset
 
 
@@ -57,26 +86,30 @@ def minmax_new(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """Fresh running statistics (min = +inf, max = -inf)."""
     mn = torch.empty(n, dtype=torch.float32, device=device)
     mx = torch.empty(n, dtype=torch.float32, device=device)
-    _lib.call("mq_minmax_init", mn.data_ptr(), mx.data_ptr(), n, _stream())
+    with _on(mn, mx):
+        _lib.call("mq_minmax_init", mn.data_ptr(), mx.data_ptr(), n, _stream())
     return mn, mx
 
 
 def minmax_tensor_(x: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
     """Running per-tensor update: mn[0] = min(mn[0], x.min()), mx[0] = max(mx[0], x.max())."""
     x = _dev(x, "x").contiguous()
-    _lib.call("mq_minmax_tensor", x.data_ptr(), _fdt(x), x.numel(), mn.data_ptr(), mx.data_ptr(), _stream())
+    with _on(x, mn, mx):
+        _lib.call("mq_minmax_tensor", x.data_ptr(), _fdt(x), x.numel(), mn.data_ptr(), mx.data_ptr(), _stream())
 
 
 def minmax_rows_(x2d: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
     x2d = _dev(x2d, "x").contiguous()
     rows, cols = x2d.shape
-    _lib.call("mq_minmax_rows", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
+    with _on(x2d, mn, mx):
+        _lib.call("mq_minmax_rows", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
 
 
 def minmax_cols_(x2d: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
     x2d = _dev(x2d, "x").contiguous()
     rows, cols = x2d.shape
-    _lib.call("mq_minmax_cols", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
+    with _on(x2d, mn, mx):
+        _lib.call("mq_minmax_cols", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
 
 
 def minmax_tensor(x: torch.Tensor):
@@ -84,8 +117,9 @@ def minmax_tensor(x: torch.Tensor):
     x = _dev(x, "x").contiguous()
     buf = torch.empty(2 + 1024, dtype=torch.float32, device=x.device)     # [min | max | scratch]
     mn, mx, scratch = buf[0:1], buf[1:2], buf[2:]
-    _lib.call("mq_minmax_tensor_fresh", x.data_ptr(), _fdt(x), x.numel(), mn.data_ptr(), mx.data_ptr(), scratch.data_ptr(),
-              scratch.numel(), _stream())
+    with _on(x):
+        _lib.call("mq_minmax_tensor_fresh", x.data_ptr(), _fdt(x), x.numel(), mn.data_ptr(), mx.data_ptr(), scratch.data_ptr(),
+                  scratch.numel(), _stream())
     return mn, mx
 
 
@@ -118,8 +152,9 @@ def fake_quant(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin:
     s, o = _f32(scale, "scale"), _f32(offset, "offset")
     rows, cols = _rows_cols(x, s.numel())
     y = torch.empty_like(x) if out is None else out
-    _lib.call("mq_fake_quant", x.data_ptr(), y.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(),
-              s.numel(), float(qmin), float(qmax), _stream())
+    with _on(x, s, o, y):
+        _lib.call("mq_fake_quant", x.data_ptr(), y.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(),
+                  s.numel(), float(qmin), float(qmax), _stream())
     return y
 
 
@@ -132,8 +167,9 @@ def fake_quant_backward(x: torch.Tensor, grad_y: torch.Tensor, scale: torch.Tens
     rows, cols = _rows_cols(x, s.numel())
     gx = torch.empty_like(x)
     gs, go = torch.zeros_like(s), torch.zeros_like(o)
-    _lib.call("mq_fake_quant_backward", x.data_ptr(), g.data_ptr(), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(),
-              float(qmin), float(qmax), gx.data_ptr(), gs.data_ptr(), go.data_ptr(), _stream())
+    with _on(x, g, s, o):
+        _lib.call("mq_fake_quant_backward", x.data_ptr(), g.data_ptr(), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(),
+                  float(qmin), float(qmax), gx.data_ptr(), gs.data_ptr(), go.data_ptr(), _stream())
     return gx, gs, go
 
 
@@ -148,8 +184,9 @@ def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: f
     cols = x.numel() // max(rows, 1)
     q = torch.empty(x.shape, dtype=_QDT[q_dtype], device=x.device)
     rs = torch.empty(rows, dtype=torch.int32, device=x.device) if want_row_sum else None
-    _lib.call("mq_quantize", x.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(), float(qmin),
-              float(qmax), int(shift), q.data_ptr(), q_dtype, rs.data_ptr() if rs is not None else None, _stream())
+    with _on(x, s, o):
+        _lib.call("mq_quantize", x.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(), float(qmin),
+                  float(qmax), int(shift), q.data_ptr(), q_dtype, rs.data_ptr() if rs is not None else None, _stream())
     return (q, rs) if want_row_sum else q
 
 
@@ -162,9 +199,10 @@ def linear_epilogue_prepare(a_scale, a_offset, a_shift: int, w_scale, w_offset, 
     alpha = torch.empty(N, dtype=torch.float32, device=dev)
     w_zp = torch.empty(N, dtype=torch.int32, device=dev)
     col_term = torch.empty(N, dtype=torch.int32, device=dev)
-    _lib.call("mq_linear_epilogue_prepare", sa.data_ptr(), oa.data_ptr(), int(a_shift), sw.data_ptr(), ow.data_ptr(),
-              sw.numel(), int(w_shift), w_colsum.data_ptr(), N, int(K), alpha.data_ptr(), w_zp.data_ptr(),
-              col_term.data_ptr(), _stream())
+    with _on(w_colsum, sa, oa, sw, ow):
+        _lib.call("mq_linear_epilogue_prepare", sa.data_ptr(), oa.data_ptr(), int(a_shift), sw.data_ptr(), ow.data_ptr(),
+                  sw.numel(), int(w_shift), w_colsum.data_ptr(), N, int(K), alpha.data_ptr(), w_zp.data_ptr(),
+                  col_term.data_ptr(), _stream())
     return alpha, w_zp, col_term
 
 
@@ -191,11 +229,12 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
     fn = "mq_w8a8_linear_tiled" if a_tiled_rows is not None else ("mq_w4a8_linear" if w4 else "mq_w8a8_linear")
-    _lib.call(fn, a_q.data_ptr(), w_q.data_ptr(), M, N, K,
-              a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(),
-              col_term.data_ptr(), b.data_ptr() if b is not None else None,
-              os_.data_ptr() if os_ is not None else None, oo_.data_ptr() if oo_ is not None else None,
-              float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype, _stream())
+    with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, os_, oo_, out):
+        _lib.call(fn, a_q.data_ptr(), w_q.data_ptr(), M, N, K,
+                  a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(),
+                  col_term.data_ptr(), b.data_ptr() if b is not None else None,
+                  os_.data_ptr() if os_ is not None else None, oo_.data_ptr() if oo_ is not None else None,
+                  float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype, _stream())
     return out
 
 
@@ -212,8 +251,9 @@ def quantize_tiled(x2d: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor,
     q = torch.empty(((M + 15) // 16 * 16, K), dtype=torch.int8, device=x2d.device)
     rs = torch.empty(M, dtype=torch.int32, device=x2d.device) if want_row_sum else None
     s, o = _f32(scale, "scale"), _f32(offset, "offset")
-    _lib.call("mq_quantize_tiled", x2d.data_ptr(), _fdt(x2d), M, K, s.data_ptr(), o.data_ptr(), float(qmin), float(qmax),
-              int(shift), q.data_ptr(), rs.data_ptr() if rs is not None else None, _stream())
+    with _on(x2d, s, o):
+        _lib.call("mq_quantize_tiled", x2d.data_ptr(), _fdt(x2d), M, K, s.data_ptr(), o.data_ptr(), float(qmin), float(qmax),
+                  int(shift), q.data_ptr(), rs.data_ptr() if rs is not None else None, _stream())
     return (q, rs) if want_row_sum else q
 
 
@@ -236,11 +276,12 @@ def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qma
     b = _f32(bias, "bias") if bias is not None else None
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
-    _lib.call("mq_w4a8_linear_f32in" if w4 else "mq_w8a8_linear_f32in", x2d.data_ptr(), sa.data_ptr(), oa.data_ptr(), float(a_qmin), float(a_qmax), int(a_shift),
-              w_q.data_ptr(), M, N, K, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
-              b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
-              oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype,
-              _stream())
+    with _on(x2d, sa, oa, w_q, alpha, w_zp, col_term, b, os_, oo_, out):
+        _lib.call("mq_w4a8_linear_f32in" if w4 else "mq_w8a8_linear_f32in", x2d.data_ptr(), sa.data_ptr(), oa.data_ptr(), float(a_qmin), float(a_qmax), int(a_shift),
+                  w_q.data_ptr(), M, N, K, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
+                  b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
+                  oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), out.data_ptr(), out_dtype,
+                  _stream())
     return out
 
 
@@ -269,12 +310,13 @@ def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_gr
         rs = torch.empty(rows, dtype=torch.int32, device=x.device)
         if emit_tiled:
             qt = torch.empty(((rows + 15) // 16 * 16, cols), dtype=torch.int8, device=x.device)
-    _lib.call("mq_layernorm_quant" if layernorm else "mq_rmsnorm_quant", x.data_ptr(), rows, cols, w.data_ptr(),
-              b.data_ptr() if b is not None else None, float(eps),
-              si.data_ptr() if si is not None else None, oi.data_ptr() if oi is not None else None, iqmin, iqmax,
-              so.data_ptr() if so is not None else None, oo.data_ptr() if oo is not None else None, oqmin, oqmax,
-              y.data_ptr(), q.data_ptr() if q is not None else None, qt.data_ptr() if qt is not None else None, shift,
-              rs.data_ptr() if rs is not None else None, _stream())
+    with _on(x, w, b, si, oi, so, oo):
+        _lib.call("mq_layernorm_quant" if layernorm else "mq_rmsnorm_quant", x.data_ptr(), rows, cols, w.data_ptr(),
+                  b.data_ptr() if b is not None else None, float(eps),
+                  si.data_ptr() if si is not None else None, oi.data_ptr() if oi is not None else None, iqmin, iqmax,
+                  so.data_ptr() if so is not None else None, oo.data_ptr() if oo is not None else None, oqmin, oqmax,
+                  y.data_ptr(), q.data_ptr() if q is not None else None, qt.data_ptr() if qt is not None else None, shift,
+                  rs.data_ptr() if rs is not None else None, _stream())
     return (y, q, rs, shift, qt) if emit_int8 else y
 
 
@@ -288,7 +330,8 @@ def act_quant(x: torch.Tensor, act: str, in_grid=None, mid_grid=None, out_grid=N
             ptrs += [None, None, 0.0, 0.0]
         else:
             ptrs += [_f32(g[0], "scale").data_ptr(), _f32(g[1], "offset").data_ptr(), float(g[2]), float(g[3])]
-    _lib.call("mq_act_quant", x.data_ptr(), x.numel(), {"silu": 0, "gelu": 1}[act], *ptrs, y.data_ptr(), _stream())
+    with _on(x):
+        _lib.call("mq_act_quant", x.data_ptr(), x.numel(), {"silu": 0, "gelu": 1}[act], *ptrs, y.data_ptr(), _stream())
     return y
 
 
@@ -297,5 +340,6 @@ def pack_w4(nibbles: torch.Tensor) -> torch.Tensor:
     nibbles = _dev(nibbles, "nibbles").contiguous()
     N, K = nibbles.shape
     packed = torch.empty((N, K // 2), dtype=torch.uint8, device=nibbles.device)
-    _lib.call("mq_pack_w4", nibbles.data_ptr(), N, K, packed.data_ptr(), _stream())
+    with _on(nibbles):
+        _lib.call("mq_pack_w4", nibbles.data_ptr(), N, K, packed.data_ptr(), _stream())
     return packed

@@ -20,6 +20,7 @@ operation order.
 from __future__ import annotations
 
 import math
+import threading
 import weakref
 from copy import deepcopy
 from dataclasses import dataclass
@@ -60,6 +61,28 @@ def _as_f32(v, device=None) -> torch.Tensor:
 
 def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _ver(t: torch.Tensor) -> int:
+    """Version counter for cache keys.  Inference tensors (created under torch.inference_mode()) have none -- reading
+    ``_version`` raises -- and cannot be modified outside inference mode, so they key as version 0."""
+    return 0 if t.is_inference() else t._version
+
+
+def _tag_grid(y: torch.Tensor, q: "Quantizer") -> torch.Tensor:
+    """Remember on the tensor OBJECT which quantizer's grid its values sit on.  A QLinear without an input quantizer
+    (q/k/v/o/w1/w3, qmodule.py:848-850) reads the tag to find its producer's LIVE grid -- trained scales, a changed
+    bitwidth or a 16-bit producer are seen as they are, never assumed from a calibration file."""
+    try:
+        y._mq_grid = weakref.ref(q)
+    except (AttributeError, TypeError):
+        pass
+    return y
+
+
+def _producer_grid(x: torch.Tensor):
+    ref = getattr(x, "_mq_grid", None)
+    return ref() if ref is not None else None
 
 
 def compute_min_max_from_tensor(x: torch.Tensor, is_per_channel: bool = False, group_size: int = -1):
@@ -161,6 +184,7 @@ class Quantizer(nn.Module):
         self.qcfg = deepcopy(qcfg)
         self.lwc = False
         self.enable = True
+        self._gen = 0                 # bumped whenever (scale, offset) are re-created: cache keys never rely on addresses
 
     # -- configuration ---------------------------------------------------------------------------
     def update_qcfg(self, qcfg):
@@ -168,6 +192,7 @@ class Quantizer(nn.Module):
             assert isinstance(qcfg, dict)
             qcfg = QuantConfig.from_dict(qcfg)
         self.qcfg = deepcopy(qcfg)
+        self._gen = getattr(self, "_gen", 0) + 1
         for name in ("scale", "offset"):          # a new config invalidates the cached grid
             if hasattr(self, name):
                 delattr(self, name)
@@ -228,6 +253,7 @@ class Quantizer(nn.Module):
         scale, offset, _, _, q_min, q_max = compute_scale_offset_from_min_max(
             min_val, max_val, self.qcfg.bitwidth, self.qcfg.is_symmetric)
         self.qmin, self.qmax = q_min, q_max
+        self._gen = getattr(self, "_gen", 0) + 1
         scale, offset = scale.to(device), offset.to(device)
         for name in ("scale", "offset"):
             if hasattr(self, name):
@@ -246,7 +272,7 @@ class Quantizer(nn.Module):
         # (grid_token).  Dropped as soon as scale / offset are touched again.
         if isinstance(min_val, (int, float)) and isinstance(max_val, (int, float)):
             self._host_range = (float(min_val), float(max_val), int(self.qcfg.bitwidth), bool(self.qcfg.is_symmetric),
-                                self.scale._version, self.offset._version)
+                                self._gen, _ver(self.scale), _ver(self.offset))
         else:
             self._host_range = None
 
@@ -254,10 +280,9 @@ class Quantizer(nn.Module):
         """Hashable identity of the current per-tensor grid: value based when the range came from host numbers and
         the tensors were not modified since, storage based otherwise."""
         hr = getattr(self, "_host_range", None)
-        if hr is not None and self._has_grid() and hr[4:] == (self.scale._version, self.offset._version):
+        if hr is not None and self._has_grid() and hr[4:] == (self._gen, _ver(self.scale), _ver(self.offset)):
             return ("host",) + hr[:4]
-        return ("dev", self.scale.data_ptr(), self.scale._version, self.offset.data_ptr(), self.offset._version,
-                self.qmin, self.qmax)
+        return ("dev", id(self), self._gen, _ver(self.scale), _ver(self.offset), self.qmin, self.qmax)
 
     def set_scale_offset_from_tensor(self, x, cache_mode=None):
         mn, mx = compute_min_max_from_tensor(x, self.qcfg.is_per_channel, self.qcfg.group_size)
@@ -288,7 +313,7 @@ class Quantizer(nn.Module):
             y = _FakeQuantFn.apply(x, self.scale, self.offset, self.qmin, self.qmax)
         else:
             y = ops.fake_quant(x, self.scale.detach(), self.offset.detach(), self.qmin, self.qmax)
-        return y.reshape(input_.shape) if grouped else y
+        return y.reshape(input_.shape) if grouped else _tag_grid(y, self)
 
     def quantize_to_int(self, x, q_dtype=MQ_I8, want_row_sum=False, rows=None):
         """Integer indices of x on this quantizer's grid (static per-tensor or per-row grids).
@@ -368,7 +393,8 @@ class _SharedActivation:
 
     @staticmethod
     def _base_key(x):
-        return (x._version, x.data_ptr(), tuple(x.shape), x.dtype)
+        stream = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0      # images are ordered on ONE stream
+        return (_ver(x), x.data_ptr(), tuple(x.shape), x.dtype, stream)
 
     def _same(self, x):
         return self._ref is not None and self._ref() is x and self._base == self._base_key(x)
@@ -387,7 +413,22 @@ class _SharedActivation:
         self._vals[(grid.grid_token(), tag)] = val
 
 
-_shared_activation = _SharedActivation()
+class _PerThread(threading.local):
+    def __init__(self):
+        self.memo = _SharedActivation()
+
+
+class _SharedActivationProxy:
+    """One memo per Python thread (and, through the key, per HIP stream): two threads driving two models never see each
+    other's activation images."""
+
+    _tls = _PerThread()
+
+    def __getattr__(self, name):
+        return getattr(self._tls.memo, name)
+
+
+_shared_activation = _SharedActivationProxy()
 
 
 class QLinear(nn.Linear, _QuantizedOp):
@@ -412,10 +453,16 @@ class QLinear(nn.Linear, _QuantizedOp):
         q.set_scale_offset_from_minmax(min_val, max_val, None, self.weight.device)
         self._input_grid = q
 
-    def _activation_grid(self) -> Optional[Quantizer]:
+    def _activation_grid(self, x=None) -> Optional[Quantizer]:
+        """The grid the int8 image of x is formed on: the own input quantizer; else the LIVE output quantizer of the module
+        that produced x (tag left on the tensor object); else the grid declared by wire_integer_inputs (for inputs whose tag
+        is lost on the way, e.g. o_proj behind a transpose / reshape).  None -> simulated path (e.g. a 16-bit producer)."""
         iq = self.input_quantizer
         if iq is not None and not iq.bypassed():
             return iq if _static_per_tensor(iq, 8) else None
+        prod = _producer_grid(x) if x is not None else None
+        if prod is not None:
+            return prod if _static_per_tensor(prod, 8) else None
         return self._input_grid
 
     def _int8_ready(self, x, weight) -> bool:
@@ -426,7 +473,13 @@ class QLinear(nn.Linear, _QuantizedOp):
             return False
         if wq.qcfg.is_per_channel and wq.qcfg.group_size != -1:
             return False
-        if weight.shape[1] % 128 or weight.shape[0] % 4 or self._activation_grid() is None:
+        K, N = weight.shape[1], weight.shape[0]
+        M = x.numel() // max(K, 1)
+        if K % 128 or N % 4 or K > 65536 or M * K >= 2 ** 31 or N * K >= 2 ** 31 or M * N >= 2 ** 40:
+            return False                    # the C ABI's shape limits (mq_w8a8_linear): outside them, the simulated path
+        if (x.data_ptr() % 16 and x.is_contiguous()) or (self.bias is not None and self.bias.data_ptr() % 16):
+            return False                    # 16-byte alignment of the operands the kernels read directly
+        if self._activation_grid(x) is None:
             return False
         oq = self.output_quantizer
         if oq is not None and not oq.bypassed() and not _static_per_tensor(oq, 16):
@@ -439,10 +492,10 @@ class QLinear(nn.Linear, _QuantizedOp):
         wq = self.weight_quantizer
         if not wq._has_grid():
             wq._prepare(weight, "parameter")           # first forward: range from the weight itself
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), wq.scale.data_ptr(), wq.scale._version,
-               wq.offset._version, wq.qcfg.bitwidth, wq.qcfg.is_symmetric, wq.qcfg.is_per_channel)
+        key = (weight.data_ptr(), _ver(weight), tuple(weight.shape), wq.grid_token(), wq.qcfg.bitwidth, wq.qcfg.is_symmetric,
+               wq.qcfg.is_per_channel)
         plan = self._plan
-        if plan is not None and plan["key"] == key:
+        if plan is not None and plan["key"] == key and plan["wref"]() is weight:
             return plan
         w4 = wq.qcfg.bitwidth == 4
         w32 = weight.detach().to(torch.float32)
@@ -452,12 +505,12 @@ class QLinear(nn.Linear, _QuantizedOp):
             wint, shift = ops.pack_w4(q), wq.qmin
         else:
             wint, colsum, shift = wq.quantize_to_int(w32, MQ_I8, want_row_sum=True, rows=weight.shape[0])
-        plan = {"key": key, "w": wint, "colsum": colsum, "shift": shift, "w4": w4, "epi_key": None}
+        plan = {"key": key, "wref": weakref.ref(weight), "w": wint, "colsum": colsum, "shift": shift, "w4": w4, "epi_key": None}
         self._plan = plan
         return plan
 
     def _forward_int8(self, x, weight, bias):
-        wq, oq, grid = self.weight_quantizer, self.output_quantizer, self._activation_grid()
+        wq, oq, grid = self.weight_quantizer, self.output_quantizer, self._activation_grid(x)
         plan = self._weight_plan(weight)
         K, N = weight.shape[1], weight.shape[0]
         if grid.scale.device != x.device:
@@ -484,7 +537,7 @@ class QLinear(nn.Linear, _QuantizedOp):
                 hit = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
                 _shared_activation.put(x, grid, a_shift, hit)
             a_q, a_rs, a_shift = hit
-        epi_key = (grid.scale.data_ptr(), grid.scale._version, grid.offset._version, a_shift)
+        epi_key = (grid.grid_token(), a_shift)
         if plan["epi_key"] != epi_key:
             plan["alpha"], plan["w_zp"], plan["col_term"] = ops.linear_epilogue_prepare(
                 grid.scale.detach(), grid.offset.detach(), a_shift, wq.scale.detach(), wq.offset.detach(),
@@ -499,13 +552,15 @@ class QLinear(nn.Linear, _QuantizedOp):
                 plan["w_zp"], plan["col_term"], bias, out_scale=oq.scale.detach() if fused else None,
                 out_offset=oq.offset.detach() if fused else None, out_qmin=oq.qmin if fused else 0.0,
                 out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, w4=plan["w4"])
-            return out.reshape(*x.shape[:-1], N)
+            out = out.reshape(*x.shape[:-1], N)
+            return _tag_grid(out, oq) if fused else out
         out = ops.int8_linear(
             a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
             out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
             out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0,
             out_dtype=MQ_F16 if x.dtype == torch.float16 else MQ_F32, w4=plan["w4"], a_tiled_rows=tiled_rows)
-        return out.reshape(*x.shape[:-1], N)
+        out = out.reshape(*x.shape[:-1], N)
+        return _tag_grid(out, oq) if fused else out
 
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, input_):
@@ -574,7 +629,7 @@ def _fused_norm(self, input_, weight, bias, layernorm):
         return None
     # the fake-quantised [dim] weight vector is cached until the weight or its grid changes (the first call
     # also fixes the weight range from the weight itself, qmodule.py:262-277)
-    key = (weight.data_ptr(), weight._version, None if wq is None or not wq._has_grid() else wq.grid_token(),
+    key = (weight.data_ptr(), _ver(weight), None if wq is None or not wq._has_grid() else wq.grid_token(),
            None if wq is None else (wq.enable, wq.lwc, wq.qcfg.bitwidth, wq.qcfg.is_dynamic))
     cached = getattr(self, "_wfq", None)
     if cached is not None and cached[0] == key and key[2] is not None:
@@ -593,8 +648,9 @@ def _fused_norm(self, input_, weight, bias, layernorm):
     tiled = emit and (input_.shape[-1] % 128 == 0) and (rows >= 1536 if tiled is None else bool(tiled))
     res = ops.rmsnorm_quant(input_, wfq, bias, self.eps, gi, go, emit_int8=emit, layernorm=layernorm, emit_tiled=tiled)
     if not emit:
-        return res
+        return _tag_grid(res, self.output_quantizer) if go is not None else res
     y, q, rs, shift, qt = res
+    _tag_grid(y, self.output_quantizer)
     _shared_activation.put(y, self.output_quantizer, shift, (q, rs, shift))
     if qt is not None:
         _shared_activation.put(y, self.output_quantizer, ("tiled", shift), (qt, rs, shift))
@@ -713,7 +769,8 @@ def _fused_activation(module, x, act, quantizers):
         if g is False or (g is not None and (g[0].device != x.device or _needs_grad(q.scale, q.offset))):
             return None
         grids.append(g)
-    return ops.act_quant(x, act, *grids)
+    y = ops.act_quant(x, act, *grids)
+    return _tag_grid(y, quantizers[-1]) if grids[-1] is not None else y
 
 
 class QSiLU(nn.Module, _QuantizedOp):
@@ -877,10 +934,14 @@ def set_scale_and_offset(model, act_dict, use_scale_offset_as="buffer"):
 
 
 def wire_integer_inputs(model, act_bitwidth=8, act_is_symmetric=False):
-    """Graph pass the integer path needs and the reference never did (hard parts):
-    every QLinear without an input quantizer is told the grid its producer quantized to, which is the
-    calibrated range of its own input (``act_dict[name]['input']``, kept by set_scale_offset) on the
-    activation bitwidth.  Returns the number of linears wired."""
+    """Graph pass the integer path needs and the reference never did (hard parts): every QLinear
+    without an input quantizer is told the grid its input sits on.  At run time the LIVE grid of the producing quantizer
+    (the tag Quantizer.forward / the fused kernels leave on their output tensor) always wins -- trained scales, changed
+    configs and 16-bit producers are seen as they are.  This pass only supplies the DECLARED fallback for inputs whose tag
+    is lost between producer and consumer (o_proj: pv_bmm -> transpose -> reshape): the calibrated range of the linear's
+    own input (``act_dict[name]['input']``, kept by set_scale_offset) on the activation bitwidth.  A declared grid is a
+    promise by the caller; a model whose producers were re-trained must be re-wired (or left to the tags / the simulated
+    path).  Returns the number of linears wired."""
     n = 0
     for _, m in model.named_modules():
         if isinstance(m, QLinear) and m.input_quantizer is None and "input" in getattr(m, "_act_range", {}):

@@ -234,18 +234,24 @@ def qlinear_sim(x, weight, bias, w_q: QuantizerOracle | None, in_q: QuantizerOra
     return out
 
 
-def qlinear_int_exact(qa, za, sa, qw, zw, sw, bias=None):
+def qlinear_int_exact(qa, za, sa, qw, zw, sw, bias=None, blas=False):
     """Integer-GEMM equivalence of QLinear (SURVEY 8a' item 9), exact contraction.
 
     ``out[m,n] = sa*sw[n] * sum_k (qa[m,k]-za)(qw[n,k]-zw[n]) + bias[n]``.  The contraction is
     done in int64 (exact); the scaling mirrors the HIP epilogue: one int->fp32 conversion, one
     multiply by fp32(sa*sw[n]), one add.  Returns (acc_int64, out_fp32).
+    blas=True: the same contraction as a float64 BLAS product -- still exact (every partial sum is an integer below
+    K * 511 * 511 < 2^53 for K <= 65536), and fast enough to check EVERY output of the full-size BASELINE shapes.
     """
     qa = np.asarray(qa, dtype=np.int64)
     qw = np.asarray(qw, dtype=np.int64)
     za_i = np.asarray(za, dtype=np.int64)
     zw_i = np.asarray(zw, dtype=np.int64).reshape(-1, 1) if np.ndim(zw) else np.int64(zw)
-    acc = (qa - za_i) @ (qw - zw_i).T
+    if blas:
+        assert qa.shape[1] * 511 * 511 < 2 ** 53
+        acc = np.rint((qa - za_i).astype(np.float64) @ (qw - zw_i).astype(np.float64).T).astype(np.int64)
+    else:
+        acc = (qa - za_i) @ (qw - zw_i).T
     alpha = (F32(sa) * np.asarray(sw, dtype=F32).reshape(-1)).astype(F32)
     out = (acc.astype(F32) * alpha).astype(F32)
     if bias is not None:

@@ -1,5 +1,6 @@
 """The C-ABI library builds for gfx950 (cross-compiled, no GPU needed), loads, and exports exactly the
-entry points include/mobilequant_amd.h declares.  No compute calls here."""
+entry points include/*.h declare (mobilequant_amd.h: the drop-in boundary; mobilequant_amd_tuning.h: profiling knobs).
+No compute calls here."""
 import ctypes
 import os
 import re
@@ -8,13 +9,21 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "mobilequant_amd.h")
+HEADERS = sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
 
 
-def declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", src)))
+def declared_functions(headers=None):
+    found = set()
+    for h in headers or HEADERS:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        found |= set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", src))
+    return sorted(found)
+
+
+def test_tuning_knobs_are_not_part_of_the_boundary_header():
+    boundary = declared_functions([os.path.join(ROOT, "include", "mobilequant_amd.h")])
+    assert not any(n.startswith("mq_gemm_set_") or n == "mq_gemm_variant_name" for n in boundary)
+    assert "mq_w8a8_linear" in boundary and "mq_minmax_tensor" in boundary
 
 
 @pytest.fixture(scope="module")
@@ -70,6 +79,20 @@ def test_generated_isa_is_current(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     inc = os.path.join(root, "mobilequant_amd", "csrc", "mq_gemm_pp_asm.inc")
     spec = importlib.util.spec_from_file_location("gen_pp_asm", os.path.join(root, "tools", "gen_pp_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = str(tmp_path / "fresh.inc")
+    mod.main(fresh)
+    assert open(fresh).read() == open(inc).read()
+
+
+def test_generated_free_running_kernel_is_current(tmp_path):
+    """csrc/mq_gemm_fr_asm.inc (tools/gen_fr_asm.py: the whole-kernel ISA of GEMM variant 11) is committed: regenerating must
+    reproduce it, and the generator's VMEM-queue simulation must hold (it asserts the loop body is a fixed point)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "mobilequant_amd", "csrc", "mq_gemm_fr_asm.inc")
+    spec = importlib.util.spec_from_file_location("gen_fr_asm", os.path.join(root, "tools", "gen_fr_asm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     fresh = str(tmp_path / "fresh.inc")

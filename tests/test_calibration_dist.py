@@ -50,8 +50,15 @@ def _worker(rank, world, port, per_channel, empty_rank, q):
             calls["n"] += 1
             return real(*a, **k)
         dist.all_reduce = counting
+        real_gather = dist.all_gather_object
+
+        def counting_gather(*a, **k):          # any second (object) collective would show up in the count
+            calls["n"] += 1
+            return real_gather(*a, **k)
+        dist.all_gather_object = counting_gather
         mine = O.ActRangeOracle(per_channel)
-        for s in samples[rank::world]:
+        # get_act_range's sharding: round-robin, and a rank that owns no sample re-runs a duplicate (min / max are idempotent)
+        for s in (samples[rank::world] or [samples[rank % len(samples)]]):
             for name, field, t in s:
                 mine.update(name, field, t)
         for (name, field), i in col.slots.items():          # inject this rank's running statistics
@@ -63,7 +70,7 @@ def _worker(rank, world, port, per_channel, empty_rank, q):
             else:
                 col._mn[i], col._mx[i] = float(v[0]), float(v[1])
         col.all_reduce()
-        dist.all_reduce = real
+        dist.all_reduce, dist.all_gather_object = real, real_gather
         got = col.act_dict()
         full = O.ActRangeOracle(per_channel)
         for s in samples:

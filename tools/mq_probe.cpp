@@ -10,10 +10,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <utility>
 #include <random>
 #include <vector>
 
 #include "mobilequant_amd.h"
+#include "mobilequant_amd_tuning.h"
 extern "C" int mq_gemm_set_debug_buffer_(void*) __attribute__((weak));   // ablation builds of the library only
 
 #define HIPCHK(x)                                                                   \
@@ -64,8 +66,12 @@ static Problem make_problem(int M, int N, int K, unsigned seed, bool per_row) {
   std::uniform_int_distribution<int> d8(-128, 127);
   p.a.resize((size_t)M * K);
   p.w.resize((size_t)N * K);
-  for (auto& v : p.a) v = (int8_t)d8(g);
-  for (auto& v : p.w) v = (int8_t)d8(g);
+  // MQ_PROBE_FILL = zero | small: DVFS what-if (the chip clocks to its power budget, and operand toggling is power); results are
+  // still checked against the host reference
+  const char* fill = getenv("MQ_PROBE_FILL");
+  std::uniform_int_distribution<int> d4(-8, 7);
+  for (auto& v : p.a) v = (int8_t)(!fill ? d8(g) : !strcmp(fill, "zero") ? 0 : d4(g));
+  for (auto& v : p.w) v = (int8_t)(!fill ? d8(g) : !strcmp(fill, "zero") ? 0 : d4(g));
   p.rs.resize(M);
   for (int m = 0; m < M; ++m) {
     int s = 0;
@@ -106,7 +112,7 @@ static void make_tiled(Problem& p) {
 }
 
 static int run_linear(Problem& p, int variant, const float* os, const float* oo, float qmax, void* dout, int out_dtype) {
-  if (variant == 9) {       // generated-ISA loop: fragment-blocked activations through the tiled entry point
+  if (variant == 9 || variant == 11) {       // generated-ISA kernels: fragment-blocked activations through the tiled entry point
     make_tiled(p);
     return mq_w8a8_linear_tiled(p.dat, p.dw, p.M, p.N, p.K, p.drs, p.dalpha, p.dzw, p.dct, p.dbias, os, oo, 0.f, qmax, dout,
                                 out_dtype, nullptr);
@@ -141,7 +147,7 @@ static int check(Problem& p, int variant, int out_dtype, bool outq) {
   HIPCHK(hipMalloc(&dout, (size_t)p.M * p.N * esz));
   HIPCHK(hipMemset(dout, 0xCD, (size_t)p.M * p.N * esz));
   mq_gemm_set_variant(variant);
-  if (variant == 9 && !mq_gemm_tiled_supported(p.M, p.N, p.K)) { hipFree(dout); return 0; }   // shape not served
+  if ((variant == 9 || variant == 11) && !mq_gemm_tiled_supported(p.M, p.N, p.K)) { hipFree(dout); return 0; }   // shape not served
   MQCHK(run_linear(p, variant, outq ? p.dos : nullptr, outq ? p.doo : nullptr, out_dtype == MQ_U16 ? 65535.f : 255.f, dout, out_dtype));
   HIPCHK(hipDeviceSynchronize());
   std::vector<uint8_t> h((size_t)p.M * p.N * esz);
@@ -186,7 +192,7 @@ static float time_variant(Problem& p, int variant, int out_dtype, bool outq, int
   mq_gemm_set_variant(variant);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  if (variant == 9 && !mq_gemm_tiled_supported(p.M, p.N, p.K)) return 0.f;
+  if ((variant == 9 || variant == 11) && !mq_gemm_tiled_supported(p.M, p.N, p.K)) return 0.f;
   auto run = [&]() { MQCHK(run_linear(p, variant, outq ? p.dos : nullptr, outq ? p.doo : nullptr, 255.f, dout, out_dtype)); };
   for (int i = 0; i < 5; ++i) run();
   HIPCHK(hipDeviceSynchronize());
@@ -222,15 +228,20 @@ int main(int argc, char** argv) {
     const int M = argc > 7 ? atoi(argv[5]) : 2048, N = argc > 7 ? atoi(argv[6]) : 5632, K = argc > 7 ? atoi(argv[7]) : 2048;
     const int od = argc > 8 ? atoi(argv[8]) : MQ_U8;
     Problem p = make_problem(M, N, K, 99u, false);
+    const int nb0 = ((M + 255) / 256) * ((N + 175) / 176);
+    unsigned long long* d0 = nullptr;
+    if ((dbg & 16) && mq_gemm_set_debug_buffer_) {      // stamp builds write unconditionally: the buffer must exist before the first launch
+      d0 = dmalloc<unsigned long long>((size_t)nb0 * 8 * 16);
+      HIPCHK(hipMemset(d0, 0, (size_t)nb0 * 8 * 16 * 8));
+      mq_gemm_set_debug_buffer_(d0);
+    }
     if ((dbg & ~16) == 0) printf("prof check %s: bad=%d\n", mq_gemm_variant_name(v), check(p, v, od, od != MQ_F32 && od != MQ_F16));
     mq_gemm_set_debug(dbg);
     float t = time_variant(p, v, od, od != MQ_F32 && od != MQ_F16, n);
     printf("prof %s dbg=%d %dx%dx%d od=%d: %.2f us\n", mq_gemm_variant_name(v), dbg, M, N, K, od, t * 1e3);
     if ((dbg & 16) && mq_gemm_set_debug_buffer_) {   // s_memtime stamps: [block][wave][t0, loop start, loop end, end]
       const int nb = ((M + 255) / 256) * ((N + 175) / 176), nw = 8;
-      unsigned long long* d = dmalloc<unsigned long long>((size_t)nb * nw * 16);
-      HIPCHK(hipMemset(d, 0, (size_t)nb * nw * 16 * 8));
-      mq_gemm_set_debug_buffer_(d);
+      unsigned long long* d = d0;
       time_variant(p, v, od, true, 3);
       std::vector<unsigned long long> h((size_t)nb * nw * 16);
       HIPCHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
@@ -243,6 +254,25 @@ int main(int argc, char** argv) {
       const double n2 = nb * nw;
       printf("stamps (cycles, mean over %d waves): prologue %.0f  loop %.0f (%.0f per K=128 stage)  epilogue %.0f  total %.0f; first start -> last end %llu\n",
              nb * nw, pro / n2, loop / n2, loop / n2 / (K / 128), epi / n2, tot / n2, gmax - gmin);
+      if (v == 11) {   // free-running kernel: d[4], d[5] = s_memrealtime (100 MHz, chip-wide) at wave start / end; distribution of the segments
+        std::vector<double> tot, pr, lp, ep;
+        unsigned long long r0 = ~0ull, r1 = 0; double ticks = 0, rts = 0;
+        for (int i = 0; i < nb * nw; ++i) {
+          const unsigned long long* q = &h[(size_t)i * 16];
+          tot.push_back((double)(q[3] - q[0])); pr.push_back((double)(q[1] - q[0])); lp.push_back((double)(q[2] - q[1])); ep.push_back((double)(q[3] - q[2]));
+          r0 = std::min(r0, q[4]); r1 = std::max(r1, q[5]); ticks += (double)(q[3] - q[0]); rts += (double)(q[5] - q[4]);
+        }
+        auto pct = [](std::vector<double> x, double p) { std::sort(x.begin(), x.end()); return x[(size_t)(p * (x.size() - 1))]; };
+        printf("realtime: waves alive from first start to last end %.2f us (one launch); shader clock = %.0f MHz (memtime ticks / realtime)\n",
+               (double)(r1 - r0) / 100.0, ticks / rts * 100.0);
+        for (auto& pr_ : {std::make_pair("total", &tot), std::make_pair("prologue", &pr), std::make_pair("loop", &lp), std::make_pair("epilogue", &ep)})
+          printf("  %-9s min %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f\n", pr_.first, pct(*pr_.second, 0), pct(*pr_.second, 0.5), pct(*pr_.second, 0.9),
+                 pct(*pr_.second, 0.99), pct(*pr_.second, 1.0));
+        // start skew: when does each workgroup start relative to the first one (realtime)
+        std::vector<double> st;
+        for (int b = 0; b < nb; ++b) st.push_back((double)(h[(size_t)b * nw * 16 + 4] - r0) / 100.0);
+        printf("  workgroup start after the first (us): p50 %.2f  p90 %.2f  max %.2f\n", pct(st, 0.5), pct(st, 0.9), pct(st, 1.0));
+      }
       // per-group breakdown for block 0
       for (int b : {0, 100}) for (int w = 0; w < nw; ++w) { const unsigned long long* q = &h[((size_t)b * nw + w) * 16]; printf("  blk%d wave%d: pro %llu loop %llu epi %llu | stage8: %llu %llu %llu %llu\n", b, w, q[1]-q[0], q[2]-q[1], q[3]-q[2], q[5]-q[4], q[6]-q[5], q[7]-q[6], q[8]-q[7]); }
       mq_gemm_set_debug_buffer_(nullptr);
