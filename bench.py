@@ -157,10 +157,10 @@ class Step:
         x = self.x[i % N_BATCHES]
         if self.tiled:
             _lib.call("mq_quantize_tiled", x.data_ptr(), MQ_F32, M, K, self.aq.scale.data_ptr(), self.aq.offset.data_ptr(),
-                      0.0, 255.0, 128, self.a8s[slot].data_ptr(), self.rss[slot].data_ptr(), torch.cuda.current_stream().cuda_stream)
+                      0.0, 255.0, 128, None, self.a8s[slot].data_ptr(), self.rss[slot].data_ptr(), torch.cuda.current_stream().cuda_stream)
             return
         _lib.call("mq_quantize", x.data_ptr(), MQ_F32, M, K, self.aq.scale.data_ptr(), self.aq.offset.data_ptr(), 1,
-                  0.0, 255.0, 128, self.a8s[slot].data_ptr(), MQ_I8, self.rss[slot].data_ptr(),
+                  0.0, 255.0, 128, None, self.a8s[slot].data_ptr(), MQ_I8, self.rss[slot].data_ptr(),
                   torch.cuda.current_stream().cuda_stream)
 
     def gemm(self, slot=0):
@@ -372,10 +372,12 @@ def bench_decode(dev, w4=False):
 
 def bench_layer(dev):
     """The quantized-linear path of ONE TinyLlama decoder layer at prefill (S = 2048) through the module API:
-    attention_norm -> q/k/v, o_proj, ffn_norm -> w1/w3, w2 (W8A8, 8-bit activations, 16-bit norm inputs; attention,
-    RoPE, SiLU*mul and residuals are not part of the hot path and are left out: every linear gets a ready input).
-    Reports the hipGraph time of the 2 norms + 7 linears with the fused kernels / integer chaining, and with
-    fused_mode = "off" + no chaining (composite norms, every linear quantising its own input)."""
+    input_layernorm -> q/k/v, o_proj, post_attention_layernorm -> [w1, w3 -> act_fn -> * -> w2] (W8A8 recipe of
+    ptq/mobilequant.py:175-201: 8-bit activations, 16-bit norm inputs, 16-bit o_proj / w2 outputs, per-channel w2).  Attention
+    itself (RoPE, the two bmm's, softmax) and the residual adds are left out: q/k/v outputs are produced, o_proj gets a ready
+    input.  Reports the hipGraph time with (a) the integer chain: fused norms -> int8 images -> GEMMs, the FFN as pair GEMM ->
+    gated-activation kernel -> w2 GEMM (fuse_gated_mlp); (b) the chain of modules on their integer paths without the FFN fusion;
+    (c) composite: fused_mode = "off", every linear quantising its own input."""
     import mobilequant_amd as mq
     from mobilequant_amd.quantization import qmodule as Q
     from mobilequant_amd.quantization.fp_ops import HFRMSNorm
@@ -383,8 +385,9 @@ def bench_layer(dev):
     S, H, F_, KV = 2048, 2048, 5632, 256
     torch.manual_seed(1337)
 
-    def lin(k, n, own_input_quantizer):
-        ql = mq.QLinear.from_float(torch.nn.Linear(k, n, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+    def lin(k, n, own_input_quantizer, out_bits=8, per_channel=False):
+        ql = mq.QLinear.from_float(torch.nn.Linear(k, n, bias=False).to(dev), a8, mq.QuantConfig(bitwidth=8, is_per_channel=per_channel),
+                                   mq.QuantConfig(bitwidth=out_bits)).requires_grad_(False)
         if not own_input_quantizer:
             ql.input_quantizer = None
         ql.set_scale_offset({"input": [-4.0, 4.0], "output": [-3.0, 3.0]}, "buffer")
@@ -395,39 +398,51 @@ def bench_layer(dev):
         n.set_scale_offset({"input": [-5.0, 5.0], "output": [-4.0, 4.0]}, "buffer")
         return n
 
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w1, self.w3, self.w2 = lin(H, F_, False), lin(H, F_, False), lin(F_, H, True, out_bits=16, per_channel=True)
+            self.act_fn = mq.QSiLU(None, a8, a8)
+            self.act_fn.set_scale_offset({"output": [-0.3, 3.0]}, "buffer")
+
+        def forward(self, x):
+            return self.w2(self.act_fn(self.w1(x)) * self.w3(x))
+
     class Layer(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.attention_norm, self.ffn_norm = norm(), norm()
+            self.input_layernorm, self.post_attention_layernorm = norm(), norm()
             self.q_proj, self.k_proj, self.v_proj = lin(H, H, False), lin(H, KV, False), lin(H, KV, False)
-            self.o_proj, self.w1, self.w3, self.w2 = lin(H, H, True), lin(H, F_, False), lin(H, F_, False), lin(F_, H, True)
+            self.o_proj = lin(H, H, True, out_bits=16)
+            self.mlp = MLP()
 
-        def forward(self, x, attn_out, ffn_mid):
-            h = self.attention_norm(x)
+        def forward(self, x, attn_out):
+            h = self.input_layernorm(x)
             q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
             o = self.o_proj(attn_out)
-            g = self.ffn_norm(x)
-            a, b = self.w1(g), self.w3(g)
-            d = self.w2(ffn_mid)
-            return q, k, v, o, a, b, d
+            return q, k, v, o, self.mlp(self.post_attention_layernorm(x))
     layer = Layer()
     mq.wire_integer_inputs(layer)
-    x, attn_out, ffn_mid = torch.randn(1, S, H, device=dev), torch.randn(1, S, H, device=dev), torch.randn(1, S, F_, device=dev)
+    mq.fuse_gated_mlp(layer)
+    x, attn_out = torch.randn(1, S, H, device=dev), torch.randn(1, S, H, device=dev)
     res = {}
-    for mode in ("fused", "composite"):
+    for mode in ("integer_chain", "module_chain", "composite"):
         for m in layer.modules():
             if hasattr(m, "fused_mode"):
-                m.fused_mode = "auto" if mode == "fused" else "off"
+                m.fused_mode = "off" if mode == "composite" else "auto"
+        layer.mlp.fused_mode = "auto" if mode == "integer_chain" else "off"
 
         def fwd():
             if mode == "composite":
                 Q._shared_activation.clear()
-            layer(x, attn_out, ffn_mid)
+            layer(x, attn_out)
         fwd()
         res[mode + "_us"] = round(event_time(fwd, 5) * 1e6, 1)
     ops_layer = 2.0 * S * (H * H * 2 + H * KV * 2 + H * F_ * 3)
-    res["tops_fused"] = round(ops_layer / (res["fused_us"] * 1e-6) / 1e12, 1)
-    res["scope"] = "2 QRMSNorm + 7 QLinear of one TinyLlama layer, S = 2048, W8A8, module API, hipGraph"
+    res["tops_integer_chain"] = round(ops_layer / (res["integer_chain_us"] * 1e-6) / 1e12, 1)
+    res["frac_of_int8_peak"] = round(res["tops_integer_chain"] / INT8_MFMA_PEAK_TOPS, 4)
+    res["scope"] = ("one TinyLlama layer minus the attention core, S = 2048, W8A8 recipe: 2 QRMSNorm + q/k/v/o + gated FFN (w1, w3, QSiLU, "
+                    "product, w2), module API, hipGraph")
     return res
 
 

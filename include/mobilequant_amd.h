@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 100 /* 0.1.0 */
+#define MQ_VERSION 200 /* 0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h */
 
 typedef void* mq_stream_t;
 
@@ -112,10 +112,15 @@ int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, in
 /* The integer index itself (qmodule.py:286-287) written as integers instead of being dequantised.
  * q_dtype MQ_I8: i8 storage (index - shift, see top);  MQ_U8 / MQ_I16 / MQ_U16 / MQ_I32: the plain
  * index.  row_sum (nullable, [rows] int32): sum over the row of the STORED values -- the
- * zero-point correction term of the integer GEMM (SURVEY 8a' item 9), produced in the same pass. */
+ * zero-point correction term of the integer GEMM (SURVEY 8a' item 9), produced in the same pass.
+ * chan_scale (nullable, [cols] fp32; needs float32 x and a per-tensor grid): SmoothQuant per-channel scale fused in front
+ * of the quantizer -- the index of x[m,k] / chan_scale[k] (IEEE divide, then the arithmetic above op for op).  This is the
+ * run-time form of the scales the reference folds into the weights (`ln.weight /= s; fc.weight *= s`:
+ * ptq/smoothquant.py:64-69, mobilellm/quantization/algorithm.py:47-68) for an activation whose producer cannot absorb
+ * 1/s; the consumer's integer weights are then formed from weight * s. */
 int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale,
-                const float* offset, int64_t n_scale, float qmin, float qmax, int shift, void* q,
-                int q_dtype, int32_t* row_sum, mq_stream_t stream);
+                const float* offset, int64_t n_scale, float qmin, float qmax, int shift,
+                const float* chan_scale, void* q, int q_dtype, int32_t* row_sum, mq_stream_t stream);
 
 /* ---- a8: QLinear.forward as a real-int8 GEMM (qmodule.py:341-358; SURVEY 8a' item 9) --------- */
 /* Epilogue vectors of one QLinear, computed on device from quantizer state (no host sync):
@@ -153,16 +158,29 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
  * Layout of q_tiled (ceil(rows/16)*16 * cols bytes): 1-KiB blocks of 16 rows x 64 k ordered [row block][k block]; inside
  * a block byte offset 16 * ((row & 15) + 16 * ((k & 63) >> 4)) + (k & 15).  Rows past `rows` are padding.
  * mq_quantize_tiled: per-tensor grid (scale/offset: 1 element), int8 storage (index - shift), cols % 128 == 0; row_sum
- * (nullable) as in mq_quantize. */
+ * (nullable) and chan_scale (nullable, [cols], 16-byte aligned, float32 x only) as in mq_quantize. */
 int mq_gemm_tiled_supported(int64_t M, int64_t N, int64_t K);
 int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale,
-                      const float* offset, float qmin, float qmax, int shift, int8_t* q_tiled,
-                      int32_t* row_sum, mq_stream_t stream);
+                      const float* offset, float qmin, float qmax, int shift, const float* chan_scale,
+                      int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream);
 int mq_w8a8_linear_tiled(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K,
                          const int32_t* a_rowsum, const float* alpha, const int32_t* w_zp,
                          const int32_t* col_term, const float* bias, const float* out_scale,
                          const float* out_offset, float out_qmin, float out_qmax, void* out,
                          int out_dtype, mq_stream_t stream);
+
+/* Two QLinears over the SAME activation in one launch -- w1 / w3 of a gated FFN receive the same tensor (hf_model.py:1057:
+ * w2(act(w1(x)) * w3(x))).  Both problems have the shape M x N x K (mq_gemm_tiled_supported, K % 256 == 0, K >= 768), their
+ * own weights, epilogue vectors and 8-bit unsigned output grid (out_qmin 0, out_qmax 255), and write the output INDICES
+ * (out_dtype MQ_U8, or MQ_I8 = index - 128) the next integer kernel consumes.  Results are bit-identical to two
+ * mq_w8a8_linear_tiled calls; the launch streams the activation panel once per tile pair and pays the kernel boundary once. */
+int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                              const int8_t* w0, const float* alpha0, const int32_t* w_zp0,
+                              const int32_t* col_term0, const float* bias0, const float* out_scale0,
+                              const float* out_offset0, void* out0, const int8_t* w1, const float* alpha1,
+                              const int32_t* w_zp1, const int32_t* col_term1, const float* bias1,
+                              const float* out_scale1, const float* out_offset1, void* out1, int out_dtype,
+                              mq_stream_t stream);
 
 /* Decode shapes (M <= 8 tokens, M*K < 64 KiB, K % 256 == 0): the activation quantizer (qmodule.py:349-351) fused
  * into the weight-streaming GEMV -- x is the fp32 [M,K] activation, quantised on the fly to its grid
@@ -231,6 +249,22 @@ int mq_act_quant(const float* x, int64_t numel, int act, const float* in_scale, 
                  float in_qmin, float in_qmax, const float* mid_scale, const float* mid_offset,
                  float mid_qmin, float mid_qmax, const float* out_scale, const float* out_offset,
                  float out_qmin, float out_qmax, float* y, mq_stream_t stream);
+
+/* ---- f1: the gated FFN's act(w1(x)) * w3(x) -> integer input image of w2 (hf_model.py:1057; qmodule.py:739-753) -------- */
+/* p = Qact(act(va)) * vb (QSiLU: act(va) = va * Qmid(sigmoid(va)); QGELU: gelu(va); the product itself is not quantised in
+ * the reference), then w2's input quantizer: q_out = int8 storage (index - q_shift) of p on the output grid, row_sum as
+ * mq_quantize would produce it, y (nullable) = p in fp32.  in_dtype MQ_F32: a / b are fp32 values.  in_dtype MQ_U8: a / b are
+ * the 8-bit output INDICES written by the w1 / w3 GEMMs (mq_w8a8_linear_tiled_pair) on the grids (a_scale, a_offset) /
+ * (b_scale, b_offset) -- the kernel dequantises (q - offset) * scale, bit-identical to the fp32 values of the fake-quant
+ * path, and the fp32 intermediates never exist in memory.  Per-tensor grids (1 element; NULL pair = quantizer absent; mid is
+ * ignored for GELU); cols % 16 == 0.  Same arithmetic and tolerance as mq_act_quant. */
+int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows, int64_t cols, int act,
+                       const float* a_scale, const float* a_offset, const float* b_scale,
+                       const float* b_offset, const float* mid_scale, const float* mid_offset,
+                       float mid_qmin, float mid_qmax, const float* act_scale, const float* act_offset,
+                       float act_qmin, float act_qmax, const float* out_scale, const float* out_offset,
+                       float out_qmin, float out_qmax, int q_shift, int8_t* q_out, int32_t* row_sum,
+                       float* y, mq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,18 +35,21 @@ _SIGNATURES = {
     "mq_minmax_cols": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "mq_fake_quant": (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, _P]),
     "mq_fake_quant_backward": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, _P, _P, _P, _P]),
-    "mq_quantize": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, c_int, _P, c_int, _P, _P]),
+    "mq_quantize": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, c_int, _P, _P, c_int, _P, _P]),
     "mq_linear_epilogue_prepare": (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "mq_w8a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
     "mq_gemm_tiled_supported": (c_int, [c_int64, c_int64, c_int64]),
-    "mq_quantize_tiled": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_float, c_float, c_int, _P, _P, _P]),
+    "mq_quantize_tiled": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P]),
     "mq_w8a8_linear_tiled": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
+    "mq_w8a8_linear_tiled_pair": (c_int, [_P, c_int64, c_int64, c_int64, _P] + [_P] * 16 + [c_int, _P]),
     "mq_w8a8_linear_f32in": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P,
                                      c_float, c_float, _P, c_int, _P]),
     "mq_w4a8_linear_f32in": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P,
                                      c_float, c_float, _P, c_int, _P]),
     "mq_pack_w4": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "mq_act_quant": (c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P]),
+    "mq_gated_act_quant": (c_int, [_P, _P, c_int, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, c_float, c_float,
+                                   _P, _P, c_float, c_float, c_int, _P, _P, _P, _P]),
     "mq_rmsnorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
                                  _P, _P, c_int, _P, _P]),
     "mq_layernorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
@@ -78,7 +81,7 @@ def load() -> ctypes.CDLL:
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype, fn.argtypes = res, args
-    if lib.mq_version() < 100:
+    if lib.mq_version() < 200:
         raise MobileQuantLibraryError("libmobilequant_amd.so is older than this Python package")
     _lib = lib
     return lib

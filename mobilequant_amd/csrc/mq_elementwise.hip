@@ -165,12 +165,15 @@ __device__ __forceinline__ QT to_store(float q, int shift) {
   return static_cast<QT>(static_cast<int>(q) - shift);
 }
 
-template <typename T, typename QT, bool PER_ROW>
+// CS: SmoothQuant per-channel scale fused in front of the quantizer: x[m,k] / chan_scale[k] (IEEE divide), then the index
+// arithmetic op for op -- the run-time form of the reference's offline fold `ln.weight /= s; fc.weight *= s`
+// (ptq/smoothquant.py:64-69, algorithm.py:47-68) for activations whose producer cannot absorb 1/s.
+template <typename T, typename QT, bool PER_ROW, bool CS = false>
 __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict__ x, QT* __restrict__ q,
                                                             int64_t cols, const float* __restrict__ scale,
                                                             const float* __restrict__ offset, float qmin,
                                                             float qmax, int shift, int32_t* __restrict__ row_sum,
-                                                            int vec_ok) {
+                                                            int vec_ok, const float* __restrict__ chan_scale = nullptr) {
   using V = Vec16<T>;
   const int64_t row = blockIdx.x;
   const float s = scale[PER_ROW ? row : 0];
@@ -186,7 +189,9 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
       QT out[V::N];
 #pragma unroll
       for (int j = 0; j < V::N; ++j) {
-        float qi = q_index(V::get(a, j), s, o, qmin, qmax);
+        float xv = V::get(a, j);
+        if constexpr (CS) xv = __fdiv_rn(xv, chan_scale[i * V::N + j]);
+        float qi = q_index(xv, s, o, qmin, qmax);
         int st_v = static_cast<int>(qi) - shift;
         acc += st_v;
         out[j] = static_cast<QT>(st_v);
@@ -200,7 +205,9 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
     }
   } else {
     for (int64_t i = threadIdx.x; i < cols; i += 256) {
-      float qi = q_index(ld<T>(xr, i), s, o, qmin, qmax);
+      float xv = ld<T>(xr, i);
+      if constexpr (CS) xv = __fdiv_rn(xv, chan_scale[i]);
+      float qi = q_index(xv, s, o, qmin, qmax);
       int st_v = static_cast<int>(qi) - shift;
       acc += st_v;
       qr[i] = static_cast<QT>(st_v);
@@ -218,12 +225,13 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
 // fp32 -> 1-byte indices, wave-per-row: a lane converts 16 consecutive elements (four independent 16-byte
 // loads in flight, one 16-byte store), so a wave instruction stores 1 KiB contiguous; the row sum is a
 // wave reduction (no LDS, no barrier).  Needs cols % 16 == 0 and 16-byte aligned rows.
-template <typename QT, bool PER_ROW>
+template <typename QT, bool PER_ROW, bool CS = false>
 __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float* __restrict__ x, QT* __restrict__ q,
                                                                     int64_t rows, int64_t cols,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ offset, float qmin,
-                                                                    float qmax, int shift, int32_t* __restrict__ row_sum) {
+                                                                    float qmax, int shift, int32_t* __restrict__ row_sum,
+                                                                    const float* __restrict__ chan_scale = nullptr) {
   static_assert(sizeof(QT) == 1, "one byte per index");
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -237,7 +245,14 @@ __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float*
     for (int64_t c = (int64_t)lane * 16; c < cols; c += 1024) {
       const float4* p = reinterpret_cast<const float4*>(xr + c);
       const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-      const float f[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+      float f[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+      if constexpr (CS) {      // the [cols] vector is shared by every row: L2 / L1 resident after the first rows
+        const float4* cp = reinterpret_cast<const float4*>(chan_scale + c);
+        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+        const float cs[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = __fdiv_rn(f[e], cs[e]);
+      }
       uint32_t w[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -388,11 +403,12 @@ static int launch_fake_quant(const T* x, T* y, int64_t rows, int64_t cols, const
 // ~20 VALU ops per element, so leaving half the CUs idle doubles the kernel).  A wave converts 8 rows x 2 k blocks per
 // step: lane = r + 8 * kq + 32 * ksel reads the 64 bytes (16 fp32) of row r, k block kb0 + ksel, quarter kq and stores
 // its 16 bytes at the fragment position; the 8 lanes (kq, ksel) of a row reduce the row sum, LDS atomics across waves.
-template <typename T, bool HAS_SUM, int STEPS>   // STEPS: (k block pairs per wave) held in flight at once (0: generic loop)
+template <typename T, bool HAS_SUM, int STEPS, bool CS = false>   // STEPS: (k block pairs per wave) held in flight at once (0: generic loop)
 __global__ void __launch_bounds__(512) quantize_tiled_kernel(const T* __restrict__ x, int8_t* __restrict__ q, int64_t rows,
                                                              int64_t cols, const float* __restrict__ scale,
                                                              const float* __restrict__ offset, float qmin, float qmax,
-                                                             int shift, int32_t* __restrict__ row_sum) {
+                                                             int shift, int32_t* __restrict__ row_sum,
+                                                             const float* __restrict__ chan_scale = nullptr) {
   __shared__ int s_sum[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 7, kq = (lane >> 3) & 3, ksel = lane >> 5;
@@ -407,7 +423,17 @@ __global__ void __launch_bounds__(512) quantize_tiled_kernel(const T* __restrict
   int acc = 0;
   const T* xrow = x + row * cols + kq * 16;
   int8_t* qdst = q + ((rb * kblocks) << 10) + ((r16 + 16 * kq) << 4);
-  auto emit = [&](int kb, const float (&f)[16]) {
+  auto emit = [&](int kb, const float (&fin)[16]) {
+    float f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) f[e] = fin[e];
+    if constexpr (CS) {        // this lane's 16 channels: k = kb * 64 + kq * 16 + e
+      const float4* cp = reinterpret_cast<const float4*>(chan_scale + (int64_t)kb * 64 + kq * 16);
+      const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+      const float cs[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) f[e] = __fdiv_rn(f[e], cs[e]);
+    }
     uint32_t w[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -457,9 +483,28 @@ __global__ void __launch_bounds__(512) quantize_tiled_kernel(const T* __restrict
 
 template <typename T, typename QT>
 static int launch_quantize(const T* x, QT* q, int64_t rows, int64_t cols, const float* scale, const float* offset,
-                           bool per_row, float qmin, float qmax, int shift, int32_t* row_sum, hipStream_t st) {
+                           bool per_row, float qmin, float qmax, int shift, int32_t* row_sum, const float* chan_scale,
+                           hipStream_t st) {
   constexpr int VN = Vec16<T>::N;
   const int vec_ok = aligned(x, 16) && aligned(q, sizeof(QT) * VN) && (cols % VN == 0);
+  if (chan_scale != nullptr) {       // SmoothQuant channel scale: per-tensor grids of fp32 activations (checked by the caller)
+    if constexpr (std::is_same<T, float>::value) {
+      if constexpr (sizeof(QT) == 1) {
+        if (aligned(x, 16) && aligned(q, 16) && aligned(chan_scale, 16) && cols % 16 == 0 && cols >= 256) {
+          int64_t blocks = (rows + 3) / 4;
+          if (blocks > 256 * 16) blocks = 256 * 16;
+          quantize_rows_f32_b16_kernel<QT, false, true><<<(unsigned)blocks, 256, 0, st>>>(x, q, rows, cols, scale, offset, qmin,
+                                                                                          qmax, shift, row_sum, chan_scale);
+          MQ_LAUNCH_CHECK("mq_quantize");
+          return MQ_OK;
+        }
+      }
+      quantize_rows_kernel<T, QT, false, true><<<(unsigned)rows, 256, 0, st>>>(x, q, cols, scale, offset, qmin, qmax, shift,
+                                                                             row_sum, vec_ok, chan_scale);
+      MQ_LAUNCH_CHECK("mq_quantize");
+      return MQ_OK;
+    }
+  }
   if constexpr (std::is_same<T, float>::value && sizeof(QT) == 1) {
     if (aligned(x, 16) && aligned(q, 16) && cols % 16 == 0 && cols >= 256) {
       int64_t blocks = (rows + 3) / 4;
@@ -561,15 +606,17 @@ int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, in
 }
 
 int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
-                int64_t n_scale, float qmin, float qmax, int shift, void* q, int q_dtype, int32_t* row_sum,
-                mq_stream_t stream) {
+                int64_t n_scale, float qmin, float qmax, int shift, const float* chan_scale, void* q, int q_dtype,
+                int32_t* row_sum, mq_stream_t stream) {
   MQ_REQUIRE(rows >= 0 && cols >= 0 && rows < (int64_t)0x7fffffff, "mq_quantize: bad shape %lld x %lld",
              (long long)rows, (long long)cols);
   MQ_REQUIRE(n_scale == 1 || n_scale == rows, "mq_quantize: n_scale=%lld must be 1 or rows=%lld", (long long)n_scale,
              (long long)rows);
   if (rows == 0 || cols == 0) return MQ_OK;      // empty tensor (its data pointer may be NULL)
   MQ_REQUIRE(x && q && scale && offset, "mq_quantize: null pointer");
-  const bool per_row = (n_scale == rows) && rows > 1;
+  MQ_REQUIRE(chan_scale == nullptr || (dtype == MQ_F32 && n_scale == 1),
+             "mq_quantize: chan_scale needs float32 activations and a per-tensor grid");
+  const bool per_row = (n_scale == rows) && rows > 1 && chan_scale == nullptr;
   const float lo = qmin - (float)shift, hi = qmax - (float)shift;
   hipStream_t st = as_stream(stream);
 #define MQ_Q(T, QT, LO, HI)                                                                                          \
@@ -577,7 +624,7 @@ int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const floa
     MQ_REQUIRE(lo >= (float)(LO) && hi <= (float)(HI), "mq_quantize: [%g,%g]-%d does not fit the storage type", qmin, \
                qmax, shift);                                                                                         \
     return launch_quantize<T, QT>((const T*)x, (QT*)q, rows, cols, scale, offset, per_row, qmin, qmax, shift,        \
-                                  row_sum, st);                                                                      \
+                                  row_sum, chan_scale, st);                                                          \
   } while (0)
 #define MQ_QD(T)                                          \
   switch (q_dtype) {                                      \
@@ -597,7 +644,8 @@ int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const floa
 }
 
 int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
-                      float qmin, float qmax, int shift, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream) {
+                      float qmin, float qmax, int shift, const float* chan_scale, int8_t* q_tiled, int32_t* row_sum,
+                      mq_stream_t stream) {
   MQ_REQUIRE(rows != 0 ? (x && q_tiled && scale && offset) : true, "mq_quantize_tiled: null pointer");
   MQ_REQUIRE(rows >= 0 && cols > 0 && cols % 128 == 0 && (rows + 15) / 8 < (int64_t)0x7fffffff,
              "mq_quantize_tiled: bad shape %lld x %lld (cols must be a multiple of 128)", (long long)rows, (long long)cols);
@@ -605,6 +653,8 @@ int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, cons
              qmin, qmax, shift);
   if (rows == 0) return MQ_OK;
   MQ_REQUIRE(aligned(x, 16) && aligned(q_tiled, 16), "mq_quantize_tiled: pointers must be 16-byte aligned");
+  MQ_REQUIRE(chan_scale == nullptr || (dtype == MQ_F32 && aligned(chan_scale, 16)),
+             "mq_quantize_tiled: chan_scale needs float32 activations and a 16-byte aligned vector");
   const unsigned grid = (unsigned)(((rows + 15) / 16) * 2);      // 8 rows per workgroup, padding rows included
   hipStream_t st = as_stream(stream);
 #define MQ_QT(T, KBW)                                                                                                 \
@@ -613,7 +663,10 @@ int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, cons
     else quantize_tiled_kernel<T, false, KBW><<<grid, 512, 0, st>>>((const T*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);       \
   } while (0)
   const int64_t kblocks = cols >> 6;
-  if (dtype == MQ_F32) {
+  if (chan_scale != nullptr) {       // the SmoothQuant form: x / chan_scale[k] in front of the same index arithmetic
+    if (row_sum) quantize_tiled_kernel<float, true, 0, true><<<grid, 512, 0, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum, chan_scale);
+    else quantize_tiled_kernel<float, false, 0, true><<<grid, 512, 0, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum, chan_scale);
+  } else if (dtype == MQ_F32) {
     if (kblocks == 32) MQ_QT(float, 2);            // K = 2048: 2 steps of 2 k blocks per wave, all in flight
     else if (kblocks == 16) MQ_QT(float, 1);
     else MQ_QT(float, 0);

@@ -699,11 +699,11 @@ __global__ void __launch_bounds__(64 * WM * WN)
 // The whole workgroup program (prologue, software-pipelined main loop, epilogue) is generated gfx950 ISA; C++ only forms
 // the per-lane addresses and the scalar arguments.  256 x 176 tile, fragment-blocked activations, int8 weights, 8-bit
 // UNSIGNED output grid (u8 storage, or i8 storage = index - 128), K % 256 == 0, K >= 768.
-__global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) {
+__device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, int nblk) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
+  tile_of_block(bid, nblk, args.grid_m, args.grid_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * 176;
   const int M = args.M, N = args.N, K = args.K;
   const int KT = K / BK;
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) {
   const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
   const unsigned tid = threadIdx.x;
 #if MQ_FR_ASM_STAMP
-  unsigned long long* dbg = args.dbg_ts + ((size_t)blockIdx.x * 8 + wave) * 16;
+  unsigned long long* dbg = args.dbg_ts + ((size_t)bid * 8 + wave) * 16;
 #endif
   asm volatile(MQ_FR_ASM_BODY
                :
@@ -763,9 +763,44 @@ __global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) {
                : MQ_FR_ASM_CLOBBERS);
 }
 
+__global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) { gemm_i8_fr_body(args, blockIdx.x, gridDim.x); }
+
+// Two QLinears that consume the SAME activation (w1 / w3 of an FFN: hf_model.py:1057) in ONE launch: workgroups
+// [0, nblk) compute problem 0, [nblk, 2 nblk) problem 1 with the same block -> tile map, so the second problem's tiles land on
+// the CUs / XCD that just streamed the same activation panel.  Twice the tiles per launch: the kernel-boundary cost and the
+// prologue burst are paid once, and a CU's second workgroup starts while other CUs are still in their first epilogue.
+struct GemmPairArgs {
+  GemmArgs p[2];
+};
+__global__ void __launch_bounds__(512) gemm_i8_fr_pair_kernel(const GemmPairArgs args) {
+  const int nblk = (int)(gridDim.x >> 1);
+  const int which = __builtin_amdgcn_readfirstlane(blockIdx.x >= (unsigned)nblk ? 1 : 0);
+  if (which) gemm_i8_fr_body(args.p[1], (int)blockIdx.x - nblk, nblk);
+  else gemm_i8_fr_body(args.p[0], (int)blockIdx.x, nblk);
+}
+
 static bool gemm_fr_supported(const GemmArgs& a) {
   return a.a_tiled && (a.out_dtype == MQ_U8 || a.out_dtype == MQ_I8) && a.out_scale != nullptr && a.out_qmin == 0.0f &&
          a.out_qmax == 255.0f && a.K % 256 == 0 && a.K >= 768 && a.N % 176 == 0;
+}
+
+static int launch_fr_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t st) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_fr_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_FR_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", MQ_FR_LDS_BYTES, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  GemmPairArgs pa;
+  pa.p[0] = a0;
+  pa.p[1] = a1;
+  gemm_i8_fr_pair_kernel<<<2 * a0.grid_m * a0.grid_n, 512, MQ_FR_LDS_BYTES, st>>>(pa);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
 }
 
 static int launch_fr(const GemmArgs& a, hipStream_t st) {
@@ -1030,6 +1065,39 @@ int mq_w8a8_linear_tiled(const int8_t* a_tiled, const int8_t* w, int64_t M, int6
   GemmArgs g{a_tiled, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
              out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 1, 0, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                              const int8_t* w0, const float* alpha0, const int32_t* w_zp0, const int32_t* col_term0,
+                              const float* bias0, const float* out_scale0, const float* out_offset0, void* out0,
+                              const int8_t* w1, const float* alpha1, const int32_t* w_zp1, const int32_t* col_term1,
+                              const float* bias1, const float* out_scale1, const float* out_offset1, void* out1,
+                              int out_dtype, mq_stream_t stream) {
+  const char* fn = "mq_w8a8_linear_tiled_pair";
+  int rc = check_common(fn, a_tiled, w0, M, N, K, a_rowsum, alpha0, w_zp0, col_term0, bias0, out_scale0, out_offset0, out0, 1);
+  if (rc != MQ_OK) return rc;
+  rc = check_common(fn, a_tiled, w1, M, N, K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1, out1, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32), "%s: activation too large", fn);
+  MQ_REQUIRE(out_scale0 && out_scale1 && (out_dtype == MQ_U8 || out_dtype == MQ_I8),
+             "%s: both outputs carry an 8-bit unsigned output grid (u8 / i8 storage)", fn);
+  GemmArgs g0{a_tiled, w0, (int)M, (int)N, (int)K, a_rowsum, alpha0, w_zp0, col_term0, bias0, out_scale0, out_offset0,
+              0.f, 255.f, out0, out_dtype, 0, 0, bias0 != nullptr, 1, 0, g_dbg_ts};
+  GemmArgs g1{a_tiled, w1, (int)M, (int)N, (int)K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1,
+              0.f, 255.f, out1, out_dtype, 0, 0, bias1 != nullptr, 1, 0, g_dbg_ts};
+  if (!gemm_tiled_supported(M, N, K) || !gemm_fr_supported(g0)) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled_supported, K %% 256 == 0, K >= 768)", fn, (long long)M, (long long)N,
+              (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  for (GemmArgs* g : {&g0, &g1}) {
+    g->has_rowsum = g->a_rowsum != nullptr;
+    if (g->a_rowsum == nullptr) g->a_rowsum = g->col_term;
+    if (g->bias == nullptr) g->bias = g->alpha;
+    g->grid_m = (g->M + 255) / 256;
+    g->grid_n = (g->N + 175) / 176;
+  }
+  return launch_fr_pair(g0, g1, as_stream(stream));
 }
 
 static int linear_f32in(const char* fn, int w4, const float* x, const float* a_scale, const float* a_offset, float a_qmin,

@@ -335,6 +335,144 @@ __global__ void __launch_bounds__(256) act_quant_kernel(const ActArgs a) {
   for (int64_t i = (nvec << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.numel; i += stride) a.y[i] = f(a.x[i]);
 }
 
+
+// ---- f1: the gated FFN's  act(w1(x)) * w3(x)  -> integer input image of w2, ONE launch ------------------------------------------
+// Reference chain (hf_model.py:1057, qmodule.py:739-753): y1 = Qact(va * Qmid(sigmoid(va))) (QSiLU; QGELU: Qact(gelu(va))), the
+// plain fp32 product p = y1 * vb (ElementwiseMul is not quantised), then w2's input quantizer.  va / vb arrive either as fp32 values
+// or -- the integer chain -- as the 8-bit output INDICES the w1 / w3 GEMMs wrote (va = (qa - oa) * sa: exactly the fp32 value the
+// fake-quant path would hold).  Output: int8 storage (index - shift) of p on w2's input grid + row sums (what mq_quantize would
+// produce from p), optionally p itself.  3 B per element instead of 17 for the composite chain.  Wave per row, 16 elements per lane.
+struct GatedArgs {
+  const void* a;
+  const void* b;
+  int in_index;                // 0: fp32 values, 1: u8 indices
+  int64_t rows, cols;
+  int act;
+  const float* s[5];           // a grid, b grid, mid (sigmoid) grid, activation output grid, w2 input grid
+  const float* o[5];
+  float qmin[5], qmax[5];
+  int shift;
+  int8_t* q;
+  int32_t* row_sum;
+  float* y;
+};
+
+template <bool INDEX, bool WRITE_Y>
+__global__ void __launch_bounds__(256) gated_act_quant_kernel(const GatedArgs g) {
+  float sc[5], of[5];
+  bool has[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    has[k] = g.s[k] != nullptr;
+    sc[k] = has[k] ? g.s[k][0] : 1.f;
+    of[k] = has[k] ? g.o[k][0] : 0.f;
+  }
+  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < g.rows; row += nwaves) {
+    int acc = 0;
+    for (int64_t c = (int64_t)lane * 16; c < g.cols; c += 1024) {
+      float va[16], vb[16];
+      const int64_t at = row * g.cols + c;
+      if constexpr (INDEX) {
+        const uint4 pa = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(g.a) + at);
+        const uint4 pb = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(g.b) + at);
+        const uint32_t wa[4] = {pa.x, pa.y, pa.z, pa.w}, wb[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          va[e] = nq_dequant((float)((wa[e >> 2] >> (8 * (e & 3))) & 0xffu), sc[0], of[0]);
+          vb[e] = nq_dequant((float)((wb[e >> 2] >> (8 * (e & 3))) & 0xffu), sc[1], of[1]);
+        }
+      } else {
+        const float4* pa = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.a) + at);
+        const float4* pb = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.b) + at);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float4 x = pa[d], z = pb[d];
+          va[4 * d] = x.x; va[4 * d + 1] = x.y; va[4 * d + 2] = x.z; va[4 * d + 3] = x.w;
+          vb[4 * d] = z.x; vb[4 * d + 1] = z.y; vb[4 * d + 2] = z.z; vb[4 * d + 3] = z.w;
+        }
+      }
+      float p[16];
+      uint32_t w[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xi = va[4 * d + e];
+          float r;
+          if (g.act == 0) {
+            const float gate = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-xi)));
+            r = __fmul_rn(xi, fq(2, gate));
+          } else {
+            r = __fmul_rn(__fmul_rn(0.5f, xi), __fadd_rn(1.0f, erff(__fmul_rn(xi, 0.70710678118654752440f))));
+          }
+          const float prod = __fmul_rn(fq(3, r), vb[4 * d + e]);
+          p[4 * d + e] = prod;
+          const float qi = nq_index(prod, sc[4], of[4], g.qmin[4], g.qmax[4]);
+          // integer storage has no NaN: saturate like mq_quantize does
+          const int st_v = (qi != qi ? (int)g.qmin[4] : (int)qi) - g.shift;
+          acc += st_v;
+          pk |= ((uint32_t)st_v & 0xffu) << (8 * e);
+        }
+        w[d] = pk;
+      }
+      *reinterpret_cast<uint4*>(g.q + at) = make_uint4(w[0], w[1], w[2], w[3]);
+      if constexpr (WRITE_Y) {
+        float4* py = reinterpret_cast<float4*>(g.y + at);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) py[d] = make_float4(p[4 * d], p[4 * d + 1], p[4 * d + 2], p[4 * d + 3]);
+      }
+    }
+    if (g.row_sum != nullptr) {
+      acc = wave_sum(acc);
+      if (lane == 0) g.row_sum[row] = acc;
+    }
+  }
+}
+
+}  // namespace mq
+
+extern "C" int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows, int64_t cols, int act,
+                                  const float* a_scale, const float* a_offset, const float* b_scale, const float* b_offset,
+                                  const float* mid_scale, const float* mid_offset, float mid_qmin, float mid_qmax,
+                                  const float* act_scale, const float* act_offset, float act_qmin, float act_qmax,
+                                  const float* out_scale, const float* out_offset, float out_qmin, float out_qmax, int q_shift,
+                                  int8_t* q_out, int32_t* row_sum, float* y, mq_stream_t stream) {
+  using namespace mq;
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && cols % 16 == 0 && (act == 0 || act == 1),
+             "mq_gated_act_quant: bad arguments (cols %% 16 == 0; act = 0 SiLU, 1 GELU)");
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(a && b && q_out && out_scale && out_offset, "mq_gated_act_quant: null pointer (a, b, q_out and the output grid are required)");
+  MQ_REQUIRE(in_dtype == MQ_F32 || in_dtype == MQ_U8, "mq_gated_act_quant: inputs are float32 values or uint8 indices");
+  MQ_REQUIRE(in_dtype == MQ_F32 || (a_scale && a_offset && b_scale && b_offset), "mq_gated_act_quant: index inputs need their grids");
+  MQ_REQUIRE(aligned(a, 16) && aligned(b, 16) && aligned(q_out, 16) && (!y || aligned(y, 16)), "mq_gated_act_quant: pointers must be 16-byte aligned");
+  MQ_REQUIRE((mid_scale == nullptr) == (mid_offset == nullptr) && (act_scale == nullptr) == (act_offset == nullptr),
+             "mq_gated_act_quant: scale/offset must both be set or NULL");
+  MQ_REQUIRE(out_qmin - (float)q_shift >= -128.f && out_qmax - (float)q_shift <= 127.f, "mq_gated_act_quant: output grid does not fit int8");
+  const bool idx = in_dtype == MQ_U8;
+  GatedArgs g{a, b, idx ? 1 : 0, rows, cols, act,
+              {idx ? a_scale : nullptr, idx ? b_scale : nullptr, mid_scale, act_scale, out_scale},
+              {idx ? a_offset : nullptr, idx ? b_offset : nullptr, mid_offset, act_offset, out_offset},
+              {0.f, 0.f, mid_qmin, act_qmin, out_qmin}, {0.f, 0.f, mid_qmax, act_qmax, out_qmax}, q_shift, q_out, row_sum, y};
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = as_stream(stream);
+  if (idx) {
+    if (y) gated_act_quant_kernel<true, true><<<(unsigned)blocks, 256, 0, st>>>(g);
+    else gated_act_quant_kernel<true, false><<<(unsigned)blocks, 256, 0, st>>>(g);
+  } else {
+    if (y) gated_act_quant_kernel<false, true><<<(unsigned)blocks, 256, 0, st>>>(g);
+    else gated_act_quant_kernel<false, false><<<(unsigned)blocks, 256, 0, st>>>(g);
+  }
+  MQ_LAUNCH_CHECK("mq_gated_act_quant");
+  return MQ_OK;
+}
+
+namespace mq {
 }  // namespace mq
 
 extern "C" int mq_act_quant(const float* x, int64_t numel, int act, const float* in_scale, const float* in_offset, float in_qmin,

@@ -173,10 +173,21 @@ def fake_quant_backward(x: torch.Tensor, grad_y: torch.Tensor, scale: torch.Tens
     return gx, gs, go
 
 
+def _chan(chan_scale, cols: int, x: torch.Tensor):
+    if chan_scale is None:
+        return None
+    cs = _f32(chan_scale, "chan_scale").reshape(-1)
+    if cs.numel() != cols or x.dtype != torch.float32:
+        raise RuntimeError(f"mobilequant_amd: chan_scale needs {cols} fp32 entries (got {cs.numel()}) and float32 activations")
+    return cs
+
+
 def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, *,
-             q_dtype: int = MQ_I8, shift: int = 0, rows: Optional[int] = None, want_row_sum: bool = False):
+             q_dtype: int = MQ_I8, shift: int = 0, rows: Optional[int] = None, want_row_sum: bool = False,
+             chan_scale: Optional[torch.Tensor] = None):
     """Integer indices (qmodule.py:286-287) as integers; optional per-row sums of the stored values.
-    x is viewed as [rows, -1]; rows defaults to the number of scales (per-row) or all leading dims."""
+    x is viewed as [rows, -1]; rows defaults to the number of scales (per-row) or all leading dims.
+    chan_scale [cols]: SmoothQuant per-channel scale fused in front (index of x / chan_scale; per-tensor grids, fp32)."""
     x = _dev(x, "x").contiguous()
     s, o = _f32(scale, "scale"), _f32(offset, "offset")
     if rows is None:
@@ -184,9 +195,11 @@ def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: f
     cols = x.numel() // max(rows, 1)
     q = torch.empty(x.shape, dtype=_QDT[q_dtype], device=x.device)
     rs = torch.empty(rows, dtype=torch.int32, device=x.device) if want_row_sum else None
-    with _on(x, s, o):
+    cs = _chan(chan_scale, cols, x)
+    with _on(x, s, o, cs):
         _lib.call("mq_quantize", x.data_ptr(), _fdt(x), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(), float(qmin),
-                  float(qmax), int(shift), q.data_ptr(), q_dtype, rs.data_ptr() if rs is not None else None, _stream())
+                  float(qmax), int(shift), cs.data_ptr() if cs is not None else None, q.data_ptr(), q_dtype,
+                  rs.data_ptr() if rs is not None else None, _stream())
     return (q, rs) if want_row_sum else q
 
 
@@ -244,16 +257,18 @@ def gemm_tiled_supported(M: int, N: int, K: int) -> bool:
 
 
 def quantize_tiled(x2d: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, shift: int,
-                   want_row_sum: bool = True):
+                   want_row_sum: bool = True, chan_scale: Optional[torch.Tensor] = None):
     """[M,K] activations -> fragment-blocked int8 ([ceil16(M), K] buffer, layout: include/mobilequant_amd.h) + row sums."""
     x2d = _dev(x2d, "x").contiguous()
     M, K = x2d.shape
     q = torch.empty(((M + 15) // 16 * 16, K), dtype=torch.int8, device=x2d.device)
     rs = torch.empty(M, dtype=torch.int32, device=x2d.device) if want_row_sum else None
     s, o = _f32(scale, "scale"), _f32(offset, "offset")
-    with _on(x2d, s, o):
+    cs = _chan(chan_scale, K, x2d)
+    with _on(x2d, s, o, cs):
         _lib.call("mq_quantize_tiled", x2d.data_ptr(), _fdt(x2d), M, K, s.data_ptr(), o.data_ptr(), float(qmin), float(qmax),
-                  int(shift), q.data_ptr(), rs.data_ptr() if rs is not None else None, _stream())
+                  int(shift), cs.data_ptr() if cs is not None else None, q.data_ptr(), rs.data_ptr() if rs is not None else None,
+                  _stream())
     return (q, rs) if want_row_sum else q
 
 
@@ -343,3 +358,53 @@ def pack_w4(nibbles: torch.Tensor) -> torch.Tensor:
     with _on(nibbles):
         _lib.call("mq_pack_w4", nibbles.data_ptr(), N, K, packed.data_ptr(), _stream())
     return packed
+
+
+# ---- f1: integer chaining inside the gated FFN ---------------------------------------------------------------------------------
+def int8_linear_pair(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch.Tensor], first: dict, second: dict,
+                     out_dtype: int = MQ_U8):
+    """Two QLinears over the SAME fragment-blocked activation in one launch (w1 / w3 of a gated FFN).  `first` / `second`:
+    dicts with w [N,K] int8, alpha, w_zp, col_term, bias (or None), out_scale, out_offset (8-bit unsigned output grids).
+    Returns the two [rows, N] index tensors (u8, or i8 = index - 128)."""
+    M, K = int(rows), a_tiled.shape[1]
+    N = first["w"].shape[0]
+    outs = [torch.empty((M, N), dtype=_OUT_TORCH[out_dtype], device=a_tiled.device) for _ in range(2)]
+    ptrs, keep = [], []
+    for p, o in zip((first, second), outs):
+        b = _f32(p["bias"], "bias") if p.get("bias") is not None else None
+        os_, oo_ = _f32(p["out_scale"], "out_scale"), _f32(p["out_offset"], "out_offset")
+        keep += [b, os_, oo_]
+        ptrs += [p["w"].data_ptr(), p["alpha"].data_ptr(), p["w_zp"].data_ptr(), p["col_term"].data_ptr(),
+                 b.data_ptr() if b is not None else None, os_.data_ptr(), oo_.data_ptr(), o.data_ptr()]
+    with _on(a_tiled, a_rowsum, first["w"], second["w"], first["alpha"], second["alpha"], *[k for k in keep if k is not None]):
+        _lib.call("mq_w8a8_linear_tiled_pair", a_tiled.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
+                  *ptrs, out_dtype, _stream())
+    return outs[0], outs[1]
+
+
+def gated_act_quant(a: torch.Tensor, b: torch.Tensor, act: str, out_grid, *, a_grid=None, b_grid=None, mid_grid=None, act_grid=None,
+                    q_shift: int = 128, want_y: bool = False):
+    """act(a) * b -> int8 image on `out_grid` (+ row sums, + the fp32 product when want_y) in one launch: the gated FFN between
+    the w1 / w3 GEMMs and w2.  a / b: fp32 values [rows, cols], or uint8 output indices of the GEMMs with their grids
+    (a_grid / b_grid).  Grids: (scale, offset, qmin, qmax) per-tensor or None."""
+    a, b = _dev(a, "a").contiguous(), _dev(b, "b").contiguous()
+    if a.dtype != b.dtype or a.shape != b.shape or a.dtype not in (torch.float32, torch.uint8):
+        raise RuntimeError("mobilequant_amd: gated_act_quant needs two float32 or two uint8 tensors of one shape")
+    cols = a.shape[-1]
+    rows = a.numel() // max(cols, 1)
+    q = torch.empty(a.shape, dtype=torch.int8, device=a.device)
+    rs = torch.empty(rows, dtype=torch.int32, device=a.device)
+    y = torch.empty(a.shape, dtype=torch.float32, device=a.device) if want_y else None
+    ptrs, keep = [], []
+    for g, with_limits in ((a_grid, False), (b_grid, False), (mid_grid, True), (act_grid, True), (out_grid, True)):
+        if g is None:
+            ptrs += [None, None] + ([0.0, 0.0] if with_limits else [])
+        else:
+            s, o = _f32(g[0], "scale"), _f32(g[1], "offset")
+            keep += [s, o]
+            ptrs += [s.data_ptr(), o.data_ptr()] + ([float(g[2]), float(g[3])] if with_limits else [])
+    with _on(a, b, *keep):
+        _lib.call("mq_gated_act_quant", a.data_ptr(), b.data_ptr(), MQ_U8 if a.dtype == torch.uint8 else MQ_F32, rows, cols,
+                  {"silu": 0, "gelu": 1}[act], *ptrs, int(q_shift), q.data_ptr(), rs.data_ptr(),
+                  y.data_ptr() if y is not None else None, _stream())
+    return (q, rs, y) if want_y else (q, rs)

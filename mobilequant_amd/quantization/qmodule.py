@@ -176,6 +176,37 @@ class _FakeQuantFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None), gs, go, None, None
 
 
+class _RangeFn(torch.autograd.Function):
+    """min / max of a weight as the reference's ``torch.amin`` / ``torch.amax`` (qmodule.py:263-268) with their gradient:
+    the forward is the single-pass HIP reduction; the backward sends the gradient of a row's (or the tensor's) min / max to
+    its extreme element(s), split evenly between ties -- what torch autograd does.  Only reached when learnable weight
+    clipping trains through the range (algorithm.py:381 / :587); weight-sized elementwise torch ops, training time only."""
+
+    @staticmethod
+    def forward(ctx, x2, per_channel):
+        if per_channel:
+            lead = x2.shape[:-1]
+            mn, mx = ops.minmax_rows(x2.reshape(-1, x2.shape[-1]))
+            mn, mx = mn.reshape(*lead, 1), mx.reshape(*lead, 1)
+        else:
+            mn, mx = ops.minmax_tensor(x2)
+            mn, mx = mn.reshape(()), mx.reshape(())
+        ctx.save_for_backward(x2, mn, mx)
+        ctx.per_channel = per_channel
+        return mn.to(x2.dtype), mx.to(x2.dtype)
+
+    @staticmethod
+    def backward(ctx, g_mn, g_mx):
+        x2, mn, mx = ctx.saved_tensors
+        is_mn, is_mx = (x2 == mn.to(x2.dtype)), (x2 == mx.to(x2.dtype))
+        if ctx.per_channel:
+            n_mn, n_mx = is_mn.sum(-1, keepdim=True), is_mx.sum(-1, keepdim=True)
+        else:
+            n_mn, n_mx = is_mn.sum(), is_mx.sum()
+        gx = is_mn * (g_mn / n_mn) + is_mx * (g_mx / n_mx)
+        return gx.to(x2.dtype), None
+
+
 class Quantizer(nn.Module):
     """Fake-quantizer with cached or on-the-fly (scale, offset) (reference: qmodule.py:112-295)."""
 
@@ -223,6 +254,9 @@ class Quantizer(nn.Module):
 
     def _tensor_range(self, x2):
         """min/max of the (already group-reshaped) tensor, with the LWC factors applied if enabled."""
+        if self.lwc and _needs_grad(x2):          # the reference's amin / amax back-propagate into the extreme elements
+            mn, mx = _RangeFn.apply(x2, self.qcfg.is_per_channel)
+            return torch.sigmoid(self.lowbound_factor) * mn, torch.sigmoid(self.upbound_factor) * mx
         if self.qcfg.is_per_channel:
             lead = x2.shape[:-1]
             mn, mx = ops.minmax_rows(x2.reshape(-1, x2.shape[-1]))
@@ -315,12 +349,12 @@ class Quantizer(nn.Module):
             y = ops.fake_quant(x, self.scale.detach(), self.offset.detach(), self.qmin, self.qmax)
         return y.reshape(input_.shape) if grouped else _tag_grid(y, self)
 
-    def quantize_to_int(self, x, q_dtype=MQ_I8, want_row_sum=False, rows=None):
+    def quantize_to_int(self, x, q_dtype=MQ_I8, want_row_sum=False, rows=None, chan_scale=None):
         """Integer indices of x on this quantizer's grid (static per-tensor or per-row grids).
         Returns (q, row_sum or None, shift): int8 storage subtracts shift = 128 from unsigned grids."""
         shift = 128 if (q_dtype == MQ_I8 and self.qmax > 127) else 0
         out = ops.quantize(x, self.scale.detach(), self.offset.detach(), self.qmin, self.qmax, q_dtype=q_dtype,
-                           shift=shift, rows=rows, want_row_sum=want_row_sum)
+                           shift=shift, rows=rows, want_row_sum=want_row_sum, chan_scale=chan_scale)
         q, rs = out if want_row_sum else (out, None)
         return q, rs, shift
 
@@ -443,6 +477,8 @@ class QLinear(nn.Linear, _QuantizedOp):
         self.int8_mode = "auto"        # "auto" | "off": real-int8 MFMA path when the config allows it
         self._input_grid = None        # producer's output grid for linears without an input quantizer
         self._plan = None
+        self.input_chan_scale = None   # SmoothQuant per-input-channel scale applied at RUN time (set_input_channel_scale)
+        self._scaled_weight = None
 
     # -- integer path ------------------------------------------------------------------------------
     def set_input_grid(self, min_val, max_val, bitwidth=8, is_symmetric=False):
@@ -452,6 +488,39 @@ class QLinear(nn.Linear, _QuantizedOp):
         q = Quantizer(QuantConfig(bitwidth=bitwidth, is_symmetric=is_symmetric))
         q.set_scale_offset_from_minmax(min_val, max_val, None, self.weight.device)
         self._input_grid = q
+
+    # -- SmoothQuant at run time ---------------------------------------------------------------------
+    def set_input_channel_scale(self, scales: Optional[torch.Tensor]):
+        """Apply a SmoothQuant per-input-channel scale s at RUN time: ``out = Qout(linear(Qin(x / s), Qw(W * s)))``.
+        The reference folds s offline into the producer (``ln.weight /= s``) and the consumer (``fc.weight *= s``;
+        ptq/smoothquant.py:64-69, algorithm.py:47-68); this is the same transformation for a producer that cannot absorb
+        1/s: the division is fused into the activation quantize kernel (``mq_quantize(..., chan_scale)``), the integer
+        weights are formed from ``W * s``.  Needs this linear's own input quantizer (its grid is that of x / s).
+        ``None`` removes the scale."""
+        if scales is None:
+            self.input_chan_scale = None
+        else:
+            s = scales.detach().to(device=self.weight.device, dtype=torch.float32).reshape(-1).contiguous()
+            assert s.numel() == self.in_features, (s.numel(), self.in_features)
+            assert self.input_quantizer is not None, "a run-time channel scale needs the linear's own input quantizer"
+            self.input_chan_scale = s
+        self._scaled_weight = None
+        self._plan = None
+        return self
+
+    def _effective_weight(self, weight):
+        """W * s (per input channel), cached until W or s change."""
+        cs = self.input_chan_scale
+        if cs is None:
+            return weight
+        key = (weight.data_ptr(), _ver(weight), cs.data_ptr(), _ver(cs))
+        hit = self._scaled_weight
+        if hit is not None and hit[0] == key and hit[1]() is weight and not _needs_grad(weight):
+            return hit[2]
+        w = weight * cs.view(1, -1).to(weight.dtype)
+        if not _needs_grad(weight):
+            self._scaled_weight = (key, weakref.ref(weight), w)
+        return w
 
     def _activation_grid(self, x=None) -> Optional[Quantizer]:
         """The grid the int8 image of x is formed on: the own input quantizer; else the LIVE output quantizer of the module
@@ -509,8 +578,11 @@ class QLinear(nn.Linear, _QuantizedOp):
         self._plan = plan
         return plan
 
-    def _forward_int8(self, x, weight, bias):
-        wq, oq, grid = self.weight_quantizer, self.output_quantizer, self._activation_grid(x)
+    def _input_image(self, x, weight):
+        """int8 image of the activation on this linear's input grid: (grid, a_q, a_rs, a_shift, tiled_rows, decode).  An image
+        left by a producer (fused norm) or a sibling linear wins: no quantize launch at all; the large FFN shapes want the
+        fragment-blocked layout of the generated-ISA GEMM kernels.  decode (M <= 8): no image, the GEMV quantises itself."""
+        grid = self._activation_grid(x)
         plan = self._weight_plan(weight)
         K, N = weight.shape[1], weight.shape[0]
         if grid.scale.device != x.device:
@@ -519,57 +591,85 @@ class QLinear(nn.Linear, _QuantizedOp):
         decode = x.dtype == torch.float32 and ops.decode_shape(x2d.shape[0], K)
         a_shift = 128 if grid.qmax > 127 else 0
         tiled_rows = None
-        if not decode:
-            # an integer image left by a producer (fused norm) or a sibling linear wins: no quantize launch at all.
-            # The large FFN shapes want the fragment-blocked layout of the generated-ISA GEMM loop.
-            eligible = (not plan["w4"]) and ops.gemm_tiled_supported(x2d.shape[0], N, K)
-            hit = _shared_activation.get(x, grid, ("tiled", a_shift)) if eligible else None
-            if hit is not None:
-                tiled_rows = x2d.shape[0]
-            else:
-                hit = _shared_activation.get(x, grid, a_shift)
-            if hit is None and eligible:
-                q_t, rs_t = ops.quantize_tiled(x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift)
-                hit = (q_t, rs_t, a_shift)
-                _shared_activation.put(x, grid, ("tiled", a_shift), hit)
-                tiled_rows = x2d.shape[0]
-            elif hit is None:
-                hit = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True)
-                _shared_activation.put(x, grid, a_shift, hit)
-            a_q, a_rs, a_shift = hit
+        cs = self.input_chan_scale
+        cs_tag = None if cs is None else ("cs", cs.data_ptr(), _ver(cs))      # images of x / s are not images of x
+        if decode and cs is not None:
+            decode = False                  # the fused decode GEMV quantises x itself: take quantize + GEMV instead
+        if decode:
+            return grid, None, None, a_shift, None, True
+        eligible = (not plan["w4"]) and ops.gemm_tiled_supported(x2d.shape[0], N, K)
+        hit = _shared_activation.get(x, grid, ("tiled", a_shift, cs_tag)) if eligible else None
+        if hit is not None:
+            tiled_rows = x2d.shape[0]
+        else:
+            hit = _shared_activation.get(x, grid, (a_shift, cs_tag))
+        if hit is None and eligible:
+            q_t, rs_t = ops.quantize_tiled(x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift,
+                                           chan_scale=cs)
+            hit = (q_t, rs_t, a_shift)
+            _shared_activation.put(x, grid, ("tiled", a_shift, cs_tag), hit)
+            tiled_rows = x2d.shape[0]
+        elif hit is None:
+            hit = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=True, chan_scale=cs)
+            _shared_activation.put(x, grid, (a_shift, cs_tag), hit)
+        a_q, a_rs, a_shift = hit
+        return grid, a_q, a_rs, a_shift, tiled_rows, False
+
+    def _forward_int8(self, x, weight, bias):
+        grid, a_q, a_rs, a_shift, tiled_rows, decode = self._input_image(x, weight)
+        return self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=decode)
+
+    def _epilogue_vectors(self, plan, grid, a_shift, K):
+        wq = self.weight_quantizer
         epi_key = (grid.grid_token(), a_shift)
         if plan["epi_key"] != epi_key:
             plan["alpha"], plan["w_zp"], plan["col_term"] = ops.linear_epilogue_prepare(
                 grid.scale.detach(), grid.offset.detach(), a_shift, wq.scale.detach(), wq.offset.detach(),
                 plan["shift"], plan["colsum"], K)
             plan["epi_key"] = epi_key
+        return plan
+
+    def _int8_from_image(self, x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=False, lead_shape=None):
+        """The GEMM half of the integer path: a ready int8 image of the activation (row-major, or fragment-blocked with
+        tiled_rows) on `grid` -> this linear's output.  x only supplies dtype / leading shape (and the fp32 values for the
+        fused decode GEMV); it may be None when lead_shape is given."""
+        oq = self.output_quantizer
+        K, N = weight.shape[1], weight.shape[0]
+        plan = self._epilogue_vectors(self._weight_plan(weight), grid, a_shift, K)
         fused = oq is not None and not oq.bypassed()
-        if fused and oq.scale.device != x.device:
-            oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
+        dev = a_q.device if a_q is not None else x.device
+        if fused and oq.scale.device != dev:
+            oq.scale.data, oq.offset.data = oq.scale.to(dev), oq.offset.to(dev)
+        lead = tuple(lead_shape) if lead_shape is not None else tuple(x.shape[:-1])
+        f16 = x is not None and x.dtype == torch.float16
         if decode:   # M <= 8: activation quantize fused into the weight-streaming GEMV (one launch)
+            x2d = x.reshape(-1, K)
             out = ops.int8_linear_f32in(
                 x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift, plan["w"], plan["alpha"],
                 plan["w_zp"], plan["col_term"], bias, out_scale=oq.scale.detach() if fused else None,
                 out_offset=oq.offset.detach() if fused else None, out_qmin=oq.qmin if fused else 0.0,
                 out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, w4=plan["w4"])
-            out = out.reshape(*x.shape[:-1], N)
+            out = out.reshape(*lead, N)
             return _tag_grid(out, oq) if fused else out
         out = ops.int8_linear(
             a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
             out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
             out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0,
-            out_dtype=MQ_F16 if x.dtype == torch.float16 else MQ_F32, w4=plan["w4"], a_tiled_rows=tiled_rows)
-        out = out.reshape(*x.shape[:-1], N)
+            out_dtype=MQ_F16 if f16 else MQ_F32, w4=plan["w4"], a_tiled_rows=tiled_rows)
+        out = out.reshape(*lead, N)
         return _tag_grid(out, oq) if fused else out
 
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
         bias = self.temp_bias if self.use_temporary_parameter else self.bias
+        weight = self._effective_weight(weight)
         if self._int8_ready(input_, weight):
             return self._forward_int8(input_, weight, bias)
         # simulated path: HIP fake-quant kernels around the library GEMM
         weight = _apply(self.weight_quantizer, weight)
+        if self.input_chan_scale is not None:
+            input_ = input_ / self.input_chan_scale.to(input_.dtype)
         input_ = _apply(self.input_quantizer, input_)
         out = F.linear(input_, weight, bias=bias)
         return _apply(self.output_quantizer, out)
@@ -651,9 +751,9 @@ def _fused_norm(self, input_, weight, bias, layernorm):
         return _tag_grid(res, self.output_quantizer) if go is not None else res
     y, q, rs, shift, qt = res
     _tag_grid(y, self.output_quantizer)
-    _shared_activation.put(y, self.output_quantizer, shift, (q, rs, shift))
+    _shared_activation.put(y, self.output_quantizer, (shift, None), (q, rs, shift))
     if qt is not None:
-        _shared_activation.put(y, self.output_quantizer, ("tiled", shift), (qt, rs, shift))
+        _shared_activation.put(y, self.output_quantizer, ("tiled", shift, None), (qt, rs, shift))
     return y
 
 
@@ -931,6 +1031,93 @@ def set_scale_and_offset(model, act_dict, use_scale_offset_as="buffer"):
             assert name in act_dict
             module.set_scale_offset(act_dict[name], use_scale_offset_as)
     return model
+
+
+def _u8_grid(q: Optional[Quantizer]) -> bool:
+    return _static_per_tensor(q, 8) and q.qmin == 0 and q.qmax == 255
+
+
+def _gated_mlp_forward(self, x):
+    """``w2(act_fn(w1(x)) * w3(x))`` (hf_model.py:1057) on the integer chain, in four launches and without a single fp32
+    intermediate: [int8 image of x -- usually left by the norm] -> ONE pair GEMM writing the 8-bit output indices of w1 and
+    w3 -> ONE gated-activation kernel (dequantise the indices, QSiLU / QGELU, product, w2's input quantizer -> int8 + row sums)
+    -> w2's GEMM.  Bit-identical to the chain of modules on their integer paths; anything the chain cannot serve falls back to
+    the chain itself."""
+    w1, w2, w3, act = self.w1, self.w2, self.w3, self.act_fn
+    plain = self._mq_plain_forward
+
+    def weight_of(m):
+        return m._effective_weight(m.temp_weight if m.use_temporary_parameter else m.weight)
+    if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32
+            or any(m.use_temporary_parameter or m.input_chan_scale is not None for m in (w1, w2, w3))):
+        return plain(x)
+    wt1, wt3, wt2 = weight_of(w1), weight_of(w3), weight_of(w2)
+    if not (w1._int8_ready(x, wt1) and w3._int8_ready(x, wt3) and wt1.shape == wt3.shape):
+        return plain(x)
+    M, (N, K) = x.numel() // x.shape[-1], wt1.shape
+    if not (_u8_grid(w1.output_quantizer) and _u8_grid(w3.output_quantizer) and _u8_grid(w2.input_quantizer)
+            and ops.gemm_tiled_supported(M, N, K) and K >= 768 and K % 256 == 0 and N % 16 == 0):
+        return plain(x)
+    silu = isinstance(act, QSiLU)
+    act_in = act.input_quantizer
+    if act_in is not None and not act_in.bypassed():
+        return plain(x)                     # (the surgery leaves QSiLU / QGELU without an input quantizer, qmodule.py:855,858)
+    mid = QRMSNorm._grid_or_none(act.input2_quantizer) if silu else None
+    aout = QRMSNorm._grid_or_none(act.output_quantizer)
+    if mid is False or aout is False or act.fused_mode == "off":
+        return plain(x)
+    g1, g3 = w1._activation_grid(x), w3._activation_grid(x)
+    if g1.grid_token() != g3.grid_token():
+        return plain(x)
+    # w2: what _int8_ready would check on the product tensor, which never exists here
+    wq2, oq2 = w2.weight_quantizer, w2.output_quantizer
+    if (w2.int8_mode == "off" or wq2 is None or wq2.bypassed() or wq2.qcfg.bitwidth > 8 or wq2.qcfg.is_dynamic or wq2.lwc
+            or (wq2.qcfg.is_per_channel and wq2.qcfg.group_size != -1) or wt2.shape[1] % 128 or wt2.shape[0] % 4
+            or (oq2 is not None and not oq2.bypassed() and not _static_per_tensor(oq2, 16))
+            or _needs_grad(wt2, w2.bias, getattr(wq2, "scale", None))):
+        return plain(x)
+    grid, a_q, a_rs, a_shift, tiled_rows, _ = w1._input_image(x, wt1)
+    if tiled_rows is None:
+        return plain(x)
+    halves = []
+    for m, wt in ((w1, wt1), (w3, wt3)):
+        plan = m._epilogue_vectors(m._weight_plan(wt), grid, a_shift, K)
+        oq = m.output_quantizer
+        if oq.scale.device != x.device:
+            oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
+        halves.append(dict(w=plan["w"], alpha=plan["alpha"], w_zp=plan["w_zp"], col_term=plan["col_term"],
+                           bias=m.temp_bias if m.use_temporary_parameter else m.bias, out_scale=oq.scale.detach(),
+                           out_offset=oq.offset.detach()))
+    a_idx, b_idx = ops.int8_linear_pair(a_q, M, a_rs, halves[0], halves[1], out_dtype=MQ_U8)
+    iq2 = w2.input_quantizer
+    for q in (iq2, act.output_quantizer, act.input2_quantizer if silu else None):
+        if q is not None and not q.bypassed() and q.scale.device != x.device:
+            q.scale.data, q.offset.data = q.scale.to(x.device), q.offset.to(x.device)
+    o1, o3 = w1.output_quantizer, w3.output_quantizer
+    p_q, p_rs = ops.gated_act_quant(a_idx, b_idx, "silu" if silu else "gelu",
+                                    (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),
+                                    a_grid=(o1.scale.detach(), o1.offset.detach()), b_grid=(o3.scale.detach(), o3.offset.detach()),
+                                    mid_grid=QRMSNorm._grid_or_none(act.input2_quantizer) if silu else None,
+                                    act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
+    return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q.view(M, N), p_rs, 128,
+                               None, lead_shape=x.shape[:-1])
+
+
+def fuse_gated_mlp(model) -> int:
+    """Graph pass (like wire_integer_inputs, no counterpart in the reference): every block with QLinear children w1 / w2 / w3
+    and a QSiLU / QGELU child act_fn -- the reference's HFMLP after create_sim_qmodel (hf_model.py:1042-1062) -- gets the
+    integer-chain forward above.  The block keeps its children and parameters; `block.fused_mode = "off"` restores the chain.
+    Returns the number of blocks fused."""
+    import types
+    n = 0
+    for _, m in model.named_modules():
+        kids = dict(m.named_children())
+        if (all(isinstance(kids.get(k), QLinear) for k in ("w1", "w2", "w3")) and isinstance(kids.get("act_fn"), (QSiLU, QGELU))
+                and not hasattr(m, "_mq_plain_forward")):
+            m._mq_plain_forward = m.forward
+            m.forward = types.MethodType(_gated_mlp_forward, m)
+            n += 1
+    return n
 
 
 def wire_integer_inputs(model, act_bitwidth=8, act_is_symmetric=False):

@@ -19,6 +19,11 @@ Fixtures written (all data, no reference source text):
   qact_cases.npz          a10    QSiLU / QGELU.forward (sigmoid grid [0,1], 8- and 16-bit outputs)
   nonfinite_cases.npz     a1/a3/a5 NaN and +-inf inputs: torch.clamp / amin / amax propagate NaN
   api_surface.json        state_dict keys / export_qcfg / export_act_range of a toy sim model
+  lwc_cases.npz           a7     learnable weight clipping: forward values, gradients to the bound factors and the weight, run_lwc
+  qmatmul_cases.npz       a10    QMatMul.forward at attention shapes (qk_bmm / pv_bmm mixed-precision rules)
+  toy_lm_nll.npz          perplexity proxy: the reference's W8A8-sim logits + NLL of the toy LM on 96 tokens
+  smooth_cases.npz        n1/f3/f4 on the reference's real HFForCausalLM (2 layers): fp logits, get_act_scales, smooth_lm fold,
+                          smooth_lm_temporary / _inplace (LET) temp weights, Quantizer indices of x / s
 """
 import hashlib
 import importlib.util
@@ -59,7 +64,7 @@ torch.set_num_threads(1)          # fixed summation order for the fp32 matmuls w
 
 
 def npf(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()       # a COPY: .numpy() aliases the tensor, and smooth_lm / *_inplace rewrite weights in place
 
 
 def sha(a: np.ndarray) -> str:
@@ -604,8 +609,248 @@ def gen_api_surface():
                         **{"sd|" + k: v for k, v in sd0.items()})
 
 
+# ------------------------------------------------------------------------------------------------
+def gen_lwc_cases():
+    """a7: learnable weight clipping (qmodule.py:133-185, :262-277).  Every recipe passes --lwc, so the forward values with
+    non-trivial bound factors, the gradients to upbound_factor / lowbound_factor / the weight (autograd of the reference,
+    incl. the amin / amax path into the extreme elements) and run_lwc's clamped weights are frozen."""
+    out, meta = {}, []
+    g = torch.Generator().manual_seed(77)
+    for tag, bits, sym, per_ch, shape in (("pt8", 8, False, False, (24, 64)), ("pc8", 8, False, True, (24, 64)),
+                                          ("pc4", 4, False, True, (16, 128)), ("pc4s", 4, True, True, (16, 128))):
+        w = (torch.randn(shape, generator=g) * 0.05)
+        qz = Q.Quantizer(Q.QuantConfig(bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch))
+        with torch.enable_grad():
+            wp = w.clone().requires_grad_(True)
+            qz.enable_lwc(wp)
+            up0 = (torch.randn(qz.upbound_factor.shape, generator=g) * 0.7 + 1.5)
+            lo0 = (torch.randn(qz.lowbound_factor.shape, generator=g) * 0.7 + 1.5)
+            qz.upbound_factor.data.copy_(up0)
+            qz.lowbound_factor.data.copy_(lo0)
+            y = qz(wp)
+            gy = torch.randn(shape, generator=g)
+            (y * gy).sum().backward()
+        out[tag + "_w"], out[tag + "_up"], out[tag + "_lo"], out[tag + "_gy"] = npf(w), npf(up0), npf(lo0), npf(gy)
+        out[tag + "_y"] = npf(y)
+        out[tag + "_scale"], out[tag + "_offset"] = npf(qz.scale), npf(qz.offset)
+        out[tag + "_g_up"], out[tag + "_g_lo"], out[tag + "_g_w"] = npf(qz.upbound_factor.grad), npf(qz.lowbound_factor.grad), npf(wp.grad)
+        out[tag + "_clamped"] = npf(qz.run_lwc(w))           # also drops the LWC state (qmodule.py:176-180)
+        assert not qz.lwc and not hasattr(qz, "upbound_factor")
+        meta.append(dict(id=tag, bitwidth=bits, is_symmetric=sym, is_per_channel=per_ch))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "lwc_cases.npz"), **out)
+    print("lwc_cases:", len(meta))
+
+
+def gen_qmatmul_cases():
+    """a10: QMatMul.forward (qmodule.py:453-466) at attention shapes under the mixed-precision rules of
+    ptq/mobilequant.py:190-201: qk_bmm (8-bit q, 8-bit k^T, 16-bit scores) and pv_bmm (16-bit probabilities, 8-bit v, 8-bit
+    output), plus a plain 8/8/8 case; k^T enters as a transposed view exactly as hf_model.py:513 passes it."""
+    out, meta = {}, []
+    g = torch.Generator().manual_seed(123)
+    H, S, D = 4, 48, 32
+    q = torch.randn(1, H, S, D, generator=g)
+    k = torch.randn(1, H, S, D, generator=g)
+    v = torch.randn(1, H, S, D, generator=g)
+    probs = torch.softmax(torch.randn(1, H, S, S, generator=g) * 2, dim=-1)
+
+    def run(tag, a, b, bits):
+        m = Q.QMatMul(Q.QuantConfig(bitwidth=bits[0]), Q.QuantConfig(bitwidth=bits[1]), Q.QuantConfig(bitwidth=bits[2]))
+        y_fp = torch.matmul(a, b)
+        act = {"input": [a.min().item(), a.max().item()], "input2": [b.min().item(), b.max().item()],
+               "output": [y_fp.min().item(), y_fp.max().item()]}
+        m.set_scale_offset(act, "buffer")
+        y = m(a, b)
+        out[tag + "_a"], out[tag + "_b"], out[tag + "_y"] = npf(a), npf(b.contiguous()), npf(y)
+        meta.append(dict(id=tag, bits=list(bits), act=act, b_transposed=(tag != "pv")))
+    run("qk", q, k.transpose(2, 3), (8, 8, 16))
+    run("pv", probs, v, (16, 8, 8))
+    run("qk888", q, k.transpose(2, 3), (8, 8, 8))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "qmatmul_cases.npz"), **out)
+    print("qmatmul_cases:", len(meta))
+
+
+def gen_toy_lm_nll():
+    """Proxy for "quantized perplexity within 0.05 of the reference" (no checkpoints / datasets offline): the reference's own
+    W8A8-sim logits of the 2-block toy LM on a 96-token input, with seeded labels -- the test compares the NLL / perplexity of
+    the HIP path against the NLL / perplexity of these frozen logits."""
+    torch.manual_seed(3)
+    m = _ToyLM().eval()
+    sd0 = {k: npf(v) for k, v in m.state_dict().items()}
+    gg = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 96, 32, generator=gg)
+    labels = torch.randint(0, 50, (96,), generator=gg)
+    fp = m(x)
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+
+    class _M(nn.Module):
+        def __init__(s, inner):
+            super().__init__(); s.inner = inner
+        def forward(s, ids):
+            return s.inner(x)
+    act = rng_mod.get_act_range(_M(m), _Tok(), [{"text": "1 2 3"}], 1, 8)
+    act = {k[len("inner."):]: v for k, v in act.items()}
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=8), Q.QuantConfig(bitwidth=8))
+    for name, mod in m.named_modules():          # mixed precision rules of ptq/mobilequant.py:175-201
+        if isinstance(mod, Q.QLinear):
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    Q.set_scale_and_offset(m, act, "buffer")
+    yq = m(x)
+    nll = lambda lg: float(torch.nn.functional.cross_entropy(lg[0], labels))      # noqa: E731
+    np.savez_compressed(os.path.join(OUT, "toy_lm_nll.npz"), x=npf(x), labels=npf(labels), y_fp=npf(fp), y_w8a8=npf(yq),
+                        act=np.array(json.dumps(act)), nll_fp=np.float64(nll(fp)), nll_w8a8=np.float64(nll(yq)),
+                        **{"sd|" + k: v for k, v in sd0.items()})
+    print("toy_lm_nll: nll fp %.5f w8a8 %.5f" % (nll(fp), nll(yq)))
+
+
+# ------------------------------------------------------------------------------------------------
+def _tiny_hf(kv_heads, seed):
+    from mobilellm.model.hf_config import HFConfig
+    from mobilellm.model.hf_model import HFForCausalLM
+    cfg = HFConfig(vocab_size=50, hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+                   num_key_value_heads=kv_heads, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(seed)
+    m = HFForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():                      # livelier statistics than the default init
+            if p_.dim() >= 2:
+                p_.normal_(0.0, 0.3)
+            else:
+                p_.uniform_(0.5, 1.5)
+    return m, cfg
+
+
+def gen_smooth_cases():
+    """n1 / f3 / f4 on the reference's REAL model classes (HFForCausalLM, 2 layers, hidden 64):
+      * fp logits (pins mobilequant_amd/llama.py against hf_model.py);
+      * get_act_scales (generate_act_scale_shift.py:42-93) -> smooth_lm (smoothquant.py:109-139): weights after the fold, with
+        grouped-query heads (v -> o fold skipped, as for TinyLlama) and with full heads (v -> o folded);
+      * smooth_lm_temporary (algorithm.py:187-233) with LET scales / shifts on a sim-quantised layer: every temp_weight /
+        temp_bias and the layer output;
+      * the run-time activation form: reference Quantizer indices of x / s for the scales smooth_ln_fcs derives."""
+    sq = _load_script(os.path.join(REF, "ptq", "smoothquant.py"), ["x", "--hf_path", "none"])
+    ss = _load_script(os.path.join(REF, "ptq", "generate_act_scale_shift.py"), ["x", "--hf_path", "none"])
+    import mobilellm.quantization.algorithm as A
+    out, meta = {}, {}
+    for tag, kv in (("gqa", 2), ("mha", 4)):
+        m, cfg = _tiny_hf(kv, 5 + kv)
+        g = torch.Generator().manual_seed(31 + kv)
+        ids = [torch.randint(0, 50, (1, 24), generator=g) for _ in range(3)]
+        out[tag + "_ids"] = np.stack([npf(i[0]) for i in ids])
+        for k_, v_ in m.state_dict().items():
+            out[f"{tag}|sd|{k_}"] = npf(v_)
+        out[tag + "_logits_fp"] = npf(m(ids[0], use_cache=False).logits)
+
+        class _Tk:
+            bos_token_id, vocab_size = 1, 50
+            def __call__(s_, line, return_tensors="pt", max_length=None, truncation=True):
+                return types.SimpleNamespace(input_ids=ids[int(line)])
+        ss.args.use_rand_samples = False
+        _orig = m.forward
+        m.forward = lambda x_, **kw: _orig(x_, use_cache=False)      # the scripts call model(ids); transformers 5 needs use_cache=False
+        scales = ss.get_act_scales(m, _Tk(), [{"text": str(i)} for i in range(3)], 3, 64)
+        m.forward = _orig
+        for k_, v_ in scales.items():
+            out[f"{tag}|scale|{k_}"] = npf(v_)
+        sq.smooth_lm(m, scales, 0.5, False, False)
+        for k_, v_ in m.state_dict().items():
+            out[f"{tag}|smoothed|{k_}"] = npf(v_)
+        out[tag + "_logits_smoothed"] = npf(m(ids[0], use_cache=False).logits)
+        meta[tag] = dict(kv_heads=kv, alpha=0.5)
+
+    # ---- LET temporary weights on a sim-quantised decoder layer (MHA so that every pair exists) -----------------------
+    m, cfg = _tiny_hf(4, 77)
+    g = torch.Generator().manual_seed(5)
+    layer = m.model.layers[0]
+    for k_, v_ in layer.state_dict().items():
+        out[f"let|sd|{k_}"] = npf(v_)
+    Q.create_sim_qmodel(layer, Q.QuantConfig(bitwidth=8, is_per_channel=True), Q.QuantConfig(bitwidth=8))
+    with torch.no_grad():
+        for lin in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj, layer.mlp.w1,
+                    layer.mlp.w2, layer.mlp.w3):            # LET on q/k needs biases (algorithm.py:89-96); give every linear one
+            lin.bias = nn.Parameter(torch.randn(lin.out_features, generator=g) * 0.1)
+    for k_, v_ in layer.state_dict().items():
+        if k_.endswith(".bias"):
+            out[f"let|sd|{k_}"] = npf(v_)
+    params = {}
+    for name, dim in (("qkv", 64), ("fc1", 64), ("out", 64), ("fc2", 96), ("qkt", 64)):
+        sc = torch.rand(dim, generator=g) * 1.5 + 0.5
+        layer.register_parameter(f"{name}_smooth_scale", nn.Parameter(sc))
+        params[f"{name}_smooth_scale"] = sc
+        if name != "qkt":
+            sh = torch.randn(dim, generator=g) * 0.1
+            layer.register_parameter(f"{name}_smooth_shift", nn.Parameter(sh))
+            params[f"{name}_smooth_shift"] = sh
+    for k_, v_ in params.items():
+        out["let|param|" + k_] = npf(v_)
+    A.smooth_lm_temporary(layer, cfg, True, use_shift=True)
+    for name, mod in layer.named_modules():
+        if isinstance(mod, (Q.QLinear, Q.QRMSNorm)):
+            out[f"let|temp_weight|{name}"] = npf(mod.temp_weight)
+            if getattr(mod, "temp_bias", None) is not None:
+                out[f"let|temp_bias|{name}"] = npf(mod.temp_bias)
+    A.smooth_lm_inplace(layer, cfg, True, use_shift=True)
+    for k_, v_ in layer.state_dict().items():
+        if k_.endswith("weight") or k_.endswith("bias"):
+            out[f"let|inplace|{k_}"] = npf(v_)
+
+    # ---- the run-time activation form: indices of x / s ---------------------------------------------------------------
+    x = torch.randn(40, 128, generator=g) * torch.linspace(0.2, 6.0, 128)         # outlier channels, what SmoothQuant is for
+    w = torch.randn(96, 128, generator=g) * 0.05
+    act_scales = x.abs().max(0)[0]
+    wsc = w.abs().max(0)[0].clamp(min=1e-5)
+    sc = (act_scales.pow(0.5) / wsc.pow(0.5)).clamp(min=1e-5)                     # smoothquant.py:60-62
+    xs = x / sc
+    qz = Q.Quantizer(Q.QuantConfig(bitwidth=8))
+    qz.set_scale_offset_from_minmax(xs.min().item(), xs.max().item(), "buffer", None)
+    y = qz(xs)
+    out["cs_x"], out["cs_scales"], out["cs_range"] = npf(x), npf(sc), np.array([xs.min().item(), xs.max().item()], np.float32)
+    out["cs_y"], out["cs_index"] = npf(y), npf(ref_index(qz, xs)[0])
+    out["cs_w"], out["cs_w_scaled"] = npf(w), npf(w * sc.view(1, -1))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "smooth_cases.npz"), **out)
+    print("smooth_cases:", len(out), "arrays")
+
+
+def gen_artifacts():
+    """a14: files as the reference's own writers produce them -- act_dict.json through mobilellm.utils.io.json_save (io.py:34-36)
+    from the toy model's calibrated ranges, act_scales.pth through torch.save of get_act_scales' dictionary
+    (generate_act_scale_shift.py:170-175).  Data files only."""
+    from mobilellm.utils.io import json_save
+    act = json.load(open(os.path.join(OUT, "api_surface.json")))["act_dict"]
+    json_save(os.path.join(OUT, "act_dict_ref.json"), act)
+    z = np.load(os.path.join(OUT, "smooth_cases.npz"))
+    scales = {k.split("|", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith("gqa|scale|")}
+    torch.save(scales, os.path.join(OUT, "act_scales_ref.pth"))
+    print("artifacts: act_dict_ref.json", os.path.getsize(os.path.join(OUT, "act_dict_ref.json")), "bytes; act_scales_ref.pth", len(scales), "tensors")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    if only:                                  # python oracle/gen_golden.py gen_lwc_cases ...: regenerate selected fixtures
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
+    gen_lwc_cases()
+    gen_qmatmul_cases()
+    gen_toy_lm_nll()
+    gen_smooth_cases()
     gen_scale_offset_grid()
     gen_quantizer_cases()
     gen_nonfinite()
@@ -616,5 +861,6 @@ if __name__ == "__main__":
     gen_calib_stream()
     gen_checksums()
     gen_api_surface()
+    gen_artifacts()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", os.path.normpath(OUT), f"({tot/1024:.0f} KiB)")

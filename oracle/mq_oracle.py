@@ -410,3 +410,90 @@ def unpack_w4(packed, qmin: int):
     blk = p.reshape(n, kh // 16, 16).astype(np.int32)
     out = np.stack((blk & 15, blk >> 4), axis=2).reshape(n, kh * 2)
     return out + qmin
+
+
+# ----------------------------------------------------------------------------------------------
+# a7  learnable weight clipping                      qmodule.py:133-185, :262-277
+# ----------------------------------------------------------------------------------------------
+def sigmoid_f32(x):
+    """torch.sigmoid in fp32 (vectorised CPU kernels differ from this expression by at most one ulp; tests state it)."""
+    x = np.asarray(x, dtype=F32)
+    return (F32(1.0) / (F32(1.0) + np.exp(-x).astype(F32))).astype(F32)
+
+
+def lwc_range(w, up_factor, low_factor, is_per_channel: bool):
+    """Clipped range of a weight under LWC: ``max * sigmoid(upbound_factor)``, ``min * sigmoid(lowbound_factor)``
+    (qmodule.py:271-273; the same lines in run_lwc :172-174)."""
+    mn, mx = min_max_from_tensor(w, is_per_channel, -1)
+    return (sigmoid_f32(low_factor) * mn).astype(F32), (sigmoid_f32(up_factor) * mx).astype(F32)
+
+
+def lwc_forward(w, up_factor, low_factor, bitwidth: int, is_symmetric: bool, is_per_channel: bool):
+    """Quantizer.forward with LWC enabled (qmodule.py:262-290): grid from the clipped range, then fake-quant.
+    Returns (y, scale, offset)."""
+    mn, mx = lwc_range(w, up_factor, low_factor, is_per_channel)
+    scale, offset, qmin, qmax = scale_offset_from_min_max(mn, mx, bitwidth, is_symmetric)
+    return fake_quant(w, scale, offset, qmin, qmax), scale, offset
+
+
+def run_lwc(w, up_factor, low_factor, is_per_channel: bool):
+    """Quantizer.run_lwc (qmodule.py:159-185): clamp the weight to its clipped range."""
+    mn, mx = lwc_range(w, up_factor, low_factor, is_per_channel)
+    return np.clip(np.asarray(w, dtype=F32), mn, mx).astype(F32)
+
+
+def lwc_backward(w, up_factor, low_factor, grad_y, bitwidth: int, is_symmetric: bool, is_per_channel: bool):
+    """Gradients of ``(lwc_forward(w) * grad_y).sum()`` w.r.t. upbound_factor, lowbound_factor and w, as torch autograd derives
+    them from qmodule.py:262-290 + :40-61: through fake_quant to (scale, offset) (fake_quant_backward), through
+    ``scale = clamp(alpha / qmax)``, ``offset = -round(beta / scale)`` (round: zero gradient) to the clipped (min, max), through
+    the sigmoid to the factors, and through amin / amax (gradient to the extreme element, split evenly between ties) to w."""
+    w = np.asarray(w, dtype=F32)
+    mn0, mx0 = min_max_from_tensor(w, is_per_channel, -1)
+    su, sl = sigmoid_f32(up_factor), sigmoid_f32(low_factor)
+    mn, mx = (sl * mn0).astype(F32), (su * mx0).astype(F32)
+    scale, offset, qmin, qmax = scale_offset_from_min_max(mn, mx, bitwidth, is_symmetric)
+    gx, gs, go = fake_quant_backward(w, grad_y, scale, offset, qmin, qmax)
+    # offset = -round(beta / scale): torch.round has zero gradient -> nothing flows through the offset
+    raw = (mx - mn) / F32(qmax) if not is_symmetric else np.maximum(np.abs(mn), np.abs(mx)) / F32(qmax)
+    inside = ((raw >= CLIPMIN) & (raw <= CLIPMAX)).astype(F32)            # clamp(min=1e-5, max=1e6)
+    g_alpha = gs.reshape(np.shape(scale)) * inside / F32(qmax)
+    if is_symmetric:
+        take_max = (np.abs(mx) >= np.abs(mn)).astype(F32)                 # torch.maximum: gradient to the larger (ties: split)
+        tie = (np.abs(mx) == np.abs(mn)).astype(F32)
+        wmx = take_max - 0.5 * tie
+        wmn = (1 - take_max) + 0.5 * tie
+        g_mx = g_alpha * wmx * np.sign(mx)
+        g_mn = g_alpha * wmn * np.sign(mn)
+    else:
+        g_mx, g_mn = g_alpha, -g_alpha
+    g_up = (g_mx * mx0 * su * (1 - su)).astype(F32)
+    g_lo = (g_mn * mn0 * sl * (1 - sl)).astype(F32)
+    # amax / amin backward: the extreme element(s) of each reduction group
+    is_mx = (w == mx0).astype(F32)
+    is_mn = (w == mn0).astype(F32)
+    ax = -1 if is_per_channel else None
+    g_w = gx + (g_mx * su) * is_mx / is_mx.sum(axis=ax, keepdims=is_per_channel) \
+             + (g_mn * sl) * is_mn / is_mn.sum(axis=ax, keepdims=is_per_channel)
+    return g_up, g_lo, g_w.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# a10  QMatMul.forward                               qmodule.py:453-466
+# ----------------------------------------------------------------------------------------------
+def qmatmul_sim(a, b, q1: QuantizerOracle | None, q2: QuantizerOracle | None, out_q: QuantizerOracle | None):
+    """fake-quant both operands, fp32 matmul (summation order BLAS-defined), fake-quant the product."""
+    a = np.asarray(a, dtype=F32)
+    b = np.asarray(b, dtype=F32)
+    if q1 is not None:
+        a = q1.forward(a)
+    if q2 is not None:
+        b = q2.forward(b)
+    out = np.matmul(a, b).astype(F32)
+    return out_q.forward(out) if out_q is not None else out
+
+
+def qmatmul_int_exact(qa, za, sa, qb, zb, sb):
+    """Integer equivalent of the product inside QMatMul: ``sa*sb * sum_k (qa-za)(qb-zb)`` with an exact contraction (float64
+    BLAS over integers), scaled once: one int -> fp32 conversion, one multiply by fp32(sa*sb).  qa [..., M, K], qb [..., K, N]."""
+    acc = np.rint(np.matmul((np.asarray(qa, np.float64) - np.float64(za)), (np.asarray(qb, np.float64) - np.float64(zb)))).astype(np.int64)
+    return acc, (acc.astype(F32) * (F32(sa) * F32(sb))).astype(F32)

@@ -55,7 +55,7 @@ def test_library_contains_gfx950_code_only(lib_path):
 def test_binding_loads_and_reports_errors_without_a_gpu(lib_path):
     from mobilequant_amd import _lib
     lib = _lib.load()
-    assert lib.mq_version() >= 100
+    assert lib.mq_version() >= 200
     nvar = lib.mq_gemm_set_variant(-1)
     assert nvar >= 4 and lib.mq_gemm_variant_name(0).decode().startswith("t")
     # argument validation happens before any HIP call: null pointers -> MQ_EINVAL + a message, no crash
@@ -108,7 +108,7 @@ def test_argument_checks_fail_before_any_launch():
     lib = L.load()
     p = ctypes.c_void_p(0x10000)
     # cols must be a multiple of 128 for the fragment-blocked layout
-    assert lib.mq_quantize_tiled(p, L.MQ_F32, 32, 100, p, p, 0.0, 255.0, 128, p, None, None) == 1
+    assert lib.mq_quantize_tiled(p, L.MQ_F32, 32, 100, p, p, 0.0, 255.0, 128, None, p, None, None) == 1
     assert b"multiple of 128" in lib.mq_last_error()
     # fused norm: cols % 4, integer output without an output grid
     assert lib.mq_rmsnorm_quant(p, 4, 30, p, None, 1e-5, None, None, 0.0, 0.0, None, None, 0.0, 0.0, p, None, None, 0, None, None) == 1

@@ -244,3 +244,321 @@ def test_get_act_range_end_to_end_through_an_rccl_all_reduce(dev, nccl_single_ra
                 assert torch.equal(forced[name][field], plain[name][field]) and torch.equal(forced[name][field], want[name][field].cpu())
             else:
                 assert forced[name][field] == plain[name][field] == want[name][field], (name, field)
+
+
+# ---- a7: learnable weight clipping against the reference's frozen forward / autograd -------------------------------------------
+def test_lwc_forward_backward_and_run_lwc_golden(dev):
+    import mobilequant_amd as mq
+    from conftest import load_meta, load_npz
+    z = load_npz("lwc_cases.npz")
+    for m in load_meta(z):
+        t = m["id"]
+        qz = mq.Quantizer(mq.QuantConfig(bitwidth=m["bitwidth"], is_symmetric=m["is_symmetric"], is_per_channel=m["is_per_channel"]))
+        w = T(z[t + "_w"], dev).requires_grad_(True)
+        qz.enable_lwc(w)
+        assert qz.upbound_factor.shape == z[t + "_up"].shape and float(qz.upbound_factor.flatten()[0]) == 4.0     # init 4.0 (qmodule.py:135)
+        with torch.no_grad():
+            qz.upbound_factor.copy_(T(z[t + "_up"], dev))
+            qz.lowbound_factor.copy_(T(z[t + "_lo"], dev))
+        y = qz(w)
+        (y * T(z[t + "_gy"], dev)).sum().backward()
+        want_y = z[t + "_y"]
+        d = np.abs(y.detach().cpu().numpy() - want_y)
+        # the grid comes from sigmoid(factor) * range: one ulp of the device sigmoid moves values by ~1e-7 relative, never a grid step
+        assert d.max() <= 4e-8 + 1e-6 * np.abs(want_y).max(), (t, d.max())
+        assert np.allclose(qz.scale.detach().cpu().numpy().reshape(-1), z[t + "_scale"].reshape(-1), rtol=3e-7, atol=0)
+        assert np.array_equal(qz.offset.detach().cpu().numpy().reshape(-1), z[t + "_offset"].reshape(-1))
+        for got, key in ((qz.upbound_factor.grad, "_g_up"), (qz.lowbound_factor.grad, "_g_lo"), (w.grad, "_g_w")):
+            want = z[t + key]
+            assert got is not None and np.abs(got.cpu().numpy().reshape(-1) - want.reshape(-1)).max() <= 1e-5 * np.abs(want).max(), (t, key)
+        with torch.no_grad():
+            clamped = qz.run_lwc(T(z[t + "_w"], dev))
+        assert np.abs(clamped.cpu().numpy() - z[t + "_clamped"]).max() <= 4e-8
+        assert not qz.lwc and not hasattr(qz, "upbound_factor") and not hasattr(qz, "scale")      # run_lwc drops the state
+
+
+# ---- a10: QMatMul against the reference at attention shapes ----------------------------------------------------------------------
+def test_qmatmul_golden(dev):
+    import mobilequant_amd as mq
+    from conftest import load_meta, load_npz
+    z = load_npz("qmatmul_cases.npz")
+    for m in load_meta(z):
+        t = m["id"]
+        mod = mq.QMatMul(*(mq.QuantConfig(bitwidth=b) for b in m["bits"]))
+        mod.set_scale_offset(m["act"], "buffer")
+        a, b = T(z[t + "_a"], dev), T(z[t + "_b"], dev)
+        if m["b_transposed"]:            # the reference passes k.transpose(2, 3): a non-contiguous view
+            b = b.transpose(2, 3).contiguous().transpose(2, 3)
+            assert not b.is_contiguous()
+        with torch.no_grad():
+            y = mod(a, b).cpu().numpy()
+        lsb = float(mod.output_quantizer.scale)
+        d = np.abs(y - z[t + "_y"])
+        assert d.max() <= lsb * 1.001 and (d == 0).mean() > 0.99, (t, d.max() / lsb, (d == 0).mean())
+
+
+# ---- perplexity proxy: NLL of the toy LM against the reference's W8A8-sim logits ----------------------------------------------
+def test_toy_lm_nll_within_perplexity_bound_of_reference(dev):
+    """north_star: "quantized perplexity within 0.05 of reference".  No checkpoints / datasets offline, so: the reference's own
+    W8A8-sim logits of a 2-block toy LM on 96 tokens are frozen (tests/golden/toy_lm_nll.npz); the HIP path (integer linears,
+    fused norms, chained int8 activations) must reproduce their NLL so that |perplexity - reference perplexity| <= 0.05."""
+    import json
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    from toy_models import ToyLM, apply_mixed_precision
+    z = load_npz("toy_lm_nll.npz")
+    m = ToyLM().eval()
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd|")})
+    m = m.to(dev)
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(m, a8, a8)
+    apply_mixed_precision(m, mq)
+    mq.set_scale_and_offset(m, json.loads(str(z["act"])), "buffer")
+    mq.wire_integer_inputs(m)
+    labels = torch.from_numpy(z["labels"]).to(dev)
+    nll = lambda lg: float(torch.nn.functional.cross_entropy(lg[0], labels))       # noqa: E731
+    with torch.no_grad():
+        for mode in ("auto", "off"):            # integer path and simulated (HIP fake-quant) path
+            for mod in m.modules():
+                if isinstance(mod, mq.QLinear):
+                    mod.int8_mode = mode
+            got = nll(m(T(z["x"], dev)))
+            ref = float(z["nll_w8a8"])
+            assert abs(np.exp(got) - np.exp(ref)) <= 0.05, (mode, got, ref, np.exp(got) - np.exp(ref))
+            assert abs(got - ref) <= 1e-3, (mode, got, ref)
+    assert abs(float(z["nll_w8a8"]) - float(z["nll_fp"])) < 0.05           # the fixture itself: quantisation moved the NLL, mildly
+
+
+# ---- n1 / f3 / f4: SmoothQuant statistics, fold, LET temporaries, run-time channel scale ------------------------------------
+def test_chan_scale_fused_quantize_bit_exact_vs_reference(dev):
+    """mq_quantize / mq_quantize_tiled with chan_scale: the index of x / s, bit-exact against the reference Quantizer applied to
+    x / s (scales from smoothquant.py:60-62); same row sums in both layouts; NULL chan_scale is the plain kernel."""
+    from conftest import load_npz
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_I8, MQ_U8
+    z = load_npz("smooth_cases.npz")
+    x, s = T(z["cs_x"], dev), T(z["cs_scales"], dev)
+    lo, hi = (float(v) for v in z["cs_range"])
+    sc, of, qmin, qmax = O.scale_offset_from_min_max(lo, hi, 8, False)
+    sct, oft = T(np.array([sc], F32), dev), T(np.array([of], F32), dev)
+    q = ops.quantize(x, sct, oft, qmin, qmax, q_dtype=MQ_U8, rows=x.shape[0], chan_scale=s)
+    assert np.array_equal(q.cpu().numpy().astype(np.float32), z["cs_index"])
+    q8, rs = ops.quantize(x, sct, oft, qmin, qmax, q_dtype=MQ_I8, shift=128, rows=x.shape[0], want_row_sum=True, chan_scale=s)
+    assert np.array_equal(q8.cpu().numpy().astype(np.int32) + 128, z["cs_index"].astype(np.int32))
+    assert np.array_equal(rs.cpu().numpy(), (z["cs_index"].astype(np.int64) - 128).sum(1))
+    qt, rst = ops.quantize_tiled(x, sct, oft, qmin, qmax, 128, chan_scale=s)
+    M, K = x.shape
+    Mp = (M + 15) // 16 * 16
+    back = qt.view(Mp // 16, K // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, K)[:M]
+    assert torch.equal(back, q8) and torch.equal(rst, rs)
+    # wide rows take the 16-elements-per-lane kernel: compare it with the generic one through an unaligned view
+    g = torch.Generator().manual_seed(1)
+    xb = torch.randn(64, 1024, generator=g).to(dev) * 3
+    sb = (torch.rand(1024, generator=g) + 0.5).to(dev)
+    a = ops.quantize(xb, sct, oft, qmin, qmax, q_dtype=MQ_U8, rows=64, chan_scale=sb)
+    want = O.quantize_index((xb.cpu().numpy() / sb.cpu().numpy()).astype(F32), sc, of, qmin, qmax)
+    assert np.array_equal(a.cpu().numpy().astype(F32), want)
+    assert torch.equal(ops.quantize(xb, sct, oft, qmin, qmax, q_dtype=MQ_U8, rows=64, chan_scale=None),
+                       ops.quantize(xb, sct, oft, qmin, qmax, q_dtype=MQ_U8, rows=64))
+
+
+def test_qlinear_run_time_channel_scale_equals_offline_fold(dev):
+    """QLinear.set_input_channel_scale(s): out = Qout(linear(Qin(x / s), Qw(W * s))) on the integer path == the same module with
+    the scale folded by hand (x / s fed in, weight W * s), and within one output LSB of the simulated path."""
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    z = load_npz("smooth_cases.npz")
+    x, s, w = T(z["cs_x"], dev), T(z["cs_scales"], dev), T(z["cs_w"], dev)
+    a8 = mq.QuantConfig(bitwidth=8)
+    lo, hi = (float(v) for v in z["cs_range"])
+
+    def make(weight):
+        lin = torch.nn.Linear(128, 96, bias=False).to(dev)
+        with torch.no_grad():
+            lin.weight.copy_(weight)
+        ql = mq.QLinear.from_float(lin, a8, mq.QuantConfig(bitwidth=8, is_per_channel=True), a8).requires_grad_(False)
+        y = (x / s) @ (w * s).T
+        ql.set_scale_offset({"input": [lo, hi], "output": [float(y.min()), float(y.max())]}, "buffer")
+        return ql
+    run_time, folded = make(w).set_input_channel_scale(s), make(w * s.view(1, -1))
+    assert np.array_equal((w * s.view(1, -1)).cpu().numpy(), z["cs_w_scaled"])
+    with torch.no_grad():
+        assert run_time._int8_ready(x, run_time._effective_weight(run_time.weight))
+        y_rt = run_time(x)
+        y_fold = folded(x / s)
+        assert torch.equal(y_rt, y_fold)
+        run_time.int8_mode = "off"
+        y_sim = run_time(x)
+    lsb = float(run_time.output_quantizer.scale)
+    d = (y_rt - y_sim).abs()
+    assert float(d.max()) <= lsb * 1.001 and float((d == 0).float().mean()) > 0.99
+
+
+def test_smoothquant_statistics_and_fold_vs_reference(dev):
+    """get_act_scales (device-resident absmax statistics, generate_act_scale_shift.py:42-93) and smooth_lm (smoothquant.py:109-139)
+    on the llama-shaped model against the reference's real model: scales exact, folded weights within 2e-6 relative (torch's
+    device pow vs CPU pow), the fold is function preserving."""
+    from conftest import load_npz
+    from test_llama_host import llama_from_fixture
+    from mobilequant_amd import smoothquant as S
+    z = load_npz("smooth_cases.npz")
+    for tag in ("gqa", "mha"):
+        m = llama_from_fixture(z, tag).to(dev)
+        ids = [torch.from_numpy(r[None]).long() for r in z[tag + "_ids"]]
+        scales = S.get_act_scales(m, ids)
+        want = {k.split("|", 2)[2]: z[k] for k in z.files if k.startswith(f"{tag}|scale|")}
+        ours = {("model." + k if not k.startswith("lm_head") else k): v for k, v in scales.items()}
+        assert ours.keys() == want.keys(), sorted(set(ours) ^ set(want))[:5]
+        for k in want:
+            assert np.allclose(ours[k].numpy(), want[k], rtol=2e-6, atol=1e-7), k      # fp32 library GEMMs in front of the statistic
+        with torch.no_grad():
+            before = m(ids[0].to(dev))
+        S.smooth_lm(m, {k[len("model."):] if k.startswith("model.") else k: torch.from_numpy(v) for k, v in want.items()}, 0.5)
+        for k in z.files:
+            if k.startswith(f"{tag}|smoothed|") and "rotary" not in k:
+                name = k.split("|", 2)[2]
+                name = name[len("model."):] if name.startswith("model.") else name
+                got = m.state_dict()[name].cpu().numpy()
+                assert np.allclose(got, z[k], rtol=3e-6, atol=1e-8), name
+        with torch.no_grad():
+            after = m(ids[0].to(dev))
+        assert float((after - before).abs().max()) <= 2e-3 * float(before.abs().max())
+        assert np.abs(after.cpu().numpy() - z[tag + "_logits_smoothed"]).max() <= 2e-3 * np.abs(z[tag + "_logits_smoothed"]).max()
+
+
+def test_let_temporary_and_inplace_weights_vs_reference(dev):
+    """smooth_lm_temporary / smooth_lm_inplace (algorithm.py:147-233) on a sim-quantised decoder layer: every temp_weight /
+    temp_bias and the folded weights against the reference's."""
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    from mobilequant_amd.llama import DecoderLayer, LlamaShape
+    z = load_npz("smooth_cases.npz")
+    layer = DecoderLayer(LlamaShape(hidden=64, layers=1, heads=4, kv_heads=4, head_dim=16, ffn=96, vocab=50, eps=1e-5, max_pos=64))
+    for lin in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj, layer.mlp.w1, layer.mlp.w2,
+                layer.mlp.w3):
+        lin.bias = torch.nn.Parameter(torch.zeros(lin.out_features))
+    sd = {k.split("|", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith("let|sd|") and "rotary" not in k}
+    layer.load_state_dict(sd)
+    layer = layer.to(dev)
+    mq.create_sim_qmodel(layer, mq.QuantConfig(bitwidth=8, is_per_channel=True), mq.QuantConfig(bitwidth=8))
+    for k in z.files:
+        if k.startswith("let|param|"):
+            layer.register_parameter(k.split("|", 2)[2], torch.nn.Parameter(T(z[k], dev)))
+    cfg = type("Cfg", (), dict(shared_attention_norm=False, num_linears_per_mlp=3))()
+    mq.smooth_lm_temporary(layer, cfg, True, use_shift=True)
+    mods = dict(layer.named_modules())
+    n = 0
+    for k in z.files:
+        if k.startswith("let|temp_weight|") or k.startswith("let|temp_bias|"):
+            kind, name = k.split("|")[1], k.split("|", 2)[2]
+            got = getattr(mods[name], kind).detach().cpu().numpy()
+            assert np.allclose(got, z[k], rtol=2e-6, atol=1e-7), k
+            n += 1
+    assert n >= 16 and all(m.use_temporary_parameter for m in mods.values() if isinstance(m, mq.QLinear))
+    mq.smooth_lm_inplace(layer, cfg, True, use_shift=True)
+    for k in z.files:
+        if k.startswith("let|inplace|"):
+            name = k.split("|", 2)[2]
+            got = layer.state_dict()[name].cpu().numpy()
+            assert np.allclose(got, z[k], rtol=3e-6, atol=2e-7), name
+    assert not any(m.use_temporary_parameter for m in mods.values() if isinstance(m, mq.QLinear))
+
+
+# ---- f1: integer chain inside the gated FFN ------------------------------------------------------------------------------------
+def _ffn(dev, act="silu", hidden=1024, ffn=5632, rows=1536, seed=0):
+    """A reference-shaped gated FFN (w1 / w2 / w3 / act_fn) under the W8A8 recipe with static ranges."""
+    import mobilequant_amd as mq
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w1 = torch.nn.Linear(hidden, ffn, bias=False)
+            self.w2 = torch.nn.Linear(ffn, hidden, bias=False)
+            self.w3 = torch.nn.Linear(hidden, ffn, bias=False)
+            self.act_fn = torch.nn.SiLU() if act == "silu" else torch.nn.GELU()
+
+        def forward(self, x):
+            return self.w2(self.act_fn(self.w1(x)) * self.w3(x))
+    torch.manual_seed(seed)
+    m = MLP().to(dev)
+    x = torch.randn(1, rows, hidden, device=dev)
+    with torch.no_grad():
+        a, b = m.w1(x), m.w3(x)
+        y1 = m.act_fn(a)
+        p = y1 * b
+        out = m.w2(p)
+    rng = lambda t: [float(t.min()), float(t.max())]       # noqa: E731
+    act_dict = {"w1": {"input": rng(x), "output": rng(a)}, "w3": {"input": rng(x), "output": rng(b)},
+                "act_fn": {"input": rng(a), "output": rng(y1)}, "w2": {"input": rng(p), "output": rng(out)}}
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(m, a8, a8)
+    m.w2.weight_quantizer.qcfg.is_per_channel = True          # ptq/mobilequant.py:180-182
+    m.w2.output_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(m, act_dict, "buffer")
+    mq.wire_integer_inputs(m)
+    return m.requires_grad_(False), x, act_dict
+
+
+@pytest.mark.parametrize("act", ["silu", "gelu"])
+def test_fused_gated_mlp_equals_module_chain(dev, act):
+    """fuse_gated_mlp: pair GEMM (8-bit output indices of w1 / w3 in one launch) -> gated activation kernel on the indices ->
+    w2 GEMM == the chain of Q-modules on their integer paths, bit for bit; and each new kernel against its composite."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_U8
+    m, x, act_dict = _ffn(dev, act)
+    with torch.no_grad():
+        chain = m(x)
+        a_fp, b_fp = m.w1(x), m.w3(x)                       # fake-quantised fp32 outputs of the integer path
+        assert mq.fuse_gated_mlp(m) == 1 and mq.fuse_gated_mlp(m) == 0
+        calls = []
+        real_pair, real_gate = ops.int8_linear_pair, ops.gated_act_quant
+        ops.int8_linear_pair = lambda *a, **k: (calls.append("pair"), real_pair(*a, **k))[1]
+        ops.gated_act_quant = lambda *a, **k: (calls.append("gate"), real_gate(*a, **k))[1]
+        try:
+            fused = m(x)
+        finally:
+            ops.int8_linear_pair, ops.gated_act_quant = real_pair, real_gate
+        assert calls == ["pair", "gate"]
+        assert torch.equal(fused, chain)
+        m.fused_mode = "off"
+        assert torch.equal(m(x), chain)
+        # the pair GEMM's indices are the indices of the two single GEMMs' fake-quantised outputs
+        o1, o3 = m.w1.output_quantizer, m.w3.output_quantizer
+        grid, a_q, a_rs, a_shift, tiled_rows, _ = m.w1._input_image(x, m.w1.weight)
+        assert tiled_rows == x.shape[1]
+        halves = []
+        for lin in (m.w1, m.w3):
+            plan = lin._epilogue_vectors(lin._weight_plan(lin.weight), grid, a_shift, lin.weight.shape[1])
+            halves.append(dict(w=plan["w"], alpha=plan["alpha"], w_zp=plan["w_zp"], col_term=plan["col_term"], bias=None,
+                               out_scale=lin.output_quantizer.scale, out_offset=lin.output_quantizer.offset))
+        ia, ib = ops.int8_linear_pair(a_q, tiled_rows, a_rs, halves[0], halves[1], out_dtype=MQ_U8)
+        for idx, fp, oq in ((ia, a_fp, o1), (ib, b_fp, o3)):
+            deq = (idx.float() - oq.offset) * oq.scale
+            assert torch.equal(deq.view_as(fp), fp)
+        # gated kernel on indices == on the fp32 values == composite Q-modules + mq_quantize
+        iq2 = m.w2.input_quantizer
+        og = (iq2.scale, iq2.offset, iq2.qmin, iq2.qmax)
+        mid = None if act == "gelu" else (m.act_fn.input2_quantizer.scale, m.act_fn.input2_quantizer.offset, 0.0, 255.0)
+        ao = m.act_fn.output_quantizer
+        kw = dict(mid_grid=mid, act_grid=(ao.scale, ao.offset, ao.qmin, ao.qmax), q_shift=128)
+        q_i, rs_i = ops.gated_act_quant(ia, ib, act, og, a_grid=(o1.scale, o1.offset), b_grid=(o3.scale, o3.offset), **kw)
+        q_f, rs_f, y_f = ops.gated_act_quant(a_fp.reshape(ia.shape), b_fp.reshape(ib.shape), act, og, want_y=True, **kw)
+        assert torch.equal(q_i, q_f) and torch.equal(rs_i, rs_f)
+        prod = m.act_fn(a_fp) * b_fp
+        assert torch.equal(y_f.view_as(prod), prod)
+        q_ref, rs_ref, _ = iq2.quantize_to_int(prod.reshape(ia.shape), want_row_sum=True)
+        assert torch.equal(q_i, q_ref) and torch.equal(rs_i, rs_ref)
+
+
+def test_pair_gemm_rejects_what_it_does_not_serve(dev):
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    one = torch.ones(1, device=dev)
+    a = torch.zeros(2048, 512, dtype=torch.int8, device=dev)
+    w = torch.zeros(5632, 512, dtype=torch.int8, device=dev)
+    v = torch.zeros(5632, device=dev)
+    zi = torch.zeros(5632, dtype=torch.int32, device=dev)
+    half = dict(w=w, alpha=v, w_zp=zi, col_term=zi, bias=None, out_scale=one, out_offset=one)
+    with pytest.raises(mq._lib.MobileQuantLibraryError, match="not served"):
+        ops.int8_linear_pair(a, 2048, None, half, half)                 # K = 512 < 768

@@ -353,3 +353,35 @@ def test_qsilu_qgelu_cases():
         assert act_close(y, z[m["id"] + "_y"], m), m
         n += 1
     assert n == 8
+
+
+# ---- round 2: LWC, QMatMul -----------------------------------------------------------------------------------------
+def test_lwc_oracle_matches_reference_forward_and_autograd():
+    """a7: forward values, run_lwc and the gradients to upbound_factor / lowbound_factor / the weight (incl. the amin / amax
+    path) against the reference's autograd; torch's vectorised sigmoid may differ from exp-based fp32 by an ulp, hence 1e-6."""
+    z = load_npz("lwc_cases.npz")
+    for m in load_meta(z):
+        t = m["id"]
+        args = (m["bitwidth"], m["is_symmetric"], m["is_per_channel"])
+        y, s, o = O.lwc_forward(z[t + "_w"], z[t + "_up"], z[t + "_lo"], *args)
+        assert np.allclose(s.reshape(-1), z[t + "_scale"].reshape(-1), rtol=3e-7, atol=0)
+        assert np.array_equal(o.reshape(-1), z[t + "_offset"].reshape(-1))
+        assert np.abs(y - z[t + "_y"]).max() <= 4e-8 + 1e-6 * np.abs(z[t + "_y"]).max()
+        assert np.abs(O.run_lwc(z[t + "_w"], z[t + "_up"], z[t + "_lo"], m["is_per_channel"]) - z[t + "_clamped"]).max() <= 4e-8
+        gu, gl, gw = O.lwc_backward(z[t + "_w"], z[t + "_up"], z[t + "_lo"], z[t + "_gy"], *args)
+        for got, want in ((gu, z[t + "_g_up"]), (gl, z[t + "_g_lo"]), (gw, z[t + "_g_w"])):
+            assert np.abs(got.reshape(-1) - want.reshape(-1)).max() <= 2e-6 * np.abs(want).max(), t
+
+
+def test_qmatmul_oracle_matches_reference():
+    z = load_npz("qmatmul_cases.npz")
+    for m in load_meta(z):
+        t = m["id"]
+        qs = []
+        for bits, rng in zip(m["bits"], (m["act"]["input"], m["act"]["input2"], m["act"]["output"])):
+            q = O.QuantizerOracle(bits)
+            q.set_from_minmax(*rng)
+            qs.append(q)
+        y = O.qmatmul_sim(z[t + "_a"], z[t + "_b"], *qs)
+        d = np.abs(y - z[t + "_y"])
+        assert d.max() <= float(qs[2].scale) * 1.001 and (d == 0).mean() > 0.99, (t, d.max(), (d == 0).mean())

@@ -67,6 +67,7 @@ S_RT = 84                         # 84..87: s_memrealtime (constant 100 MHz) at 
 # what-if switches for profiling builds (results are wrong): MQ_FR_NO_A / _NO_W / _NO_READ / _NO_MFMA drop the in-loop activation
 # loads / W LDS-DMA / W fragment reads / MFMAs
 NO_A, NO_W, NO_READ, NO_MFMA = (bool(os.environ.get("MQ_FR_" + k)) for k in ("NO_A", "NO_W", "NO_READ", "NO_MFMA"))
+STORE_POLICY = os.environ.get("MQ_FR_STORE", "nt")      # cache policy of the output stores: "" (write-back) | nt | sc1 | "sc0 sc1" | none
 
 out = []
 
@@ -389,7 +390,8 @@ def epilogue(stamp):
             emit("s_and_b64 exec, exec, vcc")
             if i == 1:
                 emit(f"v_add_u32 v{V_GOFS + r}, s{S_TMP2}, v{V_GOFS + r}")
-            emit(f"global_store_dwordx4 v{V_GOFS + r}, v[{b}:{b + 3}], %[outw] nt")
+            if STORE_POLICY != "none":
+                emit(f"global_store_dwordx4 v{V_GOFS + r}, v[{b}:{b + 3}], %[outw] {STORE_POLICY}".rstrip())
             emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
     if stamp:
         emit("s_waitcnt vmcnt(0)")                                           # the wave's stores have left
