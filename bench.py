@@ -323,7 +323,78 @@ def cpu_baseline():
                                 "mixed-precision rules of ptq/mobilequant.py:175-201) at S=2048"}}
 
 
-def bench_decode(dev, w4=False):
+def bench_decode_full(dev, context=256, steps=64):
+    """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
+    model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
+    one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
+    softmax / pv_bmm, o_proj + residual, norm + w1|w3 stream + QSiLU * (.) + w2 input quantizer, w2 + residual), final norm +
+    fp32 lm_head, embedding gather; one hipGraph per token, position in device memory.  Timed at a context of `context` tokens."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.calibration import get_act_range
+    from mobilequant_amd.decode import DecodeEngine
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    shape = LlamaShape.tinyllama(max_pos=2048)
+    model = LlamaForCausalLM(shape)
+    model.reset_parameters(seed=1337)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(1337)
+    calib = [torch.randint(3, shape.vocab, (1, 256), generator=g) for _ in range(2)]
+    act = get_act_range(model, calib)
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(model, a8, a8)
+    for name, mod in model.named_modules():               # ptq/mobilequant.py:175-201
+        if isinstance(mod, mq.QLinear):
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(model, act, "buffer")
+    eng = DecodeEngine(model, cache_len=1024)
+    for p in model.parameters():                            # the float weights of the decoder layers are no longer needed
+        if p.dim() == 2 and p.shape[0] != shape.vocab:
+            p.data = torch.empty(0, device=dev)
+    torch.cuda.empty_cache()
+    for c in eng.k_cache + eng.v_cache:                     # a context's worth of cached keys / values
+        c[:, :context].normal_()
+    eng.pos.fill_(context)
+    eng.tok.fill_(17)
+    eng.capture()
+    for _ in range(3):
+        eng.step()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(3):
+        eng.pos.fill_(context)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            eng.graph.replay()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / steps)
+    t = best * 1e-3
+    kv_bytes = 22 * 2 * shape.kv_heads * (context + steps // 2) * shape.head_dim * 4
+    total = eng.weight_bytes + eng.head_bytes + kv_bytes
+    return {"decode_tok_s": round(1.0 / t, 1), "ms_per_token": round(t * 1e3, 4), "context": context,
+            "int8_weight_GB_per_token": round(eng.weight_bytes / 1e9, 4), "lm_head_fp32_GB_per_token": round(eng.head_bytes / 1e9, 4),
+            "kv_cache_GB_per_token": round(kv_bytes / 1e9, 4), "achieved_GBps": round(total / t / 1e9, 1),
+            "weight_stream_GBps": round(eng.weight_bytes / t / 1e9, 1), "peak_GBps": 8000.0, "frac_of_hbm_peak": round(total / t / 8e12, 4),
+            "kernels_per_token": len(eng.phases) + 2,
+            "scope": "FULL decode step, TinyLlama-1.1B shape, W8A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, 22 x "
+                     "[norm+qkv, attention over the static KV cache, o_proj+residual, norm+w1|w3+SiLU*mul+quantize, w2+residual], final "
+                     "norm + fp32 lm_head; batch 1, one hipGraph per token"}
+
+
+def bench_decode_linears(dev, w4=False):
     """TinyLlama-1.1B decode, linears only: per layer quantize(x) -> GEMV qkv (2048->2560) -> quantize -> GEMV o
     (2048->2048) -> quantize -> GEMV w1|w3 (2048->11264) -> quantize -> GEMV w2 (5632->2048), 22 layers with their own
     int8 weights (0.97 GB streamed per token), one hipGraph per token.  Attention, norms and sampling are outside the
@@ -615,9 +686,11 @@ def main():
             tm = event_time(lambda: ql(x3), 30)
             extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
                                             "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
-            decode = bench_decode(dev)
+            decode = bench_decode_full(dev)
             torch.cuda.empty_cache()
-            extras["decode_w4a8"] = bench_decode(dev, w4=True)      # the reference's deployment mode: 4-bit weights
+            decode["linears_only_w8a8"] = bench_decode_linears(dev)
+            torch.cuda.empty_cache()
+            decode["linears_only_w4a8"] = bench_decode_linears(dev, w4=True)      # the reference's deployment mode: 4-bit weights
             torch.cuda.empty_cache()
             extras["layer_prefill"] = bench_layer(dev)
             if not args.no_cpu_baseline:

@@ -266,6 +266,71 @@ int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows,
                        float out_qmin, float out_qmax, int q_shift, int8_t* q_out, int32_t* row_sum,
                        float* y, mq_stream_t stream);
 
+/* ---- f2: single-token decode step (mobilellm/model/sim_model.py:160-221 on the quantized module graph) -------------------- */
+/* A per-tensor quantizer grid on the device: scale / offset point at 1 float each; scale == NULL means "no quantizer here". */
+typedef struct mq_grid {
+  const float* scale;
+  const float* offset;
+  float qmin, qmax;
+} mq_grid;
+
+/* One fused weight-streaming phase of a decoder layer at M = 1 (DESIGN.md "Decode").  The activation is either fp32 x [K]
+ * (quantised on a_grid -- 8-bit unsigned -- inside the kernel; with norm_w != NULL the QRMSNorm of qmodule.py:515-531 runs first:
+ * norm_in = its input grid, norm_w = its fake-quantised weight vector, a_grid = its output grid) or a ready int8 image xq [K]
+ * (index - 128).  Weights: int8 [N, K] (index - 128), per-row epilogue vectors of mq_linear_epilogue_prepare for a_grid.
+ * Plain mode (gate_q == NULL): y[n] = (resid ? resid[n] : 0) + Qout_seg(n)(alpha[n] * (...) + bias[n]); rows [0, seg_end[0]) use
+ *   out_grid[0], [seg_end[0], seg_end[1]) out_grid[1], the rest out_grid[2] (q | k | v in one stream).
+ * Gate mode (gate_q != NULL): weight rows 2i / 2i+1 are row i of w1 / w3 (out_grid[0] / out_grid[1]); the epilogue applies
+ *   QSiLU (gate_act 0; gate_mid = sigmoid grid) or QGELU (1) with output grid gate_actout, the product, and w2's input quantizer
+ *   gate_out: gate_q[i] = int8 storage (index - 128); y (nullable) = the fp32 product. */
+typedef struct mq_decode_gemv_args {
+  const float* x;
+  const int8_t* xq;
+  int K, N;
+  const float* norm_w;
+  mq_grid norm_in;
+  float eps;
+  mq_grid a_grid;
+  const int8_t* w;
+  const float* alpha;
+  const int32_t* w_zp;
+  const int32_t* col_term;
+  const float* bias;
+  int seg_end[2];
+  mq_grid out_grid[3];
+  const float* resid;
+  float* y;
+  int gate_act;
+  mq_grid gate_mid, gate_actout, gate_out;
+  int8_t* gate_q;
+} mq_decode_gemv_args;
+int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream);
+
+/* Attention of one query token over a static KV cache (hf_model.py:486-534; QMatMul qk_bmm / pv_bmm of qmodule.py:453-466):
+ * qkv = [heads*D | kv_heads*D | kv_heads*D] fp32 outputs of the q|k|v phase; RoPE with cos / sin [max_pos, D] (rotate-half) at
+ * position *pos (device memory: one captured graph serves every step); k_cache / v_cache [kv_heads, cache_len, D] fp32 hold the
+ * post-RoPE keys / the values of positions < *pos ALREADY ON their QMatMul input grids (qk_b / pv_b: the reference re-quantises
+ * the cached tensors at every step with static grids, which is idempotent) and receive position *pos; out [heads*D] = pv_bmm's
+ * (quantised) output. */
+typedef struct mq_decode_attention_args {
+  const float* qkv;
+  float* k_cache;
+  float* v_cache;
+  const float* cos;
+  const float* sin;
+  const int* pos;
+  int heads, kv_heads, head_dim, cache_len;
+  float inv_sqrt_d;
+  mq_grid qk_a, qk_b, qk_out, pv_a, pv_b, pv_out;
+  float* out;
+} mq_decode_attention_args;
+int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream);
+
+/* Final HFRMSNorm (floating point: the surgery skips it, qmodule.py:843; norm_weight NULL = no norm) fused in front of the fp32
+ * lm_head stream: logits[v] = sum_k w[v,k] * norm(x)[k] (+ bias[v]). */
+int mq_decode_head(const float* x, const float* norm_weight, float eps, const float* w, const float* bias, int64_t K,
+                   int64_t V, float* logits, mq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,26 @@ MQ_F32, MQ_F16, MQ_I8, MQ_U8, MQ_I16, MQ_U16, MQ_I32 = range(7)
 MQ_OK = 0
 
 _P = c_void_p
+
+
+class MqGrid(ctypes.Structure):
+    _fields_ = [("scale", c_void_p), ("offset", c_void_p), ("qmin", c_float), ("qmax", c_float)]
+
+
+class MqDecodeGemvArgs(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("xq", c_void_p), ("K", c_int), ("N", c_int), ("norm_w", c_void_p), ("norm_in", MqGrid),
+                ("eps", c_float), ("a_grid", MqGrid), ("w", c_void_p), ("alpha", c_void_p), ("w_zp", c_void_p),
+                ("col_term", c_void_p), ("bias", c_void_p), ("seg_end", c_int * 2), ("out_grid", MqGrid * 3),
+                ("resid", c_void_p), ("y", c_void_p), ("gate_act", c_int), ("gate_mid", MqGrid), ("gate_actout", MqGrid),
+                ("gate_out", MqGrid), ("gate_q", c_void_p)]
+
+
+class MqDecodeAttentionArgs(ctypes.Structure):
+    _fields_ = [("qkv", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p), ("cos", c_void_p), ("sin", c_void_p),
+                ("pos", c_void_p), ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("cache_len", c_int),
+                ("inv_sqrt_d", c_float), ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
+                ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p)]
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "mq_version": (c_int, []),
@@ -55,6 +75,9 @@ _SIGNATURES = {
     "mq_layernorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
                                    _P, _P, c_int, _P, _P]),
     "mq_w4a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
+    "mq_decode_gemv": (c_int, [POINTER(MqDecodeGemvArgs), _P]),
+    "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
+    "mq_decode_head": (c_int, [_P, _P, c_float, _P, _P, c_int64, c_int64, _P, _P]),
     "mq_gemm_set_variant": (c_int, [c_int]),
     "mq_gemm_variant_name": (c_char_p, [c_int]),
     "mq_gemm_set_debug": (c_int, [c_int]),

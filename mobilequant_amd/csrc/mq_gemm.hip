@@ -222,7 +222,10 @@ __global__ void __launch_bounds__(64 * WM * WN)
     pz[r] = args.w_zp[n];
     pc[r] = args.col_term[n];
   }
-  constexpr bool FOLD_OO = OUTQ && (OUT == MQ_U8 || OUT == MQ_I8);
+  // 8-bit output grids carry the (integer-valued, <= 255) offset inside the fma's addend -- for EVERY storage type, so the index
+  // a linear produces does not depend on whether its consumer asked for indices or for the dequantised value; 16-bit grids keep
+  // it out (an addend of up to 65535 would cost the fma 8 more fraction bits)
+  const bool FOLD_OO = OUTQ && (args.out_qmax - args.out_qmin <= 255.0f);
   float so = 1.f, oo = 0.f, inv_so = 1.f;
   if constexpr (OUTQ) {
     so = args.out_scale[0];
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
             float q = __builtin_fmaf((float)t, al[e], bs[e]);
             if constexpr (!FAST) {                 // the u8 fast path leaves rint and clamp to cvt_pk_u8
               q = rintf(q);
-              if constexpr (!FOLD_OO) q += oo;
+              if (!FOLD_OO) q += oo;
               q = __builtin_amdgcn_fmed3f(q, qmin, qmax);
             }
             if constexpr (OUT == MQ_F32 || OUT == MQ_F16) v[e] = __fmul_rn(__fsub_rn(q, oo), so);
@@ -678,7 +681,7 @@ __global__ void __launch_bounds__(64 * WM * WN)
       }
     }
   };
-  if constexpr (FOLD_OO) {
+  if constexpr (OUTQ && (OUT == MQ_U8 || OUT == MQ_I8)) {
     if (u8_grid) store_tile(std::true_type{});
     else store_tile(std::false_type{});
   } else {

@@ -1,0 +1,247 @@
+"""Single-token decode with a static KV cache: MI355X-native counterpart of the per-token body of ``SimModel.generate``
+(mobilellm/model/sim_model.py:160-221) for a simulated-quant llama-style model.
+
+``DecodeEngine`` takes a ``mobilequant_amd.llama.LlamaForCausalLM`` that went through the reference's surgery
+(``create_sim_qmodel`` -> ``update_qcfg`` / mixed-precision rules -> ``set_scale_and_offset``) and lowers every decoder layer to the
+five fused launches of ``csrc/mq_decode.hip``:
+
+    input_layernorm + q|k|v stream  ->  RoPE / cache append / qk_bmm / softmax / pv_bmm  ->  o_proj stream + residual
+    ->  post_attention_layernorm + interleaved w1|w3 stream + QSiLU * (.) + w2's input quantizer  ->  w2 stream + residual
+
+plus final norm + lm_head (floating point, as the surgery leaves them: qmodule.py:843).  Integer weights, epilogue vectors and
+quantizer grids are taken from the Q-modules themselves (the same caches the prefill path uses), so a decode step computes what
+the module graph computes for that position: each logit within the tolerance the prefill kernels state.  The token
+id and the position live in device memory: ``capture()`` records ONE hipGraph that serves every step of a generation.
+W8A8 (8-bit weights); 8-bit unsigned activation grids; 16-bit grids where the recipe puts them (norm inputs, o_proj / w2 outputs,
+qk_bmm output, pv_bmm input).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import MqDecodeAttentionArgs, MqDecodeGemvArgs, MqGrid
+from .quantization import qmodule as Q
+
+
+def _grid(q: Optional[Q.Quantizer], keep: list) -> MqGrid:
+    """Device view of a static per-tensor quantizer (absent / bypassed -> the null grid)."""
+    if q is None or q.bypassed():
+        return MqGrid(None, None, 0.0, 0.0)
+    if not Q._static_per_tensor(q, 16):
+        raise RuntimeError("DecodeEngine needs static per-tensor activation grids (set_scale_and_offset first)")
+    s, o = q.scale.detach().float().contiguous(), q.offset.detach().float().contiguous()
+    keep += [s, o]
+    return MqGrid(s.data_ptr(), o.data_ptr(), float(q.qmin), float(q.qmax))
+
+
+class _Linear:
+    """Integer image of one or several QLinears that read the same activation grid: weights [N, K] int8 (index - 128) and the
+    per-row epilogue vectors for that grid, concatenated (q|k|v) or row-interleaved (w1|w3)."""
+
+    def __init__(self, linears: List[Q.QLinear], a_grid: Q.Quantizer, interleave: bool = False):
+        ws, alphas, zps, cts, biases = [], [], [], [], []
+        for lin in linears:
+            if lin.weight_quantizer is None or lin.weight_quantizer.qcfg.bitwidth != 8:
+                raise RuntimeError("DecodeEngine: 8-bit weight quantizers only")
+            K = lin.weight.shape[1]
+            plan = lin._epilogue_vectors(lin._weight_plan(lin.weight), a_grid, 128, K)
+            ws.append(plan["w"]); alphas.append(plan["alpha"].clone()); zps.append(plan["w_zp"].clone()); cts.append(plan["col_term"].clone())
+            biases.append(lin.bias.detach().float() if lin.bias is not None else None)
+            plan["epi_key"] = None                      # the prefill path re-derives its vectors for its own grid object
+        cat = (lambda ts: torch.stack(ts, dim=1).reshape(-1, *ts[0].shape[1:])) if interleave else (lambda ts: torch.cat(ts, dim=0))
+        self.w = cat(ws).contiguous()
+        self.alpha, self.w_zp, self.col_term = cat(alphas).contiguous(), cat(zps).contiguous(), cat(cts).contiguous()
+        self.bias = None
+        if any(b is not None for b in biases):
+            self.bias = cat([b if b is not None else torch.zeros(l.weight.shape[0], device=l.weight.device)
+                             for b, l in zip(biases, linears)]).contiguous()
+        self.N, self.K = self.w.shape
+        self.rows = [l.weight.shape[0] for l in linears]
+
+
+class DecodeEngine:
+    def __init__(self, model, cache_len: int = 2048):
+        from .llama import LlamaForCausalLM
+        assert isinstance(model, LlamaForCausalLM)
+        self.model, self.shape = model, model.shape
+        s = self.shape
+        dev = next(model.parameters()).device
+        self.dev, self.cache_len = dev, int(cache_len)
+        self._keep: list = []
+        self.x = torch.zeros(s.hidden, device=dev)
+        self.qkv = torch.zeros((s.heads + 2 * s.kv_heads) * s.head_dim, device=dev)
+        self.attn = torch.zeros(s.heads * s.head_dim, device=dev)
+        self.gate_q = torch.zeros(s.ffn, dtype=torch.int8, device=dev)
+        self.logits = torch.zeros(s.vocab, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tok = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.k_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, device=dev) for _ in model.layers]
+        self.v_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, device=dev) for _ in model.layers]
+        self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
+        assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
+        self.embed = model.embed_tokens.weight.detach()
+        self.norm_w = model.norm.weight.detach().float().contiguous()
+        self.lm_w = model.lm_head.weight.detach().float().contiguous()
+        self.lm_b = model.lm_head.bias.detach().float().contiguous() if model.lm_head.bias is not None else None
+        self.phases = []          # (kind, ctypes struct) in launch order
+        for q in model.modules():                 # grids set from act_dict.json sit on the host until a forward moves them
+            if isinstance(q, Q.Quantizer) and q._has_grid() and q.scale.device != dev:
+                q.scale.data, q.offset.data = q.scale.to(dev), q.offset.to(dev)
+        with torch.no_grad():
+            for li, layer in enumerate(model.layers):
+                self._lower_layer(li, layer)
+        self.weight_bytes = sum(p[1]._mq_bytes for p in self.phases if p[0] == "gemv")
+        self.head_bytes = self.lm_w.numel() * 4
+        self.graph = None
+
+    # -- lowering ----------------------------------------------------------------------------------------------------------
+    def _norm_args(self, norm: Q.QRMSNorm, a: MqDecodeGemvArgs):
+        if not isinstance(norm, Q.QRMSNorm) or norm.l2norm_as_rmsnorm or norm.bias is not None:
+            raise RuntimeError("DecodeEngine: QRMSNorm layers (plain RMS form, no bias) only")
+        wfq = Q._apply(norm.weight_quantizer, norm.weight.detach()).float().contiguous()
+        self._keep.append(wfq)
+        a.norm_w, a.norm_in, a.eps = wfq.data_ptr(), _grid(norm.input_quantizer, self._keep), float(norm.eps)
+        a.a_grid = _grid(norm.output_quantizer, self._keep)
+        if norm.output_quantizer is None or norm.output_quantizer.qmax != 255:
+            raise RuntimeError("DecodeEngine: the norm feeding a linear needs an 8-bit unsigned output grid")
+        return norm.output_quantizer
+
+    def _gemv(self, lin: _Linear, **fields) -> MqDecodeGemvArgs:
+        a = MqDecodeGemvArgs()
+        a.K, a.N = lin.K, lin.N
+        a.w, a.alpha, a.w_zp, a.col_term = lin.w.data_ptr(), lin.alpha.data_ptr(), lin.w_zp.data_ptr(), lin.col_term.data_ptr()
+        a.bias = lin.bias.data_ptr() if lin.bias is not None else None
+        a.seg_end[0] = a.seg_end[1] = lin.N
+        for k, v in fields.items():
+            setattr(a, k, v)
+        a._mq_bytes = lin.N * lin.K
+        self._keep.append(lin)
+        return a
+
+    def _lower_layer(self, li, layer):
+        s, keep = self.shape, self._keep
+        attn, mlp = layer.self_attn, layer.mlp
+        for m in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.w1, mlp.w2, mlp.w3):
+            if not isinstance(m, Q.QLinear):
+                raise RuntimeError("DecodeEngine: run create_sim_qmodel first")
+        # (1) input_layernorm + q|k|v
+        a = MqDecodeGemvArgs()
+        g_in = self._norm_args(layer.input_layernorm, a)
+        qkv = _Linear([attn.q_proj, attn.k_proj, attn.v_proj], g_in)
+        p1 = self._gemv(qkv, x=self.x.data_ptr(), norm_w=a.norm_w, norm_in=a.norm_in, eps=a.eps, a_grid=a.a_grid, y=self.qkv.data_ptr())
+        p1.seg_end[0], p1.seg_end[1] = qkv.rows[0], qkv.rows[0] + qkv.rows[1]
+        for k, lin in enumerate((attn.q_proj, attn.k_proj, attn.v_proj)):
+            p1.out_grid[k] = _grid(lin.output_quantizer, keep)
+        self.phases.append(("gemv", p1))
+        # (2) attention core
+        at = MqDecodeAttentionArgs()
+        at.qkv, at.k_cache, at.v_cache = self.qkv.data_ptr(), self.k_cache[li].data_ptr(), self.v_cache[li].data_ptr()
+        at.cos, at.sin, at.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
+        at.heads, at.kv_heads, at.head_dim, at.cache_len = s.heads, s.kv_heads, s.head_dim, self.cache_len
+        at.inv_sqrt_d = 1.0 / math.sqrt(s.head_dim)
+        qk, pv = attn.qk_bmm, attn.pv_bmm
+        at.qk_a, at.qk_b, at.qk_out = (_grid(q, keep) for q in (qk.input_quantizer, qk.input2_quantizer, qk.output_quantizer))
+        at.pv_a, at.pv_b, at.pv_out = (_grid(q, keep) for q in (pv.input_quantizer, pv.input2_quantizer, pv.output_quantizer))
+        at.out = self.attn.data_ptr()
+        self.phases.append(("attn", at))
+        # (3) o_proj + residual: its input sits on pv_bmm's output grid (the live producer), else on its declared / own grid
+        g_o = attn.o_proj.input_quantizer if attn.o_proj.input_quantizer is not None else (
+            pv.output_quantizer if Q._static_per_tensor(pv.output_quantizer, 8) else attn.o_proj._input_grid)
+        if g_o is None or g_o.qmax != 255:
+            raise RuntimeError("DecodeEngine: o_proj needs an 8-bit unsigned input grid (pv_bmm output)")
+        op = _Linear([attn.o_proj], g_o)
+        p3 = self._gemv(op, x=self.attn.data_ptr(), a_grid=_grid(g_o, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
+        p3.out_grid[0] = _grid(attn.o_proj.output_quantizer, keep)
+        self.phases.append(("gemv", p3))
+        # (4) post_attention_layernorm + interleaved w1|w3 + gated activation + w2's input quantizer
+        a2 = MqDecodeGemvArgs()
+        g_ffn = self._norm_args(layer.post_attention_layernorm, a2)
+        w13 = _Linear([mlp.w1, mlp.w3], g_ffn, interleave=True)
+        act = mlp.act_fn
+        if not isinstance(act, (Q.QSiLU, Q.QGELU)) or (act.input_quantizer is not None and not act.input_quantizer.bypassed()):
+            raise RuntimeError("DecodeEngine: act_fn must be QSiLU / QGELU without an input quantizer (the reference's surgery)")
+        iq2 = mlp.w2.input_quantizer
+        if iq2 is None or iq2.qmax != 255:
+            raise RuntimeError("DecodeEngine: w2 needs its own 8-bit unsigned input quantizer")
+        p4 = self._gemv(w13, x=self.x.data_ptr(), norm_w=a2.norm_w, norm_in=a2.norm_in, eps=a2.eps, a_grid=a2.a_grid,
+                        gate_q=self.gate_q.data_ptr(), gate_act=0 if isinstance(act, Q.QSiLU) else 1,
+                        gate_mid=_grid(act.input2_quantizer if isinstance(act, Q.QSiLU) else None, keep),
+                        gate_actout=_grid(act.output_quantizer, keep), gate_out=_grid(iq2, keep))
+        p4.out_grid[0], p4.out_grid[1] = _grid(mlp.w1.output_quantizer, keep), _grid(mlp.w3.output_quantizer, keep)
+        self.phases.append(("gemv", p4))
+        # (5) w2 from the int8 image + residual
+        w2 = _Linear([mlp.w2], iq2)
+        p5 = self._gemv(w2, xq=self.gate_q.data_ptr(), a_grid=_grid(iq2, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
+        p5.out_grid[0] = _grid(mlp.w2.output_quantizer, keep)
+        self.phases.append(("gemv", p5))
+
+    # -- running -------------------------------------------------------------------------------------------------------------
+    def _launch(self):
+        """embedding gather + 5 launches per layer + norm / lm_head, on the current stream; reads self.tok / self.pos."""
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        torch.index_select(self.embed, 0, self.tok, out=self.x.view(1, -1))
+        for kind, a in self.phases:
+            _lib.call("mq_decode_gemv" if kind == "gemv" else "mq_decode_attention", ctypes.byref(a), st)
+        _lib.call("mq_decode_head", self.x.data_ptr(), self.norm_w.data_ptr(), float(self.model.norm.eps), self.lm_w.data_ptr(),
+                  self.lm_b.data_ptr() if self.lm_b is not None else None, self.shape.hidden, self.shape.vocab, self.logits.data_ptr(), st)
+
+    def capture(self):
+        """Record one decode step (incl. the position increment) as a hipGraph; replay it with step()."""
+        tok0, pos0 = self.tok.clone(), self.pos.clone()
+        with torch.cuda.device(self.dev):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._launch()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch()
+                self.pos.add_(1)
+        self.tok.copy_(tok0); self.pos.copy_(pos0)
+        self.graph = g
+        return self
+
+    def reset(self):
+        self.pos.zero_()
+        for c in self.k_cache + self.v_cache:
+            c.zero_()
+
+    @torch.no_grad()
+    def step(self, token: Optional[int] = None) -> torch.Tensor:
+        """One token in, logits [vocab] out (device tensor, overwritten by the next step); the position advances by one.
+        token None: use the token already sitting in self.tok (e.g. written by a device-side argmax)."""
+        if token is not None:
+            self.tok.fill_(int(token))
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            with torch.cuda.device(self.dev):
+                self._launch()
+            self.pos.add_(1)
+        return self.logits
+
+    @torch.no_grad()
+    def generate(self, context_ids, max_new_tokens: int, eos_token_id=None):
+        """Greedy generation (sim_model.py:160-221 with do_sample = False): feed the context token by token, then argmax on
+        the device into self.tok; the host reads one token id per step only to test for EOS."""
+        ids = [int(t) for t in context_ids]
+        assert len(ids) + max_new_tokens <= self.cache_len
+        self.reset()
+        for t in ids:
+            self.step(t)
+        out = list(ids)
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        for _ in range(max_new_tokens):
+            torch.argmax(self.logits, dim=-1, keepdim=True, out=self.tok)
+            nxt = int(self.tok.item())
+            out.append(nxt)
+            if nxt in eos:
+                break
+            self.step()
+        return out

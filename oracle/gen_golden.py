@@ -22,6 +22,7 @@ Fixtures written (all data, no reference source text):
   lwc_cases.npz           a7     learnable weight clipping: forward values, gradients to the bound factors and the weight, run_lwc
   qmatmul_cases.npz       a10    QMatMul.forward at attention shapes (qk_bmm / pv_bmm mixed-precision rules)
   toy_lm_nll.npz          perplexity proxy: the reference's W8A8-sim logits + NLL of the toy LM on 96 tokens
+  decode_case.npz         f2: W8A8-sim logits of the reference's real HFForCausalLM (2 layers) at every position of a sequence
   smooth_cases.npz        n1/f3/f4 on the reference's real HFForCausalLM (2 layers): fp logits, get_act_scales, smooth_lm fold,
                           smooth_lm_temporary / _inplace (LET) temp weights, Quantizer indices of x / s
 """
@@ -840,6 +841,68 @@ def gen_artifacts():
     print("artifacts: act_dict_ref.json", os.path.getsize(os.path.join(OUT, "act_dict_ref.json")), "bytes; act_scales_ref.pth", len(scales), "tensors")
 
 
+def gen_decode_case():
+    """f2: a decode loop must reproduce, token by token, what the reference's W8A8-simulated model computes for the same
+    sequence (causal attention: position t depends on tokens <= t only; static per-tensor grids).  The REAL reference classes:
+    a 2-layer HFForCausalLM (hidden 256, 4 heads / 2 KV heads, head_dim 64, FFN 512 -- sizes the decode kernels accept),
+    calibrated by the reference's get_act_range, create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201,
+    logits at every position of a 40-token sequence."""
+    from mobilellm.model.hf_config import HFConfig
+    from mobilellm.model.hf_model import HFForCausalLM
+    cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                   num_key_value_heads=2, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(2024)
+    m = HFForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() >= 2:
+                p_.normal_(0.0, 0.08)
+            else:
+                p_.uniform_(0.7, 1.3)
+    out = {"sd|" + k_: npf(v_) for k_, v_ in m.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    ids = torch.randint(0, 96, (1, 40), generator=g)
+    calib = [torch.randint(0, 96, (1, 40), generator=g) for _ in range(4)] + [ids]
+    out["ids"] = npf(ids[0])
+    out["logits_fp"] = npf(m(ids, use_cache=False).logits)
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+
+    class _Tk:
+        bos_token_id, vocab_size = 1, 96
+        def __call__(s_, line, return_tensors="pt", max_length=None, truncation=True):
+            return types.SimpleNamespace(input_ids=calib[int(line)])
+    _orig = m.forward
+    m.forward = lambda x_, **kw: _orig(x_, use_cache=False)
+    act = rng_mod.get_act_range(m, _Tk(), [{"text": str(i)} for i in range(len(calib))], len(calib), 64)
+    m.forward = _orig
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=8), Q.QuantConfig(bitwidth=8))
+    for name, mod in m.named_modules():          # ptq/mobilequant.py:175-201
+        if isinstance(mod, Q.QLinear):
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU)))}
+    Q.set_scale_and_offset(m, act, "buffer")
+    out["logits_w8a8"] = npf(m(ids, use_cache=False).logits)
+    out["act"] = np.array(json.dumps(act))
+    out["qcfg"] = np.array(json.dumps(Q.export_qcfg(m)))
+    np.savez_compressed(os.path.join(OUT, "decode_case.npz"), **out)
+    d = out["logits_w8a8"] - out["logits_fp"]
+    print("decode_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
@@ -851,6 +914,7 @@ if __name__ == "__main__":
     gen_qmatmul_cases()
     gen_toy_lm_nll()
     gen_smooth_cases()
+    gen_decode_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()
     gen_nonfinite()
