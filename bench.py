@@ -441,6 +441,22 @@ def bench_decode_linears(dev, w4=False):
             "scope": "linears only (22 layers x [qkv, o, w1|w3, w2] %s GEMV with the activation quantize fused in), batch 1, hipGraph" % ("W4A8" if w4 else "W8A8")}
 
 
+def bench_pair(step):
+    """w1 and w3 of the FFN in ONE launch (mq_w8a8_linear_tiled_pair: 512 tiles, two per CU, same activation panel): the
+    headline GEMM as the layer actually runs it.  Both halves use the headline problem's operands."""
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_U8
+    if not step.tiled:
+        return None
+    half = dict(w=step.w8, alpha=step.alpha, w_zp=step.wzp, col_term=step.ct, bias=None, out_scale=step.oq.scale, out_offset=step.oq.offset)
+    step.quantize(0)
+    t = event_time(lambda: ops.int8_linear_pair(step.a8s[0], M, step.rss[0], half, half, out_dtype=MQ_U8), 30)
+    tops = 2 * OPS_PER_STEP / t / 1e12
+    return {"avg_launch_us": round(t * 1e6, 2), "us_per_gemm": round(t * 1e6 / 2, 2), "achieved_TOPS": round(tops, 1),
+            "frac_of_int8_peak": round(tops / INT8_MFMA_PEAK_TOPS, 4),
+            "note": "2 x (2048 x 2048 -> 5632) in one launch; allocates its two [M, N] outputs inside the timed call"}
+
+
 def bench_layer(dev):
     """The quantized-linear path of ONE TinyLlama decoder layer at prefill (S = 2048) through the module API:
     input_layernorm -> q/k/v, o_proj, post_attention_layernorm -> [w1, w3 -> act_fn -> * -> w2] (W8A8 recipe of
@@ -686,6 +702,7 @@ def main():
             tm = event_time(lambda: ql(x3), 30)
             extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
                                             "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
+            extras["ffn_pair_gemm"] = bench_pair(step)
             decode = bench_decode_full(dev)
             torch.cuda.empty_cache()
             decode["linears_only_w8a8"] = bench_decode_linears(dev)
