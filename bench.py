@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--per-channel", action="store_true", help="--workload calibration: per-channel statistics")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--headline-only", action="store_true", help="only the timed steps and the roofline leg (profiler passes)")
     p.add_argument("--gemm-variant", type=int, default=-1, help="force a GEMM tile variant (experiments)")
     p.add_argument("--row-major-activations", action="store_true",
                    help="A/B: quantise row-major and run the C++ ping-pong GEMM loop instead of the fragment-blocked layout")
@@ -259,21 +260,21 @@ def event_time(fn, iters):
 
 def pmc_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01/pmc_fetch + pmc_write; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
+    (profiles/r02/pmc_fetch + pmc_write; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
     streams on gfx950).  Counters cannot be read from inside the bench, so this is the last profiled value."""
     import re
-    d = os.path.join(ROOT, "profiles", "r01")
+    d = os.path.join(ROOT, "profiles", "r02")
     vals = {}
     for fn, key in (("pmc_fetch.summary.txt", "FETCH_SIZE"), ("pmc_write.summary.txt", "WRITE_SIZE")):
         try:
             txt = open(os.path.join(d, fn)).read()
         except OSError:
             return None, None
-        m = re.search(r"gemm_i8_kernel<256, 176, 8, 1, 3,[^\n]*\n(?:\s+\S+\s+[\d.]+[^\n]*\n)*?\s+" + key + r"\s+([\d.]+)", txt)
+        m = re.search(r"kernel: mq::gemm_i8_fr_kernel\([^\n]*\n(?:\s+\S+\s+[\d.]+[^\n]*\n)*?\s+" + key + r"\s+([\d.]+)", txt)
         if not m:
             return None, None
         vals[key] = float(m.group(1)) * 1024.0
-    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "profiles/r01/pmc_fetch.summary.txt + pmc_write.summary.txt"
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "profiles/r02/pmc_fetch.summary.txt + pmc_write.summary.txt"
 
 
 def cpu_baseline():
@@ -533,6 +534,88 @@ def bench_layer(dev):
     return res
 
 
+def bench_layer_full(dev):
+    """ONE whole TinyLlama decoder layer at prefill (B = 1, S = 2048) on the reference's module graph (mobilequant_amd/llama.py:
+    norms, q/k/v/o, RoPE, qk_bmm / pv_bmm QMatMuls, softmax, gated FFN, residual adds), W8A8 recipe of ptq/mobilequant.py:175-201,
+    ranges from this package's own calibration pass over the fp32 layer.  hipGraph time with (a) everything fused (fuse_attention:
+    integer q.k^T / p.v with the softmax in one kernel; fuse_gated_mlp; fused norms), (b) the attention as the chain of modules
+    (the [32, S, S] score tensor goes through memory ~6 times), (c) composite: every fused_mode off."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import get_act_range
+    from mobilequant_amd.quantization import qmodule as Q
+    S = 2048
+    shape = llama.LlamaShape.tinyllama(layers=1, max_pos=S, vocab=4096)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=1337, std=0.05)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, shape.vocab, (1, S), generator=g).to(dev)
+    with torch.no_grad():
+        act = get_act_range(model, [ids])
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(model, a8, a8)
+    for name, mod in model.named_modules():                 # ptq/mobilequant.py:175-201
+        if isinstance(mod, mq.QLinear) and "w2" in name:
+            mod.weight_quantizer.qcfg.is_per_channel = True
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QLinear) and "o_proj" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QMatMul) and "qk_bmm" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QMatMul) and "pv_bmm" in name:
+            mod.input_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(model, act, "buffer")
+    mq.wire_integer_inputs(model)
+    mq.fuse_gated_mlp(model)
+    llama.fuse_attention(model)
+    layer = model.layers[0]
+    with torch.no_grad():
+        x = model.embed_tokens(ids)
+    cos, sin = model.cos[:S], model.sin[:S]
+    mask = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    mask._mq_causal = True
+    res = {}
+    outs = {}
+    for mode in ("fused", "attention_chain", "composite"):
+        for m in layer.modules():
+            if hasattr(m, "fused_mode"):
+                m.fused_mode = "off" if mode == "composite" else "auto"
+        layer.mlp.fused_mode = "off" if mode == "composite" else "auto"
+        layer.self_attn.fused_mode = "auto" if mode == "fused" else "off"
+
+        def fwd():
+            if mode == "composite":
+                Q._shared_activation.clear()
+            with torch.no_grad():
+                outs[mode] = layer(x, cos, sin, mask)
+        fwd()
+        res[mode + "_us"] = round(event_time(fwd, 3) * 1e6, 1)
+    # the attention op alone (prep + core kernels), with the arguments the fused layer hands it
+    from mobilequant_amd import ops as _ops
+    rec, real = [], _ops.attention_quant
+    _ops.attention_quant = lambda *a, **k: (rec.append((a, k)), real(*a, **k))[1]
+    try:
+        layer.self_attn.fused_mode, layer.mlp.fused_mode = "auto", "auto"
+        with torch.no_grad():
+            layer(x, cos, sin, mask)
+    finally:
+        _ops.attention_quant = real
+    (a_args, a_kw), = rec
+    res["attention_op_us"] = round(event_time(lambda: real(*a_args, **a_kw), 5) * 1e6, 1)
+    span = float(outs["attention_chain"].max() - outs["attention_chain"].min())
+    res["fused_vs_chain_max_over_span"] = round(float((outs["fused"] - outs["attention_chain"]).abs().max()) / span, 5)
+    hidden, kv, ffn = shape.hidden, shape.kv_heads * shape.head_dim, shape.ffn
+    ops_lin = 2.0 * S * (hidden * hidden * 2 + hidden * kv * 2 + hidden * ffn * 3)
+    ops_att = 2.0 * shape.heads * shape.head_dim * S * S          # causal: q.k^T + p.v, each 2 * S^2 / 2 * D per head
+    res["tops_fused"] = round((ops_lin + ops_att) / (res["fused_us"] * 1e-6) / 1e12, 1)
+    res["scope"] = "one whole TinyLlama decoder layer, B = 1, S = 2048, W8A8 recipe, module API, hipGraph"
+    return res
+
+
 def calibration_run(dev, rank, world, layers, n_samples, seq, per_channel):
     """ptq/generate_act_range.py:49-122 data-parallel: every rank holds the same random-init TinyLlama-shaped fp32 model
     (mobilequant_amd/llama.py: the reference's leaf-module graph incl. the two FMatMuls), runs samples rank, rank + world, ...
@@ -628,6 +711,36 @@ def bench_calibration(args, rank, world, dev):
         "cpu_baseline": None}))
 
 
+def bench_variants(dev, step, args):
+    """The non-headline legs of the qlinear workload (rank 0): module forward, pair GEMM, decode, layer benchmarks."""
+    extras = {}
+    # drop-in nn.Module forward: fp32 in -> fp32 out, weight cached as int8 after the first call
+    import mobilequant_amd as mq
+    lin = torch.nn.Linear(K, N, bias=False, device=dev)
+    with torch.no_grad():
+        lin.weight.copy_(step.w_fp)
+    a8 = mq.QuantConfig(bitwidth=8)
+    ql = mq.QLinear.from_float(lin, a8, a8, a8).requires_grad_(False)
+    ql.input_quantizer.set_scale_offset_from_minmax(float(step.x[0].min()), float(step.x[0].max()), "buffer", dev)
+    ql.output_quantizer.set_scale_offset_from_minmax(-3.0, 3.0, "buffer", dev)
+    x3 = step.x[0].view(1, M, K)
+    ql(x3)
+    tm = event_time(lambda: ql(x3), 30)
+    extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
+                                    "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
+    extras["ffn_pair_gemm"] = bench_pair(step)
+    decode = bench_decode_full(dev)
+    torch.cuda.empty_cache()
+    decode["linears_only_w8a8"] = bench_decode_linears(dev)
+    torch.cuda.empty_cache()
+    decode["linears_only_w4a8"] = bench_decode_linears(dev, w4=True)      # the reference's deployment mode: 4-bit weights
+    torch.cuda.empty_cache()
+    extras["layer_prefill"] = bench_layer(dev)
+    extras["layer_prefill_full"] = bench_layer_full(dev)
+    extras["_decode"] = decode
+    return extras
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -661,56 +774,41 @@ def main():
         roof = cpu = decode = None
         # the data-parallel half of the hot path, bounded: 8 samples per rank through 2 TinyLlama-shaped layers + the single
         # all-reduce -- so every multi-GPU run of this file also drives the RCCL path (full configs[4]: --workload calibration)
-        cal = calibration_run(dev, rank, world, layers=2, n_samples=8 * world, seq=2048, per_channel=False)
-        extras["calibration_dp"] = {"samples_per_s": round(cal["samples_per_s"], 2), "n_gpus": world, "samples": 8 * world, "layers": 2,
-                                    "seq": 2048, "collectives": cal["collectives"], "scaling": "weak (8 samples per rank)"}
-        torch.cuda.empty_cache()
+        if not args.headline_only:
+            cal = calibration_run(dev, rank, world, layers=2, n_samples=8 * world, seq=2048, per_channel=False)
+            extras["calibration_dp"] = {"samples_per_s": round(cal["samples_per_s"], 2), "n_gpus": world, "samples": 8 * world, "layers": 2,
+                                        "seq": 2048, "collectives": cal["collectives"], "scaling": "weak (8 samples per rank)"}
+            torch.cuda.empty_cache()
         if rank == 0:
             # dominant kernel alone, HIP events on its stream
             t_gemm = event_time(step.gemm, 50)
             t_quant = event_time(lambda: step.quantize(0), 50)
             achieved = OPS_PER_STEP / t_gemm / 1e12
             traffic, traffic_src = pmc_traffic()
-            roof = {"bound": "mfma", "kernel": "mq::gemm_i8_kernel (%s)" % ("mq_w8a8_linear_tiled: generated-ISA loop, fragment-blocked activations"
-                                                                        if step.tiled else "mq_w8a8_linear"), "achieved": round(achieved, 1),
+            roof = {"bound": "mfma", "kernel": ("mq::gemm_i8_fr_kernel (mq_w8a8_linear_tiled: free-running whole-kernel gfx950 ISA, fragment-blocked "
+                                                "activations)" if step.tiled else "mq::gemm_i8_kernel (mq_w8a8_linear)"), "achieved": round(achieved, 1),
                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOPS", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
                     "avg_launch_us": round(t_gemm * 1e6, 2), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": M * K + N * K + M * N,
                     "algorithmic_ops_per_launch": OPS_PER_STEP,
+                    "notes": "MFMA busy 22 528 cycles per SIMD of ~31 k wave cycles; the chip clocks ~1.8 GHz under this load (s_memtime / "
+                             "s_memrealtime inside the kernel, profiles/r02) and ~5 us of each launch period lie outside the waves' "
+                             "lifetime (dispatch + end-of-kernel release): DESIGN.md 4.2",
                     "quantize_kernel": {"bound": "hbm", "avg_launch_us": round(t_quant * 1e6, 2),
                                         "achieved_GBps": round((M * K * 5 + M * 4) / t_quant / 1e9, 1), "peak_GBps": 8000.0}}
             if pipelined:
                 t_ser = run_steps(step, min(args.steps, 100), 5, 1, use_graph=True, pipelined=False)
                 extras["serial_u8"] = {"ms_per_step": round(t_ser * 1e3, 5), "value": round(OPS_PER_STEP / t_ser / 1e12, 1),
                                        "note": "quantize and GEMM back to back on one stream"}
-            for name, code in (("out_f16", MQ_F16), ("out_f32", MQ_F32)):
+            for name, code in (() if args.headline_only else (("out_f16", MQ_F16), ("out_f32", MQ_F32))):
                 s2 = Step(dev, code, seed=rank)
                 t2 = run_steps(s2, min(args.steps, 100), 5, 1, use_graph=not args.no_graph)
                 extras[name] = {"ms_per_step": round(t2 * 1e3, 5), "value": round(OPS_PER_STEP / t2 / 1e12, 1)}
                 del s2
-            # drop-in nn.Module forward: fp32 in -> fp32 out, weight cached as int8 after the first call
-            import mobilequant_amd as mq
-            lin = torch.nn.Linear(K, N, bias=False, device=dev)
-            with torch.no_grad():
-                lin.weight.copy_(step.w_fp)
-            a8 = mq.QuantConfig(bitwidth=8)
-            ql = mq.QLinear.from_float(lin, a8, a8, a8).requires_grad_(False)
-            ql.input_quantizer.set_scale_offset_from_minmax(float(step.x[0].min()), float(step.x[0].max()), "buffer", dev)
-            ql.output_quantizer.set_scale_offset_from_minmax(-3.0, 3.0, "buffer", dev)
-            x3 = step.x[0].view(1, M, K)
-            ql(x3)
-            tm = event_time(lambda: ql(x3), 30)
-            extras["module_forward_f32"] = {"ms_per_step": round(tm * 1e3, 5), "value": round(OPS_PER_STEP / tm / 1e12, 1),
-                                            "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
-            extras["ffn_pair_gemm"] = bench_pair(step)
-            decode = bench_decode_full(dev)
-            torch.cuda.empty_cache()
-            decode["linears_only_w8a8"] = bench_decode_linears(dev)
-            torch.cuda.empty_cache()
-            decode["linears_only_w4a8"] = bench_decode_linears(dev, w4=True)      # the reference's deployment mode: 4-bit weights
-            torch.cuda.empty_cache()
-            extras["layer_prefill"] = bench_layer(dev)
-            if not args.no_cpu_baseline:
+            if not args.headline_only:
+                extras.update(bench_variants(dev, step, args))
+                decode = extras.pop("_decode")
+            if not args.no_cpu_baseline and not args.headline_only:
                 cpu = cpu_baseline()
 
     if rank == 0:

@@ -331,6 +331,34 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
 int mq_decode_head(const float* x, const float* norm_weight, float eps, const float* w, const float* bias, int64_t K,
                    int64_t V, float* logits, mq_stream_t stream);
 
+/* ---- a10: quantized causal attention at prefill (hf_model.py:486-534 with the two QMatMuls of qmodule.py:453-466) ------------ */
+/* One sequence.  q [seq, heads*D], k / v [seq, kv_heads*D] fp32 = the q / k / v projection outputs BEFORE RoPE; cos / sin [seq, D]
+ * (rotate-half); out [seq, heads*D] fp32 = pv_bmm's (quantised when pv_out.scale != NULL) output in o_proj's input layout.
+ * Grids: qk_a / qk_b / pv_b 8-bit unsigned per tensor; qk_out (nullable scale = no output quantizer) and pv_a (<= 16 bit unsigned).
+ * Causal mask only (the mask of hf_model.py:1180-1205 at prefill); the scores are divided by sqrt(D) AFTER qk_out, as the reference.
+ * Scratch (caller-owned, overwritten): q_i8 [heads][seq][D], k_i8 [kv_heads][seq][D], vt_i8 [kv_heads][seq/64][D][64] (values
+ * transposed, keys permuted inside each 64-block), q_rowsum [heads][seq], k_rowsum [kv_heads][seq] (the zero-point terms of the integer
+ * q.k^T, derived from the row sums of the images), v_colsum [kv_heads][seq/64][D].
+ * Limits: head_dim == 64, seq % 64 == 0.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
+typedef struct mq_attention_args {
+  const float* q;
+  const float* k;
+  const float* v;
+  const float* cos;
+  const float* sin;
+  int seq, heads, kv_heads, head_dim;
+  float inv_sqrt_d;
+  mq_grid qk_a, qk_b, qk_out, pv_a, pv_b, pv_out;
+  float* out;
+  int8_t* q_i8;
+  int8_t* k_i8;
+  int8_t* vt_i8;
+  int32_t* q_rowsum;
+  int32_t* k_rowsum;
+  int32_t* v_colsum;
+} mq_attention_args;
+int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

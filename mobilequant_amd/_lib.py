@@ -42,6 +42,14 @@ class MqDecodeAttentionArgs(ctypes.Structure):
                 ("inv_sqrt_d", c_float), ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
                 ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p)]
 
+class MqAttentionArgs(ctypes.Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("seq", c_int),
+                ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("inv_sqrt_d", c_float), ("qk_a", MqGrid),
+                ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid), ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p),
+                ("q_i8", c_void_p), ("k_i8", c_void_p), ("vt_i8", c_void_p), ("q_rowsum", c_void_p), ("k_rowsum", c_void_p),
+                ("v_colsum", c_void_p)]
+
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "mq_version": (c_int, []),
@@ -78,6 +86,7 @@ _SIGNATURES = {
     "mq_decode_gemv": (c_int, [POINTER(MqDecodeGemvArgs), _P]),
     "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
     "mq_decode_head": (c_int, [_P, _P, c_float, _P, _P, c_int64, c_int64, _P, _P]),
+    "mq_attention_quant": (c_int, [POINTER(MqAttentionArgs), _P]),
     "mq_gemm_set_variant": (c_int, [c_int]),
     "mq_gemm_variant_name": (c_char_p, [c_int]),
     "mq_gemm_set_debug": (c_int, [c_int]),

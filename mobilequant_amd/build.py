@@ -19,7 +19,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmobilequant_amd.so")
-SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemv.hip", "mq_norm.hip", "mq_decode.hip"]
+SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemv.hip", "mq_norm.hip", "mq_decode.hip", "mq_attention.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ABLATE = (["-DMQ_GEMM_ABLATE"] if os.environ.get("MQ_GEMM_ABLATE") else []) + \
     ([f"-DMQ_PP_PRIO={os.environ['MQ_PP_PRIO']}"] if os.environ.get("MQ_PP_PRIO") else [])

@@ -1,0 +1,348 @@
+// Quantized causal attention for prefill: the core of HFAttention.forward (mobilellm/model/hf_model.py:486-534) with its two QMatMuls
+// (mobilellm/quantization/qmodule.py:453-466) as REAL integer matrix products, the S x S score tensor never written to memory.
+//
+//   reference (per head):  q, k <- RoPE (fp32)
+//     s  = Qqk_out( matmul(Qqk_a(q), Qqk_b(k^T)) ) / sqrt(D)  (+ causal mask)          8-bit x 8-bit -> 16-bit grid,  [S, S] fp32
+//     p  = softmax(s)                                                                   fp32
+//     o  = Qpv_out( matmul(Qpv_a(p), Qpv_b(v)) )                                        16-bit x 8-bit -> 8-bit grid
+//   The simulated form makes ~6 passes over 32 x S x S floats per layer (537 MB each at S = 2048): that, not the linears, is where a
+//   prefill layer's time goes.
+//
+// Here:  mq_attention_prep   RoPE + the three input quantizers -> int8 images: q [H][S][D], k [KV][S][D] (+ row sums of the stored
+//                            values) and v TRANSPOSED and key-permuted per 64-key block: vT [KV][S/64][D][64] (+ per-block column sums)
+//        mq_attention_quant  one workgroup per (64-query block, head), 4 waves x 16 queries.  Two sweeps over the key blocks up to the
+//                            diagonal, both on v_mfma_i32_16x16x64_i8:
+//                              sweep 1: integer q.k^T -> zero-point correction -> 16-bit output grid -> /sqrt(D) -> mask -> online row
+//                                       max / sum of exp
+//                              sweep 2: the same scores again (bit-identical), p = exp(s - m) / l -> 16-bit grid index -> split into
+//                                       two unsigned bytes -> integer p.v as TWO int8 products (high and low byte) -> exact integer
+//                                       combination in double -> 8-bit output grid
+//                            The MFMA is issued as mfma(K tile, Q tile): D[t][s], a lane owns ONE query row and 4 keys per tile, so the
+//                            softmax statistics are lane-local plus two cross-lane steps.  The D layout of the scores is used directly
+//                            as the A-operand layout of the p.v product by permuting the keys inside a 64-block (kappa = 16 tq + 4 j + e
+//                            <-> t = 16 j + 4 tq + e); vT is stored in that order, so no data moves between the two products.
+// Arithmetic: integer contractions are exact; quantizers use the reciprocal-multiply form of the GEMM epilogues (index within one grid
+// step of the divide form on a vanishing fraction of elements); softmax in fp32.
+#include "mq_common.h"
+
+namespace mq {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+#pragma clang fp contract(off)
+
+struct AGrid {
+  float s, o, qmin, qmax, inv_s;
+  bool on;
+};
+__device__ __forceinline__ AGrid a_load_grid(const mq_grid& g) {
+  AGrid r;
+  r.on = g.scale != nullptr;
+  r.s = r.on ? g.scale[0] : 1.f;
+  r.o = r.on ? g.offset[0] : 0.f;
+  r.qmin = g.qmin;
+  r.qmax = g.qmax;
+  r.inv_s = __fdiv_rn(1.0f, r.s);
+  return r;
+}
+// exact form (qmodule.py:286-287), used by the prep kernel
+__device__ __forceinline__ float a_index_exact(float x, const AGrid& g) {
+  const float t = __fdiv_rn(x, g.s);
+  const float q = __fadd_rn(__fadd_rn(__fsub_rn(rintf(t), t), t), g.o);
+  const float c = fminf(fmaxf(q, g.qmin), g.qmax);
+  return q != q ? g.qmin : c;
+}
+// reciprocal-multiply form, used inside the attention kernel
+__device__ __forceinline__ float a_index_fast(float x, const AGrid& g) {
+  return fminf(fmaxf(rintf(x * g.inv_s) + g.o, g.qmin), g.qmax);
+}
+
+// ---- prep: RoPE + input quantizers -> integer images ----------------------------------------------------------------------------
+// grid: (S / 64, H + 2 KV).  Block b of part p: rows s = 64 b .. 64 b + 63.  256 threads: thread (r = tid >> 2, c = tid & 3) handles
+// row r, 16 columns 16 c .. 16 c + 15  (D = 64).
+__global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_args a) {
+  const int D = 64;
+  const int H = a.heads, KV = a.kv_heads, S = a.seq;
+  const int part = blockIdx.y;                       // [0, H): q head; [H, H+KV): k head; [H+KV, H+2KV): v head
+  const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const int s = blockIdx.x * 64 + r;
+  __shared__ int s_rs[64];
+  __shared__ int8_t s_v[64][64 + 4];
+  if (threadIdx.x < 64) s_rs[threadIdx.x] = 0;
+  __syncthreads();
+  const bool is_q = part < H, is_k = !is_q && part < H + KV;
+  const int head = is_q ? part : (is_k ? part - H : part - H - KV);
+  const float* src = (is_q ? a.q : (is_k ? a.k : a.v)) + (size_t)s * (is_q ? H : KV) * D + (size_t)head * D;
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = src[16 * c + i];
+  const AGrid g = a_load_grid(is_q ? a.qk_a : (is_k ? a.qk_b : a.pv_b));
+  int st[16];
+  if (is_q || is_k) {                                 // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
+    float y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = 16 * c + i;
+      const float partner = d < 32 ? -src[d + 32] : src[d - 32];
+      y[i] = __fadd_rn(__fmul_rn(x[i], a.cos[(size_t)s * D + d]), __fmul_rn(partner, a.sin[(size_t)s * D + d]));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = (int)a_index_exact(y[i], g) - 128;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = (int)a_index_exact(x[i], g) - 128;
+  }
+  int sum = 0;
+  unsigned w[4];
+#pragma unroll
+  for (int d4 = 0; d4 < 4; ++d4) {
+    unsigned pk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sum += st[4 * d4 + e];
+      pk |= ((unsigned)st[4 * d4 + e] & 0xffu) << (8 * e);
+    }
+    w[d4] = pk;
+  }
+  if (is_q || is_k) {
+    int8_t* dst = (is_q ? a.q_i8 + (size_t)head * S * D : a.k_i8 + (size_t)head * S * D) + (size_t)s * D + 16 * c;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    // the zero-point terms of sum_d (qi - zq)(ki - zk) = sum qs ks - zq' rowsum(ks) - zk' rowsum(qs) + D zq' zk'  (primes: - 128)
+    const int zq = (int)a_load_grid(a.qk_a).o - 128, zk = (int)a_load_grid(a.qk_b).o - 128;
+    if (c == 0) {
+      if (is_q) a.q_rowsum[(size_t)head * S + s] = D * zq * zk - zk * sum;
+      else a.k_rowsum[(size_t)head * S + s] = -zq * sum;
+    }
+  } else {
+    // vT [KV][S/64][D][64]: position kappa of key t (inside its 64-block): t = 16 j + 4 tq + e  <->  kappa = 16 tq + 4 j + e
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_v[16 * c + i][r] = (int8_t)st[i];
+    __syncthreads();
+    // thread (d = tid >> 2, quarter c): 16 kappa = 16 c .. 16 c + 15  -> tq = c, (j, e) = (i >> 2, i & 3) -> t = 16 j + 4 c + e
+    const int d = threadIdx.x >> 2;
+    unsigned o4[4];
+    int csum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int v = s_v[d][16 * j + 4 * c + e];
+        csum += v;
+        pk |= ((unsigned)v & 0xffu) << (8 * e);
+      }
+      o4[j] = pk;
+    }
+    int8_t* dst = a.vt_i8 + (((size_t)head * (S >> 6) + blockIdx.x) * D + d) * 64 + 16 * c;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    csum += __shfl_xor(csum, 1, 64);
+    csum += __shfl_xor(csum, 2, 64);
+    if (c == 0) a.v_colsum[((size_t)head * (S >> 6) + blockIdx.x) * D + d] = csum;
+  }
+}
+
+// ---- the attention kernel ---------------------------------------------------------------------------------------------------------
+// Per score element the VALU chain is what bounds this kernel (2 sweeps x ~10 instructions; the MFMAs run beside it), so the two
+// quantizers are evaluated in the "magic number" form: f = fma(float(ti), beta, o + 1.5 * 2^23) IS round-to-nearest-even of
+// ti * beta + o in the low mantissa bits; the clamp is one v_med3_f32 against [magic + qmin, magic + qmax]; differences of two such
+// values are exact integers; the 16-bit probability index is read from the mantissa bytes with v_perm_b32.
+constexpr float kMagic = 12582912.0f;             // 1.5 * 2^23
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <bool QK_OUT>
+__global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention_args a) {
+  const int D = 64;
+  const int S = a.seq, H = a.heads, KV = a.kv_heads;
+  const int h = blockIdx.y, kvh = h / (H / KV);
+  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;              // long (late) query blocks first: better tail balance
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int srow = lane & 15, tq = lane >> 4;
+  const int s_abs = qb * 64 + wave * 16 + srow;                     // this lane's query row
+  const AGrid gqa = a_load_grid(a.qk_a), gqb = a_load_grid(a.qk_b), gqo = a_load_grid(a.qk_out);
+  const AGrid gpa = a_load_grid(a.pv_a), gpb = a_load_grid(a.pv_b), gpo = a_load_grid(a.pv_out);
+  const int zv = (int)gpb.o - 128, zp = (int)gpa.o;
+  const float alpha_qk = __fmul_rn(gqa.s, gqb.s);
+  // scores: QK_OUT: f = magic + index on the 16-bit grid; value = (index - o) * s / 8.   else: f = ti * alpha / 8 (the value itself)
+  const float beta = QK_OUT ? alpha_qk * gqo.inv_s : alpha_qk * 0.125f;
+  const float fbias = QK_OUT ? gqo.o + kMagic : 0.f;
+  const float flo = kMagic + gqo.qmin, fhi = kMagic + gqo.qmax;
+  const float cexp = QK_OUT ? gqo.s * 0.125f * kLog2e : kLog2e;     // exp(value - max) = exp2((f - fmax) * cexp)
+
+  const int8_t* qbase = a.q_i8 + ((size_t)h * S + (size_t)qb * 64 + wave * 16) * D;
+  const v4i qf = *reinterpret_cast<const v4i*>(qbase + srow * D + tq * 16);
+  const int qconst = a.q_rowsum[(size_t)h * S + s_abs];             // D zq zk - zk * rowsum(q), from the prep kernel
+  const int8_t* kbase = a.k_i8 + (size_t)kvh * S * D;
+  const int* kterm = a.k_rowsum + (size_t)kvh * S;                  // -zq * rowsum(k)
+  const int nkb = qb + 1;                                           // key blocks 0 .. qb (causal)
+  const v4i cinit = {qconst, qconst, qconst, qconst};
+
+  struct KTile {
+    v4i kf[4];
+    int4 kt[4];
+  };
+  auto load_k = [&](int kb, KTile& t) {
+    const int8_t* kp = kbase + (size_t)kb * 64 * D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t.kf[j] = *reinterpret_cast<const v4i*>(kp + (16 * j + srow) * D + tq * 16);
+      t.kt[j] = *reinterpret_cast<const int4*>(kterm + kb * 64 + 16 * j + 4 * tq);
+    }
+  };
+  // f values of this lane's row against keys t = 64 kb + 16 j + 4 tq + e
+  auto scores = [&](const KTile& t, bool diag, int kb, float (&f)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(t.kf[j], qf, cinit, 0, 0, 0);
+      const int kt[4] = {t.kt[j].x, t.kt[j].y, t.kt[j].z, t.kt[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ti = (float)(acc[e] + kt[e]);                    // sum_d (qi - zq)(ki - zk), exact (< 2^24)
+        float v = __builtin_fmaf(ti, beta, fbias);
+        if (QK_OUT) v = __builtin_amdgcn_fmed3f(v, flo, fhi);
+        f[4 * j + e] = v;
+      }
+    }
+    if (diag) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t_abs = kb * 64 + 16 * (i >> 2) + 4 * tq + (i & 3);
+        f[i] = t_abs <= s_abs ? f[i] : -INFINITY;
+      }
+    }
+  };
+
+  // ---- sweep 1: row max and sum of exp ----------------------------------------------------------------------------------------
+  float m = -INFINITY, l = 0.f;
+  {
+    KTile cur, nxt;
+    load_k(0, cur);
+    for (int kb = 0; kb < nkb; ++kb) {
+      if (kb + 1 < nkb) load_k(kb + 1, nxt);
+      float f[16];
+      scores(cur, kb == qb, kb, f);
+      float bm = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
+      bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(f[8], f[9]), fmaxf(f[10], f[11])), fmaxf(fmaxf(f[12], f[13]), fmaxf(f[14], f[15]))));
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m, bm);                                 // finite: key 0 is never masked
+      float bs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bs += fast_exp2((f[i] - mn) * cexp);
+      bs += __shfl_xor(bs, 16, 64);
+      bs += __shfl_xor(bs, 32, 64);
+      l = l * fast_exp2((m - mn) * cexp) + bs;
+      m = mn;
+      if (kb + 1 < nkb) cur = nxt;
+    }
+  }
+  // p index = clamp(rint((e / l) / s_p) + z_p): g = fma(e, 1 / (l s_p), z_p + magic), index = low mantissa bits of med3(g, ...)
+  const float rp = __fdiv_rn(gpa.inv_s, l);
+  const float pbias = gpa.o + kMagic, plo = kMagic + gpa.qmin, phi = kMagic + gpa.qmax;
+
+  // ---- sweep 2: probabilities on their 16-bit grid, integer p.v ------------------------------------------------------------------
+  v4i acc_hi[4], acc_lo[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) acc_hi[dt] = acc_lo[dt] = v4i{0, 0, 0, 0};
+  unsigned psum_hi = 0, psum_lo = 0;                                // sums of the unsigned high / low bytes (this lane's share)
+  int vsum[4][4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vsum[dt][e] = 0;
+  const int8_t* vbase = a.vt_i8 + (size_t)kvh * (S >> 6) * D * 64;
+  const int* vcs = a.v_colsum + (size_t)kvh * (S >> 6) * D;
+  {
+    KTile cur, nxt;
+    load_k(0, cur);
+    for (int kb = 0; kb < nkb; ++kb) {
+      const int8_t* vt = vbase + (size_t)kb * D * 64;
+      v4i vf[4];
+      int4 cs[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        vf[dt] = *reinterpret_cast<const v4i*>(vt + (16 * dt + srow) * 64 + tq * 16);      // rows d, kappa = 16 tq .. (key-permuted)
+        cs[dt] = *reinterpret_cast<const int4*>(vcs + kb * D + 16 * dt + 4 * tq);
+      }
+      if (kb + 1 < nkb) load_k(kb + 1, nxt);
+      float f[16];
+      scores(cur, kb == qb, kb, f);
+      v4i pf_hi, pf_lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ex = fast_exp2((f[4 * j + e] - m) * cexp);     // masked keys: exp2(-inf) = 0 -> index z_p -> contributes (z_p - z_p) = 0
+          const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(ex, rp, pbias), plo, phi);
+          b[e] = __float_as_uint(g);
+        }
+        const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+        const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u), hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
+        psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
+        psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+        pf_lo[j] = (int)(lo ^ 0x80808080u);
+        pf_hi[j] = (int)(hi ^ 0x80808080u);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
+        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
+        vsum[dt][0] += cs[dt].x; vsum[dt][1] += cs[dt].y; vsum[dt][2] += cs[dt].z; vsum[dt][3] += cs[dt].w;
+      }
+      if (kb + 1 < nkb) cur = nxt;
+    }
+  }
+  long long psum = 256ll * psum_hi + psum_lo;
+  psum += __shfl_xor(psum, 16, 64);
+  psum += __shfl_xor(psum, 32, 64);
+  const long long nproc = (long long)nkb * 64;
+  // out[s][d] = sp * sv * sum_t (p_idx - zp)(v_st - zv),  p_idx = 256 (hi_s + 128) + (lo_s + 128)
+  //           = sp * sv * [ 256 A_hi + A_lo + 32896 V - zv P - zp V + zp zv T' ],  A_* = sum byte * v_st, V = sum v_st, P = sum p_idx
+  const float alpha_pv = __fmul_rn(gpa.s, gpb.s);
+  float* orow = a.out + (size_t)s_abs * H * D + (size_t)h * D;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long V = vsum[dt][e];
+      const long long tot = 256ll * acc_hi[dt][e] + (long long)acc_lo[dt][e] + 32896ll * V - (long long)zv * psum - (long long)zp * V +
+                            (long long)zp * zv * nproc;
+      const float pre = (float)((double)tot * (double)alpha_pv);
+      o4[e] = gpo.on ? __fmul_rn(__fsub_rn(a_index_fast(pre, gpo), gpo.o), gpo.s) : pre;
+    }
+    *reinterpret_cast<float4*>(orow + 16 * dt + 4 * tq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+  }
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream) {
+  MQ_REQUIRE(args != nullptr, "mq_attention_quant: null argument block");
+  const mq_attention_args& a = *args;
+  MQ_REQUIRE(a.q && a.k && a.v && a.cos && a.sin && a.out && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum && a.v_colsum,
+             "mq_attention_quant: null pointer");
+  MQ_REQUIRE(a.head_dim == 64 && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
+             "mq_attention_quant: head_dim 64, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
+  MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmax == 255.f && a.qk_b.qmax == 255.f && a.pv_b.qmax == 255.f &&
+                 a.qk_a.qmin == 0.f && a.qk_b.qmin == 0.f && a.pv_b.qmin == 0.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
+             "mq_attention_quant: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
+  MQ_REQUIRE(aligned(a.q, 16) && aligned(a.k, 16) && aligned(a.v, 16) && aligned(a.out, 16) && aligned(a.q_i8, 16) && aligned(a.k_i8, 16) &&
+                 aligned(a.vt_i8, 16) && aligned(a.k_rowsum, 16) && aligned(a.v_colsum, 16),
+             "mq_attention_quant: pointers must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  attention_prep_kernel<<<dim3((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), 256, 0, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
+  if (a.qk_out.scale != nullptr)
+    attention_quant_kernel<true><<<dim3((unsigned)(a.seq / 64), (unsigned)a.heads), 256, 0, st>>>(a);
+  else
+    attention_quant_kernel<false><<<dim3((unsigned)(a.seq / 64), (unsigned)a.heads), 256, 0, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_attention_quant");
+  return MQ_OK;
+}

@@ -96,6 +96,59 @@ class Attention(nn.Module):
         return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
 
 
+def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
+    """Attention.forward with RoPE, both QMatMuls, 1/sqrt(d), the causal mask and the softmax in ONE pair of launches
+    (ops.attention_quant: integer q.k^T and p.v on the MFMA units, no [S, S] tensor in memory).  Serves causal prefill from position
+    0 with static per-tensor grids (8-bit q / k / v, <= 16-bit probabilities) at head_dim 64; everything else -- training, decode steps,
+    a custom mask, other shapes -- runs the module chain.  Installed by fuse_attention()."""
+    from . import ops
+    from .quantization import qmodule as Q
+    s = self.s
+    plain = self._mq_plain_forward
+    qk, pv = self.qk_bmm, self.pv_bmm
+    B, S, _ = x.shape
+    if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim != 64 or S < 2
+            or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
+            or Q._needs_grad(x, *self.parameters())):
+        return plain(x, cos, sin, mask, cache, pos)
+    if not (Q._u8_grid(qk.input_quantizer) and Q._u8_grid(qk.input2_quantizer) and Q._u8_grid(pv.input2_quantizer)
+            and Q._static_per_tensor(pv.input_quantizer, 16) and pv.input_quantizer.qmin == 0):
+        return plain(x, cos, sin, mask, cache, pos)
+    grids = {}
+    for name, quantizer in (("qk_a", qk.input_quantizer), ("qk_b", qk.input2_quantizer), ("qk_out", qk.output_quantizer),
+                            ("pv_a", pv.input_quantizer), ("pv_b", pv.input2_quantizer), ("pv_out", pv.output_quantizer)):
+        g = Q.QRMSNorm._grid_or_none(quantizer)
+        if g is False:
+            return plain(x, cos, sin, mask, cache, pos)
+        if g is not None and g[0].device != x.device:
+            quantizer.scale.data, quantizer.offset.data = quantizer.scale.to(x.device), quantizer.offset.to(x.device)
+            g = Q.QRMSNorm._grid_or_none(quantizer)
+        grids[name] = g
+    q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+    if cache is not None:
+        cache[0][:, :, :S] = apply_rope(k.view(B, S, s.kv_heads, 64).transpose(1, 2), cos, sin)
+        cache[1][:, :, :S] = v.view(B, S, s.kv_heads, 64).transpose(1, 2)
+    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids) for b in range(B)])
+    if pv.output_quantizer is not None and not pv.output_quantizer.bypassed():
+        Q._tag_grid(out, pv.output_quantizer)
+    return self.o_proj(out)
+
+
+def fuse_attention(model) -> int:
+    """Graph pass (no counterpart in the reference, like quantization.fuse_gated_mlp): every Attention block whose qk_bmm / pv_bmm
+    became QMatMuls gets the fused forward above.  `block.fused_mode = "off"` restores the chain.  Returns the number fused."""
+    import types
+    from .quantization import qmodule as Q
+    n = 0
+    for m in model.modules():
+        if (isinstance(m, Attention) and isinstance(m.qk_bmm, Q.QMatMul) and isinstance(m.pv_bmm, Q.QMatMul)
+                and not hasattr(m, "_mq_plain_forward")):
+            m._mq_plain_forward = m.forward
+            m.forward = types.MethodType(_fused_attention_forward, m)
+            n += 1
+    return n
+
+
 class MLP(nn.Module):
     def __init__(self, s: LlamaShape):
         super().__init__()
@@ -156,6 +209,7 @@ class LlamaForCausalLM(nn.Module):
         mask = None
         if S > 1:
             mask = torch.full((S, pos + S), float("-inf"), device=x.device, dtype=x.dtype).triu(pos + 1)
+            mask._mq_causal = True          # lets a fused attention skip the masked key blocks instead of reading the mask
         for i, layer in enumerate(self.layers):
             x = layer(x, cos, sin, mask, None if cache is None else cache[i], pos)
         return self.lm_head(self.norm(x))

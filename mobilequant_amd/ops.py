@@ -6,6 +6,7 @@ otherwise -- there is no CPU or eager-PyTorch fallback.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -408,3 +409,46 @@ def gated_act_quant(a: torch.Tensor, b: torch.Tensor, act: str, out_grid, *, a_g
                   {"silu": 0, "gelu": 1}[act], *ptrs, int(q_shift), q.data_ptr(), rs.data_ptr(),
                   y.data_ptr() if y is not None else None, _stream())
     return (q, rs, y) if want_y else (q, rs)
+
+
+def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int,
+                    kv_heads: int, grids: dict) -> torch.Tensor:
+    """Quantized causal prefill attention of ONE sequence (mq_attention_quant): q [S, heads*64], k / v [S, kv_heads*64] fp32
+    projection outputs before RoPE, cos / sin [S, 64]; grids: qk_a, qk_b, qk_out, pv_a, pv_b, pv_out -> (scale, offset, qmin, qmax)
+    per tensor or None (qk_out / pv_out only).  Returns pv_bmm's output [S, heads*64] fp32 (o_proj's input layout)."""
+    q, k, v = (_dev(t, n).contiguous() for t, n in ((q, "q"), (k, "k"), (v, "v")))
+    cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
+    S, D = q.shape[0], 64
+    if (q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or q.shape != (S, heads * D)
+            or k.shape != (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, D) or sin.shape != (S, D)):
+        raise RuntimeError("mobilequant_amd: attention_quant needs fp32 q [S, H*64], k / v [S, KV*64], cos / sin [S, 64]")
+    S_real = S
+    if S % 64:                    # pad the sequence: under the causal mask a padded key is only ever seen by padded queries
+        pad = 64 - S % 64
+        q, k, v, cos, sin = (torch.nn.functional.pad(t, (0, 0, 0, pad)) for t in (q, k, v, cos, sin))
+        S += pad
+    a = _lib.MqAttentionArgs()
+    keep = []
+    for name in ("qk_a", "qk_b", "qk_out", "pv_a", "pv_b", "pv_out"):
+        g = grids.get(name)
+        if g is None:
+            setattr(a, name, _lib.MqGrid(None, None, 0.0, 0.0))
+        else:
+            s, o = _f32(g[0], "scale"), _f32(g[1], "offset")
+            keep += [s, o]
+            setattr(a, name, _lib.MqGrid(s.data_ptr(), o.data_ptr(), float(g[2]), float(g[3])))
+    dev = q.device
+    out = torch.empty(S, heads * D, dtype=torch.float32, device=dev)
+    q_i8 = torch.empty(heads * S * D, dtype=torch.int8, device=dev)
+    k_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
+    vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
+    q_rs = torch.empty(heads * S, dtype=torch.int32, device=dev)
+    k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
+    v_cs = torch.empty(kv_heads * max(S // 64, 1) * D, dtype=torch.int32, device=dev)
+    a.q, a.k, a.v, a.cos, a.sin = q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    a.seq, a.heads, a.kv_heads, a.head_dim, a.inv_sqrt_d = S, heads, kv_heads, D, 1.0 / (D ** 0.5)
+    a.out, a.q_i8, a.k_i8, a.vt_i8 = out.data_ptr(), q_i8.data_ptr(), k_i8.data_ptr(), vt_i8.data_ptr()
+    a.q_rowsum, a.k_rowsum, a.v_colsum = q_rs.data_ptr(), k_rs.data_ptr(), v_cs.data_ptr()
+    with _on(q, k, v, cos, sin, *keep):
+        _lib.call("mq_attention_quant", ctypes.byref(a), _stream())
+    return out if S_real == S else out[:S_real].contiguous()

@@ -497,3 +497,35 @@ def qmatmul_int_exact(qa, za, sa, qb, zb, sb):
     BLAS over integers), scaled once: one int -> fp32 conversion, one multiply by fp32(sa*sb).  qa [..., M, K], qb [..., K, N]."""
     acc = np.rint(np.matmul((np.asarray(qa, np.float64) - np.float64(za)), (np.asarray(qb, np.float64) - np.float64(zb)))).astype(np.int64)
     return acc, (acc.astype(F32) * (F32(sa) * F32(sb))).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# a10 (in context)  attention core around the two QMatMuls      hf_model.py:486-534
+# ----------------------------------------------------------------------------------------------
+def rope_rotate_half(x, cos, sin):
+    """x [..., S, D], cos / sin [S, D]:  x * cos + rotate_half(x) * sin  (hf_model.py:486-488 -> apply_rotary_pos_emb)."""
+    x = np.asarray(x, dtype=F32)
+    h = x.shape[-1] // 2
+    rot = np.concatenate((-x[..., h:], x[..., :h]), axis=-1)
+    return (x * cos.astype(F32)).astype(F32) + (rot * sin.astype(F32)).astype(F32)
+
+
+def attention_sim(q, k, v, cos, sin, heads, kv_heads, qk: tuple, pv: tuple):
+    """Causal prefill attention of one sequence as the reference computes it: q [S, heads*D], k / v [S, kv_heads*D] projection
+    outputs; RoPE; repeat_kv (hf_model.py:509-510); qk_bmm (a QMatMul: qk = (input, input2, output) QuantizerOracles) / sqrt(D);
+    + causal mask; fp32 softmax; pv_bmm (pv = its three quantizers).  Returns [S, heads*D] (the layout o_proj reads)."""
+    S = q.shape[0]
+    D = q.shape[1] // heads
+    qh = rope_rotate_half(np.asarray(q, F32).reshape(S, heads, D).transpose(1, 0, 2), cos, sin)
+    kh = rope_rotate_half(np.asarray(k, F32).reshape(S, kv_heads, D).transpose(1, 0, 2), cos, sin)
+    vh = np.asarray(v, F32).reshape(S, kv_heads, D).transpose(1, 0, 2)
+    rep = heads // kv_heads
+    kh, vh = np.repeat(kh, rep, axis=0), np.repeat(vh, rep, axis=0)
+    att = qmatmul_sim(qh, kh.transpose(0, 2, 1), *qk) / F32(np.sqrt(F32(D)))
+    mask = np.triu(np.full((S, S), -np.inf, dtype=F32), 1)
+    att = (att + mask).astype(F32)
+    att = att - att.max(axis=-1, keepdims=True)
+    e = np.exp(att, dtype=F32)
+    p = (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    out = qmatmul_sim(p, vh, *pv)
+    return out.transpose(1, 0, 2).reshape(S, heads * D)

@@ -687,3 +687,144 @@ def test_decode_engine_generic_head_dim_matches_module_graph(dev):
     span = float(np.ptp(want))
     d = np.abs(got - want)
     assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span and (d <= 0.01 * span).mean() >= 0.97, (d.max() / span, np.median(d) / span)
+
+
+def test_integer_path_runs_under_inference_mode(dev):
+    """Cache keys must not read Tensor._version of inference tensors: norm -> q/k/v chain and a QLinear with its own
+    input quantizer give the same results under torch.inference_mode() as under no_grad."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    a8, a16 = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16)
+    torch.manual_seed(0)
+    norm = mq.QRMSNorm.from_float(HFRMSNorm(256).to(dev), a16, a16, a8).requires_grad_(False)
+    norm.set_scale_offset({"input": [-5.0, 5.0], "output": [-4.0, 4.0]}, "buffer")
+    q = mq.QLinear.from_float(torch.nn.Linear(256, 192, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+    q.input_quantizer = None
+    q.set_scale_offset({"output": [-3.0, 3.0]}, "buffer")
+    w2 = mq.QLinear.from_float(torch.nn.Linear(192, 256, bias=True).to(dev), a8, a8, a16).requires_grad_(False)
+    w2.set_scale_offset({"input": [-3.0, 3.0], "output": [-3.0, 3.0]}, "buffer")
+    x = torch.randn(2, 40, 256, device=dev)
+    with torch.no_grad():
+        want = w2(q(norm(x)))
+    with torch.inference_mode():
+        h = norm(x)
+        assert h.is_inference() and q._int8_ready(h, q.weight)
+        got = w2(q(h))
+        got2 = w2(q(norm(x)))
+    assert torch.equal(got, want) and torch.equal(got2, want)
+
+
+# ---- a10 in context: fused quantized prefill attention ------------------------------------------------------------------------
+def _attention_case(S, heads, kv_heads, seed, qk_out_bits=16, pv_out_bits=8):
+    rng = np.random.default_rng(seed)
+    D = 64
+    q = rng.standard_normal((S, heads * D), dtype=np.float32) * 1.5
+    k = rng.standard_normal((S, kv_heads * D), dtype=np.float32) * 1.5
+    v = rng.standard_normal((S, kv_heads * D), dtype=np.float32)
+    inv = 1.0 / (10000.0 ** (np.arange(0, D, 2, dtype=np.float32) / D))
+    ang = np.outer(np.arange(S, dtype=np.float32), inv).astype(np.float32)
+    ang = np.concatenate((ang, ang), axis=-1)
+    cos, sin = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+
+    def mk(bits, lo, hi):
+        o = O.QuantizerOracle(bitwidth=bits)
+        o.set_from_minmax(np.float32(lo), np.float32(hi))
+        return o
+    qr, kr = O.rope_rotate_half(q.reshape(S, heads, D).transpose(1, 0, 2), cos, sin), O.rope_rotate_half(
+        k.reshape(S, kv_heads, D).transpose(1, 0, 2), cos, sin)
+    sc = np.einsum("hsd,htd->hst", qr, np.repeat(kr, heads // kv_heads, axis=0))
+    qk = (mk(8, qr.min(), qr.max()), mk(8, kr.min(), kr.max()), mk(qk_out_bits, sc.min(), sc.max()) if qk_out_bits else None)
+    pv = (mk(16, 0.0, 1.0), mk(8, v.min(), v.max()), mk(pv_out_bits, -0.8 * np.abs(v).max(), 0.8 * np.abs(v).max()) if pv_out_bits else None)
+    return q, k, v, cos, sin, qk, pv
+
+
+def _grid_of(o, dev):
+    if o is None:
+        return None
+    return (torch.tensor([float(o.scale)], device=dev), torch.tensor([float(o.offset)], device=dev), float(o.qmin), float(o.qmax))
+
+
+@pytest.mark.parametrize("S,heads,kv_heads,qk_out_bits,pv_out_bits", [(64, 2, 1, 16, 8), (100, 2, 2, 16, 8), (192, 4, 2, 16, 8), (256, 4, 4, 16, 16), (128, 4, 2, 0, 0)])
+def test_attention_quant_vs_oracle(dev, S, heads, kv_heads, qk_out_bits, pv_out_bits):
+    """mq_attention_quant against the numpy restatement of hf_model.py:486-534 with its two QMatMuls.  The integer contractions are
+    exact where the reference's fp32 matmuls round, and the kernel's quantizers use reciprocal multiplies: a 16-bit score index may
+    sit one step off on a vanishing fraction of elements, so the output is compared to one step of its own grid."""
+    from mobilequant_amd import ops
+    q, k, v, cos, sin, qk, pv = _attention_case(S, heads, kv_heads, seed=S + heads, qk_out_bits=qk_out_bits, pv_out_bits=pv_out_bits)
+    want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids).cpu().numpy()
+    assert got.shape == want.shape and np.isfinite(got).all()
+    diff = np.abs(got - want)
+    span = float(want.max() - want.min())
+    if pv_out_bits == 8:
+        step = float(pv[2].scale)
+        assert diff.max() <= 1.001 * step, (diff.max(), step)
+        assert (diff > 0.5 * step).mean() < 0.02
+    else:
+        assert diff.max() <= 2e-3 * span, (diff.max(), span)
+    assert np.median(diff) <= 2e-4 * span
+
+
+def test_fuse_attention_matches_module_chain_and_the_reference_logits(dev):
+    """fuse_attention(model) on the 2-layer llama graph of decode_case.npz (the reference's REAL W8A8-simulated HFForCausalLM and
+    its logits for a 40-token sequence): prefill with the fused attention against (i) this package's chain of QMatMul modules
+    and (ii) the reference's logits, at the budget the decode test states; turning the fused mode off restores the chain."""
+    from mobilequant_amd import llama
+    m, z = _decode_model(dev)
+    ids = torch.from_numpy(z["ids"]).long().to(dev).view(1, -1)
+    ref = z["logits_w8a8"][0]
+    with torch.no_grad():
+        base = m(ids)
+        assert llama.fuse_attention(m) == 2 and llama.fuse_attention(m) == 0
+        calls = []
+        from mobilequant_amd import ops
+        real = ops.attention_quant
+        ops.attention_quant = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            fused = m(ids)
+        finally:
+            ops.attention_quant = real
+        assert len(calls) == 2
+        for mod in m.modules():
+            if isinstance(mod, llama.Attention):
+                mod.fused_mode = "off"
+        assert torch.equal(m(ids), base)
+    span = float(np.ptp(ref))
+    for name, other in (("chain", base[0].cpu().numpy()), ("reference", ref)):
+        d = np.abs(fused[0].cpu().numpy() - other)
+        assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span and (d <= 0.01 * span).mean() >= 0.97, (
+            name, d.max() / span, np.median(d) / span)
+
+
+def test_fuse_attention_longer_prefill_with_cache(dev):
+    """S = 200 (padded to 256 inside the op), batch 2, static KV cache written on the side: fused == chain within the budget, and the
+    cache contents equal the chain's."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import get_act_range
+    from toy_models import apply_mixed_precision
+    m = llama.LlamaForCausalLM(llama.LlamaShape(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=64, max_pos=256))
+    m.reset_parameters(seed=5, std=0.08)
+    m = m.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 64, (2, 200), generator=g)
+    act = get_act_range(m, [ids[:1], ids[1:]])
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(m, a8, a8)
+    apply_mixed_precision(m, mq)
+    mq.set_scale_and_offset(m, act, "buffer")
+    mq.wire_integer_inputs(m)
+    ids = ids.to(dev)
+    with torch.no_grad():
+        c0 = m.new_cache(2, 256, device=dev)
+        base = m(ids, cache=c0)
+        llama.fuse_attention(m)
+        c1 = m.new_cache(2, 256, device=dev)
+        fused = m(ids, cache=c1)
+    assert torch.equal(c0[0][0], c1[0][0]) and torch.equal(c0[0][1], c1[0][1])      # layer 0: same inputs -> same cache
+    span = float(base.max() - base.min())
+    d = (fused - base).abs()
+    assert float(d.max()) <= 0.05 * span and float(d.median()) <= 0.001 * span, (float(d.max()) / span, float(d.median()) / span)

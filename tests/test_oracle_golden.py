@@ -385,3 +385,21 @@ def test_qmatmul_oracle_matches_reference():
         y = O.qmatmul_sim(z[t + "_a"], z[t + "_b"], *qs)
         d = np.abs(y - z[t + "_y"])
         assert d.max() <= float(qs[2].scale) * 1.001 and (d == 0).mean() > 0.99, (t, d.max(), (d == 0).mean())
+
+
+def test_attention_sim_without_quantizers_is_causal_sdpa():
+    """oracle.attention_sim (hf_model.py:486-534 restated) with every quantizer absent == torch's causal attention on the RoPE'd heads."""
+    import torch
+    rng = np.random.default_rng(0)
+    S, H, KV, D = 48, 4, 2, 32
+    q, k, v = (rng.standard_normal((S, n * D), dtype=np.float32) for n in (H, KV, KV))
+    inv = 1.0 / (10000.0 ** (np.arange(0, D, 2, dtype=np.float32) / D))
+    ang = np.outer(np.arange(S, dtype=np.float32), inv).astype(np.float32)
+    ang = np.concatenate((ang, ang), -1)
+    cos, sin = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    got = O.attention_sim(q, k, v, cos, sin, H, KV, (None, None, None), (None, None, None))
+    t = lambda a, n: torch.from_numpy(a).view(S, n, D).transpose(0, 1)      # noqa: E731
+    rope = lambda x: x * torch.from_numpy(cos) + torch.cat((-x[..., D // 2:], x[..., :D // 2]), -1) * torch.from_numpy(sin)    # noqa: E731
+    qh, kh, vh = rope(t(q, H)), rope(t(k, KV)).repeat_interleave(H // KV, 0), t(v, KV).repeat_interleave(H // KV, 0)
+    want = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, is_causal=True).transpose(0, 1).reshape(S, H * D).numpy()
+    assert np.allclose(got, want, atol=2e-6, rtol=1e-5)
