@@ -356,6 +356,14 @@ typedef struct mq_attention_args {
   int32_t* q_rowsum;
   int32_t* k_rowsum;
   int32_t* v_colsum;
+  /* optional second output for the consumer linear (o_proj): pv_out indices as its int8 input image (storage = index - out_shift)
+   * + row sums: row-major [rows, heads*64] (out_i8_tiled = 0) or the fragment-blocked [ceil16(rows), heads*64] layout of
+   * mq_quantize_tiled (1); this sequence owns rows out_row0 .. out_row0 + seq_real - 1 (seq_real <= seq: rows beyond it are
+   * padding and are not written).  With out_i8 set, `out` may be NULL. */
+  int8_t* out_i8;
+  int32_t* out_rowsum;
+  int64_t out_row0;
+  int seq_real, out_shift, out_i8_tiled;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
 

@@ -69,25 +69,34 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   __shared__ int s_rs[64];
   __shared__ int8_t s_v[64][64 + 4];
   if (threadIdx.x < 64) s_rs[threadIdx.x] = 0;
+  if (a.out_i8 != nullptr && blockIdx.y == 0 && threadIdx.x < 64 && (int)(blockIdx.x * 64 + threadIdx.x) < a.seq_real)
+    a.out_rowsum[a.out_row0 + blockIdx.x * 64 + threadIdx.x] = 0;          // the core kernel accumulates one share per head
   __syncthreads();
   const bool is_q = part < H, is_k = !is_q && part < H + KV;
   const int head = is_q ? part : (is_k ? part - H : part - H - KV);
   const float* src = (is_q ? a.q : (is_k ? a.k : a.v)) + (size_t)s * (is_q ? H : KV) * D + (size_t)head * D;
-  float x[16];
+  auto load16 = [](const float* p, float (&d)[16]) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) x[i] = src[16 * c + i];
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = reinterpret_cast<const float4*>(p)[i];
+      d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
+    }
+  };
+  float x[16];
+  load16(src + 16 * c, x);
   const AGrid g = a_load_grid(is_q ? a.qk_a : (is_k ? a.qk_b : a.pv_b));
   int st[16];
   if (is_q || is_k) {                                 // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
-    float y[16];
+    float pr[16], cs[16], sn[16];
+    load16(src + ((16 * c + 32) & 63), pr);
+    load16(a.cos + (size_t)s * D + 16 * c, cs);
+    load16(a.sin + (size_t)s * D + 16 * c, sn);
+    const float sign = c < 2 ? -1.f : 1.f;            // (-x) * sin == -(x * sin) exactly
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int d = 16 * c + i;
-      const float partner = d < 32 ? -src[d + 32] : src[d - 32];
-      y[i] = __fadd_rn(__fmul_rn(x[i], a.cos[(size_t)s * D + d]), __fmul_rn(partner, a.sin[(size_t)s * D + d]));
+      const float y = __fadd_rn(__fmul_rn(x[i], cs[i]), __fmul_rn(sign * pr[i], sn[i]));
+      st[i] = (int)a_index_exact(y, g) - 128;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) st[i] = (int)a_index_exact(y[i], g) - 128;
   } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = (int)a_index_exact(x[i], g) - 128;
@@ -304,6 +313,8 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
   //           = sp * sv * [ 256 A_hi + A_lo + 32896 V - zv P - zp V + zp zv T' ],  A_* = sum byte * v_st, V = sum v_st, P = sum p_idx
   const float alpha_pv = __fmul_rn(gpa.s, gpb.s);
   float* orow = a.out + (size_t)s_abs * H * D + (size_t)h * D;
+  int rsum = 0;
+  unsigned opk = 0;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     float o4[4];
@@ -313,9 +324,27 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
       const long long tot = 256ll * acc_hi[dt][e] + (long long)acc_lo[dt][e] + 32896ll * V - (long long)zv * psum - (long long)zp * V +
                             (long long)zp * zv * nproc;
       const float pre = (float)((double)tot * (double)alpha_pv);
-      o4[e] = gpo.on ? __fmul_rn(__fsub_rn(a_index_fast(pre, gpo), gpo.o), gpo.s) : pre;
+      const float qi = gpo.on ? a_index_fast(pre, gpo) : 0.f;
+      o4[e] = gpo.on ? __fmul_rn(__fsub_rn(qi, gpo.o), gpo.s) : pre;
+      const int st = (int)qi - a.out_shift;
+      rsum += st;
+      opk |= ((unsigned)st & 0xffu) << (8 * e);
     }
-    *reinterpret_cast<float4*>(orow + 16 * dt + 4 * tq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    if (a.out != nullptr) *reinterpret_cast<float4*>(orow + 16 * dt + 4 * tq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    // o_proj's int8 input image, row-major or fragment-blocked (layout: include/mobilequant_amd.h): 1-KiB block (row >> 4, k >> 6 = h), byte
+    // 16 * ((row & 15) + 16 * ((k & 63) >> 4)) + (k & 15), k & 63 = 16 dt + 4 tq + e
+    if (a.out_i8 != nullptr && s_abs < a.seq_real) {
+      const int64_t row = a.out_row0 + s_abs;
+      int8_t* dst = a.out_i8_tiled ? a.out_i8 + ((row >> 4) * H + h) * 1024 + 16 * ((row & 15) + 16 * dt) + 4 * tq
+                                   : a.out_i8 + row * H * D + h * D + 16 * dt + 4 * tq;
+      *reinterpret_cast<unsigned*>(dst) = opk;
+    }
+    opk = 0;
+  }
+  if (a.out_i8 != nullptr) {
+    rsum += __shfl_xor(rsum, 16, 64);
+    rsum += __shfl_xor(rsum, 32, 64);
+    if (tq == 0 && s_abs < a.seq_real) atomicAdd(a.out_rowsum + a.out_row0 + s_abs, rsum);
   }
 }
 
@@ -326,16 +355,23 @@ using namespace mq;
 extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_attention_quant: null argument block");
   const mq_attention_args& a = *args;
-  MQ_REQUIRE(a.q && a.k && a.v && a.cos && a.sin && a.out && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum && a.v_colsum,
+  MQ_REQUIRE(a.q && a.k && a.v && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum && a.v_colsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.head_dim == 64 && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
              "mq_attention_quant: head_dim 64, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
   MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmax == 255.f && a.qk_b.qmax == 255.f && a.pv_b.qmax == 255.f &&
                  a.qk_a.qmin == 0.f && a.qk_b.qmin == 0.f && a.pv_b.qmin == 0.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
              "mq_attention_quant: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
-  MQ_REQUIRE(aligned(a.q, 16) && aligned(a.k, 16) && aligned(a.v, 16) && aligned(a.out, 16) && aligned(a.q_i8, 16) && aligned(a.k_i8, 16) &&
+  MQ_REQUIRE(aligned(a.q, 16) && aligned(a.k, 16) && aligned(a.v, 16) && (!a.out || aligned(a.out, 16)) && aligned(a.q_i8, 16) && aligned(a.k_i8, 16) &&
                  aligned(a.vt_i8, 16) && aligned(a.k_rowsum, 16) && aligned(a.v_colsum, 16),
              "mq_attention_quant: pointers must be 16-byte aligned");
+  if (a.out_i8 != nullptr) {
+    MQ_REQUIRE(a.out_rowsum != nullptr && a.pv_out.scale != nullptr && a.pv_out.qmin - (float)a.out_shift >= -128.f &&
+                   a.pv_out.qmax - (float)a.out_shift <= 127.f && a.out_row0 >= 0 && a.seq_real > 0 && a.seq_real <= a.seq &&
+                   aligned(a.out_i8, 16),
+               "mq_attention_quant: the int8 output image needs an 8-bit pv_out grid that fits int8 after out_shift, out_rowsum, "
+               "0 < seq_real <= seq");
+  }
   hipStream_t st = as_stream(stream);
   attention_prep_kernel<<<dim3((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), 256, 0, st>>>(a);
   MQ_LAUNCH_CHECK("mq_attention_quant(prep)");

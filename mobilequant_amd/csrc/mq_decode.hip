@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         if (GATE && c >= kchunks) acc1 = dot16(buf[u], av, acc1);
         else acc0 = dot16(buf[u], av, acc0);
         if (j2 == cpl - 1) {                                     // logical row slot t2 complete
-          const int row = row0 + DG_WAVES * t2;
           const int s0 = wave_sum_dpp(acc0), s1 = GATE ? wave_sum_dpp(acc1) : 0;
           acc0 = acc1 = 0;
           if (lane == t2) {                                      // lane t keeps the contraction(s) of row slot t

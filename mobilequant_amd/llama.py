@@ -128,10 +128,25 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
     if cache is not None:
         cache[0][:, :, :S] = apply_rope(k.view(B, S, s.kv_heads, 64).transpose(1, 2), cos, sin)
         cache[1][:, :, :S] = v.view(B, S, s.kv_heads, 64).transpose(1, 2)
+    oq, o_proj = pv.output_quantizer, self.o_proj
+    if Q._u8_grid(oq) and isinstance(o_proj, Q.QLinear) and not o_proj.use_temporary_parameter and o_proj.input_chan_scale is None:
+        # o_proj reads pv_bmm's output grid: hand it the int8 image (fragment-blocked, + row sums) straight from the attention
+        # kernel -- no fp32 [B, S, hidden] tensor, no quantize launch.  The probe tensor is never written nor read.
+        M, K = B * S, s.heads * 64
+        probe = Q._tag_grid(torch.empty(1, dtype=torch.float32, device=x.device).expand(B, S, K), oq)
+        w_o = o_proj._effective_weight(o_proj.weight)
+        if (o_proj.input_quantizer is None and o_proj._int8_ready(probe, w_o) and o_proj.weight_quantizer.qcfg.bitwidth == 8
+                and M > 8 and o_proj._activation_grid(probe) is oq):
+            tiled = ops.gemm_tiled_supported(M, w_o.shape[0], K)
+            q_i8 = torch.empty(((M + 15) // 16 * 16 if tiled else M, K), dtype=torch.int8, device=x.device)
+            rs = torch.empty(M, dtype=torch.int32, device=x.device)
+            for b in range(B):
+                ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False)
+            return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S))
     out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids) for b in range(B)])
-    if pv.output_quantizer is not None and not pv.output_quantizer.bypassed():
-        Q._tag_grid(out, pv.output_quantizer)
-    return self.o_proj(out)
+    if oq is not None and not oq.bypassed():
+        Q._tag_grid(out, oq)
+    return o_proj(out)
 
 
 def fuse_attention(model) -> int:

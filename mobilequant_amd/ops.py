@@ -412,10 +412,13 @@ def gated_act_quant(a: torch.Tensor, b: torch.Tensor, act: str, out_grid, *, a_g
 
 
 def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int,
-                    kv_heads: int, grids: dict) -> torch.Tensor:
+                    kv_heads: int, grids: dict, image=None, want_out: bool = True):
     """Quantized causal prefill attention of ONE sequence (mq_attention_quant): q [S, heads*64], k / v [S, kv_heads*64] fp32
     projection outputs before RoPE, cos / sin [S, 64]; grids: qk_a, qk_b, qk_out, pv_a, pv_b, pv_out -> (scale, offset, qmin, qmax)
-    per tensor or None (qk_out / pv_out only).  Returns pv_bmm's output [S, heads*64] fp32 (o_proj's input layout)."""
+    per tensor or None (qk_out / pv_out only).  Returns pv_bmm's output [S, heads*64] fp32 (o_proj's input layout).
+    image = (q_i8, row_sum [rows] int32, row0, shift, tiled): additionally (want_out=False: only) write the pv_out indices of this
+    sequence as rows row0 .. row0+S-1 of the consumer linear's int8 input image: row-major [rows, heads*64], or (tiled) the
+    fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled."""
     q, k, v = (_dev(t, n).contiguous() for t, n in ((q, "q"), (k, "k"), (v, "v")))
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
     S, D = q.shape[0], 64
@@ -438,7 +441,7 @@ def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torc
             keep += [s, o]
             setattr(a, name, _lib.MqGrid(s.data_ptr(), o.data_ptr(), float(g[2]), float(g[3])))
     dev = q.device
-    out = torch.empty(S, heads * D, dtype=torch.float32, device=dev)
+    out = torch.empty(S, heads * D, dtype=torch.float32, device=dev) if want_out or image is None else None
     q_i8 = torch.empty(heads * S * D, dtype=torch.int8, device=dev)
     k_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
     vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
@@ -447,8 +450,19 @@ def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torc
     v_cs = torch.empty(kv_heads * max(S // 64, 1) * D, dtype=torch.int32, device=dev)
     a.q, a.k, a.v, a.cos, a.sin = q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr()
     a.seq, a.heads, a.kv_heads, a.head_dim, a.inv_sqrt_d = S, heads, kv_heads, D, 1.0 / (D ** 0.5)
-    a.out, a.q_i8, a.k_i8, a.vt_i8 = out.data_ptr(), q_i8.data_ptr(), k_i8.data_ptr(), vt_i8.data_ptr()
+    a.out, a.q_i8, a.k_i8, a.vt_i8 = out.data_ptr() if out is not None else None, q_i8.data_ptr(), k_i8.data_ptr(), vt_i8.data_ptr()
     a.q_rowsum, a.k_rowsum, a.v_colsum = q_rs.data_ptr(), k_rs.data_ptr(), v_cs.data_ptr()
+    a.seq_real = S_real
+    if image is not None:
+        q_t, rs_t, row0, shift, tiled = image
+        need = (row0 + S_real + 15) // 16 * 16 if tiled else row0 + S_real
+        if (q_t.dtype != torch.int8 or rs_t.dtype != torch.int32 or not q_t.is_contiguous() or q_t.shape[-1] != heads * D
+                or row0 < 0 or row0 + S_real > rs_t.numel() or need > q_t.shape[0]):
+            raise RuntimeError("mobilequant_amd: attention_quant image must be int8 [rows (tiled: ceil16), heads*64] + int32 row sums [rows]")
+        keep += [q_t, rs_t]
+        a.out_i8, a.out_rowsum, a.out_row0, a.out_shift, a.out_i8_tiled = q_t.data_ptr(), rs_t.data_ptr(), int(row0), int(shift), int(bool(tiled))
     with _on(q, k, v, cos, sin, *keep):
         _lib.call("mq_attention_quant", ctypes.byref(a), _stream())
+    if out is None:
+        return None
     return out if S_real == S else out[:S_real].contiguous()

@@ -828,3 +828,37 @@ def test_fuse_attention_longer_prefill_with_cache(dev):
     span = float(base.max() - base.min())
     d = (fused - base).abs()
     assert float(d.max()) <= 0.05 * span and float(d.median()) <= 0.001 * span, (float(d.max()) / span, float(d.median()) / span)
+
+
+@pytest.mark.parametrize("S,tiled", [(128, False), (100, False), (128, True), (100, True)])
+def test_attention_quant_int8_image_for_o_proj(dev, S, tiled):
+    """The optional int8 output image (o_proj's input on pv_bmm's output grid): stored index - 128 must be exactly the index of the
+    fp32 output on that grid, in the row-major or the fragment-blocked layout, at a row offset inside a larger image, with row sums;
+    rows outside [row0, row0 + S) stay untouched."""
+    from mobilequant_amd import ops
+    heads, kv_heads = 4, 2
+    q, k, v, cos, sin, qk, pv = _attention_case(S, heads, kv_heads, seed=9)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)       # noqa: E731
+    K, row0, rows = heads * 64, 32, 32 + S + 7
+    img = torch.full(((rows + 15) // 16 * 16, K), 77, dtype=torch.int8, device=dev)
+    rs = torch.full((rows,), -5, dtype=torch.int32, device=dev)
+    out = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, image=(img, rs, row0, 128, tiled))
+    only = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, image=(img.clone(), rs.clone(), row0, 128, tiled),
+                               want_out=False)
+    assert only is None
+    sc, of = np.float32(pv[2].scale), np.float32(pv[2].offset)
+    idx = np.rint(out.cpu().numpy() / sc + of).astype(np.int32)
+    assert np.array_equal(((idx.astype(np.float32) - of) * sc).astype(np.float32), out.cpu().numpy())       # out sits on the grid
+    want = np.full((img.shape[0], K), 77, dtype=np.int8)
+    want[row0:row0 + S] = (idx - 128).astype(np.int8)
+    got = img.cpu().numpy()
+    if tiled:
+        # rows of a touched 16-row block that this sequence does not own keep their previous bytes
+        assert np.array_equal(got.reshape(-1), tiled_image(want).reshape(-1))
+    else:
+        assert np.array_equal(got, want)
+    rs_want = np.full(rows, -5, dtype=np.int64)
+    rs_want[row0:row0 + S] = (idx - 128).sum(1)
+    assert np.array_equal(rs.cpu().numpy().astype(np.int64), rs_want)

@@ -1,0 +1,42 @@
+"""Runs mq_attention_quant alone at TinyLlama's prefill shape (S = 2048, 32 heads / 4 KV heads) for rocprofv3:
+    rocprofv3 --kernel-trace --stats -d /tmp/p -o p -- python tools/prof_attention.py
+    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace ...
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mobilequant_amd import ops  # noqa: E402
+
+S, H, KV, D = int(os.environ.get("MQ_ATT_S", 2048)), 32, 4, 64
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+q, k, v = torch.randn(S, H * D, device=dev), torch.randn(S, KV * D, device=dev), torch.randn(S, KV * D, device=dev)
+inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32, device=dev) / D))
+ang = torch.outer(torch.arange(S, dtype=torch.float32, device=dev), inv)
+ang = torch.cat((ang, ang), -1)
+cos, sin = ang.cos(), ang.sin()
+
+
+def grid(lo, hi, bits):
+    n = float(2 ** bits - 1)
+    sc = (hi - lo) / n
+    return (torch.tensor([sc], device=dev), torch.tensor([round(-lo / sc)], device=dev, dtype=torch.float32), 0.0, n)
+
+
+grids = dict(qk_a=grid(-6.0, 6.0, 8), qk_b=grid(-6.0, 6.0, 8), qk_out=grid(-60.0, 60.0, 16), pv_a=grid(0.0, 1.0, 16), pv_b=grid(-4.5, 4.5, 8),
+             pv_out=grid(-2.0, 2.0, 8))
+img = torch.empty(S, H * D, dtype=torch.int8, device=dev)
+rs = torch.empty(S, dtype=torch.int32, device=dev)
+for _ in range(int(os.environ.get("MQ_ATT_ITERS", 20))):
+    ops.attention_quant(q, k, v, cos, sin, H, KV, grids, image=(img, rs, 0, 128, False), want_out=False)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.attention_quant(q, k, v, cos, sin, H, KV, grids, image=(img, rs, 0, 128, False), want_out=False)
+e1.record()
+torch.cuda.synchronize()
+print("attention op (prep + core), eager: %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))
