@@ -338,7 +338,7 @@ int mq_decode_head(const float* x, const float* norm_weight, float eps, const fl
  * Causal mask only (the mask of hf_model.py:1180-1205 at prefill); the scores are divided by sqrt(D) AFTER qk_out, as the reference.
  * Scratch (caller-owned, overwritten): q_i8 [heads][seq][D], k_i8 [kv_heads][seq][D], vt_i8 [kv_heads][seq/64][D][64] (values
  * transposed, keys permuted inside each 64-block), q_rowsum [heads][seq], k_rowsum [kv_heads][seq] (the zero-point terms of the integer
- * q.k^T, derived from the row sums of the images), v_colsum [kv_heads][seq/64][D].
+ * q.k^T, derived from the row sums of the images).
  * Limits: head_dim == 64, seq % 64 == 0.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
 typedef struct mq_attention_args {
   const float* q;
@@ -355,7 +355,6 @@ typedef struct mq_attention_args {
   int8_t* vt_i8;
   int32_t* q_rowsum;
   int32_t* k_rowsum;
-  int32_t* v_colsum;
   /* optional second output for the consumer linear (o_proj): pv_out indices as its int8 input image (storage = index - out_shift)
    * + row sums: row-major [rows, heads*64] (out_i8_tiled = 0) or the fragment-blocked [ceil16(rows), heads*64] layout of
    * mq_quantize_tiled (1); this sequence owns rows out_row0 .. out_row0 + seq_real - 1 (seq_real <= seq: rows beyond it are

@@ -47,7 +47,7 @@ class MqAttentionArgs(ctypes.Structure):
                 ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("inv_sqrt_d", c_float), ("qk_a", MqGrid),
                 ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid), ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p),
                 ("q_i8", c_void_p), ("k_i8", c_void_p), ("vt_i8", c_void_p), ("q_rowsum", c_void_p), ("k_rowsum", c_void_p),
-                ("v_colsum", c_void_p), ("out_i8", c_void_p), ("out_rowsum", c_void_p), ("out_row0", c_int64), ("seq_real", c_int),
+                ("out_i8", c_void_p), ("out_rowsum", c_void_p), ("out_row0", c_int64), ("seq_real", c_int),
                 ("out_shift", c_int), ("out_i8_tiled", c_int)]
 
 

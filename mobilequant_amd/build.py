@@ -20,6 +20,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmobilequant_amd.so")
 SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemv.hip", "mq_norm.hip", "mq_decode.hip", "mq_attention.hip"]
+# per-file additions: the attention kernel is VALU-bound and consumes every MFMA result with VALU instructions -- keep the MFMA
+# results in VGPRs (no v_accvgpr_read per score element)
+PER_FILE_FLAGS = {"mq_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ABLATE = (["-DMQ_GEMM_ABLATE"] if os.environ.get("MQ_GEMM_ABLATE") else []) + \
     ([f"-DMQ_PP_PRIO={os.environ['MQ_PP_PRIO']}"] if os.environ.get("MQ_PP_PRIO") else [])
@@ -53,7 +56,7 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra_flags
     procs = []
     for src in SOURCES:
         obj = os.path.join(libdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src, ()), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

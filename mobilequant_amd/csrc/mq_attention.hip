@@ -9,7 +9,7 @@
 //   prefill layer's time goes.
 //
 // Here:  mq_attention_prep   RoPE + the three input quantizers -> int8 images: q [H][S][D], k [KV][S][D] (+ row sums of the stored
-//                            values) and v TRANSPOSED and key-permuted per 64-key block: vT [KV][S/64][D][64] (+ per-block column sums)
+//                            values) and v TRANSPOSED and key-permuted per 64-key block: vT [KV][S/64][D][64]
 //        mq_attention_quant  one workgroup per (64-query block, head), 4 waves x 16 queries.  Two sweeps over the key blocks up to the
 //                            diagonal, both on v_mfma_i32_16x16x64_i8:
 //                              sweep 1: integer q.k^T -> zero-point correction -> 16-bit output grid -> /sqrt(D) -> mask -> online row
@@ -132,23 +132,15 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     // thread (d = tid >> 2, quarter c): 16 kappa = 16 c .. 16 c + 15  -> tq = c, (j, e) = (i >> 2, i & 3) -> t = 16 j + 4 c + e
     const int d = threadIdx.x >> 2;
     unsigned o4[4];
-    int csum = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned pk = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int v = s_v[d][16 * j + 4 * c + e];
-        csum += v;
-        pk |= ((unsigned)v & 0xffu) << (8 * e);
-      }
+      for (int e = 0; e < 4; ++e) pk |= ((unsigned)s_v[d][16 * j + 4 * c + e] & 0xffu) << (8 * e);
       o4[j] = pk;
     }
     int8_t* dst = a.vt_i8 + (((size_t)head * (S >> 6) + blockIdx.x) * D + d) * 64 + 16 * c;
     *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-    csum += __shfl_xor(csum, 1, 64);
-    csum += __shfl_xor(csum, 2, 64);
-    if (c == 0) a.v_colsum[((size_t)head * (S >> 6) + blockIdx.x) * D + d] = csum;
   }
 }
 
@@ -166,8 +158,12 @@ template <bool QK_OUT>
 __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention_args a) {
   const int D = 64;
   const int S = a.seq, H = a.heads, KV = a.kv_heads;
-  const int h = blockIdx.y, kvh = h / (H / KV);
-  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;              // long (late) query blocks first: better tail balance
+  // Work per workgroup is proportional to qb + 1 (causal).  The hardware hands out workgroups in id order to whichever slot frees
+  // up, so the ids run over ALL heads of the longest query block first, then the next block, ...: a longest-first list schedule.
+  // With 2 resident workgroups per CU and H * S/64 = 2 * (2 * 256) of them, slots pair up (S/64 - i) with (i + 1): even finish.
+  // (Per-head ordering instead measured 138 us vs the 74 us of perfectly packed wave cycles: the last heads' long blocks started late.)
+  const int h = (int)blockIdx.x % H, kvh = h / (H / KV);
+  const int qb = S / 64 - 1 - (int)blockIdx.x / H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int srow = lane & 15, tq = lane >> 4;
   const int s_abs = qb * 64 + wave * 16 + srow;                     // this lane's query row
@@ -225,85 +221,102 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
   };
 
   // ---- sweep 1: row max and sum of exp ----------------------------------------------------------------------------------------
-  float m = -INFINITY, l = 0.f;
-  {
-    KTile cur, nxt;
-    load_k(0, cur);
-    for (int kb = 0; kb < nkb; ++kb) {
-      if (kb + 1 < nkb) load_k(kb + 1, nxt);
-      float f[16];
-      scores(cur, kb == qb, kb, f);
-      float bm = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
-      bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(f[8], f[9]), fmaxf(f[10], f[11])), fmaxf(fmaxf(f[12], f[13]), fmaxf(f[14], f[15]))));
-      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m, bm);                                 // finite: key 0 is never masked
-      float bs = 0.f;
+  // exp(value - max) = exp2(f * cexp - R) with ONE fma per element: R = fl(fmax * cexp) is a per-row constant, so its rounding error
+  // shifts every exponent of the row alike and cancels in e / l (softmax is shift invariant); R - R' below is exact (Sterbenz).
+  float m = -INFINITY, l = 0.f, R = -INFINITY;
+  auto sweep1 = [&](const KTile& t, int kb) {
+    float f[16];
+    scores(t, kb == qb, kb, f);
+    float bm = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
+    bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(f[8], f[9]), fmaxf(f[10], f[11])), fmaxf(fmaxf(f[12], f[13]), fmaxf(f[14], f[15]))));
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);                                   // finite: key 0 is never masked
+    const float Rn = mn * cexp;
+    float bs = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) bs += fast_exp2((f[i] - mn) * cexp);
-      bs += __shfl_xor(bs, 16, 64);
-      bs += __shfl_xor(bs, 32, 64);
-      l = l * fast_exp2((m - mn) * cexp) + bs;
-      m = mn;
-      if (kb + 1 < nkb) cur = nxt;
+    for (int i = 0; i < 16; ++i) bs += fast_exp2(__builtin_fmaf(f[i], cexp, -Rn));
+    bs += __shfl_xor(bs, 16, 64);
+    bs += __shfl_xor(bs, 32, 64);
+    l = l * fast_exp2(R - Rn) + bs;                                  // first block: exp2(-inf) = 0
+    m = mn;
+    R = Rn;
+  };
+  {
+    KTile t0, t1;                                                    // two register sets, no copies: the loop handles two blocks per trip
+    load_k(0, t0);
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+      load_k(kb + 1, t1);
+      sweep1(t0, kb);
+      if (kb + 2 < nkb) load_k(kb + 2, t0);
+      sweep1(t1, kb + 1);
     }
+    if (kb < nkb) sweep1(t0, kb);
   }
   // p index = clamp(rint((e / l) / s_p) + z_p): g = fma(e, 1 / (l s_p), z_p + magic), index = low mantissa bits of med3(g, ...)
   const float rp = __fdiv_rn(gpa.inv_s, l);
   const float pbias = gpa.o + kMagic, plo = kMagic + gpa.qmin, phi = kMagic + gpa.qmax;
 
   // ---- sweep 2: probabilities on their 16-bit grid, integer p.v ------------------------------------------------------------------
-  v4i acc_hi[4], acc_lo[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) acc_hi[dt] = acc_lo[dt] = v4i{0, 0, 0, 0};
+  v4i acc_hi[4], acc_lo[4], acc_v[4];                               // acc_v: column sums of the stored v over the processed keys -- one more
+#pragma unroll                                                      // MFMA against an all-ones tile (the MFMA pipe idles, the VALU does not)
+  for (int dt = 0; dt < 4; ++dt) acc_hi[dt] = acc_lo[dt] = acc_v[dt] = v4i{0, 0, 0, 0};
+  const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   unsigned psum_hi = 0, psum_lo = 0;                                // sums of the unsigned high / low bytes (this lane's share)
-  int vsum[4][4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) vsum[dt][e] = 0;
   const int8_t* vbase = a.vt_i8 + (size_t)kvh * (S >> 6) * D * 64;
-  const int* vcs = a.v_colsum + (size_t)kvh * (S >> 6) * D;
-  {
-    KTile cur, nxt;
-    load_k(0, cur);
-    for (int kb = 0; kb < nkb; ++kb) {
-      const int8_t* vt = vbase + (size_t)kb * D * 64;
-      v4i vf[4];
-      int4 cs[4];
+  struct VTile {
+    v4i vf[4];
+  };
+  auto load_v = [&](int kb, VTile& t) {
+    const int8_t* vt = vbase + (size_t)kb * D * 64;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        vf[dt] = *reinterpret_cast<const v4i*>(vt + (16 * dt + srow) * 64 + tq * 16);      // rows d, kappa = 16 tq .. (key-permuted)
-        cs[dt] = *reinterpret_cast<const int4*>(vcs + kb * D + 16 * dt + 4 * tq);
+    for (int dt = 0; dt < 4; ++dt) t.vf[dt] = *reinterpret_cast<const v4i*>(vt + (16 * dt + srow) * 64 + tq * 16);   // rows d, key-permuted
+  };
+  auto sweep2 = [&](const KTile& t, const VTile& vt, int kb) {
+    float f[16];
+    scores(t, kb == qb, kb, f);
+    v4i pf_hi, pf_lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ex = fast_exp2(__builtin_fmaf(f[4 * j + e], cexp, -R));     // masked keys: exp2(-inf) = 0 -> index z_p -> (z_p - z_p) = 0
+        const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(ex, rp, pbias), plo, phi);
+        b[e] = __float_as_uint(g);
       }
-      if (kb + 1 < nkb) load_k(kb + 1, nxt);
-      float f[16];
-      scores(cur, kb == qb, kb, f);
-      v4i pf_hi, pf_lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned b[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ex = fast_exp2((f[4 * j + e] - m) * cexp);     // masked keys: exp2(-inf) = 0 -> index z_p -> contributes (z_p - z_p) = 0
-          const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(ex, rp, pbias), plo, phi);
-          b[e] = __float_as_uint(g);
-        }
-        const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
-        const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u), hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
-        psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
-        psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
-        pf_lo[j] = (int)(lo ^ 0x80808080u);
-        pf_hi[j] = (int)(hi ^ 0x80808080u);
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
-        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
-        vsum[dt][0] += cs[dt].x; vsum[dt][1] += cs[dt].y; vsum[dt][2] += cs[dt].z; vsum[dt][3] += cs[dt].w;
-      }
-      if (kb + 1 < nkb) cur = nxt;
+      const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+      const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u), hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
+      psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
+      psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+      pf_lo[j] = (int)(lo ^ 0x80808080u);
+      pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
+      acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
+      acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], ones, acc_v[dt], 0, 0, 0);
+    }
+  };
+  {
+    KTile t0, t1;
+    VTile v0, v1;
+    load_k(0, t0);
+    load_v(0, v0);
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+      load_k(kb + 1, t1);
+      load_v(kb + 1, v1);
+      sweep2(t0, v0, kb);
+      if (kb + 2 < nkb) {
+        load_k(kb + 2, t0);
+        load_v(kb + 2, v0);
+      }
+      sweep2(t1, v1, kb + 1);
+    }
+    if (kb < nkb) sweep2(t0, v0, kb);
   }
   long long psum = 256ll * psum_hi + psum_lo;
   psum += __shfl_xor(psum, 16, 64);
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
     float o4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long V = vsum[dt][e];
+      const long long V = acc_v[dt][e];
       const long long tot = 256ll * acc_hi[dt][e] + (long long)acc_lo[dt][e] + 32896ll * V - (long long)zv * psum - (long long)zp * V +
                             (long long)zp * zv * nproc;
       const float pre = (float)((double)tot * (double)alpha_pv);
@@ -355,7 +368,7 @@ using namespace mq;
 extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_attention_quant: null argument block");
   const mq_attention_args& a = *args;
-  MQ_REQUIRE(a.q && a.k && a.v && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum && a.v_colsum,
+  MQ_REQUIRE(a.q && a.k && a.v && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.head_dim == 64 && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
              "mq_attention_quant: head_dim 64, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
@@ -363,7 +376,7 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
                  a.qk_a.qmin == 0.f && a.qk_b.qmin == 0.f && a.pv_b.qmin == 0.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
              "mq_attention_quant: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
   MQ_REQUIRE(aligned(a.q, 16) && aligned(a.k, 16) && aligned(a.v, 16) && (!a.out || aligned(a.out, 16)) && aligned(a.q_i8, 16) && aligned(a.k_i8, 16) &&
-                 aligned(a.vt_i8, 16) && aligned(a.k_rowsum, 16) && aligned(a.v_colsum, 16),
+                 aligned(a.vt_i8, 16) && aligned(a.k_rowsum, 16),
              "mq_attention_quant: pointers must be 16-byte aligned");
   if (a.out_i8 != nullptr) {
     MQ_REQUIRE(a.out_rowsum != nullptr && a.pv_out.scale != nullptr && a.pv_out.qmin - (float)a.out_shift >= -128.f &&
@@ -376,9 +389,9 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   attention_prep_kernel<<<dim3((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), 256, 0, st>>>(a);
   MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
   if (a.qk_out.scale != nullptr)
-    attention_quant_kernel<true><<<dim3((unsigned)(a.seq / 64), (unsigned)a.heads), 256, 0, st>>>(a);
+    attention_quant_kernel<true><<<dim3((unsigned)(a.seq / 64 * a.heads)), 256, 0, st>>>(a);
   else
-    attention_quant_kernel<false><<<dim3((unsigned)(a.seq / 64), (unsigned)a.heads), 256, 0, st>>>(a);
+    attention_quant_kernel<false><<<dim3((unsigned)(a.seq / 64 * a.heads)), 256, 0, st>>>(a);
   MQ_LAUNCH_CHECK("mq_attention_quant");
   return MQ_OK;
 }

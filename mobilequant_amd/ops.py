@@ -447,11 +447,10 @@ def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torc
     vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
     q_rs = torch.empty(heads * S, dtype=torch.int32, device=dev)
     k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
-    v_cs = torch.empty(kv_heads * max(S // 64, 1) * D, dtype=torch.int32, device=dev)
     a.q, a.k, a.v, a.cos, a.sin = q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr()
     a.seq, a.heads, a.kv_heads, a.head_dim, a.inv_sqrt_d = S, heads, kv_heads, D, 1.0 / (D ** 0.5)
     a.out, a.q_i8, a.k_i8, a.vt_i8 = out.data_ptr() if out is not None else None, q_i8.data_ptr(), k_i8.data_ptr(), vt_i8.data_ptr()
-    a.q_rowsum, a.k_rowsum, a.v_colsum = q_rs.data_ptr(), k_rs.data_ptr(), v_cs.data_ptr()
+    a.q_rowsum, a.k_rowsum = q_rs.data_ptr(), k_rs.data_ptr()
     a.seq_real = S_real
     if image is not None:
         q_t, rs_t, row0, shift, tiled = image
