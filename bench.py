@@ -570,8 +570,7 @@ def bench_layer_full(dev):
             mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
     mq.wire_integer_inputs(model)
-    mq.fuse_gated_mlp(model)
-    llama.fuse_attention(model)
+    llama.fuse_decoder_layer(model)          # fuse_attention + fuse_gated_mlp + residual adds inside the o_proj / w2 GEMM stores
     layer = model.layers[0]
     with torch.no_grad():
         x = model.embed_tokens(ids)
@@ -586,6 +585,7 @@ def bench_layer_full(dev):
                 m.fused_mode = "off" if mode == "composite" else "auto"
         layer.mlp.fused_mode = "off" if mode == "composite" else "auto"
         layer.self_attn.fused_mode = "auto" if mode == "fused" else "off"
+        layer.fused_mode = "off" if mode == "composite" else "auto"
 
         def fwd():
             if mode == "composite":
@@ -599,7 +599,7 @@ def bench_layer_full(dev):
     rec, real = [], _ops.attention_quant
     _ops.attention_quant = lambda *a, **k: (rec.append((a, k)), real(*a, **k))[1]
     try:
-        layer.self_attn.fused_mode, layer.mlp.fused_mode = "auto", "auto"
+        layer.self_attn.fused_mode, layer.mlp.fused_mode, layer.fused_mode = "auto", "auto", "auto"
         with torch.no_grad():
             layer(x, cos, sin, mask)
     finally:

@@ -150,6 +150,14 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
                    const float* out_offset, float out_qmin, float out_qmax, void* out, int out_dtype,
                    mq_stream_t stream);
 
+/* mq_w8a8_linear with fp32 output PLUS a residual: out[m, n] = resid[m, n] + Qout(linear)[m, n] (plain fp32 add, what
+ * `x + self_attn(...)` / `x + mlp(...)` do in the decoder layer, hf_model.py:1127-1141) -- the add costs no launch and no extra
+ * pass.  Row-major int8 activations, M > 8.  resid may alias nothing the kernel writes (out != resid). */
+int mq_w8a8_linear_residual(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                            const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                            const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
+                            const float* resid, float* out, mq_stream_t stream);
+
 /* Fragment-blocked activations for the large FFN shapes.  mq_gemm_tiled_supported(M, N, K) != 0 (N a multiple of 176,
  * K a multiple of 256, at least 192 tiles of 256 x 176) means: quantise with mq_quantize_tiled instead of mq_quantize and
  * call mq_w8a8_linear_tiled instead of mq_w8a8_linear -- same arguments and results (bit-identical), ~7 % faster: the

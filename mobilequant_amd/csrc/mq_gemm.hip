@@ -57,6 +57,7 @@ struct GemmArgs {
   int a_tiled;                  // A is in the fragment-blocked layout of mq_quantize_tiled (generated-ISA variant only)
   int has_rowsum;               // a_rowsum == NULL (caller guarantees w_zp == 0): dummy pointer, element 0 only
   unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
+  const float* resid;           // fp32 [M, N] added to the (quantised) output at the store (o_proj / w2 + the residual stream); fp32 out only
 };
 
 #ifndef MQ_PP_PRIO
@@ -668,15 +669,31 @@ __global__ void __launch_bounds__(64 * WM * WN)
           if (16 * CH % 64 == 0 || c < 16 * CH) {
             const int row = c / CH, ch = c - row * CH;
             const int m = mrow0 + row, n = n0 + wave_n * TN + ch * EPC;
-            const v4i val = *reinterpret_cast<const v4i*>(stg + row * ROWP + ch * 16);
-            if (m < M && n < N) __builtin_nontemporal_store(val, reinterpret_cast<v4i*>(outp + (size_t)m * N + n));
+            v4i val = *reinterpret_cast<const v4i*>(stg + row * ROWP + ch * 16);
+            if (m < M && n < N) {
+              if constexpr (OUT == MQ_F32) {
+                if (args.resid != nullptr) {           // x + Qout(linear): the residual add of the decoder layer, plain fp32 add
+                  const v4f r = *reinterpret_cast<const v4f*>(args.resid + (size_t)m * N + n);
+                  v4f f = __builtin_bit_cast(v4f, val);
+                  f[0] = __fadd_rn(r[0], f[0]); f[1] = __fadd_rn(r[1], f[1]); f[2] = __fadd_rn(r[2], f[2]); f[3] = __fadd_rn(r[3], f[3]);
+                  val = __builtin_bit_cast(v4i, f);
+                }
+              }
+              __builtin_nontemporal_store(val, reinterpret_cast<v4i*>(outp + (size_t)m * N + n));
+            }
           }
         }
       } else {
         for (int c = lane; c < 16 * TN; c += 64) {        // ragged N: element-wise
           const int row = c / TN, col = c - row * TN;
           const int m = mrow0 + row, n = n0 + wave_n * TN + col;
-          if (m < M && n < N) outp[(size_t)m * N + n] = *reinterpret_cast<const OT*>(stg + row * ROWP + col * ESZ);
+          if (m < M && n < N) {
+            OT o = *reinterpret_cast<const OT*>(stg + row * ROWP + col * ESZ);
+            if constexpr (OUT == MQ_F32) {
+              if (args.resid != nullptr) o = __fadd_rn(args.resid[(size_t)m * N + n], o);
+            }
+            outp[(size_t)m * N + n] = o;
+          }
         }
       }
     }
@@ -1052,6 +1069,18 @@ int mq_w8a8_linear(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64
   }
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
              out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 0, 0, g_dbg_ts};
+  return run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_residual(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                            const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                            const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
+                            const float* resid, float* out, mq_stream_t stream) {
+  int rc = check_common("mq_w8a8_linear_residual", a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset, out, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(resid != nullptr && aligned(resid, 16) && M > 8, "mq_w8a8_linear_residual: resid must be non-null and 16-byte aligned; M > 8");
+  GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
+             out_qmin, out_qmax, out, MQ_F32, 0, 0, bias != nullptr, 0, 0, g_dbg_ts, resid};
   return run_gemm<false>(g, as_stream(stream));
 }
 

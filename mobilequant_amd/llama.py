@@ -96,7 +96,7 @@ class Attention(nn.Module):
         return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
 
 
-def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
+def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, resid=None):
     """Attention.forward with RoPE, both QMatMuls, 1/sqrt(d), the causal mask and the softmax in ONE pair of launches
     (ops.attention_quant: integer q.k^T and p.v on the MFMA units, no [S, S] tensor in memory).  Serves causal prefill from position
     0 with static per-tensor grids (8-bit q / k / v, <= 16-bit probabilities) at head_dim 64; everything else -- training, decode steps,
@@ -104,7 +104,11 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
     from . import ops
     from .quantization import qmodule as Q
     s = self.s
-    plain = self._mq_plain_forward
+    plain0 = self._mq_plain_forward
+
+    def plain(*a):
+        out = plain0(*a)
+        return out if resid is None else resid + out
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
     if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim != 64 or S < 2
@@ -142,11 +146,12 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
             rs = torch.empty(M, dtype=torch.int32, device=x.device)
             for b in range(B):
                 ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False)
-            return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S))
+            return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S), resid=resid)
     out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids) for b in range(B)])
     if oq is not None and not oq.bypassed():
         Q._tag_grid(out, oq)
-    return o_proj(out)
+    out = o_proj(out)
+    return out if resid is None else resid + out
 
 
 def fuse_attention(model) -> int:
@@ -160,6 +165,33 @@ def fuse_attention(model) -> int:
                 and not hasattr(m, "_mq_plain_forward")):
             m._mq_plain_forward = m.forward
             m.forward = types.MethodType(_fused_attention_forward, m)
+            n += 1
+    return n
+
+
+def _fused_layer_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
+    """DecoderLayer.forward with the two residual adds (ElementwiseAdd, hf_model.py:1257, :1270 -- plain fp32 adds, not in the surgery
+    list) folded into the stores of the o_proj and w2 GEMMs.  Needs the fused attention and the fused gated MLP on this layer; their
+    own fallbacks add the residual as a plain op, so the result is the module chain's in every case."""
+    if getattr(self, "fused_mode", "auto") == "off" or not hasattr(self.self_attn, "_mq_plain_forward") or not hasattr(self.mlp, "_mq_plain_forward"):
+        return self._mq_plain_forward(x, cos, sin, mask, cache, pos)
+    x = self.self_attn(self.input_layernorm(x), cos, sin, mask, cache, pos, resid=x)
+    return self.mlp(self.post_attention_layernorm(x), resid=x)
+
+
+def fuse_decoder_layer(model) -> int:
+    """fuse_attention + quantization.fuse_gated_mlp + the residual adds inside the o_proj / w2 GEMM stores, on every DecoderLayer.
+    Returns the number of layers fused; `layer.fused_mode = "off"` restores the plain layer forward."""
+    import types
+    from .quantization import qmodule as Q
+    fuse_attention(model)
+    Q.fuse_gated_mlp(model)
+    n = 0
+    for m in model.modules():
+        if (isinstance(m, DecoderLayer) and hasattr(m.self_attn, "_mq_plain_forward") and hasattr(m.mlp, "_mq_plain_forward")
+                and not hasattr(m, "_mq_plain_forward")):
+            m._mq_plain_forward = m.forward
+            m.forward = types.MethodType(_fused_layer_forward, m)
             n += 1
     return n
 

@@ -228,10 +228,13 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
                 w_zp: torch.Tensor, col_term: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
                 out_scale: Optional[torch.Tensor] = None, out_offset: Optional[torch.Tensor] = None,
                 out_qmin: float = 0.0, out_qmax: float = 255.0, out_dtype: int = MQ_F32, w4: bool = False,
-                out: Optional[torch.Tensor] = None, a_tiled_rows: Optional[int] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, a_tiled_rows: Optional[int] = None,
+                resid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """QLinear as an int8 MFMA GEMM with fused dequant (+ output quantizer).  a_q [M,K] int8, w_q [N,K]
     int8 (or [N,K/2] packed nibbles when w4).  a_tiled_rows = M: a_q is the fragment-blocked buffer of
-    quantize_tiled ([ceil16(M), K] bytes) and the generated-ISA GEMM path runs (gemm_tiled_supported shapes)."""
+    quantize_tiled ([ceil16(M), K] bytes) and the generated-ISA GEMM path runs (gemm_tiled_supported shapes).
+    resid [M, N] fp32 (row-major int8 weights and activations, fp32 output, M > 8): out = resid + Qout(linear), the add fused into
+    the GEMM's store (residual_supported())."""
     _dev(a_q, "a_q"); _dev(w_q, "w_q")
     M, K = a_q.shape
     if a_tiled_rows is not None:
@@ -242,6 +245,19 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     b = _f32(bias, "bias") if bias is not None else None
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
+    if resid is not None:
+        if a_tiled_rows is not None or w4 or out_dtype != MQ_F32 or M <= 8:
+            raise RuntimeError("mobilequant_amd: int8_linear(resid=...) needs row-major int8 operands, fp32 output and M > 8")
+        resid = _f32(_dev(resid, "resid"), "resid")
+        if resid.numel() != M * N or resid.data_ptr() == out.data_ptr():
+            raise RuntimeError("mobilequant_amd: resid must be [M, N] and must not alias the output")
+        with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, os_, oo_, out, resid):
+            _lib.call("mq_w8a8_linear_residual", a_q.data_ptr(), w_q.data_ptr(), M, N, K,
+                      a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
+                      b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
+                      oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), resid.data_ptr(), out.data_ptr(),
+                      _stream())
+        return out
     fn = "mq_w8a8_linear_tiled" if a_tiled_rows is not None else ("mq_w4a8_linear" if w4 else "mq_w8a8_linear")
     with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, os_, oo_, out):
         _lib.call(fn, a_q.data_ptr(), w_q.data_ptr(), M, N, K,

@@ -629,10 +629,11 @@ class QLinear(nn.Linear, _QuantizedOp):
             plan["epi_key"] = epi_key
         return plan
 
-    def _int8_from_image(self, x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=False, lead_shape=None):
+    def _int8_from_image(self, x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=False, lead_shape=None, resid=None):
         """The GEMM half of the integer path: a ready int8 image of the activation (row-major, or fragment-blocked with
         tiled_rows) on `grid` -> this linear's output.  x only supplies dtype / leading shape (and the fp32 values for the
-        fused decode GEMV); it may be None when lead_shape is given."""
+        fused decode GEMV); it may be None when lead_shape is given.  resid (fp32, the output's shape): returns
+        resid + output -- fused into the GEMM's store where the kernel allows (no launch, no pass), a plain add elsewhere."""
         oq = self.output_quantizer
         K, N = weight.shape[1], weight.shape[0]
         plan = self._epilogue_vectors(self._weight_plan(weight), grid, a_shift, K)
@@ -650,7 +651,18 @@ class QLinear(nn.Linear, _QuantizedOp):
                 out_offset=oq.offset.detach() if fused else None, out_qmin=oq.qmin if fused else 0.0,
                 out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, w4=plan["w4"])
             out = out.reshape(*lead, N)
+            if resid is not None:
+                return resid + out
             return _tag_grid(out, oq) if fused else out
+        if resid is not None:
+            if (tiled_rows is None and not plan["w4"] and not f16 and a_q.shape[0] > 8 and resid.dtype == torch.float32
+                    and resid.is_contiguous()):
+                out = ops.int8_linear(
+                    a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
+                    out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
+                    out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, resid=resid)
+                return out.reshape(*lead, N)
+            return resid + self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode, lead_shape)
         out = ops.int8_linear(
             a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
             out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
@@ -1037,14 +1049,19 @@ def _u8_grid(q: Optional[Quantizer]) -> bool:
     return _static_per_tensor(q, 8) and q.qmin == 0 and q.qmax == 255
 
 
-def _gated_mlp_forward(self, x):
+def _gated_mlp_forward(self, x, resid=None):
     """``w2(act_fn(w1(x)) * w3(x))`` (hf_model.py:1057) on the integer chain, in four launches and without a single fp32
     intermediate: [int8 image of x -- usually left by the norm] -> ONE pair GEMM writing the 8-bit output indices of w1 and
     w3 -> ONE gated-activation kernel (dequantise the indices, QSiLU / QGELU, product, w2's input quantizer -> int8 + row sums)
     -> w2's GEMM.  Bit-identical to the chain of modules on their integer paths; anything the chain cannot serve falls back to
-    the chain itself."""
+    the chain itself.  resid (optional, the output's shape): returns resid + mlp(x) with the add inside w2's GEMM store (used by
+    llama.fuse_decoder_layer)."""
     w1, w2, w3, act = self.w1, self.w2, self.w3, self.act_fn
-    plain = self._mq_plain_forward
+    plain0 = self._mq_plain_forward
+
+    def plain(t):
+        out = plain0(t)
+        return out if resid is None else resid + out
 
     def weight_of(m):
         return m._effective_weight(m.temp_weight if m.use_temporary_parameter else m.weight)
@@ -1100,7 +1117,7 @@ def _gated_mlp_forward(self, x):
                                     mid_grid=QRMSNorm._grid_or_none(act.input2_quantizer) if silu else None,
                                     act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
     return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q.view(M, N), p_rs, 128,
-                               None, lead_shape=x.shape[:-1])
+                               None, lead_shape=x.shape[:-1], resid=resid)
 
 
 def fuse_gated_mlp(model) -> int:

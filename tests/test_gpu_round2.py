@@ -524,6 +524,17 @@ def test_fused_gated_mlp_equals_module_chain(dev, act):
             ops.int8_linear_pair, ops.gated_act_quant = real_pair, real_gate
         assert calls == ["pair", "gate"]
         assert torch.equal(fused, chain)
+        # the residual variant (llama.fuse_decoder_layer): resid + mlp(x) with the add inside w2's GEMM store
+        r = torch.randn_like(chain)
+        seen = []
+        real_lin = ops.int8_linear
+        ops.int8_linear = lambda *a, **k: (seen.append(k.get("resid") is not None), real_lin(*a, **k))[1]
+        try:
+            with_resid = m(x, resid=r)
+        finally:
+            ops.int8_linear = real_lin
+        assert seen == [True]
+        assert torch.equal(with_resid, r + chain)
         m.fused_mode = "off"
         assert torch.equal(m(x), chain)
         # the pair GEMM's indices are the indices of the two single GEMMs' fake-quantised outputs
@@ -803,7 +814,7 @@ def test_fuse_attention_longer_prefill_with_cache(dev):
     """S = 200 (padded to 256 inside the op), batch 2, static KV cache written on the side: fused == chain within the budget, and the
     cache contents equal the chain's."""
     import mobilequant_amd as mq
-    from mobilequant_amd import llama
+    from mobilequant_amd import llama, ops
     from mobilequant_amd.calibration import get_act_range
     from toy_models import apply_mixed_precision
     m = llama.LlamaForCausalLM(llama.LlamaShape(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=64, max_pos=256))
@@ -824,6 +835,18 @@ def test_fuse_attention_longer_prefill_with_cache(dev):
         llama.fuse_attention(m)
         c1 = m.new_cache(2, 256, device=dev)
         fused = m(ids, cache=c1)
+        assert llama.fuse_decoder_layer(m) == 2          # + residual adds inside the o_proj / w2 GEMM stores: the same fp32 add
+        calls = []
+        real = ops.int8_linear
+        ops.int8_linear = lambda *a, **k: (calls.append(k.get("resid") is not None), real(*a, **k))[1]
+        try:
+            whole = m(ids, cache=m.new_cache(2, 256, device=dev))
+        finally:
+            ops.int8_linear = real
+        assert sum(calls) == 2                           # o_proj of both layers (this toy FFN is too small for the fused MLP: plain add)
+        assert torch.equal(whole, fused)
+        m.layers[0].fused_mode = "off"
+        assert torch.equal(m(ids, cache=m.new_cache(2, 256, device=dev)), fused)
     assert torch.equal(c0[0][0], c1[0][0]) and torch.equal(c0[0][1], c1[0][1])      # layer 0: same inputs -> same cache
     span = float(base.max() - base.min())
     d = (fused - base).abs()
