@@ -534,7 +534,7 @@ def bench_layer(dev):
     return res
 
 
-def bench_layer_full(dev):
+def bench_layer_full(dev, modes=("fused", "attention_chain", "composite")):
     """ONE whole TinyLlama decoder layer at prefill (B = 1, S = 2048) on the reference's module graph (mobilequant_amd/llama.py:
     norms, q/k/v/o, RoPE, qk_bmm / pv_bmm QMatMuls, softmax, gated FFN, residual adds), W8A8 recipe of ptq/mobilequant.py:175-201,
     ranges from this package's own calibration pass over the fp32 layer.  hipGraph time with (a) everything fused (fuse_attention:
@@ -579,7 +579,7 @@ def bench_layer_full(dev):
     mask._mq_causal = True
     res = {}
     outs = {}
-    for mode in ("fused", "attention_chain", "composite"):
+    for mode in modes:
         for m in layer.modules():
             if hasattr(m, "fused_mode"):
                 m.fused_mode = "off" if mode == "composite" else "auto"
@@ -606,12 +606,14 @@ def bench_layer_full(dev):
         _ops.attention_quant = real
     (a_args, a_kw), = rec
     res["attention_op_us"] = round(event_time(lambda: real(*a_args, **a_kw), 5) * 1e6, 1)
-    span = float(outs["attention_chain"].max() - outs["attention_chain"].min())
-    res["fused_vs_chain_max_over_span"] = round(float((outs["fused"] - outs["attention_chain"]).abs().max()) / span, 5)
+    if "fused" in outs and "attention_chain" in outs:
+        span = float(outs["attention_chain"].max() - outs["attention_chain"].min())
+        res["fused_vs_chain_max_over_span"] = round(float((outs["fused"] - outs["attention_chain"]).abs().max()) / span, 5)
     hidden, kv, ffn = shape.hidden, shape.kv_heads * shape.head_dim, shape.ffn
     ops_lin = 2.0 * S * (hidden * hidden * 2 + hidden * kv * 2 + hidden * ffn * 3)
     ops_att = 2.0 * shape.heads * shape.head_dim * S * S          # causal: q.k^T + p.v, each 2 * S^2 / 2 * D per head
-    res["tops_fused"] = round((ops_lin + ops_att) / (res["fused_us"] * 1e-6) / 1e12, 1)
+    if "fused_us" in res:
+        res["tops_fused"] = round((ops_lin + ops_att) / (res["fused_us"] * 1e-6) / 1e12, 1)
     res["scope"] = "one whole TinyLlama decoder layer, B = 1, S = 2048, W8A8 recipe, module API, hipGraph"
     return res
 

@@ -106,8 +106,8 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
     s = self.s
     plain0 = self._mq_plain_forward
 
-    def plain(*a):
-        out = plain0(*a)
+    def plain(t, *a):
+        out = plain0(Q._materialize(t), *a)
         return out if resid is None else resid + out
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
@@ -175,8 +175,14 @@ def _fused_layer_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
     own fallbacks add the residual as a plain op, so the result is the module chain's in every case."""
     if getattr(self, "fused_mode", "auto") == "off" or not hasattr(self.self_attn, "_mq_plain_forward") or not hasattr(self.mlp, "_mq_plain_forward"):
         return self._mq_plain_forward(x, cos, sin, mask, cache, pos)
-    x = self.self_attn(self.input_layernorm(x), cos, sin, mask, cache, pos, resid=x)
-    return self.mlp(self.post_attention_layernorm(x), resid=x)
+    from .quantization import qmodule as Q
+
+    def norm(mod, t, layout):
+        return mod.forward_images(t, layout) if isinstance(mod, Q.QRMSNorm) else mod(t)
+    # the norms' only consumers here are integer linears: they write just the int8 image those read (q/k/v: row-major; w1/w3: the
+    # fragment-blocked layout), not the fp32 tensor
+    x = self.self_attn(norm(self.input_layernorm, x, "rowmajor"), cos, sin, mask, cache, pos, resid=x)
+    return self.mlp(norm(self.post_attention_layernorm, x, "tiled"), resid=x)
 
 
 def fuse_decoder_layer(model) -> int:

@@ -318,16 +318,19 @@ def int8_linear_f32in(x2d: torch.Tensor, a_scale, a_offset, a_qmin: float, a_qma
 
 
 def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_grid=None, out_grid=None, emit_int8: bool = False,
-                  layernorm: bool = False, emit_tiled: bool = False):
+                  layernorm: bool = False, emit_tiled: bool = False, want_y: bool = True, emit_rowmajor: bool = True):
     """QRMSNorm.forward (layernorm=True: QLayerNorm.forward) in one launch.  in_grid / out_grid: None or
     (scale, offset, qmin, qmax) per-tensor.  Returns y, or (y, q_int8, row_sum, shift, q_tiled) with emit_int8
-    (8-bit output grids only; q_tiled = the fragment-blocked copy when emit_tiled, else None)."""
+    (8-bit output grids only; q_tiled = the fragment-blocked copy when emit_tiled, else None).  want_y=False (emit_int8 only): the
+    fp32 result is not written (y = None); emit_rowmajor=False: only the fragment-blocked image (q_int8 = None)."""
     x = _f32(_dev(x, "x"), "x").contiguous()
     cols = x.shape[-1]
     rows = x.numel() // cols
     w = _f32(weight, "weight").contiguous()
     b = _f32(bias, "bias").contiguous() if bias is not None else None
-    y = torch.empty_like(x)
+    if not want_y and not emit_int8:
+        raise RuntimeError("mobilequant_amd: rmsnorm_quant(want_y=False) needs emit_int8")
+    y = torch.empty_like(x) if want_y else None
     si = oi = so = oo = None
     iqmin = iqmax = oqmin = oqmax = 0.0
     if in_grid is not None:
@@ -338,7 +341,8 @@ def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_gr
     shift = 0
     if emit_int8:
         shift = 128 if oqmax > 127 else 0
-        q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+        if emit_rowmajor or not emit_tiled:
+            q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
         rs = torch.empty(rows, dtype=torch.int32, device=x.device)
         if emit_tiled:
             qt = torch.empty(((rows + 15) // 16 * 16, cols), dtype=torch.int8, device=x.device)
@@ -347,7 +351,8 @@ def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, bias, eps: float, in_gr
                   b.data_ptr() if b is not None else None, float(eps),
                   si.data_ptr() if si is not None else None, oi.data_ptr() if oi is not None else None, iqmin, iqmax,
                   so.data_ptr() if so is not None else None, oo.data_ptr() if oo is not None else None, oqmin, oqmax,
-                  y.data_ptr(), q.data_ptr() if q is not None else None, qt.data_ptr() if qt is not None else None, shift,
+                  y.data_ptr() if y is not None else None, q.data_ptr() if q is not None else None,
+                  qt.data_ptr() if qt is not None else None, shift,
                   rs.data_ptr() if rs is not None else None, _stream())
     return (y, q, rs, shift, qt) if emit_int8 else y
 

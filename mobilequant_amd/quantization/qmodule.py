@@ -603,6 +603,8 @@ class QLinear(nn.Linear, _QuantizedOp):
             tiled_rows = x2d.shape[0]
         else:
             hit = _shared_activation.get(x, grid, (a_shift, cs_tag))
+        if hit is None and getattr(x, "_mq_image_only", False):
+            x2d = _materialize(x).reshape(-1, K)        # the producer left its image in another layout: rebuild the values
         if hit is None and eligible:
             q_t, rs_t = ops.quantize_tiled(x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift,
                                            chan_scale=cs)
@@ -678,6 +680,7 @@ class QLinear(nn.Linear, _QuantizedOp):
         weight = self._effective_weight(weight)
         if self._int8_ready(input_, weight):
             return self._forward_int8(input_, weight, bias)
+        input_ = _materialize(input_)
         # simulated path: HIP fake-quant kernels around the library GEMM
         weight = _apply(self.weight_quantizer, weight)
         if self.input_chan_scale is not None:
@@ -722,10 +725,46 @@ class QMatMul(nn.Module, _QuantizedOp):
         return _apply(self.output_quantizer, out)
 
 
-def _fused_norm(self, input_, weight, bias, layernorm):
+def _image_only(shape, device, quantizer):
+    """Stand-in for an activation that exists only as its int8 image in the shared-activation memo: a 1-element tensor expanded
+    to `shape`, tagged with the producer grid.  Integer consumers look the image up by this object and never touch its memory;
+    anything else calls _materialize() first."""
+    t = _tag_grid(torch.empty(1, dtype=torch.float32, device=device).expand(*shape), quantizer)
+    t._mq_image_only = True
+    return t
+
+
+def _materialize(x):
+    """fp32 values of an image-only activation: (index - offset) * scale from the memo image -- the arithmetic of the fake-quant
+    output itself, so the result is what the producer would have written."""
+    if not getattr(x, "_mq_image_only", False):
+        return x
+    grid = _producer_grid(x)
+    K = x.shape[-1]
+    M = x.numel() // K
+    for tag in ((128, None), (0, None)):
+        hit = _shared_activation.get(x, grid, tag)
+        if hit is not None:
+            q = hit[0].reshape(M, K)
+            break
+    else:
+        for shift in (128, 0):
+            hit = _shared_activation.get(x, grid, ("tiled", shift, None))
+            if hit is not None:
+                break
+        if hit is None:
+            raise RuntimeError("mobilequant_amd: image-only activation without an image (consumed on another thread / stream?)")
+        q = hit[0].view(-1, K // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(-1, K)[:M]
+    y = (q.to(torch.float32) + float(hit[2]) - grid.offset.detach()) * grid.scale.detach()
+    return _tag_grid(y.reshape(x.shape), grid)
+
+
+def _fused_norm(self, input_, weight, bias, layernorm, images=None):
     """QRMSNorm / QLayerNorm.forward as ONE launch (mq_rmsnorm_quant / mq_layernorm_quant) instead of six; with an
     8-bit output grid the int8 indices + row sums are handed to the consumer linears through the shared-activation
-    memo, so q/k/v (w1/w3) launch no quantize.  None -> the caller runs the composite ops."""
+    memo, so q/k/v (w1/w3) launch no quantize.  None -> the caller runs the composite ops.
+    images = "rowmajor" | "tiled" (the decoder-layer pass, whose consumers are all integer): ONLY that int8 image is written -- no
+    fp32 result (16 of the 24 MB the kernel writes at [2048, 2048]); the return value is an _image_only() stand-in."""
     if (self.fused_mode == "off" or weight is None or not input_.is_cuda or input_.dtype != torch.float32
             or weight.dtype != torch.float32 or input_.shape[-1] % 4 or input_.numel() == 0
             or _needs_grad(input_, weight, bias)):
@@ -758,6 +797,15 @@ def _fused_norm(self, input_, weight, bias, layernorm):
     rows = input_.numel() // input_.shape[-1]
     tiled = getattr(self, "int8_tiled", None)
     tiled = emit and (input_.shape[-1] % 128 == 0) and (rows >= 1536 if tiled is None else bool(tiled))
+    if images is not None and emit and rows > 8 and (images == "rowmajor" or input_.shape[-1] % 64 == 0):   # (M <= 8: the decode GEMV reads fp32)
+        _, q, rs, shift, qt = ops.rmsnorm_quant(input_, wfq, bias, self.eps, gi, go, emit_int8=True, layernorm=layernorm,
+                                                emit_tiled=images == "tiled", want_y=False, emit_rowmajor=images == "rowmajor")
+        y = _image_only(input_.shape, input_.device, self.output_quantizer)
+        if q is not None:
+            _shared_activation.put(y, self.output_quantizer, (shift, None), (q, rs, shift))
+        if qt is not None:
+            _shared_activation.put(y, self.output_quantizer, ("tiled", shift, None), (qt, rs, shift))
+        return y
     res = ops.rmsnorm_quant(input_, wfq, bias, self.eps, gi, go, emit_int8=emit, layernorm=layernorm, emit_tiled=tiled)
     if not emit:
         return _tag_grid(res, self.output_quantizer) if go is not None else res
@@ -791,10 +839,17 @@ class QRMSNorm(HFRMSNorm, _QuantizedOp):
             return False
         return (q.scale.detach(), q.offset.detach(), q.qmin, q.qmax)
 
-    def _forward_fused(self, input_, weight):
+    def _forward_fused(self, input_, weight, images=None):
         if self.l2norm_as_rmsnorm:
             return None
-        return _fused_norm(self, input_, weight, self.bias, layernorm=False)
+        return _fused_norm(self, input_, weight, self.bias, layernorm=False, images=images)
+
+    def forward_images(self, input_, layout: str):
+        """forward() for callers whose consumers are all integer linears (llama.fuse_decoder_layer): only the int8 image in
+        `layout` ("rowmajor" | "tiled") is produced where the fused kernel applies; otherwise the ordinary forward."""
+        weight = self.temp_weight if self.use_temporary_parameter else self.weight
+        out = self._forward_fused(input_, weight, images=layout)
+        return out if out is not None else self.forward(input_)
 
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
@@ -1060,7 +1115,7 @@ def _gated_mlp_forward(self, x, resid=None):
     plain0 = self._mq_plain_forward
 
     def plain(t):
-        out = plain0(t)
+        out = plain0(_materialize(t))
         return out if resid is None else resid + out
 
     def weight_of(m):

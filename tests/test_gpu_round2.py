@@ -885,3 +885,32 @@ def test_attention_quant_int8_image_for_o_proj(dev, S, tiled):
     rs_want = np.full(rows, -5, dtype=np.int64)
     rs_want[row0:row0 + S] = (idx - 128).sum(1)
     assert np.array_equal(rs.cpu().numpy().astype(np.int64), rs_want)
+
+
+def test_image_only_norm_outputs_and_their_fallbacks(dev):
+    """QRMSNorm.forward_images (used by llama.fuse_decoder_layer): only the int8 image is written; an integer consumer takes it from
+    the memo, and every non-integer consumer gets the exact fp32 values back through _materialize -- in both layouts."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.quantization import qmodule as Q
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    torch.manual_seed(0)
+    a8, a16 = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16)
+    n = mq.QRMSNorm.from_float(HFRMSNorm(256, eps=1e-5).to(dev), a16, a16, a8).requires_grad_(False)
+    n.set_scale_offset({"input": [-5.0, 5.0], "output": [-4.0, 4.0]}, "buffer")
+    lin = mq.QLinear.from_float(torch.nn.Linear(256, 64, bias=False).to(dev), a8, a8, a8).requires_grad_(False)
+    lin.input_quantizer = None
+    lin.set_scale_offset({"output": [-3.0, 3.0]}, "buffer")
+    x = torch.randn(2, 40, 256, device=dev) * 1.5
+    with torch.no_grad():
+        y = n(x)
+        want = lin(y)
+        for layout in ("rowmajor", "tiled"):
+            p = n.forward_images(x, layout)
+            assert getattr(p, "_mq_image_only", False) and p.shape == y.shape and p.untyped_storage().nbytes() <= 16
+            assert torch.equal(Q._materialize(p), y)
+            assert torch.equal(lin(p), want)                       # integer path (memo hit, or rebuilt from the other layout)
+            lin.int8_mode = "off"
+            assert torch.equal(lin(n.forward_images(x, layout)), lin(y))      # simulated path: materialised first
+            lin.int8_mode = "auto"
+        small = n.forward_images(x[:1, :4], "rowmajor")            # decode-sized: the GEMV reads fp32 -> ordinary forward
+        assert not getattr(small, "_mq_image_only", False) and torch.equal(small, n(x[:1, :4]))
