@@ -348,6 +348,14 @@ int mq_decode_head(const float* x, const float* norm_weight, float eps, const fl
  * transposed, keys permuted inside each 64-block), q_rowsum [heads][seq], k_rowsum [kv_heads][seq] (the zero-point terms of the integer
  * q.k^T, derived from the row sums of the images).
  * Limits: head_dim == 64, seq % 64 == 0.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
+/* q | k | v (or any 1..3 linears reading one activation) as ONE int8 GEMM whose column segments carry their own 8-bit unsigned
+ * output grids: weights / epilogue vectors concatenated along N, segment i = columns [seg_end[i-1], seg_end[i]) (seg_end[-1] = 0,
+ * seg_end[n_segments-1] = N, multiples of 4) quantised on grids[i]; out = uint8 indices [M, N] -- per column exactly the index
+ * mq_w8a8_linear writes for that linear alone.  Row-major int8 activations, M > 8. */
+int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                             const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                             const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream);
+
 typedef struct mq_attention_args {
   const float* q;
   const float* k;
@@ -371,6 +379,11 @@ typedef struct mq_attention_args {
   int32_t* out_rowsum;
   int64_t out_row0;
   int seq_real, out_shift, out_i8_tiled;
+  /* alternative input: the uint8 output indices [seq, (heads + 2 kv_heads) * 64] of a fused q|k|v GEMM (mq_w8a8_linear_segmented)
+   * with the three output grids; the prep kernel dequantises (index - offset) * scale -- the fp32 value the linear would have
+   * written.  When qkv_idx is set, q / k / v are ignored (may be NULL). */
+  const uint8_t* qkv_idx;
+  mq_grid q_in, k_in, v_in;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
 

@@ -48,7 +48,7 @@ class MqAttentionArgs(ctypes.Structure):
                 ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid), ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p),
                 ("q_i8", c_void_p), ("k_i8", c_void_p), ("vt_i8", c_void_p), ("q_rowsum", c_void_p), ("k_rowsum", c_void_p),
                 ("out_i8", c_void_p), ("out_rowsum", c_void_p), ("out_row0", c_int64), ("seq_real", c_int),
-                ("out_shift", c_int), ("out_i8_tiled", c_int)]
+                ("out_shift", c_int), ("out_i8_tiled", c_int), ("qkv_idx", c_void_p), ("q_in", MqGrid), ("k_in", MqGrid), ("v_in", MqGrid)]
 
 
 _SIGNATURES = {
@@ -68,6 +68,7 @@ _SIGNATURES = {
     "mq_linear_epilogue_prepare": (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "mq_w8a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
     "mq_w8a8_linear_residual": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
+    "mq_w8a8_linear_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
     "mq_gemm_tiled_supported": (c_int, [c_int64, c_int64, c_int64]),
     "mq_quantize_tiled": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P]),
     "mq_w8a8_linear_tiled": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),

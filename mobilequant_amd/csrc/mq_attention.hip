@@ -82,13 +82,24 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
       d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
     }
   };
+  // index input: the uint8 output indices of the fused q|k|v GEMM, dequantised as that linear's fp32 output would read
+  const uint8_t* isrc = a.qkv_idx ? a.qkv_idx + ((size_t)s * (H + 2 * KV) + part) * D : nullptr;
+  const AGrid gin = a_load_grid(is_q ? a.q_in : (is_k ? a.k_in : a.v_in));
+  auto load16_idx = [&](const uint8_t* p, float (&d)[16]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = __fmul_rn(__fsub_rn((float)((w4[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
+  };
   float x[16];
-  load16(src + 16 * c, x);
+  if (isrc) load16_idx(isrc + 16 * c, x);
+  else load16(src + 16 * c, x);
   const AGrid g = a_load_grid(is_q ? a.qk_a : (is_k ? a.qk_b : a.pv_b));
   int st[16];
   if (is_q || is_k) {                                 // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
     float pr[16], cs[16], sn[16];
-    load16(src + ((16 * c + 32) & 63), pr);
+    if (isrc) load16_idx(isrc + ((16 * c + 32) & 63), pr);
+    else load16(src + ((16 * c + 32) & 63), pr);
     load16(a.cos + (size_t)s * D + 16 * c, cs);
     load16(a.sin + (size_t)s * D + 16 * c, sn);
     const float sign = c < 2 ? -1.f : 1.f;            // (-x) * sin == -(x * sin) exactly
@@ -368,14 +379,15 @@ using namespace mq;
 extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_attention_quant: null argument block");
   const mq_attention_args& a = *args;
-  MQ_REQUIRE(a.q && a.k && a.v && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
+  MQ_REQUIRE(((a.q && a.k && a.v) || a.qkv_idx) && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.head_dim == 64 && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
              "mq_attention_quant: head_dim 64, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
   MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmax == 255.f && a.qk_b.qmax == 255.f && a.pv_b.qmax == 255.f &&
                  a.qk_a.qmin == 0.f && a.qk_b.qmin == 0.f && a.pv_b.qmin == 0.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
              "mq_attention_quant: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
-  MQ_REQUIRE(aligned(a.q, 16) && aligned(a.k, 16) && aligned(a.v, 16) && (!a.out || aligned(a.out, 16)) && aligned(a.q_i8, 16) && aligned(a.k_i8, 16) &&
+  MQ_REQUIRE((a.qkv_idx ? aligned(a.qkv_idx, 16) && a.q_in.scale && a.k_in.scale && a.v_in.scale : aligned(a.q, 16) && aligned(a.k, 16) && aligned(a.v, 16)) &&
+                 (!a.out || aligned(a.out, 16)) && aligned(a.q_i8, 16) && aligned(a.k_i8, 16) &&
                  aligned(a.vt_i8, 16) && aligned(a.k_rowsum, 16),
              "mq_attention_quant: pointers must be 16-byte aligned");
   if (a.out_i8 != nullptr) {

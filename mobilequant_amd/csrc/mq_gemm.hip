@@ -58,6 +58,11 @@ struct GemmArgs {
   int has_rowsum;               // a_rowsum == NULL (caller guarantees w_zp == 0): dummy pointer, element 0 only
   unsigned long long* dbg_ts;   // ablation builds only: per-wave s_memtime stamps [block][wave][4]
   const float* resid;           // fp32 [M, N] added to the (quantised) output at the store (o_proj / w2 + the residual stream); fp32 out only
+  // column segments with their own 8-bit output grids (q | k | v in one launch; integer index outputs only): columns
+  // [seg_end[i-1], seg_end[i]) use seg_scale[i-1] / seg_offset[i-1]; columns below seg_end[0] use out_scale / out_offset
+  int seg_end[2];
+  const float* seg_scale[2];
+  const float* seg_offset[2];
 };
 
 #ifndef MQ_PP_PRIO
@@ -240,9 +245,20 @@ __global__ void __launch_bounds__(64 * WM * WN)
     for (int r = 0; r < PR; ++r) {
       const int tt = (int)threadIdx.x + r * 64 * NW;
       if (tt < BN) {
-        const float a_v = OUTQ ? pa[r] * inv_so : pa[r];
+        float inv_c = inv_so, oo_c = oo;
+        if constexpr (OUTQ && (OUT == MQ_U8 || OUT == MQ_I8)) {
+          if (args.seg_scale[0] != nullptr) {          // this column's own output grid (block-uniform branch)
+            const int n = n0 + tt;
+            const int sg = (n >= args.seg_end[0]) + (args.seg_scale[1] != nullptr && n >= args.seg_end[1]);
+            if (sg > 0) {
+              inv_c = __fdiv_rn(1.0f, args.seg_scale[sg - 1][0]);
+              oo_c = args.seg_offset[sg - 1][0];
+            }
+          }
+        }
+        const float a_v = OUTQ ? pa[r] * inv_c : pa[r];
         const float bias_v = args.has_bias ? pb[r] : 0.f;
-        const float b_v = OUTQ ? (FOLD_OO ? bias_v * inv_so + oo : bias_v * inv_so) : bias_v;
+        const float b_v = OUTQ ? (FOLD_OO ? bias_v * inv_c + oo_c : bias_v * inv_c) : bias_v;
         const unsigned base = (unsigned)(size_t)MQ_LDS_PTR(smem + PAR) + tt * 4;     // LDS byte address
         asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%5\n\tds_write_b32 %0, %3 offset:%6\n\t"
                      "ds_write_b32 %0, %4 offset:%7"
@@ -1081,6 +1097,32 @@ int mq_w8a8_linear_residual(const int8_t* a, const int8_t* w, int64_t M, int64_t
   MQ_REQUIRE(resid != nullptr && aligned(resid, 16) && M > 8, "mq_w8a8_linear_residual: resid must be non-null and 16-byte aligned; M > 8");
   GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
              out_qmin, out_qmax, out, MQ_F32, 0, 0, bias != nullptr, 0, 0, g_dbg_ts, resid};
+  return run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                             const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                             const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream) {
+  const char* fn = "mq_w8a8_linear_segmented";
+  MQ_REQUIRE(n_segments >= 1 && n_segments <= 3 && seg_end != nullptr && grids != nullptr, "%s: 1..3 segments", fn);
+  int rc = check_common(fn, a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset, out, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(M > 8, "%s: M > 8 (decode shapes: mq_decode_gemv)", fn);
+  int64_t prev = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    MQ_REQUIRE(grids[i].scale && grids[i].offset && grids[i].qmin == 0.f && grids[i].qmax == 255.f,
+               "%s: segment %d needs an 8-bit unsigned output grid", fn, i);
+    MQ_REQUIRE(seg_end[i] > prev && seg_end[i] <= N && seg_end[i] % 4 == 0, "%s: segment ends must increase, be multiples of 4, <= N", fn);
+    prev = seg_end[i];
+  }
+  MQ_REQUIRE(prev == N, "%s: the last segment must end at N", fn);
+  GemmArgs g{a, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset,
+             0.f, 255.f, out, MQ_U8, 0, 0, bias != nullptr, 0, 0, g_dbg_ts, nullptr, {0, 0}, {nullptr, nullptr}, {nullptr, nullptr}};
+  for (int i = 1; i < n_segments; ++i) {
+    g.seg_end[i - 1] = (int)seg_end[i - 1];
+    g.seg_scale[i - 1] = grids[i].scale;
+    g.seg_offset[i - 1] = grids[i].offset;
+  }
   return run_gemm<false>(g, as_stream(stream));
 }
 

@@ -128,7 +128,15 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
             quantizer.scale.data, quantizer.offset.data = quantizer.scale.to(x.device), quantizer.offset.to(x.device)
             g = Q.QRMSNorm._grid_or_none(quantizer)
         grids[name] = g
-    q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+    fused_qkv = _qkv_indices(self, x) if cache is None and getattr(self, "fuse_qkv", True) else None
+    if fused_qkv is not None:
+        idx, in_grids = fused_qkv                    # uint8 [B*S, (H + 2 KV) * 64]: one GEMM, three output grids
+        idx = idx.view(B, S, -1)
+        q = k = v = [None] * B
+        qkv = [(idx[b], in_grids) for b in range(B)]
+    else:
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        qkv = [None] * B
     if cache is not None:
         cache[0][:, :, :S] = apply_rope(k.view(B, S, s.kv_heads, 64).transpose(1, 2), cos, sin)
         cache[1][:, :, :S] = v.view(B, S, s.kv_heads, 64).transpose(1, 2)
@@ -145,13 +153,58 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
             q_i8 = torch.empty(((M + 15) // 16 * 16 if tiled else M, K), dtype=torch.int8, device=x.device)
             rs = torch.empty(M, dtype=torch.int32, device=x.device)
             for b in range(B):
-                ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False)
+                ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False,
+                                    qkv_idx=qkv[b])
             return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S), resid=resid)
-    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids) for b in range(B)])
+    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b]) for b in range(B)])
     if oq is not None and not oq.bypassed():
         Q._tag_grid(out, oq)
     out = o_proj(out)
     return out if resid is None else resid + out
+
+
+def _qkv_indices(self, x):
+    """q_proj | k_proj | v_proj as ONE int8 GEMM with three output grids (ops.int8_linear_segmented) -> (uint8 indices
+    [rows, (H + 2 KV) * 64], their (scale, offset) grids), or None when the three linears cannot share a launch (then each runs on its
+    own).  Per column the index is exactly what that linear's own GEMM writes; the concatenated operands are cached on the block."""
+    from . import ops
+    from .quantization import qmodule as Q
+    lins = (self.q_proj, self.k_proj, self.v_proj)
+    if not all(isinstance(m, Q.QLinear) and not m.use_temporary_parameter and m.input_chan_scale is None and m.input_quantizer is None
+               and Q._u8_grid(m.output_quantizer) for m in lins):
+        return None
+    ws = [m._effective_weight(m.weight) for m in lins]
+    if not all(m._int8_ready(x, w) and m.weight_quantizer.qcfg.bitwidth == 8 for m, w in zip(lins, ws)):
+        return None
+    grids_in = [m._activation_grid(x) for m in lins]
+    if any(g.grid_token() != grids_in[0].grid_token() for g in grids_in) or x.numel() // x.shape[-1] <= 8:
+        return None
+    if (any(m.bias is not None for m in lins) and not all(m.bias is not None for m in lins)):
+        return None
+    grid, a_q, a_rs, a_shift, tiled_rows, decode = lins[0]._input_image(x, ws[0])
+    if tiled_rows is not None or decode:
+        return None
+    K = ws[0].shape[1]
+    plans = [m._epilogue_vectors(m._weight_plan(w), grid, a_shift, K) for m, w in zip(lins, ws)]
+    key = tuple((p["key"], p["epi_key"]) for p in plans) + tuple(None if m.bias is None else (m.bias.data_ptr(), Q._ver(m.bias)) for m in lins)
+    cat = getattr(self, "_qkv_cat", None)
+    if cat is None or cat["key"] != key:
+        cat = {"key": key, "w": torch.cat([p["w"] for p in plans]), "alpha": torch.cat([p["alpha"] for p in plans]),
+               "w_zp": torch.cat([p["w_zp"] for p in plans]), "col_term": torch.cat([p["col_term"] for p in plans]),
+               "bias": None if lins[0].bias is None else torch.cat([m.bias.detach().float() for m in lins])}
+        self._qkv_cat = cat
+    ends, tot = [], 0
+    for w in ws:
+        tot += w.shape[0]
+        ends.append(tot)
+    out_grids = []
+    for m in lins:
+        oq = m.output_quantizer
+        if oq.scale.device != x.device:
+            oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
+        out_grids.append((oq.scale.detach(), oq.offset.detach()))
+    idx = ops.int8_linear_segmented(a_q, cat["w"], a_rs, cat["alpha"], cat["w_zp"], cat["col_term"], cat["bias"], ends, out_grids)
+    return idx, out_grids
 
 
 def fuse_attention(model) -> int:

@@ -268,6 +268,30 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     return out
 
 
+def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.Tensor, alpha: torch.Tensor, w_zp: torch.Tensor,
+                          col_term: torch.Tensor, bias: Optional[torch.Tensor], seg_ends, grids) -> torch.Tensor:
+    """1..3 linears reading one row-major int8 activation as ONE GEMM (mq_w8a8_linear_segmented): w_q / alpha / w_zp / col_term /
+    bias concatenated along N, seg_ends = cumulative column ends, grids[i] = (scale, offset) of segment i's 8-bit unsigned output
+    grid.  Returns the uint8 output indices [M, N]."""
+    _dev(a_q, "a_q"); _dev(w_q, "w_q")
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    n = len(seg_ends)
+    out = torch.empty((M, N), dtype=torch.uint8, device=a_q.device)
+    b = _f32(bias, "bias") if bias is not None else None
+    ends = (ctypes.c_int64 * n)(*[int(e) for e in seg_ends])
+    keep, gs = [], (_lib.MqGrid * n)()
+    for i, g in enumerate(grids):
+        sc, of = _f32(g[0], "scale"), _f32(g[1], "offset")
+        keep += [sc, of]
+        gs[i] = _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0)
+    with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, out, *keep):
+        _lib.call("mq_w8a8_linear_segmented", a_q.data_ptr(), w_q.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
+                  alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(), b.data_ptr() if b is not None else None, n, ends, gs,
+                  out.data_ptr(), _stream())
+    return out
+
+
 def gemm_tiled_supported(M: int, N: int, K: int) -> bool:
     """Shapes served by the fragment-blocked activation layout + generated-ISA GEMM loop (TinyLlama / StableLM FFN)."""
     return bool(_lib.load().mq_gemm_tiled_supported(int(M), int(N), int(K)))
@@ -432,24 +456,38 @@ def gated_act_quant(a: torch.Tensor, b: torch.Tensor, act: str, out_grid, *, a_g
     return (q, rs, y) if want_y else (q, rs)
 
 
-def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int,
-                    kv_heads: int, grids: dict, image=None, want_out: bool = True):
+def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
+                    heads: int, kv_heads: int, grids: dict, image=None, want_out: bool = True, qkv_idx=None):
     """Quantized causal prefill attention of ONE sequence (mq_attention_quant): q [S, heads*64], k / v [S, kv_heads*64] fp32
     projection outputs before RoPE, cos / sin [S, 64]; grids: qk_a, qk_b, qk_out, pv_a, pv_b, pv_out -> (scale, offset, qmin, qmax)
     per tensor or None (qk_out / pv_out only).  Returns pv_bmm's output [S, heads*64] fp32 (o_proj's input layout).
     image = (q_i8, row_sum [rows] int32, row0, shift, tiled): additionally (want_out=False: only) write the pv_out indices of this
     sequence as rows row0 .. row0+S-1 of the consumer linear's int8 input image: row-major [rows, heads*64], or (tiled) the
     fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled."""
-    q, k, v = (_dev(t, n).contiguous() for t, n in ((q, "q"), (k, "k"), (v, "v")))
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
-    S, D = q.shape[0], 64
-    if (q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or q.shape != (S, heads * D)
-            or k.shape != (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, D) or sin.shape != (S, D)):
-        raise RuntimeError("mobilequant_amd: attention_quant needs fp32 q [S, H*64], k / v [S, KV*64], cos / sin [S, 64]")
+    D = 64
+    idx = None
+    if qkv_idx is not None:       # (uint8 [S, (heads + 2 kv_heads) * 64] of int8_linear_segmented, ((scale, offset) x 3))
+        idx, in_grids = qkv_idx
+        idx = _dev(idx, "qkv_idx").contiguous()
+        S = idx.shape[0]
+        if idx.dtype != torch.uint8 or idx.shape != (S, (heads + 2 * kv_heads) * D) or cos.shape != (S, D) or sin.shape != (S, D):
+            raise RuntimeError("mobilequant_amd: attention_quant qkv_idx must be uint8 [S, (H + 2 KV) * 64], cos / sin [S, 64]")
+        q = k = v = None
+    else:
+        q, k, v = (_dev(t, n).contiguous() for t, n in ((q, "q"), (k, "k"), (v, "v")))
+        S = q.shape[0]
+        if (q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or q.shape != (S, heads * D)
+                or k.shape != (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, D) or sin.shape != (S, D)):
+            raise RuntimeError("mobilequant_amd: attention_quant needs fp32 q [S, H*64], k / v [S, KV*64], cos / sin [S, 64]")
     S_real = S
     if S % 64:                    # pad the sequence: under the causal mask a padded key is only ever seen by padded queries
         pad = 64 - S % 64
-        q, k, v, cos, sin = (torch.nn.functional.pad(t, (0, 0, 0, pad)) for t in (q, k, v, cos, sin))
+        cos, sin = (torch.nn.functional.pad(t, (0, 0, 0, pad)) for t in (cos, sin))
+        if idx is not None:
+            idx = torch.nn.functional.pad(idx, (0, 0, 0, pad))
+        else:
+            q, k, v = (torch.nn.functional.pad(t, (0, 0, 0, pad)) for t in (q, k, v))
         S += pad
     a = _lib.MqAttentionArgs()
     keep = []
@@ -461,14 +499,23 @@ def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torc
             s, o = _f32(g[0], "scale"), _f32(g[1], "offset")
             keep += [s, o]
             setattr(a, name, _lib.MqGrid(s.data_ptr(), o.data_ptr(), float(g[2]), float(g[3])))
-    dev = q.device
+    first = idx if idx is not None else q
+    dev = first.device
+    if idx is not None:
+        a.qkv_idx = idx.data_ptr()
+        for name, g in zip(("q_in", "k_in", "v_in"), in_grids):
+            sc, of = _f32(g[0], "scale"), _f32(g[1], "offset")
+            keep += [sc, of]
+            setattr(a, name, _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0))
     out = torch.empty(S, heads * D, dtype=torch.float32, device=dev) if want_out or image is None else None
     q_i8 = torch.empty(heads * S * D, dtype=torch.int8, device=dev)
     k_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
     vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
     q_rs = torch.empty(heads * S, dtype=torch.int32, device=dev)
     k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
-    a.q, a.k, a.v, a.cos, a.sin = q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    if idx is None:
+        a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    a.cos, a.sin = cos.data_ptr(), sin.data_ptr()
     a.seq, a.heads, a.kv_heads, a.head_dim, a.inv_sqrt_d = S, heads, kv_heads, D, 1.0 / (D ** 0.5)
     a.out, a.q_i8, a.k_i8, a.vt_i8 = out.data_ptr() if out is not None else None, q_i8.data_ptr(), k_i8.data_ptr(), vt_i8.data_ptr()
     a.q_rowsum, a.k_rowsum = q_rs.data_ptr(), k_rs.data_ptr()
@@ -481,7 +528,7 @@ def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torc
             raise RuntimeError("mobilequant_amd: attention_quant image must be int8 [rows (tiled: ceil16), heads*64] + int32 row sums [rows]")
         keep += [q_t, rs_t]
         a.out_i8, a.out_rowsum, a.out_row0, a.out_shift, a.out_i8_tiled = q_t.data_ptr(), rs_t.data_ptr(), int(row0), int(shift), int(bool(tiled))
-    with _on(q, k, v, cos, sin, *keep):
+    with _on(first, k, v, cos, sin, *keep):
         _lib.call("mq_attention_quant", ctypes.byref(a), _stream())
     if out is None:
         return None

@@ -799,6 +799,19 @@ def test_fuse_attention_matches_module_chain_and_the_reference_logits(dev):
         finally:
             ops.attention_quant = real
         assert len(calls) == 2
+        # q | k | v as one segmented GEMM (uint8 indices, dequantised in the attention prep) == three GEMMs writing fp32: bit for bit
+        seg = []
+        real_seg = ops.int8_linear_segmented
+        ops.int8_linear_segmented = lambda *a, **k: (seg.append(1), real_seg(*a, **k))[1]
+        try:
+            again = m(ids)
+        finally:
+            ops.int8_linear_segmented = real_seg
+        assert len(seg) == 2 and torch.equal(again, fused)
+        for mod in m.modules():
+            if isinstance(mod, llama.Attention):
+                mod.fuse_qkv = False
+        assert torch.equal(m(ids), fused)
         for mod in m.modules():
             if isinstance(mod, llama.Attention):
                 mod.fused_mode = "off"
@@ -914,3 +927,36 @@ def test_image_only_norm_outputs_and_their_fallbacks(dev):
             lin.int8_mode = "auto"
         small = n.forward_images(x[:1, :4], "rowmajor")            # decode-sized: the GEMV reads fp32 -> ordinary forward
         assert not getattr(small, "_mq_image_only", False) and torch.equal(small, n(x[:1, :4]))
+
+
+def test_segmented_gemm_equals_the_three_linears(dev):
+    """mq_w8a8_linear_segmented (q | k | v in one launch, three 8-bit output grids): every column's uint8 index equals the index the
+    linear's own mq_w8a8_linear launch writes, at TinyLlama's q|k|v shape and at a ragged one."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_I8, MQ_U8
+    for M, K, Ns in ((2048, 2048, (2048, 256, 256)), (200, 256, (64, 128, 36))):
+        g = torch.Generator(device="cpu").manual_seed(M)
+        x = torch.randn(M, K, generator=g).to(dev)
+        aq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+        aq.set_scale_offset_from_minmax(float(x.min()), float(x.max()), "buffer", dev)
+        a_q, a_rs, a_shift = aq.quantize_to_int(x, MQ_I8, want_row_sum=True)
+        parts, singles, grids = [], [], []
+        for i, N in enumerate(Ns):
+            w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+            bias = (torch.randn(N, generator=g) * 0.1).to(dev)
+            wq = mq.Quantizer(mq.QuantConfig(bitwidth=8, is_per_channel=(i == 1)))
+            wq(w)
+            w8, colsum, wshift = wq.quantize_to_int(w, MQ_I8, want_row_sum=True, rows=N)
+            alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, a_shift, wq.scale.detach(), wq.offset.detach(), wshift, colsum, K)
+            y = torch.nn.functional.linear(x, w, bias)
+            oq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+            oq.set_scale_offset_from_minmax(float(y.min()) * (0.7 + 0.2 * i), float(y.max()) * (0.7 + 0.2 * i), "buffer", dev)
+            singles.append(ops.int8_linear(a_q, w8, a_rs, alpha, wzp, ct, bias, out_scale=oq.scale, out_offset=oq.offset, out_qmin=0.0,
+                                           out_qmax=255.0, out_dtype=MQ_U8))
+            parts.append((w8, alpha, wzp, ct, bias))
+            grids.append((oq.scale, oq.offset))
+        cat = [torch.cat([p[j] for p in parts]) for j in range(5)]
+        ends = np.cumsum(Ns).tolist()
+        got = ops.int8_linear_segmented(a_q, cat[0], a_rs, cat[1], cat[2], cat[3], cat[4], ends, grids)
+        assert got.dtype == torch.uint8 and torch.equal(got, torch.cat(singles, dim=1)), (M, K, Ns)
