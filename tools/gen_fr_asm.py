@@ -67,7 +67,10 @@ S_RT = 84                         # 84..87: s_memrealtime (constant 100 MHz) at 
 # what-if switches for profiling builds (results are wrong): MQ_FR_NO_A / _NO_W / _NO_READ / _NO_MFMA drop the in-loop activation
 # loads / W LDS-DMA / W fragment reads / MFMAs
 NO_A, NO_W, NO_READ, NO_MFMA = (bool(os.environ.get("MQ_FR_" + k)) for k in ("NO_A", "NO_W", "NO_READ", "NO_MFMA"))
-STORE_POLICY = os.environ.get("MQ_FR_STORE", "nt")      # cache policy of the output stores: "" (write-back) | nt | sc1 | "sc0 sc1" | none
+# cache policy of the output stores: "" (write-back, default) | nt | sc1 | "sc0 sc1" | none.  Same kernel time for all (profiles/r02),
+# but nt pushes the partial 32 B sectors of the 176-byte tile rows out before their neighbours merge: WRITE_SIZE 14.5 MB vs the exact
+# M * N = 11.5 MB with write-back
+STORE_POLICY = os.environ.get("MQ_FR_STORE", "")
 
 out = []
 
