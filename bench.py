@@ -614,6 +614,8 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite")):
     ops_att = 2.0 * shape.heads * shape.head_dim * S * S          # causal: q.k^T + p.v, each 2 * S^2 / 2 * D per head
     if "fused_us" in res:
         res["tops_fused"] = round((ops_lin + ops_att) / (res["fused_us"] * 1e-6) / 1e12, 1)
+        res["frac_of_int8_peak"] = round(res["tops_fused"] / INT8_MFMA_PEAK_TOPS, 4)
+        res["launches_per_layer"] = 9
     res["scope"] = "one whole TinyLlama decoder layer, B = 1, S = 2048, W8A8 recipe, module API, hipGraph"
     return res
 
@@ -713,6 +715,36 @@ def bench_calibration(args, rank, world, dev):
         "cpu_baseline": None}))
 
 
+def bench_other_configs(dev):
+    """BASELINE.json configs[2] and configs[3] as module-API QLinear steps at M = 2048 (fp32 in -> quantize -> int8 GEMM -> 8-bit output
+    indices' fp32 values), hipGraph, per shape of the model's FFN / attention linears:
+      configs[2] stablelm-2-1.6B W8A8, per-channel weight grids (hidden 2048, FFN 5632);
+      configs[3] gemma-2B W4A8, packed 4-bit weights unpacked in registers in front of the int8 MFMA (hidden 2048, FFN 16384)."""
+    import mobilequant_amd as mq
+    out = {}
+    torch.manual_seed(7)
+    x = torch.randn(1, 2048, 2048, device=dev)
+    for cfg, wbits, per_channel, shapes in (("configs[2] stablelm-2-1.6B W8A8 per-channel", 8, True, (("w1/w3", 2048, 5632), ("w2", 5632, 2048), ("q/o", 2048, 2048))),
+                                            ("configs[3] gemma-2B W4A8", 4, False, (("w1/w3", 2048, 16384), ("w2", 16384, 2048), ("q/o", 2048, 2048)))):
+        rows = {}
+        for name, k, n in shapes:
+            lin = torch.nn.Linear(k, n, bias=False, device=dev)
+            a8 = mq.QuantConfig(bitwidth=8)
+            ql = mq.QLinear.from_float(lin, a8, mq.QuantConfig(bitwidth=wbits, is_per_channel=per_channel), a8).requires_grad_(False)
+            xin = x if k == 2048 else torch.randn(1, 2048, k, device=dev)
+            ql.input_quantizer.set_scale_offset_from_minmax(float(xin.min()), float(xin.max()), "buffer", dev)
+            ql.output_quantizer.set_scale_offset_from_minmax(-3.0, 3.0, "buffer", dev)
+            with torch.no_grad():
+                ql(xin)
+                t = event_time(lambda: ql(xin), 10)
+            rows[f"{name} {n}<-{k}"] = {"us": round(t * 1e6, 1), "tops": round(2.0 * 2048 * k * n / t / 1e12, 1)}
+            del ql, lin
+            torch.cuda.empty_cache()
+        out[cfg] = rows
+    out["scope"] = "QLinear.forward (quantize + int8 GEMM, fp32 out) per linear shape at M = 2048, hipGraph"
+    return out
+
+
 def bench_variants(dev, step, args):
     """The non-headline legs of the qlinear workload (rank 0): module forward, pair GEMM, decode, layer benchmarks."""
     extras = {}
@@ -739,6 +771,8 @@ def bench_variants(dev, step, args):
     torch.cuda.empty_cache()
     extras["layer_prefill"] = bench_layer(dev)
     extras["layer_prefill_full"] = bench_layer_full(dev)
+    torch.cuda.empty_cache()
+    extras["other_configs"] = bench_other_configs(dev)
     extras["_decode"] = decode
     return extras
 

@@ -446,6 +446,67 @@ __global__ void __launch_bounds__(256) gated_act_quant_kernel(const GatedArgs g)
   }
 }
 
+// Index inputs without the fp32 side output (the integer chain of fuse_gated_mlp): a WORKGROUP per row and 8 elements per thread
+// and trip, so that [2048, 5632] puts 8 waves on every SIMD instead of 2 -- the kernel is a latency-bound stream (two LDS table reads
+// and one exact divide per element), occupancy is what it lacks.  Same tables, same per-element arithmetic as the kernel above.
+__global__ void __launch_bounds__(256) gated_index_rows_kernel(const GatedArgs g) {
+  __shared__ float lut[2][256];
+  __shared__ int s_part[4];
+  const float so = g.s[4][0], oo = g.o[4][0];
+  {
+    float sc[4], of[4];
+    bool has[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      has[k] = g.s[k] != nullptr;
+      sc[k] = has[k] ? g.s[k][0] : 1.f;
+      of[k] = has[k] ? g.o[k][0] : 0.f;
+    }
+    auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
+    const float xi = nq_dequant((float)threadIdx.x, sc[0], of[0]);
+    float r;
+    if (g.act == 0) {
+      const float gate = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-xi)));
+      r = __fmul_rn(xi, fq(2, gate));
+    } else {
+      r = __fmul_rn(__fmul_rn(0.5f, xi), __fadd_rn(1.0f, erff(__fmul_rn(xi, 0.70710678118654752440f))));
+    }
+    lut[0][threadIdx.x] = fq(3, r);
+    lut[1][threadIdx.x] = nq_dequant((float)threadIdx.x, sc[1], of[1]);
+  }
+  __syncthreads();
+  const int64_t row = blockIdx.x;
+  const uint8_t* pa = reinterpret_cast<const uint8_t*>(g.a) + row * g.cols;
+  const uint8_t* pb = reinterpret_cast<const uint8_t*>(g.b) + row * g.cols;
+  int8_t* pq = g.q + row * g.cols;
+  int acc = 0;
+  for (int64_t c = (int64_t)threadIdx.x * 8; c < g.cols; c += 2048) {
+    const uint2 va = *reinterpret_cast<const uint2*>(pa + c), vb = *reinterpret_cast<const uint2*>(pb + c);
+    const uint32_t wa[2] = {va.x, va.y}, wb[2] = {vb.x, vb.y};
+    uint32_t w[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      uint32_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float prod = __fmul_rn(lut[0][(wa[d] >> (8 * e)) & 0xffu], lut[1][(wb[d] >> (8 * e)) & 0xffu]);
+        const float qi = nq_index(prod, so, oo, g.qmin[4], g.qmax[4]);
+        const int st_v = (qi != qi ? (int)g.qmin[4] : (int)qi) - g.shift;
+        acc += st_v;
+        pk |= ((uint32_t)st_v & 0xffu) << (8 * e);
+      }
+      w[d] = pk;
+    }
+    *reinterpret_cast<uint2*>(pq + c) = make_uint2(w[0], w[1]);
+  }
+  if (g.row_sum != nullptr) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) g.row_sum[row] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+  }
+}
+
 }  // namespace mq
 
 extern "C" int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows, int64_t cols, int act,
@@ -473,7 +534,9 @@ extern "C" int mq_gated_act_quant(const void* a, const void* b, int in_dtype, in
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipStream_t st = as_stream(stream);
-  if (idx) {
+  if (idx && !y && cols % 8 == 0 && rows < (int64_t)0x7fffffff && aligned(a, 8) && aligned(b, 8)) {
+    gated_index_rows_kernel<<<(unsigned)rows, 256, 0, st>>>(g);
+  } else if (idx) {
     if (y) gated_act_quant_kernel<true, true><<<(unsigned)blocks, 256, 0, st>>>(g);
     else gated_act_quant_kernel<true, false><<<(unsigned)blocks, 256, 0, st>>>(g);
   } else {
