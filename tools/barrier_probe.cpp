@@ -1,0 +1,67 @@
+// Cost of a software grid barrier on MI355X (one 1024-thread workgroup per CU, all resident): the question behind a persistent
+// per-token decode kernel.  hipcc --offload-arch=gfx950 -O2 tools/barrier_probe.cpp -o tools/barrier_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) barrier_kernel(unsigned* counter, unsigned* flag, int rounds, float* data, long long* cycles) {
+  const unsigned nb = gridDim.x;
+  unsigned epoch = 0;
+  const long long t0 = __builtin_readcyclecounter();
+  for (int r = 0; r < rounds; ++r) {
+    if (MODE >= 1) {                       // every block publishes a value the others read after the barrier
+      if (threadIdx.x == 0) data[(r & 1) * 4096 + blockIdx.x] = (float)(r + blockIdx.x);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      epoch += nb;
+      if (MODE >= 1) __threadfence();
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { *flag = 1; break; }
+      }
+      if (MODE >= 1) __threadfence();
+    }
+    __syncthreads();
+    if (MODE >= 1) {
+      const float v = data[(r & 1) * 4096 + ((blockIdx.x + 1) % nb)];
+      if (v != (float)(r + (blockIdx.x + 1) % nb) && threadIdx.x == 0) *flag = 2;
+    }
+  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = __builtin_readcyclecounter() - t0;
+}
+
+int main(int argc, char** argv) {
+  int rounds = argc > 1 ? atoi(argv[1]) : 1000;
+  hipDeviceProp_t p;
+  CK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  unsigned *counter, *flag;
+  float* data;
+  long long* cyc;
+  CK(hipMalloc(&counter, 4)); CK(hipMalloc(&flag, 4)); CK(hipMalloc(&data, 2 * 4096 * 4)); CK(hipMalloc(&cyc, 8));
+  for (int mode = 0; mode < 2; ++mode) {
+    for (int blocks : {cus, cus / 2, 64}) {
+      CK(hipMemset(counter, 0, 4)); CK(hipMemset(flag, 0, 4));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0));
+      if (mode == 0) barrier_kernel<0><<<blocks, 1024>>>(counter, flag, rounds, data, cyc);
+      else barrier_kernel<1><<<blocks, 1024>>>(counter, flag, rounds, data, cyc);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned f;
+      CK(hipMemcpy(&f, flag, 4, hipMemcpyDeviceToHost));
+      printf("mode %d (%s) blocks %3d x 1024 threads: %.3f us per barrier (flag %u)\n", mode, mode ? "publish + fences + check" : "counter only", blocks,
+             ms * 1e3 / rounds, f);
+    }
+  }
+  return 0;
+}
