@@ -903,6 +903,66 @@ def gen_decode_case():
     print("decode_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
 
 
+def gen_layer_case():
+    """The whole simulated-quant forward at BASELINE size: ONE TinyLlama-1.1B decoder layer (hidden 2048, 32 heads / 4 KV heads,
+    head_dim 64, FFN 5632 -- mobilellm/model/sim_model.py:43-44) of the REAL reference HFForCausalLM on a 2048-token sequence, W8A8
+    recipe of ptq/mobilequant.py:175-201, ranges from the reference's own get_act_range.  Weights come from
+    tests/toy_models.seeded_parameters_ (regenerated on the test side), so the fixture holds only ids, ranges, configs and the
+    logits of every 8th position over a 128-word vocabulary."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from seeded import seeded_parameters_
+    from mobilellm.model.hf_config import HFConfig
+    from mobilellm.model.hf_model import HFForCausalLM
+    S, V = 2048, 128
+    cfg = HFConfig(vocab_size=V, hidden_size=2048, intermediate_size=5632, num_hidden_layers=1, num_attention_heads=32,
+                   num_key_value_heads=4, max_position_embeddings=S, hidden_act="silu", use_matmul_as_module=True)
+    cfg._attn_implementation = "eager"
+    m = HFForCausalLM(cfg).eval()
+    seeded_parameters_(m, std=0.05, strip="model.")
+    g = torch.Generator().manual_seed(31)
+    ids = torch.randint(0, V, (1, S), generator=g)
+    calib = [torch.randint(0, V, (1, S), generator=g), ids]
+    out = {"ids": npf(ids[0])}
+    with torch.no_grad():
+        out["logits_fp"] = npf(m(ids, use_cache=False).logits[0, ::8])
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+
+    class _Tk:
+        bos_token_id, vocab_size = 1, V
+        def __call__(s_, line, return_tensors="pt", max_length=None, truncation=True):
+            return types.SimpleNamespace(input_ids=calib[int(line)])
+    _orig = m.forward
+    m.forward = lambda x_, **kw: _orig(x_, use_cache=False)
+    act = rng_mod.get_act_range(m, _Tk(), [{"text": str(i)} for i in range(len(calib))], len(calib), S)
+    m.forward = _orig
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=8), Q.QuantConfig(bitwidth=8))
+    for name, mod in m.named_modules():          # ptq/mobilequant.py:175-201
+        if isinstance(mod, Q.QLinear):
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU)))}
+    Q.set_scale_and_offset(m, act, "buffer")
+    with torch.no_grad():
+        out["logits_w8a8"] = npf(m(ids, use_cache=False).logits[0, ::8])
+    out["act"] = np.array(json.dumps(act))
+    out["qcfg"] = np.array(json.dumps(Q.export_qcfg(m)))
+    np.savez_compressed(os.path.join(OUT, "layer_case.npz"), **out)
+    d = out["logits_w8a8"] - out["logits_fp"]
+    print("layer_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
@@ -915,6 +975,7 @@ if __name__ == "__main__":
     gen_toy_lm_nll()
     gen_smooth_cases()
     gen_decode_case()
+    gen_layer_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()
     gen_nonfinite()

@@ -74,3 +74,6 @@ def apply_mixed_precision(model, Q):
                 mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name:
                 mod.input_quantizer.qcfg.bitwidth = 16
+
+
+from seeded import seeded_parameters_  # noqa: E402,F401  (standalone: oracle/gen_golden.py imports it without this package)
