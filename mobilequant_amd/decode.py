@@ -227,14 +227,37 @@ class DecodeEngine:
         return self.logits
 
     @torch.no_grad()
-    def generate(self, context_ids, max_new_tokens: int, eos_token_id=None):
-        """Greedy generation (sim_model.py:160-221 with do_sample = False): feed the context token by token, then argmax on
-        the device into self.tok; the host reads one token id per step only to test for EOS."""
+    def prefill(self, context_ids) -> torch.Tensor:
+        """Context encoding in ONE forward over the whole context (sim_model.py:176-193) instead of len(context) steps: the module
+        graph's prefill (with llama.fuse_decoder_layer: 9 launches per layer) runs with a KV cache attached, the cached keys /
+        values are put on their QMatMul input grids (what the step kernels keep in the cache) and the position is set behind the
+        context.  Returns the logits of the last context position (self.logits)."""
+        ids = torch.as_tensor([int(t) for t in context_ids], dtype=torch.long, device=self.dev).view(1, -1)
+        S = ids.shape[1]
+        assert 0 < S <= self.cache_len
+        raw = self.model.new_cache(1, S, device=self.dev)
+        logits = self.model(ids, cache=raw)
+        for li, layer in enumerate(self.model.layers):
+            att = layer.self_attn
+            self.k_cache[li][:, :S] = Q._apply(att.qk_bmm.input2_quantizer, raw[li][0][0])
+            self.v_cache[li][:, :S] = Q._apply(att.pv_bmm.input2_quantizer, raw[li][1][0])
+        self.pos.fill_(S)
+        self.logits.copy_(logits[0, -1])
+        return self.logits
+
+    @torch.no_grad()
+    def generate(self, context_ids, max_new_tokens: int, eos_token_id=None, prefill: bool = True):
+        """Greedy generation (sim_model.py:160-221 with do_sample = False): context encoding in one prefill forward (prefill=False:
+        token by token through the step kernels), then argmax on the device into self.tok; the host reads one token id per step only
+        to test for EOS."""
         ids = [int(t) for t in context_ids]
         assert len(ids) + max_new_tokens <= self.cache_len
         self.reset()
-        for t in ids:
-            self.step(t)
+        if prefill and len(ids) > 1:
+            self.prefill(ids)
+        else:
+            for t in ids:
+                self.step(t)
         out = list(ids)
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         for _ in range(max_new_tokens):

@@ -635,6 +635,25 @@ def test_decode_engine_reproduces_the_reference_model_token_by_token(dev):
     # greedy generation runs end to end and continues from the context
     out = eng.generate(ids[:8].tolist(), 6)
     assert out[:8] == ids[:8].tolist() and len(out) == 14 and all(0 <= t < 96 for t in out)
+    # context encoding in one prefill forward (sim_model.py:176-193), with and without the fused decoder-layer pass: the logits behind
+    # the context and those of the following steps stay within the same budget of the reference's
+    from mobilequant_amd import llama
+    for fused in (False, True):
+        if fused:
+            assert llama.fuse_decoder_layer(m) == 2
+        eng.reset()
+        n_ctx = 24
+        lg = eng.prefill(ids[:n_ctx].tolist()).cpu().numpy().copy()
+        assert int(eng.pos.item()) == n_ctx
+        rest = np.stack([eng.step(int(t)).cpu().numpy().copy() for t in ids[n_ctx:]])
+        got = np.concatenate([lg[None], rest])
+        want = ref[n_ctx - 1:]
+        d = np.abs(got - want)
+        assert d.max() <= 0.05 * span and np.median(d) <= 0.002 * span and (d <= 0.01 * span).mean() >= 0.97, (
+            fused, d.max() / span, np.median(d) / span, (d <= 0.01 * span).mean())
+        d2 = np.abs(got - eager[n_ctx - 1:])
+        assert d2.max() <= 0.05 * span and np.median(d2) <= 0.003 * span, (fused, d2.max() / span, np.median(d2) / span)
+    assert eng.generate(ids[:8].tolist(), 6, prefill=True)[:8] == ids[:8].tolist()
 
 
 def test_decode_gemv_modes_against_prefill_kernels(dev):
