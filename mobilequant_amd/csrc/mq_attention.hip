@@ -166,7 +166,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <bool QK_OUT>
-__global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention_args a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) attention_quant_kernel(const mq_attention_args a) {
   const int D = 64;
   const int S = a.seq, H = a.heads, KV = a.kv_heads;
   // Work per workgroup is proportional to qb + 1 (causal).  The hardware hands out workgroups in id order to whichever slot frees
@@ -208,19 +208,23 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
       t.kt[j] = *reinterpret_cast<const int4*>(kterm + kb * 64 + 16 * j + 4 * tq);
     }
   };
-  // f values of this lane's row against keys t = 64 kb + 16 j + 4 tq + e
-  auto scores = [&](const KTile& t, bool diag, int kb, float (&f)[16]) {
+  // integer scores of this lane's row against keys t = 64 kb + 16 j + 4 tq + e: sum_d (qi - zq)(ki - zk), exact (< 2^24).  After this
+  // the tile's registers are dead: the caller requests the NEXT block into the same registers, and the loads land under the ~1 000
+  // cycles of VALU work that follow (single-buffered tiles: 3 waves per SIMD fit, and they hide what is left).
+  auto int_scores = [&](const KTile& t, int (&ti)[16]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(t.kf[j], qf, cinit, 0, 0, 0);
-      const int kt[4] = {t.kt[j].x, t.kt[j].y, t.kt[j].z, t.kt[j].w};
+      ti[4 * j] = acc[0] + t.kt[j].x; ti[4 * j + 1] = acc[1] + t.kt[j].y; ti[4 * j + 2] = acc[2] + t.kt[j].z; ti[4 * j + 3] = acc[3] + t.kt[j].w;
+    }
+  };
+  // -> f: the score on its 16-bit grid in magic-number form (QK_OUT), or the score value itself
+  auto grid_scores = [&](const int (&ti)[16], bool diag, int kb, float (&f)[16]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float ti = (float)(acc[e] + kt[e]);                    // sum_d (qi - zq)(ki - zk), exact (< 2^24)
-        float v = __builtin_fmaf(ti, beta, fbias);
-        if (QK_OUT) v = __builtin_amdgcn_fmed3f(v, flo, fhi);
-        f[4 * j + e] = v;
-      }
+    for (int i = 0; i < 16; ++i) {
+      float v = __builtin_fmaf((float)ti[i], beta, fbias);
+      if (QK_OUT) v = __builtin_amdgcn_fmed3f(v, flo, fhi);
+      f[i] = v;
     }
     if (diag) {
 #pragma unroll
@@ -235,9 +239,9 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
   // exp(value - max) = exp2(f * cexp - R) with ONE fma per element: R = fl(fmax * cexp) is a per-row constant, so its rounding error
   // shifts every exponent of the row alike and cancels in e / l (softmax is shift invariant); R - R' below is exact (Sterbenz).
   float m = -INFINITY, l = 0.f, R = -INFINITY;
-  auto sweep1 = [&](const KTile& t, int kb) {
+  auto sweep1 = [&](const int (&ti)[16], int kb) {
     float f[16];
-    scores(t, kb == qb, kb, f);
+    grid_scores(ti, kb == qb, kb, f);
     float bm = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
     bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(f[8], f[9]), fmaxf(f[10], f[11])), fmaxf(fmaxf(f[12], f[13]), fmaxf(f[14], f[15]))));
     bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
@@ -254,16 +258,14 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
     R = Rn;
   };
   {
-    KTile t0, t1;                                                    // two register sets, no copies: the loop handles two blocks per trip
-    load_k(0, t0);
-    int kb = 0;
-    for (; kb + 1 < nkb; kb += 2) {
-      load_k(kb + 1, t1);
-      sweep1(t0, kb);
-      if (kb + 2 < nkb) load_k(kb + 2, t0);
-      sweep1(t1, kb + 1);
+    KTile t;
+    load_k(0, t);
+    for (int kb = 0; kb < nkb; ++kb) {
+      int ti[16];
+      int_scores(t, ti);
+      if (kb + 1 < nkb) load_k(kb + 1, t);
+      sweep1(ti, kb);
     }
-    if (kb < nkb) sweep1(t0, kb);
   }
   // p index = clamp(rint((e / l) / s_p) + z_p): g = fma(e, 1 / (l s_p), z_p + magic), index = low mantissa bits of med3(g, ...)
   const float rp = __fdiv_rn(gpa.inv_s, l);
@@ -284,10 +286,9 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) t.vf[dt] = *reinterpret_cast<const v4i*>(vt + (16 * dt + srow) * 64 + tq * 16);   // rows d, key-permuted
   };
-  auto sweep2 = [&](const KTile& t, const VTile& vt, int kb) {
+  auto probs = [&](const int (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo) {
     float f[16];
-    scores(t, kb == qb, kb, f);
-    v4i pf_hi, pf_lo;
+    grid_scores(ti, kb == qb, kb, f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned b[4];
@@ -304,30 +305,26 @@ __global__ void __launch_bounds__(256) attention_quant_kernel(const mq_attention
       pf_lo[j] = (int)(lo ^ 0x80808080u);
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
-      acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
-      acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], ones, acc_v[dt], 0, 0, 0);
-    }
   };
   {
-    KTile t0, t1;
-    VTile v0, v1;
-    load_k(0, t0);
-    load_v(0, v0);
-    int kb = 0;
-    for (; kb + 1 < nkb; kb += 2) {
-      load_k(kb + 1, t1);
-      load_v(kb + 1, v1);
-      sweep2(t0, v0, kb);
-      if (kb + 2 < nkb) {
-        load_k(kb + 2, t0);
-        load_v(kb + 2, v0);
+    KTile t;
+    VTile vt;
+    load_k(0, t);
+    load_v(0, vt);
+    for (int kb = 0; kb < nkb; ++kb) {
+      int ti[16];
+      int_scores(t, ti);
+      if (kb + 1 < nkb) load_k(kb + 1, t);
+      v4i pf_hi, pf_lo;
+      probs(ti, kb, pf_hi, pf_lo);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
+        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
+        acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], ones, acc_v[dt], 0, 0, 0);
       }
-      sweep2(t1, v1, kb + 1);
+      if (kb + 1 < nkb) load_v(kb + 1, vt);
     }
-    if (kb < nkb) sweep2(t0, v0, kb);
   }
   long long psum = 256ll * psum_hi + psum_lo;
   psum += __shfl_xor(psum, 16, 64);
