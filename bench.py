@@ -715,6 +715,72 @@ def bench_calibration(args, rank, world, dev):
         "cpu_baseline": None}))
 
 
+def bench_model_prefill(dev):
+    """The whole simulated-quant forward the reference's eval / PTQ loops run (harness_eval, ptq/mobilequant.py): TinyLlama-1.1B shape,
+    22 layers, vocab 32000, ONE 2048-token sequence, W8A8 recipe, ranges from this package's calibration pass over the fp32 model
+    (random-init weights).  tokens/s with (a) llama.fuse_decoder_layer (9 launches per layer) and (b) every fused mode off (the HIP
+    fake-quant kernels around library GEMMs, module by module).  embed_tokens, the final norm and the fp32 lm_head over all 2048
+    positions are inside the timed region in both."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import get_act_range
+    from mobilequant_amd.quantization import qmodule as Q
+    S = 2048
+    shape = llama.LlamaShape.tinyllama(max_pos=S)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=1337, std=0.03)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, shape.vocab, (1, S), generator=g).to(dev)
+    with torch.no_grad():
+        act = get_act_range(model, [ids])
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(model, a8, a8)
+    for name, mod in model.named_modules():                 # ptq/mobilequant.py:175-201
+        if isinstance(mod, mq.QLinear) and "w2" in name:
+            mod.weight_quantizer.qcfg.is_per_channel = True
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QLinear) and "o_proj" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QMatMul) and "qk_bmm" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QMatMul) and "pv_bmm" in name:
+            mod.input_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(model, act, "buffer")
+    mq.wire_integer_inputs(model)
+    res = {}
+
+    def set_mode(off):
+        for m in model.modules():
+            if hasattr(m, "fused_mode") or isinstance(m, (llama.DecoderLayer, llama.Attention, llama.MLP)):
+                m.fused_mode = "off" if off else "auto"
+            if isinstance(m, mq.QLinear):
+                m.int8_mode = "off" if off else "auto"
+
+    def fwd():
+        Q._shared_activation.clear()
+        with torch.no_grad():
+            return model(ids)
+    set_mode(True)
+    fwd()
+    t_sim = event_time(fwd, 1)
+    set_mode(False)
+    llama.fuse_decoder_layer(model)
+    fwd()
+    t_fused = event_time(fwd, 2)
+    res["fused_ms"], res["simulated_ms"] = round(t_fused * 1e3, 3), round(t_sim * 1e3, 3)
+    res["fused_tokens_per_s"], res["simulated_tokens_per_s"] = round(S / t_fused), round(S / t_sim)
+    res["speedup"] = round(t_sim / t_fused, 2)
+    res["scope"] = ("TinyLlama-1.1B shape (22 layers, vocab 32000), one 2048-token sequence, W8A8 recipe, module API, hipGraph; 'simulated' = "
+                    "the reference's execution model on this GPU (fake-quant kernels around fp32 library GEMMs, every module on its own)")
+    del model
+    torch.cuda.empty_cache()
+    return res
+
+
 def bench_other_configs(dev):
     """BASELINE.json configs[2] and configs[3] as module-API QLinear steps at M = 2048 (fp32 in -> quantize -> int8 GEMM -> 8-bit output
     indices' fp32 values), hipGraph, per shape of the model's FFN / attention linears:
@@ -773,6 +839,8 @@ def bench_variants(dev, step, args):
     extras["layer_prefill_full"] = bench_layer_full(dev)
     torch.cuda.empty_cache()
     extras["other_configs"] = bench_other_configs(dev)
+    torch.cuda.empty_cache()
+    extras["model_prefill"] = bench_model_prefill(dev)
     extras["_decode"] = decode
     return extras
 
