@@ -258,6 +258,24 @@ def event_time(fn, iters):
     return best * 1e-3
 
 
+def cold_time(fn, flush_bytes=768 << 20, reps=10):
+    """Average duration of `fn` with the operand caches flushed in front of every launch (the L2-flushing variant): a
+    768 MiB fill (3x the 256 MB Infinity Cache, far beyond the 8 x 4 MB L2s) precedes each launch inside one hipGraph; the same graph
+    without `fn` is subtracted.  Best of 5 for both."""
+    buf = torch.empty(flush_bytes, dtype=torch.uint8, device="cuda")
+
+    def both():
+        buf.fill_(1)
+        fn()
+
+    def flush_only():
+        buf.fill_(1)
+    t_both = event_time(both, reps)
+    t_flush = event_time(flush_only, reps)
+    del buf
+    return max(t_both - t_flush, 0.0)
+
+
 def pmc_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r02/pmc_fetch + pmc_write; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
@@ -888,11 +906,15 @@ def main():
             t_gemm = event_time(step.gemm, 50)
             t_quant = event_time(lambda: step.quantize(0), 50)
             achieved = OPS_PER_STEP / t_gemm / 1e12
+            t_cold = cold_time(step.gemm)
             traffic, traffic_src = pmc_traffic()
             roof = {"bound": "mfma", "kernel": ("mq::gemm_i8_fr_kernel (mq_w8a8_linear_tiled: free-running whole-kernel gfx950 ISA, fragment-blocked "
                                                 "activations)" if step.tiled else "mq::gemm_i8_kernel (mq_w8a8_linear)"), "achieved": round(achieved, 1),
                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOPS", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
-                    "avg_launch_us": round(t_gemm * 1e6, 2), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "avg_launch_us": round(t_gemm * 1e6, 2),
+                    "cold_caches": {"avg_launch_us": round(t_cold * 1e6, 2), "frac": round(OPS_PER_STEP / t_cold / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                    "how": "768 MiB fill in front of every launch in one hipGraph, minus the same graph without the GEMM"},
+                    "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": M * K + N * K + M * N,
                     "algorithmic_ops_per_launch": OPS_PER_STEP,
                     "notes": "MFMA busy 22 528 cycles per SIMD of ~31 k wave cycles; the chip clocks ~1.8 GHz under this load (s_memtime / "
