@@ -859,6 +859,8 @@ def bench_variants(dev, step, args):
     extras["other_configs"] = bench_other_configs(dev)
     torch.cuda.empty_cache()
     extras["model_prefill"] = bench_model_prefill(dev)
+    torch.cuda.empty_cache()
+    extras["calibration_reductions"] = bench_minmax(dev, 2048)      # HBM GB/s of the min / max kernels
     extras["_decode"] = decode
     return extras
 
