@@ -66,9 +66,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   const int part = blockIdx.y;                       // [0, H): q head; [H, H+KV): k head; [H+KV, H+2KV): v head
   const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
   const int s = blockIdx.x * 64 + r;
-  __shared__ int s_rs[64];
   __shared__ int8_t s_v[64][64 + 4];
-  if (threadIdx.x < 64) s_rs[threadIdx.x] = 0;
   if (a.out_i8 != nullptr && blockIdx.y == 0 && threadIdx.x < 64 && (int)(blockIdx.x * 64 + threadIdx.x) < a.seq_real)
     a.out_rowsum[a.out_row0 + blockIdx.x * 64 + threadIdx.x] = 0;          // the core kernel accumulates one share per head
   __syncthreads();
