@@ -1127,9 +1127,12 @@ def _gated_mlp_forward(self, x, resid=None):
     if not (w1._int8_ready(x, wt1) and w3._int8_ready(x, wt3) and wt1.shape == wt3.shape):
         return plain(x)
     M, (N, K) = x.numel() // x.shape[-1], wt1.shape
-    if not (_u8_grid(w1.output_quantizer) and _u8_grid(w3.output_quantizer) and _u8_grid(w2.input_quantizer)
-            and ops.gemm_tiled_supported(M, N, K) and K >= 768 and K % 256 == 0 and N % 16 == 0):
+    if not (_u8_grid(w1.output_quantizer) and _u8_grid(w3.output_quantizer) and _u8_grid(w2.input_quantizer) and N % 16 == 0 and M > 8):
         return plain(x)
+    # ONE pair launch of the free-running kernel where it applies (int8 weights, N % 176 == 0, >= 192 tiles); every other shape or a
+    # 4-bit weight (Gemma's FFN, small batches, W4A8 recipes) runs w1 and w3 as two GEMMs writing indices -- the rest of the chain is
+    # the same
+    pair = ops.gemm_tiled_supported(M, N, K) and K >= 768 and K % 256 == 0
     silu = isinstance(act, QSiLU)
     act_in = act.input_quantizer
     if act_in is not None and not act_in.bypassed():
@@ -1148,9 +1151,13 @@ def _gated_mlp_forward(self, x, resid=None):
             or (oq2 is not None and not oq2.bypassed() and not _static_per_tensor(oq2, 16))
             or _needs_grad(wt2, w2.bias, getattr(wq2, "scale", None))):
         return plain(x)
-    grid, a_q, a_rs, a_shift, tiled_rows, _ = w1._input_image(x, wt1)
-    if tiled_rows is None:
+    grid, a_q, a_rs, a_shift, tiled_rows, decode = w1._input_image(x, wt1)
+    if decode:
         return plain(x)
+    any_w4 = w1._weight_plan(wt1)["w4"] or w3._weight_plan(wt3)["w4"]
+    if any_w4 and tiled_rows is not None:
+        return plain(x)                     # (a 4-bit sibling of an int8 linear that chose the fragment-blocked image: not a real recipe)
+    pair = pair and tiled_rows is not None and not any_w4
     halves = []
     for m, wt in ((w1, wt1), (w3, wt3)):
         plan = m._epilogue_vectors(m._weight_plan(wt), grid, a_shift, K)
@@ -1160,7 +1167,13 @@ def _gated_mlp_forward(self, x, resid=None):
         halves.append(dict(w=plan["w"], alpha=plan["alpha"], w_zp=plan["w_zp"], col_term=plan["col_term"],
                            bias=m.temp_bias if m.use_temporary_parameter else m.bias, out_scale=oq.scale.detach(),
                            out_offset=oq.offset.detach()))
-    a_idx, b_idx = ops.int8_linear_pair(a_q, M, a_rs, halves[0], halves[1], out_dtype=MQ_U8)
+    if pair:
+        a_idx, b_idx = ops.int8_linear_pair(a_q, M, a_rs, halves[0], halves[1], out_dtype=MQ_U8)
+    else:
+        a_idx, b_idx = (ops.int8_linear(a_q, h["w"], a_rs, h["alpha"], h["w_zp"], h["col_term"], h["bias"], out_scale=h["out_scale"],
+                                        out_offset=h["out_offset"], out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8, w4=m._weight_plan(wt)["w4"],
+                                        a_tiled_rows=tiled_rows)
+                        for h, (m, wt) in zip(halves, ((w1, wt1), (w3, wt3))))
     iq2 = w2.input_quantizer
     for q in (iq2, act.output_quantizer, act.input2_quantizer if silu else None):
         if q is not None and not q.bypassed() and q.scale.device != x.device:

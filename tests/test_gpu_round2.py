@@ -1028,3 +1028,48 @@ def test_baseline_sized_layer_against_the_reference_model(dev):
         assert mx <= 0.5 * quant_noise and med <= 1e-4 and share >= 0.95, (name, res[name], quant_noise)
     d = np.abs(fused - chain) / span
     assert d.max() <= 0.5 * quant_noise and np.median(d) <= 1e-4, (float(d.max()), float(np.median(d)))
+
+
+@pytest.mark.parametrize("wbits,rows,hidden,ffn", [(4, 512, 256, 1024), (8, 300, 256, 512), (4, 2048, 2048, 16384)])
+def test_fused_gated_mlp_generalised_shapes_and_w4(dev, wbits, rows, hidden, ffn):
+    """fuse_gated_mlp beyond the pair kernel's shapes: packed 4-bit weights (the reference's W4A8 recipes), FFN widths that are no
+    multiple of 176 (Gemma: 16384) and small batches run w1 / w3 as two index-writing GEMMs, then the same gated kernel and w2 GEMM.
+    Bit-identical to the chain of modules on their integer paths, with and without the residual."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import ops
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            a8, w = mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=wbits, is_per_channel=wbits == 4)
+            mk = lambda k, n: mq.QLinear.from_float(torch.nn.Linear(k, n, bias=False).to(dev), a8, w, a8)      # noqa: E731
+            self.w1, self.w3, self.w2 = mk(hidden, ffn), mk(hidden, ffn), mk(ffn, hidden)
+            self.w1.input_quantizer = self.w3.input_quantizer = None
+            self.act_fn = mq.QSiLU(None, a8, a8)
+
+        def forward(self, x):
+            return self.w2(self.act_fn(self.w1(x)) * self.w3(x))
+    torch.manual_seed(wbits + rows)
+    m = MLP().requires_grad_(False)
+    x = torch.randn(1, rows, hidden, device=dev)
+    xq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+    xq.set_scale_offset_from_minmax(float(x.min()), float(x.max()), "buffer", dev)
+    with torch.no_grad():
+        x = xq(x)                                           # a tagged activation on an 8-bit grid, as the norm would leave it
+        m.w1.set_scale_offset({"output": [-2.0, 2.0]}, "buffer"); m.w3.set_scale_offset({"output": [-2.0, 2.0]}, "buffer")
+        m.act_fn.set_scale_offset({"output": [-0.3, 2.0]}, "buffer")
+        m.w2.set_scale_offset({"input": [-3.0, 3.0], "output": [-3.0, 3.0]}, "buffer")
+        chain = m(x)
+        assert mq.fuse_gated_mlp(m) == 1
+        calls = []
+        real_pair, real_gate = ops.int8_linear_pair, ops.gated_act_quant
+        ops.int8_linear_pair = lambda *a, **k: (calls.append("pair"), real_pair(*a, **k))[1]
+        ops.gated_act_quant = lambda *a, **k: (calls.append("gate"), real_gate(*a, **k))[1]
+        try:
+            fused = m(x)
+            r = torch.randn_like(chain)
+            with_resid = m(x, resid=r)
+        finally:
+            ops.int8_linear_pair, ops.gated_act_quant = real_pair, real_gate
+    assert calls == ["gate", "gate"]                        # no pair kernel here, but the fused chain ran
+    assert torch.equal(fused, chain) and torch.equal(with_resid, r + chain)
