@@ -347,7 +347,7 @@ int mq_decode_head(const float* x, const float* norm_weight, float eps, const fl
  * Scratch (caller-owned, overwritten): q_i8 [heads][seq][D], k_i8 [kv_heads][seq][D], vt_i8 [kv_heads][seq/64][D][64] (values
  * transposed, keys permuted inside each 64-block), q_rowsum [heads][seq], k_rowsum [kv_heads][seq] (the zero-point terms of the integer
  * q.k^T, derived from the row sums of the images).
- * Limits: head_dim == 64, seq % 64 == 0.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
+ * Limits: head_dim == 64, seq % 64 == 0, seq <= 65536.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
 /* q | k | v (or any 1..3 linears reading one activation) as ONE int8 GEMM whose column segments carry their own 8-bit unsigned
  * output grids: weights / epilogue vectors concatenated along N, segment i = columns [seg_end[i-1], seg_end[i]) (seg_end[-1] = 0,
  * seg_end[n_segments-1] = N, multiples of 4) quantised on grids[i]; out = uint8 indices [M, N] -- per column exactly the index
