@@ -342,7 +342,7 @@ def cpu_baseline():
                                 "mixed-precision rules of ptq/mobilequant.py:175-201) at S=2048"}}
 
 
-def bench_decode_full(dev, context=256, steps=64):
+def bench_decode_full(dev, context=256, steps=64, wbits=8):
     """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
     model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
     one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
@@ -360,7 +360,7 @@ def bench_decode_full(dev, context=256, steps=64):
     calib = [torch.randint(3, shape.vocab, (1, 256), generator=g) for _ in range(2)]
     act = get_act_range(model, calib)
     a8 = mq.QuantConfig(bitwidth=8)
-    mq.create_sim_qmodel(model, a8, a8)
+    mq.create_sim_qmodel(model, a8 if wbits == 8 else mq.QuantConfig(bitwidth=wbits, is_per_channel=True), a8)
     for name, mod in model.named_modules():               # ptq/mobilequant.py:175-201
         if isinstance(mod, mq.QLinear):
             if "w2" in name:
@@ -408,7 +408,7 @@ def bench_decode_full(dev, context=256, steps=64):
             "kv_cache_GB_per_token": round(kv_bytes / 1e9, 4), "achieved_GBps": round(total / t / 1e9, 1),
             "weight_stream_GBps": round(eng.weight_bytes / t / 1e9, 1), "peak_GBps": 8000.0, "frac_of_hbm_peak": round(total / t / 8e12, 4),
             "kernels_per_token": len(eng.phases) + 2,
-            "scope": "FULL decode step, TinyLlama-1.1B shape, W8A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, 22 x "
+            "scope": f"FULL decode step, TinyLlama-1.1B shape, W{wbits}A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, 22 x "
                      "[norm+qkv, attention over the static KV cache, o_proj+residual, norm+w1|w3+SiLU*mul+quantize, w2+residual], final "
                      "norm + fp32 lm_head; batch 1, one hipGraph per token"}
 
@@ -848,6 +848,9 @@ def bench_variants(dev, step, args):
                                     "note": "QLinear.forward from Python, eager (includes host launch overhead)"}
     extras["ffn_pair_gemm"] = bench_pair(step)
     decode = bench_decode_full(dev)
+    torch.cuda.empty_cache()
+    w4 = bench_decode_full(dev, wbits=4)                    # the reference's deployment mode: packed 4-bit per-channel weights
+    decode["full_step_w4a8"] = {k: w4[k] for k in ("decode_tok_s", "ms_per_token", "int8_weight_GB_per_token", "weight_stream_GBps", "scope")}
     torch.cuda.empty_cache()
     decode["linears_only_w8a8"] = bench_decode_linears(dev)
     torch.cuda.empty_cache()

@@ -311,6 +311,8 @@ typedef struct mq_decode_gemv_args {
   int gate_act;
   mq_grid gate_mid, gate_actout, gate_out;
   int8_t* gate_q;
+  int w4; /* 1: w holds packed unsigned nibbles [N, K/2] (mq_pack_w4; gate mode: rows 2i / 2i+1 interleaved alike), w_zp / col_term in
+           * the unsigned-nibble domain as for mq_w4a8_linear -- the reference's W4A8 deployment mode */
 } mq_decode_gemv_args;
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream);
 

@@ -33,7 +33,7 @@ class MqDecodeGemvArgs(ctypes.Structure):
                 ("eps", c_float), ("a_grid", MqGrid), ("w", c_void_p), ("alpha", c_void_p), ("w_zp", c_void_p),
                 ("col_term", c_void_p), ("bias", c_void_p), ("seg_end", c_int * 2), ("out_grid", MqGrid * 3),
                 ("resid", c_void_p), ("y", c_void_p), ("gate_act", c_int), ("gate_mid", MqGrid), ("gate_actout", MqGrid),
-                ("gate_out", MqGrid), ("gate_q", c_void_p)]
+                ("gate_out", MqGrid), ("gate_q", c_void_p), ("w4", c_int)]
 
 
 class MqDecodeAttentionArgs(ctypes.Structure):

@@ -79,7 +79,10 @@ __device__ __forceinline__ float wave_max_f(float v) {
 constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 8;
 
 // GATE: a logical row r is the weight-row pair (2r, 2r+1) = (w1 row r, w3 row r), 2K contiguous bytes.
-template <bool GATE>
+// W4: weight rows hold packed unsigned nibbles (mq_pack_w4: K/2 bytes; a 16-byte group = 32 consecutive k, element j in the low and
+//     j + 16 in the high nibble of byte j): unpacked in registers, two dot products per loaded chunk; w_zp / col_term are in the
+//     unsigned-nibble domain as for mq_w4a8_linear.
+template <bool GATE, bool W4>
 __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode_gemv_args g, const int rows_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [K] int8 activation image, then scratch
   __shared__ float s_red[DG_WAVES];
@@ -89,7 +92,8 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = g.K;
   const int NL = GATE ? g.N >> 1 : g.N;                            // logical rows
-  const int kchunks = K >> 4;                                      // 16-byte chunks per weight row
+  const int kchunks = W4 ? K >> 5 : K >> 4;                        // 16-byte chunks per weight row
+  const int wrow = W4 ? K >> 1 : K;                                // bytes per weight row
   const int lchunks = GATE ? 2 * kchunks : kchunks;                // chunks per logical row
   const int cpl = (lchunks + 63) >> 6;
   const int row0 = blockIdx.x * rows_per_wg + wave;
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       const int row = row0 + DG_WAVES * t;
       const int c = lane + 64 * j;
       if (row < row_end && c < lchunks)
-        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * (GATE ? 2 : 1) * K) + c);
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * (GATE ? 2 : 1) * wrow) + c);
       else
         buf[u] = v4i{0, 0, 0, 0};
       if (++j == cpl) { j = 0; ++t; }
@@ -216,9 +220,21 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         int c = lane + 64 * j2;
         c = c < lchunks ? c : lchunks - 1;                       // buf[u] is zero there
         const int ck = GATE ? (c >= kchunks ? c - kchunks : c) : c;
-        const v4i av = *reinterpret_cast<const v4i*>(smem + (size_t)ck * 16);
-        if (GATE && c >= kchunks) acc1 = dot16(buf[u], av, acc1);
-        else acc0 = dot16(buf[u], av, acc0);
+        int part;
+        if constexpr (W4) {
+          const v4i a_lo = *reinterpret_cast<const v4i*>(smem + (size_t)ck * 32), a_hi = *reinterpret_cast<const v4i*>(smem + (size_t)ck * 32 + 16);
+          v4i w_lo, w_hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            w_lo[e] = buf[u][e] & 0x0f0f0f0f;
+            w_hi[e] = (int)(((unsigned)buf[u][e] >> 4) & 0x0f0f0f0fu);
+          }
+          part = dot16(w_hi, a_hi, dot16(w_lo, a_lo, 0));
+        } else {
+          part = dot16(buf[u], *reinterpret_cast<const v4i*>(smem + (size_t)ck * 16), 0);
+        }
+        if (GATE && c >= kchunks) acc1 += part;
+        else acc0 += part;
         if (j2 == cpl - 1) {                                     // logical row slot t2 complete
           const int s0 = wave_sum_dpp(acc0), s1 = GATE ? wave_sum_dpp(acc1) : 0;
           acc0 = acc1 = 0;
@@ -488,8 +504,13 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   const unsigned grid = (unsigned)((NL + rows_per_wg - 1) / rows_per_wg);
   const size_t lds = (size_t)g.K + 64;
   hipStream_t st = as_stream(stream);
-  if (gate) decode_gemv_kernel<true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
-  else decode_gemv_kernel<false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+  if (g.w4) {
+    if (gate) decode_gemv_kernel<true, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+    else decode_gemv_kernel<false, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+  } else {
+    if (gate) decode_gemv_kernel<true, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+    else decode_gemv_kernel<false, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+  }
   MQ_LAUNCH_CHECK("mq_decode_gemv");
   return MQ_OK;
 }

@@ -45,10 +45,14 @@ class _Linear:
 
     def __init__(self, linears: List[Q.QLinear], a_grid: Q.Quantizer, interleave: bool = False):
         ws, alphas, zps, cts, biases = [], [], [], [], []
+        bits = {lin.weight_quantizer.qcfg.bitwidth if lin.weight_quantizer is not None else None for lin in linears}
+        if len(bits) != 1 or not bits <= {4, 8}:
+            raise RuntimeError("DecodeEngine: the linears of one phase need the same 8- or 4-bit weight quantizer width")
+        self.w4 = bits == {4}
         for lin in linears:
-            if lin.weight_quantizer is None or lin.weight_quantizer.qcfg.bitwidth != 8:
-                raise RuntimeError("DecodeEngine: 8-bit weight quantizers only")
             K = lin.weight.shape[1]
+            if self.w4 and K % 64:
+                raise RuntimeError("DecodeEngine: packed 4-bit weights need K % 64 == 0")
             plan = lin._epilogue_vectors(lin._weight_plan(lin.weight), a_grid, 128, K)
             ws.append(plan["w"]); alphas.append(plan["alpha"].clone()); zps.append(plan["w_zp"].clone()); cts.append(plan["col_term"].clone())
             biases.append(lin.bias.detach().float() if lin.bias is not None else None)
@@ -60,7 +64,7 @@ class _Linear:
         if any(b is not None for b in biases):
             self.bias = cat([b if b is not None else torch.zeros(l.weight.shape[0], device=l.weight.device)
                              for b, l in zip(biases, linears)]).contiguous()
-        self.N, self.K = self.w.shape
+        self.N, self.K = self.w.shape[0], linears[0].weight.shape[1]
         self.rows = [l.weight.shape[0] for l in linears]
 
 
@@ -119,7 +123,8 @@ class DecodeEngine:
         a.seg_end[0] = a.seg_end[1] = lin.N
         for k, v in fields.items():
             setattr(a, k, v)
-        a._mq_bytes = lin.N * lin.K
+        a.w4 = int(lin.w4)
+        a._mq_bytes = lin.N * lin.K // (2 if lin.w4 else 1)
         self._keep.append(lin)
         return a
 

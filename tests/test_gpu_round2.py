@@ -1073,3 +1073,35 @@ def test_fused_gated_mlp_generalised_shapes_and_w4(dev, wbits, rows, hidden, ffn
             ops.int8_linear_pair, ops.gated_act_quant = real_pair, real_gate
     assert calls == ["gate", "gate"]                        # no pair kernel here, but the fused chain ran
     assert torch.equal(fused, chain) and torch.equal(with_resid, r + chain)
+
+
+def test_decode_engine_w4a8_matches_module_graph(dev):
+    """The reference's deployment mode: packed 4-bit per-channel weights, 8-bit activations.  mq_decode_gemv unpacks the nibbles in
+    registers (all five phases, incl. the interleaved w1|w3 gate phase); the engine must agree with this package's own module-graph
+    forward (mq_w4a8_linear GEMMs) on a random-init model calibrated by this package, eagerly and from the captured graph."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.calibration import get_act_range
+    from mobilequant_amd.decode import DecodeEngine
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    from toy_models import apply_mixed_precision
+    m = LlamaForCausalLM(LlamaShape(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=64, max_pos=64))
+    m.reset_parameters(seed=6, std=0.08)
+    m = m.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 64, (1, 24), generator=g)
+    act = get_act_range(m, [ids, torch.randint(0, 64, (1, 24), generator=g)])
+    mq.create_sim_qmodel(m, mq.QuantConfig(bitwidth=4, is_per_channel=True), mq.QuantConfig(bitwidth=8))
+    apply_mixed_precision(m, mq)
+    mq.set_scale_and_offset(m, act, "buffer")
+    with torch.no_grad():
+        want = m(ids.to(dev))[0].cpu().numpy()
+    eng = DecodeEngine(m, cache_len=64)
+    assert all(p[1].w4 == 1 for p in eng.phases if p[0] == "gemv")
+    got = np.stack([eng.step(int(t)).cpu().numpy().copy() for t in ids[0]])
+    eng.reset()
+    eng.capture()
+    replay = np.stack([eng.step(int(t)).cpu().numpy().copy() for t in ids[0]])
+    assert np.array_equal(got, replay)
+    span = float(np.ptp(want))
+    d = np.abs(got - want)
+    assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span and (d <= 0.01 * span).mean() >= 0.97, (d.max() / span, np.median(d) / span)
