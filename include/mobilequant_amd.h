@@ -358,6 +358,11 @@ int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_
                              const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
                              const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream);
 
+/* the same for packed 4-bit weights (mq_pack_w4 layout, w_zp / col_term in the unsigned-nibble domain as for mq_w4a8_linear) */
+int mq_w4a8_linear_segmented(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                             const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                             const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream);
+
 typedef struct mq_attention_args {
   const float* q;
   const float* k;

@@ -1100,14 +1100,14 @@ int mq_w8a8_linear_residual(const int8_t* a, const int8_t* w, int64_t M, int64_t
   return run_gemm<false>(g, as_stream(stream));
 }
 
-int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
-                             const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
-                             const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream) {
-  const char* fn = "mq_w8a8_linear_segmented";
+static int linear_segmented(const char* fn, bool w4, const int8_t* a, const void* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                            const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                            const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream) {
   MQ_REQUIRE(n_segments >= 1 && n_segments <= 3 && seg_end != nullptr && grids != nullptr, "%s: 1..3 segments", fn);
-  int rc = check_common(fn, a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset, out, 1);
+  int rc = check_common(fn, a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset, out, w4 ? 2 : 1);
   if (rc != MQ_OK) return rc;
   MQ_REQUIRE(M > 8, "%s: M > 8 (decode shapes: mq_decode_gemv)", fn);
+  MQ_REQUIRE(!w4 || K % 64 == 0, "%s: packed 4-bit weights need K %% 64 == 0", fn);
   int64_t prev = 0;
   for (int i = 0; i < n_segments; ++i) {
     MQ_REQUIRE(grids[i].scale && grids[i].offset && grids[i].qmin == 0.f && grids[i].qmax == 255.f,
@@ -1123,7 +1123,21 @@ int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_
     g.seg_scale[i - 1] = grids[i].scale;
     g.seg_offset[i - 1] = grids[i].offset;
   }
-  return run_gemm<false>(g, as_stream(stream));
+  return w4 ? run_gemm<true>(g, as_stream(stream)) : run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                             const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                             const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream) {
+  return linear_segmented("mq_w8a8_linear_segmented", false, a, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, n_segments, seg_end, grids,
+                          out, stream);
+}
+
+int mq_w4a8_linear_segmented(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                             const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                             const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream) {
+  return linear_segmented("mq_w4a8_linear_segmented", true, a, w_packed, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, n_segments, seg_end,
+                          grids, out, stream);
 }
 
 int mq_gemm_tiled_supported(int64_t M, int64_t N, int64_t K) { return gemm_tiled_supported(M, N, K) ? 1 : 0; }

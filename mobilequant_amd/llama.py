@@ -174,7 +174,7 @@ def _qkv_indices(self, x):
                and Q._u8_grid(m.output_quantizer) for m in lins):
         return None
     ws = [m._effective_weight(m.weight) for m in lins]
-    if not all(m._int8_ready(x, w) and m.weight_quantizer.qcfg.bitwidth == 8 for m, w in zip(lins, ws)):
+    if not all(m._int8_ready(x, w) for m, w in zip(lins, ws)) or len({m.weight_quantizer.qcfg.bitwidth for m in lins}) != 1:
         return None
     grids_in = [m._activation_grid(x) for m in lins]
     if any(g.grid_token() != grids_in[0].grid_token() for g in grids_in) or x.numel() // x.shape[-1] <= 8:
@@ -203,7 +203,8 @@ def _qkv_indices(self, x):
         if oq.scale.device != x.device:
             oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
         out_grids.append((oq.scale.detach(), oq.offset.detach()))
-    idx = ops.int8_linear_segmented(a_q, cat["w"], a_rs, cat["alpha"], cat["w_zp"], cat["col_term"], cat["bias"], ends, out_grids)
+    idx = ops.int8_linear_segmented(a_q, cat["w"], a_rs, cat["alpha"], cat["w_zp"], cat["col_term"], cat["bias"], ends, out_grids,
+                                    w4=plans[0]["w4"])
     return idx, out_grids
 
 

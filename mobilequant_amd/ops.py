@@ -269,10 +269,10 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
 
 
 def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.Tensor, alpha: torch.Tensor, w_zp: torch.Tensor,
-                          col_term: torch.Tensor, bias: Optional[torch.Tensor], seg_ends, grids) -> torch.Tensor:
+                          col_term: torch.Tensor, bias: Optional[torch.Tensor], seg_ends, grids, w4: bool = False) -> torch.Tensor:
     """1..3 linears reading one row-major int8 activation as ONE GEMM (mq_w8a8_linear_segmented): w_q / alpha / w_zp / col_term /
     bias concatenated along N, seg_ends = cumulative column ends, grids[i] = (scale, offset) of segment i's 8-bit unsigned output
-    grid.  Returns the uint8 output indices [M, N]."""
+    grid.  Returns the uint8 output indices [M, N].  w4: w_q holds packed nibbles [N, K/2] (pack_w4)."""
     _dev(a_q, "a_q"); _dev(w_q, "w_q")
     M, K = a_q.shape
     N = w_q.shape[0]
@@ -286,7 +286,7 @@ def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.
         keep += [sc, of]
         gs[i] = _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0)
     with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, out, *keep):
-        _lib.call("mq_w8a8_linear_segmented", a_q.data_ptr(), w_q.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
+        _lib.call("mq_w4a8_linear_segmented" if w4 else "mq_w8a8_linear_segmented", a_q.data_ptr(), w_q.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
                   alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(), b.data_ptr() if b is not None else None, n, ends, gs,
                   out.data_ptr(), _stream())
     return out

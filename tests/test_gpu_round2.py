@@ -954,7 +954,7 @@ def test_segmented_gemm_equals_the_three_linears(dev):
     import mobilequant_amd as mq
     from mobilequant_amd import ops
     from mobilequant_amd._lib import MQ_I8, MQ_U8
-    for M, K, Ns in ((2048, 2048, (2048, 256, 256)), (200, 256, (64, 128, 36))):
+    for M, K, Ns, wbits in ((2048, 2048, (2048, 256, 256), 8), (200, 256, (64, 128, 36), 8), (512, 512, (256, 64, 64), 4)):
         g = torch.Generator(device="cpu").manual_seed(M)
         x = torch.randn(M, K, generator=g).to(dev)
         aq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
@@ -964,21 +964,26 @@ def test_segmented_gemm_equals_the_three_linears(dev):
         for i, N in enumerate(Ns):
             w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
             bias = (torch.randn(N, generator=g) * 0.1).to(dev)
-            wq = mq.Quantizer(mq.QuantConfig(bitwidth=8, is_per_channel=(i == 1)))
+            wq = mq.Quantizer(mq.QuantConfig(bitwidth=wbits, is_per_channel=(i == 1)))
             wq(w)
-            w8, colsum, wshift = wq.quantize_to_int(w, MQ_I8, want_row_sum=True, rows=N)
+            if wbits == 4:      # unsigned nibbles (index - qmin), packed two per byte (QLinear._weight_plan)
+                qn, colsum = ops.quantize(w, wq.scale.detach(), wq.offset.detach(), wq.qmin, wq.qmax, q_dtype=MQ_U8, shift=wq.qmin, rows=N,
+                                          want_row_sum=True)
+                w8, wshift = ops.pack_w4(qn), wq.qmin
+            else:
+                w8, colsum, wshift = wq.quantize_to_int(w, MQ_I8, want_row_sum=True, rows=N)
             alpha, wzp, ct = ops.linear_epilogue_prepare(aq.scale, aq.offset, a_shift, wq.scale.detach(), wq.offset.detach(), wshift, colsum, K)
             y = torch.nn.functional.linear(x, w, bias)
             oq = mq.Quantizer(mq.QuantConfig(bitwidth=8))
             oq.set_scale_offset_from_minmax(float(y.min()) * (0.7 + 0.2 * i), float(y.max()) * (0.7 + 0.2 * i), "buffer", dev)
             singles.append(ops.int8_linear(a_q, w8, a_rs, alpha, wzp, ct, bias, out_scale=oq.scale, out_offset=oq.offset, out_qmin=0.0,
-                                           out_qmax=255.0, out_dtype=MQ_U8))
+                                           out_qmax=255.0, out_dtype=MQ_U8, w4=wbits == 4))
             parts.append((w8, alpha, wzp, ct, bias))
             grids.append((oq.scale, oq.offset))
         cat = [torch.cat([p[j] for p in parts]) for j in range(5)]
         ends = np.cumsum(Ns).tolist()
-        got = ops.int8_linear_segmented(a_q, cat[0], a_rs, cat[1], cat[2], cat[3], cat[4], ends, grids)
-        assert got.dtype == torch.uint8 and torch.equal(got, torch.cat(singles, dim=1)), (M, K, Ns)
+        got = ops.int8_linear_segmented(a_q, cat[0], a_rs, cat[1], cat[2], cat[3], cat[4], ends, grids, w4=wbits == 4)
+        assert got.dtype == torch.uint8 and torch.equal(got, torch.cat(singles, dim=1)), (M, K, Ns, wbits)
 
 
 def _layer_case_model(dev):
@@ -1105,3 +1110,17 @@ def test_decode_engine_w4a8_matches_module_graph(dev):
     span = float(np.ptp(want))
     d = np.abs(got - want)
     assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span and (d <= 0.01 * span).mean() >= 0.97, (d.max() / span, np.median(d) / span)
+    # the fused prefill passes on the same W4A8 model: q|k|v as one segmented W4 GEMM, w1 / w3 as two index-writing W4 GEMMs
+    from mobilequant_amd import llama, ops
+    seg = []
+    real_seg = ops.int8_linear_segmented
+    ops.int8_linear_segmented = lambda *a, **k: (seg.append(k.get("w4")), real_seg(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            assert llama.fuse_decoder_layer(m) == 2
+            fused = m(ids.to(dev))[0].cpu().numpy()
+    finally:
+        ops.int8_linear_segmented = real_seg
+    assert seg == [True, True]
+    d = np.abs(fused - want)
+    assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span, (d.max() / span, np.median(d) / span)
