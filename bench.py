@@ -552,7 +552,7 @@ def bench_layer(dev):
     return res
 
 
-def bench_layer_full(dev, modes=("fused", "attention_chain", "composite")):
+def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits=8):
     """ONE whole TinyLlama decoder layer at prefill (B = 1, S = 2048) on the reference's module graph (mobilequant_amd/llama.py:
     norms, q/k/v/o, RoPE, qk_bmm / pv_bmm QMatMuls, softmax, gated FFN, residual adds), W8A8 recipe of ptq/mobilequant.py:175-201,
     ranges from this package's own calibration pass over the fp32 layer.  hipGraph time with (a) everything fused (fuse_attention:
@@ -572,7 +572,7 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite")):
     with torch.no_grad():
         act = get_act_range(model, [ids])
     a8 = mq.QuantConfig(bitwidth=8)
-    mq.create_sim_qmodel(model, a8, a8)
+    mq.create_sim_qmodel(model, a8 if wbits == 8 else mq.QuantConfig(bitwidth=wbits, is_per_channel=True), a8)
     for name, mod in model.named_modules():                 # ptq/mobilequant.py:175-201
         if isinstance(mod, mq.QLinear) and "w2" in name:
             mod.weight_quantizer.qcfg.is_per_channel = True
@@ -633,8 +633,8 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite")):
     if "fused_us" in res:
         res["tops_fused"] = round((ops_lin + ops_att) / (res["fused_us"] * 1e-6) / 1e12, 1)
         res["frac_of_int8_peak"] = round(res["tops_fused"] / INT8_MFMA_PEAK_TOPS, 4)
-        res["launches_per_layer"] = 9
-    res["scope"] = "one whole TinyLlama decoder layer, B = 1, S = 2048, W8A8 recipe, module API, hipGraph"
+        res["launches_per_layer"] = 9 if wbits == 8 else 10
+    res["scope"] = f"one whole TinyLlama decoder layer, B = 1, S = 2048, W{wbits}A8 recipe, module API, hipGraph"
     return res
 
 
@@ -858,6 +858,8 @@ def bench_variants(dev, step, args):
     torch.cuda.empty_cache()
     extras["layer_prefill"] = bench_layer(dev)
     extras["layer_prefill_full"] = bench_layer_full(dev)
+    torch.cuda.empty_cache()
+    extras["layer_prefill_full_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4)     # packed 4-bit per-channel weights
     torch.cuda.empty_cache()
     extras["other_configs"] = bench_other_configs(dev)
     torch.cuda.empty_cache()
