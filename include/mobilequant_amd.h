@@ -274,6 +274,17 @@ int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows,
                        float out_qmin, float out_qmax, int q_shift, int8_t* q_out, int32_t* row_sum,
                        float* y, mq_stream_t stream);
 
+/* The same map as a table: with index inputs and static grids, act(a) * b -> w2's input index is a function of the two 8-bit
+ * indices.  mq_gated_table evaluates mq_gated_act_quant's per-element arithmetic for all 65 536 (ia, ib) pairs -> table[ia * 256 + ib]
+ * (int8 storage, index - q_shift; build once per set of grids); mq_gated_lookup then maps index tensors [rows, cols] (cols % 8 == 0)
+ * to the int8 image + row sums with one LDS byte read per element -- bit-identical to mq_gated_act_quant by construction. */
+int mq_gated_table(int act, const float* a_scale, const float* a_offset, const float* b_scale, const float* b_offset,
+                   const float* mid_scale, const float* mid_offset, float mid_qmin, float mid_qmax, const float* act_scale,
+                   const float* act_offset, float act_qmin, float act_qmax, const float* out_scale, const float* out_offset,
+                   float out_qmin, float out_qmax, int q_shift, int8_t* table, mq_stream_t stream);
+int mq_gated_lookup(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_out,
+                    int32_t* row_sum, mq_stream_t stream);
+
 /* ---- f2: single-token decode step (mobilellm/model/sim_model.py:160-221 on the quantized module graph) -------------------- */
 /* A per-tensor quantizer grid on the device: scale / offset point at 1 float each; scale == NULL means "no quantizer here". */
 typedef struct mq_grid {

@@ -507,7 +507,156 @@ __global__ void __launch_bounds__(256) gated_index_rows_kernel(const GatedArgs g
   }
 }
 
+// ---- the same map as a 256 x 256 table --------------------------------------------------------------------------------------------
+// With index inputs and static grids, act(a) * b -> w2's input index is a FUNCTION of the two 8-bit indices: 65 536 values, computed
+// once per set of grids (mq_gated_table: the per-element arithmetic of the kernels above, evaluated for every (ia, ib) pair -- the
+// table IS that arithmetic, so results are bit-identical) and then looked up (mq_gated_lookup): one LDS byte read per element instead
+// of two table reads, a multiply and an IEEE divide.  The lookup kernel is a pure stream (2 B in, 1 B out per element).
+__global__ void __launch_bounds__(256) gated_table_kernel(const GatedArgs g, int8_t* __restrict__ table) {
+  float sc[5], of[5];
+  bool has[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    has[k] = g.s[k] != nullptr;
+    sc[k] = has[k] ? g.s[k][0] : 1.f;
+    of[k] = has[k] ? g.o[k][0] : 0.f;
+  }
+  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
+  const int ia = blockIdx.x, ib = threadIdx.x;
+  const float xi = nq_dequant((float)ia, sc[0], of[0]);
+  float r;
+  if (g.act == 0) {
+    const float gate = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-xi)));
+    r = __fmul_rn(xi, fq(2, gate));
+  } else {
+    r = __fmul_rn(__fmul_rn(0.5f, xi), __fadd_rn(1.0f, erff(__fmul_rn(xi, 0.70710678118654752440f))));
+  }
+  const float prod = __fmul_rn(fq(3, r), nq_dequant((float)ib, sc[1], of[1]));
+  const float qi = nq_index(prod, sc[4], of[4], g.qmin[4], g.qmax[4]);
+  table[ia * 256 + ib] = (int8_t)((qi != qi ? (int)g.qmin[4] : (int)qi) - g.shift);
+}
+
+constexpr int GL_TABLE = 65536;
+// 1024 threads = four groups of four waves; a group owns one row at a time (rows strided by 4 * gridDim), requests the whole row up
+// front (<= 4 x 8 bytes per lane and operand), then looks up.  Two such workgroups are resident per CU (2 x 64 KiB of LDS): 8 waves
+// per SIMD, and at [2048, 5632] every group handles exactly one row -- the kernel is one round of loads, lookups and stores.
+__global__ void __launch_bounds__(1024) gated_lookup_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int64_t rows, int64_t cols,
+                                                            const int8_t* __restrict__ table, int8_t* __restrict__ q, int32_t* __restrict__ row_sum) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lut[];      // [256][256]
+  __shared__ int s_sum[4];
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  constexpr int MAXIT = 4;                                          // cols <= 8192 on the fast path (host-checked); longer rows loop
+  const int64_t row0 = (int64_t)blockIdx.x * 4 + grp;
+  uint2 va[MAXIT], vb[MAXIT];
+  const bool fast = cols <= 2048 * MAXIT;
+  if (fast && row0 < rows) {                                        // first row's operands go out before the table copy
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int64_t c = (int64_t)tid * 8 + 2048 * it;
+      if (c < cols) {
+        va[it] = *reinterpret_cast<const uint2*>(a + row0 * cols + c);
+        vb[it] = *reinterpret_cast<const uint2*>(b + row0 * cols + c);
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < GL_TABLE / 16; i += 1024) reinterpret_cast<uint4*>(lut)[i] = reinterpret_cast<const uint4*>(table)[i];
+  __syncthreads();
+  auto convert = [&](uint2 x, uint2 y, int& acc) {
+    const uint32_t wa[2] = {x.x, x.y}, wb[2] = {y.x, y.y};
+    uint32_t w[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      uint32_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int st_v = lut[(((wa[d] >> (8 * e)) & 0xffu) << 8) | ((wb[d] >> (8 * e)) & 0xffu)];
+        acc += st_v;
+        pk |= ((uint32_t)st_v & 0xffu) << (8 * e);
+      }
+      w[d] = pk;
+    }
+    return make_uint2(w[0], w[1]);
+  };
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < rows; base += stride) {      // uniform trip count for the whole workgroup
+    const int64_t row = base + grp;
+    int acc = 0;
+    if (row < rows) {
+      if (fast) {
+        if (base != (int64_t)blockIdx.x * 4) {
+#pragma unroll
+          for (int it = 0; it < MAXIT; ++it) {
+            const int64_t c = (int64_t)tid * 8 + 2048 * it;
+            if (c < cols) {
+              va[it] = *reinterpret_cast<const uint2*>(a + row * cols + c);
+              vb[it] = *reinterpret_cast<const uint2*>(b + row * cols + c);
+            }
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+          const int64_t c = (int64_t)tid * 8 + 2048 * it;
+          if (c < cols) *reinterpret_cast<uint2*>(q + row * cols + c) = convert(va[it], vb[it], acc);
+        }
+      } else {
+        for (int64_t c = (int64_t)tid * 8; c < cols; c += 2048)
+          *reinterpret_cast<uint2*>(q + row * cols + c) =
+              convert(*reinterpret_cast<const uint2*>(a + row * cols + c), *reinterpret_cast<const uint2*>(b + row * cols + c), acc);
+      }
+    }
+    if (row_sum != nullptr) {
+      if (tid < 1) s_sum[grp] = 0;
+      __syncthreads();
+      acc = wave_sum(acc);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum[grp], acc);
+      __syncthreads();
+      if (tid == 0 && row < rows) row_sum[row] = s_sum[grp];
+    }
+  }
+}
+
 }  // namespace mq
+
+extern "C" int mq_gated_table(int act, const float* a_scale, const float* a_offset, const float* b_scale, const float* b_offset,
+                              const float* mid_scale, const float* mid_offset, float mid_qmin, float mid_qmax, const float* act_scale,
+                              const float* act_offset, float act_qmin, float act_qmax, const float* out_scale, const float* out_offset,
+                              float out_qmin, float out_qmax, int q_shift, int8_t* table, mq_stream_t stream) {
+  using namespace mq;
+  MQ_REQUIRE((act == 0 || act == 1) && a_scale && a_offset && b_scale && b_offset && out_scale && out_offset && table,
+             "mq_gated_table: null pointer / bad act (0 SiLU, 1 GELU)");
+  MQ_REQUIRE((mid_scale == nullptr) == (mid_offset == nullptr) && (act_scale == nullptr) == (act_offset == nullptr),
+             "mq_gated_table: scale/offset must both be set or NULL");
+  MQ_REQUIRE(out_qmin - (float)q_shift >= -128.f && out_qmax - (float)q_shift <= 127.f, "mq_gated_table: output grid does not fit int8");
+  GatedArgs g{nullptr, nullptr, 1, 0, 0, act, {a_scale, b_scale, mid_scale, act_scale, out_scale}, {a_offset, b_offset, mid_offset, act_offset, out_offset},
+              {0.f, 0.f, mid_qmin, act_qmin, out_qmin}, {0.f, 0.f, mid_qmax, act_qmax, out_qmax}, q_shift, nullptr, nullptr, nullptr};
+  gated_table_kernel<<<256, 256, 0, as_stream(stream)>>>(g, table);
+  MQ_LAUNCH_CHECK("mq_gated_table");
+  return MQ_OK;
+}
+
+extern "C" int mq_gated_lookup(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_out,
+                               int32_t* row_sum, mq_stream_t stream) {
+  using namespace mq;
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && cols % 8 == 0, "mq_gated_lookup: cols %% 8 == 0");
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(a && b && table && q_out && aligned(a, 8) && aligned(b, 8) && aligned(q_out, 8) && aligned(table, 16),
+             "mq_gated_lookup: null or misaligned pointer");
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gated_lookup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GL_TABLE);
+    if (e != hipSuccess) {
+      set_error("mq_gated_lookup: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  int64_t blocks = (rows + 3) / 4;                          // four rows per workgroup and trip; two resident workgroups per CU
+  if (blocks > 512) blocks = 512;
+  gated_lookup_kernel<<<(unsigned)blocks, 1024, GL_TABLE, as_stream(stream)>>>(a, b, rows, cols, table, q_out, row_sum);
+  MQ_LAUNCH_CHECK("mq_gated_lookup");
+  return MQ_OK;
+}
 
 extern "C" int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows, int64_t cols, int act,
                                   const float* a_scale, const float* a_offset, const float* b_scale, const float* b_offset,

@@ -456,6 +456,37 @@ def gated_act_quant(a: torch.Tensor, b: torch.Tensor, act: str, out_grid, *, a_g
     return (q, rs, y) if want_y else (q, rs)
 
 
+def gated_table(act: str, out_grid, a_grid, b_grid, mid_grid=None, act_grid=None, q_shift: int = 128) -> torch.Tensor:
+    """The 256 x 256 table of gated_act_quant on index inputs (mq_gated_table): int8 [65536], entry [ia * 256 + ib]."""
+    dev = out_grid[0].device
+    table = torch.empty(65536, dtype=torch.int8, device=dev)
+    ptrs, keep = [], []
+    for g, with_limits in ((a_grid, False), (b_grid, False), (mid_grid, True), (act_grid, True), (out_grid, True)):
+        if g is None:
+            ptrs += [None, None] + ([0.0, 0.0] if with_limits else [])
+        else:
+            s, o = _f32(g[0], "scale"), _f32(g[1], "offset")
+            keep += [s, o]
+            ptrs += [s.data_ptr(), o.data_ptr()] + ([float(g[2]), float(g[3])] if with_limits else [])
+    with _on(table, *keep):
+        _lib.call("mq_gated_table", {"silu": 0, "gelu": 1}[act], *ptrs, int(q_shift), table.data_ptr(), _stream())
+    return table
+
+
+def gated_lookup(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor):
+    """uint8 index tensors a, b [rows, cols] -> (int8 image, row sums) through a gated_table (mq_gated_lookup)."""
+    a, b = _dev(a, "a").contiguous(), _dev(b, "b").contiguous()
+    if a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.shape != b.shape or table.dtype != torch.int8 or table.numel() != 65536:
+        raise RuntimeError("mobilequant_amd: gated_lookup needs two uint8 tensors of one shape and an int8 [65536] table")
+    cols = a.shape[-1]
+    rows = a.numel() // max(cols, 1)
+    q = torch.empty(a.shape, dtype=torch.int8, device=a.device)
+    rs = torch.empty(rows, dtype=torch.int32, device=a.device)
+    with _on(a, b, table):
+        _lib.call("mq_gated_lookup", a.data_ptr(), b.data_ptr(), rows, cols, table.data_ptr(), q.data_ptr(), rs.data_ptr(), _stream())
+    return q, rs
+
+
 def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
                     heads: int, kv_heads: int, grids: dict, image=None, want_out: bool = True, qkv_idx=None):
     """Quantized causal prefill attention of ONE sequence (mq_attention_quant): q [S, heads*64], k / v [S, kv_heads*64] fp32

@@ -1179,11 +1179,25 @@ def _gated_mlp_forward(self, x, resid=None):
         if q is not None and not q.bypassed() and q.scale.device != x.device:
             q.scale.data, q.offset.data = q.scale.to(x.device), q.offset.to(x.device)
     o1, o3 = w1.output_quantizer, w3.output_quantizer
-    p_q, p_rs = ops.gated_act_quant(a_idx, b_idx, "silu" if silu else "gelu",
-                                    (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),
-                                    a_grid=(o1.scale.detach(), o1.offset.detach()), b_grid=(o3.scale.detach(), o3.offset.detach()),
-                                    mid_grid=QRMSNorm._grid_or_none(act.input2_quantizer) if silu else None,
+    if N % 8 == 0 and getattr(self, "gated_table", True):
+        # static grids: act(a) * b -> index is a function of the two 8-bit indices -- a 64 KiB table built once per set of grids
+        mid_q = act.input2_quantizer if silu else None
+        key = ("silu" if silu else "gelu",) + tuple(None if q is None or q.bypassed() else q.grid_token()
+                                                    for q in (o1, o3, mid_q, act.output_quantizer, iq2))
+        cached = getattr(self, "_gated_lut", None)
+        if cached is None or cached[0] != key or cached[1].device != x.device:
+            table = ops.gated_table(key[0], (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),
+                                    (o1.scale.detach(), o1.offset.detach()), (o3.scale.detach(), o3.offset.detach()),
+                                    mid_grid=QRMSNorm._grid_or_none(mid_q) if silu else None,
                                     act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
+            cached = self._gated_lut = (key, table)
+        p_q, p_rs = ops.gated_lookup(a_idx, b_idx, cached[1])
+    else:
+        p_q, p_rs = ops.gated_act_quant(a_idx, b_idx, "silu" if silu else "gelu",
+                                        (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),
+                                        a_grid=(o1.scale.detach(), o1.offset.detach()), b_grid=(o3.scale.detach(), o3.offset.detach()),
+                                        mid_grid=QRMSNorm._grid_or_none(act.input2_quantizer) if silu else None,
+                                        act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
     return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q.view(M, N), p_rs, 128,
                                None, lead_shape=x.shape[:-1], resid=resid)
 

@@ -515,15 +515,19 @@ def test_fused_gated_mlp_equals_module_chain(dev, act):
         a_fp, b_fp = m.w1(x), m.w3(x)                       # fake-quantised fp32 outputs of the integer path
         assert mq.fuse_gated_mlp(m) == 1 and mq.fuse_gated_mlp(m) == 0
         calls = []
-        real_pair, real_gate = ops.int8_linear_pair, ops.gated_act_quant
+        real_pair, real_gate, real_look = ops.int8_linear_pair, ops.gated_act_quant, ops.gated_lookup
         ops.int8_linear_pair = lambda *a, **k: (calls.append("pair"), real_pair(*a, **k))[1]
         ops.gated_act_quant = lambda *a, **k: (calls.append("gate"), real_gate(*a, **k))[1]
+        ops.gated_lookup = lambda *a, **k: (calls.append("lookup"), real_look(*a, **k))[1]
         try:
-            fused = m(x)
+            fused = m(x)                                    # the gated step through its 256 x 256 table (built on first use)
+            m.gated_table = False
+            fused_kernel = m(x)                             # ... and through the per-element kernel
+            m.gated_table = True
         finally:
-            ops.int8_linear_pair, ops.gated_act_quant = real_pair, real_gate
-        assert calls == ["pair", "gate"]
-        assert torch.equal(fused, chain)
+            ops.int8_linear_pair, ops.gated_act_quant, ops.gated_lookup = real_pair, real_gate, real_look
+        assert calls == ["pair", "lookup", "pair", "gate"]
+        assert torch.equal(fused, chain) and torch.equal(fused_kernel, chain)
         # the residual variant (llama.fuse_decoder_layer): resid + mlp(x) with the add inside w2's GEMM store
         r = torch.randn_like(chain)
         seen = []
@@ -1067,15 +1071,15 @@ def test_fused_gated_mlp_generalised_shapes_and_w4(dev, wbits, rows, hidden, ffn
         chain = m(x)
         assert mq.fuse_gated_mlp(m) == 1
         calls = []
-        real_pair, real_gate = ops.int8_linear_pair, ops.gated_act_quant
+        real_pair, real_look = ops.int8_linear_pair, ops.gated_lookup
         ops.int8_linear_pair = lambda *a, **k: (calls.append("pair"), real_pair(*a, **k))[1]
-        ops.gated_act_quant = lambda *a, **k: (calls.append("gate"), real_gate(*a, **k))[1]
+        ops.gated_lookup = lambda *a, **k: (calls.append("gate"), real_look(*a, **k))[1]
         try:
             fused = m(x)
             r = torch.randn_like(chain)
             with_resid = m(x, resid=r)
         finally:
-            ops.int8_linear_pair, ops.gated_act_quant = real_pair, real_gate
+            ops.int8_linear_pair, ops.gated_lookup = real_pair, real_look
     assert calls == ["gate", "gate"]                        # no pair kernel here, but the fused chain ran
     assert torch.equal(fused, chain) and torch.equal(with_resid, r + chain)
 
@@ -1124,3 +1128,28 @@ def test_decode_engine_w4a8_matches_module_graph(dev):
     assert seg == [True, True]
     d = np.abs(fused - want)
     assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span, (d.max() / span, np.median(d) / span)
+
+
+@pytest.mark.parametrize("act", ["silu", "gelu"])
+def test_gated_table_is_the_gated_kernel_for_every_index_pair(dev, act):
+    """mq_gated_table / mq_gated_lookup against mq_gated_act_quant on ALL 65 536 (ia, ib) pairs (and a ragged-width random tensor): the
+    table is the kernel's arithmetic evaluated once per pair, so images and row sums are identical."""
+    from mobilequant_amd import ops
+    import mobilequant_amd as mq
+
+    def grid(lo, hi):
+        q = mq.Quantizer(mq.QuantConfig(bitwidth=8))
+        q.set_scale_offset_from_minmax(lo, hi, "buffer", dev)
+        return (q.scale.detach(), q.offset.detach(), q.qmin, q.qmax)
+    ga, gb, gmid, gact, gout = grid(-3.0, 2.5), grid(-2.0, 3.0), grid(0.0, 1.0), grid(-0.3, 2.5), grid(-4.0, 5.0)
+    mid = gmid if act == "silu" else None
+    table = ops.gated_table(act, gout, ga[:2], gb[:2], mid_grid=mid, act_grid=gact, q_shift=128)
+    ia = torch.arange(256, device=dev, dtype=torch.uint8).view(256, 1).expand(256, 256).contiguous()
+    ib = torch.arange(256, device=dev, dtype=torch.uint8).view(1, 256).expand(256, 256).contiguous()
+    for a_idx, b_idx in ((ia, ib), (torch.randint(0, 256, (37, 1008), device=dev, dtype=torch.uint8),
+                                    torch.randint(0, 256, (37, 1008), device=dev, dtype=torch.uint8))):
+        want_q, want_rs = ops.gated_act_quant(a_idx, b_idx, act, gout, a_grid=ga[:2], b_grid=gb[:2], mid_grid=mid, act_grid=gact, q_shift=128)
+        got_q, got_rs = ops.gated_lookup(a_idx, b_idx, table)
+        assert torch.equal(got_q, want_q) and torch.equal(got_rs, want_rs)
+    assert torch.equal(table.view(256, 256), ops.gated_act_quant(ia, ib, act, gout, a_grid=ga[:2], b_grid=gb[:2], mid_grid=mid, act_grid=gact,
+                                                                 q_shift=128)[0])
