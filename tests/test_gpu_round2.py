@@ -883,6 +883,9 @@ def test_fuse_attention_longer_prefill_with_cache(dev):
         assert torch.equal(whole, fused)
         m.layers[0].fused_mode = "off"
         assert torch.equal(m(ids, cache=m.new_cache(2, 256, device=dev)), fused)
+        m.layers[0].fused_mode = "auto"
+    with torch.inference_mode():                         # inference tensors have no version counter: every cache key must cope
+        assert torch.equal(m(ids), whole)
     assert torch.equal(c0[0][0], c1[0][0]) and torch.equal(c0[0][1], c1[0][1])      # layer 0: same inputs -> same cache
     span = float(base.max() - base.min())
     d = (fused - base).abs()
