@@ -1,3 +1,4 @@
+"""Random-shape fuzz of mq_attention_quant against the oracle (test infrastructure; run by hand on an MI355X: python tests/fuzz_attention.py)."""
 import sys, numpy as np, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from oracle import mq_oracle as O
