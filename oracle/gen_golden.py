@@ -903,6 +903,63 @@ def gen_decode_case():
     print("decode_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
 
 
+def gen_decode_case_w4():
+    """The reference's deployment recipe on the 2-layer model of gen_decode_case: packed-4-bit-style weights (4-bit per-channel
+    asymmetric, as experiments/w4a8/main/e2e_llama-s1024-ep60.sh:23), 8-bit activations, mixed-precision rules of
+    ptq/mobilequant.py:175-201.  Weights from tests/seeded.py (not stored); logits of the REAL HFForCausalLM at every position."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from seeded import seeded_parameters_
+    from mobilellm.model.hf_config import HFConfig
+    from mobilellm.model.hf_model import HFForCausalLM
+    cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                   num_key_value_heads=2, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
+    cfg._attn_implementation = "eager"
+    m = HFForCausalLM(cfg).eval()
+    seeded_parameters_(m, std=0.08, strip="model.")
+    g = torch.Generator().manual_seed(18)
+    ids = torch.randint(0, 96, (1, 40), generator=g)
+    calib = [torch.randint(0, 96, (1, 40), generator=g) for _ in range(4)] + [ids]
+    out = {"ids": npf(ids[0])}
+    with torch.no_grad():
+        out["logits_fp"] = npf(m(ids, use_cache=False).logits)
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+
+    class _Tk:
+        bos_token_id, vocab_size = 1, 96
+        def __call__(s_, line, return_tensors="pt", max_length=None, truncation=True):
+            return types.SimpleNamespace(input_ids=calib[int(line)])
+    _orig = m.forward
+    m.forward = lambda x_, **kw: _orig(x_, use_cache=False)
+    act = rng_mod.get_act_range(m, _Tk(), [{"text": str(i)} for i in range(len(calib))], len(calib), 64)
+    m.forward = _orig
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=4, is_per_channel=True), Q.QuantConfig(bitwidth=8))
+    for name, mod in m.named_modules():          # ptq/mobilequant.py:175-201
+        if isinstance(mod, Q.QLinear):
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU)))}
+    Q.set_scale_and_offset(m, act, "buffer")
+    with torch.no_grad():
+        out["logits_w4a8"] = npf(m(ids, use_cache=False).logits)
+    out["act"] = np.array(json.dumps(act))
+    out["qcfg"] = np.array(json.dumps(Q.export_qcfg(m)))
+    np.savez_compressed(os.path.join(OUT, "decode_case_w4.npz"), **out)
+    d = out["logits_w4a8"] - out["logits_fp"]
+    print("decode_case_w4: logits", out["logits_w4a8"].shape, "max |w4a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
+
+
 def gen_layer_case():
     """The whole simulated-quant forward at BASELINE size: ONE TinyLlama-1.1B decoder layer (hidden 2048, 32 heads / 4 KV heads,
     head_dim 64, FFN 5632 -- mobilellm/model/sim_model.py:43-44) of the REAL reference HFForCausalLM on a 2048-token sequence, W8A8
@@ -975,6 +1032,7 @@ if __name__ == "__main__":
     gen_toy_lm_nll()
     gen_smooth_cases()
     gen_decode_case()
+    gen_decode_case_w4()
     gen_layer_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()

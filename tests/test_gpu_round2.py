@@ -1156,3 +1156,40 @@ def test_gated_table_is_the_gated_kernel_for_every_index_pair(dev, act):
         assert torch.equal(got_q, want_q) and torch.equal(got_rs, want_rs)
     assert torch.equal(table.view(256, 256), ops.gated_act_quant(ia, ib, act, gout, a_grid=ga[:2], b_grid=gb[:2], mid_grid=mid, act_grid=gact,
                                                                  q_shift=128)[0])
+
+
+def test_w4a8_recipe_against_the_reference_model(dev):
+    """The reference's W4A8 deployment recipe (4-bit per-channel weights, 8-bit activations) on the 2-layer model, against the logits of
+    the reference's REAL HFForCausalLM (tests/golden/decode_case_w4.npz; weights regenerated from tests/seeded.py): the module graph on
+    the W4 integer GEMMs, the fused prefill passes (segmented W4 q|k|v, two-GEMM gated MLP) and the W4 decode engine token by token."""
+    import json
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    from mobilequant_amd import llama
+    from mobilequant_amd.decode import DecodeEngine
+    from seeded import seeded_parameters_
+    z = load_npz("decode_case_w4.npz")
+    m = llama.LlamaForCausalLM(llama.LlamaShape(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=96, eps=1e-5, max_pos=64)).eval()
+    seeded_parameters_(m, std=0.08)
+    m = m.to(dev)
+    strip = lambda d: {(k[len("model."):] if k.startswith("model.") else k): v for k, v in d.items()}      # noqa: E731
+    mq.create_sim_qmodel(m, mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8))
+    mq.update_qcfg(m, strip(json.loads(str(z["qcfg"]))))
+    mq.set_scale_and_offset(m, strip(json.loads(str(z["act"]))), "buffer")
+    mq.wire_integer_inputs(m)
+    m.requires_grad_(False)
+    assert all(mod.weight_quantizer.qcfg.bitwidth == 4 for mod in m.modules() if isinstance(mod, mq.QLinear))
+    ids = torch.from_numpy(z["ids"]).long()
+    ref, span = z["logits_w4a8"][0], float(np.ptp(z["logits_fp"]))
+    noise = float(np.abs(z["logits_w4a8"] - z["logits_fp"]).max()) / span
+    assert noise > 0.1                                   # 4-bit weights move these logits a lot: the bar below is 1/10 of that
+    with torch.no_grad():
+        chain = m(ids[None].to(dev))[0].cpu().numpy()
+    eng = DecodeEngine(m, cache_len=64)
+    steps = np.stack([eng.step(int(t)).cpu().numpy().copy() for t in ids])
+    with torch.no_grad():
+        assert llama.fuse_decoder_layer(m) == 2
+        fused = m(ids[None].to(dev))[0].cpu().numpy()
+    for name, got in (("chain", chain), ("decode", steps), ("fused", fused)):
+        d = np.abs(got - ref) / span
+        assert d.max() <= 0.1 * noise + 0.02 and np.median(d) <= 0.002, (name, float(d.max()), float(np.median(d)), noise)
