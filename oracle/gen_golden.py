@@ -903,7 +903,7 @@ def gen_decode_case():
     print("decode_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
 
 
-def gen_decode_case_w4():
+def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2):
     """The reference's deployment recipe on the 2-layer model of gen_decode_case: packed-4-bit-style weights (4-bit per-channel
     asymmetric, as experiments/w4a8/main/e2e_llama-s1024-ep60.sh:23), 8-bit activations, mixed-precision rules of
     ptq/mobilequant.py:175-201.  Weights from tests/seeded.py (not stored); logits of the REAL HFForCausalLM at every position."""
@@ -912,7 +912,7 @@ def gen_decode_case_w4():
     from mobilellm.model.hf_config import HFConfig
     from mobilellm.model.hf_model import HFForCausalLM
     cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
-                   num_key_value_heads=2, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
+                   num_key_value_heads=kv_heads, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
     cfg._attn_implementation = "eager"
     m = HFForCausalLM(cfg).eval()
     seeded_parameters_(m, std=0.08, strip="model.")
@@ -933,7 +933,7 @@ def gen_decode_case_w4():
     m.forward = lambda x_, **kw: _orig(x_, use_cache=False)
     act = rng_mod.get_act_range(m, _Tk(), [{"text": str(i)} for i in range(len(calib))], len(calib), 64)
     m.forward = _orig
-    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=4, is_per_channel=True), Q.QuantConfig(bitwidth=8))
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=wbits, is_per_channel=True), Q.QuantConfig(bitwidth=8))
     for name, mod in m.named_modules():          # ptq/mobilequant.py:175-201
         if isinstance(mod, Q.QLinear):
             if "w2" in name:
@@ -952,12 +952,17 @@ def gen_decode_case_w4():
     act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU)))}
     Q.set_scale_and_offset(m, act, "buffer")
     with torch.no_grad():
-        out["logits_w4a8"] = npf(m(ids, use_cache=False).logits)
+        out["logits_w4a8"] = npf(m(ids, use_cache=False).logits)      # (key kept for every variant: the quantised logits)
     out["act"] = np.array(json.dumps(act))
     out["qcfg"] = np.array(json.dumps(Q.export_qcfg(m)))
-    np.savez_compressed(os.path.join(OUT, "decode_case_w4.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"decode_case_{tag}.npz"), **out)
     d = out["logits_w4a8"] - out["logits_fp"]
-    print("decode_case_w4: logits", out["logits_w4a8"].shape, "max |w4a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
+    print(f"decode_case_{tag}: logits", out["logits_w4a8"].shape, "max |quantised - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
+
+
+def gen_decode_case_w8pc_mha():
+    """configs[2]-style recipe on the same graph: 8-bit PER-CHANNEL weights everywhere, and full multi-head attention (4 / 4 heads)."""
+    gen_decode_case_w4(tag="w8pc_mha", wbits=8, kv_heads=4)
 
 
 def gen_layer_case():
@@ -1033,6 +1038,7 @@ if __name__ == "__main__":
     gen_smooth_cases()
     gen_decode_case()
     gen_decode_case_w4()
+    gen_decode_case_w8pc_mha()
     gen_layer_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()
