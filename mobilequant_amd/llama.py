@@ -34,6 +34,7 @@ class LlamaShape:
     eps: float = 1e-5
     rope_theta: float = 10000.0
     max_pos: int = 2048
+    hidden_act: str = "silu"            # "silu" (llama: SwiGLU) | "gelu" (gemma-style GeGLU, erf form: transformers' ACT2FN["gelu"])
 
     @classmethod
     def tinyllama(cls, **kw) -> "LlamaShape":
@@ -262,7 +263,7 @@ class MLP(nn.Module):
         self.w1 = nn.Linear(s.hidden, s.ffn, bias=False)
         self.w2 = nn.Linear(s.ffn, s.hidden, bias=False)
         self.w3 = nn.Linear(s.hidden, s.ffn, bias=False)
-        self.act_fn = nn.SiLU()
+        self.act_fn = nn.SiLU() if s.hidden_act == "silu" else nn.GELU()
 
     def forward(self, x):      # hf_model.py:1057
         return self.w2(self.act_fn(self.w1(x)) * self.w3(x))

@@ -903,7 +903,7 @@ def gen_decode_case():
     print("decode_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
 
 
-def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2):
+def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2, act="silu"):
     """The reference's deployment recipe on the 2-layer model of gen_decode_case: packed-4-bit-style weights (4-bit per-channel
     asymmetric, as experiments/w4a8/main/e2e_llama-s1024-ep60.sh:23), 8-bit activations, mixed-precision rules of
     ptq/mobilequant.py:175-201.  Weights from tests/seeded.py (not stored); logits of the REAL HFForCausalLM at every position."""
@@ -912,7 +912,7 @@ def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2):
     from mobilellm.model.hf_config import HFConfig
     from mobilellm.model.hf_model import HFForCausalLM
     cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
-                   num_key_value_heads=kv_heads, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
+                   num_key_value_heads=kv_heads, max_position_embeddings=64, hidden_act=act, use_matmul_as_module=True)
     cfg._attn_implementation = "eager"
     m = HFForCausalLM(cfg).eval()
     seeded_parameters_(m, std=0.08, strip="model.")
@@ -949,7 +949,7 @@ def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2):
                 mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name:
                 mod.input_quantizer.qcfg.bitwidth = 16
-    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU)))}
+    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU, Q.QGELU)))}
     Q.set_scale_and_offset(m, act, "buffer")
     with torch.no_grad():
         out["logits_w4a8"] = npf(m(ids, use_cache=False).logits)      # (key kept for every variant: the quantised logits)
@@ -963,6 +963,11 @@ def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2):
 def gen_decode_case_w8pc_mha():
     """configs[2]-style recipe on the same graph: 8-bit PER-CHANNEL weights everywhere, and full multi-head attention (4 / 4 heads)."""
     gen_decode_case_w4(tag="w8pc_mha", wbits=8, kv_heads=4)
+
+
+def gen_decode_case_gelu():
+    """Gemma-style gated MLP (GeGLU: act_fn = GELU -> QGELU, qmodule.py:756-798, :856) with multi-query attention (4 / 1 heads), W4A8."""
+    gen_decode_case_w4(tag="w4_geglu_mqa", wbits=4, kv_heads=1, act="gelu")
 
 
 def gen_layer_case():
@@ -1039,6 +1044,7 @@ if __name__ == "__main__":
     gen_decode_case()
     gen_decode_case_w4()
     gen_decode_case_w8pc_mha()
+    gen_decode_case_gelu()
     gen_layer_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()

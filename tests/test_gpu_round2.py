@@ -1158,9 +1158,10 @@ def test_gated_table_is_the_gated_kernel_for_every_index_pair(dev, act):
                                                                  q_shift=128)[0])
 
 
-@pytest.mark.parametrize("tag,wbits,kv_heads", [("w4", 4, 2), ("w8pc_mha", 8, 4)])
-def test_other_recipes_against_the_reference_model(dev, tag, wbits, kv_heads):
-    """(w8pc_mha: the configs[2]-style recipe -- 8-bit per-channel weights everywhere -- with full multi-head attention.)
+@pytest.mark.parametrize("tag,wbits,kv_heads,act", [("w4", 4, 2, "silu"), ("w8pc_mha", 8, 4, "silu"), ("w4_geglu_mqa", 4, 1, "gelu")])
+def test_other_recipes_against_the_reference_model(dev, tag, wbits, kv_heads, act):
+    """(w8pc_mha: the configs[2]-style recipe -- 8-bit per-channel weights everywhere -- with full multi-head attention;
+    w4_geglu_mqa: gemma-style GeGLU MLP (QGELU) with multi-query attention, W4A8.)
     The reference's W4A8 deployment recipe (4-bit per-channel weights, 8-bit activations) on the 2-layer model, against the logits of
     the reference's REAL HFForCausalLM (tests/golden/decode_case_w4.npz; weights regenerated from tests/seeded.py): the module graph on
     the W4 integer GEMMs, the fused prefill passes (segmented W4 q|k|v, two-GEMM gated MLP) and the W4 decode engine token by token."""
@@ -1172,7 +1173,7 @@ def test_other_recipes_against_the_reference_model(dev, tag, wbits, kv_heads):
     from seeded import seeded_parameters_
     z = load_npz(f"decode_case_{tag}.npz")
     m = llama.LlamaForCausalLM(llama.LlamaShape(hidden=256, layers=2, heads=4, kv_heads=kv_heads, head_dim=64, ffn=512, vocab=96, eps=1e-5,
-                                                max_pos=64)).eval()
+                                                max_pos=64, hidden_act=act)).eval()
     seeded_parameters_(m, std=0.08)
     m = m.to(dev)
     strip = lambda d: {(k[len("model."):] if k.startswith("model.") else k): v for k, v in d.items()}      # noqa: E731
