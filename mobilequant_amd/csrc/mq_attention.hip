@@ -255,14 +255,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     m = mn;
     R = Rn;
   };
+  // With a score grid whose whole span is < 2^96 in exp2 units (any sane 16-bit range: 65 535 steps x cexp ~ 20), the grid's TOP can
+  // stand in for the row maximum: no running max, no rescale, no dependency between blocks -- exp2((f - top) c) can neither overflow
+  // nor flush the row's largest term, and the common factor cancels in e / l like the rounding of R does.
+  const bool fixed_ref = QK_OUT && (fhi - flo) * cexp < 96.f;
+  auto sweep1_fixed = [&](const int (&ti)[16], int kb) {
+    float f[16];
+    grid_scores(ti, kb == qb, kb, f);
+    float bs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs += fast_exp2(__builtin_fmaf(f[i], cexp, -R));
+    l += bs;
+  };
   {
     KTile t;
     load_k(0, t);
-    for (int kb = 0; kb < nkb; ++kb) {
-      int ti[16];
-      int_scores(t, ti);
-      if (kb + 1 < nkb) load_k(kb + 1, t);
-      sweep1(ti, kb);
+    if (fixed_ref) {
+      R = fhi * cexp;
+      for (int kb = 0; kb < nkb; ++kb) {
+        int ti[16];
+        int_scores(t, ti);
+        if (kb + 1 < nkb) load_k(kb + 1, t);
+        sweep1_fixed(ti, kb);
+      }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    } else {
+      for (int kb = 0; kb < nkb; ++kb) {
+        int ti[16];
+        int_scores(t, ti);
+        if (kb + 1 < nkb) load_k(kb + 1, t);
+        sweep1(ti, kb);
+      }
     }
   }
   // p index = clamp(rint((e / l) / s_p) + z_p): g = fma(e, 1 / (l s_p), z_p + magic), index = low mantissa bits of med3(g, ...)
