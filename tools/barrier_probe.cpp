@@ -36,6 +36,46 @@ __global__ void __launch_bounds__(1024) barrier_kernel(unsigned* counter, unsign
   if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = __builtin_readcyclecounter() - t0;
 }
 
+// Hierarchical variant: workgroup w lives on XCD w % 8 (round-robin dispatch).  Level 1: the 32 workgroups of an XCD meet on their own
+// counter (own cache line); level 2: one leader per XCD meets the other 7 on a global counter and then releases its XCD through a
+// per-XCD epoch word.  Same-address traffic drops from 256 to 32 + 8 requesters.
+template <int MODE>
+__global__ void __launch_bounds__(1024) hbarrier_kernel(unsigned* ctr /* [8][32] per-XCD arrive, [8][32] per-XCD release, [32] global */, unsigned* flag,
+                                                        int rounds, float* data) {
+  const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, per = nb >> 3;
+  unsigned* arrive = ctr + xcd * 32;
+  unsigned* release = ctr + 8 * 32 + xcd * 32;
+  unsigned* global = ctr + 16 * 32;
+  for (int r = 0; r < rounds; ++r) {
+    if (MODE >= 1 && threadIdx.x == 0) data[(r & 1) * 4096 + blockIdx.x] = (float)(r + blockIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (MODE >= 1) __threadfence();
+      const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      if (old == (unsigned)(r + 1) * per - 1) {                 // last arriver of this XCD: go to the global level
+        __hip_atomic_fetch_add(global, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(global, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(r + 1) * 8) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) { *flag = 1; break; }
+        }
+        __hip_atomic_store(release, (unsigned)(r + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while (__hip_atomic_load(release, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(r + 1)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) { *flag = 1; break; }
+        }
+      }
+      if (MODE >= 1) __threadfence();
+    }
+    __syncthreads();
+    if (MODE >= 1) {
+      const float v = data[(r & 1) * 4096 + ((blockIdx.x + 1) % nb)];
+      if (v != (float)(r + (blockIdx.x + 1) % nb) && threadIdx.x == 0) *flag = 2;
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   int rounds = argc > 1 ? atoi(argv[1]) : 1000;
   hipDeviceProp_t p;
@@ -62,6 +102,24 @@ int main(int argc, char** argv) {
       printf("mode %d (%s) blocks %3d x 1024 threads: %.3f us per barrier (flag %u)\n", mode, mode ? "publish + fences + check" : "counter only", blocks,
              ms * 1e3 / rounds, f);
     }
+  }
+  unsigned* hctr;
+  CK(hipMalloc(&hctr, 17 * 32 * 4));
+  for (int mode = 0; mode < 2; ++mode) {
+    CK(hipMemset(hctr, 0, 17 * 32 * 4)); CK(hipMemset(flag, 0, 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    if (mode == 0) hbarrier_kernel<0><<<cus, 1024>>>(hctr, flag, rounds, data);
+    else hbarrier_kernel<1><<<cus, 1024>>>(hctr, flag, rounds, data);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned f;
+    CK(hipMemcpy(&f, flag, 4, hipMemcpyDeviceToHost));
+    printf("hierarchical (per-XCD, then global) mode %d (%s) blocks %3d x 1024 threads: %.3f us per barrier (flag %u)\n", mode,
+           mode ? "publish + fences + check" : "counters only", cus, ms * 1e3 / rounds, f);
   }
   return 0;
 }
