@@ -78,12 +78,24 @@ __device__ __forceinline__ float wave_max_f(float v) {
 
 constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 8;
 
+// Profiling builds (-DMQ_DECODE_STAMPS, tools/decode_stamps.py): every workgroup leaves s_memrealtime stamps (100 MHz, one clock for
+// the whole chip) at its phase boundaries.  Production builds compile the stamps out; the pointer argument stays null.
+#ifdef MQ_DECODE_STAMPS
+#define DG_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DG_STAMP(k) do { } while (0)
+#endif
+
 // GATE: a logical row r is the weight-row pair (2r, 2r+1) = (w1 row r, w3 row r), 2K contiguous bytes.
 // W4: weight rows hold packed unsigned nibbles (mq_pack_w4: K/2 bytes; a 16-byte group = 32 consecutive k, element j in the low and
 //     j + 16 in the high nibble of byte j): unpacked in registers, two dot products per loaded chunk; w_zp / col_term are in the
 //     unsigned-nibble domain as for mq_w4a8_linear.
 template <bool GATE, bool W4>
-__global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode_gemv_args g, const int rows_per_wg) {
+__global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode_gemv_args g, const int rows_per_wg, unsigned long long* stamps) {
+  DG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [K] int8 activation image, then scratch
   __shared__ float s_red[DG_WAVES];
   __shared__ int s_redi[DG_WAVES];
@@ -160,6 +172,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       for (int w = 0; w < DG_WAVES; ++w) tot += s_red[w];
       const float mean = __fdiv_rn(tot, (float)K);
       r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, g.eps)));
+      DG_STAMP(1);
     }
     for (int i = threadIdx.x; i < (K >> 2); i += DG_THREADS) {
       float4 v = reinterpret_cast<const float4*>(g.x)[i];
@@ -192,6 +205,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
     }
     __syncthreads();
   }
+  DG_STAMP(2);
   if (row0 >= row_end) return;
   const int rs = s_rowsum;
 
@@ -250,6 +264,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
     j = j2;
     if (t < nslots) issue_pass(t, j);
   }
+  DG_STAMP(3);
   // ---- epilogue, one row per LANE: every row of the wave goes through its quantizers at the same time -----------------------
   if (lane < nslots) {
     const int row = row0 + DG_WAVES * lane;
@@ -281,6 +296,11 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       g.y[row] = v;
     }
   }
+  DG_STAMP(4);
+#ifdef MQ_DECODE_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DG_STAMP(5);
+#endif
 }
 
 // ---- attention for ONE query token over a static KV cache -------------------------------------------------------------------------
@@ -289,7 +309,8 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
 //   s[t] = Qqk_out( sum_d Qqk_a(q[d]) * Qqk_b(K[t][d]) ) / sqrt(D),   t = 0 .. pos        (the mask admits exactly these)
 //   p = softmax(s)  (fp32)
 //   o[d] = Qpv_out( sum_t Qpv_a(p[t]) * Qpv_b(V[t][d]) )
-__global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_attention_args a) {
+__global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_attention_args a, unsigned long long* stamps) {
+  DG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_p = reinterpret_cast<float*>(smem_raw);               // [T] scores / probabilities
   __shared__ float s_q[256], s_k[256], s_v[256], s_red[4], s_o[4][256];
@@ -323,6 +344,7 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
     }
   }
   __syncthreads();
+  DG_STAMP(1);
   // At M = 1 this kernel is a chain of dependent memory round trips, so every phase issues its loads in bulk: positions are
   // processed in chunks of 256; a thread holds 16 float4 of keys (4 lanes per position, 64 positions per unit, 4 units) and 16
   // float4 of values (16 lanes per position row, 16 rows per unit, 16 units) -- and the FIRST chunk's values are requested
@@ -385,6 +407,7 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
   lmax = wave_max_f(lmax);
   if (lane == 0) s_red[wv] = lmax;
   __syncthreads();
+  DG_STAMP(2);
   const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   __syncthreads();
   float lsum = 0.f;
@@ -399,6 +422,7 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
   const float inv_sum = __fdiv_rn(1.0f, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
   for (int t = tid; t < T; t += 256) s_p[t] = pa.fq(__fmul_rn(s_p[t], inv_sum));      // pv_bmm's input quantizer, once per position
   __syncthreads();
+  DG_STAMP(3);
   float* s_acc = &s_o[0][0];                                        // [16][64] partial outputs (fast path) / [4][256] (generic)
   if (fast) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -418,6 +442,7 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
     }
     reinterpret_cast<float4*>(s_acc + vr * 64)[vq] = acc;
     __syncthreads();
+    DG_STAMP(4);
     if (tid < 64) {
       float tot = 0.f;
 #pragma unroll
@@ -433,12 +458,17 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
     __syncthreads();
     if (tid < D) a.out[(size_t)h * D + tid] = po.fq((s_o[0][tid] + s_o[1][tid]) + (s_o[2][tid] + s_o[3][tid]));
   }
+#ifdef MQ_DECODE_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DG_STAMP(5);
+#endif
 }
 
 // ---- final norm (floating point HFRMSNorm) + lm_head (fp32 weights) ----------------------------------------------------------------
 __global__ void __launch_bounds__(256) decode_head_kernel(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
                                                           const float* __restrict__ w, const float* __restrict__ bias, int K, int V,
-                                                          float* __restrict__ logits) {
+                                                          float* __restrict__ logits, unsigned long long* stamps) {
+  DG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);               // [K] normalised activation
   __shared__ float s_red[4];
@@ -469,11 +499,39 @@ __global__ void __launch_bounds__(256) decode_head_kernel(const float* __restric
     acc = wave_sum_f(acc);
     if (lane == 0) logits[row] = bias ? acc + bias[row] : acc;
   }
+  DG_STAMP(4);
 }
 
 }  // namespace mq
 
 using namespace mq;
+
+#ifdef MQ_DECODE_STAMPS
+// profiling builds only (not in any header): stamp buffer + a host log of (kind, grid, base slot) per launch
+static unsigned long long* g_stamp_buf = nullptr;
+static long long g_stamp_cap = 0, g_stamp_next = 0;
+static long long g_stamp_log[3 * 4096];
+static int g_stamp_nlog = 0;
+static unsigned long long* stamp_slot(int kind, unsigned grid) {
+  if (!g_stamp_buf || g_stamp_next + (long long)grid * 8 > g_stamp_cap || g_stamp_nlog >= 4096) return nullptr;
+  unsigned long long* p = g_stamp_buf + g_stamp_next;
+  g_stamp_log[3 * g_stamp_nlog] = kind, g_stamp_log[3 * g_stamp_nlog + 1] = grid, g_stamp_log[3 * g_stamp_nlog + 2] = g_stamp_next;
+  ++g_stamp_nlog;
+  g_stamp_next += (long long)grid * 8;
+  return p;
+}
+extern "C" void mq_decode_set_stamps_(void* buf, long long cap_words) {
+  g_stamp_buf = static_cast<unsigned long long*>(buf), g_stamp_cap = cap_words, g_stamp_next = 0, g_stamp_nlog = 0;
+}
+extern "C" int mq_decode_stamp_log_(long long* out, int cap) {
+  const int n = g_stamp_nlog < cap ? g_stamp_nlog : cap;
+  for (int i = 0; i < 3 * n; ++i) out[i] = g_stamp_log[i];
+  return n;
+}
+#define STAMP_SLOT(kind, grid) stamp_slot(kind, grid)
+#else
+#define STAMP_SLOT(kind, grid) nullptr
+#endif
 
 extern "C" {
 
@@ -504,12 +562,13 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   const unsigned grid = (unsigned)((NL + rows_per_wg - 1) / rows_per_wg);
   const size_t lds = (size_t)g.K + 64;
   hipStream_t st = as_stream(stream);
+  unsigned long long* stamps = STAMP_SLOT(gate ? 1 : (g.norm_w ? 0 : (g.xq ? 3 : 2)), grid);
   if (g.w4) {
-    if (gate) decode_gemv_kernel<true, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
-    else decode_gemv_kernel<false, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+    if (gate) decode_gemv_kernel<true, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
+    else decode_gemv_kernel<false, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
   } else {
-    if (gate) decode_gemv_kernel<true, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
-    else decode_gemv_kernel<false, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg);
+    if (gate) decode_gemv_kernel<true, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
+    else decode_gemv_kernel<false, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
   }
   MQ_LAUNCH_CHECK("mq_decode_gemv");
   return MQ_OK;
@@ -522,7 +581,7 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
   MQ_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0 && a.head_dim >= 16 && a.head_dim <= 256 && a.head_dim % 16 == 0 &&
                  a.cache_len > 0 && a.cache_len <= 16384,
              "mq_decode_attention: heads=%d kv_heads=%d head_dim=%d cache_len=%d", a.heads, a.kv_heads, a.head_dim, a.cache_len);
-  decode_attention_kernel<<<(unsigned)a.heads, 256, (size_t)a.cache_len * sizeof(float), as_stream(stream)>>>(a);
+  decode_attention_kernel<<<(unsigned)a.heads, 256, (size_t)a.cache_len * sizeof(float), as_stream(stream)>>>(a, STAMP_SLOT(4, (unsigned)a.heads));
   MQ_LAUNCH_CHECK("mq_decode_attention");
   return MQ_OK;
 }
@@ -533,7 +592,8 @@ int mq_decode_head(const float* x, const float* norm_weight, float eps, const fl
   MQ_REQUIRE(aligned(w, 16), "mq_decode_head: the weight must be 16-byte aligned");
   int64_t blocks = (V + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  decode_head_kernel<<<(unsigned)blocks, 256, (size_t)K * sizeof(float), as_stream(stream)>>>(x, norm_weight, eps, w, bias, (int)K, (int)V, logits);
+  decode_head_kernel<<<(unsigned)blocks, 256, (size_t)K * sizeof(float), as_stream(stream)>>>(x, norm_weight, eps, w, bias, (int)K, (int)V, logits,
+                                                                                    STAMP_SLOT(5, (unsigned)blocks));
   MQ_LAUNCH_CHECK("mq_decode_head");
   return MQ_OK;
 }

@@ -1,0 +1,5 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03a; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+MQ_LIB_PATH=$R/mobilequant_amd/lib/stamps/libmobilequant_amd.so LAYERS=6 timeout 600 python tools/decode_stamps.py > $O/stamps_w8.log 2>&1; cat $O/stamps_w8.log | tail -12
+MQ_LIB_PATH=$R/mobilequant_amd/lib/stamps/libmobilequant_amd.so LAYERS=6 WBITS=4 timeout 600 python tools/decode_stamps.py > $O/stamps_w4.log 2>&1; cat $O/stamps_w4.log | tail -12
