@@ -302,6 +302,17 @@ typedef struct mq_grid {
  * Gate mode (gate_q != NULL): weight rows 2i / 2i+1 are row i of w1 / w3 (out_grid[0] / out_grid[1]); the epilogue applies
  *   QSiLU (gate_act 0; gate_mid = sigmoid grid) or QGELU (1) with output grid gate_actout, the product, and w2's input quantizer
  *   gate_out: gate_q[i] = int8 storage (index - 128); y (nullable) = the fp32 product. */
+/* Launch constants of the decode kernels: n <= 16 static per-tensor grids -> consts[4k .. 4k+3] = {scale, offset, 1 / scale, 0}
+ * (an absent grid, scale == NULL, packs as {1, 0, 1, 0}).  One tiny launch at engine-build time; the decode kernels then fetch all
+ * their quantizer parameters with ONE load instead of two dependent pointer chases per grid (qmodule.py:279-283 keeps scale / offset
+ * as device tensors, so they cannot travel as kernel arguments without a host read-back). */
+#define MQ_DECODE_MAX_GRIDS 16
+typedef struct mq_decode_grid_pack {
+  mq_grid grids[MQ_DECODE_MAX_GRIDS];
+  int n;
+} mq_decode_grid_pack;
+int mq_decode_pack_grids(const mq_grid* grids, int n, float* consts, mq_stream_t stream);
+
 typedef struct mq_decode_gemv_args {
   const float* x;
   const int8_t* xq;
@@ -324,6 +335,9 @@ typedef struct mq_decode_gemv_args {
   int8_t* gate_q;
   int w4; /* 1: w holds packed unsigned nibbles [N, K/2] (mq_pack_w4; gate mode: rows 2i / 2i+1 interleaved alike), w_zp / col_term in
            * the unsigned-nibble domain as for mq_w4a8_linear -- the reference's W4A8 deployment mode */
+  const float* consts; /* REQUIRED: mq_decode_pack_grids of {norm_in, a_grid, out_grid[0..2], gate_mid, gate_actout, gate_out} into
+                        * a 64-float, 16-byte aligned block (unused tail zero): the kernel reads every grid from this one cache line; the mq_grid pointers above only say
+                        * which grids are present (scale != NULL) and carry qmin / qmax */
 } mq_decode_gemv_args;
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream);
 

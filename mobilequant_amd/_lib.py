@@ -33,7 +33,7 @@ class MqDecodeGemvArgs(ctypes.Structure):
                 ("eps", c_float), ("a_grid", MqGrid), ("w", c_void_p), ("alpha", c_void_p), ("w_zp", c_void_p),
                 ("col_term", c_void_p), ("bias", c_void_p), ("seg_end", c_int * 2), ("out_grid", MqGrid * 3),
                 ("resid", c_void_p), ("y", c_void_p), ("gate_act", c_int), ("gate_mid", MqGrid), ("gate_actout", MqGrid),
-                ("gate_out", MqGrid), ("gate_q", c_void_p), ("w4", c_int)]
+                ("gate_out", MqGrid), ("gate_q", c_void_p), ("w4", c_int), ("consts", c_void_p)]
 
 
 class MqDecodeAttentionArgs(ctypes.Structure):
@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mq_layernorm_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P,
                                    _P, _P, c_int, _P, _P]),
     "mq_w4a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
+    "mq_decode_pack_grids": (c_int, [POINTER(MqGrid), c_int, _P, _P]),
     "mq_decode_gemv": (c_int, [POINTER(MqDecodeGemvArgs), _P]),
     "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
     "mq_decode_head": (c_int, [_P, _P, c_float, _P, _P, c_int64, c_int64, _P, _P]),

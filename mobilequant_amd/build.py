@@ -22,7 +22,10 @@ LIB = os.path.join(LIBDIR, "libmobilequant_amd.so")
 SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemv.hip", "mq_norm.hip", "mq_decode.hip", "mq_attention.hip"]
 # per-file additions: the attention kernel is VALU-bound and consumes every MFMA result with VALU instructions -- keep the MFMA
 # results in VGPRs (no v_accvgpr_read per score element)
-PER_FILE_FLAGS = {"mq_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# mq_decode.hip: no SLP vectorisation -- a v_pk_mul_f32 names a register PAIR although op_sel reads one half; when the other half
+# is the destination of a load still in flight, hipcc's waitcnt pass waits for it (vmcnt(0) = the whole weight stream) in front of
+# the activation-image arithmetic
+PER_FILE_FLAGS = {"mq_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "mq_decode.hip": ["-fno-slp-vectorize"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ABLATE = (["-DMQ_GEMM_ABLATE"] if os.environ.get("MQ_GEMM_ABLATE") else []) + \
     ([f"-DMQ_PP_PRIO={os.environ['MQ_PP_PRIO']}"] if os.environ.get("MQ_PP_PRIO") else [])

@@ -27,9 +27,18 @@ __device__ __forceinline__ float dq_clamp_nan(float q, float lo, float hi) {
   const float c = fminf(fmaxf(q, lo), hi);
   return q != q ? q : c;
 }
+// x / s through the correctly rounded reciprocal y = RN(1 / s) and one fma correction (Markstein): bit-identical to the IEEE divide
+// for |x / s| in [2^-2, 1e30] -- tools/div_check.cpp compares every fp32 dividend for 48 divisors on the GPU, incl. all-ones
+// significands and the scale clamps 1e-5 / 1e6 (profiles/r03/div_check.log) -- and faithful below 2^-2, where round(x / s) = 0 and
+// (round(t) - t) + t = 0 whatever the last bit of t is.  3 VALU instructions instead of the 10 + two mode switches of v_div_*: at
+// M = 1 every CU quantises the whole activation row, and that arithmetic is the launch's critical path.
+__device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
+  const float q0 = __fmul_rn(x, inv_s);
+  return __builtin_fmaf(__builtin_fmaf(-q0, s, x), inv_s, q0);
+}
 // qmodule.py:286-290 with round_ste = (round(t) - t) + t (as mq_norm.hip / mq_elementwise.hip)
-__device__ __forceinline__ float dq_index(float x, float s, float o, float qmin, float qmax) {
-  const float t = __fdiv_rn(x, s);
+__device__ __forceinline__ float dq_index(float x, float s, float inv_s, float o, float qmin, float qmax) {
+  const float t = div_by_scale(x, s, inv_s);
   const float r = __fadd_rn(__fsub_rn(rintf(t), t), t);
   return dq_clamp_nan(__fadd_rn(r, o), qmin, qmax);
 }
@@ -38,7 +47,7 @@ __device__ __forceinline__ float dq_dequant(float q, float s, float o) { return 
 struct Grid {          // device view of mq_grid
   float s, o, qmin, qmax, inv_s;
   bool on;
-  __device__ __forceinline__ float fq(float v) const { return on ? dq_dequant(dq_index(v, s, o, qmin, qmax), s, o) : v; }
+  __device__ __forceinline__ float fq(float v) const { return on ? dq_dequant(dq_index(v, s, inv_s, o, qmin, qmax), s, o) : v; }
 };
 __device__ __forceinline__ Grid load_grid(const mq_grid& g) {
   Grid r;
@@ -83,40 +92,185 @@ constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 8;
 #ifdef MQ_DECODE_STAMPS
 #define DG_STAMP(k)                                                                                   \
   do {                                                                                                \
-    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+// stamp of wave `w` once the register `reg` has arrived
+#define DG_STAMP_ARRIVED(k, w, reg)                                                                   \
+  do {                                                                                                \
+    if (stamps && wave == (w)) {                                                                      \
+      asm volatile("" ::"v"(reg));                                                                    \
+      if (lane == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();       \
+    }                                                                                                 \
   } while (0)
 #else
 #define DG_STAMP(k) do { } while (0)
+#define DG_STAMP_ARRIVED(k, w, reg) do { } while (0)
 #endif
+
+// Constants block of a launch (mq_decode_pack_grids): grid k at floats [4k .. 4k+2] = scale, offset, 1 / scale.  ONE 128-byte load
+// per wave at the very top of the kernel replaces up to 16 dependent pointer chases behind the barriers.
+__device__ __forceinline__ Grid const_grid(const float cv, const int k, const mq_grid& g) {
+  Grid r;
+  r.on = g.scale != nullptr;
+  r.s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), 4 * k));
+  r.o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), 4 * k + 1));
+  r.inv_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), 4 * k + 2));
+  r.qmin = g.qmin;
+  r.qmax = g.qmax;
+  return r;
+}
+enum { CG_NORM_IN = 0, CG_A = 1, CG_OUT0 = 2, CG_OUT1 = 3, CG_OUT2 = 4, CG_GATE_MID = 5, CG_GATE_ACTOUT = 6, CG_GATE_OUT = 7, CG_COUNT = 8 };
+
+__global__ void decode_pack_grids_kernel(const mq_decode_grid_pack p, float* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= p.n) return;
+  const float s = p.grids[k].scale ? p.grids[k].scale[0] : 1.f, o = p.grids[k].offset ? p.grids[k].offset[0] : 0.f;
+  out[4 * k] = s;
+  out[4 * k + 1] = o;
+  out[4 * k + 2] = __fdiv_rn(1.0f, s);
+  out[4 * k + 3] = 0.f;
+}
 
 // GATE: a logical row r is the weight-row pair (2r, 2r+1) = (w1 row r, w3 row r), 2K contiguous bytes.
 // W4: weight rows hold packed unsigned nibbles (mq_pack_w4: K/2 bytes; a 16-byte group = 32 consecutive k, element j in the low and
 //     j + 16 in the high nibble of byte j): unpacked in registers, two dot products per loaded chunk; w_zp / col_term are in the
 //     unsigned-nibble domain as for mq_w4a8_linear.
-template <bool GATE, bool W4>
+//
+// Wave roles.  The kernel is a chain of dependent round trips, and two machine facts decide its shape (profiles/r03/decode_stamps_*.log,
+// tools/latency_probe.cpp): (1) a CU's vector-memory pipe takes ~16 cycles per 1-KiB wave load and serves the waves' requests in
+// arrival order, so an activation load issued behind other waves' weight loads returns behind them -- microseconds, not the 0.1 us
+// of a lone load; (2) hipcc counts outstanding loads statically: one conditional load between the activation loads and their first
+// use and it waits with vmcnt(0), i.e. for the whole weight stream.  So the waves split the work:
+//   * PROLOGUE waves 0 .. DG_PRO-1 (the first to start) request ONLY the launch constants, the activation row and the norm weights,
+//     build the int8 image + row sum in LDS (norm -> quantize, arithmetic of mq_rmsnorm_quant / mq_quantize) and exit;
+//   * STREAM waves DG_PRO .. 15 request ONLY weights and epilogue parameters, meet the image at the barrier, then run the dot
+//     products as their loads return, and the epilogue (one row per lane).
+// Both roles execute the same number of s_barrier (2 with a fused norm, 1 without).
+enum { XM_NORM = 0, XM_F32 = 1, XM_I8 = 2 };
+constexpr int DG_PRO = 8, DG_STR = DG_WAVES - DG_PRO, DG_XPRE = 4;      // 512 prologue threads x 4 float4 -> K <= 8192 (fp32)
+
+template <int XMODE, bool GATE, bool W4>
 __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode_gemv_args g, const int rows_per_wg, unsigned long long* stamps) {
   DG_STAMP(0);
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K] int8 activation image, then scratch
-  __shared__ float s_red[DG_WAVES];
-  __shared__ int s_redi[DG_WAVES];
-  __shared__ int s_rowsum;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K] int8 activation image
+  __shared__ float s_red[DG_PRO];
+  __shared__ int s_redi[DG_PRO];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = g.K;
+  const float cv = g.consts[lane & 63];                            // one 256-byte line per wave, both roles
+
+  if (wave < DG_PRO) {
+    // ================================================ PROLOGUE role ====================================================================
+    const int p = threadIdx.x;                                     // 0 .. 511
+    int my_sum = 0;
+    if constexpr (XMODE == XM_I8) {                                // ready int8 image (w2 after the gated epilogue): copy + row sum
+      const int nq = K >> 4;
+      for (int i = p; i < nq; i += DG_PRO * 64) {
+        const v4i v = reinterpret_cast<const v4i*>(g.xq)[i];
+        reinterpret_cast<v4i*>(smem)[i] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) my_sum = __builtin_amdgcn_sdot4(v[e], 0x01010101, my_sum, false);
+      }
+    } else {
+      const int nvec = K >> 2;
+      float4 xv[DG_XPRE], nw[DG_XPRE];
+#pragma unroll
+      for (int u = 0; u < DG_XPRE; ++u) {
+        if (u * DG_PRO * 64 < nvec) {                              // wave-uniform
+          const int i = p + u * DG_PRO * 64;
+          xv[u] = reinterpret_cast<const float4*>(g.x)[i < nvec ? i : nvec - 1];
+          if constexpr (XMODE == XM_NORM) nw[u] = reinterpret_cast<const float4*>(g.norm_w)[i < nvec ? i : nvec - 1];
+        }
+      }
+      DG_STAMP_ARRIVED(6, 0, xv[0].x);
+      const Grid ag = const_grid(cv, CG_A, g.a_grid);            // (the constants were requested before the row: they are here)
+      float r = 1.f;
+      if constexpr (XMODE == XM_NORM) {                            // QRMSNorm.forward (qmodule.py:515-531), arithmetic of mq_rmsnorm_quant
+        const Grid ng = const_grid(cv, CG_NORM_IN, g.norm_in);
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < DG_XPRE; ++u) {
+          if (u * DG_PRO * 64 < nvec) {
+            float4& v = xv[u];
+            v.x = ng.fq(v.x); v.y = ng.fq(v.y); v.z = ng.fq(v.z); v.w = ng.fq(v.w);
+            if (p + u * DG_PRO * 64 < nvec) {
+              ss += v.x * v.x;
+              ss += v.y * v.y;
+              ss += v.z * v.z;
+              ss += v.w * v.w;
+            }
+          }
+        }
+        DG_STAMP_ARRIVED(8, 0, ss);
+        ss = wave_sum_f(ss);
+        if (lane == 0) s_red[wave] = ss;
+        DG_STAMP_ARRIVED(9, 0, ss);
+        __syncthreads();                                           // barrier 1 of 2 (the stream waves pass it right after their requests)
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < DG_PRO; ++w) tot += s_red[w];
+        const float mean = __fdiv_rn(tot, (float)K);
+        r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, g.eps)));
+        DG_STAMP(1);
+      }
+#pragma unroll
+      for (int u = 0; u < DG_XPRE; ++u) {
+        if (u * DG_PRO * 64 < nvec) {
+          const int i = p + u * DG_PRO * 64;
+          float4 v = xv[u];
+          if constexpr (XMODE == XM_NORM) {
+            const float4 w = nw[u];
+            v.x = __fmul_rn(w.x, __fmul_rn(v.x, r)); v.y = __fmul_rn(w.y, __fmul_rn(v.y, r));
+            v.z = __fmul_rn(w.z, __fmul_rn(v.z, r)); v.w = __fmul_rn(w.w, __fmul_rn(v.w, r));
+          }
+          const float f[4] = {v.x, v.y, v.z, v.w};
+          unsigned pk = 0;
+          int sum4 = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float qi = dq_index(f[e], ag.s, ag.inv_s, ag.o, ag.qmin, ag.qmax);
+            const int st = (qi != qi ? (int)ag.qmin : (int)qi) - 128;
+            sum4 += st;
+            pk |= ((unsigned)st & 0xffu) << (8 * e);
+          }
+          if (i < nvec) {
+            my_sum += sum4;
+            reinterpret_cast<unsigned*>(smem)[i] = pk;
+          }
+        }
+      }
+    }
+    DG_STAMP_ARRIVED(10, 0, my_sum);
+    const int part = wave_sum_dpp(my_sum);
+    if (lane == 0) s_redi[wave] = part;
+    __syncthreads();                                               // the image and the row sum are complete
+    DG_STAMP(2);
+    return;
+  }
+
+  // ================================================== STREAM role ======================================================================
+#ifdef MQ_DECODE_STAMPS
+  if (stamps && wave == DG_PRO && lane == 0) {
+    stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime();
+    stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  const int sw = wave - DG_PRO;                                    // 0 .. DG_STR-1
   const int NL = GATE ? g.N >> 1 : g.N;                            // logical rows
   const int kchunks = W4 ? K >> 5 : K >> 4;                        // 16-byte chunks per weight row
   const int wrow = W4 ? K >> 1 : K;                                // bytes per weight row
   const int lchunks = GATE ? 2 * kchunks : kchunks;                // chunks per logical row
   const int cpl = (lchunks + 63) >> 6;
-  const int row0 = blockIdx.x * rows_per_wg + wave;
+  const int row0 = blockIdx.x * rows_per_wg + sw;
   const int row_end = (blockIdx.x + 1) * rows_per_wg < NL ? (blockIdx.x + 1) * rows_per_wg : NL;
-
-  // ---- weight loads of the first pass and the per-row parameters go out first ------------------------------------------------
+  const int prow = row0 + DG_STR * lane;                           // lane t keeps the parameters / result of row slot t
+  const bool prow_ok = prow < row_end;
   v4i buf[DG_INFLIGHT];
   auto issue_pass = [&](int t, int j) {
 #pragma unroll
     for (int u = 0; u < DG_INFLIGHT; ++u) {
-      const int row = row0 + DG_WAVES * t;
+      const int row = row0 + DG_STR * t;
       const int c = lane + 64 * j;
       if (row < row_end && c < lchunks)
         buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * (GATE ? 2 : 1) * wrow) + c);
@@ -128,92 +282,27 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
   issue_pass(0, 0);
   float p_alpha[GATE ? 2 : 1], p_bias[GATE ? 2 : 1];
   int p_zp[GATE ? 2 : 1], p_ct[GATE ? 2 : 1];
-  {
-    const int row = row0 + DG_WAVES * lane;                        // lane t keeps the parameters of row slot t
 #pragma unroll
-    for (int h = 0; h < (GATE ? 2 : 1); ++h) {
-      const int wr = GATE ? 2 * row + h : row;
-      const bool ok = row < row_end;
-      p_alpha[h] = ok ? g.alpha[wr] : 0.f;
-      p_zp[h] = ok ? g.w_zp[wr] : 0;
-      p_ct[h] = ok ? g.col_term[wr] : 0;
-      p_bias[h] = (ok && g.bias) ? g.bias[wr] : 0.f;
-    }
+  for (int h = 0; h < (GATE ? 2 : 1); ++h) {
+    const int wr = GATE ? 2 * prow + h : prow;
+    p_alpha[h] = prow_ok ? g.alpha[wr] : 0.f;
+    p_zp[h] = prow_ok ? g.w_zp[wr] : 0;
+    p_ct[h] = prow_ok ? g.col_term[wr] : 0;
+    p_bias[h] = (prow_ok && g.bias) ? g.bias[wr] : 0.f;
   }
-
-  // ---- activation -> int8 image in LDS, once per CU ------------------------------------------------------------------------------
-  const Grid ag = load_grid(g.a_grid);
-  int my_sum = 0;
-  if (g.xq != nullptr) {                                          // ready int8 image (w2 after the gated epilogue)
-    for (int i = threadIdx.x; i < (K >> 2); i += DG_THREADS) {
-      const unsigned v = reinterpret_cast<const unsigned*>(g.xq)[i];
-      reinterpret_cast<unsigned*>(smem)[i] = v;
-      my_sum += (int)(int8_t)(v & 0xff) + (int)(int8_t)((v >> 8) & 0xff) + (int)(int8_t)((v >> 16) & 0xff) + (int)(int8_t)(v >> 24);
-    }
-  } else {
-    float r = 1.f;
-    const bool norm = g.norm_w != nullptr;
-    const Grid ng = load_grid(g.norm_in);
-    if (norm) {                                                   // QRMSNorm.forward (qmodule.py:515-531), arithmetic of mq_rmsnorm_quant
-      float ss = 0.f;
-      for (int i = threadIdx.x; i < (K >> 2); i += DG_THREADS) {
-        float4 v = reinterpret_cast<const float4*>(g.x)[i];
-        v.x = ng.fq(v.x); v.y = ng.fq(v.y); v.z = ng.fq(v.z); v.w = ng.fq(v.w);
-        ss += v.x * v.x;
-        ss += v.y * v.y;
-        ss += v.z * v.z;
-        ss += v.w * v.w;
-      }
-      ss = wave_sum_f(ss);
-      if (lane == 0) s_red[wave] = ss;
-      __syncthreads();
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < DG_WAVES; ++w) tot += s_red[w];
-      const float mean = __fdiv_rn(tot, (float)K);
-      r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, g.eps)));
-      DG_STAMP(1);
-    }
-    for (int i = threadIdx.x; i < (K >> 2); i += DG_THREADS) {
-      float4 v = reinterpret_cast<const float4*>(g.x)[i];
-      if (norm) {
-        const float4 w = reinterpret_cast<const float4*>(g.norm_w)[i];
-        v.x = __fmul_rn(w.x, __fmul_rn(ng.fq(v.x), r)); v.y = __fmul_rn(w.y, __fmul_rn(ng.fq(v.y), r));
-        v.z = __fmul_rn(w.z, __fmul_rn(ng.fq(v.z), r)); v.w = __fmul_rn(w.w, __fmul_rn(ng.fq(v.w), r));
-      }
-      const float f[4] = {v.x, v.y, v.z, v.w};
-      unsigned pk = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float qi = dq_index(f[e], ag.s, ag.o, ag.qmin, ag.qmax);
-        const int st = (qi != qi ? (int)ag.qmin : (int)qi) - 128;
-        my_sum += st;
-        pk |= ((unsigned)st & 0xffu) << (8 * e);
-      }
-      reinterpret_cast<unsigned*>(smem)[i] = pk;
-    }
-  }
-  {
-    const int part = wave_sum_dpp(my_sum);
-    if (lane == 0) s_redi[wave] = part;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-#pragma unroll
-      for (int w = 0; w < DG_WAVES; ++w) tot += s_redi[w];
-      s_rowsum = tot;
-    }
-    __syncthreads();
-  }
-  DG_STAMP(2);
+  float p_res = 0.f;
+  if (!GATE && g.resid && prow_ok) p_res = g.resid[prow];
+  if constexpr (XMODE == XM_NORM) __syncthreads();                 // barrier 1 of 2: the prologue waves' sum of squares
+  __syncthreads();                                                 // the image and the row sum are complete
   if (row0 >= row_end) return;
-  const int rs = s_rowsum;
-
-  // ---- output grids ---------------------------------------------------------------------------------------------------------------
-  Grid og[3];
+  int rs = 0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) og[k] = load_grid(g.out_grid[k]);
-  const Grid gmid = load_grid(g.gate_mid), gact = load_grid(g.gate_actout), gout = load_grid(g.gate_out);
+  for (int w = 0; w < DG_PRO; ++w) rs += s_redi[w];
+
+  // ---- output grids -----------------------------------------------------------------------------------------------------------------
+  const Grid og0 = const_grid(cv, CG_OUT0, g.out_grid[0]), og1 = const_grid(cv, CG_OUT1, g.out_grid[1]), og2 = const_grid(cv, CG_OUT2, g.out_grid[2]);
+  const Grid gmid = const_grid(cv, CG_GATE_MID, g.gate_mid), gact = const_grid(cv, CG_GATE_ACTOUT, g.gate_actout),
+             gout = const_grid(cv, CG_GATE_OUT, g.gate_out);
   auto out_q = [&](const Grid& q, float f) {        // output quantizer as the GEMM / GEMV epilogues evaluate it (reciprocal multiply)
     if (!q.on) return f;
     float v = rintf(f * q.inv_s) + q.o;
@@ -222,7 +311,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
   };
 
   // ---- dot products, DPP reduction and epilogue per completed logical row ----------------------------------------------------
-  const int nslots = (row_end - row0 + DG_WAVES - 1) / DG_WAVES;
+  const int nslots = (row_end - row0 + DG_STR - 1) / DG_STR;
   int acc0 = 0, acc1 = 0;
   int sum0 = 0, sum1 = 0;
   int t = 0, j = 0;
@@ -264,10 +353,10 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
     j = j2;
     if (t < nslots) issue_pass(t, j);
   }
-  DG_STAMP(3);
+  DG_STAMP_ARRIVED(3, DG_PRO, sum0);
   // ---- epilogue, one row per LANE: every row of the wave goes through its quantizers at the same time -----------------------
   if (lane < nslots) {
-    const int row = row0 + DG_WAVES * lane;
+    const int row = prow;
     float e0, e1 = 0.f;
     {
       const int tt = (int)((unsigned)sum0 - (unsigned)p_zp[0] * (unsigned)rs + (unsigned)p_ct[0]);
@@ -278,7 +367,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       e1 = __fadd_rn(__fmul_rn((float)tt, p_alpha[GATE ? 1 : 0]), p_bias[GATE ? 1 : 0]);
     }
     if constexpr (GATE) {
-      const float fa = out_q(og[0], e0), fb = out_q(og[1], e1);
+      const float fa = out_q(og0, e0), fb = out_q(og1, e1);
       float rr;
       if (g.gate_act == 0) {                                     // QSiLU (qmodule.py:739-753)
         const float gate = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-fa)));
@@ -287,19 +376,22 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         rr = __fmul_rn(__fmul_rn(0.5f, fa), __fadd_rn(1.0f, erff(__fmul_rn(fa, 0.70710678118654752440f))));
       }
       const float prod = __fmul_rn(gact.fq(rr), fb);
-      const float qi = dq_index(prod, gout.s, gout.o, gout.qmin, gout.qmax);
+      const float qi = dq_index(prod, gout.s, gout.inv_s, gout.o, gout.qmin, gout.qmax);
       g.gate_q[row] = (int8_t)((qi != qi ? (int)gout.qmin : (int)qi) - 128);
       if (g.y) g.y[row] = prod;
     } else {
-      float v = row < g.seg_end[0] ? out_q(og[0], e0) : (row < g.seg_end[1] ? out_q(og[1], e0) : out_q(og[2], e0));
-      if (g.resid) v = __fadd_rn(g.resid[row], v);
+      float v = row < g.seg_end[0] ? out_q(og0, e0) : (row < g.seg_end[1] ? out_q(og1, e0) : out_q(og2, e0));
+      if (g.resid) v = __fadd_rn(p_res, v);
       g.y[row] = v;
     }
   }
-  DG_STAMP(4);
 #ifdef MQ_DECODE_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  DG_STAMP(5);
+  if (stamps && wave == DG_PRO) {
+    if (lane == 0) stamps[(size_t)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) stamps[(size_t)blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
+  }
 #endif
 }
 
@@ -513,11 +605,11 @@ static long long g_stamp_cap = 0, g_stamp_next = 0;
 static long long g_stamp_log[3 * 4096];
 static int g_stamp_nlog = 0;
 static unsigned long long* stamp_slot(int kind, unsigned grid) {
-  if (!g_stamp_buf || g_stamp_next + (long long)grid * 8 > g_stamp_cap || g_stamp_nlog >= 4096) return nullptr;
+  if (!g_stamp_buf || g_stamp_next + (long long)grid * 16 > g_stamp_cap || g_stamp_nlog >= 4096) return nullptr;
   unsigned long long* p = g_stamp_buf + g_stamp_next;
   g_stamp_log[3 * g_stamp_nlog] = kind, g_stamp_log[3 * g_stamp_nlog + 1] = grid, g_stamp_log[3 * g_stamp_nlog + 2] = g_stamp_next;
   ++g_stamp_nlog;
-  g_stamp_next += (long long)grid * 8;
+  g_stamp_next += (long long)grid * 16;
   return p;
 }
 extern "C" void mq_decode_set_stamps_(void* buf, long long cap_words) {
@@ -535,10 +627,22 @@ extern "C" int mq_decode_stamp_log_(long long* out, int cap) {
 
 extern "C" {
 
+int mq_decode_pack_grids(const mq_grid* grids, int n, float* consts, mq_stream_t stream) {
+  MQ_REQUIRE(grids && consts && n > 0 && n <= MQ_DECODE_MAX_GRIDS, "mq_decode_pack_grids: 1..%d grids", MQ_DECODE_MAX_GRIDS);
+  mq_decode_grid_pack p;
+  p.n = n;
+  for (int k = 0; k < n; ++k) p.grids[k] = grids[k];
+  decode_pack_grids_kernel<<<1, 64, 0, as_stream(stream)>>>(p, consts);
+  MQ_LAUNCH_CHECK("mq_decode_pack_grids");
+  return MQ_OK;
+}
+
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_decode_gemv: null argument block");
   const mq_decode_gemv_args& g = *args;
   MQ_REQUIRE(g.w && g.alpha && g.w_zp && g.col_term && (g.x || g.xq), "mq_decode_gemv: null pointer");
+  MQ_REQUIRE(g.consts != nullptr && aligned(g.consts, 16), "mq_decode_gemv: consts (64 floats: mq_decode_pack_grids of this launch's 8 grids, zero padded) is required");
+  MQ_REQUIRE(g.xq || g.K <= DG_XPRE * 4 * DG_PRO * 64, "mq_decode_gemv: K=%d exceeds the fp32 activation row the prologue waves hold in registers (8192)", g.K);
   MQ_REQUIRE(g.K > 0 && g.K % 256 == 0 && g.K <= 32768 && g.N > 0, "mq_decode_gemv: K=%d must be a positive multiple of 256 (<= 32768), N=%d", g.K, g.N);
   MQ_REQUIRE(g.xq || (g.a_grid.scale && g.a_grid.offset && g.a_grid.qmin == 0.f && g.a_grid.qmax == 255.f),
              "mq_decode_gemv: fp32 activations need an 8-bit unsigned activation grid");
@@ -546,6 +650,7 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
              "mq_decode_gemv: pointers must be 16-byte aligned");
   const bool gate = g.gate_q != nullptr;
   MQ_REQUIRE(gate || g.y, "mq_decode_gemv: no output");
+  MQ_REQUIRE(!gate || (g.norm_w && !g.xq), "mq_decode_gemv: gate mode is served for the norm-fused prologue (fp32 x + norm_w)");
   MQ_REQUIRE(!gate || (g.N % 2 == 0 && g.gate_out.scale && g.out_grid[0].scale && g.out_grid[1].scale && (g.gate_act == 0 || g.gate_act == 1)),
              "mq_decode_gemv: gate mode needs an even N (interleaved w1 / w3 rows), both output grids and the w2 input grid");
   static std::atomic<int> cus_of[kMaxDevices];
@@ -558,18 +663,28 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   }
   const int NL = gate ? g.N / 2 : g.N;
   int rows_per_wg = (NL + cus - 1) / cus;
-  if (rows_per_wg > DG_WAVES * 64) rows_per_wg = DG_WAVES * 64;
+  if (rows_per_wg > DG_STR * 64) rows_per_wg = DG_STR * 64;
   const unsigned grid = (unsigned)((NL + rows_per_wg - 1) / rows_per_wg);
   const size_t lds = (size_t)g.K + 64;
   hipStream_t st = as_stream(stream);
   unsigned long long* stamps = STAMP_SLOT(gate ? 1 : (g.norm_w ? 0 : (g.xq ? 3 : 2)), grid);
-  if (g.w4) {
-    if (gate) decode_gemv_kernel<true, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
-    else decode_gemv_kernel<false, true><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
+  const int xmode = g.xq ? XM_I8 : (g.norm_w ? XM_NORM : XM_F32);
+#define MQ_DG_LAUNCH(XM, GT, W4)                                                                                   \
+  decode_gemv_kernel<XM, GT, W4><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps)
+  if (gate) {
+    if (g.w4) MQ_DG_LAUNCH(XM_NORM, true, true);
+    else MQ_DG_LAUNCH(XM_NORM, true, false);
+  } else if (xmode == XM_NORM) {
+    if (g.w4) MQ_DG_LAUNCH(XM_NORM, false, true);
+    else MQ_DG_LAUNCH(XM_NORM, false, false);
+  } else if (xmode == XM_F32) {
+    if (g.w4) MQ_DG_LAUNCH(XM_F32, false, true);
+    else MQ_DG_LAUNCH(XM_F32, false, false);
   } else {
-    if (gate) decode_gemv_kernel<true, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
-    else decode_gemv_kernel<false, false><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps);
+    if (g.w4) MQ_DG_LAUNCH(XM_I8, false, true);
+    else MQ_DG_LAUNCH(XM_I8, false, false);
   }
+#undef MQ_DG_LAUNCH
   MQ_LAUNCH_CHECK("mq_decode_gemv");
   return MQ_OK;
 }

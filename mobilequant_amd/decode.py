@@ -128,6 +128,18 @@ class DecodeEngine:
         self._keep.append(lin)
         return a
 
+    def _pack(self, grids) -> int:
+        """mq_decode_pack_grids: the launch's static grids -> one constants line on the device (no host read-back)."""
+        arr = (MqGrid * len(grids))(*grids)
+        out = torch.zeros(64, device=self.dev)                 # one 256-byte line: every wave reads all 64 floats
+        _lib.call("mq_decode_pack_grids", arr, len(grids), out.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
+        self._keep.append(out)
+        return out.data_ptr()
+
+    def _finish_gemv(self, a: MqDecodeGemvArgs) -> MqDecodeGemvArgs:
+        a.consts = self._pack([a.norm_in, a.a_grid, a.out_grid[0], a.out_grid[1], a.out_grid[2], a.gate_mid, a.gate_actout, a.gate_out])
+        return a
+
     def _lower_layer(self, li, layer):
         s, keep = self.shape, self._keep
         attn, mlp = layer.self_attn, layer.mlp
@@ -142,7 +154,7 @@ class DecodeEngine:
         p1.seg_end[0], p1.seg_end[1] = qkv.rows[0], qkv.rows[0] + qkv.rows[1]
         for k, lin in enumerate((attn.q_proj, attn.k_proj, attn.v_proj)):
             p1.out_grid[k] = _grid(lin.output_quantizer, keep)
-        self.phases.append(("gemv", p1))
+        self.phases.append(("gemv", self._finish_gemv(p1)))
         # (2) attention core
         at = MqDecodeAttentionArgs()
         at.qkv, at.k_cache, at.v_cache = self.qkv.data_ptr(), self.k_cache[li].data_ptr(), self.v_cache[li].data_ptr()
@@ -162,7 +174,7 @@ class DecodeEngine:
         op = _Linear([attn.o_proj], g_o)
         p3 = self._gemv(op, x=self.attn.data_ptr(), a_grid=_grid(g_o, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
         p3.out_grid[0] = _grid(attn.o_proj.output_quantizer, keep)
-        self.phases.append(("gemv", p3))
+        self.phases.append(("gemv", self._finish_gemv(p3)))
         # (4) post_attention_layernorm + interleaved w1|w3 + gated activation + w2's input quantizer
         a2 = MqDecodeGemvArgs()
         g_ffn = self._norm_args(layer.post_attention_layernorm, a2)
@@ -178,12 +190,12 @@ class DecodeEngine:
                         gate_mid=_grid(act.input2_quantizer if isinstance(act, Q.QSiLU) else None, keep),
                         gate_actout=_grid(act.output_quantizer, keep), gate_out=_grid(iq2, keep))
         p4.out_grid[0], p4.out_grid[1] = _grid(mlp.w1.output_quantizer, keep), _grid(mlp.w3.output_quantizer, keep)
-        self.phases.append(("gemv", p4))
+        self.phases.append(("gemv", self._finish_gemv(p4)))
         # (5) w2 from the int8 image + residual
         w2 = _Linear([mlp.w2], iq2)
         p5 = self._gemv(w2, xq=self.gate_q.data_ptr(), a_grid=_grid(iq2, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
         p5.out_grid[0] = _grid(mlp.w2.output_quantizer, keep)
-        self.phases.append(("gemv", p5))
+        self.phases.append(("gemv", self._finish_gemv(p5)))
 
     # -- running -------------------------------------------------------------------------------------------------------------
     def _launch(self):

@@ -71,22 +71,26 @@ def main():
     print(f"{'launch':28s} {'gap':>6s} {'ramp':>6s} | per-WG means since the launch's first stamp (us): s1 s2 s3 s4 s5 | span")
     agg = {}
     for kind, grid, base in entries:
-        s = st[base:base + grid * 8].reshape(grid, 8).astype(np.float64) / 100.0     # us
+        s = st[base:base + grid * 16].reshape(grid, 16).astype(np.float64) / 100.0     # us
         t0 = s[:, 0].min()
         gap = t0 - prev_end if prev_end is not None else float("nan")
         ramp = s[:, 0].max() - t0
         cols = []
-        for k in range(1, 6):
+        for k in (1, 2, 3, 4, 5, 8, 6, 7, 9, 10):
             v = s[:, k][s[:, k] > 0]
             cols.append(v.mean() - t0 if v.size else float("nan"))
+        raw = st[base:base + grid * 16].reshape(grid, 16)
+        ok = (raw[:, 12] > 0) & (raw[:, 11] > 0) & (raw[:, 5] > raw[:, 13])
+        mhz = float(np.mean((raw[ok, 12] - raw[ok, 11]) / ((raw[ok, 5] - raw[ok, 13]) / 100.0))) if ok.any() else float("nan")
         end = s[:, 1:6].max()
         span = end - t0
         prev_end = end
-        agg.setdefault(kind, []).append([gap, ramp] + cols + [span])
+        agg.setdefault(kind, []).append([gap, ramp] + cols + [span, mhz])
     for kind, rows in agg.items():
         r = np.nanmean(np.array(rows[1:] if len(rows) > 1 else rows), axis=0)
-        print(f"{KINDS[kind]:28s} {r[0]:6.2f} {r[1]:6.2f} | " + " ".join(f"{x:6.2f}" for x in r[2:7]) + f" | {r[7]:6.2f}   (n={len(rows)})")
-    tot = sum(np.nansum(np.array(rows)[:, [0, 7]]) for rows in agg.values())
+        print(f"{KINDS[kind]:28s} {r[0]:6.2f} {r[1]:6.2f} | " + " ".join(f"{x:6.2f}" for x in r[2:7]) + f" | {r[12]:6.2f}   (n={len(rows)})"
+              f"  x@w0 {r[8]:.2f} ss-math {r[7]:.2f} wave-sum {r[10]:.2f} [s1] quant-math {r[11]:.2f} [s2]  shader clock {r[13]:.0f} MHz")
+    tot = sum(np.nansum(np.array(rows)[:, [0, 12]]) for rows in agg.values())
     print(f"sum of gaps + spans: {tot:.1f} us")
 
 
