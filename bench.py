@@ -382,9 +382,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
         if p.dim() == 2 and p.shape[0] != shape.vocab:
             p.data = torch.empty(0, device=dev)
     torch.cuda.empty_cache()
-    for c in eng.k_cache + eng.v_cache:                     # a context's worth of cached keys / values
-        c[:, :context].normal_()
-    eng.pos.fill_(context)
+    eng.fill_cache_random(context)                          # a context's worth of cached keys / values
     eng.tok.fill_(17)
     eng.capture()
     for _ in range(3):
@@ -392,7 +390,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
     torch.cuda.synchronize()
     best = float("inf")
     for _ in range(3):
-        eng.pos.fill_(context)
+        eng.set_position(context)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
@@ -401,7 +399,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1) / steps)
     t = best * 1e-3
-    kv_bytes = 22 * 2 * shape.kv_heads * (context + steps // 2) * shape.head_dim * 4
+    kv_bytes = 22 * 2 * shape.kv_heads * (context + steps // 2) * shape.head_dim      # int8 indices
     total = eng.weight_bytes + eng.head_bytes + kv_bytes
     return {"decode_tok_s": round(1.0 / t, 1), "ms_per_token": round(t * 1e3, 4), "context": context,
             "int8_weight_GB_per_token": round(eng.weight_bytes / 1e9, 4), "lm_head_fp32_GB_per_token": round(eng.head_bytes / 1e9, 4),

@@ -341,23 +341,32 @@ typedef struct mq_decode_gemv_args {
 } mq_decode_gemv_args;
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream);
 
-/* Attention of one query token over a static KV cache (hf_model.py:486-534; QMatMul qk_bmm / pv_bmm of qmodule.py:453-466):
- * qkv = [heads*D | kv_heads*D | kv_heads*D] fp32 outputs of the q|k|v phase; RoPE with cos / sin [max_pos, D] (rotate-half) at
- * position *pos (device memory: one captured graph serves every step); k_cache / v_cache [kv_heads, cache_len, D] fp32 hold the
- * post-RoPE keys / the values of positions < *pos ALREADY ON their QMatMul input grids (qk_b / pv_b: the reference re-quantises
- * the cached tensors at every step with static grids, which is idempotent) and receive position *pos; out [heads*D] = pv_bmm's
- * (quantised) output. */
+/* Attention of one query token over a static INTEGER KV cache (hf_model.py:486-534; QMatMul qk_bmm / pv_bmm of qmodule.py:453-466):
+ * qkv = [heads*D | kv_heads*D | kv_heads*D] fp32 outputs of the q|k|v phase; RoPE (rotate-half over the first rot_dim dims; cos /
+ * sin [max_pos, rot_dim]) at position *pos (device memory: one captured graph serves every step; *pos >= cache_len: the launch
+ * does nothing).  k_cache / v_cache [kv_heads, cache_len, D] int8 hold the post-RoPE keys / the values of positions < *pos as
+ * INDICES (index - 128) on their QMatMul input grids (qk_b / pv_b: the reference re-quantises the cached tensors at every step
+ * with static grids, which is idempotent) and receive position *pos.  Both contractions are exact integer sums (as
+ * mq_attention_quant); quantizers in their exact divide form; softmax in fp32.
+ * Outputs: out (nullable) [heads*D] fp32 = pv_bmm's (quantised) output; out_q (nullable) [heads*D] int8 = its index (- 128) on the
+ * consumer linear's input grid o_in (o_proj's int8 image: mq_decode_gemv with xq).
+ * nsplit workgroups per head share the cached positions in 64-position blocks (nsplit > 1: part [nsplit, heads*D] int64 scratch and
+ * ticket [heads] uint32, zeroed once by the caller, self-resetting).  consts: mq_decode_pack_grids of {qk_a, qk_b, qk_out, pv_a, pv_b,
+ * pv_out, o_in} into a 64-float block. */
 typedef struct mq_decode_attention_args {
   const float* qkv;
-  float* k_cache;
-  float* v_cache;
+  int8_t* k_cache;
+  int8_t* v_cache;
   const float* cos;
   const float* sin;
   const int* pos;
-  int heads, kv_heads, head_dim, cache_len;
-  float inv_sqrt_d;
-  mq_grid qk_a, qk_b, qk_out, pv_a, pv_b, pv_out;
+  int heads, kv_heads, head_dim, cache_len, rot_dim, nsplit;
+  mq_grid qk_a, qk_b, qk_out, pv_a, pv_b, pv_out, o_in;
+  const float* consts;
   float* out;
+  int8_t* out_q;
+  long long* part;
+  unsigned* ticket;
 } mq_decode_attention_args;
 int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream);
 

@@ -39,8 +39,10 @@ class MqDecodeGemvArgs(ctypes.Structure):
 class MqDecodeAttentionArgs(ctypes.Structure):
     _fields_ = [("qkv", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p), ("cos", c_void_p), ("sin", c_void_p),
                 ("pos", c_void_p), ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("cache_len", c_int),
-                ("inv_sqrt_d", c_float), ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
-                ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p)]
+                ("rot_dim", c_int), ("nsplit", c_int), ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
+                ("pv_b", MqGrid), ("pv_out", MqGrid), ("o_in", MqGrid), ("consts", c_void_p), ("out", c_void_p), ("out_q", c_void_p),
+                ("part", c_void_p), ("ticket", c_void_p)]
+
 
 class MqAttentionArgs(ctypes.Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("seq", c_int),

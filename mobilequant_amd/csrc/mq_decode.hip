@@ -74,15 +74,31 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// float wave reductions on DPP moves (a __shfl_xor is an LDS round trip of ~100 cycles; six of them in a row cost ~0.25 us of
+// a kernel that lasts 3): same lane pattern as wave_sum_dpp; the result is the value of lane 63, broadcast
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
 }
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ float wave_sum_f(float v) {
+  v += dpp_f<0xB1, 0xf, true>(v);
+  v += dpp_f<0x4E, 0xf, true>(v);
+  v += dpp_f<0x141, 0xf, true>(v);
+  v += dpp_f<0x140, 0xf, true>(v);
+  v += dpp_f<0x142, 0xa, false>(v);                                 // row_bcast15 into rows 1 and 3 (0 elsewhere: x + 0 = x)
+  v += dpp_f<0x143, 0xc, false>(v);                                 // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float v) {              // inputs are finite or -inf, never NaN
+  v = fmaxf(v, dpp_f<0xB1, 0xf, true>(v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf, true>(v));
+  v = fmaxf(v, dpp_f<0x141, 0xf, true>(v));
+  v = fmaxf(v, dpp_f<0x140, 0xf, true>(v));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
+  const float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return fmaxf(fmaxf(r1, r2), fmaxf(r3, r4));
 }
 
 constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 8;
@@ -92,14 +108,14 @@ constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 8;
 #ifdef MQ_DECODE_STAMPS
 #define DG_STAMP(k)                                                                                   \
   do {                                                                                                \
-    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 // stamp of wave `w` once the register `reg` has arrived
 #define DG_STAMP_ARRIVED(k, w, reg)                                                                   \
   do {                                                                                                \
     if (stamps && wave == (w)) {                                                                      \
       asm volatile("" ::"v"(reg));                                                                    \
-      if (lane == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();       \
+      if (lane == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();       \
     }                                                                                                 \
   } while (0)
 #else
@@ -395,160 +411,256 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
 #endif
 }
 
-// ---- attention for ONE query token over a static KV cache -------------------------------------------------------------------------
-// One workgroup (256 threads) per query head.  hf_model.py:486-534 with the QMatMul pair of qmodule.py:453-466:
-//   q, k_new <- RoPE;  cache[pos] <- (k_new, v_new)           (written by the first head of each KV group)
-//   s[t] = Qqk_out( sum_d Qqk_a(q[d]) * Qqk_b(K[t][d]) ) / sqrt(D),   t = 0 .. pos        (the mask admits exactly these)
-//   p = softmax(s)  (fp32)
-//   o[d] = Qpv_out( sum_t Qpv_a(p[t]) * Qpv_b(V[t][d]) )
+// ---- attention for ONE query token over a static INTEGER KV cache ------------------------------------------------------------------
+// hf_model.py:486-534 with the QMatMul pair of qmodule.py:453-466, as the prefill kernel computes it (mq_attention.hip): the two
+// contractions are exact integer sums over the quantizer indices, everything else is the reference's fp32 arithmetic in its exact
+// (divide) form:
+//   q, k_new <- RoPE (rotate-half over the first rot_dim dims);  cache[pos] <- (index of k_new on qk_b, index of v_new on pv_b)
+//   s[t] = Qqk_out( s_q s_k sum_d (iq[d] - zq)(ik[t][d] - zk) ) / sqrt(D),   t = 0 .. pos        (the mask admits exactly these)
+//   p = softmax(s)  (fp32: exp(s - max) / sum)
+//   o[d] = Qpv_out( s_p s_v sum_t (ip[t] - zp)(iv[t][d] - zv) )  ->  index on the consumer linear's input grid (o_proj's int8 image)
+// The cache holds the keys / values as int8 indices (index - 128) ON THEIR QMatMul input grids (qk_bmm.input2, pv_bmm.input2): the
+// reference re-quantises the whole cached tensor at every step with static grids, which is idempotent, so quantising once at append
+// time gives the same numbers -- and a quarter of the bytes.
+// Grid: heads x nsplit workgroups of 256 threads.  Every workgroup of a head computes ALL scores of that head (t x D bytes of keys,
+// bit-identical statistics in every split, no exchange), then the p.v sum over ITS 64-position blocks (b = split, split + nsplit,
+// ...).  nsplit == 1: the workgroup finishes the head.  nsplit > 1: exact int64 partial sums go to `part` with write-through
+// stores, a per-head ticket counts the splits, the last one adds the partials (integers: any order is THE sum) and finishes.
+enum { AG_QK_A = 0, AG_QK_B = 1, AG_QK_OUT = 2, AG_PV_A = 3, AG_PV_B = 4, AG_PV_OUT = 5, AG_O_IN = 6, AG_COUNT = 7 };
+
+// sum over aligned groups of N = 2 / 4 adjacent lanes: DPP quad permutes (a __shfl_xor is an LDS round trip, ~100 cycles each)
+template <int N>
+__device__ __forceinline__ int quad_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);                 // quad_perm [1,0,3,2]
+  if (N == 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  return v;
+}
+
+// D = head_dim (compile time: every index below is a shift).  Scores: LPP lanes per cached position (4; 2 at D = 32), each with CH
+// 16-byte chunks of the key row (LPP * CH * 16 = D); 256 / LPP positions per pass, KB passes in flight.  p.v: a thread owns one dword (4 dims) of the
+// value rows of G = 1024 / D position groups; a 64-position block gives each thread PPB = D / 16 positions.
+template <int D>
 __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_attention_args a, unsigned long long* stamps) {
   DG_STAMP(0);
+  constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = 256 / LPP, KB = 8 / CH;
+  constexpr int DQ = D / 4, G = 256 / DQ, PPB = 64 / G, VB = 16;
+  static_assert(PPB * G == 64 && VB % PPB == 0, "block mapping");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_p = reinterpret_cast<float*>(smem_raw);               // [T] scores / probabilities
-  __shared__ float s_q[256], s_k[256], s_v[256], s_red[4], s_o[4][256];
-  const int D = a.head_dim, h = blockIdx.x, kvh = h / (a.heads / a.kv_heads);
-  const int pos = a.pos[0];
-  const int T = pos + 1;
+  float* s_sc = reinterpret_cast<float*>(smem_raw);              // [cache_len] scores -> exp -> (p index - zp) as int
+  __shared__ __attribute__((aligned(16))) int8_t s_q8[D], s_k8[D], s_v8[D];
+  __shared__ float s_redf[4];
+  __shared__ int s_redq[4];
+  __shared__ long long s_acc[1024];                              // [G][D] partial p.v sums
+  __shared__ unsigned s_ticket;
+  const int H = a.heads, rot = a.rot_dim, nsplit = a.nsplit;
+  const int h = blockIdx.x, c = blockIdx.y, kvh = h / (H / a.kv_heads);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const Grid qa = load_grid(a.qk_a), qb = load_grid(a.qk_b), qo = load_grid(a.qk_out);
-  const Grid pa = load_grid(a.pv_a), pb = load_grid(a.pv_b), po = load_grid(a.pv_out);
+  const float cv = a.consts[lane];
+  const int pos = a.pos[0];
+  // the new token's q / k / v rows (fp32 outputs of the q|k|v launch) and their RoPE partners: independent of the position
   const float* qp = a.qkv + (size_t)h * D;
-  const float* kp = a.qkv + (size_t)a.heads * D + (size_t)kvh * D;
-  const float* vp = a.qkv + (size_t)(a.heads + a.kv_heads) * D + (size_t)kvh * D;
-  float* kc = a.k_cache + (size_t)kvh * a.cache_len * D;
-  float* vc = a.v_cache + (size_t)kvh * a.cache_len * D;
-  if (tid < D) {                                                   // RoPE (rotate-half): x * cos + rot(x) * sin
-    const int half = D >> 1;
-    const float c = a.cos[(size_t)pos * D + tid], s = a.sin[(size_t)pos * D + tid];
-    const float qr = tid < half ? -qp[tid + half] : qp[tid - half];
-    const float kr = tid < half ? -kp[tid + half] : kp[tid - half];
-    const float qv = __fadd_rn(__fmul_rn(qp[tid], c), __fmul_rn(qr, s));
-    const float kv = __fadd_rn(__fmul_rn(kp[tid], c), __fmul_rn(kr, s));
-    // The cache holds the keys / values ON THEIR QMatMul input grids (qk_bmm.input2, pv_bmm.input2): the reference re-quantises
-    // the whole cached tensor at every step (qmodule.py:453-466) with static grids, which is idempotent -- quantising once at
-    // append time gives the same numbers and takes ~2 IEEE divisions per cached element per step out of this kernel.
-    s_q[tid] = qa.fq(qv);
-    s_k[tid] = qb.fq(kv);
-    s_v[tid] = pb.fq(vp[tid]);
-    if (h % (a.heads / a.kv_heads) == 0) {                         // the group's first head appends to the cache
-      kc[(size_t)pos * D + tid] = s_k[tid];
-      vc[(size_t)pos * D + tid] = s_v[tid];
+  const float* kp = a.qkv + (size_t)H * D + (size_t)kvh * D;
+  const float* vp = a.qkv + (size_t)(H + a.kv_heads) * D + (size_t)kvh * D;
+  const int dd = tid < D ? tid : D - 1;
+  const int half = rot >> 1;
+  const int dpart = dd < rot ? (dd < half ? dd + half : dd - half) : dd;
+  const float q_raw = qp[dd], q_par = qp[dpart], k_raw = kp[dd], k_par = kp[dpart], v_raw = vp[dd];
+  if (pos < 0 || pos >= a.cache_len) return;                       // a step past the cache: nothing is read or written (the host raises first)
+  const int T = pos + 1;
+  const int dr = dd < rot ? dd : 0;
+  const float cs = a.cos[(size_t)pos * rot + dr], sn = a.sin[(size_t)pos * rot + dr];
+  const int8_t* kc = a.k_cache + (size_t)kvh * a.cache_len * D;
+  const int8_t* vc = a.v_cache + (size_t)kvh * a.cache_len * D;
+  // ---- key loads of the first batch ------------------------------------------------------------------------------------------------
+  const int sub = tid & (LPP - 1), slot = tid / LPP;
+  v4i kbuf[KB][CH];
+  auto load_keys = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int t = t0 + u * PPP + slot;
+      const int tc = (t < T && t != pos) ? t : 0;                   // position 0 stands in (always valid memory); masked below
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
     }
+  };
+  load_keys(0);
+  // ---- the value loads of this split's first blocks: thread (dq = dword of 4 dims, grp): positions 64 b + grp + G j ------------
+  const int dq = tid & (DQ - 1), grp = tid / DQ;
+  int vbuf[VB];
+  auto item_pos = [&](int i) { return 64 * (c + nsplit * (i / PPB)) + grp + G * (i % PPB); };   // PPB: a power of two (shifts)
+  auto load_values = [&](int i0) {                                   // cached positions t < pos only: the new one stays in registers
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int t = item_pos(i0 + u);
+      vbuf[u] = *reinterpret_cast<const int*>(vc + (size_t)(t < pos ? t : 0) * D + dq * 4);
+    }
+  };
+  load_values(0);
+  // ---- RoPE + the three input quantizers of the new token ---------------------------------------------------------------------------
+  const Grid qa = const_grid(cv, AG_QK_A, a.qk_a), qb = const_grid(cv, AG_QK_B, a.qk_b), qo = const_grid(cv, AG_QK_OUT, a.qk_out);
+  const Grid pa = const_grid(cv, AG_PV_A, a.pv_a), pb = const_grid(cv, AG_PV_B, a.pv_b), po = const_grid(cv, AG_PV_OUT, a.pv_out);
+  const Grid oi = const_grid(cv, AG_O_IN, a.o_in);
+  int qsum_part = 0;
+  if (tid < D) {
+    float qv = q_raw, kv = k_raw;
+    if (tid < rot) {                                               // x * cos + rot(x) * sin, rot(x)[d] = d < rot/2 ? -x[d + rot/2] : x[d - rot/2]
+      const float sg = tid < half ? -1.f : 1.f;                    // (-x) * sin == -(x * sin) exactly
+      qv = __fadd_rn(__fmul_rn(q_raw, cs), __fmul_rn(sg * q_par, sn));
+      kv = __fadd_rn(__fmul_rn(k_raw, cs), __fmul_rn(sg * k_par, sn));
+    }
+    const float iq = dq_index(qv, qa.s, qa.inv_s, qa.o, qa.qmin, qa.qmax), ik = dq_index(kv, qb.s, qb.inv_s, qb.o, qb.qmin, qb.qmax);
+    const float iv = dq_index(v_raw, pb.s, pb.inv_s, pb.o, pb.qmin, pb.qmax);
+    const int sq = (iq != iq ? 0 : (int)iq) - 128, sk = (ik != ik ? 0 : (int)ik) - 128, sv = (iv != iv ? 0 : (int)iv) - 128;
+    s_q8[tid] = (int8_t)sq;
+    s_k8[tid] = (int8_t)sk;
+    s_v8[tid] = (int8_t)sv;
+    qsum_part = sq;
+    if (c == 0 && h % (H / a.kv_heads) == 0) {                     // the group's first head appends to the cache
+      a.k_cache[((size_t)kvh * a.cache_len + pos) * D + tid] = (int8_t)sk;
+      a.v_cache[((size_t)kvh * a.cache_len + pos) * D + tid] = (int8_t)sv;
+    }
+  }
+  {
+    const int w = wave_sum_dpp(qsum_part);
+    if (lane == 0) s_redq[wv] = w;
   }
   __syncthreads();
   DG_STAMP(1);
-  // At M = 1 this kernel is a chain of dependent memory round trips, so every phase issues its loads in bulk: positions are
-  // processed in chunks of 256; a thread holds 16 float4 of keys (4 lanes per position, 64 positions per unit, 4 units) and 16
-  // float4 of values (16 lanes per position row, 16 rows per unit, 16 units) -- and the FIRST chunk's values are requested
-  // before the scores are even started (they do not depend on them).
-  const float inv_sqrt_d = a.inv_sqrt_d;
-  const bool fast = D == 64;                                        // the vectorised mapping (TinyLlama / StableLM heads)
-  const int sub = tid & 3, grp = tid >> 2;                          // keys : lane sub of position grp (+ 64 u)
-  const int vq = tid & 15, vr = tid >> 4;                           // values: float4 column vq of position row vr (+ 16 u)
-  float4 vbuf[16];
-  auto load_values = [&](int c0) {
+  const int qsum = (s_redq[0] + s_redq[1]) + (s_redq[2] + s_redq[3]);
+  const int zq = (int)qa.o - 128, zk = (int)qb.o - 128, zv = (int)pb.o - 128, zp = (int)pa.o;
+  const float alpha_qk = __fmul_rn(qa.s, qb.s), alpha_pv = __fmul_rn(pa.s, pb.s);
+  const int qconst = D * zq * zk - zk * qsum;                      // sum (iq - zq)(ik - zk) = sum sq sk - zk sum sq - zq sum sk + D zq zk
+  constexpr bool pow2 = (D == 64 || D == 256);                     // sqrt(D) a power of two: the divide is an exact multiply
+  const float sqrt_d = __fsqrt_rn((float)D), inv_sqrt_d = 1.0f / (D == 64 ? 8.0f : 16.0f);
+  v4i qf[CH], kn[CH];                                              // this lane's share of the query / of the NEW key (never via memory)
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int t = c0 + 16 * u + vr;
-      vbuf[u] = (t < T && t != pos) ? reinterpret_cast<const float4*>(vc + (size_t)t * D)[vq] : reinterpret_cast<const float4*>(s_v)[vq];
-    }
-  };
-  if (fast) load_values(0);
+  for (int ch = 0; ch < CH; ++ch) {
+    qf[ch] = *reinterpret_cast<const v4i*>(s_q8 + (sub * CH + ch) * 16);
+    kn[ch] = *reinterpret_cast<const v4i*>(s_k8 + (sub * CH + ch) * 16);
+  }
+  const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+  // ---- scores ----------------------------------------------------------------------------------------------------------------------
   float lmax = -INFINITY;
-  if (fast) {
-    for (int c0 = 0; c0 < T; c0 += 256) {
-      float4 kbuf[4][4];
+  for (int t0 = 0; t0 < T; t0 += KB * PPP) {
+    if (t0 > 0) load_keys(t0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = c0 + 64 * u + grp;
-        const float* kr = (t < T && t != pos) ? kc + (size_t)t * D : s_k;     // the new key never makes the round trip through memory
+    for (int u = 0; u < KB; ++u) {
+      if (t0 + u * PPP >= T) break;                                // (uniform) the rest of the batch lies beyond the sequence
+      const int t = t0 + u * PPP + slot;
+      int dot = 0, ks = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kbuf[u][c] = reinterpret_cast<const float4*>(kr + sub * 16)[c];
+      for (int ch = 0; ch < CH; ++ch) {
+        const v4i kf = t == pos ? kn[ch] : kbuf[u][ch];
+        dot = dot16(kf, qf[ch], dot);
+        ks = dot16(kf, ones, ks);
       }
-      const float* q4 = s_q + sub * 16;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = c0 + 64 * u + grp;
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc += q4[4 * c] * kbuf[u][c].x;
-          acc += q4[4 * c + 1] * kbuf[u][c].y;
-          acc += q4[4 * c + 2] * kbuf[u][c].z;
-          acc += q4[4 * c + 3] * kbuf[u][c].w;
-        }
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 1, 64);
-        if (t < T && sub == 0) {
-          const float sc = __fmul_rn(qo.fq(acc), inv_sqrt_d);        // qk_bmm(...) / sqrt(head_dim)  (hf_model.py:513)
-          s_p[t] = sc;
-          lmax = fmaxf(lmax, sc);
-        }
+      dot = quad_sum<LPP>(dot);
+      ks = quad_sum<LPP>(ks);
+      if (t < T && sub == 0) {
+        const int ti = dot - zq * ks + qconst;
+        const float val = __fmul_rn((float)ti, alpha_qk);
+        const float qv = qo.fq(val);
+        const float sc = pow2 ? __fmul_rn(qv, inv_sqrt_d) : __fdiv_rn(qv, sqrt_d);     // qk_bmm(...) / sqrt(head_dim)  (hf_model.py:513)
+        s_sc[t] = sc;
+        lmax = fmaxf(lmax, sc);
       }
-    }
-  } else {                                                          // generic head_dim: one thread per position
-    for (int t = tid; t < T; t += 256) {
-      const float* kr = (t == pos) ? s_k : kc + (size_t)t * D;
-      float acc = 0.f;
-      for (int d = 0; d < D; ++d) acc += s_q[d] * kr[d];
-      const float sc = __fmul_rn(qo.fq(acc), inv_sqrt_d);
-      s_p[t] = sc;
-      lmax = fmaxf(lmax, sc);
     }
   }
   lmax = wave_max_f(lmax);
-  if (lane == 0) s_red[wv] = lmax;
+  if (lane == 0) s_redf[wv] = lmax;
   __syncthreads();
   DG_STAMP(2);
-  const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const float mx = fmaxf(fmaxf(s_redf[0], s_redf[1]), fmaxf(s_redf[2], s_redf[3]));
   __syncthreads();
   float lsum = 0.f;
   for (int t = tid; t < T; t += 256) {
-    const float e = expf(s_p[t] - mx);
-    s_p[t] = e;
+    const float e = expf(s_sc[t] - mx);
+    s_sc[t] = e;
     lsum += e;
   }
   lsum = wave_sum_f(lsum);
-  if (lane == 0) s_red[wv] = lsum;
+  if (lane == 0) s_redf[wv] = lsum;
   __syncthreads();
-  const float inv_sum = __fdiv_rn(1.0f, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
-  for (int t = tid; t < T; t += 256) s_p[t] = pa.fq(__fmul_rn(s_p[t], inv_sum));      // pv_bmm's input quantizer, once per position
+  const float tot_e = (s_redf[0] + s_redf[1]) + (s_redf[2] + s_redf[3]);
+  // pv_bmm's input quantizer, once per position of THIS split's blocks: (index - zp) as int
+  int* s_pi = reinterpret_cast<int*>(s_sc);
+  for (int t = tid; t < T; t += 256) {
+    if (nsplit == 1 || ((t >> 6) % nsplit) == c) {
+      const float p = __fdiv_rn(s_sc[t], tot_e);
+      const float ip = dq_index(p, pa.s, pa.inv_s, pa.o, pa.qmin, pa.qmax);
+      s_pi[t] = (ip != ip ? 0 : (int)ip) - zp;
+    }
+  }
   __syncthreads();
   DG_STAMP(3);
-  float* s_acc = &s_o[0][0];                                        // [16][64] partial outputs (fast path) / [4][256] (generic)
-  if (fast) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c0 = 0; c0 < T; c0 += 256) {
-      if (c0 > 0) load_values(c0);
+  // ---- p.v over this split's blocks: exact integers ------------------------------------------------------------------------------
+  // sum_t pi[t] (vs[t][d] - zv) = sum_t pi[t] vs[t][d] - zv sum_t pi[t]: v_bfe_i32 + v_mad_i32_i24 per element, one add per position
+  long long acc[4] = {0, 0, 0, 0};
+  long long psum = 0;
+  const int nblk = (pos + 63) >> 6;                                  // blocks of CACHED positions 0 .. pos - 1
+  const int my_blocks = c < nblk ? (nblk - 1 - c) / nsplit + 1 : 0;
+  const int items = my_blocks * PPB;
+  for (int i0 = 0; i0 < items; i0 += VB) {
+    if (i0 > 0) load_values(i0);
+    int a32[4] = {0, 0, 0, 0}, p32 = 0;                              // <= 16 positions x 65535 x 128 < 2^31
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int t = c0 + 16 * u + vr;
-        if (t < T) {
-          const float p = s_p[t];
-          acc.x += p * vbuf[u].x;
-          acc.y += p * vbuf[u].y;
-          acc.z += p * vbuf[u].z;
-          acc.w += p * vbuf[u].w;
-        }
-      }
-    }
-    reinterpret_cast<float4*>(s_acc + vr * 64)[vq] = acc;
-    __syncthreads();
-    DG_STAMP(4);
-    if (tid < 64) {
-      float tot = 0.f;
+    for (int u = 0; u < VB; ++u) {
+      const int t = item_pos(i0 + u);
+      const bool ok = i0 + u < items && t < pos;
+      const int pi = s_pi[ok ? t : 0];
+      const int pim = ok ? pi : 0;
+      p32 += pim;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot += s_acc[r * 64 + tid];
-      a.out[(size_t)h * D + tid] = po.fq(tot);
+      for (int e = 0; e < 4; ++e) a32[e] += (int)__builtin_amdgcn_sbfe(vbuf[u], 8 * e, 8) * pim;      // (the builtin returns unsigned)
     }
-  } else {
-    for (int d = lane; d < D; d += 64) {
-      float acc = 0.f;
-      for (int t = wv; t < T; t += 4) acc += s_p[t] * ((t == pos) ? s_v[d] : vc[(size_t)t * D + d]);
-      s_o[wv][d] = acc;
-    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += a32[e];
+    psum += p32;
+  }
+  if (grp == 0 && ((pos >> 6) % nsplit) == c) {                      // the new position: its split's group 0 adds it from registers
+    const int sv4 = *reinterpret_cast<const int*>(s_v8 + dq * 4);
+    const int pi = s_pi[pos];
+    psum += pi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += (long long)((int)__builtin_amdgcn_sbfe(sv4, 8 * e, 8) * pi);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] -= (long long)zv * psum;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s_acc[grp * D + dq * 4 + e] = acc[e];
+  __syncthreads();
+  DG_STAMP(4);
+  long long tot = 0;
+  if (tid < D) {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) tot += s_acc[gq * D + tid];
+  }
+  if (nsplit > 1) {
+    // publish this split's exact partial sums write-through, count the head's splits; the last one adds them (cdna guide G16 R1)
+    if (tid < D) __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.part) + ((size_t)c * H + h) * D + tid, (unsigned long long)tot,
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < D) a.out[(size_t)h * D + tid] = po.fq((s_o[0][tid] + s_o[1][tid]) + (s_o[2][tid] + s_o[3][tid]));
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.ticket + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)(nsplit - 1)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) __hip_atomic_store(a.ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (tid < D) {
+      tot = 0;
+      for (int cc = 0; cc < nsplit; ++cc)
+        tot += (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(a.part) + ((size_t)cc * H + h) * D + tid, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tid < D) {
+    const float pre = (float)((double)tot * (double)alpha_pv);     // one rounding of the exact sum (as mq_attention.hip)
+    const float y = po.fq(pre);
+    if (a.out) a.out[(size_t)h * D + tid] = y;
+    if (a.out_q) {
+      const float qi = dq_index(y, oi.s, oi.inv_s, oi.o, oi.qmin, oi.qmax);
+      a.out_q[(size_t)h * D + tid] = (int8_t)((qi != qi ? (int)oi.qmin : (int)qi) - 128);
+    }
   }
 #ifdef MQ_DECODE_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -692,11 +804,38 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
 int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_decode_attention: null argument block");
   const mq_decode_attention_args& a = *args;
-  MQ_REQUIRE(a.qkv && a.k_cache && a.v_cache && a.cos && a.sin && a.pos && a.out, "mq_decode_attention: null pointer");
-  MQ_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0 && a.head_dim >= 16 && a.head_dim <= 256 && a.head_dim % 16 == 0 &&
-                 a.cache_len > 0 && a.cache_len <= 16384,
-             "mq_decode_attention: heads=%d kv_heads=%d head_dim=%d cache_len=%d", a.heads, a.kv_heads, a.head_dim, a.cache_len);
-  decode_attention_kernel<<<(unsigned)a.heads, 256, (size_t)a.cache_len * sizeof(float), as_stream(stream)>>>(a, STAMP_SLOT(4, (unsigned)a.heads));
+  MQ_REQUIRE(a.qkv && a.k_cache && a.v_cache && a.cos && a.sin && a.pos && a.consts && (a.out || a.out_q), "mq_decode_attention: null pointer");
+  MQ_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0 && (a.head_dim == 32 || a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256) &&
+                 a.cache_len > 0 && a.cache_len <= 32768 && a.rot_dim > 0 && a.rot_dim <= a.head_dim && a.rot_dim % 2 == 0,
+             "mq_decode_attention: heads=%d kv_heads=%d head_dim=%d (32 / 64 / 128 / 256) cache_len=%d (<= 32768) rot_dim=%d", a.heads, a.kv_heads, a.head_dim,
+             a.cache_len, a.rot_dim);
+  MQ_REQUIRE(a.nsplit >= 1 && a.nsplit <= 16 && (a.nsplit == 1 || (a.part && a.ticket)), "mq_decode_attention: nsplit=%d (1..16; > 1 needs part and ticket)", a.nsplit);
+  MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmin == 0.f && a.qk_a.qmax == 255.f && a.qk_b.qmin == 0.f &&
+                 a.qk_b.qmax == 255.f && a.pv_b.qmin == 0.f && a.pv_b.qmax == 255.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
+             "mq_decode_attention: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
+  MQ_REQUIRE(!a.out_q || (a.o_in.scale && a.o_in.qmin == 0.f && a.o_in.qmax == 255.f), "mq_decode_attention: the int8 output image needs the consumer's 8-bit unsigned grid (o_in)");
+  MQ_REQUIRE(aligned(a.k_cache, 16) && aligned(a.v_cache, 16) && aligned(a.consts, 16) && aligned(a.qkv, 4), "mq_decode_attention: caches / consts must be 16-byte aligned");
+  const size_t lds = (size_t)a.cache_len * sizeof(float);
+  const void* fn = a.head_dim == 32 ? reinterpret_cast<const void*>(decode_attention_kernel<32>)
+                   : a.head_dim == 64 ? reinterpret_cast<const void*>(decode_attention_kernel<64>)
+                   : a.head_dim == 128 ? reinterpret_cast<const void*>(decode_attention_kernel<128>)
+                                       : reinterpret_cast<const void*>(decode_attention_kernel<256>);
+  static std::atomic<size_t> lds_set[kMaxDevices][4];
+  const int dev = current_device(), ki = a.head_dim == 32 ? 0 : a.head_dim == 64 ? 1 : a.head_dim == 128 ? 2 : 3;
+  if (lds > 32768 && lds_set[dev][ki].load(std::memory_order_relaxed) < lds) {
+    MQ_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+               "mq_decode_attention: %zu bytes of dynamic LDS rejected", lds);
+    lds_set[dev][ki].store(lds, std::memory_order_relaxed);
+  }
+  const dim3 grid((unsigned)a.heads, (unsigned)a.nsplit);
+  unsigned long long* stamps = STAMP_SLOT(4, grid.x * grid.y);
+  hipStream_t st = as_stream(stream);
+  switch (a.head_dim) {
+    case 32: decode_attention_kernel<32><<<grid, 256, lds, st>>>(a, stamps); break;
+    case 64: decode_attention_kernel<64><<<grid, 256, lds, st>>>(a, stamps); break;
+    case 128: decode_attention_kernel<128><<<grid, 256, lds, st>>>(a, stamps); break;
+    default: decode_attention_kernel<256><<<grid, 256, lds, st>>>(a, stamps); break;
+  }
   MQ_LAUNCH_CHECK("mq_decode_attention");
   return MQ_OK;
 }

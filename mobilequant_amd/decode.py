@@ -18,7 +18,6 @@ qk_bmm output, pv_bmm input).
 from __future__ import annotations
 
 import ctypes
-import math
 from typing import List, Optional
 
 import torch
@@ -43,9 +42,31 @@ class _Linear:
     """Integer image of one or several QLinears that read the same activation grid: weights [N, K] int8 (index - 128) and the
     per-row epilogue vectors for that grid, concatenated (q|k|v) or row-interleaved (w1|w3)."""
 
+    @staticmethod
+    def _check(lin: Q.QLinear):
+        """The conditions QLinear._int8_ready / the gated-MLP pass put on a linear before its integer path may stand in for the
+        module: what they reject, the engine must not silently compute differently (qmodule.py:341-358 is the contract)."""
+        wq, name = lin.weight_quantizer, type(lin).__name__
+        if lin.int8_mode == "off":
+            raise RuntimeError(f"DecodeEngine: {name}.int8_mode == 'off' asks for the simulated path")
+        if wq is None or wq.bypassed() or wq.qcfg.bitwidth > 8 or wq.qcfg.is_dynamic or wq.lwc:
+            raise RuntimeError("DecodeEngine: weight quantizers must be static, <= 8 bit and not in LWC mode (run the PTQ to its end first)")
+        if wq.qcfg.is_per_channel and wq.qcfg.group_size != -1:
+            raise RuntimeError("DecodeEngine: grouped per-channel weight quantizers are not served by the integer kernels")
+        if lin.use_temporary_parameter or getattr(lin, "temp_weight", None) is not None:
+            raise RuntimeError("DecodeEngine: fold the LET parameters first (smooth_lm_inplace): temp_weight / use_temporary_parameter is set")
+        if lin.input_chan_scale is not None:
+            raise RuntimeError("DecodeEngine: fold the run-time SmoothQuant channel scale into the weights first (smoothquant.smooth_lm)")
+        for role in ("input_quantizer", "output_quantizer"):
+            q = getattr(lin, role)
+            if q is not None and not q.bypassed() and not Q._static_per_tensor(q, 16):
+                raise RuntimeError(f"DecodeEngine: {role} must be a static per-tensor grid of at most 16 bits")
+
     def __init__(self, linears: List[Q.QLinear], a_grid: Q.Quantizer, interleave: bool = False):
         ws, alphas, zps, cts, biases = [], [], [], [], []
-        bits = {lin.weight_quantizer.qcfg.bitwidth if lin.weight_quantizer is not None else None for lin in linears}
+        for lin in linears:
+            self._check(lin)
+        bits = {lin.weight_quantizer.qcfg.bitwidth for lin in linears}
         if len(bits) != 1 or not bits <= {4, 8}:
             raise RuntimeError("DecodeEngine: the linears of one phase need the same 8- or 4-bit weight quantizer width")
         self.w4 = bits == {4}
@@ -69,7 +90,7 @@ class _Linear:
 
 
 class DecodeEngine:
-    def __init__(self, model, cache_len: int = 2048):
+    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None):
         from .llama import LlamaForCausalLM
         assert isinstance(model, LlamaForCausalLM)
         self.model, self.shape = model, model.shape
@@ -79,13 +100,20 @@ class DecodeEngine:
         self._keep: list = []
         self.x = torch.zeros(s.hidden, device=dev)
         self.qkv = torch.zeros((s.heads + 2 * s.kv_heads) * s.head_dim, device=dev)
-        self.attn = torch.zeros(s.heads * s.head_dim, device=dev)
+        self.attn_q = torch.zeros(s.heads * s.head_dim, dtype=torch.int8, device=dev)     # pv_bmm's output as o_proj's int8 image
+        # workgroups per head in the attention launch (64-position blocks interleaved over them)
+        self.attn_splits = int(attn_splits) if attn_splits else 1
+        assert 1 <= self.attn_splits <= 16
+        self.attn_part = torch.zeros(self.attn_splits, s.heads * s.head_dim, dtype=torch.int64, device=dev)
+        self.attn_ticket = torch.zeros(s.heads, dtype=torch.int32, device=dev)
         self.gate_q = torch.zeros(s.ffn, dtype=torch.int8, device=dev)
         self.logits = torch.zeros(s.vocab, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.tok = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.k_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, device=dev) for _ in model.layers]
-        self.v_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, device=dev) for _ in model.layers]
+        # keys / values as int8 indices (index - 128) on qk_bmm.input2 / pv_bmm.input2's grids
+        self.k_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
+        self.v_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
+        self._host_pos = 0                                   # mirror of self.pos for the cache-overflow guard (no device read-back)
         self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
         assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
         self.embed = model.embed_tokens.weight.detach()
@@ -160,19 +188,23 @@ class DecodeEngine:
         at.qkv, at.k_cache, at.v_cache = self.qkv.data_ptr(), self.k_cache[li].data_ptr(), self.v_cache[li].data_ptr()
         at.cos, at.sin, at.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
         at.heads, at.kv_heads, at.head_dim, at.cache_len = s.heads, s.kv_heads, s.head_dim, self.cache_len
-        at.inv_sqrt_d = 1.0 / math.sqrt(s.head_dim)
+        at.rot_dim, at.nsplit = self.cos.shape[1], self.attn_splits
         qk, pv = attn.qk_bmm, attn.pv_bmm
         at.qk_a, at.qk_b, at.qk_out = (_grid(q, keep) for q in (qk.input_quantizer, qk.input2_quantizer, qk.output_quantizer))
         at.pv_a, at.pv_b, at.pv_out = (_grid(q, keep) for q in (pv.input_quantizer, pv.input2_quantizer, pv.output_quantizer))
-        at.out = self.attn.data_ptr()
-        self.phases.append(("attn", at))
-        # (3) o_proj + residual: its input sits on pv_bmm's output grid (the live producer), else on its declared / own grid
+        # o_proj's input sits on pv_bmm's output grid (the live producer), else on its declared / own grid: the attention launch
+        # writes pv_bmm's output straight as o_proj's int8 image on that grid
         g_o = attn.o_proj.input_quantizer if attn.o_proj.input_quantizer is not None else (
             pv.output_quantizer if Q._static_per_tensor(pv.output_quantizer, 8) else attn.o_proj._input_grid)
         if g_o is None or g_o.qmax != 255:
             raise RuntimeError("DecodeEngine: o_proj needs an 8-bit unsigned input grid (pv_bmm output)")
+        at.o_in = _grid(g_o, keep)
+        at.out_q, at.part, at.ticket = self.attn_q.data_ptr(), self.attn_part.data_ptr(), self.attn_ticket.data_ptr()
+        at.consts = self._pack([at.qk_a, at.qk_b, at.qk_out, at.pv_a, at.pv_b, at.pv_out, at.o_in])
+        self.phases.append(("attn", at))
+        # (3) o_proj + residual from the int8 image
         op = _Linear([attn.o_proj], g_o)
-        p3 = self._gemv(op, x=self.attn.data_ptr(), a_grid=_grid(g_o, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
+        p3 = self._gemv(op, xq=self.attn_q.data_ptr(), a_grid=_grid(g_o, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
         p3.out_grid[0] = _grid(attn.o_proj.output_quantizer, keep)
         self.phases.append(("gemv", self._finish_gemv(p3)))
         # (4) post_attention_layernorm + interleaved w1|w3 + gated activation + w2's input quantizer
@@ -209,7 +241,8 @@ class DecodeEngine:
 
     def capture(self):
         """Record one decode step (incl. the position increment) as a hipGraph; replay it with step()."""
-        tok0, pos0 = self.tok.clone(), self.pos.clone()
+        tok0, pos0, hp0 = self.tok.clone(), self.pos.clone(), self._host_pos
+        self.attn_ticket.zero_()
         with torch.cuda.device(self.dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -221,11 +254,26 @@ class DecodeEngine:
                 self._launch()
                 self.pos.add_(1)
         self.tok.copy_(tok0); self.pos.copy_(pos0)
+        self._host_pos = hp0
         self.graph = g
         return self
 
+    def set_position(self, pos: int):
+        """Continue from a cache that already holds `pos` positions (benchmarks; prefill() and reset() call this)."""
+        assert 0 <= int(pos) <= self.cache_len
+        self.pos.fill_(int(pos))
+        self._host_pos = int(pos)
+
+    def fill_cache_random(self, n: int, seed: int = 0):
+        """Benchmark helper: n positions of random cached indices."""
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        for c in self.k_cache + self.v_cache:
+            c[:, :n] = torch.randint(-128, 128, c[:, :n].shape, generator=g, device=self.dev, dtype=torch.int8)
+        self.set_position(n)
+
     def reset(self):
-        self.pos.zero_()
+        self.set_position(0)
+        self.attn_ticket.zero_()
         for c in self.k_cache + self.v_cache:
             c.zero_()
 
@@ -233,6 +281,8 @@ class DecodeEngine:
     def step(self, token: Optional[int] = None) -> torch.Tensor:
         """One token in, logits [vocab] out (device tensor, overwritten by the next step); the position advances by one.
         token None: use the token already sitting in self.tok (e.g. written by a device-side argmax)."""
+        if self._host_pos >= self.cache_len:            # the kernels also refuse (they do nothing past the cache); fail loudly here
+            raise RuntimeError(f"DecodeEngine.step: the KV cache is full ({self.cache_len} positions); reset() or build a longer cache")
         if token is not None:
             self.tok.fill_(int(token))
         if self.graph is not None:
@@ -241,6 +291,7 @@ class DecodeEngine:
             with torch.cuda.device(self.dev):
                 self._launch()
             self.pos.add_(1)
+        self._host_pos += 1
         return self.logits
 
     @torch.no_grad()
@@ -256,9 +307,9 @@ class DecodeEngine:
         logits = self.model(ids, cache=raw)
         for li, layer in enumerate(self.model.layers):
             att = layer.self_attn
-            self.k_cache[li][:, :S] = Q._apply(att.qk_bmm.input2_quantizer, raw[li][0][0])
-            self.v_cache[li][:, :S] = Q._apply(att.pv_bmm.input2_quantizer, raw[li][1][0])
-        self.pos.fill_(S)
+            self.k_cache[li][:, :S] = att.qk_bmm.input2_quantizer.quantize_to_int(raw[li][0][0].contiguous())[0]
+            self.v_cache[li][:, :S] = att.pv_bmm.input2_quantizer.quantize_to_int(raw[li][1][0].contiguous())[0]
+        self.set_position(S)
         self.logits.copy_(logits[0, -1])
         return self.logits
 

@@ -510,14 +510,25 @@ def rope_rotate_half(x, cos, sin):
     return (x * cos.astype(F32)).astype(F32) + (rot * sin.astype(F32)).astype(F32)
 
 
+def rope_partial(x, cos, sin):
+    """Partial rotary embedding (hf_model.py:489-500): cos / sin [S, rot] with rot < D rotate the first rot dims of x [..., S, D],
+    the rest passes through; rot == D is the plain rotate-half form (hf_model.py:487)."""
+    rot = cos.shape[-1]
+    x = np.asarray(x, dtype=F32)
+    if rot == x.shape[-1]:
+        return rope_rotate_half(x, cos, sin)
+    return np.concatenate((rope_rotate_half(x[..., :rot], cos, sin), x[..., rot:]), axis=-1)
+
+
 def attention_sim(q, k, v, cos, sin, heads, kv_heads, qk: tuple, pv: tuple):
     """Causal prefill attention of one sequence as the reference computes it: q [S, heads*D], k / v [S, kv_heads*D] projection
-    outputs; RoPE; repeat_kv (hf_model.py:509-510); qk_bmm (a QMatMul: qk = (input, input2, output) QuantizerOracles) / sqrt(D);
-    + causal mask; fp32 softmax; pv_bmm (pv = its three quantizers).  Returns [S, heads*D] (the layout o_proj reads)."""
+    outputs; RoPE (cos / sin [S, rot_dim]: full or partial, hf_model.py:486-500); repeat_kv (hf_model.py:509-510); qk_bmm (a QMatMul:
+    qk = (input, input2, output) QuantizerOracles) / sqrt(D); + causal mask; fp32 softmax; pv_bmm (pv = its three quantizers).
+    Returns [S, heads*D] (the layout o_proj reads)."""
     S = q.shape[0]
     D = q.shape[1] // heads
-    qh = rope_rotate_half(np.asarray(q, F32).reshape(S, heads, D).transpose(1, 0, 2), cos, sin)
-    kh = rope_rotate_half(np.asarray(k, F32).reshape(S, kv_heads, D).transpose(1, 0, 2), cos, sin)
+    qh = rope_partial(np.asarray(q, F32).reshape(S, heads, D).transpose(1, 0, 2), cos, sin)
+    kh = rope_partial(np.asarray(k, F32).reshape(S, kv_heads, D).transpose(1, 0, 2), cos, sin)
     vh = np.asarray(v, F32).reshape(S, kv_heads, D).transpose(1, 0, 2)
     rep = heads // kv_heads
     kh, vh = np.repeat(kh, rep, axis=0), np.repeat(vh, rep, axis=0)

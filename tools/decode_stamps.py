@@ -36,15 +36,14 @@ def build_engine(dev, layers, wbits=8, cache_len=1024):
             if "qk_bmm" in name: mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name: mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    return DecodeEngine(model, cache_len=cache_len)
+    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')))
 
 
 def main():
     dev = torch.device("cuda:0")
     layers, context, wbits = int(os.environ.get("LAYERS", "4")), int(os.environ.get("CONTEXT", "256")), int(os.environ.get("WBITS", "8"))
     eng = build_engine(dev, layers, wbits)
-    for c in eng.k_cache + eng.v_cache: c[:, :context].normal_()
-    eng.pos.fill_(context); eng.tok.fill_(17)
+    eng.fill_cache_random(context); eng.tok.fill_(17)
     lib = _lib.load()
     if not hasattr(lib, "mq_decode_set_stamps_"):
         sys.exit("this library was built without -DMQ_DECODE_STAMPS")
@@ -64,7 +63,7 @@ def main():
     for _ in range(32): eng.graph.replay()
     e1.record(); e1.synchronize()
     print(f"graph ms/token {e0.elapsed_time(e1) / 32:.4f}  layers {layers} context {context} W{wbits} (stamped build: ~+0.1 us per launch)")
-    buf.zero_(); eng.pos.fill_(context)
+    buf.zero_(); eng.set_position(context)
     eng.graph.replay(); torch.cuda.synchronize()
     st = buf.cpu().numpy().astype(np.int64)
     prev_end = None

@@ -26,21 +26,20 @@ for name, mod in model.named_modules():
         if "qk_bmm" in name: mod.output_quantizer.qcfg.bitwidth = 16
         if "pv_bmm" in name: mod.input_quantizer.qcfg.bitwidth = 16
 mq.set_scale_and_offset(model, act, "buffer")
-eng = DecodeEngine(model, cache_len=1024)
-for c in eng.k_cache + eng.v_cache: c[:, :256].normal_()
-eng.pos.fill_(256); eng.tok.fill_(17)
+eng = DecodeEngine(model, cache_len=1024, attn_splits=int(os.environ.get('SPLITS', '1')))
+eng.fill_cache_random(256); eng.tok.fill_(17)
 for _ in range(3): eng.step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(20): eng.step()
 torch.cuda.synchronize()
 print("eager ms/token", (time.perf_counter() - t0) / 20 * 1e3)
-eng.pos.fill_(256)
+eng.set_position(256)
 eng.capture()
 for _ in range(3): eng.step()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-eng.pos.fill_(256); e0.record()
+eng.set_position(256); e0.record()
 for _ in range(64): eng.graph.replay()
 e1.record(); e1.synchronize()
 print("graph ms/token", e0.elapsed_time(e1) / 64, "layers", layers)
