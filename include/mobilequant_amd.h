@@ -340,6 +340,9 @@ typedef struct mq_decode_gemv_args {
                         * which grids are present (scale != NULL) and carry qmin / qmax */
 } mq_decode_gemv_args;
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream);
+/* How mq_decode_gemv spreads a launch's weight rows over its workgroups: workgroup b reads bytes [b, b + 1) * bytes_per_workgroup of
+ * the weight image (for mq_decode_attention's L2 prefetch rows). */
+int mq_decode_gemv_geometry(const mq_decode_gemv_args* args, int64_t* workgroups, int64_t* bytes_per_workgroup, int64_t* total_bytes);
 
 /* Attention of one query token over a static INTEGER KV cache (hf_model.py:486-534; QMatMul qk_bmm / pv_bmm of qmodule.py:453-466):
  * qkv = [heads*D | kv_heads*D | kv_heads*D] fp32 outputs of the q|k|v phase; RoPE (rotate-half over the first rot_dim dims; cos /
@@ -367,6 +370,13 @@ typedef struct mq_decode_attention_args {
   int8_t* out_q;
   long long* part;
   unsigned* ticket;
+  /* optional L2 prefetch rows (prefetch_wgs = 0: none): prefetch_wgs extra workgroups of this launch read the first
+   * prefetch_bytes_per_wg bytes of every prefetch_stride-byte piece of prefetch[0, prefetch_total) -- the weights of a LATER
+   * mq_decode_gemv launch, piece b = what its workgroup b reads (mq_decode_gemv_geometry) -- into the XCDs' L2s while the attention
+   * leaves the memory fabric idle, starting prefetch_delay x 10 ns into the launch.  Never affects results. */
+  const int8_t* prefetch;
+  int64_t prefetch_bytes_per_wg, prefetch_stride, prefetch_total;
+  int prefetch_wgs, prefetch_delay;
 } mq_decode_attention_args;
 int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream);
 

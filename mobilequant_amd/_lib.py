@@ -41,7 +41,8 @@ class MqDecodeAttentionArgs(ctypes.Structure):
                 ("pos", c_void_p), ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("cache_len", c_int),
                 ("rot_dim", c_int), ("nsplit", c_int), ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
                 ("pv_b", MqGrid), ("pv_out", MqGrid), ("o_in", MqGrid), ("consts", c_void_p), ("out", c_void_p), ("out_q", c_void_p),
-                ("part", c_void_p), ("ticket", c_void_p)]
+                ("part", c_void_p), ("ticket", c_void_p), ("prefetch", c_void_p), ("prefetch_bytes_per_wg", c_int64),
+                ("prefetch_stride", c_int64), ("prefetch_total", c_int64), ("prefetch_wgs", c_int), ("prefetch_delay", c_int)]
 
 
 class MqAttentionArgs(ctypes.Structure):
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "mq_w4a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
     "mq_decode_pack_grids": (c_int, [POINTER(MqGrid), c_int, _P, _P]),
     "mq_decode_gemv": (c_int, [POINTER(MqDecodeGemvArgs), _P]),
+    "mq_decode_gemv_geometry": (c_int, [POINTER(MqDecodeGemvArgs), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
     "mq_decode_head": (c_int, [_P, _P, c_float, _P, _P, c_int64, c_int64, _P, _P]),
     "mq_attention_quant": (c_int, [POINTER(MqAttentionArgs), _P]),

@@ -101,7 +101,7 @@ __device__ __forceinline__ float wave_max_f(float v) {              // inputs ar
   return fmaxf(fmaxf(r1, r2), fmaxf(r3, r4));
 }
 
-constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 8;
+constexpr int DG_THREADS = 1024, DG_WAVES = 16, DG_INFLIGHT = 12;   // 12: the w1|w3 launch (22 row pairs per CU over 8 stream waves: 3 x 4 chunks per lane) has every load in flight at once
 
 // Profiling builds (-DMQ_DECODE_STAMPS, tools/decode_stamps.py): every workgroup leaves s_memrealtime stamps (100 MHz, one clock for
 // the whole chip) at its phase boundaries.  Production builds compile the stamps out; the pointer argument stays null.
@@ -441,7 +441,6 @@ __device__ __forceinline__ int quad_sum(int v) {
 // value rows of G = 1024 / D position groups; a 64-position block gives each thread PPB = D / 16 positions.
 template <int D>
 __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_attention_args a, unsigned long long* stamps) {
-  DG_STAMP(0);
   constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = 256 / LPP, KB = 8 / CH;
   constexpr int DQ = D / 4, G = 256 / DQ, PPB = 64 / G, VB = 16;
   static_assert(PPB * G == 64 && VB % PPB == 0, "block mapping");
@@ -453,6 +452,36 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
   __shared__ long long s_acc[1024];                              // [G][D] partial p.v sums
   __shared__ unsigned s_ticket;
   const int H = a.heads, rot = a.rot_dim, nsplit = a.nsplit;
+  if ((int)blockIdx.y >= nsplit) {
+    // ---- L2 prefetch role (grid rows behind the attention's): this launch keeps 32 .. 128 of 256 CUs busy and moves a few hundred
+    // KB, so the memory fabric idles for its whole duration -- and the w1|w3 launch two steps down the chain is the step's biggest
+    // stream (23 MB, 4 us at the fabric's ~5.5 TB/s).  Workgroup q of these rows reads exactly what workgroup (q + first) % n of that
+    // launch will read, with default-policy loads, into the L2 of the XCD both run on under the observed (linear id % 8) placement:
+    // speed only, never correctness.  Tried first as a kernel on a parallel graph branch: the cross-queue dependencies cost 3 - 14 us
+    // per edge (1.28 ms / token instead of 0.68); rows of the SAME launch cost nothing.
+    const int q = ((int)blockIdx.y - nsplit) * H + (int)blockIdx.x;
+    if (q >= a.prefetch_wgs) return;
+    // the attention workgroups' own requests (position -> cos / sin, keys, values: a dependent chain) go first: this stream starts
+    // prefetch_delay x 10 ns into the launch (measured without it: the attention's first data arrived 2.3 us late)
+    const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() + (unsigned long long)a.prefetch_delay;
+    while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(8);
+    const int gwg = (q + nsplit * H) % a.prefetch_wgs;             // same linear id % 8 as this workgroup when prefetch_wgs % 8 == 0
+    const size_t beg = (size_t)gwg * a.prefetch_stride;
+    const size_t end = beg + a.prefetch_bytes_per_wg < a.prefetch_total ? beg + a.prefetch_bytes_per_wg : a.prefetch_total;
+    const v4i* p = reinterpret_cast<const v4i*>(a.prefetch + beg);
+    const size_t n = end > beg ? (end - beg) >> 4 : 0;
+    v4i acc = {0, 0, 0, 0};
+    for (size_t i = threadIdx.x; i < n; i += 256 * 8) {
+      v4i b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = p[i + (size_t)u * 256 < n ? i + (size_t)u * 256 : i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc |= b[u];
+    }
+    asm volatile("" ::"v"(acc));
+    return;
+  }
+  DG_STAMP(0);
   const int h = blockIdx.x, c = blockIdx.y, kvh = h / (H / a.kv_heads);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float cv = a.consts[lane];
@@ -749,6 +778,35 @@ int mq_decode_pack_grids(const mq_grid* grids, int n, float* consts, mq_stream_t
   return MQ_OK;
 }
 
+static int decode_gemv_geometry(const mq_decode_gemv_args& g, int* rows_per_wg, unsigned* grid) {
+  static std::atomic<int> cus_of[kMaxDevices];
+  const int dev = current_device();
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
+  if (!cus) {
+    hipDeviceProp_t prop;
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus_of[dev].store(cus, std::memory_order_relaxed);
+  }
+  const int NL = g.gate_q ? g.N / 2 : g.N;
+  int rpw = (NL + cus - 1) / cus;
+  if (rpw > DG_STR * 64) rpw = DG_STR * 64;
+  *rows_per_wg = rpw;
+  *grid = (unsigned)((NL + rpw - 1) / rpw);
+  return NL;
+}
+
+int mq_decode_gemv_geometry(const mq_decode_gemv_args* args, int64_t* workgroups, int64_t* bytes_per_workgroup, int64_t* total_bytes) {
+  MQ_REQUIRE(args && workgroups && bytes_per_workgroup && total_bytes && args->K > 0 && args->N > 0, "mq_decode_gemv_geometry: null / empty argument");
+  int rpw;
+  unsigned grid;
+  decode_gemv_geometry(*args, &rpw, &grid);
+  const int64_t row = (int64_t)(args->gate_q ? 2 : 1) * (args->w4 ? args->K / 2 : args->K);
+  *workgroups = grid;
+  *bytes_per_workgroup = rpw * row;
+  *total_bytes = (int64_t)args->N * (args->w4 ? args->K / 2 : args->K);
+  return MQ_OK;
+}
+
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_decode_gemv: null argument block");
   const mq_decode_gemv_args& g = *args;
@@ -765,18 +823,9 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   MQ_REQUIRE(!gate || (g.norm_w && !g.xq), "mq_decode_gemv: gate mode is served for the norm-fused prologue (fp32 x + norm_w)");
   MQ_REQUIRE(!gate || (g.N % 2 == 0 && g.gate_out.scale && g.out_grid[0].scale && g.out_grid[1].scale && (g.gate_act == 0 || g.gate_act == 1)),
              "mq_decode_gemv: gate mode needs an even N (interleaved w1 / w3 rows), both output grids and the w2 input grid");
-  static std::atomic<int> cus_of[kMaxDevices];
-  const int dev = current_device();
-  int cus = cus_of[dev].load(std::memory_order_relaxed);
-  if (!cus) {
-    hipDeviceProp_t prop;
-    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    cus_of[dev].store(cus, std::memory_order_relaxed);
-  }
-  const int NL = gate ? g.N / 2 : g.N;
-  int rows_per_wg = (NL + cus - 1) / cus;
-  if (rows_per_wg > DG_STR * 64) rows_per_wg = DG_STR * 64;
-  const unsigned grid = (unsigned)((NL + rows_per_wg - 1) / rows_per_wg);
+  int rows_per_wg;
+  unsigned grid;
+  decode_gemv_geometry(g, &rows_per_wg, &grid);
   const size_t lds = (size_t)g.K + 64;
   hipStream_t st = as_stream(stream);
   unsigned long long* stamps = STAMP_SLOT(gate ? 1 : (g.norm_w ? 0 : (g.xq ? 3 : 2)), grid);
@@ -827,8 +876,12 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
                "mq_decode_attention: %zu bytes of dynamic LDS rejected", lds);
     lds_set[dev][ki].store(lds, std::memory_order_relaxed);
   }
-  const dim3 grid((unsigned)a.heads, (unsigned)a.nsplit);
-  unsigned long long* stamps = STAMP_SLOT(4, grid.x * grid.y);
+  MQ_REQUIRE(a.prefetch_wgs == 0 || (a.prefetch && aligned(a.prefetch, 16) && a.prefetch_bytes_per_wg % 16 == 0 && a.prefetch_wgs > 0 && a.prefetch_wgs <= 4096),
+             "mq_decode_attention: prefetch needs a 16-byte aligned range and 1..4096 workgroups");
+  MQ_REQUIRE(a.prefetch_wgs == 0 || (a.prefetch_stride >= a.prefetch_bytes_per_wg && a.prefetch_stride % 16 == 0 && a.prefetch_delay >= 0 && a.prefetch_delay <= 100000),
+             "mq_decode_attention: prefetch_stride >= prefetch_bytes_per_wg (multiples of 16), prefetch_delay in 0..100000 (10 ns units)");
+  const dim3 grid((unsigned)a.heads, (unsigned)(a.nsplit + (a.prefetch_wgs + a.heads - 1) / a.heads));
+  unsigned long long* stamps = STAMP_SLOT(4, (unsigned)(a.heads * a.nsplit));
   hipStream_t st = as_stream(stream);
   switch (a.head_dim) {
     case 32: decode_attention_kernel<32><<<grid, 256, lds, st>>>(a, stamps); break;

@@ -90,7 +90,7 @@ class _Linear:
 
 
 class DecodeEngine:
-    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None):
+    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5):
         from .llama import LlamaForCausalLM
         assert isinstance(model, LlamaForCausalLM)
         self.model, self.shape = model, model.shape
@@ -127,6 +127,18 @@ class DecodeEngine:
         with torch.no_grad():
             for li, layer in enumerate(model.layers):
                 self._lower_layer(li, layer)
+        # The attention launch of layer L pulls (a share of) layer L's w1|w3 stream into the L2s with extra workgroups: it keeps 32 of
+        # 256 CUs busy and leaves the memory fabric idle, while w1|w3 is the step's biggest stream.  Measured (TinyLlama shape, context
+        # 256): share 0 / 0.5 / 0.7 / 1.0 -> 0.678 / 0.656 / 0.665 / 0.690 ms per token: the attention's own dependent loads queue
+        # behind the prefetch stream, so half of it, started 1.5 us into the launch, is the optimum.
+        if prefetch:
+            for i in range(1, len(self.phases), 5):
+                at, gate = self.phases[i][1], self.phases[i + 2][1]
+                n, per, tot = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+                _lib.call("mq_decode_gemv_geometry", ctypes.byref(gate), ctypes.byref(n), ctypes.byref(per), ctypes.byref(tot))
+                at.prefetch, at.prefetch_stride, at.prefetch_total, at.prefetch_wgs = gate.w, per.value, tot.value, n.value
+                at.prefetch_bytes_per_wg = min(per.value, int(per.value * float(prefetch)) // 1024 * 1024)
+                at.prefetch_delay = int(prefetch_delay_us * 100)
         self.weight_bytes = sum(p[1]._mq_bytes for p in self.phases if p[0] == "gemv")
         self.head_bytes = self.lm_w.numel() * 4
         self.graph = None

@@ -36,13 +36,23 @@ def build_engine(dev, layers, wbits=8, cache_len=1024):
             if "qk_bmm" in name: mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name: mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')))
+    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '1')), prefetch_delay_us=float(os.environ.get('PFDELAY', '1.5')))
 
 
 def main():
     dev = torch.device("cuda:0")
     layers, context, wbits = int(os.environ.get("LAYERS", "4")), int(os.environ.get("CONTEXT", "256")), int(os.environ.get("WBITS", "8"))
     eng = build_engine(dev, layers, wbits)
+    if os.environ.get("NOHEAD"):                        # what-if: no 262 MB lm_head stream -> a small model's weights stay in the Infinity Cache
+        import types
+        real = _lib.call
+        def _launch(self):
+            _lib.call = lambda name, *a: None if name == "mq_decode_head" else real(name, *a)
+            try:
+                type(self)._launch(self)
+            finally:
+                _lib.call = real
+        eng._launch = types.MethodType(_launch, eng)
     eng.fill_cache_random(context); eng.tok.fill_(17)
     lib = _lib.load()
     if not hasattr(lib, "mq_decode_set_stamps_"):
@@ -75,7 +85,7 @@ def main():
         gap = t0 - prev_end if prev_end is not None else float("nan")
         ramp = s[:, 0].max() - t0
         cols = []
-        for k in (1, 2, 3, 4, 5, 8, 6, 7, 9, 10):
+        for k in (1, 2, 3, 4, 5, 8, 6, 7, 9, 10, 14, 15):
             v = s[:, k][s[:, k] > 0]
             cols.append(v.mean() - t0 if v.size else float("nan"))
         raw = st[base:base + grid * 16].reshape(grid, 16)
@@ -87,9 +97,9 @@ def main():
         agg.setdefault(kind, []).append([gap, ramp] + cols + [span, mhz])
     for kind, rows in agg.items():
         r = np.nanmean(np.array(rows[1:] if len(rows) > 1 else rows), axis=0)
-        print(f"{KINDS[kind]:28s} {r[0]:6.2f} {r[1]:6.2f} | " + " ".join(f"{x:6.2f}" for x in r[2:7]) + f" | {r[12]:6.2f}   (n={len(rows)})"
-              f"  x@w0 {r[8]:.2f} ss-math {r[7]:.2f} wave-sum {r[10]:.2f} [s1] quant-math {r[11]:.2f} [s2]  shader clock {r[13]:.0f} MHz")
-    tot = sum(np.nansum(np.array(rows)[:, [0, 12]]) for rows in agg.values())
+        print(f"{KINDS[kind]:28s} {r[0]:6.2f} {r[1]:6.2f} | " + " ".join(f"{x:6.2f}" for x in r[2:7]) + f" | {r[14]:6.2f}   (n={len(rows)})"
+              f"  x@w0 {r[8]:.2f} ss-math {r[7]:.2f} wave-sum {r[10]:.2f} [s1] quant-math {r[11]:.2f} [s2]  shader clock {r[15]:.0f} MHz  kernarg@w0 {r[12]:.2f} @w8 {r[13]:.2f}")
+    tot = sum(np.nansum(np.array(rows)[:, [0, 14]]) for rows in agg.values())
     print(f"sum of gaps + spans: {tot:.1f} us")
 
 

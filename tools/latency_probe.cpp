@@ -7,6 +7,7 @@
 //   mode 2: one line per workgroup, 64 KiB apart, from 16 MiB no other launch of the graph touches (1 GiB per replay: HBM)
 //   mode 3: mode 1, and then a 64 KiB stream per workgroup from fresh pages       (what the GEMV does)
 //   mode 4: a line written by the PREVIOUS launch (other workgroup)               (the activation hand-off)
+//   mode 5: mode 3, but launch 2k+1 re-reads what launch 2k read, same block -> same XCD           (L2-resident weight stream)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -22,13 +23,13 @@ __global__ void __launch_bounds__(1024) probe(const char* __restrict__ small, co
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int acc = 0;
   if (MODE == 0) acc = reinterpret_cast<const int*>(small)[lane & 31];
-  if (MODE == 1 || MODE == 3) acc = reinterpret_cast<const int*>(small + (size_t)blockIdx.x * 128)[lane & 31];
+  if (MODE == 1 || MODE == 3 || MODE == 5) acc = reinterpret_cast<const int*>(small + (size_t)blockIdx.x * 128)[lane & 31];
   if (MODE == 2) acc = reinterpret_cast<const int*>(big + big_off + (size_t)blockIdx.x * (64u << 10))[lane & 31];
   if (MODE == 4) acc = reinterpret_cast<const int*>(handoff + (size_t)((blockIdx.x + 37) & 255) * 128)[lane & 31];
   asm volatile("s_waitcnt vmcnt(0)" ::"v"(acc) : "memory");
   const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
   unsigned long long t2 = t1;
-  if (MODE == 3) {
+  if (MODE == 3 || MODE == 5) {
     v4i b[4];
     const char* p = big + big_off + (size_t)blockIdx.x * (64u << 10) + (size_t)wave * 4096;
 #pragma unroll
@@ -55,7 +56,7 @@ int run(int threads, const char* small, const char* big, char* handoff, unsigned
   hipGraphExec_t exec;
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
   for (int i = 0; i < L; ++i) {
-    const size_t off = (size_t)i * (16u << 20);
+    const size_t off = MODE == 5 ? (size_t)(i / 2) * (16u << 20) : (size_t)i * (16u << 20);   // mode 5: launch 2k+1 re-reads launch 2k's 16 MiB
     probe<MODE><<<G, threads, 0, st>>>(small, big, handoff, off, stamps, i, sink);
   }
   CK(hipStreamEndCapture(st, &graph));
@@ -90,6 +91,16 @@ int run(int threads, const char* small, const char* big, char* handoff, unsigned
     prev_end = end;
     ++n;
   }
+  if (MODE == 5) {
+    double ev = 0, od = 0;
+    for (int i = 8; i < L; ++i) {
+      double l2 = 0;
+      for (int b = 0; b < G; ++b)
+        for (int w = 0; w < waves; ++w) { const unsigned long long* s = &h[((size_t)i * G + b) * 64 + w * 4]; l2 += (double)(s[2] - s[1]); }
+      (i & 1 ? od : ev) += l2 / (G * waves);
+    }
+    printf("   mode 5: stream time first touch (HBM / MALL) %.2f us, re-read by the next launch with the same block mapping (L2) %.2f us\n", ev / ((L - 8) / 2) / 100, od / ((L - 8) / 2) / 100);
+  }
   printf("%-58s threads %4d | period %.2f us | entry->data mean %.2f max %.2f us | stream after %.2f | start ramp %.2f | gap %.2f | span %.2f\n", what,
          threads, ms * 1e3 / (10 * L), lat / n / 100, lat_max / n / 100, lat2 / n / 100, ramp / n / 100, gap / (n - 1) / 100, span / n / 100);
   CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph)); CK(hipStreamDestroy(st));
@@ -111,6 +122,7 @@ int main() {
     if (run<2>(threads, small, big, handoff, stamps, sink, "2: line per workgroup from 16 MiB fresh per launch (HBM)")) return 1;
     if (run<3>(threads, small, big, handoff, stamps, sink, "3: resident line, then 64 KiB / workgroup fresh stream")) return 1;
     if (run<4>(threads, small, big, handoff, stamps, sink, "4: line written by the previous launch")) return 1;
+    if (run<5>(threads, small, big, handoff, stamps, sink, "5: 64 KiB / workgroup stream, every second launch re-reads")) return 1;
   }
   return 0;
 }
