@@ -47,7 +47,7 @@ __device__ __forceinline__ AGrid a_load_grid(const mq_grid& g) {
 }
 // exact form (qmodule.py:286-287), used by the prep kernel
 __device__ __forceinline__ float a_index_exact(float x, const AGrid& g) {
-  const float t = __fdiv_rn(x, g.s);
+  const float t = div_by_scale(x, g.s, g.inv_s);       // == x / s on the quantizer's domain (mq_common.h)
   const float q = __fadd_rn(__fadd_rn(__fsub_rn(rintf(t), t), t), g.o);
   const float c = fminf(fmaxf(q, g.qmin), g.qmax);
   return q != q ? g.qmin : c;

@@ -48,6 +48,18 @@ struct PerDeviceOnce {
     }                                                                                \
   } while (0)
 
+// x / s through the correctly rounded reciprocal inv_s = RN(1 / s) and one fma correction (Markstein): bit-identical to the IEEE
+// divide for |x / s| in [2^-2, 1e30] -- tools/div_check.cpp compares every fp32 dividend for 48 divisors on the GPU, incl. all-ones
+// significands and the scale clamps 1e-5 / 1e6 (profiles/r03/div_check.log) -- and faithful below 2^-2, where round(x / s) = 0 and
+// round_ste's (round(t) - t) + t = 0 whatever the last bit of t is: a quantizer INDEX (qmodule.py:286-287) can not tell the two
+// apart.  +-inf and NaN dividends give NaN, which is what the reference's round_ste makes of them.  3 VALU instructions instead of
+// the ~10 + two mode switches of v_div_scale / v_rcp / v_fma x4 / v_div_fmas / v_div_fixup: the quantize / norm kernels spend
+// most of their issue slots on this division.  NOT for quotients that are themselves results (x / chan_scale, gradients).
+__device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
+  const float q0 = __fmul_rn(x, inv_s);
+  return __builtin_fmaf(__builtin_fmaf(-q0, s, x), inv_s, q0);
+}
+
 // 64-lane wave reductions (DPP/permute based via __shfl_xor; wave = 64 on gfx950).
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll

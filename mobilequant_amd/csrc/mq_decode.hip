@@ -27,15 +27,8 @@ __device__ __forceinline__ float dq_clamp_nan(float q, float lo, float hi) {
   const float c = fminf(fmaxf(q, lo), hi);
   return q != q ? q : c;
 }
-// x / s through the correctly rounded reciprocal y = RN(1 / s) and one fma correction (Markstein): bit-identical to the IEEE divide
-// for |x / s| in [2^-2, 1e30] -- tools/div_check.cpp compares every fp32 dividend for 48 divisors on the GPU, incl. all-ones
-// significands and the scale clamps 1e-5 / 1e6 (profiles/r03/div_check.log) -- and faithful below 2^-2, where round(x / s) = 0 and
-// (round(t) - t) + t = 0 whatever the last bit of t is.  3 VALU instructions instead of the 10 + two mode switches of v_div_*: at
-// M = 1 every CU quantises the whole activation row, and that arithmetic is the launch's critical path.
-__device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
-  const float q0 = __fmul_rn(x, inv_s);
-  return __builtin_fmaf(__builtin_fmaf(-q0, s, x), inv_s, q0);
-}
+// (x / s: div_by_scale of mq_common.h -- at M = 1 every CU quantises the whole activation row, and that arithmetic is on the
+// launch's critical path)
 // qmodule.py:286-290 with round_ste = (round(t) - t) + t (as mq_norm.hip / mq_elementwise.hip)
 __device__ __forceinline__ float dq_index(float x, float s, float inv_s, float o, float qmin, float qmax) {
   const float t = div_by_scale(x, s, inv_s);

@@ -34,8 +34,8 @@ __device__ __forceinline__ int dot16(const v4i a, const v4i b, int c) {
 
 #pragma clang fp contract(off)
 // qmodule.py:286-287, the same expression tree as mq_elementwise.hip (bit-exact indices)
-__device__ __forceinline__ int q_index_i(float x, float s, float o, float qmin, float qmax) {
-  float q = __fadd_rn(rintf(__fdiv_rn(x, s)), o);
+__device__ __forceinline__ int q_index_i(float x, float s, float inv_s, float o, float qmin, float qmax) {
+  float q = __fadd_rn(rintf(div_by_scale(x, s, inv_s)), o);
   return (int)fminf(fmaxf(q, qmin), qmax);
 }
 
@@ -105,10 +105,11 @@ __global__ void __launch_bounds__(GV2_THREADS) gemv_i8_fat_kernel(const GemvArgs
     if (threadIdx.x < M) s_rs[threadIdx.x] = 0;
     __syncthreads();
     const float s = g.xq_scale[0], o = g.xq_offset[0];
+    const float inv_s = __fdiv_rn(1.0f, s);
     for (int i = threadIdx.x; i < M * (K >> 2); i += GV2_THREADS) {
       const float4 v = reinterpret_cast<const float4*>(g.x_f32)[i];
-      const int q0 = q_index_i(v.x, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q1 = q_index_i(v.y, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
-      const int q2 = q_index_i(v.z, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q3 = q_index_i(v.w, s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
+      const int q0 = q_index_i(v.x, s, inv_s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q1 = q_index_i(v.y, s, inv_s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
+      const int q2 = q_index_i(v.z, s, inv_s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift, q3 = q_index_i(v.w, s, inv_s, o, g.xq_qmin, g.xq_qmax) - g.xq_shift;
       reinterpret_cast<unsigned*>(smem)[i] = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
       // K % 256 == 0 (host check): a wave's 64 float4s never straddle a row and the trip count is a multiple of
       // 64, so every wave is fully active here

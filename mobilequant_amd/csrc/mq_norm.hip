@@ -28,8 +28,8 @@ __device__ __forceinline__ float nq_clamp_nan(float q, float lo, float hi) {
   return q != q ? q : c;
 }
 // qmodule.py:286-290 with round_ste = (round(t) - t) + t, as in mq_elementwise.hip
-__device__ __forceinline__ float nq_index(float x, float s, float o, float qmin, float qmax) {
-  const float t = __fdiv_rn(x, s);
+__device__ __forceinline__ float nq_index(float x, float s, float inv_s, float o, float qmin, float qmax) {
+  const float t = div_by_scale(x, s, inv_s);          // == x / s on the quantizer's domain (mq_common.h)
   const float r = __fadd_rn(__fsub_rn(rintf(t), t), t);
   return nq_clamp_nan(__fadd_rn(r, o), qmin, qmax);
 }
@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
     so = a.out_scale[0];
     oo = a.out_offset[0];
   }
-  auto qin = [&](float v) { return has_in ? nq_dequant(nq_index(v, si, oi, a.in_qmin, a.in_qmax), si, oi) : v; };
+  const float isi = __fdiv_rn(1.0f, si), iso = __fdiv_rn(1.0f, so);
+  auto qin = [&](float v) { return has_in ? nq_dequant(nq_index(v, si, isi, oi, a.in_qmin, a.in_qmax), si, oi) : v; };
 
   constexpr int VV = V > 0 ? V : 1;
   float4 xs[VV];
@@ -184,8 +185,8 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
       y0 = __fadd_rn(y0, b.x); y1 = __fadd_rn(y1, b.y); y2 = __fadd_rn(y2, b.z); y3 = __fadd_rn(y3, b.w);
     }
     if (has_out) {
-      const float q0 = nq_index(y0, so, oo, a.out_qmin, a.out_qmax), q1 = nq_index(y1, so, oo, a.out_qmin, a.out_qmax);
-      const float q2 = nq_index(y2, so, oo, a.out_qmin, a.out_qmax), q3 = nq_index(y3, so, oo, a.out_qmin, a.out_qmax);
+      const float q0 = nq_index(y0, so, iso, oo, a.out_qmin, a.out_qmax), q1 = nq_index(y1, so, iso, oo, a.out_qmin, a.out_qmax);
+      const float q2 = nq_index(y2, so, iso, oo, a.out_qmin, a.out_qmax), q3 = nq_index(y3, so, iso, oo, a.out_qmin, a.out_qmax);
       y0 = nq_dequant(q0, so, oo); y1 = nq_dequant(q1, so, oo); y2 = nq_dequant(q2, so, oo); y3 = nq_dequant(q3, so, oo);
       if (a.q_out || a.q_tiled) {   // NaN has no integer image: saturate to the grid's low end like mq_quantize
         const int s0 = (int)fmaxf(q0, a.out_qmin) - a.q_shift, s1 = (int)fmaxf(q1, a.out_qmin) - a.q_shift;
@@ -305,15 +306,16 @@ struct ActArgs {
 };
 
 __global__ void __launch_bounds__(256) act_quant_kernel(const ActArgs a) {
-  float sc[3], of[3];
+  float sc[3], of[3], isc[3];
   bool has[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     has[k] = a.s[k] != nullptr;
     sc[k] = has[k] ? a.s[k][0] : 1.f;
     of[k] = has[k] ? a.o[k][0] : 0.f;
+    isc[k] = __fdiv_rn(1.0f, sc[k]);
   }
-  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], a.qmin[k], a.qmax[k]), sc[k], of[k]) : v; };
+  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], isc[k], of[k], a.qmin[k], a.qmax[k]), sc[k], of[k]) : v; };
   auto f = [&](float v) {
     const float xi = fq(0, v);
     float r;
@@ -359,15 +361,16 @@ struct GatedArgs {
 
 template <bool INDEX, bool WRITE_Y>
 __global__ void __launch_bounds__(256) gated_act_quant_kernel(const GatedArgs g) {
-  float sc[5], of[5];
+  float sc[5], of[5], isc[5];
   bool has[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     has[k] = g.s[k] != nullptr;
     sc[k] = has[k] ? g.s[k][0] : 1.f;
     of[k] = has[k] ? g.o[k][0] : 0.f;
+    isc[k] = __fdiv_rn(1.0f, sc[k]);
   }
-  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
+  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], isc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
   // y1 = Qact(act(x)) of one gate input value
   auto gate_of = [&](float xi) {
     float r;
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(256) gated_act_quant_kernel(const GatedArgs g)
         for (int e = 0; e < 4; ++e) {
           const float prod = __fmul_rn(y1[4 * d + e], vb[4 * d + e]);
           p[4 * d + e] = prod;
-          const float qi = nq_index(prod, sc[4], of[4], g.qmin[4], g.qmax[4]);
+          const float qi = nq_index(prod, sc[4], isc[4], of[4], g.qmin[4], g.qmax[4]);
           // integer storage has no NaN: saturate like mq_quantize does
           const int st_v = (qi != qi ? (int)g.qmin[4] : (int)qi) - g.shift;
           acc += st_v;
@@ -453,16 +456,18 @@ __global__ void __launch_bounds__(256) gated_index_rows_kernel(const GatedArgs g
   __shared__ float lut[2][256];
   __shared__ int s_part[4];
   const float so = g.s[4][0], oo = g.o[4][0];
+  const float iso = __fdiv_rn(1.0f, so);
   {
-    float sc[4], of[4];
+    float sc[4], of[4], isc[4];
     bool has[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       has[k] = g.s[k] != nullptr;
       sc[k] = has[k] ? g.s[k][0] : 1.f;
       of[k] = has[k] ? g.o[k][0] : 0.f;
+      isc[k] = __fdiv_rn(1.0f, sc[k]);
     }
-    auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
+    auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], isc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
     const float xi = nq_dequant((float)threadIdx.x, sc[0], of[0]);
     float r;
     if (g.act == 0) {
@@ -490,7 +495,7 @@ __global__ void __launch_bounds__(256) gated_index_rows_kernel(const GatedArgs g
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float prod = __fmul_rn(lut[0][(wa[d] >> (8 * e)) & 0xffu], lut[1][(wb[d] >> (8 * e)) & 0xffu]);
-        const float qi = nq_index(prod, so, oo, g.qmin[4], g.qmax[4]);
+        const float qi = nq_index(prod, so, iso, oo, g.qmin[4], g.qmax[4]);
         const int st_v = (qi != qi ? (int)g.qmin[4] : (int)qi) - g.shift;
         acc += st_v;
         pk |= ((uint32_t)st_v & 0xffu) << (8 * e);
@@ -513,15 +518,16 @@ __global__ void __launch_bounds__(256) gated_index_rows_kernel(const GatedArgs g
 // table IS that arithmetic, so results are bit-identical) and then looked up (mq_gated_lookup): one LDS byte read per element instead
 // of two table reads, a multiply and an IEEE divide.  The lookup kernel is a pure stream (2 B in, 1 B out per element).
 __global__ void __launch_bounds__(256) gated_table_kernel(const GatedArgs g, int8_t* __restrict__ table) {
-  float sc[5], of[5];
+  float sc[5], of[5], isc[5];
   bool has[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     has[k] = g.s[k] != nullptr;
     sc[k] = has[k] ? g.s[k][0] : 1.f;
     of[k] = has[k] ? g.o[k][0] : 0.f;
+    isc[k] = __fdiv_rn(1.0f, sc[k]);
   }
-  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
+  auto fq = [&](int k, float v) { return has[k] ? nq_dequant(nq_index(v, sc[k], isc[k], of[k], g.qmin[k], g.qmax[k]), sc[k], of[k]) : v; };
   const int ia = blockIdx.x, ib = threadIdx.x;
   const float xi = nq_dequant((float)ia, sc[0], of[0]);
   float r;
@@ -532,7 +538,7 @@ __global__ void __launch_bounds__(256) gated_table_kernel(const GatedArgs g, int
     r = __fmul_rn(__fmul_rn(0.5f, xi), __fadd_rn(1.0f, erff(__fmul_rn(xi, 0.70710678118654752440f))));
   }
   const float prod = __fmul_rn(fq(3, r), nq_dequant((float)ib, sc[1], of[1]));
-  const float qi = nq_index(prod, sc[4], of[4], g.qmin[4], g.qmax[4]);
+  const float qi = nq_index(prod, sc[4], isc[4], of[4], g.qmin[4], g.qmax[4]);
   table[ia * 256 + ib] = (int8_t)((qi != qi ? (int)g.qmin[4] : (int)qi) - g.shift);
 }
 
