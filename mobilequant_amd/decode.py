@@ -75,7 +75,7 @@ class _Linear:
             if self.w4 and K % 64:
                 raise RuntimeError("DecodeEngine: packed 4-bit weights need K % 64 == 0")
             plan = lin._epilogue_vectors(lin._weight_plan(lin.weight), a_grid, 128, K)
-            ws.append(plan["w"]); alphas.append(plan["alpha"].clone()); zps.append(plan["w_zp"].clone()); cts.append(plan["col_term"].clone())
+            ws.append(Q.QLinear._decode_weights(plan)[0]); alphas.append(plan["alpha"].clone()); zps.append(plan["w_zp"].clone()); cts.append(plan["col_term"].clone())
             biases.append(lin.bias.detach().float() if lin.bias is not None else None)
             plan["epi_key"] = None                      # the prefill path re-derives its vectors for its own grid object
         cat = (lambda ts: torch.stack(ts, dim=1).reshape(-1, *ts[0].shape[1:])) if interleave else (lambda ts: torch.cat(ts, dim=0))

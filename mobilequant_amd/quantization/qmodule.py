@@ -566,17 +566,33 @@ class QLinear(nn.Linear, _QuantizedOp):
         plan = self._plan
         if plan is not None and plan["key"] == key and plan["wref"]() is weight:
             return plan
-        w4 = wq.qcfg.bitwidth == 4
+        bits4 = wq.qcfg.bitwidth == 4
         w32 = weight.detach().to(torch.float32)
-        if w4:   # unsigned nibbles (index - qmin), packed two per byte
+        if bits4:
+            # 4-bit weights: unsigned nibble values (index - qmin) in 0 .. 15.  Two images of the SAME numbers, with the same epilogue
+            # vectors: one byte per value for M > 8 -- a prefill GEMM is compute-bound, so it runs the int8 MFMA kernels (generated-ISA
+            # pair / tiled kernels, fused residual, segmented q|k|v) at their int8 speed instead of unpacking nibbles in its inner loop
+            # -- and the packed two-per-byte image (built on first use) for the weight-streaming decode kernels, which are
+            # bandwidth-bound and unpack in registers (mq_gemv.hip, mq_decode.hip).  mq_w4a8_linear (in-LDS unpack in front of the MFMAs)
+            # stays in the C ABI for callers that hold only packed weights.
             q, colsum = ops.quantize(w32, wq.scale.detach(), wq.offset.detach(), wq.qmin, wq.qmax, q_dtype=MQ_U8,
                                      shift=wq.qmin, rows=weight.shape[0], want_row_sum=True)
-            wint, shift = ops.pack_w4(q), wq.qmin
+            wint, shift = q.view(torch.int8), wq.qmin
         else:
             wint, colsum, shift = wq.quantize_to_int(w32, MQ_I8, want_row_sum=True, rows=weight.shape[0])
-        plan = {"key": key, "wref": weakref.ref(weight), "w": wint, "colsum": colsum, "shift": shift, "w4": w4, "epi_key": None}
+        plan = {"key": key, "wref": weakref.ref(weight), "w": wint, "colsum": colsum, "shift": shift, "w4": False, "bits4": bits4,
+                "packed": None, "epi_key": None}
         self._plan = plan
         return plan
+
+    @staticmethod
+    def _decode_weights(plan):
+        """(weight image, w4 flag) for the M <= 8 weight-streaming kernels: packed nibbles for 4-bit weights."""
+        if not plan["bits4"]:
+            return plan["w"], False
+        if plan["packed"] is None:
+            plan["packed"] = ops.pack_w4(plan["w"].view(torch.uint8))
+        return plan["packed"], True
 
     def _input_image(self, x, weight):
         """int8 image of the activation on this linear's input grid: (grid, a_q, a_rs, a_shift, tiled_rows, decode).  An image
@@ -647,11 +663,12 @@ class QLinear(nn.Linear, _QuantizedOp):
         f16 = x is not None and x.dtype == torch.float16
         if decode:   # M <= 8: activation quantize fused into the weight-streaming GEMV (one launch)
             x2d = x.reshape(-1, K)
+            w_dec, w4_dec = self._decode_weights(plan)
             out = ops.int8_linear_f32in(
-                x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift, plan["w"], plan["alpha"],
+                x2d, grid.scale.detach(), grid.offset.detach(), grid.qmin, grid.qmax, a_shift, w_dec, plan["alpha"],
                 plan["w_zp"], plan["col_term"], bias, out_scale=oq.scale.detach() if fused else None,
                 out_offset=oq.offset.detach() if fused else None, out_qmin=oq.qmin if fused else 0.0,
-                out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, w4=plan["w4"])
+                out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, w4=w4_dec)
             out = out.reshape(*lead, N)
             if resid is not None:
                 return resid + out

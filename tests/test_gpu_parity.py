@@ -803,7 +803,8 @@ def test_w4a8_decode_gemv(dev):
     with torch.no_grad():
         full = ql(xs)
         one = ql(xs[:, 9:10, :])
-    assert ql._plan is not None and ql._plan["w4"]
+    # 4-bit weights: the prefill ran the int8 MFMA kernels on the one-byte-per-nibble image, the decode row the packed nibbles
+    assert ql._plan is not None and ql._plan["bits4"] and ql._plan["packed"] is not None and ql._plan["w"].shape == (512, 2048)
     assert torch.equal(one, full[:, 9:10, :])
 
 
