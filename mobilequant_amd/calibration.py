@@ -120,43 +120,82 @@ class ActRangeCollector:
         self._hooks = []
 
     # -- merge -------------------------------------------------------------------------------------
-    def _packed(self) -> torch.Tensor:
+    def _layout(self) -> Dict[int, int]:
+        """Per-channel mode: {slot: channels} of what THIS rank observed."""
+        return {i: int(s[0].numel()) for i, s in enumerate(self._pc) if s is not None}
+
+    @staticmethod
+    def _layout_checksum(layout: Dict[int, int]) -> float:
+        """An integer below 2^23 (exact in fp32, and so is its negation) that depends on which slots are packed and how wide."""
+        acc = 17
+        for i in sorted(layout):
+            acc = (acc * 8191 + (i + 1) * 131 + layout[i] * 7919) % 8388593
+        return float(acc)
+
+    def _packed(self, layout: Optional[Dict[int, int]] = None) -> torch.Tensor:
         if not self.per_channel:
             return torch.cat((-self._mn, self._mx))
-        parts = []
-        for s in self._pc:
-            if s is not None:                       # never observed (on any rank: the module is not on the forward path)
+        layout = self._layout() if layout is None else layout
+        cs = self._layout_checksum(layout)
+        parts = [torch.tensor([cs, -cs], dtype=torch.float32, device=self.device)]     # MAX keeps (cs, -cs) iff every rank packed this layout
+        for i in sorted(layout):
+            s = self._pc[i]
+            if s is None:                           # observed elsewhere only: the neutral element of MAX over [-min, max]
+                parts.append(torch.full((2 * layout[i],), float("-inf"), dtype=torch.float32, device=self.device))
+            else:
                 parts += [-s[0].to(self.device), s[1].to(self.device)]
-        return torch.cat(parts) if parts else torch.empty(0, device=self.device)
+        return torch.cat(parts)
 
-    def _unpack(self, buf: torch.Tensor) -> None:
+    def _unpack(self, buf: torch.Tensor, layout: Optional[Dict[int, int]] = None) -> None:
         if not self.per_channel:
             n = len(self.slots)
             self._mn, self._mx = -buf[:n], buf[n:]
             return
-        off = 0
-        for i, s in enumerate(self._pc):
-            if s is None:
-                continue
-            c = s[0].numel()
+        layout = self._layout() if layout is None else layout
+        if float(buf[0]) != -float(buf[1]):
+            raise RuntimeError("per-channel calibration merge: the ranks packed different slot layouts (a hooked module ran on some "
+                               "ranks only); call all_reduce(verify_layout=True) / get_act_range(..., verify_layout=True)")
+        off = 2
+        for i in sorted(layout):
+            c = layout[i]
             self._pc[i] = (-buf[off:off + c], buf[off + c:off + 2 * c])
             off += 2 * c
 
-    def all_reduce(self, group=None, force: bool = False) -> None:
+    def all_reduce(self, group=None, force: bool = False, verify_layout: bool = False) -> None:
         """ONE all-reduce(MAX) over the packed [-min, max] buffer of every tensor -- per-tensor and per-channel mode alike.
-        Per-channel slot sizes come from each rank's own observations: get_act_range makes every rank run at least one
-        sample (a duplicate if it owns none; min / max are idempotent), and the reference's per-channel mode already
-        requires equal shapes across samples (generate_act_range.py:57-63), so the packed layout is identical on all ranks
-        without a second (object) collective.  force: also run the pack / reduce / unpack path in a 1-rank group (tests)."""
+        Per-tensor: the layout is the model's named_modules(), identical on every rank.  Per-channel: slot widths come from each
+        rank's own observations; get_act_range makes every rank run at least one sample (a duplicate if it owns none; min / max are
+        idempotent) and the reference's per-channel mode already requires equal shapes across samples
+        (generate_act_range.py:57-63), so on a dense graph the packed layout is identical on all ranks without a second collective.
+        The buffer carries a checksum of the layout (+c, -c under MAX): equal-length but different layouts raise instead of
+        mis-merging.  Different LENGTHS (a hooked module that ran on some ranks only: data-dependent paths, MoE) would abort inside
+        the collective, so callers with such graphs pass verify_layout=True: a 4-float guard all-reduce first and, on a mismatch,
+        one all_gather_object of the slot widths to agree on the union layout (ranks fill what they did not see with the neutral
+        element).  force: also run the pack / reduce / unpack path in a 1-rank group (tests)."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size(group) == 1 and not force:
             return
-        buf = self._packed()
+        layout = None
+        if self.per_channel and verify_layout:
+            mine = self._layout()
+            n, cs = float(2 + 2 * sum(mine.values())), self._layout_checksum(mine)
+            guard = torch.tensor([n, -n, cs, -cs], dtype=torch.float32, device=self.device)
+            dist.all_reduce(guard, op=dist.ReduceOp.MAX, group=group)
+            if float(guard[0]) != -float(guard[1]) or float(guard[2]) != -float(guard[3]):
+                every = [None] * dist.get_world_size(group)
+                dist.all_gather_object(every, mine, group=group)
+                layout = {}
+                for other in every:
+                    for i, c in other.items():
+                        if layout.setdefault(i, c) != c:
+                            name = [k for k, v in self.slots.items() if v == i][0]
+                            raise RuntimeError(f"per-channel calibration merge: slot {name} has {layout[i]} channels on one rank and {c} on another")
+        buf = self._packed(layout)
         if buf.numel():
             dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
             self.n_collectives += 1
-        self._unpack(buf)
+        self._unpack(buf, layout)
 
     # -- results -----------------------------------------------------------------------------------
     def act_dict(self) -> Dict[str, dict]:
@@ -191,7 +230,7 @@ class ActRangeCollector:
 
 @torch.no_grad()
 def get_act_range(model: nn.Module, samples: Sequence[torch.Tensor], per_channel: bool = False, group=None,
-                  forward=None, force_collective: bool = False) -> Dict[str, dict]:
+                  forward=None, force_collective: bool = False, verify_layout: bool = False) -> Dict[str, dict]:
     """Data-parallel counterpart of ``get_act_range`` (generate_act_range.py:49-122).
 
     ``samples``: the full list of calibration inputs (token-id tensors), identical on every rank; rank r
@@ -212,7 +251,7 @@ def get_act_range(model: nn.Module, samples: Sequence[torch.Tensor], per_channel
                 run(samples[i].to(dev))
     finally:
         col.detach()
-    col.all_reduce(group, force=force_collective)
+    col.all_reduce(group, force=force_collective, verify_layout=verify_layout)
     return col.act_dict()
 
 

@@ -288,6 +288,7 @@ class Quantizer(nn.Module):
             min_val, max_val, self.qcfg.bitwidth, self.qcfg.is_symmetric)
         self.qmin, self.qmax = q_min, q_max
         self._gen = getattr(self, "_gen", 0) + 1
+        self._auto_grid = False                # (_prepare sets it again when the range came from the tensor being quantised)
         scale, offset = scale.to(device), offset.to(device)
         for name in ("scale", "offset"):
             if hasattr(self, name):
@@ -328,6 +329,7 @@ class Quantizer(nn.Module):
             mn, mx = self._tensor_range(x2)
             transient = self.qcfg.is_dynamic or self.lwc
             self.set_scale_offset_from_minmax(mn, mx, None if transient else use_scale_offset_as, x2.device)
+            self._auto_grid = True            # derived from the tensor itself (first forward), not loaded / calibrated / trained
         if self.scale.device != x2.device:
             self.scale.data = self.scale.to(x2.device)
         if self.offset.device != x2.device:
@@ -506,6 +508,14 @@ class QLinear(nn.Linear, _QuantizedOp):
             self.input_chan_scale = s
         self._scaled_weight = None
         self._plan = None
+        # The weight quantizer's cached grid (first-forward range of W, qmodule.py:262-277) belongs to the OLD effective weight: the
+        # reference folds first and quantises after (smoothquant.py:64-69), so the grid of W * s must come from W * s.  A grid that
+        # was loaded, calibrated or trained is the caller's: left alone.
+        wq = self.weight_quantizer
+        if wq is not None and wq._has_grid() and getattr(wq, "_auto_grid", False):
+            wq._gen = getattr(wq, "_gen", 0) + 1
+            for name in ("scale", "offset"):
+                delattr(wq, name)
         return self
 
     def _effective_weight(self, weight):

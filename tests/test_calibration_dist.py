@@ -110,3 +110,64 @@ def test_collector_slot_layout_is_data_independent():
                              ("fc2", "output"), ("bmm", "input"), ("bmm", "output"), ("bmm", "input2"),
                              ("ln", "input"), ("ln", "output")]
     assert a.act_dict() == {}          # nothing observed yet -> nothing reported
+
+
+def _divergent_worker(rank, world, port, mode, q):
+    """4 ranks, per-channel statistics.  mode 'verify': rank 3 never ran the module behind slot ('bmm', *) -> with verify_layout
+    the ranks agree on the union layout and the merge equals the unsharded oracle.  mode 'swap': ranks observed different slots
+    of EQUAL width (same buffer length) -> the in-buffer layout checksum raises instead of mis-merging."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mobilequant_amd.calibration import ActRangeCollector
+        z = load_npz("calib_stream.npz")
+        samples = _stream(z, "stream_pc")
+        col = ActRangeCollector(CalibToy(), per_channel=True, device="cpu")
+        mine = O.ActRangeOracle(True)
+        full = O.ActRangeOracle(True)
+        skip = (lambda name, field: name == "bmm") if (mode == "verify" and rank == 3) else (lambda name, field: False)
+        for k, s in enumerate(samples):
+            for name, field, t in s:
+                if not (mode == "verify" and k % world == 3 and name == "bmm"):
+                    full.update(name, field, t)              # what the job as a whole observed
+                if k % world == rank and not skip(name, field):
+                    mine.update(name, field, t)
+        for (name, field), i in col.slots.items():
+            v = mine.act_dict.get(name, {}).get(field)
+            if v is not None:
+                col._pc[i] = (torch.from_numpy(v[0].copy()), torch.from_numpy(v[1].copy()))
+        if mode == "swap":
+            i_in, i_out = col.slots[("fc1", "input")], col.slots[("ln", "input")]
+            w = col._pc[i_in][0].numel()
+            col._pc[i_out] = (torch.zeros(w), torch.ones(w))          # same width as fc1.input
+            col._pc[i_in if rank % 2 else i_out] = None                 # odd ranks drop one, even ranks the other: equal lengths
+            try:
+                col.all_reduce()
+                q.put((rank, "no error"))
+            except RuntimeError as e:
+                q.put((rank, "raised" if "different slot layouts" in str(e) else str(e)))
+            return
+        col.all_reduce(verify_layout=True)
+        got = col.act_dict()
+        ok = got.keys() == full.act_dict.keys()
+        for name, fields in full.act_dict.items():
+            for f, v in fields.items():
+                ok &= bool(np.array_equal(got[name][f].numpy(), v))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["verify", "swap"])
+def test_four_rank_merge_with_rank_divergent_observations(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_divergent_worker, args=(r, 4, port, mode, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True if mode == "verify" else "raised") for r in range(4)], res

@@ -122,3 +122,58 @@ def test_decode_attention_every_position_vs_oracle(dev, S, heads, kv_heads, D, r
     # the int8 image: index of the fp32 output on the consumer's grid (oracle quantizer), storage index - 128
     idx = o_in.forward(got.astype(F32), return_index=True)[1].astype(np.int32) - 128
     assert np.array_equal(idx, got_q.astype(np.int32))
+
+
+def test_channel_scale_set_after_a_forward_requantises_the_weight_on_its_new_range(dev):
+    """QLinear.set_input_channel_scale AFTER the linear already ran must not keep the weight grid derived from W: the
+    reference folds first and quantises after (ptq/smoothquant.py:64-69), so the integer weights of W * s sit on the range of W * s --
+    the same numbers as a fresh module whose weight is W * s.  A calibrated / loaded weight grid is left alone."""
+    import mobilequant_amd as mq
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(96, 128, generator=g) * 0.05).to(dev)
+    s = (torch.rand(128, generator=g) * 3 + 0.5).to(dev)
+    x = torch.randn(1, 40, 128, generator=g).to(dev)
+    a8 = mq.QuantConfig(bitwidth=8)
+
+    def make(weight):
+        lin = torch.nn.Linear(128, 96, bias=False).to(dev)
+        with torch.no_grad():
+            lin.weight.copy_(weight)
+        q = mq.QLinear.from_float(lin, a8, a8, a8).requires_grad_(False)
+        q.set_scale_offset({"input": [-3.0, 3.0], "output": [-2.0, 2.0]}, "buffer")
+        return q
+    late, folded = make(w), make(w * s)
+    with torch.no_grad():
+        late(x)                                                     # first forward: grid from W
+        stale = float(late.weight_quantizer.scale)
+        late.set_input_channel_scale(s)
+        got = late(x)
+        want = folded(x / s)
+    assert float(late.weight_quantizer.scale) == float(folded.weight_quantizer.scale) != stale
+    assert torch.equal(got, want)
+    # an explicitly set weight grid survives
+    kept = make(w)
+    kept.weight_quantizer.set_scale_offset_from_minmax(-0.3, 0.3, "buffer", dev)
+    kept.set_input_channel_scale(s)
+    assert kept.weight_quantizer._has_grid() and abs(float(kept.weight_quantizer.scale) - 0.6 / 255) < 1e-7
+
+
+def test_prefill_attention_with_a_score_grid_too_wide_for_the_fixed_reference(dev):
+    """with a 16-bit qk_bmm output grid whose span exceeds 2^96 in exp2 units the prefill kernel cannot use the grid's top
+    as softmax reference and takes its running-maximum sweep (QK_OUT, not fixed_ref: mq_attention.hip) -- covered here against the
+    numpy restatement of the reference."""
+    from test_gpu_round2 import _attention_case, _grid_of
+    from mobilequant_amd import ops
+    S, heads, kv_heads = 128, 4, 2
+    q, k, v, cos, sin, qk, pv = _attention_case(S, heads, kv_heads, seed=11)
+    wide = O.QuantizerOracle(bitwidth=16)
+    wide.set_from_minmax(F32(-700.0), F32(700.0))                   # (65535 steps * s / 8) * log2(e) = 252 > 96
+    qk = (qk[0], qk[1], wide)
+    want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)                       # noqa: E731
+    got = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids).cpu().numpy()
+    step = float(pv[2].scale)
+    diff = np.abs(got - want)
+    assert np.isfinite(got).all() and diff.max() <= 1.001 * step and (diff > 0.5 * step).mean() < 0.02, (diff.max(), step)
