@@ -318,6 +318,8 @@ typedef struct mq_decode_gemv_args {
   const int8_t* xq;
   int K, N;
   const float* norm_w;
+  const float* norm_bias; /* layernorm = 1 only (nullable) */
+  int layernorm;          /* 0: QRMSNorm (qmodule.py:515-531); 1: QLayerNorm (qmodule.py:624-640) in the fused prologue */
   mq_grid norm_in;
   float eps;
   mq_grid a_grid;
@@ -380,10 +382,11 @@ typedef struct mq_decode_attention_args {
 } mq_decode_attention_args;
 int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream);
 
-/* Final HFRMSNorm (floating point: the surgery skips it, qmodule.py:843; norm_weight NULL = no norm) fused in front of the fp32
- * lm_head stream: logits[v] = sum_k w[v,k] * norm(x)[k] (+ bias[v]). */
-int mq_decode_head(const float* x, const float* norm_weight, float eps, const float* w, const float* bias, int64_t K,
-                   int64_t V, float* logits, mq_stream_t stream);
+/* Final norm (floating point: the surgery skips it, qmodule.py:843) fused in front of the fp32 lm_head stream: logits[v] = sum_k
+ * w[v,k] * norm(x)[k] (+ bias[v]).  layernorm = 0: HFRMSNorm (norm_weight NULL = no norm, norm_bias unused); layernorm = 1:
+ * nn.LayerNorm with optional weight / bias (StableLM-2: hf_model.py:1440-1441). */
+int mq_decode_head(const float* x, const float* norm_weight, const float* norm_bias, int layernorm, float eps, const float* w,
+                   const float* bias, int64_t K, int64_t V, float* logits, mq_stream_t stream);
 
 /* ---- a10: quantized causal attention at prefill (hf_model.py:486-534 with the two QMatMuls of qmodule.py:453-466) ------------ */
 /* One sequence.  q [seq, heads*D], k / v [seq, kv_heads*D] fp32 = the q / k / v projection outputs BEFORE RoPE; cos / sin [seq, D]

@@ -29,7 +29,7 @@ class MqGrid(ctypes.Structure):
 
 
 class MqDecodeGemvArgs(ctypes.Structure):
-    _fields_ = [("x", c_void_p), ("xq", c_void_p), ("K", c_int), ("N", c_int), ("norm_w", c_void_p), ("norm_in", MqGrid),
+    _fields_ = [("x", c_void_p), ("xq", c_void_p), ("K", c_int), ("N", c_int), ("norm_w", c_void_p), ("norm_bias", c_void_p), ("layernorm", c_int), ("norm_in", MqGrid),
                 ("eps", c_float), ("a_grid", MqGrid), ("w", c_void_p), ("alpha", c_void_p), ("w_zp", c_void_p),
                 ("col_term", c_void_p), ("bias", c_void_p), ("seg_end", c_int * 2), ("out_grid", MqGrid * 3),
                 ("resid", c_void_p), ("y", c_void_p), ("gate_act", c_int), ("gate_mid", MqGrid), ("gate_actout", MqGrid),
@@ -96,7 +96,7 @@ _SIGNATURES = {
     "mq_decode_gemv": (c_int, [POINTER(MqDecodeGemvArgs), _P]),
     "mq_decode_gemv_geometry": (c_int, [POINTER(MqDecodeGemvArgs), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
-    "mq_decode_head": (c_int, [_P, _P, c_float, _P, _P, c_int64, c_int64, _P, _P]),
+    "mq_decode_head": (c_int, [_P, _P, _P, c_int, c_float, _P, _P, c_int64, c_int64, _P, _P]),
     "mq_attention_quant": (c_int, [POINTER(MqAttentionArgs), _P]),
     "mq_gemm_set_variant": (c_int, [c_int]),
     "mq_gemm_variant_name": (c_char_p, [c_int]),

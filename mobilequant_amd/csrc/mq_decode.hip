@@ -155,14 +155,16 @@ __global__ void decode_pack_grids_kernel(const mq_decode_grid_pack p, float* __r
 //   * STREAM waves DG_PRO .. 15 request ONLY weights and epilogue parameters, meet the image at the barrier, then run the dot
 //     products as their loads return, and the epilogue (one row per lane).
 // Both roles execute the same number of s_barrier (2 with a fused norm, 1 without).
-enum { XM_NORM = 0, XM_F32 = 1, XM_I8 = 2 };
+//   XM_LNORM: QLayerNorm.forward (qmodule.py:624-640 around F.layer_norm; StableLM-2's norm) instead of QRMSNorm: mean, biased variance,
+//     y = (xi * rstd + (-rstd * mean)) * gamma + beta -- the arithmetic of mq_layernorm_quant; three barriers instead of two.
+enum { XM_NORM = 0, XM_F32 = 1, XM_I8 = 2, XM_LNORM = 3 };
 constexpr int DG_PRO = 8, DG_STR = DG_WAVES - DG_PRO, DG_XPRE = 4;      // 512 prologue threads x 4 float4 -> K <= 8192 (fp32)
 
 template <int XMODE, bool GATE, bool W4>
 __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode_gemv_args g, const int rows_per_wg, unsigned long long* stamps) {
   DG_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [K] int8 activation image
-  __shared__ float s_red[DG_PRO];
+  __shared__ float s_red[DG_PRO], s_red2[DG_PRO];
   __shared__ int s_redi[DG_PRO];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -183,18 +185,61 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       }
     } else {
       const int nvec = K >> 2;
-      float4 xv[DG_XPRE], nw[DG_XPRE];
+      constexpr bool ANYNORM = XMODE == XM_NORM || XMODE == XM_LNORM;
+      float4 xv[DG_XPRE], nw[DG_XPRE], nb[DG_XPRE];
 #pragma unroll
       for (int u = 0; u < DG_XPRE; ++u) {
         if (u * DG_PRO * 64 < nvec) {                              // wave-uniform
           const int i = p + u * DG_PRO * 64;
           xv[u] = reinterpret_cast<const float4*>(g.x)[i < nvec ? i : nvec - 1];
-          if constexpr (XMODE == XM_NORM) nw[u] = reinterpret_cast<const float4*>(g.norm_w)[i < nvec ? i : nvec - 1];
+          if constexpr (ANYNORM) nw[u] = reinterpret_cast<const float4*>(g.norm_w)[i < nvec ? i : nvec - 1];
+          if constexpr (XMODE == XM_LNORM)
+            nb[u] = g.norm_bias ? reinterpret_cast<const float4*>(g.norm_bias)[i < nvec ? i : nvec - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       DG_STAMP_ARRIVED(6, 0, xv[0].x);
       const Grid ag = const_grid(cv, CG_A, g.a_grid);            // (the constants were requested before the row: they are here)
-      float r = 1.f;
+      float r = 1.f, shiftv = 0.f;
+      if constexpr (XMODE == XM_LNORM) {                           // QLayerNorm.forward, arithmetic of mq_layernorm_quant (mq_norm.hip)
+        const Grid ng = const_grid(cv, CG_NORM_IN, g.norm_in);
+        float s1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < DG_XPRE; ++u) {
+          if (u * DG_PRO * 64 < nvec) {
+            float4& v = xv[u];
+            v.x = ng.fq(v.x); v.y = ng.fq(v.y); v.z = ng.fq(v.z); v.w = ng.fq(v.w);
+            if (p + u * DG_PRO * 64 < nvec) s1 += (v.x + v.y) + (v.z + v.w);
+          }
+        }
+        s1 = wave_sum_f(s1);
+        if (lane == 0) s_red[wave] = s1;
+        __syncthreads();                                           // barrier 1 of 3
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < DG_PRO; ++w) tot += s_red[w];
+        const float mu = __fdiv_rn(tot, (float)K);
+        float s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < DG_XPRE; ++u) {
+          if (u * DG_PRO * 64 < nvec && p + u * DG_PRO * 64 < nvec) {
+            const float4 v = xv[u];
+            const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+            s2 += d0 * d0;
+            s2 += d1 * d1;
+            s2 += d2 * d2;
+            s2 += d3 * d3;
+          }
+        }
+        s2 = wave_sum_f(s2);
+        if (lane == 0) s_red2[wave] = s2;
+        __syncthreads();                                           // barrier 2 of 3
+        float tot2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < DG_PRO; ++w) tot2 += s_red2[w];
+        const float var = __fdiv_rn(tot2, (float)K);
+        r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, g.eps)));
+        shiftv = __fmul_rn(-r, mu);
+      }
       if constexpr (XMODE == XM_NORM) {                            // QRMSNorm.forward (qmodule.py:515-531), arithmetic of mq_rmsnorm_quant
         const Grid ng = const_grid(cv, CG_NORM_IN, g.norm_in);
         float ss = 0.f;
@@ -232,6 +277,13 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
             const float4 w = nw[u];
             v.x = __fmul_rn(w.x, __fmul_rn(v.x, r)); v.y = __fmul_rn(w.y, __fmul_rn(v.y, r));
             v.z = __fmul_rn(w.z, __fmul_rn(v.z, r)); v.w = __fmul_rn(w.w, __fmul_rn(v.w, r));
+          }
+          if constexpr (XMODE == XM_LNORM) {
+            const float4 w = nw[u], b = nb[u];
+            v.x = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v.x, r), shiftv), w.x), b.x);
+            v.y = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v.y, r), shiftv), w.y), b.y);
+            v.z = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v.z, r), shiftv), w.z), b.z);
+            v.w = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v.w, r), shiftv), w.w), b.w);
           }
           const float f[4] = {v.x, v.y, v.z, v.w};
           unsigned pk = 0;
@@ -301,6 +353,10 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
   }
   float p_res = 0.f;
   if (!GATE && g.resid && prow_ok) p_res = g.resid[prow];
+  if constexpr (XMODE == XM_LNORM) {                               // the prologue waves' mean and variance reductions
+    __syncthreads();
+    __syncthreads();
+  }
   if constexpr (XMODE == XM_NORM) __syncthreads();                 // barrier 1 of 2: the prologue waves' sum of squares
   __syncthreads();                                                 // the image and the row sum are complete
   if (row0 >= row_end) return;
@@ -691,7 +747,8 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
 }
 
 // ---- final norm (floating point HFRMSNorm) + lm_head (fp32 weights) ----------------------------------------------------------------
-__global__ void __launch_bounds__(256) decode_head_kernel(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
+__global__ void __launch_bounds__(256) decode_head_kernel(const float* __restrict__ x, const float* __restrict__ norm_w,
+                                                          const float* __restrict__ norm_b, const int layernorm, float eps,
                                                           const float* __restrict__ w, const float* __restrict__ bias, int K, int V,
                                                           float* __restrict__ logits, unsigned long long* stamps) {
   DG_STAMP(0);
@@ -699,14 +756,40 @@ __global__ void __launch_bounds__(256) decode_head_kernel(const float* __restric
   float* s_x = reinterpret_cast<float*>(smem_raw);               // [K] normalised activation
   __shared__ float s_red[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float ss = 0.f;
-  for (int i = tid; i < K; i += 256) ss += x[i] * x[i];
-  ss = wave_sum_f(ss);
-  if (lane == 0) s_red[wv] = ss;
-  __syncthreads();
-  const float mean = __fdiv_rn((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), (float)K);
-  const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, eps)));      // hf_model.py:183 (x * rsqrt(mean + eps)), then weight *
-  for (int i = tid; i < K; i += 256) s_x[i] = norm_w ? __fmul_rn(norm_w[i], __fmul_rn(x[i], r)) : x[i];
+  if (layernorm) {                                                 // final nn.LayerNorm (StableLM-2: hf_model.py:1440-1441), fp32, torch's expression
+    float s1 = 0.f;
+    for (int i = tid; i < K; i += 256) s1 += x[i];
+    s1 = wave_sum_f(s1);
+    if (lane == 0) s_red[wv] = s1;
+    __syncthreads();
+    const float mu = __fdiv_rn((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), (float)K);
+    __syncthreads();
+    float s2 = 0.f;
+    for (int i = tid; i < K; i += 256) {
+      const float d = x[i] - mu;
+      s2 += d * d;
+    }
+    s2 = wave_sum_f(s2);
+    if (lane == 0) s_red[wv] = s2;
+    __syncthreads();
+    const float var = __fdiv_rn((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), (float)K);
+    const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, eps))), sh = __fmul_rn(-r, mu);
+    for (int i = tid; i < K; i += 256) {
+      float y = __fadd_rn(__fmul_rn(x[i], r), sh);
+      if (norm_w) y = __fmul_rn(y, norm_w[i]);
+      if (norm_b) y = __fadd_rn(y, norm_b[i]);
+      s_x[i] = y;
+    }
+  } else {
+    float ss = 0.f;
+    for (int i = tid; i < K; i += 256) ss += x[i] * x[i];
+    ss = wave_sum_f(ss);
+    if (lane == 0) s_red[wv] = ss;
+    __syncthreads();
+    const float mean = __fdiv_rn((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), (float)K);
+    const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, eps)));      // hf_model.py:183 (x * rsqrt(mean + eps)), then weight *
+    for (int i = tid; i < K; i += 256) s_x[i] = norm_w ? __fmul_rn(norm_w[i], __fmul_rn(x[i], r)) : x[i];
+  }
   __syncthreads();
   // a wave per vocabulary row, float4 loads (16 B per lane)
   const int nvec = K >> 2;
@@ -822,12 +905,19 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   const size_t lds = (size_t)g.K + 64;
   hipStream_t st = as_stream(stream);
   unsigned long long* stamps = STAMP_SLOT(gate ? 1 : (g.norm_w ? 0 : (g.xq ? 3 : 2)), grid);
-  const int xmode = g.xq ? XM_I8 : (g.norm_w ? XM_NORM : XM_F32);
+  const int xmode = g.xq ? XM_I8 : (g.norm_w ? (g.layernorm ? XM_LNORM : XM_NORM) : XM_F32);
+  MQ_REQUIRE(!g.norm_bias || (g.layernorm && aligned(g.norm_bias, 16)), "mq_decode_gemv: norm_bias belongs to the LayerNorm prologue (layernorm = 1), 16-byte aligned");
 #define MQ_DG_LAUNCH(XM, GT, W4)                                                                                   \
   decode_gemv_kernel<XM, GT, W4><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps)
-  if (gate) {
+  if (gate && xmode == XM_LNORM) {
+    if (g.w4) MQ_DG_LAUNCH(XM_LNORM, true, true);
+    else MQ_DG_LAUNCH(XM_LNORM, true, false);
+  } else if (gate) {
     if (g.w4) MQ_DG_LAUNCH(XM_NORM, true, true);
     else MQ_DG_LAUNCH(XM_NORM, true, false);
+  } else if (xmode == XM_LNORM) {
+    if (g.w4) MQ_DG_LAUNCH(XM_LNORM, false, true);
+    else MQ_DG_LAUNCH(XM_LNORM, false, false);
   } else if (xmode == XM_NORM) {
     if (g.w4) MQ_DG_LAUNCH(XM_NORM, false, true);
     else MQ_DG_LAUNCH(XM_NORM, false, false);
@@ -886,13 +976,13 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
   return MQ_OK;
 }
 
-int mq_decode_head(const float* x, const float* norm_weight, float eps, const float* w, const float* bias, int64_t K, int64_t V,
-                   float* logits, mq_stream_t stream) {
+int mq_decode_head(const float* x, const float* norm_weight, const float* norm_bias, int layernorm, float eps, const float* w, const float* bias,
+                   int64_t K, int64_t V, float* logits, mq_stream_t stream) {
   MQ_REQUIRE(x && w && logits && K > 0 && K % 4 == 0 && K <= 12288 && V > 0, "mq_decode_head: bad arguments (K %% 4 == 0, K <= 12288)");
   MQ_REQUIRE(aligned(w, 16), "mq_decode_head: the weight must be 16-byte aligned");
   int64_t blocks = (V + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  decode_head_kernel<<<(unsigned)blocks, 256, (size_t)K * sizeof(float), as_stream(stream)>>>(x, norm_weight, eps, w, bias, (int)K, (int)V, logits,
+  decode_head_kernel<<<(unsigned)blocks, 256, (size_t)K * sizeof(float), as_stream(stream)>>>(x, norm_weight, norm_bias, layernorm, eps, w, bias, (int)K, (int)V, logits,
                                                                                     STAMP_SLOT(5, (unsigned)blocks));
   MQ_LAUNCH_CHECK("mq_decode_head");
   return MQ_OK;

@@ -117,7 +117,11 @@ class DecodeEngine:
         self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
         assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
         self.embed = model.embed_tokens.weight.detach()
+        if s.embed_scale:                                    # normalize_embed (Gemma; hf_model.py:1555-1556): x = embed * hidden ** 0.5
+            self.embed = self.embed * (s.hidden ** 0.5)      # the same fp32 product the module graph forms per token
+        self.norm_ln = isinstance(model.norm, torch.nn.LayerNorm)
         self.norm_w = model.norm.weight.detach().float().contiguous()
+        self.norm_b = model.norm.bias.detach().float().contiguous() if getattr(model.norm, "bias", None) is not None else None
         self.lm_w = model.lm_head.weight.detach().float().contiguous()
         self.lm_b = model.lm_head.bias.detach().float().contiguous() if model.lm_head.bias is not None else None
         self.phases = []          # (kind, ctypes struct) in launch order
@@ -144,12 +148,22 @@ class DecodeEngine:
         self.graph = None
 
     # -- lowering ----------------------------------------------------------------------------------------------------------
-    def _norm_args(self, norm: Q.QRMSNorm, a: MqDecodeGemvArgs):
-        if not isinstance(norm, Q.QRMSNorm) or norm.l2norm_as_rmsnorm or norm.bias is not None:
-            raise RuntimeError("DecodeEngine: QRMSNorm layers (plain RMS form, no bias) only")
+    def _norm_args(self, norm, a: MqDecodeGemvArgs):
+        """QRMSNorm (qmodule.py:469-530) or QLayerNorm (qmodule.py:579-640; StableLM-2) fused in front of the weight stream."""
+        ln = isinstance(norm, Q.QLayerNorm)
+        if ln:
+            if norm.use_temporary_parameter or norm.weight is None:
+                raise RuntimeError("DecodeEngine: QLayerNorm needs its affine weight and no temporary (LET) parameters")
+        elif not isinstance(norm, Q.QRMSNorm) or norm.l2norm_as_rmsnorm or norm.bias is not None:
+            raise RuntimeError("DecodeEngine: QRMSNorm (plain RMS form, no bias) or QLayerNorm layers only")
         wfq = Q._apply(norm.weight_quantizer, norm.weight.detach()).float().contiguous()
         self._keep.append(wfq)
         a.norm_w, a.norm_in, a.eps = wfq.data_ptr(), _grid(norm.input_quantizer, self._keep), float(norm.eps)
+        a.layernorm = int(ln)
+        if ln and norm.bias is not None:
+            nb = norm.bias.detach().float().contiguous()
+            self._keep.append(nb)
+            a.norm_bias = nb.data_ptr()
         a.a_grid = _grid(norm.output_quantizer, self._keep)
         if norm.output_quantizer is None or norm.output_quantizer.qmax != 255:
             raise RuntimeError("DecodeEngine: the norm feeding a linear needs an 8-bit unsigned output grid")
@@ -190,7 +204,8 @@ class DecodeEngine:
         a = MqDecodeGemvArgs()
         g_in = self._norm_args(layer.input_layernorm, a)
         qkv = _Linear([attn.q_proj, attn.k_proj, attn.v_proj], g_in)
-        p1 = self._gemv(qkv, x=self.x.data_ptr(), norm_w=a.norm_w, norm_in=a.norm_in, eps=a.eps, a_grid=a.a_grid, y=self.qkv.data_ptr())
+        p1 = self._gemv(qkv, x=self.x.data_ptr(), norm_w=a.norm_w, norm_bias=a.norm_bias, layernorm=a.layernorm, norm_in=a.norm_in, eps=a.eps,
+                        a_grid=a.a_grid, y=self.qkv.data_ptr())
         p1.seg_end[0], p1.seg_end[1] = qkv.rows[0], qkv.rows[0] + qkv.rows[1]
         for k, lin in enumerate((attn.q_proj, attn.k_proj, attn.v_proj)):
             p1.out_grid[k] = _grid(lin.output_quantizer, keep)
@@ -229,7 +244,8 @@ class DecodeEngine:
         iq2 = mlp.w2.input_quantizer
         if iq2 is None or iq2.qmax != 255:
             raise RuntimeError("DecodeEngine: w2 needs its own 8-bit unsigned input quantizer")
-        p4 = self._gemv(w13, x=self.x.data_ptr(), norm_w=a2.norm_w, norm_in=a2.norm_in, eps=a2.eps, a_grid=a2.a_grid,
+        p4 = self._gemv(w13, x=self.x.data_ptr(), norm_w=a2.norm_w, norm_bias=a2.norm_bias, layernorm=a2.layernorm, norm_in=a2.norm_in,
+                        eps=a2.eps, a_grid=a2.a_grid,
                         gate_q=self.gate_q.data_ptr(), gate_act=0 if isinstance(act, Q.QSiLU) else 1,
                         gate_mid=_grid(act.input2_quantizer if isinstance(act, Q.QSiLU) else None, keep),
                         gate_actout=_grid(act.output_quantizer, keep), gate_out=_grid(iq2, keep))
@@ -248,7 +264,8 @@ class DecodeEngine:
         torch.index_select(self.embed, 0, self.tok, out=self.x.view(1, -1))
         for kind, a in self.phases:
             _lib.call("mq_decode_gemv" if kind == "gemv" else "mq_decode_attention", ctypes.byref(a), st)
-        _lib.call("mq_decode_head", self.x.data_ptr(), self.norm_w.data_ptr(), float(self.model.norm.eps), self.lm_w.data_ptr(),
+        _lib.call("mq_decode_head", self.x.data_ptr(), self.norm_w.data_ptr(), self.norm_b.data_ptr() if self.norm_b is not None else None,
+                  int(self.norm_ln), float(self.model.norm.eps), self.lm_w.data_ptr(),
                   self.lm_b.data_ptr() if self.lm_b is not None else None, self.shape.hidden, self.shape.vocab, self.logits.data_ptr(), st)
 
     def capture(self):

@@ -35,10 +35,38 @@ class LlamaShape:
     rope_theta: float = 10000.0
     max_pos: int = 2048
     hidden_act: str = "silu"            # "silu" (llama: SwiGLU) | "gelu" (gemma-style GeGLU, erf form: transformers' ACT2FN["gelu"])
+    # the switches of the reference's HFConfig (mobilellm/model/hf_config.py:101-179) its other two model families set:
+    norm: str = "rmsnorm"               # "layernorm": nn.LayerNorm with bias (StableLM-2; hf_model.py:1036-1040, :1197-1203, :1440)
+    qkv_bias: bool = False              # attention_bias + use_qkv_bias_only: bias on q / k / v, none on o_proj (hf_model.py:414-417)
+    rotary_pct: float = 1.0             # partial_rotary_factor: RoPE on the first int(pct * head_dim) dims (hf_model.py:419, :487-500)
+    embed_scale: bool = False           # normalize_embed: embeddings * hidden ** 0.5 (Gemma; hf_model.py:1555-1556)
+
+    @property
+    def rot_dim(self) -> int:
+        return int(self.rotary_pct * self.head_dim)
 
     @classmethod
     def tinyllama(cls, **kw) -> "LlamaShape":
         return cls(**kw)
+
+    @classmethod
+    def stablelm_2_1_6b(cls, **kw) -> "LlamaShape":
+        """BASELINE.json configs[2]: hidden 2048, 24 layers, 32 / 32 heads of 64, FFN 5632, LayerNorm, q / k / v bias, 25 % rotary
+        (the public HF config; the reference only names the model: README.md:19, scripts/convert_ckpt.py:29)."""
+        base = dict(hidden=2048, layers=24, heads=32, kv_heads=32, head_dim=64, ffn=5632, vocab=100352, eps=1e-5, max_pos=4096,
+                    norm="layernorm", qkv_bias=True, rotary_pct=0.25)
+        base.update(kw)
+        return cls(**base)
+
+    @classmethod
+    def gemma_2b(cls, **kw) -> "LlamaShape":
+        """BASELINE.json configs[3] (mobilellm/model/sim_model.py:45-46): hidden 2048, 18 layers, 8 heads / 1 KV head of 256, FFN 16384,
+        GeGLU, vocab 256000, scaled embeddings.  (Gemma's `1 + weight` norm is folded into the weights at checkpoint conversion:
+        scripts/convert_ckpt.py:48-55, so the graph carries a plain HFRMSNorm.)"""
+        base = dict(hidden=2048, layers=18, heads=8, kv_heads=1, head_dim=256, ffn=16384, vocab=256000, eps=1e-6, max_pos=8192,
+                    hidden_act="gelu", embed_scale=True)
+        base.update(kw)
+        return cls(**base)
 
     @classmethod
     def toy(cls, **kw) -> "LlamaShape":
@@ -48,15 +76,19 @@ class LlamaShape:
 
 
 def rope_tables(shape: LlamaShape, device=None):
-    """cos / sin [max_pos, head_dim] (rotate-half convention, hf_model.py:486-501)."""
-    inv = 1.0 / (shape.rope_theta ** (torch.arange(0, shape.head_dim, 2, dtype=torch.float32, device=device) / shape.head_dim))
+    """cos / sin [max_pos, rot_dim] (rotate-half convention, hf_model.py:486-501; rot_dim < head_dim: partial rotary)."""
+    rd = shape.rot_dim
+    inv = 1.0 / (shape.rope_theta ** (torch.arange(0, rd, 2, dtype=torch.float32, device=device) / rd))
     ang = torch.outer(torch.arange(shape.max_pos, dtype=torch.float32, device=device), inv)
     ang = torch.cat((ang, ang), dim=-1)
     return ang.cos(), ang.sin()
 
 
 def apply_rope(x, cos, sin):
-    """x [B, H, S, D]; cos/sin [S, D]."""
+    """x [B, H, S, D]; cos / sin [S, rot]: the first rot dims rotate, the rest passes through (hf_model.py:487-500)."""
+    rd = cos.shape[-1]
+    if rd < x.shape[-1]:
+        return torch.cat((apply_rope(x[..., :rd], cos, sin), x[..., rd:]), dim=-1)
     h = x.shape[-1] // 2
     rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
     return x * cos + rot * sin
@@ -66,9 +98,9 @@ class Attention(nn.Module):
     def __init__(self, s: LlamaShape):
         super().__init__()
         self.s = s
-        self.q_proj = nn.Linear(s.hidden, s.heads * s.head_dim, bias=False)
-        self.k_proj = nn.Linear(s.hidden, s.kv_heads * s.head_dim, bias=False)
-        self.v_proj = nn.Linear(s.hidden, s.kv_heads * s.head_dim, bias=False)
+        self.q_proj = nn.Linear(s.hidden, s.heads * s.head_dim, bias=s.qkv_bias)
+        self.k_proj = nn.Linear(s.hidden, s.kv_heads * s.head_dim, bias=s.qkv_bias)
+        self.v_proj = nn.Linear(s.hidden, s.kv_heads * s.head_dim, bias=s.qkv_bias)
         self.o_proj = nn.Linear(s.heads * s.head_dim, s.hidden, bias=False)
         self.qk_bmm, self.pv_bmm = FMatMul(), FMatMul()
 
@@ -113,7 +145,7 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
     if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim != 64 or S < 2
-            or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
+            or s.rot_dim != s.head_dim or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
             or Q._needs_grad(x, *self.parameters())):
         return plain(x, cos, sin, mask, cache, pos)
     if not (Q._u8_grid(qk.input_quantizer) and Q._u8_grid(qk.input2_quantizer) and Q._u8_grid(pv.input2_quantizer)
@@ -269,13 +301,18 @@ class MLP(nn.Module):
         return self.w2(self.act_fn(self.w1(x)) * self.w3(x))
 
 
+def _make_norm(s: LlamaShape) -> nn.Module:
+    assert s.norm in ("rmsnorm", "layernorm"), s.norm
+    return HFRMSNorm(s.hidden, eps=s.eps) if s.norm == "rmsnorm" else nn.LayerNorm(s.hidden, eps=s.eps)
+
+
 class DecoderLayer(nn.Module):
     def __init__(self, s: LlamaShape):
         super().__init__()
         self.self_attn = Attention(s)
         self.mlp = MLP(s)
-        self.input_layernorm = HFRMSNorm(s.hidden, eps=s.eps)
-        self.post_attention_layernorm = HFRMSNorm(s.hidden, eps=s.eps)
+        self.input_layernorm = _make_norm(s)
+        self.post_attention_layernorm = _make_norm(s)
 
     def forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
         x = x + self.self_attn(self.input_layernorm(x), cos, sin, mask, cache, pos)
@@ -291,7 +328,7 @@ class LlamaForCausalLM(nn.Module):
         self.shape = shape
         self.embed_tokens = nn.Embedding(shape.vocab, shape.hidden)
         self.layers = nn.ModuleList(DecoderLayer(shape) for _ in range(shape.layers))
-        self.norm = HFRMSNorm(shape.hidden, eps=shape.eps)
+        self.norm = _make_norm(shape)
         self.lm_head = nn.Linear(shape.hidden, shape.vocab, bias=False)
         cos, sin = rope_tables(shape)
         self.register_buffer("cos", cos, persistent=False)
@@ -303,8 +340,10 @@ class LlamaForCausalLM(nn.Module):
         g = None
         if seed is not None:
             g = torch.Generator(device="cpu").manual_seed(seed)
-        for p in self.parameters():
+        for name, p in self.named_parameters():
             if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * std) if g is not None else p.normal_(0.0, std)
+            elif name.endswith("bias"):
                 p.copy_(torch.randn(p.shape, generator=g) * std) if g is not None else p.normal_(0.0, std)
             else:
                 p.fill_(1.0)
@@ -313,6 +352,8 @@ class LlamaForCausalLM(nn.Module):
         """ids [B, S] token ids.  cache: list (one per layer) of (k, v) static buffers [B, KV, T, D], see Attention.forward."""
         B, S = ids.shape
         x = self.embed_tokens(ids)
+        if self.shape.embed_scale:
+            x = x * (self.shape.hidden ** 0.5)
         cos, sin = self.cos[pos:pos + S], self.sin[pos:pos + S]
         mask = None
         if S > 1:

@@ -22,6 +22,8 @@ Fixtures written (all data, no reference source text):
   lwc_cases.npz           a7     learnable weight clipping: forward values, gradients to the bound factors and the weight, run_lwc
   qmatmul_cases.npz       a10    QMatMul.forward at attention shapes (qk_bmm / pv_bmm mixed-precision rules)
   toy_lm_nll.npz          perplexity proxy: the reference's W8A8-sim logits + NLL of the toy LM on 96 tokens
+  decode_case_stablelm.npz / decode_case_gemma.npz   configs[2] / [3] leaf graphs (LayerNorm + q|k|v bias + partial rotary; head_dim 256
+                          + GeGLU + scaled embeddings) of the reference's HFForCausalLM at toy size, their recipes' logits
   decode_case.npz         f2: W8A8-sim logits of the reference's real HFForCausalLM (2 layers) at every position of a sequence
   smooth_cases.npz        n1/f3/f4 on the reference's real HFForCausalLM (2 layers): fp logits, get_act_scales, smooth_lm fold,
                           smooth_lm_temporary / _inplace (LET) temp weights, Quantizer indices of x / s
@@ -903,7 +905,7 @@ def gen_decode_case():
     print("decode_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
 
 
-def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2, act="silu"):
+def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2, act="silu", heads=4, wsym=False, cfg_kw=None):
     """The reference's deployment recipe on the 2-layer model of gen_decode_case: packed-4-bit-style weights (4-bit per-channel
     asymmetric, as experiments/w4a8/main/e2e_llama-s1024-ep60.sh:23), 8-bit activations, mixed-precision rules of
     ptq/mobilequant.py:175-201.  Weights from tests/seeded.py (not stored); logits of the REAL HFForCausalLM at every position."""
@@ -911,8 +913,8 @@ def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2, act="silu"):
     from seeded import seeded_parameters_
     from mobilellm.model.hf_config import HFConfig
     from mobilellm.model.hf_model import HFForCausalLM
-    cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
-                   num_key_value_heads=kv_heads, max_position_embeddings=64, hidden_act=act, use_matmul_as_module=True)
+    cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=heads,
+                   num_key_value_heads=kv_heads, max_position_embeddings=64, hidden_act=act, use_matmul_as_module=True, **(cfg_kw or {}))
     cfg._attn_implementation = "eager"
     m = HFForCausalLM(cfg).eval()
     seeded_parameters_(m, std=0.08, strip="model.")
@@ -933,7 +935,7 @@ def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2, act="silu"):
     m.forward = lambda x_, **kw: _orig(x_, use_cache=False)
     act = rng_mod.get_act_range(m, _Tk(), [{"text": str(i)} for i in range(len(calib))], len(calib), 64)
     m.forward = _orig
-    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=wbits, is_per_channel=True), Q.QuantConfig(bitwidth=8))
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=wbits, is_per_channel=True, is_symmetric=wsym), Q.QuantConfig(bitwidth=8))
     for name, mod in m.named_modules():          # ptq/mobilequant.py:175-201
         if isinstance(mod, Q.QLinear):
             if "w2" in name:
@@ -941,15 +943,18 @@ def gen_decode_case_w4(tag="w4", wbits=4, kv_heads=2, act="silu"):
                 mod.output_quantizer.qcfg.bitwidth = 16
             elif "o_proj" in name:
                 mod.output_quantizer.qcfg.bitwidth = 16
-        elif isinstance(mod, Q.QRMSNorm):
+        elif isinstance(mod, (Q.QRMSNorm, Q.QLayerNorm)):
             mod.input_quantizer.qcfg.bitwidth = 16
             mod.weight_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.is_symmetric = False
+            mod.weight_quantizer.qcfg.is_per_channel = False
         elif isinstance(mod, Q.QMatMul):
             if "qk_bmm" in name:
                 mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name:
                 mod.input_quantizer.qcfg.bitwidth = 16
-    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules() if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU, Q.QGELU)))}
+    act = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in m.named_modules()
+                                                  if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QLayerNorm, Q.QMatMul, Q.QSiLU, Q.QGELU)))}
     Q.set_scale_and_offset(m, act, "buffer")
     with torch.no_grad():
         out["logits_w4a8"] = npf(m(ids, use_cache=False).logits)      # (key kept for every variant: the quantised logits)
@@ -968,6 +973,21 @@ def gen_decode_case_w8pc_mha():
 def gen_decode_case_gelu():
     """Gemma-style gated MLP (GeGLU: act_fn = GELU -> QGELU, qmodule.py:756-798, :856) with multi-query attention (4 / 1 heads), W4A8."""
     gen_decode_case_w4(tag="w4_geglu_mqa", wbits=4, kv_heads=1, act="gelu")
+
+
+def gen_decode_case_stablelm():
+    """BASELINE.json configs[2], the StableLM-2 leaf graph (hf_config.py: norm_class = layernorm, attention_bias + use_qkv_bias_only,
+    partial_rotary_factor = 0.25) at toy size: nn.LayerNorm -> QLayerNorm (qmodule.py:861-862), biased q / k / v, RoPE on the first
+    16 of 64 head dims, full multi-head attention; 8-bit PER-CHANNEL weights, the mixed-precision rules of ptq/mobilequant.py:175-201."""
+    gen_decode_case_w4(tag="stablelm", wbits=8, kv_heads=4,
+                       cfg_kw=dict(norm_class="layernorm", attention_bias=True, use_qkv_bias_only=True, partial_rotary_factor=0.25))
+
+
+def gen_decode_case_gemma():
+    """BASELINE.json configs[3], the Gemma leaf graph (sim_model.py:45-46 at toy size): explicit head_dim 256 (2 heads / 1 KV head:
+    heads * head_dim != hidden), GeGLU, embeddings scaled by sqrt(hidden) (normalize_embed); 4-bit per-channel SYMMETRIC weights
+    (experiments/w4a8/main/e2e_gemma-s1024-ep60-sym.sh:23), 8-bit activations."""
+    gen_decode_case_w4(tag="gemma", wbits=4, kv_heads=1, act="gelu", heads=2, wsym=True, cfg_kw=dict(head_dim=256, normalize_embed=True))
 
 
 def gen_layer_case():
@@ -1045,6 +1065,8 @@ if __name__ == "__main__":
     gen_decode_case_w4()
     gen_decode_case_w8pc_mha()
     gen_decode_case_gelu()
+    gen_decode_case_stablelm()
+    gen_decode_case_gemma()
     gen_layer_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()

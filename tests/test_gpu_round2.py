@@ -1117,18 +1117,19 @@ def test_decode_engine_w4a8_matches_module_graph(dev):
     span = float(np.ptp(want))
     d = np.abs(got - want)
     assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span and (d <= 0.01 * span).mean() >= 0.97, (d.max() / span, np.median(d) / span)
-    # the fused prefill passes on the same W4A8 model: q|k|v as one segmented W4 GEMM, w1 / w3 as two index-writing W4 GEMMs
+    # the fused prefill passes on the same W4A8 model: q|k|v as one segmented GEMM, w1 / w3 as the pair launch
     from mobilequant_amd import llama, ops
     seg = []
     real_seg = ops.int8_linear_segmented
-    ops.int8_linear_segmented = lambda *a, **k: (seg.append(k.get("w4")), real_seg(*a, **k))[1]
+    ops.int8_linear_segmented = lambda *a, **k: (seg.append((k.get("w4"), a[1].dtype, int(a[1].max()) <= 15)), real_seg(*a, **k))[1]
     try:
         with torch.no_grad():
             assert llama.fuse_decoder_layer(m) == 2
             fused = m(ids.to(dev))[0].cpu().numpy()
     finally:
         ops.int8_linear_segmented = real_seg
-    assert seg == [True, True]
+    # 4-bit weights at prefill: the int8 MFMA kernels on the one-byte-per-nibble image (values 0 .. 15), not the packed image
+    assert seg == [(False, torch.int8, True)] * 2
     d = np.abs(fused - want)
     assert d.max() <= 0.05 * span and np.median(d) <= 0.001 * span, (d.max() / span, np.median(d) / span)
 
@@ -1158,10 +1159,14 @@ def test_gated_table_is_the_gated_kernel_for_every_index_pair(dev, act):
                                                                  q_shift=128)[0])
 
 
-@pytest.mark.parametrize("tag,wbits,kv_heads,act", [("w4", 4, 2, "silu"), ("w8pc_mha", 8, 4, "silu"), ("w4_geglu_mqa", 4, 1, "gelu")])
+@pytest.mark.parametrize("tag,wbits,kv_heads,act", [("w4", 4, 2, "silu"), ("w8pc_mha", 8, 4, "silu"), ("w4_geglu_mqa", 4, 1, "gelu"),
+                                                    ("stablelm", 8, 4, "silu"), ("gemma", 4, 1, "gelu")])
 def test_other_recipes_against_the_reference_model(dev, tag, wbits, kv_heads, act):
     """(w8pc_mha: the configs[2]-style recipe -- 8-bit per-channel weights everywhere -- with full multi-head attention;
-    w4_geglu_mqa: gemma-style GeGLU MLP (QGELU) with multi-query attention, W4A8.)
+    w4_geglu_mqa: gemma-style GeGLU MLP (QGELU) with multi-query attention, W4A8;
+    stablelm / gemma: BASELINE.json configs[2] / [3] on their OWN leaf graphs -- nn.LayerNorm -> QLayerNorm, biased q / k / v and 25 %
+    rotary; head_dim 256 with heads * head_dim != hidden, GeGLU and scaled embeddings -- from the reference's HFForCausalLM under the
+    matching HFConfig switches (hf_config.py:101-179), W8 per-channel / W4 per-channel symmetric.)
     The reference's W4A8 deployment recipe (4-bit per-channel weights, 8-bit activations) on the 2-layer model, against the logits of
     the reference's REAL HFForCausalLM (tests/golden/decode_case_w4.npz; weights regenerated from tests/seeded.py): the module graph on
     the W4 integer GEMMs, the fused prefill passes (segmented W4 q|k|v, two-GEMM gated MLP) and the W4 decode engine token by token."""
@@ -1172,8 +1177,10 @@ def test_other_recipes_against_the_reference_model(dev, tag, wbits, kv_heads, ac
     from mobilequant_amd.decode import DecodeEngine
     from seeded import seeded_parameters_
     z = load_npz(f"decode_case_{tag}.npz")
-    m = llama.LlamaForCausalLM(llama.LlamaShape(hidden=256, layers=2, heads=4, kv_heads=kv_heads, head_dim=64, ffn=512, vocab=96, eps=1e-5,
-                                                max_pos=64, hidden_act=act)).eval()
+    from test_llama_host import FAMILY_SHAPES
+    shape_kw = FAMILY_SHAPES.get(tag) or dict(hidden=256, layers=2, heads=4, kv_heads=kv_heads, head_dim=64, ffn=512, vocab=96, eps=1e-5,
+                                              max_pos=64, hidden_act=act)
+    m = llama.LlamaForCausalLM(llama.LlamaShape(**shape_kw)).eval()
     seeded_parameters_(m, std=0.08)
     m = m.to(dev)
     strip = lambda d: {(k[len("model."):] if k.startswith("model.") else k): v for k, v in d.items()}      # noqa: E731

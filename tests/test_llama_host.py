@@ -74,3 +74,34 @@ def test_reference_artifact_files_are_reproduced_byte_for_byte(tmp_path):
     S.save_act_dict_per_channel(str(p3), pc)
     back = torch.load(str(p3), map_location="cpu")
     assert back.keys() == pc.keys() and torch.equal(back["m"]["input"], pc["m"]["input"]) and back["m"]["output"].shape == (2, 3)
+
+
+FAMILY_SHAPES = {
+    # BASELINE.json configs[2] / [3]: the reference's HFConfig switches for StableLM-2 and Gemma (hf_config.py:101-179) at toy size
+    "stablelm": dict(hidden=256, layers=2, heads=4, kv_heads=4, head_dim=64, ffn=512, vocab=96, eps=1e-5, max_pos=64,
+                     norm="layernorm", qkv_bias=True, rotary_pct=0.25),
+    "gemma": dict(hidden=256, layers=2, heads=2, kv_heads=1, head_dim=256, ffn=512, vocab=96, eps=1e-5, max_pos=64, hidden_act="gelu",
+                  embed_scale=True),
+}
+
+
+@pytest.mark.parametrize("tag", ["stablelm", "gemma"])
+def test_other_model_families_equal_the_reference_hf_model(tag):
+    """LlamaShape's family switches (LayerNorm + q|k|v bias + partial rotary; explicit head_dim + GeGLU + scaled embeddings) against
+    the fp32 logits of the reference's HFForCausalLM under the matching HFConfig (tests/golden/decode_case_<tag>.npz; weights from
+    tests/seeded.py on both sides), full forward and prefill + single-token steps over the static KV cache."""
+    from seeded import seeded_parameters_
+    z = load_npz(f"decode_case_{tag}.npz")
+    m = LlamaForCausalLM(LlamaShape(**FAMILY_SHAPES[tag])).eval()
+    seeded_parameters_(m, std=0.08)
+    ids = torch.from_numpy(z["ids"]).long()[None]
+    want = z["logits_fp"]
+    with torch.no_grad():
+        got = m(ids).numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), np.abs(got - want).max()
+        cache = m.new_cache(1, 64)
+        outs = [m(ids[:, :16], cache=cache, pos=0)] + [m(ids[:, t:t + 1], cache=cache, pos=t) for t in range(16, 40)]
+        assert np.abs(torch.cat(outs, dim=1).numpy() - want).max() <= 2e-4 * np.abs(want).max()
+    names = dict(m.named_modules())
+    assert isinstance(names["layers.0.input_layernorm"], torch.nn.LayerNorm) == (tag == "stablelm")
+    assert (names["layers.0.self_attn.q_proj"].bias is not None) == (tag == "stablelm") and names["layers.0.self_attn.o_proj"].bias is None
