@@ -343,10 +343,12 @@ class DecodeEngine:
         return self.logits
 
     @torch.no_grad()
-    def generate(self, context_ids, max_new_tokens: int, eos_token_id=None, prefill: bool = True):
-        """Greedy generation (sim_model.py:160-221 with do_sample = False): context encoding in one prefill forward (prefill=False:
-        token by token through the step kernels), then argmax on the device into self.tok; the host reads one token id per step only
-        to test for EOS."""
+    def generate(self, context_ids, max_new_tokens: int, eos_token_id=None, prefill: bool = True, do_sample: bool = False,
+                 temperature: float = 0.5, generator: Optional[torch.Generator] = None):
+        """SimModel.generate (mobilellm/model/sim_model.py:160-221): context encoding in one prefill forward (prefill=False: token by
+        token through the step kernels), then per new token: next = argmax(logits) or, with do_sample, multinomial(softmax(logits /
+        temperature)) (:198-201) -- on the device, into self.tok --, append it, stop if it is an EOS (:202-204), else run the step.
+        The host reads one token id per step only to test for EOS and to return the ids."""
         ids = [int(t) for t in context_ids]
         assert len(ids) + max_new_tokens <= self.cache_len
         self.reset()
@@ -358,10 +360,16 @@ class DecodeEngine:
         out = list(ids)
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         for _ in range(max_new_tokens):
-            torch.argmax(self.logits, dim=-1, keepdim=True, out=self.tok)
+            if do_sample:
+                probs = torch.softmax(self.logits / temperature, dim=-1)
+                self.tok.copy_(torch.multinomial(probs, num_samples=1, generator=generator))
+            else:
+                torch.argmax(self.logits, dim=-1, keepdim=True, out=self.tok)
             nxt = int(self.tok.item())
             out.append(nxt)
             if nxt in eos:
+                break
+            if self._host_pos >= self.cache_len:
                 break
             self.step()
         return out

@@ -24,6 +24,7 @@ Fixtures written (all data, no reference source text):
   toy_lm_nll.npz          perplexity proxy: the reference's W8A8-sim logits + NLL of the toy LM on 96 tokens
   decode_case_stablelm.npz / decode_case_gemma.npz   configs[2] / [3] leaf graphs (LayerNorm + q|k|v bias + partial rotary; head_dim 256
                           + GeGLU + scaled embeddings) of the reference's HFForCausalLM at toy size, their recipes' logits
+  generate_case.npz       f2: greedy free-running continuation (SimModel.generate's loop) of the decode_case model under the reference
   decode_case.npz         f2: W8A8-sim logits of the reference's real HFForCausalLM (2 layers) at every position of a sequence
   smooth_cases.npz        n1/f3/f4 on the reference's real HFForCausalLM (2 layers): fp logits, get_act_scales, smooth_lm fold,
                           smooth_lm_temporary / _inplace (LET) temp weights, Quantizer indices of x / s
@@ -975,6 +976,47 @@ def gen_decode_case_gelu():
     gen_decode_case_w4(tag="w4_geglu_mqa", wbits=4, kv_heads=1, act="gelu")
 
 
+def gen_generate_case():
+    """f2: SimModel.generate's loop (mobilellm/model/sim_model.py:160-221: next token = argmax of the logits behind the context, append,
+    stop at EOS, feed the token back) run FREE on the reference's W8A8-simulated HFForCausalLM of decode_case.npz (same weights,
+    ranges and qcfg, loaded from that fixture): the greedy continuation of an 8-token context, 12 new tokens, each step a full
+    forward of the reference model (no cache: the same function of the tokens so far).  Of 300 random contexts the one whose
+    smallest top-1 / top-2 margin is largest is kept (> 1 % of the logit span: the decode tests hold the logits to a median of 0.2 %),
+    so a faithful implementation does not flip a token on rounding noise."""
+    from mobilellm.model.hf_config import HFConfig
+    from mobilellm.model.hf_model import HFForCausalLM
+    z = np.load(os.path.join(OUT, "decode_case.npz"), allow_pickle=False)
+    cfg = HFConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                   num_key_value_heads=2, max_position_embeddings=64, hidden_act="silu", use_matmul_as_module=True)
+    cfg._attn_implementation = "eager"
+    m = HFForCausalLM(cfg).eval()
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd|")}
+    m.load_state_dict(sd, strict=True)
+    Q.create_sim_qmodel(m, Q.QuantConfig(bitwidth=8), Q.QuantConfig(bitwidth=8))
+    Q.update_qcfg(m, json.loads(str(z["qcfg"])))
+    Q.set_scale_and_offset(m, json.loads(str(z["act"])), "buffer")
+    span = float(np.ptp(z["logits_fp"]))
+    g = torch.Generator().manual_seed(77)
+    best = None
+    for attempt in range(300):
+        ctx = torch.randint(3, 96, (8,), generator=g)
+        toks, margins = ctx.tolist(), []
+        for _ in range(12):
+            logits = m(torch.tensor(toks)[None], use_cache=False).logits[0, -1]
+            top = torch.topk(logits, 2).values
+            margins.append(float(top[0] - top[1]) / span)
+            toks.append(int(torch.argmax(logits)))          # sim_model.py:200-201
+            if margins[-1] < (best[0] if best else 0.0):
+                break
+        if len(margins) == 12 and (best is None or min(margins) > best[0]):
+            best = (min(margins), toks, margins)
+    assert best is not None and best[0] > 0.01, best
+    _, toks, margins = best
+    np.savez_compressed(os.path.join(OUT, "generate_case.npz"), context=np.array(toks[:8], np.int64), tokens=np.array(toks, np.int64),
+                        margins=np.array(margins, np.float32))
+    print("generate_case: tokens", toks, "min margin %.4f of span" % min(margins))
+
+
 def gen_decode_case_stablelm():
     """BASELINE.json configs[2], the StableLM-2 leaf graph (hf_config.py: norm_class = layernorm, attention_bias + use_qkv_bias_only,
     partial_rotary_factor = 0.25) at toy size: nn.LayerNorm -> QLayerNorm (qmodule.py:861-862), biased q / k / v, RoPE on the first
@@ -1065,6 +1107,7 @@ if __name__ == "__main__":
     gen_decode_case_w4()
     gen_decode_case_w8pc_mha()
     gen_decode_case_gelu()
+    gen_generate_case()
     gen_decode_case_stablelm()
     gen_decode_case_gemma()
     gen_layer_case()

@@ -177,3 +177,39 @@ def test_prefill_attention_with_a_score_grid_too_wide_for_the_fixed_reference(de
     step = float(pv[2].scale)
     diff = np.abs(got - want)
     assert np.isfinite(got).all() and diff.max() <= 1.001 * step and (diff > 0.5 * step).mean() < 0.02, (diff.max(), step)
+
+
+def test_generate_reproduces_the_reference_models_free_running_greedy_stream_and_sampling_rule(dev):
+    """DecodeEngine.generate is SimModel.generate's loop (sim_model.py:160-221).  Greedy: the 12-token continuation the reference's
+    W8A8-simulated HFForCausalLM produces for an 8-token context when run free (tests/golden/generate_case.npz: every step's
+    top-1 / top-2 margin >= 3 % of the logit span), with the context encoded by the prefill forward and token by token.  do_sample:
+    next = multinomial(softmax(logits / temperature)) (:198-199) with a seeded device generator == the same rule applied by hand to
+    the engine's own logits, step by step; EOS ends the stream AFTER the token is appended (:202-204)."""
+    from conftest import load_npz
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd.decode import DecodeEngine
+    m, _ = _decode_model(dev)
+    z = load_npz("generate_case.npz")
+    ctx, want = z["context"].tolist(), z["tokens"].tolist()
+    eng = DecodeEngine(m, cache_len=64)
+    assert eng.generate(ctx, len(want) - len(ctx)) == want
+    assert eng.generate(ctx, len(want) - len(ctx), prefill=False) == want
+    eng.capture()
+    assert eng.generate(ctx, len(want) - len(ctx)) == want
+    # EOS: the stream stops right behind the first occurrence of the EOS id, which is kept
+    eos = want[len(ctx) + 3]
+    cut = eng.generate(ctx, len(want) - len(ctx), eos_token_id=eos)
+    first = len(ctx) + [t for t in want[len(ctx):]].index(eos)
+    assert cut == want[:first + 1]
+    # sampling: the reference's rule on the engine's own logits, identically seeded generators
+    g1 = torch.Generator(device=dev).manual_seed(123)
+    got = eng.generate(ctx, 10, do_sample=True, temperature=0.7, generator=g1)
+    g2 = torch.Generator(device=dev).manual_seed(123)
+    eng.reset()
+    eng.prefill(ctx)
+    by_hand = list(ctx)
+    for _ in range(10):
+        nxt = int(torch.multinomial(torch.softmax(eng.logits / 0.7, dim=-1), num_samples=1, generator=g2))
+        by_hand.append(nxt)
+        eng.step(nxt)
+    assert got == by_hand and len(set(got[len(ctx):])) > 1
