@@ -520,11 +520,27 @@ def rope_partial(x, cos, sin):
     return np.concatenate((rope_rotate_half(x[..., :rot], cos, sin), x[..., rot:]), axis=-1)
 
 
-def attention_sim(q, k, v, cos, sin, heads, kv_heads, qk: tuple, pv: tuple):
+def _qmatmul_exact(a, b, q1: QuantizerOracle, q2: QuantizerOracle, out_q: QuantizerOracle | None, double_scale: bool):
+    """QMatMul with its contraction carried out EXACTLY over the quantizer indices (what the MFMA / dot4 kernels compute), where the
+    reference's fp32 matmul rounds after every product: s_a s_b sum_k (ia - za)(ib - zb), one rounding of fl32(s_a * s_b), then either
+    one fp32 multiply of the (exact in fp32: |sum| < 2^24) integer (double_scale False: the q.k^T product) or one rounding of the
+    double product (True: the p.v product, whose integer sums exceed 2^24 -- mq_attention.hip / mq_decode.hip)."""
+    _, ia = q1.forward(np.asarray(a, F32), return_index=True)
+    _, ib = q2.forward(np.asarray(b, F32), return_index=True)
+    acc = np.rint(np.matmul(ia.astype(np.float64) - np.float64(q1.offset), ib.astype(np.float64) - np.float64(q2.offset))).astype(np.int64)
+    alpha = F32(F32(q1.scale) * F32(q2.scale))
+    out = (acc.astype(np.float64) * np.float64(alpha)).astype(F32) if double_scale else (acc.astype(F32) * alpha).astype(F32)
+    return out_q.forward(out) if out_q is not None else out
+
+
+def attention_sim(q, k, v, cos, sin, heads, kv_heads, qk: tuple, pv: tuple, exact_int: bool = False):
     """Causal prefill attention of one sequence as the reference computes it: q [S, heads*D], k / v [S, kv_heads*D] projection
     outputs; RoPE (cos / sin [S, rot_dim]: full or partial, hf_model.py:486-500); repeat_kv (hf_model.py:509-510); qk_bmm (a QMatMul:
     qk = (input, input2, output) QuantizerOracles) / sqrt(D); + causal mask; fp32 softmax; pv_bmm (pv = its three quantizers).
-    Returns [S, heads*D] (the layout o_proj reads)."""
+    Returns [S, heads*D] (the layout o_proj reads).
+    exact_int: both contractions exact over the indices (_qmatmul_exact) instead of the reference's fp32 matmuls -- the arithmetic
+    of the integer kernels WITHOUT their fast quantizer / exponential forms: what separates "the integer path differs from an fp32
+    matmul by that matmul's own rounding" from "the kernel's approximations flipped an index" in the tests."""
     S = q.shape[0]
     D = q.shape[1] // heads
     qh = rope_partial(np.asarray(q, F32).reshape(S, heads, D).transpose(1, 0, 2), cos, sin)
@@ -532,11 +548,14 @@ def attention_sim(q, k, v, cos, sin, heads, kv_heads, qk: tuple, pv: tuple):
     vh = np.asarray(v, F32).reshape(S, kv_heads, D).transpose(1, 0, 2)
     rep = heads // kv_heads
     kh, vh = np.repeat(kh, rep, axis=0), np.repeat(vh, rep, axis=0)
-    att = qmatmul_sim(qh, kh.transpose(0, 2, 1), *qk) / F32(np.sqrt(F32(D)))
+    if exact_int:
+        att = _qmatmul_exact(qh, kh.transpose(0, 2, 1), *qk, double_scale=False) / F32(np.sqrt(F32(D)))
+    else:
+        att = qmatmul_sim(qh, kh.transpose(0, 2, 1), *qk) / F32(np.sqrt(F32(D)))
     mask = np.triu(np.full((S, S), -np.inf, dtype=F32), 1)
     att = (att + mask).astype(F32)
     att = att - att.max(axis=-1, keepdims=True)
     e = np.exp(att, dtype=F32)
     p = (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
-    out = qmatmul_sim(p, vh, *pv)
+    out = _qmatmul_exact(p, vh, *pv, double_scale=True) if exact_int else qmatmul_sim(p, vh, *pv)
     return out.transpose(1, 0, 2).reshape(S, heads * D)

@@ -629,13 +629,16 @@ def test_decode_engine_reproduces_the_reference_model_token_by_token(dev):
     assert np.array_equal(eager, replay)
     d_ref = np.abs(eager - ref)
     d_pre = np.abs(eager - ours_prefill)
-    # against the reference: quantisation-noise-sized differences only (the fixture's own |w8a8 - fp| is ~0.06 of the span)
-    assert d_ref.max() <= 0.05 * span and np.median(d_ref) <= 0.002 * span and (d_ref <= 0.01 * span).mean() >= 0.97, (
-        d_ref.max() / span, np.median(d_ref) / span, (d_ref <= 0.01 * span).mean())
-    assert (eager.argmax(-1) == ref.argmax(-1)).mean() >= 0.9
-    # against the prefill kernels of this package: same arithmetic, other summation orders
-    assert d_pre.max() <= 0.05 * span and np.median(d_pre) <= 0.0005 * span and (d_pre <= 0.01 * span).mean() >= 0.98, (
-        d_pre.max() / span, np.median(d_pre) / span)
+    # against the reference (the fixture's own |w8a8 - fp| is ~0.06 of the span).  Bars = twice what is observed (tools/observe_bars.py,
+    # round 3: max 0.0097, 99th percentile 0.0029, median 4e-7 of the span, argmax 40 / 40): a systematic one-step bias in any
+    # quantizer moves the MEDIAN by orders of magnitude, a single flipped 8-bit index upstream only the tail
+    def bars(d, what):
+        d = d / span
+        assert d.max() <= 0.02 and np.quantile(d, 0.99) <= 0.006 and np.median(d) <= 5e-6, (what, d.max(), np.quantile(d, 0.99), np.median(d))
+    bars(d_ref, "decode vs reference")
+    assert (eager.argmax(-1) == ref.argmax(-1)).mean() >= 0.975
+    # against the prefill kernels of this package: same arithmetic, other summation orders (observed: the same tail, median 3e-8)
+    bars(d_pre, "decode vs prefill")
     # greedy generation runs end to end and continues from the context
     out = eng.generate(ids[:8].tolist(), 6)
     assert out[:8] == ids[:8].tolist() and len(out) == 14 and all(0 <= t < 96 for t in out)
@@ -652,11 +655,8 @@ def test_decode_engine_reproduces_the_reference_model_token_by_token(dev):
         rest = np.stack([eng.step(int(t)).cpu().numpy().copy() for t in ids[n_ctx:]])
         got = np.concatenate([lg[None], rest])
         want = ref[n_ctx - 1:]
-        d = np.abs(got - want)
-        assert d.max() <= 0.05 * span and np.median(d) <= 0.002 * span and (d <= 0.01 * span).mean() >= 0.97, (
-            fused, d.max() / span, np.median(d) / span, (d <= 0.01 * span).mean())
-        d2 = np.abs(got - eager[n_ctx - 1:])
-        assert d2.max() <= 0.05 * span and np.median(d2) <= 0.003 * span, (fused, d2.max() / span, np.median(d2) / span)
+        bars(np.abs(got - want), f"prefill(fused={fused}) + steps vs reference")
+        bars(np.abs(got - eager[n_ctx - 1:]), f"prefill(fused={fused}) + steps vs steps only")
     assert eng.generate(ids[:8].tolist(), 6, prefill=True)[:8] == ids[:8].tolist()
 
 
@@ -1202,6 +1202,10 @@ def test_other_recipes_against_the_reference_model(dev, tag, wbits, kv_heads, ac
     with torch.no_grad():
         assert llama.fuse_decoder_layer(m) == 2
         fused = m(ids[None].to(dev))[0].cpu().numpy()
+    # bars = twice the worst observed over the five recipes (tools/observe_bars.py, round 3: max 0.021, 99th percentile 0.010, median
+    # 3.6e-6 of the span, argmax 39 / 40) -- the quantisation itself moves these logits by `noise` = 0.02 .. 0.33 of the span
     for name, got in (("chain", chain), ("decode", steps), ("fused", fused)):
         d = np.abs(got - ref) / span
-        assert d.max() <= 0.1 * noise + 0.02 and np.median(d) <= 0.002, (name, float(d.max()), float(np.median(d)), noise)
+        assert d.max() <= 0.045 and np.quantile(d, 0.99) <= 0.021 and np.median(d) <= 1e-5, (name, float(d.max()), float(np.quantile(d, 0.99)),
+                                                                                                   float(np.median(d)), noise)
+        assert (got.argmax(-1) == ref.argmax(-1)).mean() >= 0.95, name

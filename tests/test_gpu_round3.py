@@ -213,3 +213,31 @@ def test_generate_reproduces_the_reference_models_free_running_greedy_stream_and
         by_hand.append(nxt)
         eng.step(nxt)
     assert got == by_hand and len(set(got[len(ctx):])) > 1
+
+
+@pytest.mark.parametrize("S,heads,kv_heads", [(192, 4, 2), (256, 4, 4)])
+def test_attention_kernels_against_the_exact_integer_oracle(dev, S, heads, kv_heads):
+    """Where do index flips come from?  oracle.attention_sim(exact_int=True) carries both contractions out exactly over the indices --
+    the integer kernels' arithmetic without their fast forms -- so:
+      * the DECODE kernel (exact-divide quantizers, expf, true maximum) must agree with it on (practically) every output index: what
+        is left is the exponential's last bits;
+      * the PREFILL kernel's distance to it is what its reciprocal-multiply quantizers and exp2 forms cost: bounded
+        here at twice the observed rate, far below the distance either has to the fp32-matmul form of the reference."""
+    from test_gpu_round2 import _grid_of
+    from mobilequant_amd import ops
+    D = 64
+    q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, D, D, seed=S)
+    exact = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv, exact_int=True)
+    ref = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    step = float(pv[2].scale)
+    st = _Stepper(dev, heads, kv_heads, D, D, S, cos, sin, qk, pv, pv[2], 1)
+    dec = np.stack([st.step(t, q[t], k[t], v[t])[0] for t in range(S)])
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)                       # noqa: E731
+    pre = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids).cpu().numpy()
+    flips = {name: float((np.abs(got - exact) > 0.5 * step).mean()) for name, got in (("decode", dec), ("prefill", pre), ("fp32 matmul", ref))}
+    worst = {name: float(np.abs(got - exact).max() / step) for name, got in (("decode", dec), ("prefill", pre))}
+    print("index flips vs the exact-integer oracle:", flips, "max steps:", worst)
+    assert worst["decode"] <= 1.001 and flips["decode"] <= 5e-5, (flips, worst)       # observed: 0 of 49 152 and 0 of 65 536
+    assert worst["prefill"] <= 1.001 and flips["prefill"] <= 5e-4, (flips, worst)     # observed: 0 as well (fp32-matmul form: 1.5e-5)
