@@ -55,6 +55,60 @@ def get_act_scales(model: nn.Module, samples: Sequence[torch.Tensor], group=None
     return col.act_scales()
 
 
+@torch.no_grad()
+def get_act_shifts(model: nn.Module, samples: Sequence[torch.Tensor], forward=None) -> Dict[str, torch.Tensor]:
+    """``get_act_shifts`` (ptq/generate_act_scale_shift.py:97-149): per Linear / LayerNorm / RMSNorm leaf and per channel, the running
+    average ``0.99 * shift + 0.01 * (max + min) / 2`` of each sample's per-channel mid-range (the first sample initialises it), for
+    the input and the output, keyed ``"<module>_<field>"`` -- what ``--use_shift`` LET reads from ``act_shifts.pth``.  The average
+    depends on the sample ORDER, so unlike the min / max statistics it is not sharded: one stream, in order.  Per hook the reference
+    takes two reductions and two device-to-host copies; here one pass of the HIP column reduction leaves [min, max] per channel on
+    the device, the update is three fp32 elementwise ops there (the reference's, in its order: bit-identical), and the host sees
+    the result once."""
+    model.eval()
+    dev = next(model.parameters()).device
+    col = ActShiftCollector()
+
+    def hook(name):
+        def fn(m, xx, yy):
+            col.update(name, "input", xx[0] if isinstance(xx, tuple) else xx)
+            col.update(name, "output", yy[0] if isinstance(yy, tuple) else yy)
+        return fn
+    hooks = [m.register_forward_hook(hook(n)) for n, m in model.named_modules() if isinstance(m, nn.Linear) or _is_norm(m)]
+    run = forward if forward is not None else (lambda s_: model(s_))
+    try:
+        for s_ in samples:
+            with torch.cuda.device(dev) if dev.type == "cuda" else _nullcontext():
+                run(s_.to(dev))
+    finally:
+        for h in hooks:
+            h.remove()
+    return col.result()
+
+
+class ActShiftCollector:
+    """The running statistic of get_act_shifts, one tensor at a time (generate_act_scale_shift.py:102-111)."""
+
+    def __init__(self):
+        self.shifts: Dict[str, torch.Tensor] = {}
+
+    def update(self, name: str, field: str, t: torch.Tensor) -> None:
+        t2 = t.detach().reshape(-1, t.shape[-1])
+        if t2.dtype != torch.float32 or not t2.is_contiguous():
+            t2 = t2.float().contiguous()
+        mn, mx = ops.minmax_cols(t2)                       # one pass: [min, max] per channel, on the device
+        new = (mx + mn) / 2
+        key = f"{name}_{field}"
+        self.shifts[key] = 0.99 * self.shifts[key] + 0.01 * new if key in self.shifts else new
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        return {k: v.float().cpu() for k, v in self.shifts.items()}
+
+
+def save_act_shifts(path: str, act_shifts: Dict[str, torch.Tensor]) -> None:
+    """``act_shifts.pth`` as generate_act_scale_shift.py:177-180 writes it (torch.save of the CPU fp32 dictionary)."""
+    torch.save({k: v.detach().float().cpu() for k, v in act_shifts.items()}, path)
+
+
 # ---- fold ----------------------------------------------------------------------------------------------------------------
 def _is_norm(m) -> bool:
     return isinstance(m, (nn.LayerNorm, HFRMSNorm)) or any(c.__name__ == "HFRMSNorm" for c in type(m).__mro__)

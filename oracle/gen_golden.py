@@ -490,6 +490,10 @@ def gen_calib_stream():
     sc = ss_mod.get_act_scales(toy, _Tok(), ragged, len(ragged), 64)
     for k, v in sc.items():
         out[f"absmax|{k}"] = npf(v)
+    ss_mod.args.use_rand_samples = False
+    sh = ss_mod.get_act_shifts(toy, _Tok(), ragged, len(ragged), 64)       # EMA 0.99 / 0.01 of (max + min) / 2, in sample order
+    for k, v in sh.items():
+        out[f"shift|{k}"] = npf(v)
     for k, v in toy.state_dict().items():
         out["toy|" + k] = npf(v)
     out["ids_pt"] = np.array(json.dumps([d["text"] for d in ragged]))

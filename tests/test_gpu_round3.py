@@ -241,3 +241,38 @@ def test_attention_kernels_against_the_exact_integer_oracle(dev, S, heads, kv_he
     print("index flips vs the exact-integer oracle:", flips, "max steps:", worst)
     assert worst["decode"] <= 1.001 and flips["decode"] <= 5e-5, (flips, worst)       # observed: 0 of 49 152 and 0 of 65 536
     assert worst["prefill"] <= 1.001 and flips["prefill"] <= 5e-4, (flips, worst)     # observed: 0 as well (fp32-matmul form: 1.5e-5)
+
+
+def test_act_shifts_running_average_is_the_references(dev, tmp_path):
+    """smoothquant.get_act_shifts (generate_act_scale_shift.py:97-149): the per-channel mid-range (max + min) / 2 of every hooked
+    tensor and its 0.99 / 0.01 running average in SAMPLE ORDER, on the device (one HIP column reduction per tensor + three fp32
+    elementwise ops) -- bit-identical to what the reference's hooks computed on the recorded stream of tests/golden/calib_stream.npz
+    (6 ragged samples), through the statistic class and end to end through forward hooks on the device model; act_shifts.pth."""
+    from conftest import load_npz
+    from test_calibration_dist import _stream
+    from toy_models import CalibToy
+    from mobilequant_amd import smoothquant as S
+    z = load_npz("calib_stream.npz")
+    want = {k.split("|")[1]: z[k] for k in z.files if k.startswith("shift|")}
+    assert len(want) == 6
+    col = S.ActShiftCollector()
+    for sample in _stream(z, "stream_pt"):
+        for name, field, t in sample:
+            if name in ("fc1", "fc2", "ln") and field in ("input", "output"):
+                col.update(name, field, torch.from_numpy(t).to(dev))
+    got = col.result()
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k].dtype == torch.float32 and got[k].device.type == "cpu" and np.array_equal(got[k].numpy(), want[k]), k
+    # end to end: hooks on the device copy of the toy stack, the reference's own samples (GPU forward: fp32 round-off apart)
+    import json
+    toy = CalibToy()
+    toy.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("toy|")})
+    toy = toy.to(dev).eval()
+    samples = [torch.tensor([[int(t) for t in line.split()]]) for line in json.loads(str(z["ids_pt"]))]
+    e2e = S.get_act_shifts(toy, samples)
+    for k in want:
+        assert np.allclose(e2e[k].numpy(), want[k], rtol=1e-5, atol=1e-6), k
+    S.save_act_shifts(str(tmp_path / "act_shifts.pth"), e2e)
+    back = torch.load(str(tmp_path / "act_shifts.pth"), map_location="cpu")
+    assert list(back) == list(e2e) and all(torch.equal(back[k], e2e[k]) for k in e2e)
