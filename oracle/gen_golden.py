@@ -24,6 +24,7 @@ Fixtures written (all data, no reference source text):
   toy_lm_nll.npz          perplexity proxy: the reference's W8A8-sim logits + NLL of the toy LM on 96 tokens
   decode_case_stablelm.npz / decode_case_gemma.npz   configs[2] / [3] leaf graphs (LayerNorm + q|k|v bias + partial rotary; head_dim 256
                           + GeGLU + scaled embeddings) of the reference's HFForCausalLM at toy size, their recipes' logits
+  train_step.npz          f3: one e2equant inner step (LET + LWC + LRL, fp32) on a decoder layer: loss and every trainable tensor's gradient
   generate_case.npz       f2: greedy free-running continuation (SimModel.generate's loop) of the decode_case model under the reference
   decode_case.npz         f2: W8A8-sim logits of the reference's real HFForCausalLM (2 layers) at every position of a sequence
   smooth_cases.npz        n1/f3/f4 on the reference's real HFForCausalLM (2 layers): fp logits, get_act_scales, smooth_lm fold,
@@ -980,6 +981,98 @@ def gen_decode_case_gelu():
     gen_decode_case_w4(tag="w4_geglu_mqa", wbits=4, kv_heads=1, act="gelu")
 
 
+def gen_train_step():
+    """f3: ONE inner step of e2equant (mobilellm/quantization/algorithm.py:727-745, the deployment recipe's flags: --lwc --let --lrl
+    --deactive_amp, fp32, 4-bit per-channel weights: experiments/w4a8/main/e2e_llama-s1024-ep60.sh:17-23) on one decoder layer of the
+    reference's HFForCausalLM: LET scales registered (:690-706), LWC enabled on every weight quantizer (enable_quant :325-351), scale /
+    offset as nn.Parameters (LRL), smooth_lm_temporary, quantized forward, MSE against the layer's own fp output, backward -> the loss
+    and the gradient of every trainable tensor (let / lwc / lrl groups of :239-282)."""
+    import mobilellm.quantization.algorithm as A
+    m, cfg = _tiny_hf(4, 91)
+    g = torch.Generator().manual_seed(15)
+    layer = m.model.layers[0]
+    with torch.no_grad():
+        for lin in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj, layer.mlp.w1,
+                    layer.mlp.w2, layer.mlp.w3):            # LET on q / k needs biases (algorithm.py:89-96)
+            lin.bias = nn.Parameter(torch.randn(lin.out_features, generator=g) * 0.1)
+    out = {f"sd|{k_}": npf(v_) for k_, v_ in layer.state_dict().items() if "rotary" not in k_}
+    S = 24
+    x = torch.randn(1, S, 64, generator=g)
+    mask = torch.full((S, S), float("-inf")).triu(1)[None, None]
+    pos = torch.arange(S)[None]
+    with torch.no_grad():
+        y_fp = layer(x, attention_mask=mask, position_ids=pos)[0]
+    # ranges of every leaf the surgery will wrap, from this one forward (what generate_act_range.py's hooks record)
+    act = {}
+    def hook(name):
+        def fn(mod, xx, yy):
+            d = act.setdefault(name, {})
+            d["input"] = [float(xx[0].min()), float(xx[0].max())]
+            d["output"] = [float(yy.min()), float(yy.max())]
+            if isinstance(mod, FMatMul):
+                d["input2"] = [float(xx[1].min()), float(xx[1].max())]
+        return fn
+    from mobilellm.model.hf_model import HFRMSNorm
+    hs = [mod.register_forward_hook(hook(n)) for n, mod in layer.named_modules() if isinstance(mod, (nn.Linear, nn.SiLU, HFRMSNorm, FMatMul))]
+    with torch.no_grad():
+        layer(x, attention_mask=mask, position_ids=pos)
+    for h in hs:
+        h.remove()
+    Q.create_sim_qmodel(layer, Q.QuantConfig(bitwidth=4, is_per_channel=True), Q.QuantConfig(bitwidth=8))
+    for name, mod in layer.named_modules():          # ptq/mobilequant.py:175-201
+        if isinstance(mod, Q.QLinear):
+            if any(k_ in name for k_ in ("q_proj", "k_proj", "v_proj", "o_proj", "w1", "w3")):
+                mod.input_quantizer = None
+            if "w2" in name:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.is_symmetric = False
+            mod.weight_quantizer.qcfg.is_per_channel = False
+        elif isinstance(mod, Q.QMatMul):
+            if "qk_bmm" in name:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in name:
+                mod.input_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, Q.QSiLU):
+            mod.input_quantizer = None
+    Q.set_scale_and_offset(layer, act, "parameter")
+    for name, mod in layer.named_modules():          # enable_quant(args with lwc): algorithm.py:325-351
+        if isinstance(mod, (Q.QLinear, Q.QRMSNorm)):
+            mod.weight_quantizer.enable_lwc(mod.weight)
+    params = {}
+    for name, dim in (("qkv", 64), ("fc1", 64), ("out", 64), ("fc2", 96), ("qkt", 64)):
+        sc = torch.rand(dim, generator=g) * 0.6 + 0.7
+        layer.register_parameter(f"{name}_smooth_scale", nn.Parameter(sc))
+        params[f"{name}_smooth_scale"] = sc
+        if name != "qkt":                                   # registered like the reference does, unused without --use_shift
+            layer.register_parameter(f"{name}_smooth_shift", nn.Parameter(torch.zeros(dim)))
+    for p_ in layer.parameters():
+        p_.requires_grad_(True)
+    with torch.enable_grad():
+        A.smooth_lm_temporary(layer, cfg, True, False)
+        y_q = layer(x, attention_mask=mask, position_ids=pos)[0]
+        loss = torch.nn.MSELoss()(y_fp, y_q)
+        loss.backward()
+    grads = {}
+    for name, p_ in layer.named_parameters():
+        if any(t in name for t in ("bound_factor", "smooth_scale", "quantizer.offset", "quantizer.scale")):      # get_parameters :264-271
+            assert p_.grad is not None, name
+            grads[name] = p_.grad
+    for k_, v_ in params.items():
+        out["let|" + k_] = npf(v_)
+    for k_, v_ in grads.items():
+        out["grad|" + k_] = npf(v_)
+    out.update(x=npf(x), y_fp=npf(y_fp), y_q=npf(y_q.detach()), loss=np.float64(loss.item()), act=np.array(json.dumps(act)))
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    print("train_step: loss %.6f, %d gradient tensors, groups:" % (loss.item(), len(grads)),
+          {t: sum(t in k_ for k_ in grads) for t in ("bound_factor", "smooth_scale", "quantizer.scale", "quantizer.offset")})
+
+
 def gen_generate_case():
     """f2: SimModel.generate's loop (mobilellm/model/sim_model.py:160-221: next token = argmax of the logits behind the context, append,
     stop at EOS, feed the token back) run FREE on the reference's W8A8-simulated HFForCausalLM of decode_case.npz (same weights,
@@ -1112,6 +1205,7 @@ if __name__ == "__main__":
     gen_decode_case_w8pc_mha()
     gen_decode_case_gelu()
     gen_generate_case()
+    gen_train_step()
     gen_decode_case_stablelm()
     gen_decode_case_gemma()
     gen_layer_case()

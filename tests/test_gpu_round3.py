@@ -276,3 +276,83 @@ def test_act_shifts_running_average_is_the_references(dev, tmp_path):
     S.save_act_shifts(str(tmp_path / "act_shifts.pth"), e2e)
     back = torch.load(str(tmp_path / "act_shifts.pth"), map_location="cpu")
     assert list(back) == list(e2e) and all(torch.equal(back[k], e2e[k]) for k in e2e)
+
+
+def test_one_e2equant_training_step_loss_and_every_gradient_vs_the_reference(dev):
+    """f3 closed: ONE inner step of e2equant (algorithm.py:727-745) under the deployment recipe's flags (--lwc --let --lrl
+    --deactive_amp, fp32, 4-bit per-channel weights) on a decoder layer, with this package's modules: HIP fake-quant forward AND
+    backward (STE, clamp mask, LSQ gradients to scale / offset), LWC through the HIP range reduction, LET through
+    smooth_lm_temporary -- against the loss and the gradient of every trainable tensor (18 LWC bound factors, 5 LET scales, 20 + 20
+    quantizer scales / offsets) the reference's autograd produced for the same layer, input and ranges (tests/golden/train_step.npz).
+    The GPU's fp32 matmuls sum in another order than the CPU's, so a value that sits on a rounding boundary can take the other
+    grid point and move its STE mask: gradients are held to direction (cosine) and size, not bits."""
+    import json
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    from mobilequant_amd.llama import DecoderLayer, LlamaShape, rope_tables
+    from toy_models import apply_mixed_precision
+    z = load_npz("train_step.npz")
+    shape = LlamaShape(hidden=64, layers=1, heads=4, kv_heads=4, head_dim=16, ffn=96, vocab=50, eps=1e-5, max_pos=64)
+    layer = DecoderLayer(shape)
+    for lin in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj, layer.mlp.w1, layer.mlp.w2,
+                layer.mlp.w3):
+        lin.bias = torch.nn.Parameter(torch.zeros(lin.out_features))
+    layer.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd|")})
+    layer = layer.to(dev)
+    mq.create_sim_qmodel(layer, mq.QuantConfig(bitwidth=4, is_per_channel=True), mq.QuantConfig(bitwidth=8))
+    apply_mixed_precision(layer, mq)
+    for name, mod in layer.named_modules():
+        if isinstance(mod, mq.QRMSNorm):
+            mod.weight_quantizer.qcfg.is_symmetric = False
+            mod.weight_quantizer.qcfg.is_per_channel = False
+    mq.set_scale_and_offset(layer, json.loads(str(z["act"])), "parameter")
+    for name, mod in layer.named_modules():                          # enable_quant with --lwc (algorithm.py:325-351)
+        if isinstance(mod, (mq.QLinear, mq.QRMSNorm)):
+            mod.weight_quantizer.enable_lwc(mod.weight)
+    for k in z.files:
+        if k.startswith("let|"):
+            layer.register_parameter(k[4:], torch.nn.Parameter(T_(z[k], dev)))
+    for name in ("qkv", "fc1", "out", "fc2"):
+        layer.register_parameter(f"{name}_smooth_shift", torch.nn.Parameter(torch.zeros(96 if name == "fc2" else 64, device=dev)))
+    for p in layer.parameters():
+        p.requires_grad_(True)
+    cfg = type("Cfg", (), dict(shared_attention_norm=False, num_linears_per_mlp=3))()
+    x, y_fp = T_(z["x"], dev), T_(z["y_fp"], dev)
+    S = x.shape[1]
+    cos, sin = (t[:S].to(dev) for t in rope_tables(shape))
+    mask = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    mq.smooth_lm_temporary(layer, cfg, True, False)
+    y_q = layer(x, cos, sin, mask)
+    loss = torch.nn.MSELoss()(y_fp, y_q)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) <= 2e-3 * float(z["loss"]), (float(loss), float(z["loss"]))
+    d = (y_q.detach().cpu().numpy() - z["y_q"])
+    assert np.abs(d).max() <= 0.05 * np.ptp(z["y_q"]) and np.median(np.abs(d)) <= 1e-4 * np.ptp(z["y_q"])
+    named = dict(layer.named_parameters())
+    rows = []
+    for k in z.files:
+        if not k.startswith("grad|"):
+            continue
+        name, want = k[5:], z[k].astype(np.float64).ravel()
+        assert name in named and named[name].grad is not None, name
+        got = named[name].grad.detach().cpu().numpy().astype(np.float64).ravel()
+        assert got.shape == want.shape and np.isfinite(got).all(), name
+        group = next(t for t in ("bound_factor", "smooth_scale", "quantizer.scale", "quantizer.offset") if t in name)
+        rows.append((group, name, np.linalg.norm(want), np.linalg.norm(got), np.linalg.norm(got - want)))
+    assert len(rows) == 63
+    # observed (round 3): LET scales and LWC bound factors agree to 6e-6 relative; quantizer scales / offsets to 3e-2 at worst (sums
+    # with heavy cancellation over 16-bit grids), except gradients that ARE cancellation residue -- seven orders below their group's
+    # largest (pv_bmm.input2: 1.5e-5 against 1.7e+2) -- which are only required to stay at that level
+    for group, bar in (("smooth_scale", 1e-4), ("bound_factor", 1e-4), ("quantizer.scale", 0.06), ("quantizer.offset", 0.06)):
+        top = max(r[2] for r in rows if r[0] == group)
+        for _, name, nw, ng, ne in rows:
+            if _ != group:
+                continue
+            if nw <= 1e-6 * top:
+                assert ng <= 1e-5 * top, (name, nw, ng)
+            else:
+                assert ne <= bar * nw, (name, nw, ng, ne / nw)
+
+
+def T_(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
