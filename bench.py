@@ -53,7 +53,6 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--headline-only", action="store_true", help="only the timed steps and the roofline leg (profiler passes)")
-    p.add_argument("--gemm-variant", type=int, default=-1, help="force a GEMM tile variant (experiments)")
     p.add_argument("--row-major-activations", action="store_true",
                    help="A/B: quantise row-major and run the C++ ping-pong GEMM loop instead of the fragment-blocked layout")
     p.add_argument("--overlap", action="store_true",
@@ -892,9 +891,6 @@ def main():
     with torch.no_grad():
         Step.tiled_ok = not args.row_major_activations
         step = Step(dev, MQ_U8, seed=rank)
-        if args.gemm_variant >= 0:
-            from mobilequant_amd import _lib as _l
-            _l.load().mq_gemm_set_variant(args.gemm_variant)
         pipelined = args.overlap and not args.no_graph
         sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph, pipelined=pipelined)
         sec = max_over_ranks(sec, world)

@@ -356,3 +356,36 @@ def test_one_e2equant_training_step_loss_and_every_gradient_vs_the_reference(dev
 
 def T_(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_torch_ops_are_the_c_abi_kernels(dev):
+    """torch.ops.mobilequant_amd.* (torch.library registration) dispatch to the same kernels as the ctypes path: identical
+    tensors for fake_quant / quantize / minmax / w8a8_linear / w4a8_linear on random inputs; minmax_update_ mutates in place."""
+    import mobilequant_amd.torch_ops  # noqa: F401
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_I8, MQ_U8
+    ns = torch.ops.mobilequant_amd
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(24, 256, generator=g) * 2).to(dev)
+    s, o = torch.tensor([0.03], device=dev), torch.tensor([117.0], device=dev)
+    assert torch.equal(ns.fake_quant(x, s, o, 0.0, 255.0), ops.fake_quant(x, s, o, 0.0, 255.0))
+    q, rs = ns.quantize(x, s, o, 0.0, 255.0, 128)
+    q2, rs2 = ops.quantize(x, s, o, 0.0, 255.0, q_dtype=MQ_I8, shift=128, rows=24, want_row_sum=True)
+    assert torch.equal(q, q2) and torch.equal(rs, rs2)
+    mm = ns.minmax(x, False)
+    assert float(mm[0]) == float(x.min()) and float(mm[1]) == float(x.max())
+    mc = ns.minmax(x, True)
+    assert torch.equal(mc[0], x.min(0).values) and torch.equal(mc[1], x.max(0).values)
+    running = torch.stack((torch.full((256,), float("inf"), device=dev), torch.full((256,), float("-inf"), device=dev)))
+    ns.minmax_update_(running, x)
+    assert torch.equal(running, mc)
+    w = torch.randint(-128, 128, (64, 256), generator=g, dtype=torch.int8).to(dev)
+    colsum = w.to(torch.int32).sum(1).to(torch.int32)
+    ws, wo = torch.full((1,), 0.01, device=dev), torch.full((1,), 3.0, device=dev)
+    alpha, wzp, ct = ops.linear_epilogue_prepare(s, o, 128, ws, wo, 128, colsum, 256)
+    assert torch.equal(ns.w8a8_linear(q, rs, w, alpha, wzp, ct), ops.int8_linear(q, w, rs, alpha, wzp, ct))
+    nib = torch.randint(0, 16, (64, 256), generator=g, dtype=torch.uint8).to(dev)
+    packed = ns.pack_w4(nib)
+    assert torch.equal(packed, ops.pack_w4(nib))
+    a4, z4, c4 = ops.linear_epilogue_prepare(s, o, 128, ws, torch.full((1,), 5.0, device=dev), 0, nib.to(torch.int32).sum(1).to(torch.int32), 256)
+    assert torch.equal(ns.w4a8_linear(q, rs, packed, a4, z4, c4), ops.int8_linear(q, packed, rs, a4, z4, c4, w4=True))

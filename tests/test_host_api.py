@@ -138,3 +138,27 @@ def test_reference_import_path_alias():
         for k in [k for k in sys.modules if k == "mobilellm" or k.startswith("mobilellm.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_torch_library_registration_and_meta_kernels():
+    """SURVEY 8b "native boundary": the core entry points are registered as torch.ops.mobilequant_amd.* with FakeTensor (meta)
+    kernels -- shapes / dtypes without a device -- and NO CPU implementation: a CPU tensor finds nothing to dispatch to."""
+    import torch
+    import mobilequant_amd.torch_ops as T
+    ns = torch.ops.mobilequant_amd
+    for name in T.OPS:
+        assert hasattr(ns, name), name
+    x = torch.empty(6, 64, device="meta")
+    s = torch.empty(1, device="meta")
+    assert ns.fake_quant(x, s, s, 0.0, 255.0).shape == (6, 64)
+    q, rs = ns.quantize(x, s, s, 0.0, 255.0, 128)
+    assert q.dtype == torch.int8 and q.shape == (6, 64) and rs.dtype == torch.int32 and rs.shape == (6,)
+    assert ns.minmax(x, False).shape == (2,) and ns.minmax(x, True).shape == (2, 64)
+    xq, wq = torch.empty(6, 64, dtype=torch.int8, device="meta"), torch.empty(32, 64, dtype=torch.int8, device="meta")
+    v, vi = torch.empty(32, device="meta"), torch.empty(32, dtype=torch.int32, device="meta")
+    assert ns.w8a8_linear(xq, rs, wq, v, vi, vi).shape == (6, 32)
+    packed = ns.pack_w4(torch.empty(32, 64, dtype=torch.uint8, device="meta"))
+    assert packed.shape == (32, 32) and ns.w4a8_linear(xq, rs, packed, v, vi, vi).dtype == torch.float32
+    import pytest
+    with pytest.raises(NotImplementedError):
+        ns.fake_quant(torch.zeros(4, 8), torch.ones(1), torch.zeros(1), 0.0, 255.0)
