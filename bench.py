@@ -192,6 +192,9 @@ class Step:
         main.wait_stream(side)
 
 
+REPEATS = 7
+
+
 def run_steps(fn, steps, warmup, world, use_graph=True, pipelined=False):
     """W untimed warmup steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize.
     Steps are replayed from hipGraphs of GRAPH_STEPS steps each (the step is ~30 us: launch-bound from
@@ -217,17 +220,23 @@ def run_steps(fn, steps, warmup, world, use_graph=True, pipelined=False):
                     fn(i)
         graph.replay()
         torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    done = 0
-    if graph is not None:
-        for _ in range(steps // GRAPH_STEPS):
-            graph.replay()
-        done = (steps // GRAPH_STEPS) * GRAPH_STEPS
-    for i in range(done, steps):
-        fn(i)
-    barrier(world)
-    return (time.perf_counter() - t0) / steps
+    # The timed region -- EXACTLY `steps` steps between two barriers -- is a fraction of a millisecond at the driver's default
+    # --steps 20, so it is measured REPEATS times back to back and the median is reported (all values go into the line).
+    times = []
+    for _ in range(REPEATS):
+        barrier(world)
+        t0 = time.perf_counter()
+        done = 0
+        if graph is not None:
+            for _ in range(steps // GRAPH_STEPS):
+                graph.replay()
+            done = (steps // GRAPH_STEPS) * GRAPH_STEPS
+        for i in range(done, steps):
+            fn(i)
+        barrier(world)
+        times.append((time.perf_counter() - t0) / steps)
+    run_steps.last = sorted(times)
+    return run_steps.last[len(times) // 2]
 
 
 def event_time(fn, iters):
@@ -280,18 +289,21 @@ def pmc_traffic():
     (profiles/r02/pmc_fetch + pmc_write; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
     streams on gfx950).  Counters cannot be read from inside the bench, so this is the last profiled value."""
     import re
-    d = os.path.join(ROOT, "profiles", "r02")
-    vals = {}
-    for fn, key in (("pmc_fetch.summary.txt", "FETCH_SIZE"), ("pmc_write.summary.txt", "WRITE_SIZE")):
-        try:
-            txt = open(os.path.join(d, fn)).read()
-        except OSError:
-            return None, None
-        m = re.search(r"kernel: mq::gemm_i8_fr_kernel\([^\n]*\n(?:\s+\S+\s+[\d.]+[^\n]*\n)*?\s+" + key + r"\s+([\d.]+)", txt)
-        if not m:
-            return None, None
-        vals[key] = float(m.group(1)) * 1024.0
-    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "profiles/r02/pmc_fetch.summary.txt + pmc_write.summary.txt"
+    for rnd in ("r03", "r02"):
+        d = os.path.join(ROOT, "profiles", rnd)
+        vals = {}
+        for fn, key in (("pmc_fetch.summary.txt", "FETCH_SIZE"), ("pmc_write.summary.txt", "WRITE_SIZE")):
+            try:
+                txt = open(os.path.join(d, fn)).read()
+            except OSError:
+                break
+            m = re.search(r"kernel: mq::gemm_i8_fr_kernel\([^\n]*\n(?:\s+\S+\s+[\d.]+[^\n]*\n)*?\s+" + key + r"\s+([\d.]+)", txt)
+            if not m:
+                break
+            vals[key] = float(m.group(1)) * 1024.0
+        if len(vals) == 2:
+            return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], f"LAST PROFILED, not measured in this run: profiles/{rnd}/pmc_fetch.summary.txt + pmc_write.summary.txt"
+    return None, None
 
 
 def cpu_baseline():
@@ -341,7 +353,7 @@ def cpu_baseline():
                                 "mixed-precision rules of ptq/mobilequant.py:175-201) at S=2048"}}
 
 
-def bench_decode_full(dev, context=256, steps=64, wbits=8):
+def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", wsym=False, wpc=None):
     """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
     model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
     one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
@@ -351,7 +363,9 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
     from mobilequant_amd.calibration import get_act_range
     from mobilequant_amd.decode import DecodeEngine
     from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
-    shape = LlamaShape.tinyllama(max_pos=2048)
+    # family: the leaf graph (BASELINE.json configs[1] / [2] / [3]): tinyllama | stablelm_2_1_6b (LayerNorm, q|k|v bias, 25 % rotary) |
+    # gemma_2b (head_dim 256, 8 / 1 heads, GeGLU, FFN 16384, vocab 256000, scaled embeddings)
+    shape = getattr(LlamaShape, family)(max_pos=2048)
     model = LlamaForCausalLM(shape)
     model.reset_parameters(seed=1337)
     model = model.to(dev).eval().requires_grad_(False)
@@ -359,7 +373,8 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
     calib = [torch.randint(3, shape.vocab, (1, 256), generator=g) for _ in range(2)]
     act = get_act_range(model, calib)
     a8 = mq.QuantConfig(bitwidth=8)
-    mq.create_sim_qmodel(model, a8 if wbits == 8 else mq.QuantConfig(bitwidth=wbits, is_per_channel=True), a8)
+    per_channel = (wbits != 8) if wpc is None else wpc
+    mq.create_sim_qmodel(model, mq.QuantConfig(bitwidth=wbits, is_per_channel=per_channel, is_symmetric=wsym), a8)
     for name, mod in model.named_modules():               # ptq/mobilequant.py:175-201
         if isinstance(mod, mq.QLinear):
             if "w2" in name:
@@ -367,9 +382,11 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
                 mod.output_quantizer.qcfg.bitwidth = 16
             elif "o_proj" in name:
                 mod.output_quantizer.qcfg.bitwidth = 16
-        elif isinstance(mod, mq.QRMSNorm):
+        elif isinstance(mod, (mq.QRMSNorm, mq.QLayerNorm)):
             mod.input_quantizer.qcfg.bitwidth = 16
             mod.weight_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.is_symmetric = False
+            mod.weight_quantizer.qcfg.is_per_channel = False
         elif isinstance(mod, mq.QMatMul):
             if "qk_bmm" in name:
                 mod.output_quantizer.qcfg.bitwidth = 16
@@ -398,14 +415,14 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8):
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1) / steps)
     t = best * 1e-3
-    kv_bytes = 22 * 2 * shape.kv_heads * (context + steps // 2) * shape.head_dim      # int8 indices
+    kv_bytes = shape.layers * 2 * shape.kv_heads * (context + steps // 2) * shape.head_dim      # int8 indices
     total = eng.weight_bytes + eng.head_bytes + kv_bytes
     return {"decode_tok_s": round(1.0 / t, 1), "ms_per_token": round(t * 1e3, 4), "context": context,
             "int8_weight_GB_per_token": round(eng.weight_bytes / 1e9, 4), "lm_head_fp32_GB_per_token": round(eng.head_bytes / 1e9, 4),
             "kv_cache_GB_per_token": round(kv_bytes / 1e9, 4), "achieved_GBps": round(total / t / 1e9, 1),
             "weight_stream_GBps": round(eng.weight_bytes / t / 1e9, 1), "peak_GBps": 8000.0, "frac_of_hbm_peak": round(total / t / 8e12, 4),
             "kernels_per_token": len(eng.phases) + 2,
-            "scope": f"FULL decode step, TinyLlama-1.1B shape, W{wbits}A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, 22 x "
+            "scope": f"FULL decode step, {family} shape, W{wbits}A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, {shape.layers} x "
                      "[norm+qkv, attention over the static KV cache, o_proj+residual, norm+w1|w3+SiLU*mul+quantize, w2+residual], final "
                      "norm + fp32 lm_head; batch 1, one hipGraph per token"}
 
@@ -852,6 +869,15 @@ def bench_variants(dev, step, args):
     w4 = bench_decode_full(dev, wbits=4)                    # the reference's deployment mode: packed 4-bit per-channel weights
     decode["full_step_w4a8"] = {k: w4[k] for k in ("decode_tok_s", "ms_per_token", "int8_weight_GB_per_token", "weight_stream_GBps", "scope")}
     torch.cuda.empty_cache()
+    # BASELINE.json configs[2] / [3] on their own leaf graphs (random-init weights of those architectures)
+    keys = ("decode_tok_s", "ms_per_token", "int8_weight_GB_per_token", "lm_head_fp32_GB_per_token", "achieved_GBps", "frac_of_hbm_peak",
+            "kernels_per_token", "scope")
+    sl = bench_decode_full(dev, wbits=8, family="stablelm_2_1_6b", wpc=True)
+    decode["stablelm_2_1_6b_w8a8_per_channel"] = {k: sl[k] for k in keys}
+    torch.cuda.empty_cache()
+    gm = bench_decode_full(dev, wbits=4, family="gemma_2b", wsym=True)
+    decode["gemma_2b_w4a8_symmetric"] = {k: gm[k] for k in keys}
+    torch.cuda.empty_cache()
     decode["linears_only_w8a8"] = bench_decode_linears(dev)
     torch.cuda.empty_cache()
     decode["linears_only_w4a8"] = bench_decode_linears(dev, w4=True)      # the reference's deployment mode: 4-bit weights
@@ -893,6 +919,7 @@ def main():
         step = Step(dev, MQ_U8, seed=rank)
         pipelined = args.overlap and not args.no_graph
         sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph, pipelined=pipelined)
+        spread = [round(t * 1e3, 5) for t in getattr(run_steps, "last", [sec])]
         sec = max_over_ranks(sec, world)
         value = world * OPS_PER_STEP / sec / 1e12
 
@@ -911,6 +938,13 @@ def main():
             t_quant = event_time(lambda: step.quantize(0), 50)
             achieved = OPS_PER_STEP / t_gemm / 1e12
             t_cold = cold_time(step.gemm)
+            # the same launch on zero-filled operands: the chip clocks to the load, so this is the binary's time at
+            # the clock an idle datapath sustains -- the gap to avg_launch_us is power / clock, not schedule
+            keep_a, keep_w = step.a8s[0].clone(), step.w8.clone()
+            step.a8s[0].zero_(); step.w8.zero_()
+            t_zero = event_time(step.gemm, 50)
+            step.a8s[0].copy_(keep_a); step.w8.copy_(keep_w)
+            del keep_a, keep_w
             traffic, traffic_src = pmc_traffic()
             roof = {"bound": "mfma", "kernel": ("mq::gemm_i8_fr_kernel (mq_w8a8_linear_tiled: free-running whole-kernel gfx950 ISA, fragment-blocked "
                                                 "activations)" if step.tiled else "mq::gemm_i8_kernel (mq_w8a8_linear)"), "achieved": round(achieved, 1),
@@ -918,6 +952,8 @@ def main():
                     "avg_launch_us": round(t_gemm * 1e6, 2),
                     "cold_caches": {"avg_launch_us": round(t_cold * 1e6, 2), "frac": round(OPS_PER_STEP / t_cold / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
                                     "how": "768 MiB fill in front of every launch in one hipGraph, minus the same graph without the GEMM"},
+                    "zero_filled_operands": {"avg_launch_us": round(t_zero * 1e6, 2), "frac": round(OPS_PER_STEP / t_zero / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                             "how": "the same launch with all-zero int8 operands (no data-dependent switching power)"},
                     "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": M * K + N * K + M * N,
                     "algorithmic_ops_per_launch": OPS_PER_STEP,
@@ -946,6 +982,8 @@ def main():
             "metric": "W8A8 QuantLinear GEMM TOPS (% int8 MFMA peak) + TinyLlama-1.1B decode tok/s",
             "value": round(value, 1), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timing": {"what": f"the {args.steps}-step timed region measured {REPEATS} times back to back; value / ms_per_step = the median (max over ranks)",
+                       "ms_per_step_rank0_sorted": spread},
             "dtype": "i8", "data": "synthetic",
             "config": {"workload": "TinyLlama-1.1B W8A8 real-int8 QLinear step (BASELINE.json configs[1]): fp32 x[2048,2048] "
                                    "-> int8 quantize(+row sums) -> MFMA i8 GEMM 2048->5632 with fused dequant + 8-bit output "

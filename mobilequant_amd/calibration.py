@@ -36,8 +36,8 @@ _HOOKED_TYPE_NAMES = ("GELUActivation", "NewGELUActivation", "PytorchGELUTanh", 
 
 def is_calibrated_leaf(name: str, m: nn.Module) -> bool:
     """The reference's hook set (generate_act_range.py:93-95)."""
-    if isinstance(m, (nn.Linear, nn.SiLU, nn.Softmax, nn.LayerNorm, HFRMSNorm, FMatMul)):
-        return True
+    if isinstance(m, (nn.Linear, nn.SiLU, nn.GELU, nn.Softmax, nn.LayerNorm, HFRMSNorm, FMatMul)):
+        return True                 # (nn.GELU: this package's graphs carry it where the reference's carry transformers' GELUActivation)
     if any(c.__name__ in _HOOKED_TYPE_NAMES for c in type(m).__mro__):
         return True
     return "attn_quantizer" in name or "softmax_quantizer" in name
