@@ -438,6 +438,7 @@ typedef struct mq_attention_args {
    * written.  When qkv_idx is set, q / k / v are ignored (may be NULL). */
   const uint8_t* qkv_idx;
   mq_grid q_in, k_in, v_in;
+  int rot_dim; /* partial rotary (hf_model.py:489-500): RoPE on the first rot_dim dims, cos / sin [seq, rot_dim]; 0 = head_dim */
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
 

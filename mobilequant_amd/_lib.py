@@ -51,7 +51,8 @@ class MqAttentionArgs(ctypes.Structure):
                 ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid), ("pv_b", MqGrid), ("pv_out", MqGrid), ("out", c_void_p),
                 ("q_i8", c_void_p), ("k_i8", c_void_p), ("vt_i8", c_void_p), ("q_rowsum", c_void_p), ("k_rowsum", c_void_p),
                 ("out_i8", c_void_p), ("out_rowsum", c_void_p), ("out_row0", c_int64), ("seq_real", c_int),
-                ("out_shift", c_int), ("out_i8_tiled", c_int), ("qkv_idx", c_void_p), ("q_in", MqGrid), ("k_in", MqGrid), ("v_in", MqGrid)]
+                ("out_shift", c_int), ("out_i8_tiled", c_int), ("qkv_idx", c_void_p), ("q_in", MqGrid), ("k_in", MqGrid), ("v_in", MqGrid),
+                ("rot_dim", c_int)]
 
 
 _SIGNATURES = {

@@ -94,7 +94,27 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   else load16(src + 16 * c, x);
   const AGrid g = a_load_grid(is_q ? a.qk_a : (is_k ? a.qk_b : a.pv_b));
   int st[16];
-  if (is_q || is_k) {                                 // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
+  const int rot = a.rot_dim > 0 ? a.rot_dim : D;
+  if ((is_q || is_k) && rot != D) {
+    // partial rotary (hf_model.py:489-500; StableLM-2: 16 of 64 dims): dims d < rot rotate with partner d +- rot/2 and cos / sin
+    // [S, rot]; the rest passes through.  Element-wise form (the full-rotary path below keeps its vector loads).
+    const int half = rot >> 1;
+    auto one = [&](int d) {
+      if (isrc) return __fmul_rn(__fsub_rn((float)isrc[d], gin.o), gin.s);
+      return src[d];
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = 16 * c + i;
+      float y = x[i];
+      if (d < rot) {
+        const float p = one(d < half ? d + half : d - half);
+        const float sg = d < half ? -1.f : 1.f;
+        y = __fadd_rn(__fmul_rn(x[i], a.cos[(size_t)s * rot + d]), __fmul_rn(sg * p, a.sin[(size_t)s * rot + d]));
+      }
+      st[i] = (int)a_index_exact(y, g) - 128;
+    }
+  } else if (is_q || is_k) {                          // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
     float pr[16], cs[16], sn[16];
     if (isrc) load16_idx(isrc + ((16 * c + 32) & 63), pr);
     else load16(src + ((16 * c + 32) & 63), pr);
@@ -401,6 +421,7 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   MQ_REQUIRE(((a.q && a.k && a.v) || a.qkv_idx) && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.seq <= 65536, "mq_attention_quant: seq = %d exceeds 65536 (int32 accumulators of the p.v products)", a.seq);
+  MQ_REQUIRE(a.rot_dim >= 0 && a.rot_dim <= 64 && a.rot_dim % 2 == 0, "mq_attention_quant: rot_dim = %d (0 = head_dim; even, <= 64)", a.rot_dim);
   MQ_REQUIRE(a.head_dim == 64 && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
              "mq_attention_quant: head_dim 64, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
   MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmax == 255.f && a.qk_b.qmax == 255.f && a.pv_b.qmax == 255.f &&

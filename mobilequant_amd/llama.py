@@ -145,7 +145,7 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
     if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim != 64 or S < 2
-            or s.rot_dim != s.head_dim or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
+            or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
             or Q._needs_grad(x, *self.parameters())):
         return plain(x, cos, sin, mask, cache, pos)
     if not (Q._u8_grid(qk.input_quantizer) and Q._u8_grid(qk.input2_quantizer) and Q._u8_grid(pv.input2_quantizer)

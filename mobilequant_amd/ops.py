@@ -497,19 +497,22 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled."""
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
     D = 64
+    rot = cos.shape[-1]                  # partial rotary: cos / sin [S, rot_dim] with rot_dim < 64 (hf_model.py:489-500)
+    if rot > D or rot % 2 or sin.shape != cos.shape:
+        raise RuntimeError("mobilequant_amd: attention_quant cos / sin must be [S, rot_dim], rot_dim even and <= 64")
     idx = None
     if qkv_idx is not None:       # (uint8 [S, (heads + 2 kv_heads) * 64] of int8_linear_segmented, ((scale, offset) x 3))
         idx, in_grids = qkv_idx
         idx = _dev(idx, "qkv_idx").contiguous()
         S = idx.shape[0]
-        if idx.dtype != torch.uint8 or idx.shape != (S, (heads + 2 * kv_heads) * D) or cos.shape != (S, D) or sin.shape != (S, D):
+        if idx.dtype != torch.uint8 or idx.shape != (S, (heads + 2 * kv_heads) * D) or cos.shape != (S, rot):
             raise RuntimeError("mobilequant_amd: attention_quant qkv_idx must be uint8 [S, (H + 2 KV) * 64], cos / sin [S, 64]")
         q = k = v = None
     else:
         q, k, v = (_dev(t, n).contiguous() for t, n in ((q, "q"), (k, "k"), (v, "v")))
         S = q.shape[0]
         if (q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or q.shape != (S, heads * D)
-                or k.shape != (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, D) or sin.shape != (S, D)):
+                or k.shape != (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, rot)):
             raise RuntimeError("mobilequant_amd: attention_quant needs fp32 q [S, H*64], k / v [S, KV*64], cos / sin [S, 64]")
     S_real = S
     if S % 64:                    # pad the sequence: under the causal mask a padded key is only ever seen by padded queries
@@ -548,6 +551,7 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
         a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
     a.cos, a.sin = cos.data_ptr(), sin.data_ptr()
     a.seq, a.heads, a.kv_heads, a.head_dim, a.inv_sqrt_d = S, heads, kv_heads, D, 1.0 / (D ** 0.5)
+    a.rot_dim = rot
     a.out, a.q_i8, a.k_i8, a.vt_i8 = out.data_ptr() if out is not None else None, q_i8.data_ptr(), k_i8.data_ptr(), vt_i8.data_ptr()
     a.q_rowsum, a.k_rowsum = q_rs.data_ptr(), k_rs.data_ptr()
     a.seq_real = S_real

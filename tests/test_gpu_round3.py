@@ -389,3 +389,21 @@ def test_torch_ops_are_the_c_abi_kernels(dev):
     assert torch.equal(packed, ops.pack_w4(nib))
     a4, z4, c4 = ops.linear_epilogue_prepare(s, o, 128, ws, torch.full((1,), 5.0, device=dev), 0, nib.to(torch.int32).sum(1).to(torch.int32), 256)
     assert torch.equal(ns.w4a8_linear(q, rs, packed, a4, z4, c4), ops.int8_linear(q, packed, rs, a4, z4, c4, w4=True))
+
+
+@pytest.mark.parametrize("rot", [16, 32])
+def test_prefill_attention_with_partial_rotary_vs_oracle(dev, rot):
+    """mq_attention_quant with RoPE on the first rot_dim of 64 head dims (StableLM-2: partial_rotary_factor 0.25, hf_model.py:489-500)
+    against the numpy restatement; the rest of the kernel is the full-rotary one."""
+    from test_gpu_round2 import _grid_of
+    from mobilequant_amd import ops
+    S, heads, kv_heads = 128, 4, 4
+    q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, 64, rot, seed=rot)
+    want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)                       # noqa: E731
+    got = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids).cpu().numpy()
+    step = float(pv[2].scale)
+    diff = np.abs(got - want)
+    assert np.isfinite(got).all() and diff.max() <= 1.001 * step and (diff > 0.5 * step).mean() < 0.005, (diff.max(), step)
