@@ -60,21 +60,39 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
   return __builtin_fmaf(__builtin_fmaf(-q0, s, x), inv_s, q0);
 }
 
-// 64-lane wave reductions (DPP/permute based via __shfl_xor; wave = 64 on gfx950).
+// 64-lane wave reductions on DPP moves (wave = 64 on gfx950): quad permutes, row_half_mirror, row_mirror leave every lane of a
+// 16-lane row with the row's result; the four rows meet through v_readlane.  A __shfl_xor is a ds_bpermute -- an LDS round trip
+// of ~100 cycles -- and six dependent ones cost a short kernel more than its arithmetic (decode: 0.25 us of a 3 us launch).  The
+// result is wave-uniform.  (Float sums: another association than the xor butterfly -- every caller's tolerance covers the order
+// of a row reduction; min / max are exact either way.)
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) { return __builtin_bit_cast(float, dpp_mov_i<CTRL>(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+template <class Op>
+__device__ __forceinline__ float wave_reduce_f(float v, Op op) {
+  v = op(v, dpp_mov_f<0xB1>(v));                                    // quad_perm [1,0,3,2]
+  v = op(v, dpp_mov_f<0x4E>(v));                                    // quad_perm [2,3,0,1]
+  v = op(v, dpp_mov_f<0x141>(v));                                   // row_half_mirror
+  v = op(v, dpp_mov_f<0x140>(v));                                   // row_mirror
+  return op(op(readlane_f(v, 15), readlane_f(v, 31)), op(readlane_f(v, 47), readlane_f(v, 63)));
+}
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return fminf(a, b); });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return fmaxf(a, b); });
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+  return wave_reduce_f(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov_i<0xB1>(v);
+  v += dpp_mov_i<0x4E>(v);
+  v += dpp_mov_i<0x141>(v);
+  v += dpp_mov_i<0x140>(v);
+  return (__builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31)) + (__builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63));
 }
 
 // Exact float atomic min/max on the IEEE bit pattern (no CAS loop): non-negative floats order as

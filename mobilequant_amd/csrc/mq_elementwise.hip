@@ -282,11 +282,7 @@ __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float*
 // ---- a5 backward: straight-through gradients of the fake-quant (training loops, algorithm.py:381/:587) ----
 // One workgroup per row (per-row grids) or a grid-stride slab (per-tensor); grad_scale / grad_offset are
 // accumulated with float atomics into zero-initialised outputs (one pair of atomics per workgroup).
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum_f(float v) { return wave_sum_f32_dpp(v); }
 
 template <bool PER_ROW>
 __global__ void __launch_bounds__(256) fake_quant_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,

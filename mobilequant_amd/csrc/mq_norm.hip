@@ -35,11 +35,7 @@ __device__ __forceinline__ float nq_index(float x, float s, float inv_s, float o
 }
 __device__ __forceinline__ float nq_dequant(float q, float s, float o) { return __fmul_rn(__fsub_rn(q, o), s); }
 
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum_f32(float v) { return wave_sum_f32_dpp(v); }
 
 struct NormArgs {
   const float* x;

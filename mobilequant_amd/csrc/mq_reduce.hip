@@ -17,14 +17,10 @@ namespace mq {
 __device__ __forceinline__ float min_p(float a, float b) { return __builtin_elementwise_minimum(a, b); }
 __device__ __forceinline__ float max_p(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 __device__ __forceinline__ float wave_min_p(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min_p(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return min_p(a, b); });
 }
 __device__ __forceinline__ float wave_max_p(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max_p(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return max_p(a, b); });
 }
 
 template <typename T>
