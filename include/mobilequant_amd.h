@@ -177,6 +177,18 @@ int mq_w8a8_linear_tiled(const int8_t* a_tiled, const int8_t* w, int64_t M, int6
                          const float* out_offset, float out_qmin, float out_qmax, void* out,
                          int out_dtype, mq_stream_t stream);
 
+/* The same fragment-blocked path for outputs that do not tile by 176 (N = 2048: o_proj / w2; N = 2560: q | k | v): generated gfx950
+ * ISA on 128-column tiles.  mq_gemm_tiled128_supported(M, N, K) != 0: N % 128 == 0, K % 256 == 0, K >= 768.
+ *   mq_w8a8_linear_tiled_residual  = mq_w8a8_linear_residual on fragment-blocked activations, for a 16-bit output grid
+ *     (out_qmax - out_qmin > 255; QLinear.forward + `x + ...`, qmodule.py:341-358 / hf_model.py:1127-1141): same operations in
+ *     the same order, bit-identical results.  128 x 128 tiles (one per CU at 2048 x 2048 outputs), 256 x 128 beyond 512 tiles.
+ *   mq_w8a8_linear_tiled_segmented = mq_w8a8_linear_segmented on fragment-blocked activations (bit-identical indices). */
+int mq_gemm_tiled128_supported(int64_t M, int64_t N, int64_t K);
+int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                                  const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                                  const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
+                                  const float* resid, float* out, mq_stream_t stream);
+
 /* Two QLinears over the SAME activation in one launch -- w1 / w3 of a gated FFN receive the same tensor (hf_model.py:1057:
  * w2(act(w1(x)) * w3(x))).  Both problems have the shape M x N x K (mq_gemm_tiled_supported, K % 256 == 0, K >= 768), their
  * own weights, epilogue vectors and 8-bit unsigned output grid (out_qmin 0, out_qmax 255), and write the output INDICES
@@ -284,6 +296,10 @@ int mq_gated_table(int act, const float* a_scale, const float* a_offset, const f
                    float out_qmin, float out_qmax, int q_shift, int8_t* table, mq_stream_t stream);
 int mq_gated_lookup(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_out,
                     int32_t* row_sum, mq_stream_t stream);
+/* the same lookup writing the fragment-blocked layout of mq_quantize_tiled (cols % 64 == 0, ceil(rows/16)*16 * cols bytes, 16-byte
+ * aligned): the image mq_w8a8_linear_tiled_residual (w2) reads. */
+int mq_gated_lookup_tiled(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_tiled,
+                          int32_t* row_sum, mq_stream_t stream);
 
 /* ---- f2: single-token decode step (mobilellm/model/sim_model.py:160-221 on the quantized module graph) -------------------- */
 /* A per-tensor quantizer grid on the device: scale / offset point at 1 float each; scale == NULL means "no quantizer here". */
@@ -409,6 +425,9 @@ int mq_w8a8_linear_segmented(const int8_t* a, const int8_t* w, int64_t M, int64_
 int mq_w4a8_linear_segmented(const int8_t* a, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
                              const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
                              const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream);
+int mq_w8a8_linear_tiled_segmented(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                                   const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                                   const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream);
 
 typedef struct mq_attention_args {
   const float* q;

@@ -18,6 +18,8 @@ const char* mq_gemm_variant_name(int variant);
  * first stage, 2 = no MFMA loop, 4 = no epilogue, 16 = s_memtime stamps.  0 = normal operation; ignored by production
  * builds. */
 int mq_gemm_set_debug(int flags);
+/* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
+int mq_gemm_set_residual_tile(int rows);
 
 #ifdef __cplusplus
 }

@@ -73,9 +73,14 @@ _SIGNATURES = {
     "mq_w8a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
     "mq_w8a8_linear_residual": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
     "mq_w8a8_linear_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
+    "mq_w8a8_linear_tiled_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
+    "mq_w8a8_linear_tiled_residual": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
+    "mq_gemm_tiled128_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "mq_gemm_set_residual_tile": (c_int, [c_int]),
     "mq_w4a8_linear_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
     "mq_gated_table": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, c_int, _P, _P]),
     "mq_gated_lookup": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P]),
+    "mq_gated_lookup_tiled": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "mq_gemm_tiled_supported": (c_int, [c_int64, c_int64, c_int64]),
     "mq_quantize_tiled": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P]),
     "mq_w8a8_linear_tiled": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),

@@ -29,6 +29,9 @@
 #include "mq_gemv.h"
 #include "mq_gemm_pp_asm.inc"
 #include "mq_gemm_fr_asm.inc"
+#include "mq_gemm_fr128_asm.inc"
+#include "mq_gemm_fr128r_asm.inc"
+#include "mq_gemm_fr128r8_asm.inc"
 
 namespace mq {
 
@@ -801,6 +804,129 @@ __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, i
 
 __global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) { gemm_i8_fr_body(args, blockIdx.x, gridDim.x); }
 
+// ---- the free-running program on 128-column tiles (tools/gen_fr_asm.py variants fr128 / fr128r / fr128r8) ------------------------------
+// N = 2048 / 2560 outputs do not tile by 176.  FR128: 256 x 128 tiles, eight waves, 8-bit unsigned output grid PER COLUMN (the q | k | v
+// segments of mq_w8a8_linear_tiled_segmented).  FR128R: 128 x 128 tiles, FOUR waves (one per SIMD; 2048 x 2048 outputs = 256 tiles = one
+// per CU), fp32 output x + Q16(linear) with the residual add in the store (o_proj / w2).  FR128R8: that epilogue on 256 x 128 tiles.
+enum { FR128 = 1, FR128R = 2, FR128R8 = 3 };
+template <int VAR>
+__device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
+  constexpr int NWV = VAR == FR128R ? 4 : 8;
+  constexpr int BMT = 32 * NWV;
+  constexpr int PCS = 16 / NWV;                 // W LDS-DMA pieces (8 rows x 128 B) per wave and stage
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
+  const int m0 = tm * BMT, n0 = tn * 128;
+  const int M = args.M, N = args.N, K = args.K;
+  const int KT = K / BK;
+  unsigned sw[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    int row = n0 + (wave + i * NWV) * 8 + (lane >> 3);
+    row = row < N ? row : N - 1;
+    sw[i] = (unsigned)row * (unsigned)K + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+  }
+  const int m0w = m0 + wave * 32;
+  const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+  unsigned rb0 = (unsigned)(m0w >> 4), rb1 = rb0 + 1;
+  rb0 = rb0 < rb_max ? rb0 : rb_max;
+  rb1 = rb1 < rb_max ? rb1 : rb_max;
+  const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  unsigned rsofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0w + i * 16 + (lane & 15);
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
+    rsofs[i] = (unsigned)m * 4u;
+  }
+  const int8_t* a_ptr = args.a;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  const float* alpha_p = args.alpha + n0;
+  const float* bias_p = args.bias + n0;
+  const int32_t* wzp_p = args.w_zp + n0;
+  const int32_t* ct_p = args.col_term + n0;
+  const int32_t* rs_p = args.a_rowsum;
+  const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
+  const unsigned tid = threadIdx.x;
+  if constexpr (VAR == FR128) {
+    // this thread's column (tid < 128) and its output grid: segment 0 = out_scale / out_offset, later segments their own
+    const int n = n0 + (int)(tid & 127u);
+    float sc = args.out_scale[0], ooc = args.out_offset[0];
+    if (args.seg_scale[0] != nullptr) {
+      const int sg = (n >= args.seg_end[0]) + (args.seg_scale[1] != nullptr && n >= args.seg_end[1]);
+      if (sg > 0) {
+        sc = args.seg_scale[sg - 1][0];
+        ooc = args.seg_offset[sg - 1][0];
+      }
+    }
+    const float invc = __fdiv_rn(1.0f, sc);
+    uint8_t* outw = reinterpret_cast<uint8_t*>(args.out) + (size_t)m0w * N + n0;
+    const int xorv = __builtin_amdgcn_readfirstlane(args.out_dtype == MQ_I8 ? (int)0x80808080u : 0);
+    asm volatile(MQ_FR128_ASM_BODY
+                 :
+                 : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [alpha] "s"(alpha_p),
+                   [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [ldn] "s"(ldn), [mrem] "s"(mrem),
+                   [flags] "s"(flags), [xorv] "s"(xorv), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [av0] "v"(av0), [av1] "v"(av1),
+                   [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [invc] "v"(invc), [ooc] "v"(ooc)
+                 : MQ_FR128_ASM_CLOBBERS);
+  } else {
+    const float so = args.out_scale[0], oo = args.out_offset[0];
+    const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
+    const int so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(so));
+    const int oo_bits = __builtin_amdgcn_readfirstlane(__float_as_int(oo));
+    const int qmin_bits = __builtin_amdgcn_readfirstlane(__float_as_int(args.out_qmin));
+    const int qmax_bits = __builtin_amdgcn_readfirstlane(__float_as_int(args.out_qmax));
+    float* outw = reinterpret_cast<float*>(args.out) + (size_t)m0w * N + n0;
+    const float* resid = args.resid + (size_t)m0w * N + n0;
+#define MQ_FR128R_OPERANDS                                                                                                          \
+    [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [resid] "s"(resid), [alpha] "s"(alpha_p), \
+        [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),       \
+        [so] "s"(so_bits), [qmin] "s"(qmin_bits), [qmax] "s"(qmax_bits), [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags),      \
+        [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [sw0] "v"(sw[0]), [sw1] "v"(sw[1])
+    if constexpr (VAR == FR128R) {
+      asm volatile(MQ_FR128R_ASM_BODY : : MQ_FR128R_OPERANDS, [sw2] "v"(sw[2]), [sw3] "v"(sw[3]) : MQ_FR128R_ASM_CLOBBERS);
+    } else {
+      asm volatile(MQ_FR128R8_ASM_BODY : : MQ_FR128R_OPERANDS : MQ_FR128R8_ASM_CLOBBERS);
+    }
+#undef MQ_FR128R_OPERANDS
+  }
+}
+
+template <int VAR>
+__global__ void __launch_bounds__(VAR == FR128R ? 256 : 512) gemm_i8_fr128_kernel(const GemmArgs args) { gemm_i8_fr128_body<VAR>(args); }
+
+// shapes the 128-column generated kernels serve (fragment-blocked activations, int8 weights)
+static bool gemm_fr128_shape(int64_t M, int64_t N, int64_t K) { return M > 0 && N % 128 == 0 && K % 256 == 0 && K >= 768; }
+
+template <int VAR>
+static int launch_fr128(GemmArgs a, hipStream_t st) {
+  constexpr int LDS = VAR == FR128 ? MQ_FR128_LDS_BYTES : (VAR == FR128R ? MQ_FR128R_LDS_BYTES : MQ_FR128R8_LDS_BYTES);
+  constexpr int BMT = VAR == FR128R ? 128 : 256;
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_fr128_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  a.has_rowsum = a.a_rowsum != nullptr;
+  if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;
+  if (a.bias == nullptr) a.bias = a.alpha;
+  a.grid_m = (a.M + BMT - 1) / BMT;
+  a.grid_n = a.N / 128;
+  gemm_i8_fr128_kernel<VAR><<<a.grid_m * a.grid_n, VAR == FR128R ? 256 : 512, LDS, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
+}
+
 // Two QLinears that consume the SAME activation (w1 / w3 of an FFN: hf_model.py:1057) in ONE launch: workgroups
 // [0, nblk) compute problem 0, [nblk, 2 nblk) problem 1 with the same block -> tile map, so the second problem's tiles land on
 // the CUs / XCD that just streamed the same activation panel.  Twice the tiles per launch: the kernel-boundary cost and the
@@ -1186,6 +1312,69 @@ int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64
     g->grid_n = (g->N + 175) / 176;
   }
   return launch_fr_pair(g0, g1, as_stream(stream));
+}
+
+int mq_gemm_tiled128_supported(int64_t M, int64_t N, int64_t K) { return gemm_fr128_shape(M, N, K) ? 1 : 0; }
+
+static std::atomic<int> g_fr128r_tile{0};     // tuning hook (mobilequant_amd_tuning.h): 0 = by shape, 128 / 256 = force the tile height
+int mq_gemm_set_residual_tile(int rows) {
+  g_fr128r_tile = (rows == 128 || rows == 256) ? rows : 0;
+  return 0;
+}
+
+int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                                  const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                                  const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
+                                  const float* resid, float* out, mq_stream_t stream) {
+  const char* fn = "mq_w8a8_linear_tiled_residual";
+  int rc = check_common(fn, a_tiled, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset, out, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32) && M * N * 4 < (1ll << 32), "%s: operand too large", fn);
+  MQ_REQUIRE(resid != nullptr && aligned(resid, 16), "%s: resid must be non-null and 16-byte aligned", fn);
+  MQ_REQUIRE(out_scale != nullptr && out_qmax - out_qmin > 255.0f, "%s: a 16-bit output grid is required (8-bit grids: mq_w8a8_linear_residual)", fn);
+  if (!gemm_fr128_shape(M, N, K)) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled128_supported: N %% 128 == 0, K %% 256 == 0, K >= 768)", fn, (long long)M,
+              (long long)N, (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  GemmArgs g{a_tiled, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
+             out_qmin, out_qmax, out, MQ_F32, 0, 0, bias != nullptr, 1, 0, g_dbg_ts, resid};
+  // 128-row tiles while they give every CU at most ~two rounds of work; taller tiles (twice the MFMAs per W fragment) beyond
+  const int forced = g_fr128r_tile.load();
+  const int64_t tiles128 = ((M + 127) / 128) * (N / 128);
+  const bool tall = forced ? forced == 256 : tiles128 > 512;
+  return tall ? launch_fr128<FR128R8>(g, as_stream(stream)) : launch_fr128<FR128R>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_tiled_segmented(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                                   const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                                   const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream) {
+  const char* fn = "mq_w8a8_linear_tiled_segmented";
+  MQ_REQUIRE(n_segments >= 1 && n_segments <= 3 && seg_end != nullptr && grids != nullptr, "%s: 1..3 segments", fn);
+  int rc = check_common(fn, a_tiled, w, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset, out, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32), "%s: activation too large", fn);
+  int64_t prev = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    MQ_REQUIRE(grids[i].scale && grids[i].offset && grids[i].qmin == 0.f && grids[i].qmax == 255.f,
+               "%s: segment %d needs an 8-bit unsigned output grid", fn, i);
+    MQ_REQUIRE(seg_end[i] > prev && seg_end[i] <= N && seg_end[i] % 4 == 0, "%s: segment ends must increase, be multiples of 4, <= N", fn);
+    prev = seg_end[i];
+  }
+  MQ_REQUIRE(prev == N, "%s: the last segment must end at N", fn);
+  if (!gemm_fr128_shape(M, N, K)) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled128_supported: N %% 128 == 0, K %% 256 == 0, K >= 768)", fn, (long long)M,
+              (long long)N, (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  GemmArgs g{a_tiled, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset,
+             0.f, 255.f, out, MQ_U8, 0, 0, bias != nullptr, 1, 0, g_dbg_ts, nullptr, {0, 0}, {nullptr, nullptr}, {nullptr, nullptr}};
+  for (int i = 1; i < n_segments; ++i) {
+    g.seg_end[i - 1] = (int)seg_end[i - 1];
+    g.seg_scale[i - 1] = grids[i].scale;
+    g.seg_offset[i - 1] = grids[i].offset;
+  }
+  return launch_fr128<FR128>(g, as_stream(stream));
 }
 
 static int linear_f32in(const char* fn, int w4, const float* x, const float* a_scale, const float* a_offset, float a_qmin,

@@ -542,8 +542,15 @@ constexpr int GL_TABLE = 65536;
 // 1024 threads = four groups of four waves; a group owns one row at a time (rows strided by 4 * gridDim), requests the whole row up
 // front (<= 4 x 8 bytes per lane and operand), then looks up.  Two such workgroups are resident per CU (2 x 64 KiB of LDS): 8 waves
 // per SIMD, and at [2048, 5632] every group handles exactly one row -- the kernel is one round of loads, lookups and stores.
+// TILED: q is the fragment-blocked image of mq_quantize_tiled (1-KiB blocks of 16 rows x 64 k; a lane's eight bytes stay inside one
+// 16-byte fragment chunk, and the four rows of a workgroup's trip -- rows 4 n .. 4 n + 3 -- fill whole 64-byte pieces of a block).
+template <bool TILED>
 __global__ void __launch_bounds__(1024) gated_lookup_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int64_t rows, int64_t cols,
                                                             const int8_t* __restrict__ table, int8_t* __restrict__ q, int32_t* __restrict__ row_sum) {
+  auto dst = [&](int64_t row, int64_t c) -> int8_t* {
+    if constexpr (TILED) return q + (((row >> 4) * (cols >> 6) + (c >> 6)) << 10) + ((((int)row & 15) + 16 * (((int)c >> 4) & 3)) << 4) + ((int)c & 15);
+    else return q + row * cols + c;
+  };
   extern __shared__ __attribute__((aligned(16))) int8_t lut[];      // [256][256]
   __shared__ int s_sum[4];
   const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
@@ -598,11 +605,11 @@ __global__ void __launch_bounds__(1024) gated_lookup_kernel(const uint8_t* __res
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int64_t c = (int64_t)tid * 8 + 2048 * it;
-          if (c < cols) *reinterpret_cast<uint2*>(q + row * cols + c) = convert(va[it], vb[it], acc);
+          if (c < cols) *reinterpret_cast<uint2*>(dst(row, c)) = convert(va[it], vb[it], acc);
         }
       } else {
         for (int64_t c = (int64_t)tid * 8; c < cols; c += 2048)
-          *reinterpret_cast<uint2*>(q + row * cols + c) =
+          *reinterpret_cast<uint2*>(dst(row, c)) =
               convert(*reinterpret_cast<const uint2*>(a + row * cols + c), *reinterpret_cast<const uint2*>(b + row * cols + c), acc);
       }
     }
@@ -636,28 +643,40 @@ extern "C" int mq_gated_table(int act, const float* a_scale, const float* a_offs
   return MQ_OK;
 }
 
-extern "C" int mq_gated_lookup(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_out,
-                               int32_t* row_sum, mq_stream_t stream) {
+static int gated_lookup_launch(const char* fn, bool tiled, const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table,
+                               int8_t* q_out, int32_t* row_sum, mq_stream_t stream) {
   using namespace mq;
-  MQ_REQUIRE(rows >= 0 && cols >= 0 && cols % 8 == 0, "mq_gated_lookup: cols %% 8 == 0");
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && cols % (tiled ? 64 : 8) == 0, "%s: cols %% %d == 0", fn, tiled ? 64 : 8);
   if (rows == 0 || cols == 0) return MQ_OK;
-  MQ_REQUIRE(a && b && table && q_out && aligned(a, 8) && aligned(b, 8) && aligned(q_out, 8) && aligned(table, 16),
-             "mq_gated_lookup: null or misaligned pointer");
-  static PerDeviceOnce attr_set;
+  MQ_REQUIRE(a && b && table && q_out && aligned(a, 8) && aligned(b, 8) && aligned(q_out, tiled ? 16 : 8) && aligned(table, 16),
+             "%s: null or misaligned pointer", fn);
+  static PerDeviceOnce attr_set[2];
   const int dev = current_device();
-  if (!attr_set.done(dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gated_lookup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GL_TABLE);
+  if (!attr_set[tiled].done(dev)) {
+    hipError_t e = hipFuncSetAttribute(tiled ? (const void*)gated_lookup_kernel<true> : (const void*)gated_lookup_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GL_TABLE);
     if (e != hipSuccess) {
-      set_error("mq_gated_lookup: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      set_error("%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
       return MQ_EHIP;
     }
-    attr_set.mark(dev);
+    attr_set[tiled].mark(dev);
   }
   int64_t blocks = (rows + 3) / 4;                          // four rows per workgroup and trip; two resident workgroups per CU
   if (blocks > 512) blocks = 512;
-  gated_lookup_kernel<<<(unsigned)blocks, 1024, GL_TABLE, as_stream(stream)>>>(a, b, rows, cols, table, q_out, row_sum);
-  MQ_LAUNCH_CHECK("mq_gated_lookup");
+  if (tiled) gated_lookup_kernel<true><<<(unsigned)blocks, 1024, GL_TABLE, as_stream(stream)>>>(a, b, rows, cols, table, q_out, row_sum);
+  else gated_lookup_kernel<false><<<(unsigned)blocks, 1024, GL_TABLE, as_stream(stream)>>>(a, b, rows, cols, table, q_out, row_sum);
+  MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
+}
+
+extern "C" int mq_gated_lookup(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_out,
+                               int32_t* row_sum, mq_stream_t stream) {
+  return gated_lookup_launch("mq_gated_lookup", false, a, b, rows, cols, table, q_out, row_sum, stream);
+}
+
+extern "C" int mq_gated_lookup_tiled(const uint8_t* a, const uint8_t* b, int64_t rows, int64_t cols, const int8_t* table, int8_t* q_tiled,
+                                     int32_t* row_sum, mq_stream_t stream) {
+  return gated_lookup_launch("mq_gated_lookup_tiled", true, a, b, rows, cols, table, q_tiled, row_sum, stream);
 }
 
 extern "C" int mq_gated_act_quant(const void* a, const void* b, int in_dtype, int64_t rows, int64_t cols, int act,

@@ -182,7 +182,9 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         w_o = o_proj._effective_weight(o_proj.weight)
         if (o_proj.input_quantizer is None and o_proj._int8_ready(probe, w_o) and o_proj.weight_quantizer.qcfg.bitwidth == 8
                 and M > 8 and o_proj._activation_grid(probe) is oq):
-            tiled = ops.gemm_tiled_supported(M, w_o.shape[0], K)
+            tiled = ops.gemm_tiled_supported(M, w_o.shape[0], K) or (
+                resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and not o_proj._weight_plan(w_o)["w4"]
+                and o_proj._tiled_residual_ok(M, w_o.shape[0], K))
             q_i8 = torch.empty(((M + 15) // 16 * 16 if tiled else M, K), dtype=torch.int8, device=x.device)
             rs = torch.empty(M, dtype=torch.int32, device=x.device)
             for b in range(B):
@@ -214,10 +216,21 @@ def _qkv_indices(self, x):
         return None
     if (any(m.bias is not None for m in lins) and not all(m.bias is not None for m in lins)):
         return None
-    grid, a_q, a_rs, a_shift, tiled_rows, decode = lins[0]._input_image(x, ws[0])
-    if tiled_rows is not None or decode:
-        return None
     K = ws[0].shape[1]
+    M = x.numel() // x.shape[-1]
+    # the fragment-blocked image a fused norm left for this block (the decoder-layer pass asks for it when the 128-column generated
+    # kernel serves q | k | v): no row-major image exists then
+    grid = grids_in[0]
+    t_shift = 128 if grid.qmax > 127 else 0
+    t_hit = None
+    if all(not m._weight_plan(w)["w4"] for m, w in zip(lins, ws)) and ops.gemm_tiled128_supported(M, sum(w.shape[0] for w in ws), K):
+        t_hit = Q._shared_activation.get(x, grid, ("tiled", t_shift, None))
+    if t_hit is not None:
+        (a_q, a_rs, a_shift), tiled_rows = t_hit, M
+    else:
+        grid, a_q, a_rs, a_shift, tiled_rows, decode = lins[0]._input_image(x, ws[0])
+        if tiled_rows is not None or decode:
+            return None
     plans = [m._epilogue_vectors(m._weight_plan(w), grid, a_shift, K) for m, w in zip(lins, ws)]
     key = tuple((p["key"], p["epi_key"]) for p in plans) + tuple(None if m.bias is None else (m.bias.data_ptr(), Q._ver(m.bias)) for m in lins)
     cat = getattr(self, "_qkv_cat", None)
@@ -237,7 +250,7 @@ def _qkv_indices(self, x):
             oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
         out_grids.append((oq.scale.detach(), oq.offset.detach()))
     idx = ops.int8_linear_segmented(a_q, cat["w"], a_rs, cat["alpha"], cat["w_zp"], cat["col_term"], cat["bias"], ends, out_grids,
-                                    w4=plans[0]["w4"])
+                                    w4=plans[0]["w4"], a_tiled_rows=tiled_rows)
     return idx, out_grids
 
 
@@ -268,8 +281,21 @@ def _fused_layer_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
         return mod.forward_images(t, layout) if isinstance(mod, Q.QRMSNorm) else mod(t)
     # the norms' only consumers here are integer linears: they write just the int8 image those read (q/k/v: row-major; w1/w3: the
     # fragment-blocked layout), not the fp32 tensor
-    x = self.self_attn(norm(self.input_layernorm, x, "rowmajor"), cos, sin, mask, cache, pos, resid=x)
+    x = self.self_attn(norm(self.input_layernorm, x, _qkv_image_layout(self.self_attn, x)), cos, sin, mask, cache, pos, resid=x)
     return self.mlp(norm(self.post_attention_layernorm, x, "tiled"), resid=x)
+
+
+def _qkv_image_layout(attn, x):
+    """Which int8 image the input norm should write for this attention block: the fragment-blocked one when q | k | v run as the
+    segmented GEMM on the 128-column generated kernel (int8 weight images, N % 128 == 0, K % 256 == 0), else row-major."""
+    from . import ops
+    from .quantization import qmodule as Q
+    lins = (attn.q_proj, attn.k_proj, attn.v_proj)
+    if not getattr(attn, "fuse_qkv", True) or not all(isinstance(m, Q.QLinear) and m.weight_quantizer is not None for m in lins):
+        return "rowmajor"
+    M, K = x.numel() // x.shape[-1], x.shape[-1]
+    n = sum(m.weight.shape[0] for m in lins)
+    return "tiled" if M > 8 and K % 64 == 0 and ops.gemm_tiled128_supported(M, n, K) else "rowmajor"
 
 
 def fuse_decoder_layer(model) -> int:

@@ -246,13 +246,16 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
     if resid is not None:
-        if a_tiled_rows is not None or w4 or out_dtype != MQ_F32 or M <= 8:
-            raise RuntimeError("mobilequant_amd: int8_linear(resid=...) needs row-major int8 operands, fp32 output and M > 8")
+        if w4 or out_dtype != MQ_F32 or M <= 8:
+            raise RuntimeError("mobilequant_amd: int8_linear(resid=...) needs int8 operands, fp32 output and M > 8")
+        if a_tiled_rows is not None and not (os_ is not None and out_qmax - out_qmin > 255.0 and gemm_tiled128_supported(M, N, K)):
+            raise RuntimeError("mobilequant_amd: int8_linear(resid=..., a_tiled_rows=...) needs a 16-bit output grid and a "
+                               "gemm_tiled128_supported shape")
         resid = _f32(_dev(resid, "resid"), "resid")
         if resid.numel() != M * N or resid.data_ptr() == out.data_ptr():
             raise RuntimeError("mobilequant_amd: resid must be [M, N] and must not alias the output")
         with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, os_, oo_, out, resid):
-            _lib.call("mq_w8a8_linear_residual", a_q.data_ptr(), w_q.data_ptr(), M, N, K,
+            _lib.call("mq_w8a8_linear_tiled_residual" if a_tiled_rows is not None else "mq_w8a8_linear_residual", a_q.data_ptr(), w_q.data_ptr(), M, N, K,
                       a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
                       b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
                       oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), resid.data_ptr(), out.data_ptr(),
@@ -269,12 +272,19 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
 
 
 def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.Tensor, alpha: torch.Tensor, w_zp: torch.Tensor,
-                          col_term: torch.Tensor, bias: Optional[torch.Tensor], seg_ends, grids, w4: bool = False) -> torch.Tensor:
+                          col_term: torch.Tensor, bias: Optional[torch.Tensor], seg_ends, grids, w4: bool = False,
+                          a_tiled_rows: Optional[int] = None) -> torch.Tensor:
     """1..3 linears reading one row-major int8 activation as ONE GEMM (mq_w8a8_linear_segmented): w_q / alpha / w_zp / col_term /
     bias concatenated along N, seg_ends = cumulative column ends, grids[i] = (scale, offset) of segment i's 8-bit unsigned output
-    grid.  Returns the uint8 output indices [M, N].  w4: w_q holds packed nibbles [N, K/2] (pack_w4)."""
+    grid.  Returns the uint8 output indices [M, N].  w4: w_q holds packed nibbles [N, K/2] (pack_w4).  a_tiled_rows = M: a_q is the
+    fragment-blocked image (gemm_tiled128_supported shapes, int8 weights)."""
     _dev(a_q, "a_q"); _dev(w_q, "w_q")
     M, K = a_q.shape
+    fn = "mq_w4a8_linear_segmented" if w4 else "mq_w8a8_linear_segmented"
+    if a_tiled_rows is not None:
+        if w4:
+            raise RuntimeError("mobilequant_amd: the fragment-blocked segmented GEMM takes int8 weights")
+        M, fn = int(a_tiled_rows), "mq_w8a8_linear_tiled_segmented"
     N = w_q.shape[0]
     n = len(seg_ends)
     out = torch.empty((M, N), dtype=torch.uint8, device=a_q.device)
@@ -286,10 +296,15 @@ def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.
         keep += [sc, of]
         gs[i] = _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0)
     with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, out, *keep):
-        _lib.call("mq_w4a8_linear_segmented" if w4 else "mq_w8a8_linear_segmented", a_q.data_ptr(), w_q.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
+        _lib.call(fn, a_q.data_ptr(), w_q.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
                   alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(), b.data_ptr() if b is not None else None, n, ends, gs,
                   out.data_ptr(), _stream())
     return out
+
+
+def gemm_tiled128_supported(M: int, N: int, K: int) -> bool:
+    """Shapes served by the 128-column generated kernels on fragment-blocked activations (o_proj / w2 with the residual, q | k | v)."""
+    return bool(_lib.load().mq_gemm_tiled128_supported(int(M), int(N), int(K)))
 
 
 def gemm_tiled_supported(M: int, N: int, K: int) -> bool:
@@ -473,17 +488,18 @@ def gated_table(act: str, out_grid, a_grid, b_grid, mid_grid=None, act_grid=None
     return table
 
 
-def gated_lookup(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor):
-    """uint8 index tensors a, b [rows, cols] -> (int8 image, row sums) through a gated_table (mq_gated_lookup)."""
+def gated_lookup(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, tiled: bool = False):
+    """uint8 index tensors a, b [rows, cols] -> (int8 image, row sums) through a gated_table (mq_gated_lookup).  tiled: the image
+    in the fragment-blocked layout of quantize_tiled ([ceil16(rows), cols], cols % 64 == 0)."""
     a, b = _dev(a, "a").contiguous(), _dev(b, "b").contiguous()
     if a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.shape != b.shape or table.dtype != torch.int8 or table.numel() != 65536:
         raise RuntimeError("mobilequant_amd: gated_lookup needs two uint8 tensors of one shape and an int8 [65536] table")
     cols = a.shape[-1]
     rows = a.numel() // max(cols, 1)
-    q = torch.empty(a.shape, dtype=torch.int8, device=a.device)
+    q = torch.empty(((rows + 15) // 16 * 16, cols) if tiled else a.shape, dtype=torch.int8, device=a.device)
     rs = torch.empty(rows, dtype=torch.int32, device=a.device)
     with _on(a, b, table):
-        _lib.call("mq_gated_lookup", a.data_ptr(), b.data_ptr(), rows, cols, table.data_ptr(), q.data_ptr(), rs.data_ptr(), _stream())
+        _lib.call("mq_gated_lookup_tiled" if tiled else "mq_gated_lookup", a.data_ptr(), b.data_ptr(), rows, cols, table.data_ptr(), q.data_ptr(), rs.data_ptr(), _stream())
     return q, rs
 
 

@@ -643,6 +643,12 @@ class QLinear(nn.Linear, _QuantizedOp):
         a_q, a_rs, a_shift = hit
         return grid, a_q, a_rs, a_shift, tiled_rows, False
 
+    def _tiled_residual_ok(self, M, N, K):
+        """x + Q16(linear) from a fragment-blocked activation image (mq_w8a8_linear_tiled_residual): o_proj / w2 of the fused layer."""
+        oq = self.output_quantizer
+        return (oq is not None and not oq.bypassed() and _static_per_tensor(oq, 16) and oq.qmax - oq.qmin > 255
+                and ops.gemm_tiled128_supported(M, N, K))
+
     def _forward_int8(self, x, weight, bias):
         grid, a_q, a_rs, a_shift, tiled_rows, decode = self._input_image(x, weight)
         return self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=decode)
@@ -684,12 +690,14 @@ class QLinear(nn.Linear, _QuantizedOp):
                 return resid + out
             return _tag_grid(out, oq) if fused else out
         if resid is not None:
-            if (tiled_rows is None and not plan["w4"] and not f16 and a_q.shape[0] > 8 and resid.dtype == torch.float32
-                    and resid.is_contiguous()):
+            rows = a_q.shape[0] if tiled_rows is None else tiled_rows
+            if (not plan["w4"] and not f16 and rows > 8 and resid.dtype == torch.float32 and resid.is_contiguous()
+                    and (tiled_rows is None or self._tiled_residual_ok(rows, N, K))):
                 out = ops.int8_linear(
                     a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
                     out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
-                    out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, resid=resid)
+                    out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, resid=resid,
+                    a_tiled_rows=tiled_rows)
                 return out.reshape(*lead, N)
             return resid + self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode, lead_shape)
         out = ops.int8_linear(
@@ -1218,7 +1226,13 @@ def _gated_mlp_forward(self, x, resid=None):
                                     mid_grid=QRMSNorm._grid_or_none(mid_q) if silu else None,
                                     act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
             cached = self._gated_lut = (key, table)
-        p_q, p_rs = ops.gated_lookup(a_idx, b_idx, cached[1])
+        # w2 with the residual: the fragment-blocked image its generated kernel reads
+        w2_tiled = (resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and N % 64 == 0
+                    and not w2._weight_plan(wt2)["w4"] and w2._tiled_residual_ok(M, wt2.shape[0], N))
+        p_q, p_rs = ops.gated_lookup(a_idx, b_idx, cached[1], tiled=w2_tiled)
+        if w2_tiled:
+            return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q, p_rs, 128, M,
+                                       lead_shape=x.shape[:-1], resid=resid)
     else:
         p_q, p_rs = ops.gated_act_quant(a_idx, b_idx, "silu" if silu else "gelu",
                                         (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),

@@ -98,6 +98,11 @@ def test_generated_free_running_kernel_is_current(tmp_path):
     fresh = str(tmp_path / "fresh.inc")
     mod.main(fresh)
     assert open(fresh).read() == open(inc).read()
+    # the 128-column variants of the same generator (q | k | v; o_proj / w2 with the residual add)
+    for variant, (_, _, _, _, fname) in mod.VARIANTS.items():
+        fresh = str(tmp_path / ("fresh_" + variant + ".inc"))
+        mod.main(fresh, variant=variant)
+        assert open(fresh).read() == open(os.path.join(root, "mobilequant_amd", "csrc", fname)).read(), variant
 
 
 def test_argument_checks_fail_before_any_launch():

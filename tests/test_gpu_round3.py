@@ -407,3 +407,82 @@ def test_prefill_attention_with_partial_rotary_vs_oracle(dev, rot):
     step = float(pv[2].scale)
     diff = np.abs(got - want)
     assert np.isfinite(got).all() and diff.max() <= 1.001 * step and (diff > 0.5 * step).mean() < 0.005, (diff.max(), step)
+
+
+# ---- the 128-column generated kernels on fragment-blocked activations -------------------------------------------------------------
+def _to_tiled(a_q):
+    """row-major int8 [M, K] -> the fragment-blocked image of mq_quantize_tiled ([ceil16(M), K]; include/mobilequant_amd.h)."""
+    M, K = a_q.shape
+    Mp = (M + 15) // 16 * 16
+    pad = torch.zeros((Mp, K), dtype=torch.int8, device=a_q.device)
+    pad[:M] = a_q
+    return pad.view(Mp // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().view(Mp, K)
+
+
+def _gemm_operands(dev, M, N, K, seed, w_zp_zero=False, bias=True):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a_q = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g).to(dev)
+    w_q = torch.randint(-128, 128, (N, K), dtype=torch.int8, generator=g).to(dev)
+    a_rs = a_q.to(torch.int32).sum(dim=1, dtype=torch.int32)
+    alpha = (torch.rand(N, generator=g) * 2e-4 + 1e-5).to(dev)
+    w_zp = (torch.zeros(N, dtype=torch.int32) if w_zp_zero else torch.randint(-100, 100, (N,), dtype=torch.int32, generator=g)).to(dev)
+    col_term = torch.randint(-50000, 50000, (N,), dtype=torch.int32, generator=g).to(dev)
+    b = (torch.randn(N, generator=g) * 0.3).to(dev) if bias else None
+    return a_q, w_q, a_rs, alpha, w_zp, col_term, b
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(2048, 2048, 2048, 0), (2048, 2048, 5632, 128), (2048, 2048, 2048, 256), (300, 256, 768, 128),
+                                        (300, 256, 768, 256), (129, 384, 1024, 0), (4096, 2048, 1024, 0)])
+def test_tiled_residual_gemm_is_the_rowmajor_residual_gemm_bit_for_bit(dev, M, N, K, tile):
+    """mq_w8a8_linear_tiled_residual (generated ISA, 128 x 128 / 256 x 128 tiles, fragment-blocked activations) against
+    mq_w8a8_linear_residual (the C++ kernel the golden decode / layer cases pin): x + Q16(linear), same bits."""
+    import mobilequant_amd._lib as L
+    from mobilequant_amd import ops
+    for variant, (zp0, bias) in enumerate(((False, True), (True, False))):
+        a_q, w_q, a_rs, alpha, w_zp, col_term, b = _gemm_operands(dev, M, N, K, 11 * M + N + K + variant, zp0, bias)
+        resid = torch.randn(M, N, device=dev)
+        so = torch.tensor([3.1e-4], device=dev)
+        oo = torch.tensor([32768.0 if variant == 0 else 30111.0], device=dev)
+        kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0)
+        want = ops.int8_linear(a_q, w_q, None if zp0 else a_rs, alpha, w_zp, col_term, b, resid=resid, **kw)
+        L.load().mq_gemm_set_residual_tile(tile)
+        try:
+            got = ops.int8_linear(_to_tiled(a_q), w_q, None if zp0 else a_rs, alpha, w_zp, col_term, b, resid=resid, a_tiled_rows=M, **kw)
+        finally:
+            L.load().mq_gemm_set_residual_tile(0)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and torch.equal(got, want), (variant, (got - want).abs().max().item())
+        q = torch.round((want - resid) / so + oo)            # the grid is actually exercised (not saturated everywhere)
+        assert q.min() < 20000 and q.max() > 45000
+
+
+@pytest.mark.parametrize("M,K,ends", [(2048, 2048, (2048, 2304, 2560)), (300, 768, (128, 256)), (513, 1024, (384,))])
+def test_tiled_segmented_gemm_is_the_rowmajor_segmented_gemm_bit_for_bit(dev, M, K, ends):
+    """mq_w8a8_linear_tiled_segmented (q | k | v on 256 x 128 tiles of generated ISA, one output grid per column segment) against
+    mq_w8a8_linear_segmented."""
+    from mobilequant_amd import ops
+    N = ends[-1]
+    a_q, w_q, a_rs, alpha, w_zp, col_term, b = _gemm_operands(dev, M, N, K, 5 * M + K)
+    alpha = alpha * 0.02
+    grids = [(torch.tensor([0.011 * (i + 1)], device=dev), torch.tensor([100.0 + 20 * i], device=dev)) for i in range(len(ends))]
+    want = ops.int8_linear_segmented(a_q, w_q, a_rs, alpha, w_zp, col_term, b, ends, grids)
+    got = ops.int8_linear_segmented(_to_tiled(a_q), w_q, a_rs, alpha, w_zp, col_term, b, ends, grids, a_tiled_rows=M)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), (got.int() - want.int()).abs().max().item()
+    assert 5 < want.float().mean() < 250 and want.min() == 0 and want.max() == 255
+
+
+def test_gated_lookup_tiled_is_the_rowmajor_lookup_in_the_fragment_blocked_layout(dev):
+    from mobilequant_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    table = torch.randint(-128, 128, (65536,), dtype=torch.int8, generator=g).to(dev)
+    for rows, cols in ((2048, 5632), (37, 128), (130, 8192 + 64)):
+        a = torch.randint(0, 256, (rows, cols), dtype=torch.uint8, generator=g).to(dev)
+        b = torch.randint(0, 256, (rows, cols), dtype=torch.uint8, generator=g).to(dev)
+        q, rs = ops.gated_lookup(a, b, table)
+        qt, rst = ops.gated_lookup(a, b, table, tiled=True)
+        torch.cuda.synchronize()
+        assert torch.equal(rs, rst)
+        Mp = (rows + 15) // 16 * 16
+        back = qt.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
+        assert torch.equal(back, q)

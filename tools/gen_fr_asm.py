@@ -32,15 +32,42 @@ K % 256 == 0 and K >= 768 (two head stages + pairs of steady stages + four tail 
 Run:  python tools/gen_fr_asm.py   (writes the .inc next to mq_gemm.hip; the file is committed and checked by the tests)."""
 import os
 
-BK, BM, BN = 128, 256, 176
-W_BYTES = BN * BK                 # 22528
+BK = 128
 RING = 4
-PAR = RING * W_BYTES              # 90112: alpha' | bias' | -w_zp | col_term
-STG = PAR + 16 * BN               # 92928
-ROWP = BN                         # staging pitch (u8): 176 B rows, writes <= 2-way conflicted
-STG_WAVE = 2 * 16 * ROWP          # 5632
-LDS_BYTES = STG + 8 * STG_WAVE    # 137984
-FN = BN // 16
+
+# Variants: the same program parameterised by the N tile (FN W fragments of 16 columns), the number of waves stacked along M (32 rows
+# each) and the epilogue.  "fr" is the original 256 x 176 kernel (its .inc must stay byte-identical: tests/test_cabi.py).
+VARIANTS = {
+    #  name     BN   NW  epilogue  macro prefix   file
+    "fr":      (176, 8, "u8",   "MQ_FR",      "mq_gemm_fr_asm.inc"),
+    "fr128":   (128, 8, "u8",   "MQ_FR128",   "mq_gemm_fr128_asm.inc"),      # q|k|v (N = 2560): 256 x 128 tiles, per-column output grids
+    "fr128r":  (128, 4, "f32r", "MQ_FR128R",  "mq_gemm_fr128r_asm.inc"),     # o_proj / w2 (N = 2048): 128 x 128 tiles, x + Q16(linear) in fp32
+    "fr128r8": (128, 8, "f32r", "MQ_FR128R8", "mq_gemm_fr128r8_asm.inc"),    # the same epilogue on 256 x 128 tiles
+}
+
+
+def configure(name):
+    """binds the module-level tile constants of one variant (the emitters read them at call time)"""
+    global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF
+    BN, NW, EPI, PREFIX, FILE = VARIANTS[name]
+    BM = 32 * NW
+    FN = BN // 16
+    W_BYTES = BN * BK                 # 22528 / 16384
+    PAR = RING * W_BYTES              # alpha' | bias' | -w_zp | col_term
+    STG = PAR + 16 * BN
+    if EPI == "u8":
+        # staging pitch (u8 rows): 176 B as is (writes <= 2-way conflicted); 128 B rows padded to 144 (bank = 36 frow + kq: conflict-free)
+        ROWP = BN if BN % 128 else BN + 16
+        STG_WAVE = 2 * 16 * ROWP
+    else:
+        # fp32 staging of HALF a 16-row block's columns at a time (64 columns = 256-byte row pieces), pitch 272
+        HALF = 64
+        ROWP = HALF * 4 + 16
+        STG_WAVE = 16 * ROWP
+    LDS_BYTES = STG + NW * STG_WAVE
+    PIECES = (BN // 8 + NW - 1) // NW   # most W LDS-DMA pieces (8 rows x 128 B) a wave owns per stage
+    assert LDS_BYTES <= 160 * 1024
+
 
 # ---- registers -------------------------------------------------------------------------------------------------------------------
 V_T = 98                          # first temporary VGPR
@@ -56,7 +83,7 @@ V_TMP = 127
 S0 = 58                           # first temporary SGPR
 S_ABASE, S_WBASE = 58, 60         # pairs: activation pointer of stage t+1; weight pointer of the stage whose DMA is issued next
 S_CUR, S_NXT, S_DMA = 62, 63, 64  # ring slot byte offsets: stage t, t+1, t+3
-S_WK0, S_WK1, S_WK2 = 65, 66, 67  # wave*1024 + i*8192: LDS offset of this wave's piece i inside a slot
+S_WK = (65, 66, 67, 71)           # wave*1024 + i*NW*1024: LDS offset of this wave's piece i inside a slot
 S_CNT = 68                        # steady-state pairs left
 S_TMP, S_TMP2 = 69, 70
 S_EXEC = 72                       # pair
@@ -97,12 +124,12 @@ def accr(i, j, e):
 
 
 def wreg(set_, j):
-    b = 44 * set_ + 4 * j
+    b = 4 * FN * set_ + 4 * j
     return f"a[{b}:{b + 3}]"
 
 
 def areg(set_, ks, i):
-    b = 88 + 16 * set_ + 8 * ks + 4 * i
+    b = 8 * FN + 16 * set_ + 8 * ks + 4 * i
     return f"a[{b}:{b + 3}]"
 
 
@@ -131,7 +158,7 @@ class Queue:
 def issue_w(q, t, nw, slot_sgpr):
     """this wave's LDS-DMA pieces of W(t) -> ring slot `slot_sgpr`; source k offset = S_WBASE (advanced by 128 afterwards)"""
     for i in range(nw):
-        emit(f"s_add_u32 m0, s{slot_sgpr}, s{S_WK0 + i}")
+        emit(f"s_add_u32 m0, s{slot_sgpr}, s{S_WK[i]}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 %[sw{i}], s[{S_WBASE}:{S_WBASE + 1}]")
         q.issue(("W", t))
@@ -141,7 +168,7 @@ def issue_w(q, t, nw, slot_sgpr):
 
 def w_piece(q, t, i, slot_sgpr):
     def f():
-        emit(f"s_add_u32 m0, s{slot_sgpr}, s{S_WK0 + i}")
+        emit(f"s_add_u32 m0, s{slot_sgpr}, s{S_WK[i]}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 %[sw{i}], s[{S_WBASE}:{S_WBASE + 1}]")
         q.issue(("W", t))
@@ -164,7 +191,9 @@ def kstep(cur, aset, ks, rd_slot, rd_woff, nxt, vmem, read=True, mfma_first=0):
     places = {}
     for n, (kind, f) in enumerate(vmem):      # A loads early (their registers are free), DMA pieces in the second half
         na = sum(1 for k, _ in vmem[:n] if k == kind)
-        places.setdefault(1 + 2 * na if kind == "a" else 12 + 3 * na, []).append(f)
+        nwp = sum(1 for k, _ in vmem if k == "w")
+        wstep = 3 if FN == 11 else max(1, (FN - 1) // max(nwp, 1))
+        places.setdefault(1 + 2 * na if kind == "a" else FN + 1 + wstep * na, []).append(f)
     m = 0
     for j in range(FN):
         for i in range(2):
@@ -225,9 +254,9 @@ def prologue(q, nw, stamp):
     # loop state
     emit(f"s_mov_b64 s[{S_ABASE}:{S_ABASE + 1}], %[aptr]")
     emit(f"s_mov_b64 s[{S_WBASE}:{S_WBASE + 1}], %[wptr]")
-    emit(f"s_lshl_b32 s{S_WK0}, %[wave], 10")
-    emit(f"s_add_u32 s{S_WK1}, s{S_WK0}, 8192")
-    emit(f"s_add_u32 s{S_WK2}, s{S_WK0}, 16384")
+    emit(f"s_lshl_b32 s{S_WK[0]}, %[wave], 10")
+    for i in range(1, max(PIECES, 3) if BN == 176 else PIECES):
+        emit(f"s_add_u32 s{S_WK[i]}, s{S_WK[0]}, {i * NW * 1024}")
     emit(f"s_mov_b32 s{S_CUR}, 0")
     emit(f"s_mov_b32 s{S_NXT}, {W_BYTES}")
     emit(f"s_mov_b32 s{S_DMA}, {3 * W_BYTES}")
@@ -269,7 +298,7 @@ def prologue(q, nw, stamp):
     # staging write address: STG + wave*STG_WAVE + frow*ROWP + kq*4 ; alpha' chunk address: PAR + kq*16
     emit(f"v_and_b32 v{V_STW}, 15, v{V_TMP}")
     emit(f"v_mul_u32_u24 v{V_STW}, {ROWP}, v{V_STW}")
-    emit(f"v_lshl_add_u32 v{V_STW}, v{V_PAR}, 2, v{V_STW}")
+    emit(f"v_lshl_add_u32 v{V_STW}, v{V_PAR}, {2 if EPI == 'u8' else 4}, v{V_STW}")   # + kq*4 bytes (u8) / kq*16 (fp32)
     emit(f"s_mul_i32 s{S_TMP}, %[wave], {STG_WAVE}")
     emit(f"s_add_u32 s{S_TMP}, s{S_TMP}, {STG}")
     emit(f"v_add_u32 v{V_STW}, s{S_TMP}, v{V_STW}")
@@ -291,9 +320,13 @@ def prologue(q, nw, stamp):
     emit(f"s_cbranch_scc1 {l}")
     emit(f"v_mov_b32 v{V_P0 + 1}, 0")
     emit(f"{l}:")
-    emit(f"v_mul_f32 v{V_P0}, %[inv_so], v{V_P0}")
-    emit(f"v_mul_f32 v{V_P0 + 1}, %[inv_so], v{V_P0 + 1}")
-    emit(f"v_add_f32 v{V_P0 + 1}, %[oo], v{V_P0 + 1}")
+    # 176: one output grid (scalars);  128 / u8: this column's grid (per-lane operands: q | k | v segments);  f32r: 16-bit grid,
+    # the offset stays outside the fma (added after the rounding, as in the C++ epilogue)
+    inv, oo = ("%[inv_so]", "%[oo]") if (BN == 176 or EPI != "u8") else ("%[invc]", "%[ooc]")
+    emit(f"v_mul_f32 v{V_P0}, {inv}, v{V_P0}")
+    emit(f"v_mul_f32 v{V_P0 + 1}, {inv}, v{V_P0 + 1}")
+    if EPI == "u8":
+        emit(f"v_add_f32 v{V_P0 + 1}, {oo}, v{V_P0 + 1}")
     emit(f"v_sub_u32 v{V_P0 + 2}, 0, v{V_P0 + 2}")
     emit(f"v_lshlrev_b32 v{V_TMP}, 2, %[tid]")
     emit(f"v_add_u32 v{V_TMP}, {PAR}, v{V_TMP}")
@@ -356,17 +389,23 @@ def epilogue(stamp):
         for i in range(2):
             emit(f"v_xor_b32 v{VP[i]}, %[xorv], v{VP[i]}")
             emit(f"ds_write_b32 v{V_STW}, v{VP[i]} offset:{i * 16 * ROWP + j * 16}")
-    # chunk c = lane + 64 r (r = 0..2) of the 16 x 11 chunks of a row block: row = c / 11, ch = c % 11
+    # chunk c = lane + 64 r of the 16 x FN chunks of a row block: row = c / FN, ch = c % FN
+    R = (16 * FN + 63) // 64
     emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")
     emit(f"s_mul_i32 s{S_TMP}, %[wave], {STG_WAVE}")
     emit(f"s_add_u32 s{S_TMP}, s{S_TMP}, {STG}")
-    for r in range(3):
+    for r in range(R):
         c, row, ch = 124, 125, 126
         emit(f"v_add_u32 v{c}, {64 * r}, v{V_TMP}")
-        emit(f"v_mul_u32_u24 v{row}, 5958, v{c}")                            # floor(c / 11) for c < 192 (5958 = ceil(2^16 / 11))
-        emit(f"v_lshrrev_b32 v{row}, 16, v{row}")
-        emit(f"v_mul_u32_u24 v{ch}, 11, v{row}")
-        emit(f"v_sub_u32 v{ch}, v{c}, v{ch}")
+        if FN == 11:
+            emit(f"v_mul_u32_u24 v{row}, 5958, v{c}")                        # floor(c / 11) for c < 192 (5958 = ceil(2^16 / 11))
+            emit(f"v_lshrrev_b32 v{row}, 16, v{row}")
+            emit(f"v_mul_u32_u24 v{ch}, 11, v{row}")
+            emit(f"v_sub_u32 v{ch}, v{c}, v{ch}")
+        else:
+            assert FN == 8
+            emit(f"v_lshrrev_b32 v{row}, 3, v{c}")
+            emit(f"v_and_b32 v{ch}, 7, v{c}")
         emit(f"v_lshlrev_b32 v{ch}, 4, v{ch}")                               # ch * 16 bytes
         emit(f"v_mul_u32_u24 v{V_LDSO + r}, {ROWP}, v{row}")
         emit(f"v_add_u32 v{V_LDSO + r}, v{V_LDSO + r}, v{ch}")
@@ -376,18 +415,18 @@ def epilogue(stamp):
         emit(f"v_mov_b32 v{V_E + r}, v{row}")                                # row index kept for the M bound
     emit("s_waitcnt lgkmcnt(0)")
     for i in range(2):
-        for r in range(3):
-            b = (i * 3 + r) * 4
+        for r in range(R):
+            b = (i * R + r) * 4
             emit(f"ds_read_b128 v[{b}:{b + 3}], v{V_LDSO + r} offset:{i * 16 * ROWP}")
     emit(f"s_lshl_b32 s{S_TMP2}, %[ldn], 4")                                 # 16 rows further down
     emit("s_waitcnt lgkmcnt(0)")
     for i in range(2):
-        for r in range(3):
-            b = (i * 3 + r) * 4
-            # rows valid for this wave: %[mrem] (may be <= 0 or > 32); lane active if i*16 + row < mrem (and c < 176 for r = 2)
+        for r in range(R):
+            b = (i * R + r) * 4
+            # rows valid for this wave: %[mrem] (may be <= 0 or > 32); lane active if i*16 + row < mrem (and c < 16 FN in a partial round)
             emit(f"v_add_u32 v{V_TMP}, {16 * i}, v{V_E + r}")
             emit(f"v_cmp_gt_i32 vcc, %[mrem], v{V_TMP}")
-            if r == 2:
+            if 64 * (r + 1) > 16 * FN:
                 emit(f"v_cmp_gt_u32_e64 s[{S_MR}:{S_MR + 1}], 16, v{V_E + r}")
                 emit(f"s_and_b64 vcc, vcc, s[{S_MR}:{S_MR + 1}]")
             emit("s_and_b64 exec, exec, vcc")
@@ -412,6 +451,134 @@ def epilogue(stamp):
             emit(f"v_mov_b32 v1, s{src + 1}")
             emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:{8 * k}")
         emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    emit("s_waitcnt vmcnt(0)")
+
+
+# ---- fp32 epilogue with the residual add: out = resid + (clamp(rint(fma(float(acc), alpha', bias')) + oo, qmin, qmax) - oo) * so ------
+# (o_proj / w2: a 16-bit output grid in front of the residual stream; the same operations in the same order as the C++ epilogue of
+# gemm_i8_kernel<.., MQ_F32, OUTQ>, so both kernels produce the same bits.)  A wave converts one UNIT = (row block i, column half h)
+# at a time: 16 rows x 64 columns through a wave-private fp32 staging tile, read back as 256-byte row pieces -- lane (row0 = lane >> 4,
+# ch = lane & 15) handles chunk ch of rows row0 + 4 r, r = 0..3.  The residual rows of unit u + 1 are requested before unit u is
+# converted (two register sets: v[78:93] and the accumulators unit 0 has released).
+V_RDB, V_G = 98, (99, 94, 95, 96)   # staging read-back address; global byte offsets of the lane's chunk in rows row0 + 4 r
+V_ROW, V_QMIN, V_QMAX = 97, 122, 123
+S_OB, S_RB, S_STEP = 74, 76, 78     # output / residual pointers of the current unit (pairs); 4 rows in bytes
+S_MASK = 80                         # 80..95: exec masks of (i, r)
+
+
+def epilogue_f32r():
+    emit("; ==== epilogue: fp32 x + Qout16(linear), unit by unit")
+    emit("s_nop 15")
+    emit("s_nop 3")
+    D = [106 + 4 * r for r in range(4)]
+    RS = [[78 + 4 * r for r in range(4)], [(2 * jj) * 4 for jj in range(4)]]     # residual register sets (set 1 = acc(0, 0..3))
+    EA = [V_E, V_P0]
+    q = Queue()
+
+    emit(f"v_mov_b32 v{V_QMIN}, %[qmin]")
+    emit(f"v_mov_b32 v{V_QMAX}, %[qmax]")
+    emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")
+    emit(f"v_lshrrev_b32 v{V_ROW}, 4, v{V_TMP}")                             # row0
+    emit(f"v_and_b32 v{V_TMP}, 15, v{V_TMP}")
+    emit(f"v_lshlrev_b32 v{V_TMP}, 4, v{V_TMP}")                             # ch * 16 bytes
+    emit(f"s_mul_i32 s{S_TMP}, %[wave], {STG_WAVE}")
+    emit(f"s_add_u32 s{S_TMP}, s{S_TMP}, {STG}")
+    emit(f"v_mul_u32_u24 v{V_RDB}, {ROWP}, v{V_ROW}")
+    emit(f"v_add_u32 v{V_RDB}, v{V_RDB}, v{V_TMP}")
+    emit(f"v_add_u32 v{V_RDB}, s{S_TMP}, v{V_RDB}")
+    emit(f"s_lshl_b32 s{S_TMP}, %[ldn], 2")                                  # bytes per output row
+    emit(f"s_lshl_b32 s{S_STEP}, %[ldn], 4")                                 # 4 rows
+    emit(f"v_mul_lo_u32 v{V_G[0]}, v{V_ROW}, s{S_TMP}")
+    emit(f"v_add_u32 v{V_G[0]}, v{V_G[0]}, v{V_TMP}")
+    for r in range(1, 4):
+        emit(f"v_add_u32 v{V_G[r]}, s{S_STEP}, v{V_G[r - 1]}")
+    emit(f"s_mov_b64 s[{S_OB}:{S_OB + 1}], %[outw]")
+    emit(f"s_mov_b64 s[{S_RB}:{S_RB + 1}], %[resid]")
+    emit(f"s_lshl_b32 s{S_TMP2}, %[ldn], 6")                                 # 16 rows ...
+    emit(f"s_sub_u32 s{S_TMP2}, s{S_TMP2}, {HALF * 4}")                      # ... minus the half row already advanced
+    for i in range(2):
+        for r in range(4):
+            m = S_MASK + 2 * (4 * i + r)
+            emit(f"v_add_u32 v{V_TMP}, {16 * i + 4 * r}, v{V_ROW}")
+            emit(f"v_cmp_gt_i32_e64 s[{m}:{m + 1}], %[mrem], v{V_TMP}")
+
+    def advance(sp, u):
+        if u == 3:
+            return
+        if u == 1:
+            emit(f"s_add_u32 s{sp}, s{sp}, s{S_TMP2}")
+        else:
+            emit(f"s_add_u32 s{sp}, s{sp}, {HALF * 4}")
+        emit(f"s_addc_u32 s{sp + 1}, s{sp + 1}, 0")
+
+    def issue_resid(u):
+        i = u >> 1
+        for r in range(4):
+            m = S_MASK + 2 * (4 * i + r)
+            b = RS[u & 1][r]
+            emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")
+            emit(f"global_load_dwordx4 v[{b}:{b + 3}], v{V_G[r]}, s[{S_RB}:{S_RB + 1}]")
+            q.issue(("R", u))
+        emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+        advance(S_RB, u)
+
+    def load_params(j, st):
+        emit(f"ds_read_b128 v[{EA[st]}:{EA[st] + 3}], v{V_PAR} offset:{j * 64}")
+        emit(f"ds_read_b128 v[{EA[st] + 4}:{EA[st] + 7}], v{V_PAR} offset:{4 * BN + j * 64}")
+
+    def convert(u):
+        i, h = u >> 1, u & 1
+        js = list(range(4 * h, 4 * h + 4))
+        load_params(js[0], 0)
+        for n, j in enumerate(js):
+            st = n & 1
+            if n + 1 < len(js):
+                load_params(js[n + 1], 1 - st)
+                emit("s_waitcnt lgkmcnt(2)")
+            else:
+                emit("s_waitcnt lgkmcnt(0)")
+            regs = [accr(i, j, e) for e in range(4)]
+            for e, x in enumerate(regs):
+                emit(f"v_cvt_f32_i32 {x}, {x}")
+            for e, x in enumerate(regs):
+                emit(f"v_fma_f32 {x}, {x}, v{EA[st] + e}, v{EA[st] + 4 + e}")
+            for x in regs:
+                emit(f"v_rndne_f32 {x}, {x}")
+            for x in regs:
+                emit(f"v_add_f32 {x}, %[oo], {x}")
+            for x in regs:
+                emit(f"v_med3_f32 {x}, {x}, v{V_QMIN}, v{V_QMAX}")
+            for x in regs:
+                emit(f"v_subrev_f32 {x}, %[oo], {x}")
+            for x in regs:
+                emit(f"v_mul_f32 {x}, %[so], {x}")
+            emit(f"ds_write_b128 v{V_STW}, {acc(i, j)} offset:{n * 64}")
+
+    issue_resid(0)
+    for u in range(4):
+        i = u >> 1
+        if u:
+            emit("s_nop 2")                                                  # the stores of unit u - 1 have taken their data (D = the parameter registers)
+        convert(u)
+        if u + 1 < 4 and u == 0:
+            issue_resid(1)                                                   # set 1 = accumulators unit 0 has just released
+        for r in range(4):
+            emit(f"ds_read_b128 v[{D[r]}:{D[r] + 3}], v{V_RDB} offset:{r * 4 * ROWP}")
+        emit("s_waitcnt lgkmcnt(0)")
+        q.wait_for(("R", u))
+        for r in range(4):
+            b = RS[u & 1][r]
+            for e in range(4):
+                emit(f"v_add_f32 v{D[r] + e}, v{b + e}, v{D[r] + e}")
+        for r in range(4):
+            m = S_MASK + 2 * (4 * i + r)
+            emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")
+            emit(f"global_store_dwordx4 v{V_G[r]}, v[{D[r]}:{D[r] + 3}], s[{S_OB}:{S_OB + 1}] nt")
+            q.issue(("S", u))
+        emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+        advance(S_OB, u)
+        if u + 2 < 4:
+            issue_resid(u + 2)                                               # its register set was consumed by the adds above
     emit("s_waitcnt vmcnt(0)")
 
 
@@ -451,12 +618,20 @@ def program(nw, stamp):
     for t in range(4, 8):
         stage(q, t, nw, kt=KT, sym=f"KT-{KT - t}")
     assert q.q == [], q.q
-    epilogue(stamp)
+    if EPI == "u8":
+        epilogue(stamp)
+    else:
+        assert not stamp
+        epilogue_f32r()
     return q
 
 
 def generate(stamp=False):
     emit("; generated by tools/gen_fr_asm.py -- do not edit")
+    if (BN // 8) % NW == 0:          # every wave owns the same number of W pieces: one program
+        program(BN // 8 // NW, stamp)
+        return
+    assert BN == 176 and NW == 8
     l6, lend = label("w2"), label("done")
     emit("s_cmp_lt_u32 %[wave], 6")
     emit(f"s_cbranch_scc0 {l6}")
@@ -467,25 +642,31 @@ def generate(stamp=False):
     emit(f"{lend}:")
 
 
-def main(path=None):
-    stamp = bool(os.environ.get("MQ_FR_STAMP"))
+def main(path=None, variant="fr"):
+    configure(variant)
+    del out[:]
+    _uid[0] = 0
+    stamp = bool(os.environ.get("MQ_FR_STAMP")) and variant == "fr"
     generate(stamp)
     here = os.path.dirname(os.path.abspath(__file__))
-    path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", "mq_gemm_fr_asm.inc")
-    vregs = [f'"v{r}"' for r in list(range(0, 88)) + list(range(V_T, 128))]
-    aregs = [f'"a{r}"' for r in range(0, 120)]
-    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4)]
+    path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", FILE)
+    # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
+    vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(V_T if BN == 176 else 78, 128))]
+    aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32)]
+    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)]
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")
-        f.write(f"#define MQ_FR_ASM_STAMP {1 if stamp else 0}\n")
-        f.write(f"#define MQ_FR_LDS_BYTES {LDS_BYTES}\n")
-        f.write("#define MQ_FR_ASM_BODY \\\n")
+        f.write(f"#define {PREFIX}_ASM_STAMP {1 if stamp else 0}\n")
+        f.write(f"#define {PREFIX}_LDS_BYTES {LDS_BYTES}\n")
+        f.write(f"#define {PREFIX}_ASM_BODY \\\n")
         for line in out:
             f.write('  "%s\\n\\t" \\\n' % line.replace('"', '\\"'))
         f.write('  ""\n')
-        f.write("#define MQ_FR_ASM_CLOBBERS " + ", ".join(vregs + aregs + sregs + ['"vcc"', '"scc"', '"memory"']) + "\n")
+        f.write(f"#define {PREFIX}_ASM_CLOBBERS " + ", ".join(vregs + aregs + sregs + ['"vcc"', '"scc"', '"memory"']) + "\n")
     print("wrote", os.path.normpath(path), len(out), "instructions/labels")
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    for v in (sys.argv[1:] or list(VARIANTS)):
+        main(variant=v)
