@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--calib-layers", type=int, default=22, help="--workload calibration: decoder layers (TinyLlama-1.1B: 22)")
     p.add_argument("--calib-seq", type=int, default=2048, help="--workload calibration: tokens per sample")
     p.add_argument("--per-channel", action="store_true", help="--workload calibration: per-channel statistics")
+    p.add_argument("--calib-stub-gemm", action="store_true",
+                   help="--workload calibration: every Linear / FMatMul returns a resident tensor of its output shape instead of running the "
+                        "fp32 library GEMM, so the timed region is the hot path (hooked reductions + the collective), not rocBLAS")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--headline-only", action="store_true", help="only the timed steps and the roofline leg (profiler passes)")
@@ -655,7 +658,29 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
     return res
 
 
-def calibration_run(dev, rank, world, layers, n_samples, seq, per_channel):
+def _stub_gemms(model):
+    """Replaces the forward of every nn.Linear and FMatMul by 'return a resident tensor of the output's shape' (one buffer per shape,
+    N(0, 1) values, allocated at first use).  The hooks still receive -- and fully read -- inputs and outputs of the real shapes; what
+    disappears is the fp32 library GEMM time, which is not this package's code.  Statistics are no longer those of the model."""
+    import types
+    from mobilequant_amd.quantization.fp_ops import FMatMul
+    pool = {}
+
+    def buf(shape, dev):
+        key = (tuple(shape), str(dev))
+        if key not in pool:
+            pool[key] = torch.randn(shape, device=dev)
+        return pool[key]
+
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.forward = types.MethodType(lambda self, x: buf(tuple(x.shape[:-1]) + (self.out_features,), x.device), m)
+        elif isinstance(m, FMatMul):
+            m.forward = types.MethodType(lambda self, a, b: buf(tuple(a.shape[:-1]) + (b.shape[-1],), a.device), m)
+    return pool
+
+
+def calibration_run(dev, rank, world, layers, n_samples, seq, per_channel, stub_gemm=False):
     """ptq/generate_act_range.py:49-122 data-parallel: every rank holds the same random-init TinyLlama-shaped fp32 model
     (mobilequant_amd/llama.py: the reference's leaf-module graph incl. the two FMatMuls), runs samples rank, rank + world, ...
     through it with the min/max hooks attached (one single-pass HIP reduction per hooked tensor, device-resident running
@@ -666,6 +691,8 @@ def calibration_run(dev, rank, world, layers, n_samples, seq, per_channel):
     model = LlamaForCausalLM(shape)
     model.reset_parameters(seed=1337)                      # identical weights on every rank
     model = model.to(dev).eval()
+    if stub_gemm:
+        _stub_gemms(model)
     g = torch.Generator().manual_seed(1337)
     pool = min(n_samples, 16)
     ids = torch.randint(3, shape.vocab, (pool, seq), generator=g).to(dev)      # ids as harness_eval draws them
@@ -717,10 +744,27 @@ def bench_minmax(dev, seq):
 
 def bench_calibration(args, rank, world, dev):
     """BASELINE.json configs[4]: generate_act_range over 512 calibration samples, data-parallel with one RCCL all-reduce."""
-    r = calibration_run(dev, rank, world, args.calib_layers, args.calib_samples, args.calib_seq, args.per_channel)
+    r = calibration_run(dev, rank, world, args.calib_layers, args.calib_samples, args.calib_seq, args.per_channel, args.calib_stub_gemm)
     if rank != 0:
         return
     mm = bench_minmax(dev, args.calib_seq)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the oracle's running min / max (oracle/mq_oracle.py: compute_min_max_from_tensor + update_act_range) over a bounded sample of
+        # the hooked bytes; samples/s = rate / hooked bytes per sample
+        import numpy as np
+        from oracle import mq_oracle as O
+        x = np.random.default_rng(0).standard_normal((4 * args.calib_seq, args.calib_seq), dtype=np.float32)
+        orc = O.ActRangeOracle(args.per_channel)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0:
+            orc.update("qk_bmm", "output", x)
+            n += 1
+        rate = n * x.nbytes / (time.perf_counter() - t0)
+        cpu = {"value": round(rate / max(r["hooked_bytes_per_sample"], 1), 5), "unit": "samples/s", "cores": 1, "kind": "port",
+               "GBps": round(rate / 1e9, 2),
+               "sample": f"{n} ActRangeOracle.update calls (oracle/mq_oracle.py, numpy) over a [{4 * args.calib_seq}, {args.calib_seq}] fp32 tensor (~10 s); "
+                         "samples/s = bytes/s / hooked bytes per sample (reductions only, no model forward)"}
     big = mm["qk_bmm.output [1,32,S,S]"]
     key = "minmax_cols" if args.per_channel else "minmax_tensor"
     achieved = big["bytes"] / (big[key + "_us"] * 1e-6) / 1e9
@@ -739,7 +783,8 @@ def bench_calibration(args, rank, world, dev):
                                f"TinyLlama-1.1B-shaped decoder ({args.calib_layers} layers, hidden 2048, 32/4 heads, FFN 5632; hooks on every "
                                "Linear / HFRMSNorm / SiLU / FMatMul leaf), " + ("per-channel" if args.per_channel else "per-tensor")
                                + " running [min, max], round-robin shards", "parallelism": f"dp{world}", "collectives": r["collectives"],
-                   "tensors_tracked": r["tensors"], "device": info},
+                   "tensors_tracked": r["tensors"], "device": info,
+                   "gemms": "stubbed (resident output tensors; --calib-stub-gemm)" if args.calib_stub_gemm else "fp32 library GEMMs (rocBLAS)"},
         "roofline": {"bound": "hbm", "kernel": f"mq::{key}_kernel on the [32*S, S] attention scores (the largest hooked tensor)",
                      "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                      "algorithmic_bytes_per_launch": big["bytes"], "traffic": None, "per_tensor_shapes": mm},
@@ -747,7 +792,7 @@ def bench_calibration(args, rank, world, dev):
                       "model_ms_per_sample (fp32 library GEMMs, softmax: not the hot path)": round(1e3 * r["model_seconds_per_sample"], 3),
                       "reduction_ms_per_sample": round(1e3 * r["reduction_seconds_per_sample"], 3),
                       "reduction_GBps": round(r["hooked_bytes_per_sample"] / max(r["reduction_seconds_per_sample"], 1e-9) / 1e9, 1)},
-        "cpu_baseline": None}))
+        "cpu_baseline": cpu}))
 
 
 def bench_model_prefill(dev):
