@@ -356,7 +356,8 @@ def cpu_baseline():
                                 "mixed-precision rules of ptq/mobilequant.py:175-201) at S=2048"}}
 
 
-def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", wsym=False, wpc=None):
+def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", wsym=False, wpc=None, cache_len=1024, attn_splits=None,
+                      contexts=None):
     """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
     model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
     one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
@@ -396,7 +397,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
             if "pv_bmm" in name:
                 mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    eng = DecodeEngine(model, cache_len=1024)
+    eng = DecodeEngine(model, cache_len=cache_len, attn_splits=attn_splits)
     for p in model.parameters():                            # the float weights of the decoder layers are no longer needed
         if p.dim() == 2 and p.shape[0] != shape.vocab:
             p.data = torch.empty(0, device=dev)
@@ -407,17 +408,23 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
     for _ in range(3):
         eng.step()
     torch.cuda.synchronize()
-    best = float("inf")
-    for _ in range(3):
-        eng.set_position(context)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            eng.graph.replay()
-        e1.record()
-        e1.synchronize()
-        best = min(best, e0.elapsed_time(e1) / steps)
-    t = best * 1e-3
+    def timed_at(ctx):
+        graph = eng.graph_long if eng.graph_long is not None and ctx >= eng.LONG_FROM else eng.graph      # what step() replays there
+        best = float("inf")
+        for _ in range(3):
+            eng.set_position(ctx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                graph.replay()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / steps)
+        return best
+    if contexts:                                            # sweep (tools/decode_context_sweep.py): ms per token at each context
+        eng.fill_cache_random(max(contexts))
+        return {c: round(timed_at(c), 4) for c in contexts}
+    t = timed_at(context) * 1e-3
     kv_bytes = shape.layers * 2 * shape.kv_heads * (context + steps // 2) * shape.head_dim      # int8 indices
     total = eng.weight_bytes + eng.head_bytes + kv_bytes
     return {"decode_tok_s": round(1.0 / t, 1), "ms_per_token": round(t * 1e3, 4), "context": context,

@@ -90,6 +90,8 @@ class _Linear:
 
 
 class DecodeEngine:
+    LONG_FROM, LONG_SPLITS = 768, 4
+
     def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5):
         from .llama import LlamaForCausalLM
         assert isinstance(model, LlamaForCausalLM)
@@ -101,10 +103,13 @@ class DecodeEngine:
         self.x = torch.zeros(s.hidden, device=dev)
         self.qkv = torch.zeros((s.heads + 2 * s.kv_heads) * s.head_dim, device=dev)
         self.attn_q = torch.zeros(s.heads * s.head_dim, dtype=torch.int8, device=dev)     # pv_bmm's output as o_proj's int8 image
-        # workgroups per head in the attention launch (64-position blocks interleaved over them)
+        # workgroups per head in the attention launch (64-position blocks interleaved over them).  None = by position: one workgroup
+        # per head while the cache is short (the ticket-ordered combine of a split launch costs ~3 us), LONG_SPLITS of them from
+        # LONG_FROM cached positions on, where the sweeps over the cache outweigh it (measured crossover)
+        self.auto_splits = attn_splits is None
         self.attn_splits = int(attn_splits) if attn_splits else 1
         assert 1 <= self.attn_splits <= 16
-        self.attn_part = torch.zeros(self.attn_splits, s.heads * s.head_dim, dtype=torch.int64, device=dev)
+        self.attn_part = torch.zeros(max(self.attn_splits, self.LONG_SPLITS), s.heads * s.head_dim, dtype=torch.int64, device=dev)
         self.attn_ticket = torch.zeros(s.heads, dtype=torch.int32, device=dev)
         self.gate_q = torch.zeros(s.ffn, dtype=torch.int8, device=dev)
         self.logits = torch.zeros(s.vocab, device=dev)
@@ -146,6 +151,7 @@ class DecodeEngine:
         self.weight_bytes = sum(p[1]._mq_bytes for p in self.phases if p[0] == "gemv")
         self.head_bytes = self.lm_w.numel() * 4
         self.graph = None
+        self.graph_long = None
 
     # -- lowering ----------------------------------------------------------------------------------------------------------
     def _norm_args(self, norm, a: MqDecodeGemvArgs):
@@ -268,23 +274,37 @@ class DecodeEngine:
                   int(self.norm_ln), float(self.model.norm.eps), self.lm_w.data_ptr(),
                   self.lm_b.data_ptr() if self.lm_b is not None else None, self.shape.hidden, self.shape.vocab, self.logits.data_ptr(), st)
 
+    def _set_splits(self, n: int):
+        for kind, a in self.phases:
+            if kind != "gemv":
+                a.nsplit = int(n)
+
+    def _splits_at(self, pos: int) -> int:
+        return self.LONG_SPLITS if self.auto_splits and pos >= self.LONG_FROM else self.attn_splits
+
     def capture(self):
-        """Record one decode step (incl. the position increment) as a hipGraph; replay it with step()."""
+        """Record one decode step (incl. the position increment) as a hipGraph; replay it with step().  With attn_splits=None and a
+        cache longer than LONG_FROM a second graph with the split attention launch is recorded; step() picks by position."""
         tok0, pos0, hp0 = self.tok.clone(), self.pos.clone(), self._host_pos
-        self.attn_ticket.zero_()
-        with torch.cuda.device(self.dev):
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self._launch()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch()
-                self.pos.add_(1)
-        self.tok.copy_(tok0); self.pos.copy_(pos0)
+        graphs = []
+        for splits in ([self.attn_splits, self.LONG_SPLITS] if self.auto_splits and self.cache_len > self.LONG_FROM else [self.attn_splits]):
+            self._set_splits(splits)
+            self.attn_ticket.zero_()
+            with torch.cuda.device(self.dev):
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._launch()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch()
+                    self.pos.add_(1)
+            graphs.append(g)
+            self.tok.copy_(tok0); self.pos.copy_(pos0)
+        self._set_splits(self.attn_splits)
         self._host_pos = hp0
-        self.graph = g
+        self.graph, self.graph_long = graphs[0], (graphs[1] if len(graphs) > 1 else None)
         return self
 
     def set_position(self, pos: int):
@@ -315,8 +335,9 @@ class DecodeEngine:
         if token is not None:
             self.tok.fill_(int(token))
         if self.graph is not None:
-            self.graph.replay()
+            (self.graph_long if self.graph_long is not None and self._host_pos >= self.LONG_FROM else self.graph).replay()
         else:
+            self._set_splits(self._splits_at(self._host_pos))
             with torch.cuda.device(self.dev):
                 self._launch()
             self.pos.add_(1)

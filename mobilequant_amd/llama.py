@@ -180,7 +180,7 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         M, K = B * S, s.heads * 64
         probe = Q._tag_grid(torch.empty(1, dtype=torch.float32, device=x.device).expand(B, S, K), oq)
         w_o = o_proj._effective_weight(o_proj.weight)
-        if (o_proj.input_quantizer is None and o_proj._int8_ready(probe, w_o) and o_proj.weight_quantizer.qcfg.bitwidth == 8
+        if (o_proj.input_quantizer is None and o_proj._int8_ready(probe, w_o) and not o_proj._weight_plan(w_o)["w4"]
                 and M > 8 and o_proj._activation_grid(probe) is oq):
             tiled = ops.gemm_tiled_supported(M, w_o.shape[0], K) or (
                 resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and not o_proj._weight_plan(w_o)["w4"]
