@@ -576,7 +576,7 @@ def bench_layer(dev):
     return res
 
 
-def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits=8):
+def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits=8, family="tinyllama"):
     """ONE whole TinyLlama decoder layer at prefill (B = 1, S = 2048) on the reference's module graph (mobilequant_amd/llama.py:
     norms, q/k/v/o, RoPE, qk_bmm / pv_bmm QMatMuls, softmax, gated FFN, residual adds), W8A8 recipe of ptq/mobilequant.py:175-201,
     ranges from this package's own calibration pass over the fp32 layer.  hipGraph time with (a) everything fused (fuse_attention:
@@ -587,7 +587,7 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
     from mobilequant_amd.calibration import get_act_range
     from mobilequant_amd.quantization import qmodule as Q
     S = 2048
-    shape = llama.LlamaShape.tinyllama(layers=1, max_pos=S, vocab=4096)
+    shape = getattr(llama.LlamaShape, family)(layers=1, max_pos=S, vocab=4096)
     model = llama.LlamaForCausalLM(shape)
     model.reset_parameters(seed=1337, std=0.05)
     model = model.to(dev).eval().requires_grad_(False)
@@ -603,7 +603,7 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
             mod.output_quantizer.qcfg.bitwidth = 16
         elif isinstance(mod, mq.QLinear) and "o_proj" in name:
             mod.output_quantizer.qcfg.bitwidth = 16
-        elif isinstance(mod, mq.QRMSNorm):
+        elif isinstance(mod, (mq.QRMSNorm, mq.QLayerNorm)):
             mod.input_quantizer.qcfg.bitwidth = 16
             mod.weight_quantizer.qcfg.bitwidth = 16
         elif isinstance(mod, mq.QMatMul) and "qk_bmm" in name:
@@ -646,8 +646,11 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
             layer(x, cos, sin, mask)
     finally:
         _ops.attention_quant = real
-    (a_args, a_kw), = rec
-    res["attention_op_us"] = round(event_time(lambda: real(*a_args, **a_kw), 5) * 1e6, 1)
+    if rec:                                    # (head_dim != 64: the attention runs as its module chain, no fused op to time)
+        (a_args, a_kw), = rec
+        res["attention_op_us"] = round(event_time(lambda: real(*a_args, **a_kw), 5) * 1e6, 1)
+    else:
+        res["attention_op_us"] = None
     if "fused" in outs and "attention_chain" in outs:
         span = float(outs["attention_chain"].max() - outs["attention_chain"].min())
         res["fused_vs_chain_max_over_span"] = round(float((outs["fused"] - outs["attention_chain"]).abs().max()) / span, 5)
@@ -660,8 +663,9 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
     if "fused_us" in res:
         res["tops_fused"] = round((ops_lin + ops_att) / (res["fused_us"] * 1e-6) / 1e12, 1)
         res["frac_of_int8_peak"] = round(res["tops_fused"] / INT8_MFMA_PEAK_TOPS, 4)
-        res["launches_per_layer"] = 9      # 4-bit weights run the same int8 kernels on their one-byte-per-nibble image
-    res["scope"] = f"one whole TinyLlama decoder layer, B = 1, S = 2048, W{wbits}A8 recipe, module API, hipGraph"
+        if rec:
+            res["launches_per_layer"] = 9      # 4-bit weights run the same int8 kernels on their one-byte-per-nibble image
+    res["scope"] = f"one whole {family} decoder layer, B = 1, S = 2048, W{wbits}A8 recipe, module API, hipGraph"
     return res
 
 
@@ -938,6 +942,9 @@ def bench_variants(dev, step, args):
     extras["layer_prefill_full"] = bench_layer_full(dev)
     torch.cuda.empty_cache()
     extras["layer_prefill_full_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4)     # packed 4-bit per-channel weights
+    # BASELINE.json configs[2] / [3] on their own leaf graphs (LayerNorm + biased q|k|v + 25 % rotary; head_dim 256 / MQA / GeGLU / FFN 16384)
+    extras["layer_prefill_full_stablelm_2_1_6b"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=8, family="stablelm_2_1_6b")
+    extras["layer_prefill_full_gemma_2b_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4, family="gemma_2b")
     torch.cuda.empty_cache()
     extras["other_configs"] = bench_other_configs(dev)
     torch.cuda.empty_cache()

@@ -59,9 +59,9 @@ __device__ __forceinline__ float a_index_fast(float x, const AGrid& g) {
 
 // ---- prep: RoPE + input quantizers -> integer images ----------------------------------------------------------------------------
 // grid: (S / 64, H + 2 KV).  Block b of part p: rows s = 64 b .. 64 b + 63.  256 threads: thread (r = tid >> 2, c = tid & 3) handles
-// row r, 16 columns 16 c .. 16 c + 15  (D = 64).
+// row r, 16 columns 64 dc + 16 c .. + 15 of every 64-column slab dc (D = 64: one slab; D = 256: four).
+template <int D>
 __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_args a) {
-  const int D = 64;
   const int H = a.heads, KV = a.kv_heads, S = a.seq;
   const int part = blockIdx.y;                       // [0, H): q head; [H, H+KV): k head; [H+KV, H+2KV): v head
   const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
@@ -89,12 +89,16 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = __fmul_rn(__fsub_rn((float)((w4[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
   };
-  float x[16];
-  if (isrc) load16_idx(isrc + 16 * c, x);
-  else load16(src + 16 * c, x);
   const AGrid g = a_load_grid(is_q ? a.qk_a : (is_k ? a.qk_b : a.pv_b));
-  int st[16];
   const int rot = a.rot_dim > 0 ? a.rot_dim : D;
+  int sum = 0;
+#pragma unroll 1
+  for (int dc = 0; dc < D / 64; ++dc) {
+  const int col0 = 64 * dc + 16 * c;
+  float x[16];
+  if (isrc) load16_idx(isrc + col0, x);
+  else load16(src + col0, x);
+  int st[16];
   if ((is_q || is_k) && rot != D) {
     // partial rotary (hf_model.py:489-500; StableLM-2: 16 of 64 dims): dims d < rot rotate with partner d +- rot/2 and cos / sin
     // [S, rot]; the rest passes through.  Element-wise form (the full-rotary path below keeps its vector loads).
@@ -105,7 +109,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int d = 16 * c + i;
+      const int d = col0 + i;
       float y = x[i];
       if (d < rot) {
         const float p = one(d < half ? d + half : d - half);
@@ -116,11 +120,11 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     }
   } else if (is_q || is_k) {                          // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
     float pr[16], cs[16], sn[16];
-    if (isrc) load16_idx(isrc + ((16 * c + 32) & 63), pr);
-    else load16(src + ((16 * c + 32) & 63), pr);
-    load16(a.cos + (size_t)s * D + 16 * c, cs);
-    load16(a.sin + (size_t)s * D + 16 * c, sn);
-    const float sign = c < 2 ? -1.f : 1.f;            // (-x) * sin == -(x * sin) exactly
+    if (isrc) load16_idx(isrc + ((col0 + D / 2) & (D - 1)), pr);
+    else load16(src + ((col0 + D / 2) & (D - 1)), pr);
+    load16(a.cos + (size_t)s * D + col0, cs);
+    load16(a.sin + (size_t)s * D + col0, sn);
+    const float sign = col0 < D / 2 ? -1.f : 1.f;     // (-x) * sin == -(x * sin) exactly
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float y = __fadd_rn(__fmul_rn(x[i], cs[i]), __fmul_rn(sign * pr[i], sn[i]));
@@ -130,7 +134,6 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = (int)a_index_exact(x[i], g) - 128;
   }
-  int sum = 0;
   unsigned w[4];
 #pragma unroll
   for (int d4 = 0; d4 < 4; ++d4) {
@@ -143,15 +146,17 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     w[d4] = pk;
   }
   if (is_q || is_k) {
-    int8_t* dst = (is_q ? a.q_i8 + (size_t)head * S * D : a.k_i8 + (size_t)head * S * D) + (size_t)s * D + 16 * c;
+    int8_t* dst = (is_q ? a.q_i8 + (size_t)head * S * D : a.k_i8 + (size_t)head * S * D) + (size_t)s * D + col0;
     *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    // the zero-point terms of sum_d (qi - zq)(ki - zk) = sum qs ks - zq' rowsum(ks) - zk' rowsum(qs) + D zq' zk'  (primes: - 128)
-    const int zq = (int)a_load_grid(a.qk_a).o - 128, zk = (int)a_load_grid(a.qk_b).o - 128;
-    if (c == 0) {
-      if (is_q) a.q_rowsum[(size_t)head * S + s] = D * zq * zk - zk * sum;
-      else a.k_rowsum[(size_t)head * S + s] = -zq * sum;
+    if (dc == D / 64 - 1) {
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      // the zero-point terms of sum_d (qi - zq)(ki - zk) = sum qs ks - zq' rowsum(ks) - zk' rowsum(qs) + D zq' zk'  (primes: - 128)
+      const int zq = (int)a_load_grid(a.qk_a).o - 128, zk = (int)a_load_grid(a.qk_b).o - 128;
+      if (c == 0) {
+        if (is_q) a.q_rowsum[(size_t)head * S + s] = D * zq * zk - zk * sum;
+        else a.k_rowsum[(size_t)head * S + s] = -zq * sum;
+      }
     }
   } else {
     // vT [KV][S/64][D][64]: position kappa of key t (inside its 64-block): t = 16 j + 4 tq + e  <->  kappa = 16 tq + 4 j + e
@@ -161,15 +166,46 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     // thread (d = tid >> 2, quarter c): 16 kappa = 16 c .. 16 c + 15  -> tq = c, (j, e) = (i >> 2, i & 3) -> t = 16 j + 4 c + e
     const int d = threadIdx.x >> 2;
     unsigned o4[4];
+    int csum = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned pk = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pk |= ((unsigned)s_v[d][16 * j + 4 * c + e] & 0xffu) << (8 * e);
+      for (int e = 0; e < 4; ++e) {
+        const int vv = s_v[d][16 * j + 4 * c + e];
+        csum += vv;
+        pk |= ((unsigned)vv & 0xffu) << (8 * e);
+      }
       o4[j] = pk;
     }
-    int8_t* dst = a.vt_i8 + (((size_t)head * (S >> 6) + blockIdx.x) * D + d) * 64 + 16 * c;
+    int8_t* dst = a.vt_i8 + (((size_t)head * (S >> 6) + blockIdx.x) * D + 64 * dc + d) * 64 + 16 * c;
     *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    if constexpr (D > 64) {                            // column sums of the stored values over this block's 64 keys (prefix-summed below)
+      csum += __shfl_xor(csum, 1, 64);
+      csum += __shfl_xor(csum, 2, 64);
+      if (c == 0) a.v_prefix[((size_t)head * (S >> 6) + blockIdx.x) * D + 64 * dc + d] = csum;
+      __syncthreads();                                 // s_v is rewritten by the next slab
+    }
+  }
+  }   // slabs
+}
+
+// head_dim > 64: v_prefix[kv][kb][d] <- sum over blocks 0 .. kb of the per-block column sums (the core kernel needs sum_t v[t][d] over
+// the keys it processed; with one extra all-ones MFMA per block it would also need D / 4 more accumulator registers per lane)
+__global__ void __launch_bounds__(256) attention_vprefix_kernel(int32_t* __restrict__ v_prefix, int nblk, int D) {
+  const int d = blockIdx.y * 256 + threadIdx.x;
+  if (d >= D) return;
+  int32_t* p = v_prefix + (size_t)blockIdx.x * nblk * D + d;
+  int run = 0;
+  for (int kb0 = 0; kb0 < nblk; kb0 += 32) {            // 32 independent loads in flight, then the scan in registers
+    int v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = kb0 + i < nblk ? p[(size_t)(kb0 + i) * D] : 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      run += v[i];
+      if (kb0 + i < nblk) p[(size_t)(kb0 + i) * D] = run;
+    }
   }
 }
 
@@ -183,9 +219,15 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <bool QK_OUT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) attention_quant_kernel(const mq_attention_args a) {
-  const int D = 64;
+// D = 64: the tuned kernel (three waves per SIMD).  D = 256 (Gemma: 8 heads / 1 KV head): four MFMA k-steps per score tile, 16 output
+// d-tiles (128 accumulator registers: one wave per SIMD), v tiles loaded per d-tile, and sum_t v[t][d] from the prep kernel's prefix
+// sums instead of an all-ones MFMA.
+template <int D, bool QK_OUT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 1, D == 64 ? 3 : 1)))
+    attention_quant_kernel(const mq_attention_args a) {
+  static_assert(D == 64 || D == 256, "head_dim 64 or 256 (1 / sqrt(D) a power of two)");
+  constexpr int NKS = D / 64, NDT = D / 16;
+  constexpr float kInvSqrtD = D == 64 ? 0.125f : 0.0625f;
   const int S = a.seq, H = a.heads, KV = a.kv_heads;
   // Work per workgroup is proportional to qb + 1 (causal).  The hardware hands out workgroups in id order to whichever slot frees
   // up, so the ids run over ALL heads of the longest query block first, then the next block, ...: a longest-first list schedule.
@@ -201,13 +243,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const int zv = (int)gpb.o - 128, zp = (int)gpa.o;
   const float alpha_qk = __fmul_rn(gqa.s, gqb.s);
   // scores: QK_OUT: f = magic + index on the 16-bit grid; value = (index - o) * s / 8.   else: f = ti * alpha / 8 (the value itself)
-  const float beta = QK_OUT ? alpha_qk * gqo.inv_s : alpha_qk * 0.125f;
+  const float beta = QK_OUT ? alpha_qk * gqo.inv_s : alpha_qk * kInvSqrtD;
   const float fbias = QK_OUT ? gqo.o + kMagic : 0.f;
   const float flo = kMagic + gqo.qmin, fhi = kMagic + gqo.qmax;
-  const float cexp = QK_OUT ? gqo.s * 0.125f * kLog2e : kLog2e;     // exp(value - max) = exp2((f - fmax) * cexp)
+  const float cexp = QK_OUT ? gqo.s * kInvSqrtD * kLog2e : kLog2e;  // exp(value - max) = exp2((f - fmax) * cexp)
 
   const int8_t* qbase = a.q_i8 + ((size_t)h * S + (size_t)qb * 64 + wave * 16) * D;
-  const v4i qf = *reinterpret_cast<const v4i*>(qbase + srow * D + tq * 16);
+  v4i qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qbase + srow * D + ks * 64 + tq * 16);
   const int qconst = a.q_rowsum[(size_t)h * S + s_abs];             // D zq zk - zk * rowsum(q), from the prep kernel
   const int8_t* kbase = a.k_i8 + (size_t)kvh * S * D;
   const int* kterm = a.k_rowsum + (size_t)kvh * S;                  // -zq * rowsum(k)
@@ -215,15 +259,57 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const v4i cinit = {qconst, qconst, qconst, qconst};
 
   struct KTile {
-    v4i kf[4];
+    v4i kf[4][NKS];
     int4 kt[4];
   };
   auto load_k = [&](int kb, KTile& t) {
     const int8_t* kp = kbase + (size_t)kb * 64 * D;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t.kf[j] = *reinterpret_cast<const v4i*>(kp + (16 * j + srow) * D + tq * 16);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) t.kf[j][ks] = *reinterpret_cast<const v4i*>(kp + (16 * j + srow) * D + ks * 64 + tq * 16);
       t.kt[j] = *reinterpret_cast<const int4*>(kterm + kb * 64 + 16 * j + 4 * tq);
+    }
+  };
+  // D = 256: a key block's K tile (16 KiB) and vT tile (16 KiB) do not fit the 32-KiB L1 next to each other, so four waves loading
+  // them privately miss four times (measured: 183 us at 8 heads x S = 2048, L2-bound).  Instead the workgroup stages ONE copy per
+  // block in the LDS by LDS-DMA, fragment-blocked: fragment f (K: f = 4 j + ks, 16 keys x 64 d;  vT: f = dt, 16 d x 64 keys) is the
+  // 1-KiB block whose lane l holds exactly the 16 bytes lane l feeds the MFMA -- conflict-free ds_read_b128, and the DMA's lane-linear
+  // destination is that layout when every lane sources its own fragment bytes.  Two buffers, one barrier per block.
+  constexpr int kTileBytes = D == 64 ? 16 : 32 * 1024;               // K fragments [0, 16 KiB) | vT fragments [16 KiB, 32 KiB)
+  __shared__ __attribute__((aligned(16))) char s_tile[2][kTileBytes];
+  const int8_t* vbase = a.vt_i8 + (size_t)kvh * (S >> 6) * D * 64;
+  auto dma_block = [&](int kb, int buf, bool with_v) {
+    if constexpr (D != 64) {
+      const int8_t* kp = kbase + (size_t)kb * 64 * D;
+      const int8_t* vp = vbase + (size_t)kb * D * 64;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = 4 * wave + u;                                  // this wave's four K fragments (j = wave, ks = u) ...
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + (16 * (f >> 2) + srow) * D + (f & 3) * 64 + tq * 16),
+                                         (__attribute__((address_space(3))) void*)(s_tile[buf] + f * 1024), 16, 0, 0);
+      }
+      if (with_v) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int f = 4 * wave + u;                                // ... and four vT fragments (dt = f)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + (16 * f + srow) * 64 + tq * 16),
+                                           (__attribute__((address_space(3))) void*)(s_tile[buf] + 16384 + f * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
+  auto block_ready = []() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto int_scores_lds = [&](int kb, int buf, int (&ti)[16]) {
+    const char* tb = s_tile[buf] + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int4 kt = *reinterpret_cast<const int4*>(kterm + kb * 64 + 16 * j + 4 * tq);
+      v4i acc = cinit;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i*>(tb + (4 * j + ks) * 1024), qf[ks], acc, 0, 0, 0);
+      ti[4 * j] = acc[0] + kt.x; ti[4 * j + 1] = acc[1] + kt.y; ti[4 * j + 2] = acc[2] + kt.z; ti[4 * j + 3] = acc[3] + kt.w;
     }
   };
   // integer scores of this lane's row against keys t = 64 kb + 16 j + 4 tq + e: sum_d (qi - zq)(ki - zk), exact (< 2^24).  After this
@@ -232,7 +318,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   auto int_scores = [&](const KTile& t, int (&ti)[16]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(t.kf[j], qf, cinit, 0, 0, 0);
+      v4i acc = cinit;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(t.kf[j][ks], qf[ks], acc, 0, 0, 0);
       ti[4 * j] = acc[0] + t.kt[j].x; ti[4 * j + 1] = acc[1] + t.kt[j].y; ti[4 * j + 2] = acc[2] + t.kt[j].z; ti[4 * j + 3] = acc[3] + t.kt[j].w;
     }
   };
@@ -287,7 +375,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     for (int i = 0; i < 16; ++i) bs += fast_exp2(__builtin_fmaf(f[i], cexp, -R));
     l += bs;
   };
-  {
+  if constexpr (D != 64) {
+    if (fixed_ref) R = fhi * cexp;
+    dma_block(0, 0, false);
+    for (int kb = 0; kb < nkb; ++kb) {
+      block_ready();                                               // block kb landed (everyone's pieces); buffer (kb + 1) & 1 is free
+      if (kb + 1 < nkb) dma_block(kb + 1, (kb + 1) & 1, false);
+      int ti[16];
+      int_scores_lds(kb, kb & 1, ti);
+      if (fixed_ref) sweep1_fixed(ti, kb);
+      else sweep1(ti, kb);
+    }
+    if (fixed_ref) {
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    __syncthreads();                                               // sweep 2 starts over in buffer 0
+  } else {
     KTile t;
     load_k(0, t);
     if (fixed_ref) {
@@ -314,12 +418,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const float pbias = gpa.o + kMagic, plo = kMagic + gpa.qmin, phi = kMagic + gpa.qmax;
 
   // ---- sweep 2: probabilities on their 16-bit grid, integer p.v ------------------------------------------------------------------
-  v4i acc_hi[4], acc_lo[4], acc_v[4];                               // acc_v: column sums of the stored v over the processed keys -- one more
-#pragma unroll                                                      // MFMA against an all-ones tile (the MFMA pipe idles, the VALU does not)
-  for (int dt = 0; dt < 4; ++dt) acc_hi[dt] = acc_lo[dt] = acc_v[dt] = v4i{0, 0, 0, 0};
+  v4i acc_hi[NDT], acc_lo[NDT], acc_v[D == 64 ? NDT : 1];          // acc_v (D = 64): column sums of the stored v over the processed keys -- one
+#pragma unroll                                                      // more MFMA against an all-ones tile (the MFMA pipe idles, the VALU does not)
+  for (int dt = 0; dt < NDT; ++dt) acc_hi[dt] = acc_lo[dt] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int dt = 0; dt < (D == 64 ? NDT : 1); ++dt) acc_v[dt] = v4i{0, 0, 0, 0};
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   unsigned psum_hi = 0, psum_lo = 0;                                // sums of the unsigned high / low bytes (this lane's share)
-  const int8_t* vbase = a.vt_i8 + (size_t)kvh * (S >> 6) * D * 64;
   struct VTile {
     v4i vf[4];
   };
@@ -348,7 +453,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
   };
-  {
+  if constexpr (D == 64) {
     KTile t;
     VTile vt;
     load_k(0, t);
@@ -367,6 +472,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
       }
       if (kb + 1 < nkb) load_v(kb + 1, vt);
     }
+  } else {
+    dma_block(0, 0, true);
+    for (int kb = 0; kb < nkb; ++kb) {
+      block_ready();
+      if (kb + 1 < nkb) dma_block(kb + 1, (kb + 1) & 1, true);
+      int ti[16];
+      int_scores_lds(kb, kb & 1, ti);
+      v4i pf_hi, pf_lo;
+      probs(ti, kb, pf_hi, pf_lo);
+      const char* vb = s_tile[kb & 1] + 16384 + lane * 16;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const v4i vf = *reinterpret_cast<const v4i*>(vb + dt * 1024);
+        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_hi, acc_hi[dt], 0, 0, 0);
+        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_lo, acc_lo[dt], 0, 0, 0);
+      }
+    }
   }
   long long psum = 256ll * psum_hi + psum_lo;
   psum += __shfl_xor(psum, 16, 64);
@@ -378,12 +500,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   float* orow = a.out + (size_t)s_abs * H * D + (size_t)h * D;
   int rsum = 0;
   unsigned opk = 0;
+  const int32_t* vpre = D == 64 ? nullptr : a.v_prefix + ((size_t)kvh * (S >> 6) + (nkb - 1)) * D;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
+  for (int dt = 0; dt < NDT; ++dt) {
     float o4[4];
+    int4 vsum = {0, 0, 0, 0};
+    if constexpr (D != 64) vsum = *reinterpret_cast<const int4*>(vpre + 16 * dt + 4 * tq);
+    const int vs4[4] = {vsum.x, vsum.y, vsum.z, vsum.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long V = acc_v[dt][e];
+      const long long V = D == 64 ? acc_v[D == 64 ? dt : 0][e] : vs4[e];
       const long long tot = 256ll * acc_hi[dt][e] + (long long)acc_lo[dt][e] + 32896ll * V - (long long)zv * psum - (long long)zp * V +
                             (long long)zp * zv * nproc;
       const float pre = (float)((double)tot * (double)alpha_pv);
@@ -398,7 +524,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     // 16 * ((row & 15) + 16 * ((k & 63) >> 4)) + (k & 15), k & 63 = 16 dt + 4 tq + e
     if (a.out_i8 != nullptr && s_abs < a.seq_real) {
       const int64_t row = a.out_row0 + s_abs;
-      int8_t* dst = a.out_i8_tiled ? a.out_i8 + ((row >> 4) * H + h) * 1024 + 16 * ((row & 15) + 16 * dt) + 4 * tq
+      int8_t* dst = a.out_i8_tiled ? a.out_i8 + ((row >> 4) * (H * NKS) + h * NKS + (dt >> 2)) * 1024 + 16 * ((row & 15) + 16 * (dt & 3)) + 4 * tq
                                    : a.out_i8 + row * H * D + h * D + 16 * dt + 4 * tq;
       *reinterpret_cast<unsigned*>(dst) = opk;
     }
@@ -421,9 +547,11 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   MQ_REQUIRE(((a.q && a.k && a.v) || a.qkv_idx) && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.seq <= 65536, "mq_attention_quant: seq = %d exceeds 65536 (int32 accumulators of the p.v products)", a.seq);
-  MQ_REQUIRE(a.rot_dim >= 0 && a.rot_dim <= 64 && a.rot_dim % 2 == 0, "mq_attention_quant: rot_dim = %d (0 = head_dim; even, <= 64)", a.rot_dim);
-  MQ_REQUIRE(a.head_dim == 64 && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
-             "mq_attention_quant: head_dim 64, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
+  MQ_REQUIRE((a.head_dim == 64 || a.head_dim == 256) && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
+             "mq_attention_quant: head_dim 64 or 256, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
+  MQ_REQUIRE(a.rot_dim >= 0 && a.rot_dim <= a.head_dim && a.rot_dim % 2 == 0, "mq_attention_quant: rot_dim = %d (0 = head_dim; even, <= head_dim)", a.rot_dim);
+  MQ_REQUIRE(a.head_dim == 64 || (a.v_prefix != nullptr && aligned(a.v_prefix, 16)),
+             "mq_attention_quant: head_dim 256 needs the v_prefix scratch ([kv_heads][seq/64][head_dim] int32, 16-byte aligned)");
   MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmax == 255.f && a.qk_b.qmax == 255.f && a.pv_b.qmax == 255.f &&
                  a.qk_a.qmin == 0.f && a.qk_b.qmin == 0.f && a.pv_b.qmin == 0.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
              "mq_attention_quant: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
@@ -439,12 +567,20 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
                "0 < seq_real <= seq");
   }
   hipStream_t st = as_stream(stream);
-  attention_prep_kernel<<<dim3((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), 256, 0, st>>>(a);
-  MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
-  if (a.qk_out.scale != nullptr)
-    attention_quant_kernel<true><<<dim3((unsigned)(a.seq / 64 * a.heads)), 256, 0, st>>>(a);
-  else
-    attention_quant_kernel<false><<<dim3((unsigned)(a.seq / 64 * a.heads)), 256, 0, st>>>(a);
+  const dim3 pgrid((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), cgrid((unsigned)(a.seq / 64 * a.heads));
+  if (a.head_dim == 64) {
+    attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a);
+    MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
+    if (a.qk_out.scale != nullptr) attention_quant_kernel<64, true><<<cgrid, 256, 0, st>>>(a);
+    else attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
+  } else {
+    attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a);
+    MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
+    attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1), 256, 0, st>>>(a.v_prefix, a.seq / 64, 256);
+    MQ_LAUNCH_CHECK("mq_attention_quant(prefix)");
+    if (a.qk_out.scale != nullptr) attention_quant_kernel<256, true><<<cgrid, 256, 0, st>>>(a);
+    else attention_quant_kernel<256, false><<<cgrid, 256, 0, st>>>(a);
+  }
   MQ_LAUNCH_CHECK("mq_attention_quant");
   return MQ_OK;
 }

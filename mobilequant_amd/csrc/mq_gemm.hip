@@ -1109,6 +1109,10 @@ static int pick_variant(int M, int N, bool w4) {
 
 template <bool W4>
 static int run_gemm(GemmArgs a, hipStream_t st) {
+  if (a.a_tiled && !W4 && !gemm_tiled_supported(a.M, a.N, a.K) && gemm_fr128_shape(a.M, a.N, a.K) && a.resid == nullptr &&
+      (a.out_dtype == MQ_U8 || a.out_dtype == MQ_I8) && a.out_scale != nullptr && a.out_qmin == 0.0f && a.out_qmax == 255.0f) {
+    return launch_fr128<FR128>(a, st);      // 8-bit unsigned index outputs on 256 x 128 tiles (Gemma's w1 / w3: N = 16384)
+  }
   const bool outq = a.out_scale != nullptr;
   a.has_rowsum = a.a_rowsum != nullptr;
   if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;                 // element 0 only (M may exceed N); multiplied by w_zp == 0

@@ -132,7 +132,7 @@ class Attention(nn.Module):
 def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, resid=None):
     """Attention.forward with RoPE, both QMatMuls, 1/sqrt(d), the causal mask and the softmax in ONE pair of launches
     (ops.attention_quant: integer q.k^T and p.v on the MFMA units, no [S, S] tensor in memory).  Serves causal prefill from position
-    0 with static per-tensor grids (8-bit q / k / v, <= 16-bit probabilities) at head_dim 64; everything else -- training, decode steps,
+    0 with static per-tensor grids (8-bit q / k / v, <= 16-bit probabilities) at head_dim 64 or 256; everything else -- training, decode steps,
     a custom mask, other shapes -- runs the module chain.  Installed by fuse_attention()."""
     from . import ops
     from .quantization import qmodule as Q
@@ -144,7 +144,7 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         return out if resid is None else resid + out
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
-    if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim != 64 or S < 2
+    if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim not in (64, 256) or S < 2
             or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
             or Q._needs_grad(x, *self.parameters())):
         return plain(x, cos, sin, mask, cache, pos)
@@ -170,14 +170,15 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
     else:
         q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
         qkv = [None] * B
+    D = s.head_dim
     if cache is not None:
-        cache[0][:, :, :S] = apply_rope(k.view(B, S, s.kv_heads, 64).transpose(1, 2), cos, sin)
-        cache[1][:, :, :S] = v.view(B, S, s.kv_heads, 64).transpose(1, 2)
+        cache[0][:, :, :S] = apply_rope(k.view(B, S, s.kv_heads, D).transpose(1, 2), cos, sin)
+        cache[1][:, :, :S] = v.view(B, S, s.kv_heads, D).transpose(1, 2)
     oq, o_proj = pv.output_quantizer, self.o_proj
     if Q._u8_grid(oq) and isinstance(o_proj, Q.QLinear) and not o_proj.use_temporary_parameter and o_proj.input_chan_scale is None:
         # o_proj reads pv_bmm's output grid: hand it the int8 image (fragment-blocked, + row sums) straight from the attention
         # kernel -- no fp32 [B, S, hidden] tensor, no quantize launch.  The probe tensor is never written nor read.
-        M, K = B * S, s.heads * 64
+        M, K = B * S, s.heads * D
         probe = Q._tag_grid(torch.empty(1, dtype=torch.float32, device=x.device).expand(B, S, K), oq)
         w_o = o_proj._effective_weight(o_proj.weight)
         if (o_proj.input_quantizer is None and o_proj._int8_ready(probe, w_o) and not o_proj._weight_plan(w_o)["w4"]
@@ -189,9 +190,9 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
             rs = torch.empty(M, dtype=torch.int32, device=x.device)
             for b in range(B):
                 ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False,
-                                    qkv_idx=qkv[b])
+                                    qkv_idx=qkv[b], head_dim=D)
             return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S), resid=resid)
-    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b]) for b in range(B)])
+    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b], head_dim=D) for b in range(B)])
     if oq is not None and not oq.bypassed():
         Q._tag_grid(out, oq)
     out = o_proj(out)

@@ -504,15 +504,17 @@ def gated_lookup(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, tiled: b
 
 
 def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
-                    heads: int, kv_heads: int, grids: dict, image=None, want_out: bool = True, qkv_idx=None):
-    """Quantized causal prefill attention of ONE sequence (mq_attention_quant): q [S, heads*64], k / v [S, kv_heads*64] fp32
+                    heads: int, kv_heads: int, grids: dict, image=None, want_out: bool = True, qkv_idx=None, head_dim: int = 64):
+    """Quantized causal prefill attention of ONE sequence (mq_attention_quant; head_dim 64 or 256 -- "64" below reads head_dim): q [S, heads*64], k / v [S, kv_heads*64] fp32
     projection outputs before RoPE, cos / sin [S, 64]; grids: qk_a, qk_b, qk_out, pv_a, pv_b, pv_out -> (scale, offset, qmin, qmax)
     per tensor or None (qk_out / pv_out only).  Returns pv_bmm's output [S, heads*64] fp32 (o_proj's input layout).
     image = (q_i8, row_sum [rows] int32, row0, shift, tiled): additionally (want_out=False: only) write the pv_out indices of this
     sequence as rows row0 .. row0+S-1 of the consumer linear's int8 input image: row-major [rows, heads*64], or (tiled) the
     fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled."""
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
-    D = 64
+    D = int(head_dim)
+    if D not in (64, 256):
+        raise RuntimeError("mobilequant_amd: attention_quant serves head_dim 64 and 256")
     rot = cos.shape[-1]                  # partial rotary: cos / sin [S, rot_dim] with rot_dim < 64 (hf_model.py:489-500)
     if rot > D or rot % 2 or sin.shape != cos.shape:
         raise RuntimeError("mobilequant_amd: attention_quant cos / sin must be [S, rot_dim], rot_dim even and <= 64")
@@ -563,6 +565,10 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
     q_rs = torch.empty(heads * S, dtype=torch.int32, device=dev)
     k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
+    if D != 64:
+        v_pre = torch.empty(kv_heads * (S // 64) * D, dtype=torch.int32, device=dev)
+        keep.append(v_pre)
+        a.v_prefix = v_pre.data_ptr()
     if idx is None:
         a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
     a.cos, a.sin = cos.data_ptr(), sin.data_ptr()

@@ -1186,10 +1186,18 @@ def _gated_mlp_forward(self, x, resid=None):
             or (oq2 is not None and not oq2.bypassed() and not _static_per_tensor(oq2, 16))
             or _needs_grad(wt2, w2.bias, getattr(wq2, "scale", None))):
         return plain(x)
-    grid, a_q, a_rs, a_shift, tiled_rows, decode = w1._input_image(x, wt1)
+    any_w4 = w1._weight_plan(wt1)["w4"] or w3._weight_plan(wt3)["w4"]
+    t_hit = None
+    if not pair and not any_w4 and M > 8 and ops.gemm_tiled128_supported(M, N, K):
+        # N does not tile by 176 (Gemma: 16384): w1 / w3 run one by one on the 128-column generated kernel, reading the
+        # fragment-blocked image the norm left (index outputs only -- which is all this block needs)
+        t_hit = _shared_activation.get(x, g1, ("tiled", 128 if g1.qmax > 127 else 0, None))
+    if t_hit is not None:
+        grid, (a_q, a_rs, a_shift), tiled_rows, decode = g1, t_hit, M, False
+    else:
+        grid, a_q, a_rs, a_shift, tiled_rows, decode = w1._input_image(x, wt1)
     if decode:
         return plain(x)
-    any_w4 = w1._weight_plan(wt1)["w4"] or w3._weight_plan(wt3)["w4"]
     if any_w4 and tiled_rows is not None:
         return plain(x)                     # (a 4-bit sibling of an int8 linear that chose the fragment-blocked image: not a real recipe)
     pair = pair and tiled_rows is not None and not any_w4

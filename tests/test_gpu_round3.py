@@ -486,3 +486,59 @@ def test_gated_lookup_tiled_is_the_rowmajor_lookup_in_the_fragment_blocked_layou
         Mp = (rows + 15) // 16 * 16
         back = qt.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
         assert torch.equal(back, q)
+
+
+def test_tiled_index_gemm_on_128_column_tiles_is_the_rowmajor_gemm(dev):
+    """mq_w8a8_linear_tiled for an N that does not tile by 176 (Gemma's FFN, N = 16384 here 1024): u8 index output through the
+    128-column generated kernel == mq_w8a8_linear on the row-major image."""
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_U8
+    for M, N, K in ((2048, 1024, 2048), (200, 384, 768)):
+        a_q, w_q, a_rs, alpha, w_zp, col_term, b = _gemm_operands(dev, M, N, K, M + N)
+        so, oo = torch.tensor([0.9], device=dev), torch.tensor([131.0], device=dev)
+        kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8)
+        want = ops.int8_linear(a_q, w_q, a_rs, alpha * 20, w_zp, col_term, b, **kw)
+        got = ops.int8_linear(_to_tiled(a_q), w_q, a_rs, alpha * 20, w_zp, col_term, b, a_tiled_rows=M, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and want.min() == 0 and want.max() == 255
+
+
+# ---- prefill attention at head_dim 256 (Gemma: 8 heads, 1 KV head) -------------------------------------------------------------------
+@pytest.mark.parametrize("S,heads,kv_heads,qk_out_bits,pv_out_bits", [(64, 2, 1, 16, 8), (200, 8, 1, 16, 8), (320, 4, 2, 16, 8), (128, 2, 2, 0, 0)])
+def test_prefill_attention_head_dim_256_vs_oracle(dev, S, heads, kv_heads, qk_out_bits, pv_out_bits):
+    """mq_attention_quant at head_dim 256 (four MFMA k-steps per score tile, 16 output d-tiles, sum_t v from the prep kernel's prefix
+    sums) against the numpy restatement of hf_model.py:486-534 and against its exact-integer form; the int8 output image in both
+    layouts is the fp32 output's index image."""
+    from test_gpu_round2 import _grid_of
+    from mobilequant_amd import ops
+    D = 256
+    q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, D, D, seed=7 * S + heads, qk_out_bits=qk_out_bits, pv_out_bits=pv_out_bits)
+    want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)                       # noqa: E731
+    got_t = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, head_dim=D)
+    got = got_t.cpu().numpy()
+    assert got.shape == want.shape and np.isfinite(got).all()
+    diff = np.abs(got - want)
+    span = float(want.max() - want.min())
+    if pv_out_bits == 8:
+        step = float(pv[2].scale)
+        assert diff.max() <= 1.001 * step, (diff.max(), step)
+        assert (diff > 0.5 * step).mean() < 0.02
+        exact = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv, exact_int=True)
+        assert (np.abs(got - exact) > 0.5 * step).mean() <= 5e-4
+        # the int8 images (row-major / fragment-blocked) carry exactly the indices of the fp32 output, the row sums their sums
+        idx = torch.round(got_t / float(pv[2].scale) + float(pv[2].offset)).to(torch.int32) - 128
+        for tiled in (False, True):
+            Mp = (S + 15) // 16 * 16
+            img = torch.zeros((Mp if tiled else S, heads * D), dtype=torch.int8, device=dev)
+            rs = torch.zeros(S, dtype=torch.int32, device=dev)
+            ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, image=(img, rs, 0, 128, tiled), want_out=False, head_dim=D)
+            torch.cuda.synchronize()
+            back = img.view(Mp // 16, heads * D // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, heads * D)[:S] if tiled else img
+            assert torch.equal(back.to(torch.int32), idx), tiled
+            assert torch.equal(rs, idx.sum(dim=1, dtype=torch.int32))
+    else:
+        assert diff.max() <= 2e-3 * span, (diff.max(), span)
+    assert np.median(diff) <= 2e-4 * span
