@@ -279,7 +279,7 @@ def _fused_layer_forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
     from .quantization import qmodule as Q
 
     def norm(mod, t, layout):
-        return mod.forward_images(t, layout) if isinstance(mod, Q.QRMSNorm) else mod(t)
+        return mod.forward_images(t, layout) if isinstance(mod, (Q.QRMSNorm, Q.QLayerNorm)) else mod(t)
     # the norms' only consumers here are integer linears: they write just the int8 image those read (q/k/v: row-major; w1/w3: the
     # fragment-blocked layout), not the fp32 tensor
     x = self.self_attn(norm(self.input_layernorm, x, _qkv_image_layout(self.self_attn, x)), cos, sin, mask, cache, pos, resid=x)

@@ -927,6 +927,13 @@ class QLayerNorm(nn.LayerNorm, _QuantizedOp):
         self.use_temporary_parameter = False
         self._init_quantizers(input=input_quant_cfg, weight=weight_quant_cfg, output=output_quant_cfg)
 
+    def forward_images(self, input_, layout: str):
+        """QRMSNorm.forward_images for the LayerNorm families (StableLM): only the int8 image in `layout` where the fused kernel applies."""
+        weight = self.temp_weight if self.use_temporary_parameter else self.weight
+        bias = self.temp_bias if self.use_temporary_parameter else self.bias
+        out = _fused_norm(self, input_, weight, bias, layernorm=True, images=layout)
+        return out if out is not None else self.forward(input_)
+
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
         bias = self.temp_bias if self.use_temporary_parameter else self.bias
