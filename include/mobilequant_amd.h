@@ -460,6 +460,12 @@ typedef struct mq_attention_args {
   mq_grid q_in, k_in, v_in;
   int rot_dim; /* partial rotary (hf_model.py:489-500): RoPE on the first rot_dim dims, cos / sin [seq, rot_dim]; 0 = head_dim */
   int32_t* v_prefix; /* head_dim 256 only: scratch [kv_heads][seq/64][head_dim] (running column sums of the stored v image) */
+  /* cache continuation (chunked prefill; no counterpart in the reference, whose context encoding is one forward): with cache_seq > 0
+   * k_i8 / vt_i8 / k_rowsum / v_prefix are caller-owned CACHES laid out for cache_seq rows ([kv_heads][cache_seq][D], ...) that already
+   * hold positions 0 .. pos0 - 1 from earlier calls with the same grids; this call appends rows pos0 .. pos0 + seq - 1 and attends to
+   * all of them.  q / k / v / cos / sin / out describe the chunk only (cos / sin rows of positions pos0 ...).  pos0 % 64 == 0,
+   * cache_seq % 64 == 0, pos0 + seq <= cache_seq.  cache_seq = 0: the buffers are scratch of seq rows, pos0 = 0. */
+  int pos0, cache_seq;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
 

@@ -63,6 +63,9 @@ __device__ __forceinline__ float a_index_fast(float x, const AGrid& g) {
 template <int D>
 __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_args a) {
   const int H = a.heads, KV = a.kv_heads, S = a.seq;
+  // cache continuation (chunked prefill): the K / vT images, their row sums and the v prefix sums are caller-owned caches of cache_seq
+  // rows; this chunk's rows go to positions pos0 .. pos0 + seq - 1 (pos0 % 64 == 0).  cache_seq = 0: scratch of seq rows, pos0 = 0.
+  const int CS = a.cache_seq > 0 ? a.cache_seq : S, P0 = a.cache_seq > 0 ? a.pos0 : 0;
   const int part = blockIdx.y;                       // [0, H): q head; [H, H+KV): k head; [H+KV, H+2KV): v head
   const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
   const int s = blockIdx.x * 64 + r;
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     w[d4] = pk;
   }
   if (is_q || is_k) {
-    int8_t* dst = (is_q ? a.q_i8 + (size_t)head * S * D : a.k_i8 + (size_t)head * S * D) + (size_t)s * D + col0;
+    int8_t* dst = (is_q ? a.q_i8 + ((size_t)head * S + s) * D : a.k_i8 + ((size_t)head * CS + P0 + s) * D) + col0;
     *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
     if (dc == D / 64 - 1) {
       sum += __shfl_xor(sum, 1, 64);
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
       const int zq = (int)a_load_grid(a.qk_a).o - 128, zk = (int)a_load_grid(a.qk_b).o - 128;
       if (c == 0) {
         if (is_q) a.q_rowsum[(size_t)head * S + s] = D * zq * zk - zk * sum;
-        else a.k_rowsum[(size_t)head * S + s] = -zq * sum;
+        else a.k_rowsum[(size_t)head * CS + P0 + s] = -zq * sum;
       }
     }
   } else {
@@ -178,12 +181,12 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
       }
       o4[j] = pk;
     }
-    int8_t* dst = a.vt_i8 + (((size_t)head * (S >> 6) + blockIdx.x) * D + 64 * dc + d) * 64 + 16 * c;
+    int8_t* dst = a.vt_i8 + (((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * D + 64 * dc + d) * 64 + 16 * c;
     *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     if constexpr (D > 64) {                            // column sums of the stored values over this block's 64 keys (prefix-summed below)
       csum += __shfl_xor(csum, 1, 64);
       csum += __shfl_xor(csum, 2, 64);
-      if (c == 0) a.v_prefix[((size_t)head * (S >> 6) + blockIdx.x) * D + 64 * dc + d] = csum;
+      if (c == 0) a.v_prefix[((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * D + 64 * dc + d] = csum;
       __syncthreads();                                 // s_v is rewritten by the next slab
     }
   }
@@ -192,19 +195,19 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
 
 // head_dim > 64: v_prefix[kv][kb][d] <- sum over blocks 0 .. kb of the per-block column sums (the core kernel needs sum_t v[t][d] over
 // the keys it processed; with one extra all-ones MFMA per block it would also need D / 4 more accumulator registers per lane)
-__global__ void __launch_bounds__(256) attention_vprefix_kernel(int32_t* __restrict__ v_prefix, int nblk, int D) {
+__global__ void __launch_bounds__(256) attention_vprefix_kernel(int32_t* __restrict__ v_prefix, int first, int nblk, int head_blocks, int D) {
   const int d = blockIdx.y * 256 + threadIdx.x;
   if (d >= D) return;
-  int32_t* p = v_prefix + (size_t)blockIdx.x * nblk * D + d;
-  int run = 0;
-  for (int kb0 = 0; kb0 < nblk; kb0 += 32) {            // 32 independent loads in flight, then the scan in registers
+  int32_t* p = v_prefix + (size_t)blockIdx.x * head_blocks * D + d;
+  int run = first > 0 ? p[(size_t)(first - 1) * D] : 0;   // blocks before `first` already hold their prefix sums (cache continuation)
+  for (int kb0 = first; kb0 < first + nblk; kb0 += 32) {  // 32 independent loads in flight, then the scan in registers
     int v[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = kb0 + i < nblk ? p[(size_t)(kb0 + i) * D] : 0;
+    for (int i = 0; i < 32; ++i) v[i] = kb0 + i < first + nblk ? p[(size_t)(kb0 + i) * D] : 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       run += v[i];
-      if (kb0 + i < nblk) p[(size_t)(kb0 + i) * D] = run;
+      if (kb0 + i < first + nblk) p[(size_t)(kb0 + i) * D] = run;
     }
   }
 }
@@ -229,6 +232,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   constexpr int NKS = D / 64, NDT = D / 16;
   constexpr float kInvSqrtD = D == 64 ? 0.125f : 0.0625f;
   const int S = a.seq, H = a.heads, KV = a.kv_heads;
+  const int CS = a.cache_seq > 0 ? a.cache_seq : S, PB = a.cache_seq > 0 ? a.pos0 >> 6 : 0;     // cached key blocks in front of this chunk
   // Work per workgroup is proportional to qb + 1 (causal).  The hardware hands out workgroups in id order to whichever slot frees
   // up, so the ids run over ALL heads of the longest query block first, then the next block, ...: a longest-first list schedule.
   // With 2 resident workgroups per CU and H * S/64 = 2 * (2 * 256) of them, slots pair up (S/64 - i) with (i + 1): even finish.
@@ -253,9 +257,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qbase + srow * D + ks * 64 + tq * 16);
   const int qconst = a.q_rowsum[(size_t)h * S + s_abs];             // D zq zk - zk * rowsum(q), from the prep kernel
-  const int8_t* kbase = a.k_i8 + (size_t)kvh * S * D;
-  const int* kterm = a.k_rowsum + (size_t)kvh * S;                  // -zq * rowsum(k)
-  const int nkb = qb + 1;                                           // key blocks 0 .. qb (causal)
+  const int8_t* kbase = a.k_i8 + (size_t)kvh * CS * D;
+  const int* kterm = a.k_rowsum + (size_t)kvh * CS;                 // -zq * rowsum(k)
+  const int nkb = PB + qb + 1;                                      // key blocks 0 .. PB + qb (causal; PB cached blocks in front)
+  const int kdiag = PB + qb;                                        // the block that holds the diagonal
+  const int s_key = PB * 64 + s_abs;                                // this row's absolute position (the mask compares keys against it)
   const v4i cinit = {qconst, qconst, qconst, qconst};
 
   struct KTile {
@@ -278,7 +284,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   // destination is that layout when every lane sources its own fragment bytes.  Two buffers, one barrier per block.
   constexpr int kTileBytes = D == 64 ? 16 : 32 * 1024;               // K fragments [0, 16 KiB) | vT fragments [16 KiB, 32 KiB)
   __shared__ __attribute__((aligned(16))) char s_tile[2][kTileBytes];
-  const int8_t* vbase = a.vt_i8 + (size_t)kvh * (S >> 6) * D * 64;
+  const int8_t* vbase = a.vt_i8 + (size_t)kvh * (CS >> 6) * D * 64;
   auto dma_block = [&](int kb, int buf, bool with_v) {
     if constexpr (D != 64) {
       const int8_t* kp = kbase + (size_t)kb * 64 * D;
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int t_abs = kb * 64 + 16 * (i >> 2) + 4 * tq + (i & 3);
-        f[i] = t_abs <= s_abs ? f[i] : -INFINITY;
+        f[i] = t_abs <= s_key ? f[i] : -INFINITY;
       }
     }
   };
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   float m = -INFINITY, l = 0.f, R = -INFINITY;
   auto sweep1 = [&](const int (&ti)[16], int kb) {
     float f[16];
-    grid_scores(ti, kb == qb, kb, f);
+    grid_scores(ti, kb == kdiag, kb, f);
     float bm = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
     bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(f[8], f[9]), fmaxf(f[10], f[11])), fmaxf(fmaxf(f[12], f[13]), fmaxf(f[14], f[15]))));
     bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   const bool fixed_ref = QK_OUT && (fhi - flo) * cexp < 96.f;
   auto sweep1_fixed = [&](const int (&ti)[16], int kb) {
     float f[16];
-    grid_scores(ti, kb == qb, kb, f);
+    grid_scores(ti, kb == kdiag, kb, f);
     float bs = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) bs += fast_exp2(__builtin_fmaf(f[i], cexp, -R));
@@ -435,7 +441,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   };
   auto probs = [&](const int (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo) {
     float f[16];
-    grid_scores(ti, kb == qb, kb, f);
+    grid_scores(ti, kb == kdiag, kb, f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned b[4];
@@ -500,7 +506,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   float* orow = a.out + (size_t)s_abs * H * D + (size_t)h * D;
   int rsum = 0;
   unsigned opk = 0;
-  const int32_t* vpre = D == 64 ? nullptr : a.v_prefix + ((size_t)kvh * (S >> 6) + (nkb - 1)) * D;
+  const int32_t* vpre = D == 64 ? nullptr : a.v_prefix + ((size_t)kvh * (CS >> 6) + (nkb - 1)) * D;
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
     float o4[4];
@@ -547,6 +553,10 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   MQ_REQUIRE(((a.q && a.k && a.v) || a.qkv_idx) && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.seq <= 65536, "mq_attention_quant: seq = %d exceeds 65536 (int32 accumulators of the p.v products)", a.seq);
+  MQ_REQUIRE(a.cache_seq == 0 ? a.pos0 == 0
+                              : (a.cache_seq % 64 == 0 && a.pos0 >= 0 && a.pos0 % 64 == 0 && a.pos0 + a.seq <= a.cache_seq && a.cache_seq <= 65536),
+             "mq_attention_quant: cache continuation needs pos0 %% 64 == 0, cache_seq %% 64 == 0, pos0 + seq <= cache_seq <= 65536 (pos0=%d cache_seq=%d); "
+             "without a cache (cache_seq = 0) pos0 must be 0", a.pos0, a.cache_seq);
   MQ_REQUIRE((a.head_dim == 64 || a.head_dim == 256) && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
              "mq_attention_quant: head_dim 64 or 256, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
   MQ_REQUIRE(a.rot_dim >= 0 && a.rot_dim <= a.head_dim && a.rot_dim % 2 == 0, "mq_attention_quant: rot_dim = %d (0 = head_dim; even, <= head_dim)", a.rot_dim);
@@ -576,7 +586,8 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   } else {
     attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
-    attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1), 256, 0, st>>>(a.v_prefix, a.seq / 64, 256);
+    attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1), 256, 0, st>>>(a.v_prefix, a.cache_seq > 0 ? a.pos0 / 64 : 0, a.seq / 64,
+                                                                               (a.cache_seq > 0 ? a.cache_seq : a.seq) / 64, 256);
     MQ_LAUNCH_CHECK("mq_attention_quant(prefix)");
     if (a.qk_out.scale != nullptr) attention_quant_kernel<256, true><<<cgrid, 256, 0, st>>>(a);
     else attention_quant_kernel<256, false><<<cgrid, 256, 0, st>>>(a);

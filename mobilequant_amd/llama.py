@@ -131,8 +131,8 @@ class Attention(nn.Module):
 
 def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, resid=None):
     """Attention.forward with RoPE, both QMatMuls, 1/sqrt(d), the causal mask and the softmax in ONE pair of launches
-    (ops.attention_quant: integer q.k^T and p.v on the MFMA units, no [S, S] tensor in memory).  Serves causal prefill from position
-    0 with static per-tensor grids (8-bit q / k / v, <= 16-bit probabilities) at head_dim 64 or 256; everything else -- training, decode steps,
+    (ops.attention_quant: integer q.k^T and p.v on the MFMA units, no [S, S] tensor in memory).  Serves causal prefill (from position 0, or continuing an ImageCache at a multiple of 64)
+    with static per-tensor grids (8-bit q / k / v, <= 16-bit probabilities) at head_dim 64 or 256; everything else -- training, decode steps,
     a custom mask, other shapes -- runs the module chain.  Installed by fuse_attention()."""
     from . import ops
     from .quantization import qmodule as Q
@@ -140,12 +140,16 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
     plain0 = self._mq_plain_forward
 
     def plain(t, *a):
+        if isinstance(cache, ImageCache):
+            raise RuntimeError("mobilequant_amd: an image cache (new_image_cache) only serves the fused attention -- causal chunks at "
+                               "positions that are multiples of 64, static per-tensor grids, head_dim 64 / 256, no gradients")
         out = plain0(Q._materialize(t), *a)
         return out if resid is None else resid + out
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
     if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim not in (64, 256) or S < 2
-            or pos != 0 or not getattr(mask, "_mq_causal", False) or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
+            or (pos != 0 and not isinstance(cache, ImageCache)) or pos % 64 or not getattr(mask, "_mq_causal", False)
+            or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
             or Q._needs_grad(x, *self.parameters())):
         return plain(x, cos, sin, mask, cache, pos)
     if not (Q._u8_grid(qk.input_quantizer) and Q._u8_grid(qk.input2_quantizer) and Q._u8_grid(pv.input2_quantizer)
@@ -161,6 +165,12 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
             quantizer.scale.data, quantizer.offset.data = quantizer.scale.to(x.device), quantizer.offset.to(x.device)
             g = Q.QRMSNorm._grid_or_none(quantizer)
         grids[name] = g
+    img = cache if isinstance(cache, ImageCache) else None      # chunked prefill: K / vT images of the earlier chunks
+    if img is not None:
+        cache = None
+        if len(img.per_sequence) != B or pos + S > img.per_sequence[0]["rows"]:
+            raise RuntimeError("mobilequant_amd: image cache built for another batch size or too short for this position")
+    akw = [dict(head_dim=s.head_dim) if img is None else dict(head_dim=s.head_dim, cache=img.per_sequence[b], pos0=pos) for b in range(B)]
     fused_qkv = _qkv_indices(self, x) if cache is None and getattr(self, "fuse_qkv", True) else None
     if fused_qkv is not None:
         idx, in_grids = fused_qkv                    # uint8 [B*S, (H + 2 KV) * 64]: one GEMM, three output grids
@@ -190,9 +200,9 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
             rs = torch.empty(M, dtype=torch.int32, device=x.device)
             for b in range(B):
                 ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False,
-                                    qkv_idx=qkv[b], head_dim=D)
+                                    qkv_idx=qkv[b], **akw[b])
             return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S), resid=resid)
-    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b], head_dim=D) for b in range(B)])
+    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b], **akw[b]) for b in range(B)])
     if oq is not None and not oq.bypassed():
         Q._tag_grid(out, oq)
     out = o_proj(out)
@@ -346,6 +356,13 @@ class DecoderLayer(nn.Module):
         return x + self.mlp(self.post_attention_layernorm(x))
 
 
+class ImageCache:
+    """One attention block's K / vT image caches, one per sequence of the batch (LlamaForCausalLM.new_image_cache)."""
+
+    def __init__(self, per_sequence):
+        self.per_sequence = per_sequence
+
+
 class LlamaForCausalLM(nn.Module):
     """embed -> layers -> norm -> lm_head.  `layers`, final `norm` and `lm_head` carry the names the surgery rules skip
     (qmodule.py:843)."""
@@ -389,6 +406,15 @@ class LlamaForCausalLM(nn.Module):
         for i, layer in enumerate(self.layers):
             x = layer(x, cos, sin, mask, None if cache is None else cache[i], pos)
         return self.lm_head(self.norm(x))
+
+    def new_image_cache(self, batch: int, length: int, device=None):
+        """Cache for CHUNKED prefill through the fused attention (llama.fuse_attention / fuse_decoder_layer): per layer and sequence the
+        int8 K / vT images the attention kernel keeps (ops.attention_image_cache).  Feed chunks with `model(ids[:, a:b], cache=c, pos=a)`,
+        a % 64 == 0; every chunk attends to all earlier ones.  (No counterpart in the reference: its context encoding is one forward.)"""
+        from . import ops
+        s = self.shape
+        device = device if device is not None else self.embed_tokens.weight.device
+        return [ImageCache([ops.attention_image_cache(s.kv_heads, s.head_dim, length, device) for _ in range(batch)]) for _ in self.layers]
 
     def new_cache(self, batch: int, length: int, device=None, dtype=torch.float32):
         s = self.shape

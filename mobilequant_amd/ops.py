@@ -503,14 +503,29 @@ def gated_lookup(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, tiled: b
     return q, rs
 
 
+def attention_image_cache(kv_heads: int, head_dim: int, max_len: int, device) -> dict:
+    """Caller-owned K / vT image caches for attention_quant(cache=..., pos0=...): one per attention block and sequence."""
+    rows = (int(max_len) + 63) // 64 * 64
+    dev = torch.device(device)
+    return {"rows": rows, "kv_heads": int(kv_heads), "head_dim": int(head_dim),
+            "k_i8": torch.zeros(kv_heads * rows * head_dim, dtype=torch.int8, device=dev),
+            "vt_i8": torch.zeros(kv_heads * rows * head_dim, dtype=torch.int8, device=dev),
+            "k_rs": torch.zeros(kv_heads * rows, dtype=torch.int32, device=dev),
+            "v_pre": torch.zeros(kv_heads * (rows // 64) * head_dim, dtype=torch.int32, device=dev) if head_dim != 64 else None}
+
+
 def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
-                    heads: int, kv_heads: int, grids: dict, image=None, want_out: bool = True, qkv_idx=None, head_dim: int = 64):
+                    heads: int, kv_heads: int, grids: dict, image=None, want_out: bool = True, qkv_idx=None, head_dim: int = 64,
+                    cache=None, pos0: int = 0):
     """Quantized causal prefill attention of ONE sequence (mq_attention_quant; head_dim 64 or 256 -- "64" below reads head_dim): q [S, heads*64], k / v [S, kv_heads*64] fp32
     projection outputs before RoPE, cos / sin [S, 64]; grids: qk_a, qk_b, qk_out, pv_a, pv_b, pv_out -> (scale, offset, qmin, qmax)
     per tensor or None (qk_out / pv_out only).  Returns pv_bmm's output [S, heads*64] fp32 (o_proj's input layout).
     image = (q_i8, row_sum [rows] int32, row0, shift, tiled): additionally (want_out=False: only) write the pv_out indices of this
     sequence as rows row0 .. row0+S-1 of the consumer linear's int8 input image: row-major [rows, heads*64], or (tiled) the
-    fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled."""
+    fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled.
+    cache = attention_image_cache(...) + pos0: cache continuation (chunked prefill).  The cache already holds positions 0 .. pos0 - 1
+    from earlier calls (same grids); q / k / v / cos / sin describe positions pos0 .. pos0 + S - 1, which are appended and attend to
+    everything before them.  pos0 % 64 == 0 (every chunk but the last is a multiple of 64 long)."""
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
     D = int(head_dim)
     if D not in (64, 256):
@@ -561,12 +576,23 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
             setattr(a, name, _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0))
     out = torch.empty(S, heads * D, dtype=torch.float32, device=dev) if want_out or image is None else None
     q_i8 = torch.empty(heads * S * D, dtype=torch.int8, device=dev)
-    k_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
-    vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
     q_rs = torch.empty(heads * S, dtype=torch.int32, device=dev)
-    k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
-    if D != 64:
-        v_pre = torch.empty(kv_heads * (S // 64) * D, dtype=torch.int32, device=dev)
+    if cache is not None:
+        if (cache["kv_heads"], cache["head_dim"]) != (kv_heads, D) or cache["k_i8"].device != dev:
+            raise RuntimeError("mobilequant_amd: attention_quant cache was built for another shape / device")
+        if pos0 % 64 or pos0 < 0 or pos0 + S > cache["rows"]:
+            raise RuntimeError(f"mobilequant_amd: attention_quant cache continuation needs pos0 % 64 == 0 and pos0 + padded S <= {cache['rows']} "
+                               f"(pos0={pos0}, S={S})")
+        k_i8, vt_i8, k_rs, v_pre = cache["k_i8"], cache["vt_i8"], cache["k_rs"], cache["v_pre"]
+        a.pos0, a.cache_seq = int(pos0), int(cache["rows"])
+    else:
+        if pos0:
+            raise RuntimeError("mobilequant_amd: attention_quant(pos0 > 0) needs a cache (attention_image_cache)")
+        k_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
+        vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
+        k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
+        v_pre = torch.empty(kv_heads * (S // 64) * D, dtype=torch.int32, device=dev) if D != 64 else None
+    if v_pre is not None:
         keep.append(v_pre)
         a.v_prefix = v_pre.data_ptr()
     if idx is None:

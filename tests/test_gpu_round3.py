@@ -542,3 +542,53 @@ def test_prefill_attention_head_dim_256_vs_oracle(dev, S, heads, kv_heads, qk_ou
     else:
         assert diff.max() <= 2e-3 * span, (diff.max(), span)
     assert np.median(diff) <= 2e-4 * span
+
+
+# ---- chunked prefill: the fused attention continuing a cache of K / vT images ----------------------------------------------------------
+@pytest.mark.parametrize("D,heads,kv_heads,chunks", [(64, 4, 2, (128, 64, 100)), (256, 2, 1, (64, 128, 37)), (64, 2, 2, (192, 192))])
+def test_attention_quant_cache_continuation_is_the_single_shot_result(dev, D, heads, kv_heads, chunks):
+    """mq_attention_quant with pos0 > 0: a sequence fed in chunks (each but the last a multiple of 64) through caller-owned K / vT image
+    caches gives, row for row, the bits of the single call over the whole sequence (the same key blocks in the same order), and both
+    stay on the oracle."""
+    from test_gpu_round2 import _grid_of
+    from mobilequant_amd import ops
+    S = sum(chunks)
+    q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, D, D, seed=S + D)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                       # noqa: E731
+    whole = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, head_dim=D)
+    cache = ops.attention_image_cache(kv_heads, D, S + 7, dev)
+    outs, p0 = [], 0
+    for n in chunks:
+        sl = slice(p0, p0 + n)
+        outs.append(ops.attention_quant(t(q[sl]), t(k[sl]), t(v[sl]), t(cos[sl]), t(sin[sl]), heads, kv_heads, grids, head_dim=D, cache=cache, pos0=p0))
+        p0 += n
+    got = torch.cat(outs)
+    torch.cuda.synchronize()
+    assert torch.equal(got, whole), float((got - whole).abs().max())
+    want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    assert np.abs(got.cpu().numpy() - want).max() <= 1.001 * float(pv[2].scale)
+    with pytest.raises(RuntimeError):
+        ops.attention_quant(t(q[:64]), t(k[:64]), t(v[:64]), t(cos[:64]), t(sin[:64]), heads, kv_heads, grids, head_dim=D, cache=cache, pos0=32)
+
+
+def test_chunked_prefill_through_the_fused_model_matches_the_single_forward(dev):
+    """LlamaForCausalLM.new_image_cache + fuse_decoder_layer: a 192-token context fed as 128 + 64 reproduces the single fused forward's
+    logits bit for bit (every per-row computation is the same), on the 2-layer W8A8 model of decode_case.npz."""
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd import llama
+    import dataclasses
+    m, z = _decode_model(dev)
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=256))      # the golden model's table stops at 64 positions
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, m.shape.vocab, (1, 192), generator=g).to(dev)
+    S = ids.shape[1]
+    with torch.no_grad():
+        assert llama.fuse_decoder_layer(m) == 2
+        whole = m(ids)
+        cache = m.new_image_cache(1, S)
+        parts = [m(ids[:, :64], cache=cache, pos=0), m(ids[:, 64:S], cache=cache, pos=64)]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, dim=1), whole)
