@@ -412,7 +412,7 @@ int mq_decode_head(const float* x, const float* norm_weight, const float* norm_b
  * Scratch (caller-owned, overwritten): q_i8 [heads][seq][D], k_i8 [kv_heads][seq][D], vt_i8 [kv_heads][seq/64][D][64] (values
  * transposed, keys permuted inside each 64-block), q_rowsum [heads][seq], k_rowsum [kv_heads][seq] (the zero-point terms of the integer
  * q.k^T, derived from the row sums of the images).
- * Limits: head_dim 64 or 256 (every "64" of a layout above reads head_dim; the int8 output image is [rows, heads*head_dim]),
+ * Limits: head_dim 64, 128 or 256 (every "64" of a layout above reads head_dim; the int8 output image is [rows, heads*head_dim]),
  * seq % 64 == 0, seq <= 65536.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
 /* q | k | v (or any 1..3 linears reading one activation) as ONE int8 GEMM whose column segments carry their own 8-bit unsigned
  * output grids: weights / epilogue vectors concatenated along N, segment i = columns [seg_end[i-1], seg_end[i]) (seg_end[-1] = 0,
@@ -459,7 +459,7 @@ typedef struct mq_attention_args {
   const uint8_t* qkv_idx;
   mq_grid q_in, k_in, v_in;
   int rot_dim; /* partial rotary (hf_model.py:489-500): RoPE on the first rot_dim dims, cos / sin [seq, rot_dim]; 0 = head_dim */
-  int32_t* v_prefix; /* head_dim 256 only: scratch [kv_heads][seq/64][head_dim] (running column sums of the stored v image) */
+  int32_t* v_prefix; /* head_dim 128 / 256: scratch [kv_heads][seq/64][head_dim] (running column sums of the stored v image) */
   /* cache continuation (chunked prefill; no counterpart in the reference, whose context encoding is one forward): with cache_seq > 0
    * k_i8 / vt_i8 / k_rowsum / v_prefix are caller-owned CACHES laid out for cache_seq rows ([kv_heads][cache_seq][D], ...) that already
    * hold positions 0 .. pos0 - 1 from earlier calls with the same grids; this call appends rows pos0 .. pos0 + seq - 1 and attends to

@@ -226,11 +226,11 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // d-tiles (128 accumulator registers: one wave per SIMD), v tiles loaded per d-tile, and sum_t v[t][d] from the prep kernel's prefix
 // sums instead of an all-ones MFMA.
 template <int D, bool QK_OUT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 1, D == 64 ? 3 : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : (D == 128 ? 2 : 1), D == 64 ? 3 : (D == 128 ? 2 : 1))))
     attention_quant_kernel(const mq_attention_args a) {
-  static_assert(D == 64 || D == 256, "head_dim 64 or 256 (1 / sqrt(D) a power of two)");
+  static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
   constexpr int NKS = D / 64, NDT = D / 16;
-  constexpr float kInvSqrtD = D == 64 ? 0.125f : 0.0625f;
+  constexpr float kInvSqrtD = D == 64 ? 0.125f : (D == 256 ? 0.0625f : 0.08838834764831845f);   // 1 / sqrt(D); D = 128: RN(1 / sqrt(128))
   const int S = a.seq, H = a.heads, KV = a.kv_heads;
   const int CS = a.cache_seq > 0 ? a.cache_seq : S, PB = a.cache_seq > 0 ? a.pos0 >> 6 : 0;     // cached key blocks in front of this chunk
   // Work per workgroup is proportional to qb + 1 (causal).  The hardware hands out workgroups in id order to whichever slot frees
@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   // block in the LDS by LDS-DMA, fragment-blocked: fragment f (K: f = 4 j + ks, 16 keys x 64 d;  vT: f = dt, 16 d x 64 keys) is the
   // 1-KiB block whose lane l holds exactly the 16 bytes lane l feeds the MFMA -- conflict-free ds_read_b128, and the DMA's lane-linear
   // destination is that layout when every lane sources its own fragment bytes.  Two buffers, one barrier per block.
-  constexpr int kTileBytes = D == 64 ? 16 : 32 * 1024;               // K fragments [0, 16 KiB) | vT fragments [16 KiB, 32 KiB)
+  constexpr int kKBytes = 4 * NKS * 1024;                            // K fragments [0, kKBytes) | vT fragments [kKBytes, 2 kKBytes)
+  constexpr int kTileBytes = D == 64 ? 16 : 2 * kKBytes;
   __shared__ __attribute__((aligned(16))) char s_tile[2][kTileBytes];
   const int8_t* vbase = a.vt_i8 + (size_t)kvh * (CS >> 6) * D * 64;
   auto dma_block = [&](int kb, int buf, bool with_v) {
@@ -290,17 +291,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
       const int8_t* kp = kbase + (size_t)kb * 64 * D;
       const int8_t* vp = vbase + (size_t)kb * D * 64;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int f = 4 * wave + u;                                  // this wave's four K fragments (j = wave, ks = u) ...
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + (16 * (f >> 2) + srow) * D + (f & 3) * 64 + tq * 16),
+      for (int u = 0; u < NKS; ++u) {
+        const int f = NKS * wave + u;                                // this wave's K fragments (j = wave, ks = u) ...
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + (16 * wave + srow) * D + u * 64 + tq * 16),
                                          (__attribute__((address_space(3))) void*)(s_tile[buf] + f * 1024), 16, 0, 0);
       }
       if (with_v) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int f = 4 * wave + u;                                // ... and four vT fragments (dt = f)
+        for (int u = 0; u < NDT / 4; ++u) {
+          const int f = (NDT / 4) * wave + u;                        // ... and its vT fragments (dt = f)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + (16 * f + srow) * 64 + tq * 16),
-                                           (__attribute__((address_space(3))) void*)(s_tile[buf] + 16384 + f * 1024), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void*)(s_tile[buf] + kKBytes + f * 1024), 16, 0, 0);
         }
       }
     }
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
       v4i acc = cinit;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i*>(tb + (4 * j + ks) * 1024), qf[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i*>(tb + (NKS * j + ks) * 1024), qf[ks], acc, 0, 0, 0);
       ti[4 * j] = acc[0] + kt.x; ti[4 * j + 1] = acc[1] + kt.y; ti[4 * j + 2] = acc[2] + kt.z; ti[4 * j + 3] = acc[3] + kt.w;
     }
   };
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
       int_scores_lds(kb, kb & 1, ti);
       v4i pf_hi, pf_lo;
       probs(ti, kb, pf_hi, pf_lo);
-      const char* vb = s_tile[kb & 1] + 16384 + lane * 16;
+      const char* vb = s_tile[kb & 1] + kKBytes + lane * 16;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         const v4i vf = *reinterpret_cast<const v4i*>(vb + dt * 1024);
@@ -557,11 +558,11 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
                               : (a.cache_seq % 64 == 0 && a.pos0 >= 0 && a.pos0 % 64 == 0 && a.pos0 + a.seq <= a.cache_seq && a.cache_seq <= 65536),
              "mq_attention_quant: cache continuation needs pos0 %% 64 == 0, cache_seq %% 64 == 0, pos0 + seq <= cache_seq <= 65536 (pos0=%d cache_seq=%d); "
              "without a cache (cache_seq = 0) pos0 must be 0", a.pos0, a.cache_seq);
-  MQ_REQUIRE((a.head_dim == 64 || a.head_dim == 256) && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
-             "mq_attention_quant: head_dim 64 or 256, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
+  MQ_REQUIRE((a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256) && a.seq > 0 && a.seq % 64 == 0 && a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0,
+             "mq_attention_quant: head_dim 64, 128 or 256, seq %% 64 == 0 (got head_dim=%d seq=%d heads=%d kv_heads=%d)", a.head_dim, a.seq, a.heads, a.kv_heads);
   MQ_REQUIRE(a.rot_dim >= 0 && a.rot_dim <= a.head_dim && a.rot_dim % 2 == 0, "mq_attention_quant: rot_dim = %d (0 = head_dim; even, <= head_dim)", a.rot_dim);
   MQ_REQUIRE(a.head_dim == 64 || (a.v_prefix != nullptr && aligned(a.v_prefix, 16)),
-             "mq_attention_quant: head_dim 256 needs the v_prefix scratch ([kv_heads][seq/64][head_dim] int32, 16-byte aligned)");
+             "mq_attention_quant: head_dim 128 / 256 need the v_prefix scratch ([kv_heads][seq/64][head_dim] int32, 16-byte aligned)");
   MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmax == 255.f && a.qk_b.qmax == 255.f && a.pv_b.qmax == 255.f &&
                  a.qk_a.qmin == 0.f && a.qk_b.qmin == 0.f && a.pv_b.qmin == 0.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
              "mq_attention_quant: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
@@ -584,13 +585,19 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
     if (a.qk_out.scale != nullptr) attention_quant_kernel<64, true><<<cgrid, 256, 0, st>>>(a);
     else attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
   } else {
-    attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a);
+    if (a.head_dim == 128) attention_prep_kernel<128><<<pgrid, 256, 0, st>>>(a);
+    else attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
     attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1), 256, 0, st>>>(a.v_prefix, a.cache_seq > 0 ? a.pos0 / 64 : 0, a.seq / 64,
-                                                                               (a.cache_seq > 0 ? a.cache_seq : a.seq) / 64, 256);
+                                                                               (a.cache_seq > 0 ? a.cache_seq : a.seq) / 64, a.head_dim);
     MQ_LAUNCH_CHECK("mq_attention_quant(prefix)");
-    if (a.qk_out.scale != nullptr) attention_quant_kernel<256, true><<<cgrid, 256, 0, st>>>(a);
-    else attention_quant_kernel<256, false><<<cgrid, 256, 0, st>>>(a);
+    if (a.head_dim == 128) {
+      if (a.qk_out.scale != nullptr) attention_quant_kernel<128, true><<<cgrid, 256, 0, st>>>(a);
+      else attention_quant_kernel<128, false><<<cgrid, 256, 0, st>>>(a);
+    } else {
+      if (a.qk_out.scale != nullptr) attention_quant_kernel<256, true><<<cgrid, 256, 0, st>>>(a);
+      else attention_quant_kernel<256, false><<<cgrid, 256, 0, st>>>(a);
+    }
   }
   MQ_LAUNCH_CHECK("mq_attention_quant");
   return MQ_OK;

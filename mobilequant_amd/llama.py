@@ -147,7 +147,7 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         return out if resid is None else resid + out
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
-    if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim not in (64, 256) or S < 2
+    if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim not in (64, 128, 256) or S < 2
             or (pos != 0 and not isinstance(cache, ImageCache)) or pos % 64 or not getattr(mask, "_mq_causal", False)
             or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
             or Q._needs_grad(x, *self.parameters())):

@@ -528,8 +528,8 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     everything before them.  pos0 % 64 == 0 (every chunk but the last is a multiple of 64 long)."""
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
     D = int(head_dim)
-    if D not in (64, 256):
-        raise RuntimeError("mobilequant_amd: attention_quant serves head_dim 64 and 256")
+    if D not in (64, 128, 256):
+        raise RuntimeError("mobilequant_amd: attention_quant serves head_dim 64, 128 and 256")
     rot = cos.shape[-1]                  # partial rotary: cos / sin [S, rot_dim] with rot_dim < 64 (hf_model.py:489-500)
     if rot > D or rot % 2 or sin.shape != cos.shape:
         raise RuntimeError("mobilequant_amd: attention_quant cos / sin must be [S, rot_dim], rot_dim even and <= 64")

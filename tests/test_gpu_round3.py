@@ -504,14 +504,14 @@ def test_tiled_index_gemm_on_128_column_tiles_is_the_rowmajor_gemm(dev):
 
 
 # ---- prefill attention at head_dim 256 (Gemma: 8 heads, 1 KV head) -------------------------------------------------------------------
-@pytest.mark.parametrize("S,heads,kv_heads,qk_out_bits,pv_out_bits", [(64, 2, 1, 16, 8), (200, 8, 1, 16, 8), (320, 4, 2, 16, 8), (128, 2, 2, 0, 0)])
-def test_prefill_attention_head_dim_256_vs_oracle(dev, S, heads, kv_heads, qk_out_bits, pv_out_bits):
+@pytest.mark.parametrize("D,S,heads,kv_heads,qk_out_bits,pv_out_bits", [(256, 64, 2, 1, 16, 8), (256, 200, 8, 1, 16, 8), (256, 320, 4, 2, 16, 8),
+                                                                        (256, 128, 2, 2, 0, 0), (128, 200, 4, 2, 16, 8), (128, 128, 2, 1, 0, 0)])
+def test_prefill_attention_head_dim_256_vs_oracle(dev, D, S, heads, kv_heads, qk_out_bits, pv_out_bits):
     """mq_attention_quant at head_dim 256 (four MFMA k-steps per score tile, 16 output d-tiles, sum_t v from the prep kernel's prefix
     sums) against the numpy restatement of hf_model.py:486-534 and against its exact-integer form; the int8 output image in both
     layouts is the fp32 output's index image."""
     from test_gpu_round2 import _grid_of
     from mobilequant_amd import ops
-    D = 256
     q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, D, D, seed=7 * S + heads, qk_out_bits=qk_out_bits, pv_out_bits=pv_out_bits)
     want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
     grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
@@ -545,7 +545,8 @@ def test_prefill_attention_head_dim_256_vs_oracle(dev, S, heads, kv_heads, qk_ou
 
 
 # ---- chunked prefill: the fused attention continuing a cache of K / vT images ----------------------------------------------------------
-@pytest.mark.parametrize("D,heads,kv_heads,chunks", [(64, 4, 2, (128, 64, 100)), (256, 2, 1, (64, 128, 37)), (64, 2, 2, (192, 192))])
+@pytest.mark.parametrize("D,heads,kv_heads,chunks", [(64, 4, 2, (128, 64, 100)), (256, 2, 1, (64, 128, 37)), (64, 2, 2, (192, 192)),
+                                                     (128, 4, 1, (64, 64, 70))])
 def test_attention_quant_cache_continuation_is_the_single_shot_result(dev, D, heads, kv_heads, chunks):
     """mq_attention_quant with pos0 > 0: a sequence fed in chunks (each but the last a multiple of 64) through caller-owned K / vT image
     caches gives, row for row, the bits of the single call over the whole sequence (the same key blocks in the same order), and both
