@@ -991,6 +991,17 @@ def main():
             extras["calibration_dp"] = {"samples_per_s": round(cal["samples_per_s"], 2), "n_gpus": world, "samples": 8 * world, "layers": 2,
                                         "seq": 2048, "collectives": cal["collectives"], "scaling": "weak (8 samples per rank)"}
             torch.cuda.empty_cache()
+            # BASELINE.json configs[4] at its full size in every run of this file: 512 samples x S = 2048 through the 22-layer graph,
+            # sharded over the ranks (STRONG scaling: the driver's N = 1, 2, 4, 8 runs time the same 512 samples), GEMMs stubbed so the
+            # timed region is the hot path -- hooked reductions + ONE all-reduce (--workload calibration prints the same as the headline)
+            cal = calibration_run(dev, rank, world, layers=22, n_samples=512, seq=2048, per_channel=False, stub_gemm=True)
+            extras["calibration_512_stub_gemm"] = {
+                "samples_per_s": round(cal["samples_per_s"], 2), "seconds": round(cal["seconds"], 3), "n_gpus": world, "samples": 512, "layers": 22,
+                "seq": 2048, "collectives": cal["collectives"], "tensors_tracked": cal["tensors"], "scaling": "strong (512 samples over all ranks)",
+                "hooked_GB_per_sample": round(cal["hooked_bytes_per_sample"] / 1e9, 2),
+                "reduction_ms_per_sample": round(1e3 * cal["reduction_seconds_per_sample"], 3),
+                "reduction_GBps_per_gpu": round(cal["hooked_bytes_per_sample"] / max(cal["reduction_seconds_per_sample"], 1e-9) / 1e9, 1)}
+            torch.cuda.empty_cache()
         if rank == 0:
             # dominant kernel alone, HIP events on its stream
             t_gemm = event_time(step.gemm, 50)
