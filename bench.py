@@ -669,6 +669,83 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
     return res
 
 
+def bench_train_step(dev, S=2048):
+    """SURVEY 8(f) rank 3, measured: ONE inner step of e2equant (algorithm.py:692-760 under the deployment recipe's flags --lwc --let
+    --lrl --deactive_amp: fp32, 4-bit per-channel weights, learnable activation ranges, LET scales, LWC bound factors) on one
+    TinyLlama-shaped decoder layer at S tokens: smooth_lm_temporary -> quantized forward -> MSE against the fp layer's output ->
+    backward.  Every Quantizer.forward / backward in it is the HIP fake-quant pair (STE, clamp mask, LSQ gradients); the GEMMs and
+    the softmax are torch's fp32 library kernels, as in the reference.  (Parity of exactly this step: tests/golden/train_step.npz.)"""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import get_act_range
+    shape = llama.LlamaShape.tinyllama(layers=1, max_pos=S, vocab=4096)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=1337, std=0.05)
+    for lin in (m for m in model.layers[0].modules() if isinstance(m, torch.nn.Linear)):
+        lin.bias = torch.nn.Parameter(torch.zeros(lin.out_features))
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, shape.vocab, (1, S), generator=g).to(dev)
+    cos, sin = model.cos[:S], model.sin[:S]
+    mask = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    with torch.no_grad():
+        act = get_act_range(model, [ids])
+        x = model.embed_tokens(ids)
+        y_fp = model.layers[0](x, cos, sin, mask)
+    mq.create_sim_qmodel(model, mq.QuantConfig(bitwidth=4, is_per_channel=True), mq.QuantConfig(bitwidth=8))
+    layer = model.layers[0]
+    for name, mod in layer.named_modules():                 # ptq/mobilequant.py:175-201
+        if isinstance(mod, mq.QLinear) and "w2" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QLinear) and "o_proj" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QRMSNorm):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.is_symmetric = False
+            mod.weight_quantizer.qcfg.is_per_channel = False
+        elif isinstance(mod, mq.QMatMul) and "qk_bmm" in name:
+            mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, mq.QMatMul) and "pv_bmm" in name:
+            mod.input_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(model, act, "parameter")        # learnable ranges (--lrl)
+    for mod in layer.modules():
+        if isinstance(mod, (mq.QLinear, mq.QRMSNorm)):
+            mod.weight_quantizer.enable_lwc(mod.weight)
+    for name, width in (("qkv", shape.hidden), ("fc1", shape.hidden), ("out", shape.heads * shape.head_dim), ("fc2", shape.ffn)):   # in_features of the
+        # consumer linear, as algorithm.py:699-706 registers them (the v -> o pair itself only applies without GQA, algorithm.py:212)
+        layer.register_parameter(f"{name}_smooth_scale", torch.nn.Parameter(torch.ones(width, device=dev)))
+        layer.register_parameter(f"{name}_smooth_shift", torch.nn.Parameter(torch.zeros(width, device=dev)))
+    train = [p for n, p in layer.named_parameters() if any(t in n for t in ("bound_factor", "smooth_scale", "quantizer.scale", "quantizer.offset"))]
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    for p in train:
+        p.requires_grad_(True)
+    cfg = type("Cfg", (), dict(shared_attention_norm=False, num_linears_per_mlp=3))()
+    loss_fn = torch.nn.MSELoss()
+
+    def step():
+        for p in train:
+            p.grad = None
+        mq.smooth_lm_temporary(layer, cfg, True, False)
+        loss = loss_fn(y_fp, layer(x, cos, sin, mask))
+        loss.backward()
+        return loss
+    loss0 = float(step().detach())
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    peak = torch.cuda.max_memory_allocated(dev) / 1e9
+    grads = sum(1 for p in train if p.grad is not None and torch.isfinite(p.grad).all())
+    return {"ms_per_step": round(1e3 * sorted(times)[len(times) // 2], 2), "tokens": S, "loss": round(loss0, 6), "trainable_tensors": len(train),
+            "tensors_with_finite_grad": grads, "peak_GB": round(peak, 2),
+            "scope": f"one e2equant inner step (LET + LWC + learnable ranges, W4 per-channel / A8, fp32) on one TinyLlama-shaped layer, S = {S}, eager"}
+
+
 def _stub_gemms(model):
     """Replaces the forward of every nn.Linear and FMatMul by 'return a resident tensor of the output's shape' (one buffer per shape,
     N(0, 1) values, allocated at first use).  The hooks still receive -- and fully read -- inputs and outputs of the real shapes; what
@@ -945,6 +1022,8 @@ def bench_variants(dev, step, args):
     # BASELINE.json configs[2] / [3] on their own leaf graphs (LayerNorm + biased q|k|v + 25 % rotary; head_dim 256 / MQA / GeGLU / FFN 16384)
     extras["layer_prefill_full_stablelm_2_1_6b"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=8, family="stablelm_2_1_6b")
     extras["layer_prefill_full_gemma_2b_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4, family="gemma_2b")
+    extras["train_step_e2equant"] = bench_train_step(dev)
+    torch.cuda.empty_cache()
     torch.cuda.empty_cache()
     extras["other_configs"] = bench_other_configs(dev)
     torch.cuda.empty_cache()
