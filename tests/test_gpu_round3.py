@@ -593,3 +593,23 @@ def test_chunked_prefill_through_the_fused_model_matches_the_single_forward(dev)
         parts = [m(ids[:, :64], cache=cache, pos=0), m(ids[:, 64:S], cache=cache, pos=64)]
     torch.cuda.synchronize()
     assert torch.equal(torch.cat(parts, dim=1), whole)
+
+
+@pytest.mark.parametrize("rows,cols,layernorm", [(2048, 2048, False), (100, 2048, False), (2048, 1024, True), (77, 4096, True), (64, 2048, False)])
+def test_image_only_tiled_norm_is_the_rowmajor_image_in_the_fragment_blocked_layout(dev, rows, cols, layernorm):
+    """norm_tiled8_kernel (image-only, fragment-blocked output: eight rows per workgroup, LDS-staged whole-line stores) against the
+    generic norm kernel: same int8 indices (the row-major image, permuted) and row sums, RMSNorm and LayerNorm, ragged row counts."""
+    from mobilequant_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1.7).to(dev)
+    w = (1.0 + 0.1 * torch.randn(cols, generator=g)).to(dev)
+    b = (0.1 * torch.randn(cols, generator=g)).to(dev) if layernorm else None
+    gi = (torch.tensor([10.0 / 65535], device=dev), torch.tensor([32768.0], device=dev), 0.0, 65535.0)
+    go = (torch.tensor([8.0 / 255], device=dev), torch.tensor([128.0], device=dev), 0.0, 255.0)
+    _, q, rs, shift, _ = ops.rmsnorm_quant(x, w, b, 1e-5, gi, go, emit_int8=True, layernorm=layernorm, emit_tiled=False, want_y=False, emit_rowmajor=True)
+    _, _, rst, shift_t, qt = ops.rmsnorm_quant(x, w, b, 1e-5, gi, go, emit_int8=True, layernorm=layernorm, emit_tiled=True, want_y=False, emit_rowmajor=False)
+    torch.cuda.synchronize()
+    assert shift == shift_t and torch.equal(rs, rst)
+    Mp = (rows + 15) // 16 * 16
+    back = qt.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
+    assert torch.equal(back, q.view(rows, cols))
