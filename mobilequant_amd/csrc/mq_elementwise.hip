@@ -531,6 +531,65 @@ static int launch_quantize(const T* x, QT* q, int64_t rows, int64_t cols, const 
   return MQ_OK;
 }
 
+
+// fp32 rows of 1024 .. 4096 columns: loads along the rows (a wave reads 1 KiB runs), the int8 results staged in an LDS tile in the
+// image's order, stores as 128-byte runs (8 rows x 16 B: whole lines of a fragment block).  1024 threads = four groups of 256, two
+// rows each, every load in flight before the first conversion.  Same index arithmetic as quantize_tiled_kernel: identical images.
+template <int V, bool HAS_SUM>
+__global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __restrict__ x, int8_t* __restrict__ q, int64_t rows, int64_t cols,
+                                                               const float* __restrict__ scale, const float* __restrict__ offset, float qmin,
+                                                               float qmax, int shift, int32_t* __restrict__ row_sum) {
+  extern __shared__ __attribute__((aligned(16))) int8_t stage8[];   // [cols / 16 pieces][8 rows][16 B]
+  __shared__ int s_part[8][4];
+  const int grp = threadIdx.x >> 8, lane = threadIdx.x & 255, wv_id = (threadIdx.x >> 6) & 3;
+  const int nvec = (int)(cols >> 2);
+  const int64_t row0 = (int64_t)blockIdx.x * 8;
+  const float s = scale[0], o = offset[0];
+  const float inv_s = __fdiv_rn(1.0f, s);
+  float4 xs[2][V];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t row = row0 + grp * 2 + j;
+    const float4* xr = reinterpret_cast<const float4*>(x + (row < rows ? row : rows - 1) * cols);
+#pragma unroll
+    for (int k = 0; k < V; ++k) xs[j][k] = xr[lane + 256 * k < nvec ? lane + 256 * k : nvec - 1];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int i = lane + 256 * k;
+      if (i < nvec) {
+        const float f[4] = {xs[j][k].x, xs[j][k].y, xs[j][k].z, xs[j][k].w};
+        uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int st_v = static_cast<int>(q_index(f[e], s, inv_s, o, qmin, qmax)) - shift;
+          acc += st_v;
+          pk |= (static_cast<uint32_t>(st_v) & 0xffu) << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(stage8 + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
+      }
+    }
+    if (HAS_SUM) {
+      acc = mq::wave_sum(acc);
+      if ((threadIdx.x & 63) == 0) s_part[grp * 2 + j][wv_id] = acc;
+    }
+  }
+  __syncthreads();
+  if (HAS_SUM && threadIdx.x < 8 && row0 + threadIdx.x < rows)
+    row_sum[row0 + threadIdx.x] = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]);
+  const int units = (int)(cols >> 1);                               // 8 rows x cols / 16 sixteen-byte units
+  const int64_t rb = row0 >> 4;
+  const int half = (int)(row0 & 15);
+  for (int p = threadIdx.x; p < units; p += 1024) {                 // rows past `rows` are padding of the image: written like the others
+    const int piece = p >> 3, r8 = p & 7;
+    *reinterpret_cast<uint4*>(q + ((rb * (cols >> 6) + (piece >> 2)) << 10) + ((piece & 3) << 8) + ((half + r8) << 4)) =
+        *reinterpret_cast<const uint4*>(stage8 + (p << 4));
+  }
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -645,6 +704,12 @@ int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const floa
   return MQ_EUNSUPPORTED;
 }
 
+static std::atomic<int> g_tiled8{1};            // tuning hook: 0 = the lane-per-fragment kernel for every shape
+int mq_quantize_tiled_set_staged(int on) {
+  g_tiled8 = on ? 1 : 0;
+  return 0;
+}
+
 int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
                       float qmin, float qmax, int shift, const float* chan_scale, int8_t* q_tiled, int32_t* row_sum,
                       mq_stream_t stream) {
@@ -668,6 +733,19 @@ int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, cons
   if (chan_scale != nullptr) {       // the SmoothQuant form: x / chan_scale[k] in front of the same index arithmetic
     if (row_sum) quantize_tiled_kernel<float, true, 0, true><<<grid, 512, 0, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum, chan_scale);
     else quantize_tiled_kernel<float, false, 0, true><<<grid, 512, 0, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum, chan_scale);
+  } else if (dtype == MQ_F32 && cols >= 1024 && cols <= 4096 && cols % 1024 == 0 && rows >= 64 && g_tiled8.load()) {
+    const unsigned grid8 = (unsigned)(((rows + 15) / 16) * 2);
+    const size_t lds = (size_t)cols * 8;
+#define MQ_QT8(V)                                                                                                                              \
+  do {                                                                                                                                         \
+    if (row_sum) quantize_tiled8_kernel<V, true><<<grid8, 1024, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);  \
+    else quantize_tiled8_kernel<V, false><<<grid8, 1024, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);        \
+  } while (0)
+    if (cols == 1024) MQ_QT8(1);
+    else if (cols == 2048) MQ_QT8(2);
+    else if (cols == 3072) MQ_QT8(3);
+    else MQ_QT8(4);
+#undef MQ_QT8
   } else if (dtype == MQ_F32) {
     if (kblocks == 32) MQ_QT(float, 2);            // K = 2048: 2 steps of 2 k blocks per wave, all in flight
     else if (kblocks == 16) MQ_QT(float, 1);

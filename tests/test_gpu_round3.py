@@ -613,3 +613,25 @@ def test_image_only_tiled_norm_is_the_rowmajor_image_in_the_fragment_blocked_lay
     Mp = (rows + 15) // 16 * 16
     back = qt.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
     assert torch.equal(back, q.view(rows, cols))
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 2048), (100, 2048), (333, 1024), (64, 4096), (2048, 3072)])
+def test_staged_quantize_tiled_writes_the_same_image(dev, rows, cols):
+    """mq_quantize_tiled's LDS-staged eight-row kernel (fp32, 1024 <= cols <= 4096) against the lane-per-fragment kernel it replaces there:
+    the same bytes (padding rows included where both write them) and row sums."""
+    import mobilequant_amd._lib as L
+    from mobilequant_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2.0).to(dev)
+    sc, of = torch.tensor([0.031], device=dev), torch.tensor([131.0], device=dev)
+    L.load().mq_quantize_tiled_set_staged(0)
+    try:
+        q0, rs0 = ops.quantize_tiled(x, sc, of, 0.0, 255.0, 128)
+    finally:
+        L.load().mq_quantize_tiled_set_staged(1)
+    q1, rs1 = ops.quantize_tiled(x, sc, of, 0.0, 255.0, 128)
+    torch.cuda.synchronize()
+    assert torch.equal(rs0, rs1)
+    Mp = q0.shape[0]
+    un = lambda q: q.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]      # noqa: E731
+    assert torch.equal(un(q0), un(q1))

@@ -41,31 +41,33 @@ def operands(M, N, K):
     return a_q, w_q, a_rs, alpha, w_zp, col_term
 
 
-for name, (M, N, K) in (("o_proj", (2048, 2048, 2048)), ("w2", (2048, 2048, 5632)), ("gemma w2", (2048, 2048, 16384)), ("M=4096 o", (4096, 2048, 2048))):
-    a_q, w_q, a_rs, alpha, w_zp, col_term = operands(M, N, K)
+if __name__ == "__main__":
+    for name, (M, N, K) in (("o_proj", (2048, 2048, 2048)), ("w2", (2048, 2048, 5632)), ("gemma w2", (2048, 2048, 16384)), ("M=4096 o", (4096, 2048, 2048))):
+        a_q, w_q, a_rs, alpha, w_zp, col_term = operands(M, N, K)
+        a_t = to_tiled(a_q)
+        resid = torch.randn(M, N, device=dev)
+        out = torch.empty(M, N, device=dev)
+        so, oo = torch.tensor([3.1e-4], device=dev), torch.tensor([32768.0], device=dev)
+        kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0, resid=resid, out=out)
+        t_old = timed(lambda: ops.int8_linear(a_q, w_q, a_rs, alpha, w_zp, col_term, None, **kw))
+        res = [f"rowmajor C++ {t_old:6.2f} us"]
+        for tile in (128, 256):
+            L.load().mq_gemm_set_residual_tile(tile)
+            t = timed(lambda: ops.int8_linear(a_t, w_q, a_rs, alpha, w_zp, col_term, None, a_tiled_rows=M, **kw))
+            res.append(f"tiled {tile}-row {t:6.2f} us ({2.0 * M * N * K / t / 1e6:7.1f} TOPS)")
+        L.load().mq_gemm_set_residual_tile(0)
+        print(f"{name:10s} {M}x{N}x{K}: " + " | ".join(res), flush=True)
+
+    M, K, ends = 2048, 2048, (2048, 2304, 2560)
+    a_q, w_q, a_rs, alpha, w_zp, col_term = operands(M, ends[-1], K)
     a_t = to_tiled(a_q)
-    resid = torch.randn(M, N, device=dev)
-    out = torch.empty(M, N, device=dev)
-    so, oo = torch.tensor([3.1e-4], device=dev), torch.tensor([32768.0], device=dev)
-    kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0, resid=resid, out=out)
-    t_old = timed(lambda: ops.int8_linear(a_q, w_q, a_rs, alpha, w_zp, col_term, None, **kw))
-    res = [f"rowmajor C++ {t_old:6.2f} us"]
-    for tile in (128, 256):
-        L.load().mq_gemm_set_residual_tile(tile)
-        t = timed(lambda: ops.int8_linear(a_t, w_q, a_rs, alpha, w_zp, col_term, None, a_tiled_rows=M, **kw))
-        res.append(f"tiled {tile}-row {t:6.2f} us ({2.0 * M * N * K / t / 1e6:7.1f} TOPS)")
-    L.load().mq_gemm_set_residual_tile(0)
-    print(f"{name:10s} {M}x{N}x{K}: " + " | ".join(res), flush=True)
+    grids = [(torch.tensor([0.011 * (i + 1)], device=dev), torch.tensor([100.0 + 20 * i], device=dev)) for i in range(3)]
+    t_old = timed(lambda: ops.int8_linear_segmented(a_q, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids))
+    t_new = timed(lambda: ops.int8_linear_segmented(a_t, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids, a_tiled_rows=M))
+    print(f"q|k|v      {M}x{ends[-1]}x{K}: rowmajor C++ {t_old:6.2f} us | tiled {t_new:6.2f} us ({2.0 * M * ends[-1] * K / t_new / 1e6:7.1f} TOPS)  (both allocate their output)")
 
-M, K, ends = 2048, 2048, (2048, 2304, 2560)
-a_q, w_q, a_rs, alpha, w_zp, col_term = operands(M, ends[-1], K)
-a_t = to_tiled(a_q)
-grids = [(torch.tensor([0.011 * (i + 1)], device=dev), torch.tensor([100.0 + 20 * i], device=dev)) for i in range(3)]
-t_old = timed(lambda: ops.int8_linear_segmented(a_q, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids))
-t_new = timed(lambda: ops.int8_linear_segmented(a_t, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids, a_tiled_rows=M))
-print(f"q|k|v      {M}x{ends[-1]}x{K}: rowmajor C++ {t_old:6.2f} us | tiled {t_new:6.2f} us ({2.0 * M * ends[-1] * K / t_new / 1e6:7.1f} TOPS)  (both allocate their output)")
+    table = torch.randint(-128, 128, (65536,), dtype=torch.int8, device=dev)
+    a = torch.randint(0, 256, (2048, 5632), dtype=torch.uint8, device=dev)
+    b = torch.randint(0, 256, (2048, 5632), dtype=torch.uint8, device=dev)
+    print(f"gated_lookup 2048x5632: rowmajor {timed(lambda: ops.gated_lookup(a, b, table)):6.2f} us | tiled {timed(lambda: ops.gated_lookup(a, b, table, tiled=True)):6.2f} us")
 
-table = torch.randint(-128, 128, (65536,), dtype=torch.int8, device=dev)
-a = torch.randint(0, 256, (2048, 5632), dtype=torch.uint8, device=dev)
-b = torch.randint(0, 256, (2048, 5632), dtype=torch.uint8, device=dev)
-print(f"gated_lookup 2048x5632: rowmajor {timed(lambda: ops.gated_lookup(a, b, table)):6.2f} us | tiled {timed(lambda: ops.gated_lookup(a, b, table, tiled=True)):6.2f} us")
