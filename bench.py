@@ -727,10 +727,12 @@ def bench_train_step(dev, S=2048):
     def step():
         for p in train:
             p.grad = None
-        mq.smooth_lm_temporary(layer, cfg, True, False)
-        loss = loss_fn(y_fp, layer(x, cos, sin, mask))
-        loss.backward()
+        with torch.enable_grad():                           # (the variant legs run under no_grad)
+            mq.smooth_lm_temporary(layer, cfg, True, False)
+            loss = loss_fn(y_fp, layer(x, cos, sin, mask))
+            loss.backward()
         return loss
+    torch.cuda.reset_peak_memory_stats(dev)
     loss0 = float(step().detach())
     torch.cuda.synchronize()
     times = []
