@@ -635,3 +635,29 @@ def test_staged_quantize_tiled_writes_the_same_image(dev, rows, cols):
     Mp = q0.shape[0]
     un = lambda q: q.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]      # noqa: E731
     assert torch.equal(un(q0), un(q1))
+
+
+def test_decode_engine_switches_to_the_split_attention_graph_on_a_long_cache(dev):
+    """DecodeEngine(attn_splits=None) records two step graphs when the cache is longer than LONG_FROM and replays the split-attention one
+    from LONG_FROM cached positions on: the logits are those of a one-workgroup-per-head engine, bit for bit, on both sides of the
+    switch (the split launch's int64 partials are combined in ticket order)."""
+    import dataclasses
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd import llama
+    from mobilequant_amd.decode import DecodeEngine
+    m, _ = _decode_model(dev)
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=1024))
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    auto = DecodeEngine(m, cache_len=1024)
+    one = DecodeEngine(m, cache_len=1024, attn_splits=1)
+    assert auto.auto_splits and not one.auto_splits
+    for eng in (auto, one):
+        eng.fill_cache_random(DecodeEngine.LONG_FROM - 2, seed=3)
+        eng.capture()
+    assert auto.graph_long is not None and one.graph_long is None
+    for t in (5, 17, 40, 3, 90):                         # two steps below LONG_FROM, three from it on
+        a = auto.step(t).clone()
+        b = one.step(t).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (auto._host_pos, float((a - b).abs().max()))
+    assert auto._host_pos == DecodeEngine.LONG_FROM + 3
