@@ -31,6 +31,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 #pragma clang fp contract(off)
 
+#ifndef MQ_ATT_ECACHE
+#define MQ_ATT_ECACHE 4   // key blocks per row block whose sweep-1 exponentials are kept for sweep 2 (16 KiB of LDS each: 64 KiB = two workgroups per CU)
+#endif
+
 struct AGrid {
   float s, o, qmin, qmax, inv_s;
   bool on;
@@ -374,12 +378,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   // stand in for the row maximum: no running max, no rescale, no dependency between blocks -- exp2((f - top) c) can neither overflow
   // nor flush the row's largest term, and the common factor cancels in e / l like the rounding of R does.
   const bool fixed_ref = QK_OUT && (fhi - flo) * cexp < 96.f;
+  // With the grid top as reference exponent the sweep-1 exponentials ARE the sweep-2 ones (no rescale in between): those of a row
+  // block's LAST kEC key blocks are parked in the LDS (a thread reads back only what it wrote: no barrier), and sweep 2 takes them from
+  // there instead of recomputing scores, grid and exp2 -- ~70 % of a block's sweep-2 instructions for min(kEC, nkb) / nkb of the blocks.
+  constexpr int kEC = D == 64 ? MQ_ATT_ECACHE : 0;
+  __shared__ float s_e[kEC > 0 ? kEC : 1][16][kEC > 0 ? 256 : 1];
   auto sweep1_fixed = [&](const int (&ti)[16], int kb) {
     float f[16];
     grid_scores(ti, kb == kdiag, kb, f);
     float bs = 0.f;
+    float ex[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bs += fast_exp2(__builtin_fmaf(f[i], cexp, -R));
+    for (int i = 0; i < 16; ++i) {
+      ex[i] = fast_exp2(__builtin_fmaf(f[i], cexp, -R));
+      bs += ex[i];
+    }
+    if constexpr (kEC > 0) {
+      const int slot = kb - (nkb - kEC);
+      if (slot >= 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_e[slot][i][threadIdx.x] = ex[i];
+      }
+    }
     l += bs;
   };
   if constexpr (D != 64) {
@@ -440,6 +460,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) t.vf[dt] = *reinterpret_cast<const v4i*>(vt + (16 * dt + srow) * 64 + tq * 16);   // rows d, key-permuted
   };
+  auto probs_from = [&](const float (&exv)[16], v4i& pf_hi, v4i& pf_lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(exv[4 * j + e], rp, pbias), plo, phi);
+        b[e] = __float_as_uint(g);
+      }
+      const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+      const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u), hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
+      psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
+      psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+      pf_lo[j] = (int)(lo ^ 0x80808080u);
+      pf_hi[j] = (int)(hi ^ 0x80808080u);
+    }
+  };
   auto probs = [&](const int (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo) {
     float f[16];
     grid_scores(ti, kb == kdiag, kb, f);
@@ -463,14 +500,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   if constexpr (D == 64) {
     KTile t;
     VTile vt;
-    load_k(0, t);
+    const int nrec = (kEC > 0 && fixed_ref) ? (nkb - kEC > 0 ? nkb - kEC : 0) : nkb;     // blocks whose scores are recomputed
+    if (nrec > 0) load_k(0, t);
     load_v(0, vt);
     for (int kb = 0; kb < nkb; ++kb) {
-      int ti[16];
-      int_scores(t, ti);
-      if (kb + 1 < nkb) load_k(kb + 1, t);
       v4i pf_hi, pf_lo;
-      probs(ti, kb, pf_hi, pf_lo);
+      if (kb < nrec) {
+        int ti[16];
+        int_scores(t, ti);
+        if (kb + 1 < nrec) load_k(kb + 1, t);
+        probs(ti, kb, pf_hi, pf_lo);
+      } else {
+        float exv[16];
+        const int slot = kb - (nkb - kEC);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? slot : 0][i][kEC > 0 ? threadIdx.x : 0];
+        probs_from(exv, pf_hi, pf_lo);
+      }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
