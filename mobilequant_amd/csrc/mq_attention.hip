@@ -31,6 +31,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 #pragma clang fp contract(off)
 
+#ifndef MQ_ATT_EREGS
+#define MQ_ATT_EREGS 5    // ... and of the blocks in front of those, kept in registers (16 VGPRs each; two waves per SIMD leave room)
+#endif
 #ifndef MQ_ATT_ECACHE
 #define MQ_ATT_ECACHE 4   // key blocks per row block whose sweep-1 exponentials are kept for sweep 2 (16 KiB of LDS each: 64 KiB = two workgroups per CU)
 #endif
@@ -230,7 +233,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // d-tiles (128 accumulator registers: one wave per SIMD), v tiles loaded per d-tile, and sum_t v[t][d] from the prep kernel's prefix
 // sums instead of an all-ones MFMA.
 template <int D, bool QK_OUT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : (D == 128 ? 2 : 1), D == 64 ? 3 : (D == 128 ? 2 : 1))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : 2, D == 256 ? 1 : 2)))
     attention_quant_kernel(const mq_attention_args a) {
   static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
   constexpr int NKS = D / 64, NDT = D / 16;
@@ -383,24 +386,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   // there instead of recomputing scores, grid and exp2 -- ~70 % of a block's sweep-2 instructions for min(kEC, nkb) / nkb of the blocks.
   constexpr int kEC = D == 64 ? MQ_ATT_ECACHE : 0;
   __shared__ float s_e[kEC > 0 ? kEC : 1][16][kEC > 0 ? 256 : 1];
-  auto sweep1_fixed = [&](const int (&ti)[16], int kb) {
+  constexpr int kER = D == 64 ? MQ_ATT_EREGS : 0;                    // ... and those of the kER blocks in front of them in registers
+  const int n_lds0 = nkb - kEC > 0 ? nkb - kEC : 0;                 // first block parked in the LDS
+  const int n_reg0 = n_lds0 - kER > 0 ? n_lds0 - kER : 0;           // first block parked in registers (blocks before it are recomputed)
+  float ereg[kER > 0 ? kER : 1][16];
+  auto exps = [&](const int (&ti)[16], int kb, float (&ex)[16]) {
     float f[16];
     grid_scores(ti, kb == kdiag, kb, f);
     float bs = 0.f;
-    float ex[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       ex[i] = fast_exp2(__builtin_fmaf(f[i], cexp, -R));
       bs += ex[i];
     }
+    l += bs;
+  };
+  auto sweep1_fixed = [&](const int (&ti)[16], int kb) {
+    float ex[16];
+    exps(ti, kb, ex);
     if constexpr (kEC > 0) {
-      const int slot = kb - (nkb - kEC);
-      if (slot >= 0) {
+      if (kb >= n_lds0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s_e[slot][i][threadIdx.x] = ex[i];
+        for (int i = 0; i < 16; ++i) s_e[kb - n_lds0][i][threadIdx.x] = ex[i];
       }
     }
-    l += bs;
   };
   if constexpr (D != 64) {
     if (fixed_ref) R = fhi * cexp;
@@ -423,7 +432,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
     load_k(0, t);
     if (fixed_ref) {
       R = fhi * cexp;
-      for (int kb = 0; kb < nkb; ++kb) {
+      for (int kb = 0; kb < n_reg0; ++kb) {
+        int ti[16];
+        int_scores(t, ti);
+        if (kb + 1 < nkb) load_k(kb + 1, t);
+        sweep1_fixed(ti, kb);
+      }
+      if constexpr (kER > 0) {
+#pragma unroll
+        for (int u = 0; u < kER; ++u) {                              // static register indices: the loop is unrolled, the guard wave-uniform
+          const int kb = n_reg0 + u;
+          if (kb < n_lds0) {
+            int ti[16];
+            int_scores(t, ti);
+            if (kb + 1 < nkb) load_k(kb + 1, t);
+            exps(ti, kb, ereg[u]);
+          }
+        }
+      }
+      for (int kb = n_lds0; kb < nkb; ++kb) {
         int ti[16];
         int_scores(t, ti);
         if (kb + 1 < nkb) load_k(kb + 1, t);
@@ -500,23 +527,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
   if constexpr (D == 64) {
     KTile t;
     VTile vt;
-    const int nrec = (kEC > 0 && fixed_ref) ? (nkb - kEC > 0 ? nkb - kEC : 0) : nkb;     // blocks whose scores are recomputed
+    const int nrec = fixed_ref ? n_reg0 : nkb;                       // blocks whose scores are recomputed
     if (nrec > 0) load_k(0, t);
     load_v(0, vt);
-    for (int kb = 0; kb < nkb; ++kb) {
-      v4i pf_hi, pf_lo;
-      if (kb < nrec) {
-        int ti[16];
-        int_scores(t, ti);
-        if (kb + 1 < nrec) load_k(kb + 1, t);
-        probs(ti, kb, pf_hi, pf_lo);
-      } else {
-        float exv[16];
-        const int slot = kb - (nkb - kEC);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? slot : 0][i][kEC > 0 ? threadIdx.x : 0];
-        probs_from(exv, pf_hi, pf_lo);
-      }
+    auto pv_block = [&](int kb, const v4i& pf_hi, const v4i& pf_lo) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
@@ -524,6 +538,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6
         acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vt.vf[dt], ones, acc_v[dt], 0, 0, 0);
       }
       if (kb + 1 < nkb) load_v(kb + 1, vt);
+    };
+    for (int kb = 0; kb < nrec; ++kb) {
+      v4i pf_hi, pf_lo;
+      int ti[16];
+      int_scores(t, ti);
+      if (kb + 1 < nrec) load_k(kb + 1, t);
+      probs(ti, kb, pf_hi, pf_lo);
+      pv_block(kb, pf_hi, pf_lo);
+    }
+    if (fixed_ref) {
+      if constexpr (kER > 0) {
+#pragma unroll
+        for (int u = 0; u < kER; ++u) {
+          const int kb = n_reg0 + u;
+          if (kb < n_lds0) {
+            v4i pf_hi, pf_lo;
+            probs_from(ereg[u], pf_hi, pf_lo);
+            pv_block(kb, pf_hi, pf_lo);
+          }
+        }
+      }
+      for (int kb = n_lds0; kb < nkb; ++kb) {
+        v4i pf_hi, pf_lo;
+        float exv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
+        probs_from(exv, pf_hi, pf_lo);
+        pv_block(kb, pf_hi, pf_lo);
+      }
     }
   } else {
     dma_block(0, 0, true);
