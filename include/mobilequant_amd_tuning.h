@@ -23,6 +23,9 @@ int mq_gemm_set_residual_tile(int rows);
 /* mq_quantize_tiled: 1 (default) = the LDS-staged eight-row kernel where it applies (fp32, 1024 <= cols <= 4096), 0 = the
  * lane-per-fragment kernel for every shape (A/B timing; identical images). */
 int mq_quantize_tiled_set_staged(int on);
+/* mq_attention_quant at head_dim 64: 1 = small exponential cache (two key blocks in the LDS, three waves per SIMD), anything else =
+ * the deep cache (four blocks in the LDS + five in registers, two waves per SIMD; default).  Identical results. */
+int mq_attention_set_cache(int mode);
 
 #ifdef __cplusplus
 }

@@ -232,8 +232,11 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // D = 64: the tuned kernel (three waves per SIMD).  D = 256 (Gemma: 8 heads / 1 KV head): four MFMA k-steps per score tile, 16 output
 // d-tiles (128 accumulator registers: one wave per SIMD), v tiles loaded per d-tile, and sum_t v[t][d] from the prep kernel's prefix
 // sums instead of an all-ones MFMA.
-template <int D, bool QK_OUT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : 2, D == 256 ? 1 : 2)))
+// BIG (head_dim 64): the deep exponential cache (four blocks in the LDS, five in registers: two waves per SIMD), the production
+// configuration; !BIG: two blocks in the LDS, three waves per SIMD (mq_attention_set_cache(1), A/B timing).  Prep + core at S = 2048,
+// deep vs small: 77.3 vs 85.6 us (32 / 4 heads), 73.5 vs 82.8 (32 / 8), 80.6 vs 93.5 (32 / 32); identical images.
+template <int D, bool QK_OUT, bool BIG = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2), D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2))))
     attention_quant_kernel(const mq_attention_args a) {
   static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
   constexpr int NKS = D / 64, NDT = D / 16;
@@ -384,9 +387,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
   // With the grid top as reference exponent the sweep-1 exponentials ARE the sweep-2 ones (no rescale in between): those of a row
   // block's LAST kEC key blocks are parked in the LDS (a thread reads back only what it wrote: no barrier), and sweep 2 takes them from
   // there instead of recomputing scores, grid and exp2 -- ~70 % of a block's sweep-2 instructions for min(kEC, nkb) / nkb of the blocks.
-  constexpr int kEC = D == 64 ? MQ_ATT_ECACHE : 0;
+  constexpr int kEC = D == 64 ? (BIG ? MQ_ATT_ECACHE : 2) : 0;
   __shared__ float s_e[kEC > 0 ? kEC : 1][16][kEC > 0 ? 256 : 1];
-  constexpr int kER = D == 64 ? MQ_ATT_EREGS : 0;                    // ... and those of the kER blocks in front of them in registers
+  constexpr int kER = D == 64 && BIG ? MQ_ATT_EREGS : 0;                    // ... and those of the kER blocks in front of them in registers
   const int n_lds0 = nkb - kEC > 0 ? nkb - kEC : 0;                 // first block parked in the LDS
   const int n_reg0 = n_lds0 - kER > 0 ? n_lds0 - kER : 0;           // first block parked in registers (blocks before it are recomputed)
   float ereg[kER > 0 ? kER : 1][16];
@@ -637,6 +640,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
 
 using namespace mq;
 
+static std::atomic<int> g_att_cache{0};       // tuning hook: 1 = small exponential cache, anything else = the deep cache
+extern "C" int mq_attention_set_cache(int mode) {
+  g_att_cache = mode == 1 ? 1 : 0;
+  return 0;
+}
+
 extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_attention_quant: null argument block");
   const mq_attention_args& a = *args;
@@ -671,8 +680,10 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   if (a.head_dim == 64) {
     attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
-    if (a.qk_out.scale != nullptr) attention_quant_kernel<64, true><<<cgrid, 256, 0, st>>>(a);
-    else attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
+    const bool big = g_att_cache.load() != 1;
+    if (a.qk_out.scale == nullptr) attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
+    else if (big) attention_quant_kernel<64, true, true><<<cgrid, 256, 0, st>>>(a);
+    else attention_quant_kernel<64, true><<<cgrid, 256, 0, st>>>(a);
   } else {
     if (a.head_dim == 128) attention_prep_kernel<128><<<pgrid, 256, 0, st>>>(a);
     else attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a);
