@@ -661,3 +661,28 @@ def test_decode_engine_switches_to_the_split_attention_graph_on_a_long_cache(dev
         torch.cuda.synchronize()
         assert torch.equal(a, b), (auto._host_pos, float((a - b).abs().max()))
     assert auto._host_pos == DecodeEngine.LONG_FROM + 3
+
+
+@pytest.mark.parametrize("S,heads,kv_heads", [(704, 4, 1), (130, 2, 2), (1024, 2, 1)])
+def test_attention_exponential_cache_depth_does_not_change_a_bit(dev, S, heads, kv_heads):
+    """head_dim 64: the sweep-1 exponentials of the last key blocks are reused by sweep 2 (deep cache: four blocks in the LDS + five in
+    registers; small cache: two in the LDS).  Both configurations -- and so every mix of recomputed / parked blocks, S = 704 has eleven
+    key blocks -- give the same image and row sums, and the deep one stays on the oracle."""
+    import mobilequant_amd._lib as L
+    from test_gpu_round2 import _grid_of
+    from mobilequant_amd import ops
+    q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, 64, 64, seed=S)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(a).to(dev)                       # noqa: E731
+    outs = []
+    for mode in (1, 0):
+        L.load().mq_attention_set_cache(mode)
+        try:
+            outs.append(ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids))
+        finally:
+            L.load().mq_attention_set_cache(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
+    assert np.abs(outs[1].cpu().numpy() - want).max() <= 1.001 * float(pv[2].scale)
