@@ -202,6 +202,17 @@ int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64
                               const float* out_scale1, const float* out_offset1, void* out1, int out_dtype,
                               mq_stream_t stream);
 
+/* The gated FFN's first three modules in TWO launches: w1 as mq_w8a8_linear_tiled (indices into idx_scratch [M, N] u8), then w3 on
+ * the same program whose epilogue looks (w1 index, w3 index) up in `table` (mq_gated_table; 64 KiB, LDS-resident) and writes w2's int8
+ * input image q_tiled (fragment-blocked [ceil16(M), N]) + row_sum [M] -- what mq_w8a8_linear_tiled_pair + mq_gated_lookup_tiled
+ * produce in two launches and 35 MB more traffic; bit-identical image and row sums.  Shapes as the pair launch, N % 64 == 0. */
+int mq_w8a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                               const int8_t* w0, const float* alpha0, const int32_t* w_zp0, const int32_t* col_term0,
+                               const float* bias0, const float* out_scale0, const float* out_offset0,
+                               const int8_t* w1, const float* alpha1, const int32_t* w_zp1, const int32_t* col_term1,
+                               const float* bias1, const float* out_scale1, const float* out_offset1,
+                               const int8_t* table, uint8_t* idx_scratch, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream);
+
 /* Decode shapes (M <= 8 tokens, M*K < 64 KiB, K % 256 == 0): the activation quantizer (qmodule.py:349-351) fused
  * into the weight-streaming GEMV -- x is the fp32 [M,K] activation, quantised on the fly to its grid
  * (a_scale/a_offset: 1 element; a_shift as in mq_quantize) with the row sums reduced in LDS; alpha / w_zp /

@@ -30,6 +30,7 @@
 #include "mq_gemm_pp_asm.inc"
 #include "mq_gemm_fr_asm.inc"
 #include "mq_gemm_fr128_asm.inc"
+#include "mq_gemm_frg_asm.inc"
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
 
@@ -66,6 +67,14 @@ struct GemmArgs {
   int seg_end[2];
   const float* seg_scale[2];
   const float* seg_offset[2];
+  // gated pair (mq_w8a8_linear_tiled_gated): the first launch (w1) also zeroes the row sums the second one accumulates into; the
+  // second launch (w3, gemm_i8_frg_kernel) reads w1's indices back and writes w2's input image through the gated table
+  int32_t* zero_buf;
+  int zero_count;
+  const uint8_t* gate_aidx;     // w1's u8 output indices [M, N] row-major
+  const int8_t* gate_table;     // [256][256] (mq_gated_table)
+  int8_t* gate_q;               // w2's input image, fragment-blocked [ceil16(M), N]
+  int32_t* gate_rowsum;         // [M], zeroed by the first launch
 };
 
 #ifndef MQ_PP_PRIO
@@ -739,6 +748,10 @@ __global__ void __launch_bounds__(64 * WM * WN)
 // the per-lane addresses and the scalar arguments.  256 x 176 tile, fragment-blocked activations, int8 weights, 8-bit
 // UNSIGNED output grid (u8 storage, or i8 storage = index - 128), K % 256 == 0, K >= 768.
 __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, int nblk) {
+  if (args.zero_buf != nullptr) {                                   // (gated pair, first launch: 512 ints per workgroup)
+    const int zi = bid * 512 + (int)threadIdx.x;
+    if (zi < args.zero_count) args.zero_buf[zi] = 0;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
@@ -923,6 +936,83 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
   a.grid_m = (a.M + BMT - 1) / BMT;
   a.grid_n = a.N / 128;
   gemm_i8_fr128_kernel<VAR><<<a.grid_m * a.grid_n, VAR == FR128R ? 256 : 512, LDS, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
+}
+
+// ---- w3 of a gated FFN with the gate in its epilogue (tools/gen_fr_asm.py variant frg) ------------------------------------------------
+// The free-running 256 x 176 program; its epilogue turns the tile's 8-bit output indices and w1's (gate_aidx, written by the launch
+// before) into w2's int8 input image through the LDS-resident 64-KiB gated table: no index tensor of w3, no lookup launch.
+__global__ void __launch_bounds__(512) gemm_i8_frg_kernel(const GemmArgs args) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 176;
+  const int M = args.M, N = args.N, K = args.K;
+  const int KT = K / BK;
+  unsigned sw[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int row = n0 + (wave + i * 8) * 8 + (lane >> 3);
+    row = row < N ? row : N - 1;
+    sw[i] = (unsigned)row * (unsigned)K + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+  }
+  const int m0w = m0 + wave * 32;
+  const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+  unsigned rb0 = (unsigned)(m0w >> 4), rb1 = rb0 + 1;
+  rb0 = rb0 < rb_max ? rb0 : rb_max;
+  rb1 = rb1 < rb_max ? rb1 : rb_max;
+  const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  unsigned rsofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0w + i * 16 + (lane & 15);
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
+    rsofs[i] = (unsigned)m * 4u;
+  }
+  const float so = args.out_scale[0], oo = args.out_offset[0];
+  const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
+  const int oo_bits = __builtin_amdgcn_readfirstlane(__float_as_int(oo));
+  const int8_t* a_ptr = args.a;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  const float* alpha_p = args.alpha + n0;
+  const float* bias_p = args.bias + n0;
+  const int32_t* wzp_p = args.w_zp + n0;
+  const int32_t* ct_p = args.col_term + n0;
+  const int32_t* rs_p = args.a_rowsum;
+  const uint8_t* aidx = args.gate_aidx + (size_t)m0w * N + n0;
+  const int8_t* table = args.gate_table;
+  int8_t* qout = args.gate_q;
+  int32_t* rsout = args.gate_rowsum + m0w;
+  const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
+  const int cg0 = __builtin_amdgcn_readfirstlane(tn * 11), mb0 = __builtin_amdgcn_readfirstlane(m0w >> 4);
+  const unsigned tid = threadIdx.x;
+  asm volatile(MQ_FRG_ASM_BODY
+               :
+               : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [aidx] "s"(aidx), [alpha] "s"(alpha_p),
+                 [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),
+                 [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [table] "s"(table), [qout] "s"(qout), [rsout] "s"(rsout),
+                 [cg0] "s"(cg0), [mb0] "s"(mb0), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [sw2] "v"(sw[2]), [av0] "v"(av0), [av1] "v"(av1),
+                 [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
+               : MQ_FRG_ASM_CLOBBERS);
+}
+
+static int launch_frg(const GemmArgs& a, hipStream_t st) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_FRG_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", MQ_FRG_LDS_BYTES, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  gemm_i8_frg_kernel<<<a.grid_m * a.grid_n, 512, MQ_FRG_LDS_BYTES, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
 }
@@ -1379,6 +1469,47 @@ int mq_w8a8_linear_tiled_segmented(const int8_t* a_tiled, const int8_t* w, int64
     g.seg_offset[i - 1] = grids[i].offset;
   }
   return launch_fr128<FR128>(g, as_stream(stream));
+}
+
+int mq_w8a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                               const int8_t* w0, const float* alpha0, const int32_t* w_zp0, const int32_t* col_term0,
+                               const float* bias0, const float* out_scale0, const float* out_offset0,
+                               const int8_t* w1, const float* alpha1, const int32_t* w_zp1, const int32_t* col_term1,
+                               const float* bias1, const float* out_scale1, const float* out_offset1,
+                               const int8_t* table, uint8_t* idx_scratch, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream) {
+  const char* fn = "mq_w8a8_linear_tiled_gated";
+  int rc = check_common(fn, a_tiled, w0, M, N, K, a_rowsum, alpha0, w_zp0, col_term0, bias0, out_scale0, out_offset0, idx_scratch, 1);
+  if (rc != MQ_OK) return rc;
+  rc = check_common(fn, a_tiled, w1, M, N, K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1, q_tiled, 1);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32) && ((M + 15) / 16) * 16 * N < (1ll << 32), "%s: operand too large", fn);
+  MQ_REQUIRE(out_scale0 && out_scale1 && table && row_sum && aligned(table, 16) && aligned(idx_scratch, 16) && aligned(q_tiled, 16),
+             "%s: both linears carry an 8-bit unsigned output grid; table / scratch / image must be non-null and 16-byte aligned", fn);
+  GemmArgs g0{a_tiled, w0, (int)M, (int)N, (int)K, a_rowsum, alpha0, w_zp0, col_term0, bias0, out_scale0, out_offset0,
+              0.f, 255.f, idx_scratch, MQ_U8, 0, 0, bias0 != nullptr, 1, 0, g_dbg_ts};
+  GemmArgs g1{a_tiled, w1, (int)M, (int)N, (int)K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1,
+              0.f, 255.f, q_tiled, MQ_U8, 0, 0, bias1 != nullptr, 1, 0, g_dbg_ts};
+  if (!gemm_tiled_supported(M, N, K) || !gemm_fr_supported(g0) || N % 64 != 0 || M > 256 * 512) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled_supported, K %% 256 == 0, K >= 768, N %% 64 == 0)", fn, (long long)M,
+              (long long)N, (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  for (GemmArgs* g : {&g0, &g1}) {
+    g->has_rowsum = g->a_rowsum != nullptr;
+    if (g->a_rowsum == nullptr) g->a_rowsum = g->col_term;
+    if (g->bias == nullptr) g->bias = g->alpha;
+    g->grid_m = (g->M + 255) / 256;
+    g->grid_n = (g->N + 175) / 176;
+  }
+  g0.zero_buf = row_sum;
+  g0.zero_count = (int)M;
+  g1.gate_aidx = idx_scratch;
+  g1.gate_table = table;
+  g1.gate_q = q_tiled;
+  g1.gate_rowsum = row_sum;
+  rc = launch_fr(g0, as_stream(stream));
+  if (rc != MQ_OK) return rc;
+  return launch_frg(g1, as_stream(stream));
 }
 
 static int linear_f32in(const char* fn, int w4, const float* x, const float* a_scale, const float* a_offset, float a_qmin,

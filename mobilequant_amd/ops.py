@@ -443,6 +443,31 @@ def int8_linear_pair(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch.
     return outs[0], outs[1]
 
 
+def int8_linear_gated(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch.Tensor], first: dict, second: dict, table: torch.Tensor):
+    """w1, w3 and the gate of a gated FFN in TWO launches (mq_w8a8_linear_tiled_gated): `first` (w1) writes its 8-bit indices, `second`
+    (w3) looks (w1 index, w3 index) up in `table` (gated_table) inside its epilogue.  Returns (w2's int8 input image, fragment-blocked
+    [ceil16(rows), N]; its row sums [rows]) -- the bits of int8_linear_pair + gated_lookup(tiled=True)."""
+    M, K = int(rows), a_tiled.shape[1]
+    N = first["w"].shape[0]
+    dev = a_tiled.device
+    if table.dtype != torch.int8 or table.numel() != 65536:
+        raise RuntimeError("mobilequant_amd: int8_linear_gated needs an int8 [65536] table (gated_table)")
+    idx = torch.empty((M, N), dtype=torch.uint8, device=dev)
+    q = torch.empty(((M + 15) // 16 * 16, N), dtype=torch.int8, device=dev)
+    rs = torch.empty(M, dtype=torch.int32, device=dev)
+    ptrs, keep = [], []
+    for p in (first, second):
+        b = _f32(p["bias"], "bias") if p.get("bias") is not None else None
+        os_, oo_ = _f32(p["out_scale"], "out_scale"), _f32(p["out_offset"], "out_offset")
+        keep += [b, os_, oo_]
+        ptrs += [p["w"].data_ptr(), p["alpha"].data_ptr(), p["w_zp"].data_ptr(), p["col_term"].data_ptr(),
+                 b.data_ptr() if b is not None else None, os_.data_ptr(), oo_.data_ptr()]
+    with _on(a_tiled, a_rowsum, first["w"], second["w"], first["alpha"], second["alpha"], table, *[k for k in keep if k is not None]):
+        _lib.call("mq_w8a8_linear_tiled_gated", a_tiled.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
+                  *ptrs, table.data_ptr(), idx.data_ptr(), q.data_ptr(), rs.data_ptr(), _stream())
+    return q, rs
+
+
 def gated_act_quant(a: torch.Tensor, b: torch.Tensor, act: str, out_grid, *, a_grid=None, b_grid=None, mid_grid=None, act_grid=None,
                     q_shift: int = 128, want_y: bool = False):
     """act(a) * b -> int8 image on `out_grid` (+ row sums, + the fp32 product when want_y) in one launch: the gated FFN between

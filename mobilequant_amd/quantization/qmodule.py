@@ -1217,6 +1217,17 @@ def _gated_mlp_forward(self, x, resid=None):
         halves.append(dict(w=plan["w"], alpha=plan["alpha"], w_zp=plan["w_zp"], col_term=plan["col_term"],
                            bias=m.temp_bias if m.use_temporary_parameter else m.bias, out_scale=oq.scale.detach(),
                            out_offset=oq.offset.detach()))
+    iq2 = w2.input_quantizer
+    # everything static and the pair shape: w1, then w3 with the gate in its epilogue (table lookup -> w2's fragment-blocked image):
+    # no index tensor of w3, no lookup launch
+    gate_fused = (pair and N % 64 == 0 and getattr(self, "gated_table", True) and getattr(self, "gated_epilogue", True)
+                  and resid is not None and resid.dtype == torch.float32 and resid.is_contiguous()
+                  and not w2._weight_plan(wt2)["w4"] and w2._tiled_residual_ok(M, wt2.shape[0], N))
+    if gate_fused:
+        table = _gated_table_of(self, act, silu, w1.output_quantizer, w3.output_quantizer, iq2, x.device)
+        p_q, p_rs = ops.int8_linear_gated(a_q, M, a_rs, halves[0], halves[1], table)
+        return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q, p_rs, 128, M,
+                                   lead_shape=x.shape[:-1], resid=resid)
     if pair:
         a_idx, b_idx = ops.int8_linear_pair(a_q, M, a_rs, halves[0], halves[1], out_dtype=MQ_U8)
     else:
@@ -1224,23 +1235,13 @@ def _gated_mlp_forward(self, x, resid=None):
                                         out_offset=h["out_offset"], out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8, w4=m._weight_plan(wt)["w4"],
                                         a_tiled_rows=tiled_rows)
                         for h, (m, wt) in zip(halves, ((w1, wt1), (w3, wt3))))
-    iq2 = w2.input_quantizer
     for q in (iq2, act.output_quantizer, act.input2_quantizer if silu else None):
         if q is not None and not q.bypassed() and q.scale.device != x.device:
             q.scale.data, q.offset.data = q.scale.to(x.device), q.offset.to(x.device)
     o1, o3 = w1.output_quantizer, w3.output_quantizer
     if N % 8 == 0 and getattr(self, "gated_table", True):
         # static grids: act(a) * b -> index is a function of the two 8-bit indices -- a 64 KiB table built once per set of grids
-        mid_q = act.input2_quantizer if silu else None
-        key = ("silu" if silu else "gelu",) + tuple(None if q is None or q.bypassed() else q.grid_token()
-                                                    for q in (o1, o3, mid_q, act.output_quantizer, iq2))
-        cached = getattr(self, "_gated_lut", None)
-        if cached is None or cached[0] != key or cached[1].device != x.device:
-            table = ops.gated_table(key[0], (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),
-                                    (o1.scale.detach(), o1.offset.detach()), (o3.scale.detach(), o3.offset.detach()),
-                                    mid_grid=QRMSNorm._grid_or_none(mid_q) if silu else None,
-                                    act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
-            cached = self._gated_lut = (key, table)
+        cached = (None, _gated_table_of(self, act, silu, o1, o3, iq2, x.device))
         # w2 with the residual: the fragment-blocked image its generated kernel reads
         w2_tiled = (resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and N % 64 == 0
                     and not w2._weight_plan(wt2)["w4"] and w2._tiled_residual_ok(M, wt2.shape[0], N))
@@ -1256,6 +1257,24 @@ def _gated_mlp_forward(self, x, resid=None):
                                         act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
     return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q.view(M, N), p_rs, 128,
                                None, lead_shape=x.shape[:-1], resid=resid)
+
+
+def _gated_table_of(block, act, silu, o1, o3, iq2, device):
+    """The 256 x 256 table (ia, ib) -> w2 input index of this block's grids (ops.gated_table), cached on the block."""
+    for q in (iq2, act.output_quantizer, act.input2_quantizer if silu else None):
+        if q is not None and not q.bypassed() and q.scale.device != device:
+            q.scale.data, q.offset.data = q.scale.to(device), q.offset.to(device)
+    mid_q = act.input2_quantizer if silu else None
+    key = ("silu" if silu else "gelu",) + tuple(None if q is None or q.bypassed() else q.grid_token()
+                                                for q in (o1, o3, mid_q, act.output_quantizer, iq2))
+    cached = getattr(block, "_gated_lut", None)
+    if cached is None or cached[0] != key or cached[1].device != device:
+        table = ops.gated_table(key[0], (iq2.scale.detach(), iq2.offset.detach(), iq2.qmin, iq2.qmax),
+                                (o1.scale.detach(), o1.offset.detach()), (o3.scale.detach(), o3.offset.detach()),
+                                mid_grid=QRMSNorm._grid_or_none(mid_q) if silu else None,
+                                act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
+        cached = block._gated_lut = (key, table)
+    return cached[1]
 
 
 def fuse_gated_mlp(model) -> int:

@@ -686,3 +686,31 @@ def test_attention_exponential_cache_depth_does_not_change_a_bit(dev, S, heads, 
     assert torch.equal(outs[0], outs[1])
     want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
     assert np.abs(outs[1].cpu().numpy() - want).max() <= 1.001 * float(pv[2].scale)
+
+
+@pytest.mark.parametrize("M,zp0", [(2048, False), (1700, True), (1537, False)])
+def test_gated_pair_with_the_lookup_in_the_epilogue_is_pair_plus_lookup(dev, M, zp0):
+    """mq_w8a8_linear_tiled_gated (w1 launch + w3 launch whose generated epilogue does the table lookup) against
+    mq_w8a8_linear_tiled_pair + mq_gated_lookup_tiled: the same fragment-blocked image of w2's input and the same row sums."""
+    from mobilequant_amd import ops
+    N, K = 5632, 2048
+    g = torch.Generator(device="cpu").manual_seed(M)
+    halves = []
+    a_q = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g).to(dev)
+    a_rs = a_q.to(torch.int32).sum(dim=1, dtype=torch.int32)
+    for h in range(2):
+        _, w_q, _, alpha, w_zp, col_term, b = _gemm_operands(dev, 16, N, K, 50 + h + M, zp0, bias=(h == 0))
+        halves.append(dict(w=w_q, alpha=alpha * 0.02, w_zp=w_zp, col_term=col_term, bias=b,
+                           out_scale=torch.tensor([0.011 * (h + 1)], device=dev), out_offset=torch.tensor([120.0 + 9 * h], device=dev)))
+    table = torch.randint(-128, 128, (65536,), dtype=torch.int8, generator=g).to(dev)
+    a_t = _to_tiled(a_q)
+    rs_in = None if zp0 else a_rs
+    ia, ib = ops.int8_linear_pair(a_t, M, rs_in, halves[0], halves[1])
+    q_want, rs_want = ops.gated_lookup(ia, ib, table, tiled=True)
+    q_got, rs_got = ops.int8_linear_gated(a_t, M, rs_in, halves[0], halves[1], table)
+    torch.cuda.synchronize()
+    assert 5 < ia.float().mean() < 250 and 5 < ib.float().mean() < 250
+    assert torch.equal(rs_got, rs_want)
+    Mp = q_want.shape[0]
+    un = lambda q: q.view(Mp // 16, N // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, N)[:M]      # noqa: E731
+    assert torch.equal(un(q_got), un(q_want))

@@ -43,18 +43,31 @@ VARIANTS = {
     "fr128":   (128, 8, "u8",   "MQ_FR128",   "mq_gemm_fr128_asm.inc"),      # q|k|v (N = 2560): 256 x 128 tiles, per-column output grids
     "fr128r":  (128, 4, "f32r", "MQ_FR128R",  "mq_gemm_fr128r_asm.inc"),     # o_proj / w2 (N = 2048): 128 x 128 tiles, x + Q16(linear) in fp32
     "fr128r8": (128, 8, "f32r", "MQ_FR128R8", "mq_gemm_fr128r8_asm.inc"),    # the same epilogue on 256 x 128 tiles
+    # w3 of a gated FFN with the rest of the chain in its epilogue: its 8-bit output index and w1's (read back from the first launch's
+    # output) go through the 256 x 256 gated table (64 KiB, LDS-resident) -> w2's int8 input image, fragment-blocked, + row sums
+    "frg":     (176, 8, "gate", "MQ_FRG",     "mq_gemm_frg_asm.inc"),
 }
 
 
 def configure(name):
     """binds the module-level tile constants of one variant (the emitters read them at call time)"""
-    global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF
+    global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF, RING_BASE
     BN, NW, EPI, PREFIX, FILE = VARIANTS[name]
     BM = 32 * NW
     FN = BN // 16
     W_BYTES = BN * BK                 # 22528 / 16384
-    PAR = RING * W_BYTES              # alpha' | bias' | -w_zp | col_term
+    RING_BASE = 65536 if EPI == "gate" else 0     # gate: the table sits at LDS offset 0 (ds_read_u8 addresses = ia * 256 + ib)
+    PAR = RING_BASE + RING * W_BYTES  # alpha' | bias' | -w_zp | col_term
     STG = PAR + 16 * BN
+    if EPI == "gate":
+        # staging tiles alias the W ring (one barrier after the loop): table 64 KiB + ring 88 KiB + vectors = 158 464 B of the 160 KiB
+        ROWP = BN
+        STG_WAVE = 2 * 16 * ROWP
+        STG = RING_BASE
+        LDS_BYTES = PAR + 16 * BN
+        PIECES = (BN // 8 + NW - 1) // NW
+        assert LDS_BYTES <= 160 * 1024
+        return
     if EPI == "u8":
         # staging pitch (u8 rows): 176 B as is (writes <= 2-way conflicted); 128 B rows padded to 144 (bank = 36 frow + kq: conflict-free)
         ROWP = BN if BN % 128 else BN + 16
@@ -255,6 +268,8 @@ def prologue(q, nw, stamp):
     emit(f"s_mov_b64 s[{S_ABASE}:{S_ABASE + 1}], %[aptr]")
     emit(f"s_mov_b64 s[{S_WBASE}:{S_WBASE + 1}], %[wptr]")
     emit(f"s_lshl_b32 s{S_WK[0]}, %[wave], 10")
+    if RING_BASE:
+        emit(f"s_add_u32 s{S_WK[0]}, s{S_WK[0]}, {RING_BASE}")
     for i in range(1, max(PIECES, 3) if BN == 176 else PIECES):
         emit(f"s_add_u32 s{S_WK[i]}, s{S_WK[0]}, {i * NW * 1024}")
     emit(f"s_mov_b32 s{S_CUR}, 0")
@@ -286,6 +301,21 @@ def prologue(q, nw, stamp):
         if t == 1:
             a_load(q, 1, 0, 0, 1, 0)()
             a_load(q, 1, 0, 1, 1, 0)()
+    if EPI == "gate":
+        # the 64-KiB gated table -> LDS [0, 65536): 64 pieces of 1 KiB by LDS-DMA, eight per wave, behind the first stages in the queue
+        emit(f"v_and_b32 v{V_RD}, 63, %[tid]")
+        emit(f"v_lshlrev_b32 v{V_RD}, 4, v{V_RD}")                           # lane * 16
+        emit(f"s_lshl_b32 s{S_TMP}, %[wave], 13")                            # wave * 8 KiB
+        emit(f"s_mov_b64 s[{S_TS}:{S_TS + 1}], %[table]")
+        emit(f"s_add_u32 s{S_TS}, s{S_TS}, s{S_TMP}")
+        emit(f"s_addc_u32 s{S_TS + 1}, s{S_TS + 1}, 0")
+        for i in range(8):
+            emit(f"s_add_u32 m0, s{S_TMP}, {i * 1024}")
+            emit("s_nop 0")
+            emit(f"global_load_lds_dwordx4 v{V_RD}, s[{S_TS}:{S_TS + 1}]")
+            q.issue("T")
+            emit(f"s_add_u32 s{S_TS}, s{S_TS}, 1024")
+            emit(f"s_addc_u32 s{S_TS + 1}, s{S_TS + 1}, 0")
     # per-lane constants while the loads fly
     emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")                                # lane
     emit(f"v_and_b32 v{V_WOFF0}, 15, v{V_TMP}")                            # frow
@@ -294,11 +324,13 @@ def prologue(q, nw, stamp):
     emit(f"v_xor_b32 v{V_STW}, v{V_STW}, v{V_PAR}")                        # kq ^ (lane & 7)
     emit(f"v_lshlrev_b32 v{V_STW}, 4, v{V_STW}")
     emit(f"v_lshl_add_u32 v{V_WOFF0}, v{V_WOFF0}, 7, v{V_STW}")            # frow*128 + swizzled chunk
+    if RING_BASE:
+        emit(f"v_add_u32 v{V_WOFF0}, {RING_BASE}, v{V_WOFF0}")
     emit(f"v_xor_b32 v{V_WOFF1}, 64, v{V_WOFF0}")
     # staging write address: STG + wave*STG_WAVE + frow*ROWP + kq*4 ; alpha' chunk address: PAR + kq*16
     emit(f"v_and_b32 v{V_STW}, 15, v{V_TMP}")
     emit(f"v_mul_u32_u24 v{V_STW}, {ROWP}, v{V_STW}")
-    emit(f"v_lshl_add_u32 v{V_STW}, v{V_PAR}, {2 if EPI == 'u8' else 4}, v{V_STW}")   # + kq*4 bytes (u8) / kq*16 (fp32)
+    emit(f"v_lshl_add_u32 v{V_STW}, v{V_PAR}, {4 if EPI == 'f32r' else 2}, v{V_STW}")   # + kq*4 bytes (u8) / kq*16 (fp32)
     emit(f"s_mul_i32 s{S_TMP}, %[wave], {STG_WAVE}")
     emit(f"s_add_u32 s{S_TMP}, s{S_TMP}, {STG}")
     emit(f"v_add_u32 v{V_STW}, s{S_TMP}, v{V_STW}")
@@ -325,7 +357,7 @@ def prologue(q, nw, stamp):
     inv, oo = ("%[inv_so]", "%[oo]") if (BN == 176 or EPI != "u8") else ("%[invc]", "%[ooc]")
     emit(f"v_mul_f32 v{V_P0}, {inv}, v{V_P0}")
     emit(f"v_mul_f32 v{V_P0 + 1}, {inv}, v{V_P0 + 1}")
-    if EPI == "u8":
+    if EPI in ("u8", "gate"):
         emit(f"v_add_f32 v{V_P0 + 1}, {oo}, v{V_P0 + 1}")
     emit(f"v_sub_u32 v{V_P0 + 2}, 0, v{V_P0 + 2}")
     emit(f"v_lshlrev_b32 v{V_TMP}, 2, %[tid]")
@@ -355,6 +387,120 @@ def prologue(q, nw, stamp):
         emit("s_waitcnt lgkmcnt(0)")
 
 
+# ---- gate epilogue tail: (w1 index, w3 index) -> table -> w2's int8 input image (fragment-blocked) + row sums -------------------------
+# At entry the wave's staging tile holds this tile's w3 indices (2 x 16 rows x 176 B), V_LDSO+r / V_GOFS+r / V_E+r are the LDS offset,
+# the row-major global offset and the row of chunk c = lane + 64 r (as in the u8 epilogue), s[S_TMP] the tile's LDS base.
+S_GM = 84                           # 84..95: exec masks of (i, r)
+
+
+def epilogue_gate_tail(R):
+    assert R == 3 and FN == 11
+    A0, T0, AD0 = 24, 48, 64        # w1 index chunks v[24:47]; looked-up bytes v[48:63]; addresses v[64:79]
+    GO1 = 117                       # 117..119: global offsets of the second row block (V_E + 3 .. 5 are free)
+    emit(f"s_lshl_b32 s{S_TMP2}, %[ldn], 4")                                 # 16 rows further down
+    for r in range(R):
+        emit(f"v_add_u32 v{GO1 + r}, s{S_TMP2}, v{V_GOFS + r}")
+    # masks, then the w1 indices of the six chunks (row-major u8 [M, N], written by the first launch)
+    for i in range(2):
+        for r in range(R):
+            m = S_GM + 2 * (i * R + r)
+            emit(f"v_add_u32 v{V_TMP}, {16 * i}, v{V_E + r}")
+            emit(f"v_cmp_gt_i32_e64 s[{m}:{m + 1}], %[mrem], v{V_TMP}")
+            if 64 * (r + 1) > 16 * FN:
+                emit(f"v_cmp_gt_u32_e64 s[{S_MR}:{S_MR + 1}], 16, v{V_E + r}")
+                emit(f"s_and_b64 s[{m}:{m + 1}], s[{m}:{m + 1}], s[{S_MR}:{S_MR + 1}]")
+    for i in range(2):
+        for r in range(R):
+            m = S_GM + 2 * (i * R + r)
+            a = A0 + (i * R + r) * 4
+            emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")
+            emit(f"global_load_dwordx4 v[{a}:{a + 3}], v{(V_GOFS if i == 0 else GO1) + r}, %[aidx]")
+    emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    emit("s_waitcnt lgkmcnt(0)")
+    for i in range(2):
+        for r in range(R):
+            b = (i * R + r) * 4
+            emit(f"ds_read_b128 v[{b}:{b + 3}], v{V_LDSO + r} offset:{i * 16 * ROWP}")
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    for i in range(2):
+        for r in range(R):
+            a, b = A0 + (i * R + r) * 4, (i * R + r) * 4
+            for d in range(4):
+                for e in range(4):
+                    j = 4 * d + e
+                    emit(f"v_bfe_u32 v{AD0 + j}, v{a + d}, {8 * e}, 8")
+                    emit(f"v_bfe_u32 v{T0 + j}, v{b + d}, {8 * e}, 8")
+                    emit(f"v_lshl_or_b32 v{AD0 + j}, v{AD0 + j}, 8, v{T0 + j}")
+                    emit(f"ds_read_u8 v{T0 + j}, v{AD0 + j}")
+            emit("s_waitcnt lgkmcnt(0)")
+            for d in range(4):
+                emit(f"v_lshl_or_b32 v{b + d}, v{T0 + 4 * d + 1}, 8, v{T0 + 4 * d}")
+                emit(f"v_lshl_or_b32 v{b + d}, v{T0 + 4 * d + 2}, 16, v{b + d}")
+                emit(f"v_lshl_or_b32 v{b + d}, v{T0 + 4 * d + 3}, 24, v{b + d}")
+            if 64 * (r + 1) > 16 * FN:                       # lanes past the last chunk hold no chunk: their "row" lies outside the block
+                emit(f"s_mov_b64 exec, s[{S_MR}:{S_MR + 1}]")
+            emit(f"ds_write_b128 v{V_LDSO + r}, v[{b}:{b + 3}] offset:{i * 16 * ROWP}")
+            if 64 * (r + 1) > 16 * FN:
+                emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    emit("s_waitcnt lgkmcnt(0)")
+    # ---- row sums: lane < 32 owns row32 = lane of the wave's 32 rows: 11 x 16 bytes, sum of (byte ^ 0x80) - 128 * 176
+    V_L, V_RA, V_ACC, V_T2 = 124, 125, 126, 127
+    emit(f"v_and_b32 v{V_L}, 63, %[tid]")
+    emit(f"v_and_b32 v{V_RA}, 31, v{V_L}")                                   # row32
+    emit(f"v_lshrrev_b32 v{V_T2}, 4, v{V_RA}")                               # row block 0 / 1
+    emit(f"v_mul_u32_u24 v{V_T2}, {16 * ROWP}, v{V_T2}")
+    emit(f"v_and_b32 v{V_ACC}, 15, v{V_RA}")
+    emit(f"v_mul_u32_u24 v{V_ACC}, {ROWP}, v{V_ACC}")
+    emit(f"v_add3_u32 v{V_T2}, v{V_T2}, v{V_ACC}, s{S_TMP}")                 # LDS address of the row
+    emit(f"v_cmp_gt_i32 vcc, %[mrem], v{V_RA}")
+    emit(f"s_mov_b64 s[{S_GM}:{S_GM + 1}], vcc")                             # row32 < rows left (all lanes)
+    for c in range(FN):
+        emit(f"ds_read_b128 v[{4 * c}:{4 * c + 3}], v{V_T2} offset:{16 * c}")
+    emit(f"v_mov_b32 v{V_ACC}, 0")
+    emit("s_waitcnt lgkmcnt(0)")
+    for k in range(4 * FN):
+        emit(f"v_xor_b32 v{T0}, 0x80808080, v{k}")
+        emit(f"v_sad_u8 v{V_ACC}, v{T0}, 0, v{V_ACC}")
+    emit(f"v_add_u32 v{V_ACC}, {(-128 * BN) & 0xffffffff}, v{V_ACC}")
+    emit(f"v_lshlrev_b32 v{T0 + 1}, 2, v{V_RA}")
+    emit(f"v_cmp_gt_u32 vcc, 32, v{V_L}")
+    emit(f"s_and_b64 vcc, vcc, s[{S_GM}:{S_GM + 1}]")
+    emit("s_and_b64 exec, exec, vcc")
+    emit(f"global_atomic_add v{T0 + 1}, v{V_ACC}, %[rsout]")
+    emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    # ---- image: unit u = lane + 64 r6 -> chunk ch = 2 r6 + (lane >> 5), row32 = lane & 31: 16 lanes = 16 rows of one chunk = 256 bytes
+    V_HI, V_BLK, V_R16 = 122, 123, 121
+    emit(f"v_lshrrev_b32 v{V_HI}, 5, v{V_L}")                                # lane >> 5
+    emit(f"v_lshl_add_u32 v{V_T2}, v{V_HI}, 4, v{V_T2}")                     # LDS: row address + 16 * (lane >> 5)
+    emit(f"s_lshr_b32 s{S_TMP2}, %[ldn], 6")                                 # 64-column blocks per row of blocks
+    emit(f"v_lshrrev_b32 v{V_BLK}, 4, v{V_RA}")
+    emit(f"v_add_u32 v{V_BLK}, %[mb0], v{V_BLK}")
+    emit(f"v_mul_lo_u32 v{V_BLK}, v{V_BLK}, s{S_TMP2}")                      # (mb0 + (row32 >> 4)) * blocks per row
+    emit(f"v_and_b32 v{V_R16}, 15, v{V_RA}")
+    emit(f"v_lshlrev_b32 v{V_R16}, 4, v{V_R16}")                             # (row32 & 15) * 16
+    for r6 in range(6):
+        emit(f"ds_read_b128 v[{4 * r6}:{4 * r6 + 3}], v{V_T2} offset:{32 * r6}")
+    emit("s_waitcnt lgkmcnt(0)")
+    for r6 in range(6):
+        emit(f"s_add_u32 s{S_TMP}, %[cg0], {2 * r6}")
+        emit(f"v_add_u32 v{T0}, s{S_TMP}, v{V_HI}")                          # chunk column of the whole matrix
+        emit(f"v_lshrrev_b32 v{T0 + 1}, 2, v{T0}")
+        emit(f"v_add_u32 v{T0 + 1}, v{T0 + 1}, v{V_BLK}")                    # block index
+        emit(f"v_and_b32 v{T0}, 3, v{T0}")
+        emit(f"v_lshlrev_b32 v{T0}, 8, v{T0}")
+        emit(f"v_lshl_add_u32 v{T0 + 1}, v{T0 + 1}, 10, v{T0}")
+        emit(f"v_add_u32 v{T0 + 1}, v{T0 + 1}, v{V_R16}")
+        if r6 == 5:
+            emit(f"v_cmp_eq_u32 vcc, 0, v{V_HI}")                            # chunk 11 does not exist
+            emit(f"s_and_b64 vcc, vcc, s[{S_GM}:{S_GM + 1}]")
+            emit("s_and_b64 exec, exec, vcc")
+        else:
+            emit(f"s_and_b64 exec, exec, s[{S_GM}:{S_GM + 1}]")
+        emit(f"global_store_dwordx4 v{T0 + 1}, v[{4 * r6}:{4 * r6 + 3}], %[qout]")
+        emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    emit("s_waitcnt vmcnt(0)")
+
+
 def epilogue(stamp):
     emit("; ==== epilogue: u8 = cvt_pk_u8(fma(float(acc), alpha', bias')) -> staging tile -> whole-row 16-byte stores")
     if stamp:
@@ -362,6 +508,8 @@ def epilogue(stamp):
         emit("s_waitcnt lgkmcnt(0)")
     emit("s_nop 15")
     emit("s_nop 3")
+    if EPI == "gate":
+        emit("s_barrier")         # the staging tiles alias the W ring: every wave has left the main loop
     EA = [V_E, V_P0]              # two sets of (alpha'[4], bias'[4]): v[114:121] and v[106:113] (free after the prologue)
     VP = [122, 123]               # packed dwords for i = 0, 1
 
@@ -387,7 +535,8 @@ def epilogue(stamp):
             for e in range(4):
                 emit(f"v_cvt_pk_u8_f32 v{VP[i]}, {accr(i, j, e)}, {e}, " + (f"v{VP[i]}" if e else "0"))
         for i in range(2):
-            emit(f"v_xor_b32 v{VP[i]}, %[xorv], v{VP[i]}")
+            if EPI != "gate":
+                emit(f"v_xor_b32 v{VP[i]}, %[xorv], v{VP[i]}")
             emit(f"ds_write_b32 v{V_STW}, v{VP[i]} offset:{i * 16 * ROWP + j * 16}")
     # chunk c = lane + 64 r of the 16 x FN chunks of a row block: row = c / FN, ch = c % FN
     R = (16 * FN + 63) // 64
@@ -413,6 +562,9 @@ def epilogue(stamp):
         emit(f"v_mul_lo_u32 v{V_GOFS + r}, v{row}, %[ldn]")
         emit(f"v_add_u32 v{V_GOFS + r}, v{V_GOFS + r}, v{ch}")
         emit(f"v_mov_b32 v{V_E + r}, v{row}")                                # row index kept for the M bound
+    if EPI == "gate":
+        epilogue_gate_tail(R)
+        return
     emit("s_waitcnt lgkmcnt(0)")
     for i in range(2):
         for r in range(R):
@@ -618,7 +770,7 @@ def program(nw, stamp):
     for t in range(4, 8):
         stage(q, t, nw, kt=KT, sym=f"KT-{KT - t}")
     assert q.q == [], q.q
-    if EPI == "u8":
+    if EPI in ("u8", "gate"):
         epilogue(stamp)
     else:
         assert not stamp
@@ -653,7 +805,7 @@ def main(path=None, variant="fr"):
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
     vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(V_T if BN == 176 else 78, 128))]
     aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32)]
-    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)]
+    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)] + (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")
         f.write(f"#define {PREFIX}_ASM_STAMP {1 if stamp else 0}\n")
