@@ -422,16 +422,19 @@ def epilogue_gate_tail(R):
             b = (i * R + r) * 4
             emit(f"ds_read_b128 v[{b}:{b + 3}], v{V_LDSO + r} offset:{i * 16 * ROWP}")
     emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    emit("s_mov_b32 s78, 0x05010400")                                        # bytes [a1 b1 a0 b0] / [a3 b3 a2 b2] of (w1 dword, w3 dword)
+    emit("s_mov_b32 s79, 0x07030602")
     for i in range(2):
         for r in range(R):
             a, b = A0 + (i * R + r) * 4, (i * R + r) * 4
             for d in range(4):
-                for e in range(4):
-                    j = 4 * d + e
-                    emit(f"v_bfe_u32 v{AD0 + j}, v{a + d}, {8 * e}, 8")
-                    emit(f"v_bfe_u32 v{T0 + j}, v{b + d}, {8 * e}, 8")
-                    emit(f"v_lshl_or_b32 v{AD0 + j}, v{AD0 + j}, 8, v{T0 + j}")
+                for h in range(2):                               # v_perm_b32 interleaves two (w1, w3) byte pairs into two 16-bit table addresses
+                    j = 4 * d + 2 * h
+                    emit(f"v_perm_b32 v{AD0 + j}, v{a + d}, v{b + d}, s{78 + h}")
+                    emit(f"v_lshrrev_b32 v{AD0 + j + 1}, 16, v{AD0 + j}")
+                    emit(f"v_and_b32 v{AD0 + j}, 0xffff, v{AD0 + j}")
                     emit(f"ds_read_u8 v{T0 + j}, v{AD0 + j}")
+                    emit(f"ds_read_u8 v{T0 + j + 1}, v{AD0 + j + 1}")
             emit("s_waitcnt lgkmcnt(0)")
             for d in range(4):
                 emit(f"v_lshl_or_b32 v{b + d}, v{T0 + 4 * d + 1}, 8, v{T0 + 4 * d}")
