@@ -20,6 +20,8 @@ const char* mq_gemm_variant_name(int variant);
 int mq_gemm_set_debug(int flags);
 /* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
+/* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */
+int mq_gemm_set_segmented_tile(int cols);
 /* mq_quantize_tiled: 1 (default) = the LDS-staged eight-row kernel where it applies (fp32, 1024 <= cols <= 4096), 0 = the
  * lane-per-fragment kernel for every shape (A/B timing; identical images). */
 int mq_quantize_tiled_set_staged(int on);

@@ -31,6 +31,7 @@
 #include "mq_gemm_fr_asm.inc"
 #include "mq_gemm_fr128_asm.inc"
 #include "mq_gemm_frg_asm.inc"
+#include "mq_gemm_fr160_asm.inc"
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
 
@@ -821,20 +822,22 @@ __global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) { 
 // N = 2048 / 2560 outputs do not tile by 176.  FR128: 256 x 128 tiles, eight waves, 8-bit unsigned output grid PER COLUMN (the q | k | v
 // segments of mq_w8a8_linear_tiled_segmented).  FR128R: 128 x 128 tiles, FOUR waves (one per SIMD; 2048 x 2048 outputs = 256 tiles = one
 // per CU), fp32 output x + Q16(linear) with the residual add in the store (o_proj / w2).  FR128R8: that epilogue on 256 x 128 tiles.
-enum { FR128 = 1, FR128R = 2, FR128R8 = 3 };
+// FR160: 128 x 160 tiles, four waves, per-column 8-bit grids: q | k | v at M = 2048 is 16 x 16 = 256 tiles, one per CU (256 x 128 tiles: 160).
+enum { FR128 = 1, FR128R = 2, FR128R8 = 3, FR160 = 4 };
 template <int VAR>
 __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
-  constexpr int NWV = VAR == FR128R ? 4 : 8;
+  constexpr int NWV = (VAR == FR128R || VAR == FR160) ? 4 : 8;
   constexpr int BMT = 32 * NWV;
-  constexpr int PCS = 16 / NWV;                 // W LDS-DMA pieces (8 rows x 128 B) per wave and stage
+  constexpr int BNT = VAR == FR160 ? 160 : 128;
+  constexpr int PCS = BNT / 8 / NWV;            // W LDS-DMA pieces (8 rows x 128 B) per wave and stage
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
-  const int m0 = tm * BMT, n0 = tn * 128;
+  const int m0 = tm * BMT, n0 = tn * BNT;
   const int M = args.M, N = args.N, K = args.K;
   const int KT = K / BK;
-  unsigned sw[4] = {0, 0, 0, 0};
+  unsigned sw[5] = {0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < PCS; ++i) {
     int row = n0 + (wave + i * NWV) * 8 + (lane >> 3);
@@ -866,9 +869,9 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
   const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
   const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
   const unsigned tid = threadIdx.x;
-  if constexpr (VAR == FR128) {
-    // this thread's column (tid < 128) and its output grid: segment 0 = out_scale / out_offset, later segments their own
-    const int n = n0 + (int)(tid & 127u);
+  if constexpr (VAR == FR128 || VAR == FR160) {
+    // this thread's column (tid < BNT) and its output grid: segment 0 = out_scale / out_offset, later segments their own
+    const int n = n0 + (int)(tid < (unsigned)BNT ? tid : (unsigned)BNT - 1u);
     float sc = args.out_scale[0], ooc = args.out_offset[0];
     if (args.seg_scale[0] != nullptr) {
       const int sg = (n >= args.seg_end[0]) + (args.seg_scale[1] != nullptr && n >= args.seg_end[1]);
@@ -880,13 +883,17 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
     const float invc = __fdiv_rn(1.0f, sc);
     uint8_t* outw = reinterpret_cast<uint8_t*>(args.out) + (size_t)m0w * N + n0;
     const int xorv = __builtin_amdgcn_readfirstlane(args.out_dtype == MQ_I8 ? (int)0x80808080u : 0);
-    asm volatile(MQ_FR128_ASM_BODY
-                 :
-                 : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [alpha] "s"(alpha_p),
-                   [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [ldn] "s"(ldn), [mrem] "s"(mrem),
-                   [flags] "s"(flags), [xorv] "s"(xorv), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [av0] "v"(av0), [av1] "v"(av1),
-                   [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [invc] "v"(invc), [ooc] "v"(ooc)
-                 : MQ_FR128_ASM_CLOBBERS);
+#define MQ_FR128U_OPERANDS                                                                                                        \
+    [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [alpha] "s"(alpha_p),                  \
+        [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [ldn] "s"(ldn), [mrem] "s"(mrem),                 \
+        [flags] "s"(flags), [xorv] "s"(xorv), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [av0] "v"(av0), [av1] "v"(av1),                  \
+        [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [invc] "v"(invc), [ooc] "v"(ooc)
+    if constexpr (VAR == FR128) {
+      asm volatile(MQ_FR128_ASM_BODY : : MQ_FR128U_OPERANDS : MQ_FR128_ASM_CLOBBERS);
+    } else {
+      asm volatile(MQ_FR160_ASM_BODY : : MQ_FR128U_OPERANDS, [sw2] "v"(sw[2]), [sw3] "v"(sw[3]), [sw4] "v"(sw[4]) : MQ_FR160_ASM_CLOBBERS);
+    }
+#undef MQ_FR128U_OPERANDS
   } else {
     const float so = args.out_scale[0], oo = args.out_offset[0];
     const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
@@ -911,15 +918,17 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
 }
 
 template <int VAR>
-__global__ void __launch_bounds__(VAR == FR128R ? 256 : 512) gemm_i8_fr128_kernel(const GemmArgs args) { gemm_i8_fr128_body<VAR>(args); }
+__global__ void __launch_bounds__((VAR == FR128R || VAR == FR160) ? 256 : 512) gemm_i8_fr128_kernel(const GemmArgs args) { gemm_i8_fr128_body<VAR>(args); }
 
 // shapes the 128-column generated kernels serve (fragment-blocked activations, int8 weights)
 static bool gemm_fr128_shape(int64_t M, int64_t N, int64_t K) { return M > 0 && N % 128 == 0 && K % 256 == 0 && K >= 768; }
 
 template <int VAR>
 static int launch_fr128(GemmArgs a, hipStream_t st) {
-  constexpr int LDS = VAR == FR128 ? MQ_FR128_LDS_BYTES : (VAR == FR128R ? MQ_FR128R_LDS_BYTES : MQ_FR128R8_LDS_BYTES);
-  constexpr int BMT = VAR == FR128R ? 128 : 256;
+  constexpr int LDS = VAR == FR128 ? MQ_FR128_LDS_BYTES
+                                   : (VAR == FR128R ? MQ_FR128R_LDS_BYTES : (VAR == FR160 ? MQ_FR160_LDS_BYTES : MQ_FR128R8_LDS_BYTES));
+  constexpr int BMT = (VAR == FR128R || VAR == FR160) ? 128 : 256;
+  constexpr int BNT = VAR == FR160 ? 160 : 128;
   static PerDeviceOnce attr_set;
   const int dev = current_device();
   if (!attr_set.done(dev)) {
@@ -934,8 +943,8 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
   if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;
   if (a.bias == nullptr) a.bias = a.alpha;
   a.grid_m = (a.M + BMT - 1) / BMT;
-  a.grid_n = a.N / 128;
-  gemm_i8_fr128_kernel<VAR><<<a.grid_m * a.grid_n, VAR == FR128R ? 256 : 512, LDS, st>>>(a);
+  a.grid_n = a.N / BNT;
+  gemm_i8_fr128_kernel<VAR><<<a.grid_m * a.grid_n, (VAR == FR128R || VAR == FR160) ? 256 : 512, LDS, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
 }
@@ -1410,6 +1419,12 @@ int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64
 
 int mq_gemm_tiled128_supported(int64_t M, int64_t N, int64_t K) { return gemm_fr128_shape(M, N, K) ? 1 : 0; }
 
+static std::atomic<int> g_seg_tile{0};       // tuning hook: 128 = keep the 256 x 128 tile for the segmented GEMM
+int mq_gemm_set_segmented_tile(int cols) {
+  g_seg_tile = cols == 128 ? 128 : 0;
+  return 0;
+}
+
 static std::atomic<int> g_fr128r_tile{0};     // tuning hook (mobilequant_amd_tuning.h): 0 = by shape, 128 / 256 = force the tile height
 int mq_gemm_set_residual_tile(int rows) {
   g_fr128r_tile = (rows == 128 || rows == 256) ? rows : 0;
@@ -1468,6 +1483,8 @@ int mq_w8a8_linear_tiled_segmented(const int8_t* a_tiled, const int8_t* w, int64
     g.seg_scale[i - 1] = grids[i].scale;
     g.seg_offset[i - 1] = grids[i].offset;
   }
+  // 128 x 160 tiles when they give every CU exactly (at most) one tile -- q | k | v at M = 2048: 256 tiles against 160 of 256 x 128
+  if (N % 160 == 0 && ((M + 127) / 128) * (N / 160) <= 256 && g_seg_tile.load() != 128) return launch_fr128<FR160>(g, as_stream(stream));
   return launch_fr128<FR128>(g, as_stream(stream));
 }
 

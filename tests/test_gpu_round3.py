@@ -456,7 +456,8 @@ def test_tiled_residual_gemm_is_the_rowmajor_residual_gemm_bit_for_bit(dev, M, N
         assert q.min() < 20000 and q.max() > 45000
 
 
-@pytest.mark.parametrize("M,K,ends", [(2048, 2048, (2048, 2304, 2560)), (300, 768, (128, 256)), (513, 1024, (384,))])
+@pytest.mark.parametrize("M,K,ends", [(2048, 2048, (2048, 2304, 2560)), (300, 768, (128, 256)), (513, 1024, (384,)), (300, 768, (256, 512, 640)),
+                                      (1999, 1024, (640,))])
 def test_tiled_segmented_gemm_is_the_rowmajor_segmented_gemm_bit_for_bit(dev, M, K, ends):
     """mq_w8a8_linear_tiled_segmented (q | k | v on 256 x 128 tiles of generated ISA, one output grid per column segment) against
     mq_w8a8_linear_segmented."""
@@ -469,6 +470,13 @@ def test_tiled_segmented_gemm_is_the_rowmajor_segmented_gemm_bit_for_bit(dev, M,
     got = ops.int8_linear_segmented(_to_tiled(a_q), w_q, a_rs, alpha, w_zp, col_term, b, ends, grids, a_tiled_rows=M)
     torch.cuda.synchronize()
     assert torch.equal(got, want), (got.int() - want.int()).abs().max().item()
+    import mobilequant_amd._lib as L                # N % 160 == 0 with at most 256 tiles ran on 128 x 160 tiles: also the 256 x 128 kernel
+    L.load().mq_gemm_set_segmented_tile(128)
+    try:
+        got128 = ops.int8_linear_segmented(_to_tiled(a_q), w_q, a_rs, alpha, w_zp, col_term, b, ends, grids, a_tiled_rows=M)
+    finally:
+        L.load().mq_gemm_set_segmented_tile(0)
+    assert torch.equal(got128, want)
     assert 5 < want.float().mean() < 250 and want.min() == 0 and want.max() == 255
 
 

@@ -63,6 +63,10 @@ if __name__ == "__main__":
     a_t = to_tiled(a_q)
     grids = [(torch.tensor([0.011 * (i + 1)], device=dev), torch.tensor([100.0 + 20 * i], device=dev)) for i in range(3)]
     t_old = timed(lambda: ops.int8_linear_segmented(a_q, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids))
+    L.load().mq_gemm_set_segmented_tile(128)
+    t_256 = timed(lambda: ops.int8_linear_segmented(a_t, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids, a_tiled_rows=M))
+    L.load().mq_gemm_set_segmented_tile(0)
+    print(f"           256 x 128 tiles {t_256:6.2f} us")
     t_new = timed(lambda: ops.int8_linear_segmented(a_t, w_q, a_rs, alpha * 0.02, w_zp, col_term, None, ends, grids, a_tiled_rows=M))
     print(f"q|k|v      {M}x{ends[-1]}x{K}: rowmajor C++ {t_old:6.2f} us | tiled {t_new:6.2f} us ({2.0 * M * ends[-1] * K / t_new / 1e6:7.1f} TOPS)  (both allocate their output)")
 

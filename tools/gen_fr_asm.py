@@ -43,6 +43,7 @@ VARIANTS = {
     "fr128":   (128, 8, "u8",   "MQ_FR128",   "mq_gemm_fr128_asm.inc"),      # q|k|v (N = 2560): 256 x 128 tiles, per-column output grids
     "fr128r":  (128, 4, "f32r", "MQ_FR128R",  "mq_gemm_fr128r_asm.inc"),     # o_proj / w2 (N = 2048): 128 x 128 tiles, x + Q16(linear) in fp32
     "fr128r8": (128, 8, "f32r", "MQ_FR128R8", "mq_gemm_fr128r8_asm.inc"),    # the same epilogue on 256 x 128 tiles
+    "fr160":   (160, 4, "u8",   "MQ_FR160",   "mq_gemm_fr160_asm.inc"),      # q|k|v at M = 2048: 128 x 160 tiles = 16 x 16 = one per CU
     # w3 of a gated FFN with the rest of the chain in its epilogue: its 8-bit output index and w1's (read back from the first launch's
     # output) go through the 256 x 256 gated table (64 KiB, LDS-resident) -> w2's int8 input image, fragment-blocked, + row sums
     "frg":     (176, 8, "gate", "MQ_FRG",     "mq_gemm_frg_asm.inc"),
@@ -70,7 +71,7 @@ def configure(name):
         return
     if EPI == "u8":
         # staging pitch (u8 rows): 176 B as is (writes <= 2-way conflicted); 128 B rows padded to 144 (bank = 36 frow + kq: conflict-free)
-        ROWP = BN if BN % 128 else BN + 16
+        ROWP = BN if BN % 128 else BN + 16          # (160: bank = 40 frow + kq, 2-way)
         STG_WAVE = 2 * 16 * ROWP
     else:
         # fp32 staging of HALF a 16-row block's columns at a time (64 columns = 256-byte row pieces), pitch 272
@@ -96,7 +97,7 @@ V_TMP = 127
 S0 = 58                           # first temporary SGPR
 S_ABASE, S_WBASE = 58, 60         # pairs: activation pointer of stage t+1; weight pointer of the stage whose DMA is issued next
 S_CUR, S_NXT, S_DMA = 62, 63, 64  # ring slot byte offsets: stage t, t+1, t+3
-S_WK = (65, 66, 67, 71)           # wave*1024 + i*NW*1024: LDS offset of this wave's piece i inside a slot
+S_WK = (65, 66, 67, 71, 80)       # wave*1024 + i*NW*1024: LDS offset of this wave's piece i inside a slot
 S_CNT = 68                        # steady-state pairs left
 S_TMP, S_TMP2 = 69, 70
 S_EXEC = 72                       # pair
@@ -554,6 +555,11 @@ def epilogue(stamp):
             emit(f"v_lshrrev_b32 v{row}, 16, v{row}")
             emit(f"v_mul_u32_u24 v{ch}, 11, v{row}")
             emit(f"v_sub_u32 v{ch}, v{c}, v{ch}")
+        elif FN == 10:
+            emit(f"v_mul_u32_u24 v{row}, 6554, v{c}")                        # floor(c / 10) for c < 192 (6554 = ceil(2^16 / 10))
+            emit(f"v_lshrrev_b32 v{row}, 16, v{row}")
+            emit(f"v_mul_u32_u24 v{ch}, 10, v{row}")
+            emit(f"v_sub_u32 v{ch}, v{c}, v{ch}")
         else:
             assert FN == 8
             emit(f"v_lshrrev_b32 v{row}, 3, v{c}")
@@ -806,7 +812,7 @@ def main(path=None, variant="fr"):
     here = os.path.dirname(os.path.abspath(__file__))
     path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", FILE)
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
-    vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(V_T if BN == 176 else 78, 128))]
+    vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(V_T if 8 * FN > 78 else 78, 128))]
     aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32)]
     sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)] + (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
