@@ -31,6 +31,7 @@
 #include "mq_gemm_fr_asm.inc"
 #include "mq_gemm_fr128_asm.inc"
 #include "mq_gemm_frg_asm.inc"
+#include "mq_gemm_frg128_asm.inc"
 #include "mq_gemm_fr160_asm.inc"
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
@@ -830,6 +831,10 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
   constexpr int BMT = 32 * NWV;
   constexpr int BNT = VAR == FR160 ? 160 : 128;
   constexpr int PCS = BNT / 8 / NWV;            // W LDS-DMA pieces (8 rows x 128 B) per wave and stage
+  if (args.zero_buf != nullptr) {               // (gated pair, first launch)
+    const int zi = (int)blockIdx.x * (64 * NWV) + (int)threadIdx.x;
+    if (zi < args.zero_count) args.zero_buf[zi] = 0;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
@@ -952,17 +957,18 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
 // ---- w3 of a gated FFN with the gate in its epilogue (tools/gen_fr_asm.py variant frg) ------------------------------------------------
 // The free-running 256 x 176 program; its epilogue turns the tile's 8-bit output indices and w1's (gate_aidx, written by the launch
 // before) into w2's int8 input image through the LDS-resident 64-KiB gated table: no index tensor of w3, no lookup launch.
+template <int BNT>
 __global__ void __launch_bounds__(512) gemm_i8_frg_kernel(const GemmArgs args) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 176;
+  const int m0 = tm * 256, n0 = tn * BNT;
   const int M = args.M, N = args.N, K = args.K;
   const int KT = K / BK;
-  unsigned sw[3];
+  unsigned sw[3] = {0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < (BNT == 176 ? 3 : 2); ++i) {
     int row = n0 + (wave + i * 8) * 8 + (lane >> 3);
     row = row < N ? row : N - 1;
     sw[i] = (unsigned)row * (unsigned)K + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
@@ -998,30 +1004,36 @@ __global__ void __launch_bounds__(512) gemm_i8_frg_kernel(const GemmArgs args) {
   const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
   const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
   const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
-  const int cg0 = __builtin_amdgcn_readfirstlane(tn * 11), mb0 = __builtin_amdgcn_readfirstlane(m0w >> 4);
+  const int cg0 = __builtin_amdgcn_readfirstlane(tn * (BNT / 16)), mb0 = __builtin_amdgcn_readfirstlane(m0w >> 4);
   const unsigned tid = threadIdx.x;
-  asm volatile(MQ_FRG_ASM_BODY
-               :
-               : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [aidx] "s"(aidx), [alpha] "s"(alpha_p),
-                 [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),
-                 [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [table] "s"(table), [qout] "s"(qout), [rsout] "s"(rsout),
-                 [cg0] "s"(cg0), [mb0] "s"(mb0), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [sw2] "v"(sw[2]), [av0] "v"(av0), [av1] "v"(av1),
-                 [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
-               : MQ_FRG_ASM_CLOBBERS);
+#define MQ_FRG_OPERANDS                                                                                                            \
+  [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [aidx] "s"(aidx), [alpha] "s"(alpha_p),                    \
+      [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),       \
+      [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [table] "s"(table), [qout] "s"(qout), [rsout] "s"(rsout),              \
+      [cg0] "s"(cg0), [mb0] "s"(mb0), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [av0] "v"(av0), [av1] "v"(av1),                          \
+      [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
+  if constexpr (BNT == 176) {
+    asm volatile(MQ_FRG_ASM_BODY : : MQ_FRG_OPERANDS, [sw2] "v"(sw[2]) : MQ_FRG_ASM_CLOBBERS);
+  } else {
+    asm volatile(MQ_FRG128_ASM_BODY : : MQ_FRG_OPERANDS : MQ_FRG128_ASM_CLOBBERS);
+  }
+#undef MQ_FRG_OPERANDS
 }
 
+template <int BNT>
 static int launch_frg(const GemmArgs& a, hipStream_t st) {
+  constexpr int LDS = BNT == 176 ? MQ_FRG_LDS_BYTES : MQ_FRG128_LDS_BYTES;
   static PerDeviceOnce attr_set;
   const int dev = current_device();
   if (!attr_set.done(dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_FRG_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frg_kernel<BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
-      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", MQ_FRG_LDS_BYTES, hipGetErrorString(e));
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
       return MQ_EHIP;
     }
     attr_set.mark(dev);
   }
-  gemm_i8_frg_kernel<<<a.grid_m * a.grid_n, 512, MQ_FRG_LDS_BYTES, st>>>(a);
+  gemm_i8_frg_kernel<BNT><<<a.grid_m * a.grid_n, 512, LDS, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
 }
@@ -1506,10 +1518,28 @@ int mq_w8a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int6
               0.f, 255.f, idx_scratch, MQ_U8, 0, 0, bias0 != nullptr, 1, 0, g_dbg_ts};
   GemmArgs g1{a_tiled, w1, (int)M, (int)N, (int)K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1,
               0.f, 255.f, q_tiled, MQ_U8, 0, 0, bias1 != nullptr, 1, 0, g_dbg_ts};
-  if (!gemm_tiled_supported(M, N, K) || !gemm_fr_supported(g0) || N % 64 != 0 || M > 256 * 512) {
-    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled_supported, K %% 256 == 0, K >= 768, N %% 64 == 0)", fn, (long long)M,
-              (long long)N, (long long)K);
+  const bool wide = gemm_tiled_supported(M, N, K) && gemm_fr_supported(g0) && N % 64 == 0;         // 256 x 176 tiles
+  const bool narrow = !wide && gemm_fr128_shape(M, N, K) && ((M + 255) / 256) * (N / 128) >= 192;  // 256 x 128 tiles (Gemma: N = 16384)
+  if (!(wide || narrow) || M > 256 * 512) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled_supported or N %% 128 == 0 with >= 192 tiles; K %% 256 == 0, K >= 768)",
+              fn, (long long)M, (long long)N, (long long)K);
     return MQ_EUNSUPPORTED;
+  }
+  g0.zero_buf = row_sum;
+  g0.zero_count = (int)M;
+  g1.gate_aidx = idx_scratch;
+  g1.gate_table = table;
+  g1.gate_q = q_tiled;
+  g1.gate_rowsum = row_sum;
+  if (narrow) {
+    rc = launch_fr128<FR128>(g0, as_stream(stream));
+    if (rc != MQ_OK) return rc;
+    g1.has_rowsum = g1.a_rowsum != nullptr;
+    if (g1.a_rowsum == nullptr) g1.a_rowsum = g1.col_term;
+    if (g1.bias == nullptr) g1.bias = g1.alpha;
+    g1.grid_m = (g1.M + 255) / 256;
+    g1.grid_n = g1.N / 128;
+    return launch_frg<128>(g1, as_stream(stream));
   }
   for (GemmArgs* g : {&g0, &g1}) {
     g->has_rowsum = g->a_rowsum != nullptr;
@@ -1518,15 +1548,9 @@ int mq_w8a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int6
     g->grid_m = (g->M + 255) / 256;
     g->grid_n = (g->N + 175) / 176;
   }
-  g0.zero_buf = row_sum;
-  g0.zero_count = (int)M;
-  g1.gate_aidx = idx_scratch;
-  g1.gate_table = table;
-  g1.gate_q = q_tiled;
-  g1.gate_rowsum = row_sum;
   rc = launch_fr(g0, as_stream(stream));
   if (rc != MQ_OK) return rc;
-  return launch_frg(g1, as_stream(stream));
+  return launch_frg<176>(g1, as_stream(stream));
 }
 
 static int linear_f32in(const char* fn, int w4, const float* x, const float* a_scale, const float* a_offset, float a_qmin,

@@ -1220,7 +1220,8 @@ def _gated_mlp_forward(self, x, resid=None):
     iq2 = w2.input_quantizer
     # everything static and the pair shape: w1, then w3 with the gate in its epilogue (table lookup -> w2's fragment-blocked image):
     # no index tensor of w3, no lookup launch
-    gate_fused = (pair and N % 64 == 0 and getattr(self, "gated_table", True) and getattr(self, "gated_epilogue", True)
+    narrow = (not pair) and t_hit is not None and ((M + 255) // 256) * (N // 128) >= 192     # 256 x 128 tiles (Gemma's FFN width)
+    gate_fused = ((pair or narrow) and N % 64 == 0 and getattr(self, "gated_table", True) and getattr(self, "gated_epilogue", True)
                   and resid is not None and resid.dtype == torch.float32 and resid.is_contiguous()
                   and not w2._weight_plan(wt2)["w4"] and w2._tiled_residual_ok(M, wt2.shape[0], N))
     if gate_fused:

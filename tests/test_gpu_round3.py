@@ -696,12 +696,13 @@ def test_attention_exponential_cache_depth_does_not_change_a_bit(dev, S, heads, 
     assert np.abs(outs[1].cpu().numpy() - want).max() <= 1.001 * float(pv[2].scale)
 
 
-@pytest.mark.parametrize("M,zp0", [(2048, False), (1700, True), (1537, False)])
-def test_gated_pair_with_the_lookup_in_the_epilogue_is_pair_plus_lookup(dev, M, zp0):
+@pytest.mark.parametrize("M,N,K,zp0", [(2048, 5632, 2048, False), (1700, 5632, 2048, True), (1537, 5632, 2048, False), (2048, 3072, 1024, False),
+                                       (1900, 4096, 768, True)])
+def test_gated_pair_with_the_lookup_in_the_epilogue_is_pair_plus_lookup(dev, M, N, K, zp0):
     """mq_w8a8_linear_tiled_gated (w1 launch + w3 launch whose generated epilogue does the table lookup) against
     mq_w8a8_linear_tiled_pair + mq_gated_lookup_tiled: the same fragment-blocked image of w2's input and the same row sums."""
     from mobilequant_amd import ops
-    N, K = 5632, 2048
+    from mobilequant_amd._lib import MQ_U8
     g = torch.Generator(device="cpu").manual_seed(M)
     halves = []
     a_q = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g).to(dev)
@@ -713,7 +714,11 @@ def test_gated_pair_with_the_lookup_in_the_epilogue_is_pair_plus_lookup(dev, M, 
     table = torch.randint(-128, 128, (65536,), dtype=torch.int8, generator=g).to(dev)
     a_t = _to_tiled(a_q)
     rs_in = None if zp0 else a_rs
-    ia, ib = ops.int8_linear_pair(a_t, M, rs_in, halves[0], halves[1])
+    if N % 176 == 0:
+        ia, ib = ops.int8_linear_pair(a_t, M, rs_in, halves[0], halves[1])
+    else:                                       # N = 3072 / 4096: the 256 x 128 tile variants (w1 on fr128, w3 on frg128)
+        ia, ib = (ops.int8_linear(a_t, h["w"], rs_in, h["alpha"], h["w_zp"], h["col_term"], h["bias"], out_scale=h["out_scale"],
+                                  out_offset=h["out_offset"], out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8, a_tiled_rows=M) for h in halves)
     q_want, rs_want = ops.gated_lookup(ia, ib, table, tiled=True)
     q_got, rs_got = ops.int8_linear_gated(a_t, M, rs_in, halves[0], halves[1], table)
     torch.cuda.synchronize()

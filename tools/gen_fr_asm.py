@@ -47,6 +47,7 @@ VARIANTS = {
     # w3 of a gated FFN with the rest of the chain in its epilogue: its 8-bit output index and w1's (read back from the first launch's
     # output) go through the 256 x 256 gated table (64 KiB, LDS-resident) -> w2's int8 input image, fragment-blocked, + row sums
     "frg":     (176, 8, "gate", "MQ_FRG",     "mq_gemm_frg_asm.inc"),
+    "frg128":  (128, 8, "gate", "MQ_FRG128",  "mq_gemm_frg128_asm.inc"),     # the same on 256 x 128 tiles (Gemma's FFN: N = 16384)
 }
 
 
@@ -62,7 +63,7 @@ def configure(name):
     STG = PAR + 16 * BN
     if EPI == "gate":
         # staging tiles alias the W ring (one barrier after the loop): table 64 KiB + ring 88 KiB + vectors = 158 464 B of the 160 KiB
-        ROWP = BN
+        ROWP = BN if BN % 128 else BN + 16
         STG_WAVE = 2 * 16 * ROWP
         STG = RING_BASE
         LDS_BYTES = PAR + 16 * BN
@@ -395,7 +396,8 @@ S_GM = 84                           # 84..95: exec masks of (i, r)
 
 
 def epilogue_gate_tail(R):
-    assert R == 3 and FN == 11
+    assert (R, FN) in ((3, 11), (2, 8))
+    NR6 = (FN + 1) // 2             # rounds of the image store: two chunk columns per round
     A0, T0, AD0 = 24, 48, 64        # w1 index chunks v[24:47]; looked-up bytes v[48:63]; addresses v[64:79]
     GO1 = 117                       # 117..119: global offsets of the second row block (V_E + 3 .. 5 are free)
     emit(f"s_lshl_b32 s{S_TMP2}, %[ldn], 4")                                 # 16 rows further down
@@ -482,10 +484,10 @@ def epilogue_gate_tail(R):
     emit(f"v_mul_lo_u32 v{V_BLK}, v{V_BLK}, s{S_TMP2}")                      # (mb0 + (row32 >> 4)) * blocks per row
     emit(f"v_and_b32 v{V_R16}, 15, v{V_RA}")
     emit(f"v_lshlrev_b32 v{V_R16}, 4, v{V_R16}")                             # (row32 & 15) * 16
-    for r6 in range(6):
+    for r6 in range(NR6):
         emit(f"ds_read_b128 v[{4 * r6}:{4 * r6 + 3}], v{V_T2} offset:{32 * r6}")
     emit("s_waitcnt lgkmcnt(0)")
-    for r6 in range(6):
+    for r6 in range(NR6):
         emit(f"s_add_u32 s{S_TMP}, %[cg0], {2 * r6}")
         emit(f"v_add_u32 v{T0}, s{S_TMP}, v{V_HI}")                          # chunk column of the whole matrix
         emit(f"v_lshrrev_b32 v{T0 + 1}, 2, v{T0}")
@@ -494,8 +496,8 @@ def epilogue_gate_tail(R):
         emit(f"v_lshlrev_b32 v{T0}, 8, v{T0}")
         emit(f"v_lshl_add_u32 v{T0 + 1}, v{T0 + 1}, 10, v{T0}")
         emit(f"v_add_u32 v{T0 + 1}, v{T0 + 1}, v{V_R16}")
-        if r6 == 5:
-            emit(f"v_cmp_eq_u32 vcc, 0, v{V_HI}")                            # chunk 11 does not exist
+        if 2 * r6 + 1 >= FN:
+            emit(f"v_cmp_eq_u32 vcc, 0, v{V_HI}")                            # chunk FN does not exist
             emit(f"s_and_b64 vcc, vcc, s[{S_GM}:{S_GM + 1}]")
             emit("s_and_b64 exec, exec, vcc")
         else:
@@ -812,7 +814,7 @@ def main(path=None, variant="fr"):
     here = os.path.dirname(os.path.abspath(__file__))
     path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", FILE)
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
-    vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(V_T if 8 * FN > 78 else 78, 128))]
+    vregs = [f'"v{r}"' for r in list(range(0, 88 if EPI == "gate" else 8 * FN)) + list(range(V_T if (8 * FN > 78 or EPI == "gate") else 78, 128))]
     aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32)]
     sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)] + (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
