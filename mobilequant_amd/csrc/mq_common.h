@@ -60,6 +60,26 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
   return __builtin_fmaf(__builtin_fmaf(-q0, s, x), inv_s, q0);
 }
 
+// Four activations -> the dword of their int8 image bytes (index - shift), for the image-only kernels.  index = clamp(rint(x / s) + o):
+// (rint(t) - t) + t, the reference's round_ste, IS rint(t) in fp32 for every t (|t| >= 0.5: rint(t) and t are within a factor of two,
+// the difference is exact and adding t back lands on the representable rint(t); |t| < 0.5: (0 - t) + t = 0; x = +-inf / NaN: t is
+// already NaN, div_by_scale).  The clamp is one v_med3_f32, which returns min3 when an operand is a (quiet) NaN: NaN -> qmin, the
+// integer image's convention.  u = index + (128 - shift) lies in [0, 255] (the host checks that index - shift fits int8), so
+// v_cvt_pk_u8_f32 converts AND packs in one instruction; the int8 bytes are u ^ 0x80 and sum(index - shift) = sum(u) - 128 n with
+// sum(u) from one v_sad_u8 per dword (`usum` accumulates it).  ~8.5 VALU instructions per element instead of ~16.
+__device__ __forceinline__ float image_u8f(float x, float s, float inv_s, float o, float qmin, float qmax, float bias) {
+  const float t = div_by_scale(x, s, inv_s);
+  return __fadd_rn(__builtin_amdgcn_fmed3f(__fadd_rn(rintf(t), o), qmin, qmax), bias);
+}
+__device__ __forceinline__ uint32_t image_pack4(float u0, float u1, float u2, float u3, uint32_t& usum) {
+  uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(u0, 0u, 0u);
+  pk = __builtin_amdgcn_cvt_pk_u8_f32(u1, 1u, pk);
+  pk = __builtin_amdgcn_cvt_pk_u8_f32(u2, 2u, pk);
+  pk = __builtin_amdgcn_cvt_pk_u8_f32(u3, 3u, pk);
+  usum = __builtin_amdgcn_sad_u8(pk, 0u, usum);
+  return pk ^ 0x80808080u;
+}
+
 // 64-lane wave reductions on DPP moves (wave = 64 on gfx950): quad permutes, row_half_mirror, row_mirror leave every lane of a
 // 16-lane row with the row's result; the four rows meet through v_readlane.  A __shfl_xor is a ds_bpermute -- an LDS round trip
 // of ~100 cycles -- and six dependent ones cost a short kernel more than its arithmetic (decode: 0.25 us of a 3 us launch).  The

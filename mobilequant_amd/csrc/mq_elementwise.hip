@@ -546,6 +546,7 @@ __global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __re
   const int64_t row0 = (int64_t)blockIdx.x * 8;
   const float s = scale[0], o = offset[0];
   const float inv_s = __fdiv_rn(1.0f, s);
+  const float ubias = (float)(128 - shift);               // image_u8f / image_pack4 (mq_common.h)
   float4 xs[2][V];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -556,30 +557,25 @@ __global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __re
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int acc = 0;
+    uint32_t usum = 0;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const int i = lane + 256 * k;
       if (i < nvec) {
-        const float f[4] = {xs[j][k].x, xs[j][k].y, xs[j][k].z, xs[j][k].w};
-        uint32_t pk = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int st_v = static_cast<int>(q_index(f[e], s, inv_s, o, qmin, qmax)) - shift;
-          acc += st_v;
-          pk |= (static_cast<uint32_t>(st_v) & 0xffu) << (8 * e);
-        }
+        const float4 f = xs[j][k];
+        const uint32_t pk = image_pack4(image_u8f(f.x, s, inv_s, o, qmin, qmax, ubias), image_u8f(f.y, s, inv_s, o, qmin, qmax, ubias),
+                                        image_u8f(f.z, s, inv_s, o, qmin, qmax, ubias), image_u8f(f.w, s, inv_s, o, qmin, qmax, ubias), usum);
         *reinterpret_cast<uint32_t*>(stage8 + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
       }
     }
     if (HAS_SUM) {
-      acc = mq::wave_sum(acc);
+      const int acc = mq::wave_sum((int)usum);
       if ((threadIdx.x & 63) == 0) s_part[grp * 2 + j][wv_id] = acc;
     }
   }
   __syncthreads();
   if (HAS_SUM && threadIdx.x < 8 && row0 + threadIdx.x < rows)
-    row_sum[row0 + threadIdx.x] = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]);
+    row_sum[row0 + threadIdx.x] = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]) - 128 * (int)cols;
   const int units = (int)(cols >> 1);                               // 8 rows x cols / 16 sixteen-byte units
   const int64_t rb = row0 >> 4;
   const int half = (int)(row0 & 15);

@@ -248,7 +248,16 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
   }
   const float so = a.out_scale[0], oo = a.out_offset[0];
   const float isi = __fdiv_rn(1.0f, si), iso = __fdiv_rn(1.0f, so);
-  auto qin = [&](float v) { return has_in ? nq_dequant(nq_index(v, si, isi, oi, a.in_qmin, a.in_qmax), si, oi) : v; };
+  // input quantizer, value form.  A NaN / inf element must still poison its row (the reference's clamp propagates NaN): the clamp is a
+  // v_med3 (NaN -> qmin) and `probe` = fma(v, 0, probe) turns NaN for such an element; it is added to the row statistic (+ 0.0 otherwise).
+  float probe = 0.f;
+  auto qin = [&](float v) {
+    if (!has_in) return v;
+    probe = __builtin_fmaf(v, 0.f, probe);
+    const float t = div_by_scale(v, si, isi);
+    return nq_dequant(__builtin_amdgcn_fmed3f(__fadd_rn(rintf(t), oi), a.in_qmin, a.in_qmax), si, oi);
+  };
+  const float ubias = (float)(128 - a.q_shift);                    // image_u8f / image_pack4 (mq_common.h)
   float4 xs[2][V];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {                                     // every load of both rows goes out before any arithmetic
@@ -273,6 +282,7 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
   for (int j = 0; j < 2; ++j) {
     const int64_t row = row0 + grp * 2 + j;
     float ss = 0.f;
+    probe = 0.f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       if (lane + 256 * k < nvec) {
@@ -291,6 +301,7 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
 #pragma unroll
       for (int k = 0; k < V; ++k)
         if (lane + 256 * k < nvec) s1 += (xs[j][k].x + xs[j][k].y) + (xs[j][k].z + xs[j][k].w);
+      s1 += probe;
       const float mu = __fdiv_rn(group_sum(s1, j, 0), (float)cols);
       float s2 = 0.f;
 #pragma unroll
@@ -307,11 +318,11 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
       r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, a.eps)));
       shiftv = __fmul_rn(-r, mu);
     } else {
-      ss = group_sum(ss, j, 2);
+      ss = group_sum(ss + probe, j, 2);
       const float mean = __fdiv_rn(ss, (float)cols);
       r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, a.eps)));
     }
-    int acc = 0;
+    uint32_t usum = 0;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const int i = lane + 256 * k;
@@ -329,25 +340,21 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
           const float4 b = bv[i];
           y0 = __fadd_rn(y0, b.x); y1 = __fadd_rn(y1, b.y); y2 = __fadd_rn(y2, b.z); y3 = __fadd_rn(y3, b.w);
         }
-        const float q0 = nq_index(y0, so, iso, oo, a.out_qmin, a.out_qmax), q1 = nq_index(y1, so, iso, oo, a.out_qmin, a.out_qmax);
-        const float q2 = nq_index(y2, so, iso, oo, a.out_qmin, a.out_qmax), q3 = nq_index(y3, so, iso, oo, a.out_qmin, a.out_qmax);
-        const int s0 = (int)fmaxf(q0, a.out_qmin) - a.q_shift, s1 = (int)fmaxf(q1, a.out_qmin) - a.q_shift;
-        const int s2 = (int)fmaxf(q2, a.out_qmin) - a.q_shift, s3 = (int)fmaxf(q3, a.out_qmin) - a.q_shift;
-        acc += (s0 + s1) + (s2 + s3);
-        const unsigned pk = (unsigned)(s0 & 0xff) | ((unsigned)(s1 & 0xff) << 8) | ((unsigned)(s2 & 0xff) << 16) | ((unsigned)(s3 & 0xff) << 24);
+        const uint32_t pk = image_pack4(image_u8f(y0, so, iso, oo, a.out_qmin, a.out_qmax, ubias), image_u8f(y1, so, iso, oo, a.out_qmin, a.out_qmax, ubias),
+                                        image_u8f(y2, so, iso, oo, a.out_qmin, a.out_qmax, ubias), image_u8f(y3, so, iso, oo, a.out_qmin, a.out_qmax, ubias), usum);
         // staging: piece (k >> 4) = 16-byte chunk column, then the row of the eight, then the byte:  k = 4 i
         *reinterpret_cast<unsigned*>(stage + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
       }
     }
     if (a.row_sum) {
-      acc = wave_sum(acc);
+      const int acc = wave_sum((int)usum);
       if ((threadIdx.x & 63) == 0) s_redi[j][grp][wv_id] = acc;
     }
   }
   __syncthreads();                                                  // the staging tile and the row-sum partials are complete
   if (a.row_sum && threadIdx.x < 8) {
     const int g = threadIdx.x >> 1, j = threadIdx.x & 1;
-    if (row0 + threadIdx.x < a.rows) a.row_sum[row0 + threadIdx.x] = (s_redi[j][g][0] + s_redi[j][g][1]) + (s_redi[j][g][2] + s_redi[j][g][3]);
+    if (row0 + threadIdx.x < a.rows) a.row_sum[row0 + threadIdx.x] = (s_redi[j][g][0] + s_redi[j][g][1]) + (s_redi[j][g][2] + s_redi[j][g][3]) - 128 * cols;
   }
   // copy-out: 16-byte unit p = 8 piece + row;  piece = 4 kb + kq  ->  block (row0 >> 4, kb), byte 256 kq + 16 ((row0 & 15) + row)
   const int units = cols >> 1;                                      // 8 rows x cols / 16

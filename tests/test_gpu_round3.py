@@ -645,6 +645,47 @@ def test_staged_quantize_tiled_writes_the_same_image(dev, rows, cols):
     assert torch.equal(un(q0), un(q1))
 
 
+@pytest.mark.parametrize("signed", [False, True])
+def test_packed_convert_image_kernels_on_saturating_and_non_finite_inputs(dev, signed):
+    """The staged norm / quantize kernels form their bytes with v_med3 + v_cvt_pk_u8_f32 + v_sad_u8 (mq_common.h image_u8f / image_pack4):
+    same bytes and row sums as the generic kernels on values far outside the grid, on a signed grid (shift 0), and with NaN / +-inf
+    elements -- a non-finite element saturates to qmin in mq_quantize_tiled and poisons its whole row in the norm (every index qmin)."""
+    import mobilequant_amd._lib as L
+    from mobilequant_amd import ops
+    rows, cols = 200, 2048
+    g = torch.Generator(device="cpu").manual_seed(17 + signed)
+    x = torch.randn(rows, cols, generator=g) * 3.0
+    x[3, 5], x[3, 900], x[77, 0], x[150, 2047] = float("nan"), 1e30, float("inf"), float("-inf")
+    x[10] *= 1e6
+    x = x.to(dev)
+    un = lambda q, Mp: q.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]   # noqa: E731
+    qmin, qmax, shift, off = (-128.0, 127.0, 0, 3.0) if signed else (0.0, 255.0, 128, 131.0)
+    sc, of = torch.tensor([0.031], device=dev), torch.tensor([off], device=dev)
+    L.load().mq_quantize_tiled_set_staged(0)
+    try:
+        q0, rs0 = ops.quantize_tiled(x, sc, of, qmin, qmax, shift)
+    finally:
+        L.load().mq_quantize_tiled_set_staged(1)
+    q1, rs1 = ops.quantize_tiled(x, sc, of, qmin, qmax, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(rs0, rs1) and torch.equal(un(q0, q0.shape[0]), un(q1, q1.shape[0]))
+    assert int(un(q1, q1.shape[0])[3, 5]) == int(qmin) - shift and int(un(q1, q1.shape[0])[3, 900]) == int(qmax) - shift
+    w = (1.0 + 0.1 * torch.randn(cols, generator=g)).to(dev)
+    gi = (torch.tensor([40.0 / 65535], device=dev), torch.tensor([32768.0], device=dev), 0.0, 65535.0)
+    go = (torch.tensor([8.0 / 255], device=dev), torch.tensor([off], device=dev), qmin, qmax)
+    for ln in (False, True):
+        b = (0.1 * torch.randn(cols, generator=g)).to(dev) if ln else None
+        for gin in (gi, None):
+            _, q, rs, sh, _ = ops.rmsnorm_quant(x, w, b, 1e-5, gin, go, emit_int8=True, layernorm=ln, emit_tiled=False, want_y=False, emit_rowmajor=True)
+            _, _, rst, sht, qt = ops.rmsnorm_quant(x, w, b, 1e-5, gin, go, emit_int8=True, layernorm=ln, emit_tiled=True, want_y=False, emit_rowmajor=False)
+            torch.cuda.synchronize()
+            assert sh == sht and torch.equal(rs, rst)
+            back = un(qt, (rows + 15) // 16 * 16)
+            assert torch.equal(back, q.view(rows, cols))
+            for r in ((3, 77, 150) if gin is not None else (3,)):   # no input quantizer: an inf row has 1 / rms = 0, only inf * 0 is NaN
+                assert bool((back[r] == int(qmin) - sh).all())
+
+
 def test_decode_engine_switches_to_the_split_attention_graph_on_a_long_cache(dev):
     """DecodeEngine(attn_splits=None) records two step graphs when the cache is longer than LONG_FROM and replays the split-attention one
     from LONG_FROM cached positions on: the logits are those of a one-workgroup-per-head engine, bit for bit, on both sides of the
