@@ -52,13 +52,6 @@ __device__ __forceinline__ AGrid a_load_grid(const mq_grid& g) {
   r.inv_s = __fdiv_rn(1.0f, r.s);
   return r;
 }
-// exact form (qmodule.py:286-287), used by the prep kernel
-__device__ __forceinline__ float a_index_exact(float x, const AGrid& g) {
-  const float t = div_by_scale(x, g.s, g.inv_s);       // == x / s on the quantizer's domain (mq_common.h)
-  const float q = __fadd_rn(__fadd_rn(__fsub_rn(rintf(t), t), t), g.o);
-  const float c = fminf(fmaxf(q, g.qmin), g.qmax);
-  return q != q ? g.qmin : c;
-}
 // reciprocal-multiply form, used inside the attention kernel
 __device__ __forceinline__ float a_index_fast(float x, const AGrid& g) {
   return fminf(fmaxf(rintf(x * g.inv_s) + g.o, g.qmin), g.qmax);
@@ -101,14 +94,14 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   };
   const AGrid g = a_load_grid(is_q ? a.qk_a : (is_k ? a.qk_b : a.pv_b));
   const int rot = a.rot_dim > 0 ? a.rot_dim : D;
-  int sum = 0;
+  uint32_t usum = 0;                                 // sum of the stored bytes + 128 each (image_pack4, mq_common.h)
 #pragma unroll 1
   for (int dc = 0; dc < D / 64; ++dc) {
   const int col0 = 64 * dc + 16 * c;
   float x[16];
   if (isrc) load16_idx(isrc + col0, x);
   else load16(src + col0, x);
-  int st[16];
+  float y16[16];                                     // the values the input quantizer sees
   if ((is_q || is_k) && rot != D) {
     // partial rotary (hf_model.py:489-500; StableLM-2: 16 of 64 dims): dims d < rot rotate with partner d +- rot/2 and cos / sin
     // [S, rot]; the rest passes through.  Element-wise form (the full-rotary path below keeps its vector loads).
@@ -126,7 +119,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
         const float sg = d < half ? -1.f : 1.f;
         y = __fadd_rn(__fmul_rn(x[i], a.cos[(size_t)s * rot + d]), __fmul_rn(sg * p, a.sin[(size_t)s * rot + d]));
       }
-      st[i] = (int)a_index_exact(y, g) - 128;
+      y16[i] = y;
     }
   } else if (is_q || is_k) {                          // RoPE (rotate-half): x * cos + rot(x) * sin, rot(x)[d] = d < D/2 ? -x[d + D/2] : x[d - D/2]
     float pr[16], cs[16], sn[16];
@@ -136,29 +129,22 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     load16(a.sin + (size_t)s * D + col0, sn);
     const float sign = col0 < D / 2 ? -1.f : 1.f;     // (-x) * sin == -(x * sin) exactly
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float y = __fadd_rn(__fmul_rn(x[i], cs[i]), __fmul_rn(sign * pr[i], sn[i]));
-      st[i] = (int)a_index_exact(y, g) - 128;
-    }
+    for (int i = 0; i < 16; ++i) y16[i] = __fadd_rn(__fmul_rn(x[i], cs[i]), __fmul_rn(sign * pr[i], sn[i]));
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st[i] = (int)a_index_exact(x[i], g) - 128;
+    for (int i = 0; i < 16; ++i) y16[i] = x[i];
   }
+  // exact divide form of the quantizer (qmodule.py:286-287), bytes = index - 128 (8-bit unsigned grids: the host checks), NaN -> qmin
   unsigned w[4];
 #pragma unroll
-  for (int d4 = 0; d4 < 4; ++d4) {
-    unsigned pk = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sum += st[4 * d4 + e];
-      pk |= ((unsigned)st[4 * d4 + e] & 0xffu) << (8 * e);
-    }
-    w[d4] = pk;
-  }
+  for (int d4 = 0; d4 < 4; ++d4)
+    w[d4] = image_pack4(image_idxf(y16[4 * d4], g.s, g.inv_s, g.o, g.qmin, g.qmax), image_idxf(y16[4 * d4 + 1], g.s, g.inv_s, g.o, g.qmin, g.qmax),
+                        image_idxf(y16[4 * d4 + 2], g.s, g.inv_s, g.o, g.qmin, g.qmax), image_idxf(y16[4 * d4 + 3], g.s, g.inv_s, g.o, g.qmin, g.qmax), usum);
   if (is_q || is_k) {
     int8_t* dst = (is_q ? a.q_i8 + ((size_t)head * S + s) * D : a.k_i8 + ((size_t)head * CS + P0 + s) * D) + col0;
     *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
     if (dc == D / 64 - 1) {
+      int sum = (int)usum - 32 * D;                    // D / 4 bytes per thread, each stored + 128
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);
       // the zero-point terms of sum_d (qi - zq)(ki - zk) = sum qs ks - zq' rowsum(ks) - zk' rowsum(qs) + D zq' zk'  (primes: - 128)
@@ -171,7 +157,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   } else {
     // vT [KV][S/64][D][64]: position kappa of key t (inside its 64-block): t = 16 j + 4 tq + e  <->  kappa = 16 tq + 4 j + e
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s_v[16 * c + i][r] = (int8_t)st[i];
+    for (int i = 0; i < 16; ++i) s_v[16 * c + i][r] = (int8_t)(w[i >> 2] >> (8 * (i & 3)));
     __syncthreads();
     // thread (d = tid >> 2, quarter c): 16 kappa = 16 c .. 16 c + 15  -> tq = c, (j, e) = (i >> 2, i & 3) -> t = 16 j + 4 c + e
     const int d = threadIdx.x >> 2;

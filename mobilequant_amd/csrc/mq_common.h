@@ -67,9 +67,12 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
 // integer image's convention.  u = index + (128 - shift) lies in [0, 255] (the host checks that index - shift fits int8), so
 // v_cvt_pk_u8_f32 converts AND packs in one instruction; the int8 bytes are u ^ 0x80 and sum(index - shift) = sum(u) - 128 n with
 // sum(u) from one v_sad_u8 per dword (`usum` accumulates it).  ~8.5 VALU instructions per element instead of ~16.
-__device__ __forceinline__ float image_u8f(float x, float s, float inv_s, float o, float qmin, float qmax, float bias) {
+__device__ __forceinline__ float image_idxf(float x, float s, float inv_s, float o, float qmin, float qmax) {
   const float t = div_by_scale(x, s, inv_s);
-  return __fadd_rn(__builtin_amdgcn_fmed3f(__fadd_rn(rintf(t), o), qmin, qmax), bias);
+  return __builtin_amdgcn_fmed3f(__fadd_rn(rintf(t), o), qmin, qmax);
+}
+__device__ __forceinline__ float image_u8f(float x, float s, float inv_s, float o, float qmin, float qmax, float bias) {
+  return __fadd_rn(image_idxf(x, s, inv_s, o, qmin, qmax), bias);
 }
 __device__ __forceinline__ uint32_t image_pack4(float u0, float u1, float u2, float u3, uint32_t& usum) {
   uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(u0, 0u, 0u);
