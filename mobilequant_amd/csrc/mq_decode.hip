@@ -29,11 +29,11 @@ __device__ __forceinline__ float dq_clamp_nan(float q, float lo, float hi) {
 }
 // (x / s: div_by_scale of mq_common.h -- at M = 1 every CU quantises the whole activation row, and that arithmetic is on the
 // launch's critical path)
-// qmodule.py:286-290 with round_ste = (round(t) - t) + t (as mq_norm.hip / mq_elementwise.hip)
+// qmodule.py:286-290.  round_ste = (round(t) - t) + t IS rint(t) in fp32 for every t div_by_scale returns (finite or NaN, never inf:
+// mq_common.h image_idxf has the argument) -- two instructions fewer on the M = 1 critical path
 __device__ __forceinline__ float dq_index(float x, float s, float inv_s, float o, float qmin, float qmax) {
   const float t = div_by_scale(x, s, inv_s);
-  const float r = __fadd_rn(__fsub_rn(rintf(t), t), t);
-  return dq_clamp_nan(__fadd_rn(r, o), qmin, qmax);
+  return dq_clamp_nan(__fadd_rn(rintf(t), o), qmin, qmax);
 }
 __device__ __forceinline__ float dq_dequant(float q, float s, float o) { return __fmul_rn(__fsub_rn(q, o), s); }
 
