@@ -61,12 +61,12 @@ __device__ __forceinline__ float a_index_fast(float x, const AGrid& g) {
 // grid: (S / 64, H + 2 KV).  Block b of part p: rows s = 64 b .. 64 b + 63.  256 threads: thread (r = tid >> 2, c = tid & 3) handles
 // row r, 16 columns 64 dc + 16 c .. + 15 of every 64-column slab dc (D = 64: one slab; D = 256: four).
 template <int D>
-__global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_args a) {
+__global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_args a, const int part0) {
   const int H = a.heads, KV = a.kv_heads, S = a.seq;
   // cache continuation (chunked prefill): the K / vT images, their row sums and the v prefix sums are caller-owned caches of cache_seq
   // rows; this chunk's rows go to positions pos0 .. pos0 + seq - 1 (pos0 % 64 == 0).  cache_seq = 0: scratch of seq rows, pos0 = 0.
   const int CS = a.cache_seq > 0 ? a.cache_seq : S, P0 = a.cache_seq > 0 ? a.pos0 : 0;
-  const int part = blockIdx.y;                       // [0, H): q head; [H, H+KV): k head; [H+KV, H+2KV): v head
+  const int part = blockIdx.y + part0;               // [0, H): q head; [H, H+KV): k head; [H+KV, H+2KV): v head  (part0 = H: the core kernel prepares its own q rows)
   const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
   const int s = blockIdx.x * 64 + r;
   __shared__ int8_t s_v[64][64 + 4];
@@ -221,7 +221,11 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // BIG (head_dim 64): the deep exponential cache (four blocks in the LDS, five in registers: two waves per SIMD), the production
 // configuration; !BIG: two blocks in the LDS, three waves per SIMD (mq_attention_set_cache(1), A/B timing).  Prep + core at S = 2048,
 // deep vs small: 77.3 vs 85.6 us (32 / 4 heads), 73.5 vs 82.8 (32 / 8), 80.6 vs 93.5 (32 / 32); identical images.
-template <int D, bool QK_OUT, bool BIG = false>
+// QPREP (head_dim 64, full rotary): the workgroup prepares its own 64 query rows -- the prep kernel's arithmetic for a q part, op for
+// op, with thread (wave, lane) on row 16 wave + (lane & 15), columns 16 (lane >> 4) .. + 15: exactly the 16 bytes this lane feeds the
+// score MFMAs, so the q image never exists in memory and the prep launch shrinks to the k / v parts (H + 2 KV -> 2 KV workgroups per
+// row block; 80 % of its work at 32 / 4 heads).
+template <int D, bool QK_OUT, bool BIG = false, bool QPREP = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2), D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2))))
     attention_quant_kernel(const mq_attention_args a) {
   static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
@@ -248,11 +252,57 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
   const float flo = kMagic + gqo.qmin, fhi = kMagic + gqo.qmax;
   const float cexp = QK_OUT ? gqo.s * kInvSqrtD * kLog2e : kLog2e;  // exp(value - max) = exp2((f - fmax) * cexp)
 
-  const int8_t* qbase = a.q_i8 + ((size_t)h * S + (size_t)qb * 64 + wave * 16) * D;
   v4i qf[NKS];
+  int qconst;                                                       // D zq zk - zk * rowsum(q)
+  if constexpr (QPREP) {
+    static_assert(D == 64 || !QPREP, "in-kernel q preparation: head_dim 64");
+    const int col0 = 16 * tq, colp = (col0 + 32) & 63;
+    float x[16], pr[16], cs[16], sn[16];
+    auto load16 = [](const float* p, float (&d)[16]) {
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qbase + srow * D + ks * 64 + tq * 16);
-  const int qconst = a.q_rowsum[(size_t)h * S + s_abs];             // D zq zk - zk * rowsum(q), from the prep kernel
+      for (int i = 0; i < 4; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(p)[i];
+        d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
+      }
+    };
+    if (a.qkv_idx) {                                                // the fused q|k|v GEMM's uint8 indices, dequantised as that linear's fp32 output would read
+      const AGrid gin = a_load_grid(a.q_in);
+      const uint8_t* ip = a.qkv_idx + ((size_t)s_abs * (H + 2 * KV) + h) * D;
+      const uint4 t0 = *reinterpret_cast<const uint4*>(ip + col0), t1 = *reinterpret_cast<const uint4*>(ip + colp);
+      const unsigned w0[4] = {t0.x, t0.y, t0.z, t0.w}, w1[4] = {t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = __fmul_rn(__fsub_rn((float)((w0[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
+        pr[i] = __fmul_rn(__fsub_rn((float)((w1[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
+      }
+    } else {
+      const float* src = a.q + (size_t)s_abs * H * D + (size_t)h * D;
+      load16(src + col0, x);
+      load16(src + colp, pr);
+    }
+    load16(a.cos + (size_t)s_abs * D + col0, cs);
+    load16(a.sin + (size_t)s_abs * D + col0, sn);
+    const float sign = col0 < D / 2 ? -1.f : 1.f;
+    uint32_t usum = 0;
+#pragma unroll
+    for (int d4 = 0; d4 < 4; ++d4) {
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(x[4 * d4 + e], cs[4 * d4 + e]), __fmul_rn(sign * pr[4 * d4 + e], sn[4 * d4 + e]));
+      qf[0][d4] = (int)image_pack4(image_idxf(y[0], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax), image_idxf(y[1], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax),
+                                   image_idxf(y[2], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax), image_idxf(y[3], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax), usum);
+    }
+    int sum = (int)usum - 128 * 16;
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const int zq = (int)gqa.o - 128, zk = (int)gqb.o - 128;
+    qconst = D * zq * zk - zk * sum;
+  } else {
+    const int8_t* qbase = a.q_i8 + ((size_t)h * S + (size_t)qb * 64 + wave * 16) * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qbase + srow * D + ks * 64 + tq * 16);
+    qconst = a.q_rowsum[(size_t)h * S + s_abs];                     // from the prep kernel
+  }
   const int8_t* kbase = a.k_i8 + (size_t)kvh * CS * D;
   const int* kterm = a.k_rowsum + (size_t)kvh * CS;                 // -zq * rowsum(k)
   const int nkb = PB + qb + 1;                                      // key blocks 0 .. PB + qb (causal; PB cached blocks in front)
@@ -626,6 +676,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
 
 using namespace mq;
 
+static std::atomic<int> g_att_qprep{1};       // tuning hook: 0 = the prep kernel writes the q image too (A/B timing)
+extern "C" int mq_attention_set_fused_q(int on) {
+  g_att_qprep = on ? 1 : 0;
+  return 0;
+}
 static std::atomic<int> g_att_cache{0};       // tuning hook: 1 = small exponential cache, anything else = the deep cache
 extern "C" int mq_attention_set_cache(int mode) {
   g_att_cache = mode == 1 ? 1 : 0;
@@ -664,15 +719,19 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   hipStream_t st = as_stream(stream);
   const dim3 pgrid((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), cgrid((unsigned)(a.seq / 64 * a.heads));
   if (a.head_dim == 64) {
-    attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a);
-    MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
     const bool big = g_att_cache.load() != 1;
+    // production configuration (16-bit score grid, deep cache, full rotary): the core kernel prepares its own q rows
+    const bool qprep = big && a.qk_out.scale != nullptr && (a.rot_dim == 0 || a.rot_dim == 64) && g_att_qprep.load() != 0;
+    if (qprep) attention_prep_kernel<64><<<dim3(pgrid.x, (unsigned)(2 * a.kv_heads)), 256, 0, st>>>(a, a.heads);
+    else attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a, 0);
+    MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
     if (a.qk_out.scale == nullptr) attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
+    else if (qprep) attention_quant_kernel<64, true, true, true><<<cgrid, 256, 0, st>>>(a);
     else if (big) attention_quant_kernel<64, true, true><<<cgrid, 256, 0, st>>>(a);
     else attention_quant_kernel<64, true><<<cgrid, 256, 0, st>>>(a);
   } else {
-    if (a.head_dim == 128) attention_prep_kernel<128><<<pgrid, 256, 0, st>>>(a);
-    else attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a);
+    if (a.head_dim == 128) attention_prep_kernel<128><<<pgrid, 256, 0, st>>>(a, 0);
+    else attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a, 0);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
     attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1), 256, 0, st>>>(a.v_prefix, a.cache_seq > 0 ? a.pos0 / 64 : 0, a.seq / 64,
                                                                                (a.cache_seq > 0 ? a.cache_seq : a.seq) / 64, a.head_dim);

@@ -731,10 +731,46 @@ def test_attention_exponential_cache_depth_does_not_change_a_bit(dev, S, heads, 
             outs.append(ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids))
         finally:
             L.load().mq_attention_set_cache(0)
+    # ... and the q rows prepared inside the attention workgroups (default) against the prep kernel's q image
+    L.load().mq_attention_set_fused_q(0)
+    try:
+        outs.append(ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids))
+    finally:
+        L.load().mq_attention_set_fused_q(1)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     want = O.attention_sim(q, k, v, cos, sin, heads, kv_heads, qk, pv)
     assert np.abs(outs[1].cpu().numpy() - want).max() <= 1.001 * float(pv[2].scale)
+
+
+@pytest.mark.parametrize("S,heads,kv_heads", [(200, 4, 2), (1024, 8, 1)])
+def test_attention_q_rows_prepared_in_the_core_kernel_from_gemm_indices(dev, S, heads, kv_heads):
+    """Index input (the fused q|k|v GEMM's uint8 output indices, ragged S): the attention workgroups dequantise, rotate and quantise their
+    own q rows (mq_attention_set_fused_q(1), default) -- same fp32 output, int8 image and row sums as with the prep kernel's q image."""
+    import mobilequant_amd._lib as L
+    from test_gpu_round2 import _grid_of
+    from mobilequant_amd import ops
+    _, _, _, cos, sin, qk, pv = _case(S, heads, kv_heads, 64, 64, seed=S + 1)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    g = torch.Generator(device="cpu").manual_seed(S)
+    idx = torch.randint(0, 256, (S, (heads + 2 * kv_heads) * 64), dtype=torch.uint8, generator=g).to(dev)
+    in_grids = tuple((torch.tensor([0.03 + 0.01 * i], device=dev), torch.tensor([127.0 + i], device=dev)) for i in range(3))
+    res = []
+    for on in (0, 1):
+        L.load().mq_attention_set_fused_q(on)
+        try:
+            img = torch.zeros(S, heads * 64, dtype=torch.int8, device=dev)
+            rs = torch.zeros(S, dtype=torch.int32, device=dev)
+            out = ops.attention_quant(None, None, None, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), heads, kv_heads, grids,
+                                      image=(img, rs, 0, 128, False), qkv_idx=(idx, in_grids))
+            res.append((out, img, rs))
+        finally:
+            L.load().mq_attention_set_fused_q(1)
+    torch.cuda.synchronize()
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    assert float(res[1][0].abs().max()) > 0
 
 
 @pytest.mark.parametrize("M,N,K,zp0", [(2048, 5632, 2048, False), (1700, 5632, 2048, True), (1537, 5632, 2048, False), (2048, 3072, 1024, False),
