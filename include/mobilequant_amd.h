@@ -422,7 +422,8 @@ int mq_decode_head(const float* x, const float* norm_weight, const float* norm_b
  * Causal mask only (the mask of hf_model.py:1180-1205 at prefill); the scores are divided by sqrt(D) AFTER qk_out, as the reference.
  * Scratch (caller-owned, overwritten): q_i8 [heads][seq][D], k_i8 [kv_heads][seq][D], vt_i8 [kv_heads][seq/64][D][64] (values
  * transposed, keys permuted inside each 64-block), q_rowsum [heads][seq], k_rowsum [kv_heads][seq] (the zero-point terms of the integer
- * q.k^T, derived from the row sums of the images).
+ * q.k^T, derived from the row sums of the images).  q_i8 / q_rowsum may be left untouched: at head_dim 64 with a 16-bit score grid and
+ * full rotary the attention workgroups prepare their own q rows in registers (mq_attention_set_fused_q in the tuning header).
  * Limits: head_dim 64, 128 or 256 (every "64" of a layout above reads head_dim; the int8 output image is [rows, heads*head_dim]),
  * seq % 64 == 0, seq <= 65536.  The integer contractions are exact; see DESIGN.md 4.5 for the rounding points. */
 /* q | k | v (or any 1..3 linears reading one activation) as ONE int8 GEMM whose column segments carry their own 8-bit unsigned
