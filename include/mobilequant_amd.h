@@ -19,7 +19,9 @@
  *     thread.  Nothing aborts the process.
  *   - Integer storage of 8-bit indices ("i8 storage"): the reference's index q (qmodule.py:286-287)
  *     minus `shift`, where shift = 128 for unsigned grids [0,255] and 0 for signed grids, so every
- *     stored byte is a signed int8 that the MFMA i8 instructions consume directly.
+ *     stored byte is a signed int8 that the MFMA i8 instructions consume directly.  An integer image presupposes an
+ *     INTEGRAL offset, which is what the reference produces (offset = -round(beta / scale), qmodule.py:60); with a
+ *     fractional offset the index has no integer image and the stored byte is unspecified (rounded or truncated).
  */
 #ifndef MOBILEQUANT_AMD_H
 #define MOBILEQUANT_AMD_H
