@@ -2,7 +2,9 @@
   * the 128-column generated GEMMs on fragment-blocked activations == the C++ tile kernels on the row-major image, bit for bit
     (residual epilogue with a 16-bit grid, both tile heights; segmented 8-bit index outputs);
   * mq_attention_quant at head_dim 64 / 128 / 256 against the oracle, single shot and fed in chunks through an image cache
-    (chunked == single shot, bit for bit)."""
+    (chunked == single shot, bit for bit); at head_dim 64 the q rows prepared inside the attention workgroups == the prep kernel's image;
+  * the LDS-staged image-only norm / quantize kernels (packed-convert bytes) == the generic kernels, random shapes, grids, signed and
+    unsigned, RMSNorm / LayerNorm, occasional non-finite elements."""
 import os
 import sys
 
@@ -77,6 +79,46 @@ for it in range(iters):
     if not ok or not torch.equal(chunked, whole):
         bad += 1
         print("ATTENTION", "oracle" if not ok else "chunk", D, heads, kv, chunks, qkb, pvb, float(d.max()), step, float((chunked - whole).abs().max()))
+    if D == 64:                                # q rows prepared inside the attention workgroups (default) == the prep kernel's q image
+        L.load().mq_attention_set_fused_q(0)
+        try:
+            ref_q = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv, g, head_dim=D)
+        finally:
+            L.load().mq_attention_set_fused_q(1)
+        if not torch.equal(ref_q, whole):
+            bad += 1
+            print("ATTENTION fused q", heads, kv, S, qkb, pvb, float((ref_q - whole).abs().max()))
+    # ---- image-only staged kernels (v_med3 / v_cvt_pk_u8_f32 / v_sad_u8 bytes) == the generic kernels -------------------------------------
+    rows = int(rng.choice([64, 65, 100, 333, 1000, 2048]))
+    cols = 64 * int(rng.integers(16, 65))
+    signed = bool(rng.integers(0, 2))
+    qmin, qmax, shift = (-128.0, 127.0, 0) if signed else (0.0, 255.0, 128)
+    x = (torch.randn(rows, cols, device=dev) * float(rng.uniform(0.2, 30.0)))
+    if rng.integers(0, 3) == 0:
+        x[int(rng.integers(0, rows)), int(rng.integers(0, cols))] = float(rng.choice([np.nan, np.inf, -np.inf, 1e30]))
+    sc = torch.tensor([float(rng.uniform(0.005, 0.2))], device=dev)
+    of = torch.tensor([float(rng.integers(-100, 100) if signed else rng.integers(0, 256))], device=dev)
+    unt = lambda qq, Mp: qq.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]   # noqa: E731
+    if cols in (1024, 2048, 3072, 4096):
+        L.load().mq_quantize_tiled_set_staged(0)
+        try:
+            q0, rs0 = ops.quantize_tiled(x, sc, of, qmin, qmax, shift)
+        finally:
+            L.load().mq_quantize_tiled_set_staged(1)
+        q1, rs1 = ops.quantize_tiled(x, sc, of, qmin, qmax, shift)
+        if not (torch.equal(rs0, rs1) and torch.equal(unt(q0, q0.shape[0]), unt(q1, q1.shape[0]))):
+            bad += 1
+            print("QUANTIZE staged", rows, cols, signed)
+    ln = bool(rng.integers(0, 2))
+    w = 1.0 + 0.2 * torch.randn(cols, device=dev)
+    bb = 0.1 * torch.randn(cols, device=dev) if ln else None
+    gin = (torch.tensor([float(rng.uniform(20, 400)) / 65535], device=dev), torch.tensor([32768.0], device=dev), 0.0, 65535.0) if rng.integers(0, 2) else None
+    gout = (sc * 0.5, of, qmin, qmax)
+    _, qr, rsr, sh, _ = ops.rmsnorm_quant(x, w, bb, 1e-5, gin, gout, emit_int8=True, layernorm=ln, emit_tiled=False, want_y=False, emit_rowmajor=True)
+    _, _, rst, _, qt = ops.rmsnorm_quant(x, w, bb, 1e-5, gin, gout, emit_int8=True, layernorm=ln, emit_tiled=True, want_y=False, emit_rowmajor=False)
+    if not (torch.equal(rsr, rst) and torch.equal(unt(qt, (rows + 15) // 16 * 16), qr.view(rows, cols))):
+        bad += 1
+        print("NORM staged", rows, cols, signed, ln, gin is not None)
     if it % 10 == 9:
         print(f"{it + 1} iterations, {bad} failures", flush=True)
 torch.cuda.synchronize()
