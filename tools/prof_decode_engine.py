@@ -16,7 +16,8 @@ model = LlamaForCausalLM(shape); model.reset_parameters(seed=1); model = model.t
 g = torch.Generator().manual_seed(1)
 act = get_act_range(model, [torch.randint(3, shape.vocab, (1, 256), generator=g)])
 a8 = mq.QuantConfig(bitwidth=8)
-mq.create_sim_qmodel(model, a8, a8)
+wbits = int(os.environ.get("WBITS", "8"))                # 4: packed 4-bit per-channel weights (the W4A8 recipe of bench.py)
+mq.create_sim_qmodel(model, a8 if wbits == 8 else mq.QuantConfig(bitwidth=wbits, is_per_channel=True), a8)
 for name, mod in model.named_modules():
     if isinstance(mod, mq.QLinear):
         if "w2" in name: mod.weight_quantizer.qcfg.is_per_channel = True; mod.output_quantizer.qcfg.bitwidth = 16
