@@ -47,9 +47,10 @@ def needs_build() -> bool:
     return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source()
 
 
-def build(force: bool = False, verbose: bool = False, tag: str = "", extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", extra_flags=(), only=None) -> str:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
-    tag: build an experiment copy into lib/<tag>/ (A/B timing through MQ_LIB_PATH; never loaded by default)."""
+    tag: build an experiment copy into lib/<tag>/ (A/B timing through MQ_LIB_PATH; never loaded by default);
+    only: with a tag, recompile just these sources and link the main build's objects for the rest."""
     libdir = os.path.join(LIBDIR, tag) if tag else LIBDIR
     lib = os.path.join(libdir, "libmobilequant_amd.so")
     if not force and not tag and not needs_build():
@@ -58,6 +59,9 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra_flags
     objs = []
     procs = []
     for src in SOURCES:
+        if tag and only is not None and src not in only:
+            objs.append(os.path.join(LIBDIR, src.replace(".hip", ".o")))
+            continue
         obj = os.path.join(libdir, src.replace(".hip", ".o"))
         cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src, ()), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

@@ -750,10 +750,12 @@ __global__ void __launch_bounds__(64 * WM * WN)
 // the per-lane addresses and the scalar arguments.  256 x 176 tile, fragment-blocked activations, int8 weights, 8-bit
 // UNSIGNED output grid (u8 storage, or i8 storage = index - 128), K % 256 == 0, K >= 768.
 __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, int nblk) {
-  if (args.zero_buf != nullptr) {                                   // (gated pair, first launch: 512 ints per workgroup)
-    const int zi = bid * 512 + (int)threadIdx.x;
-    if (zi < args.zero_count) args.zero_buf[zi] = 0;
-  }
+  // Nothing in front of the generated program may wait for memory beyond the kernel arguments: the first LDS-DMA requests leave as soon
+  // as the tile's addresses are formed (the output grid is loaded and inverted INSIDE the program, behind them; the row-sum zeroing of
+  // the gated pair's first launch follows the program).
+#if MQ_FR_ASM_STAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
@@ -784,9 +786,8 @@ __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, i
     m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
     rsofs[i] = (unsigned)m * 4u;
   }
-  const float so = args.out_scale[0], oo = args.out_offset[0];
-  const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
-  const int oo_bits = __builtin_amdgcn_readfirstlane(__float_as_int(oo));
+  const float* so_ptr = args.out_scale;
+  const float* oo_ptr = args.out_offset;
   const int8_t* a_ptr = args.a;
   const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
   const float* alpha_p = args.alpha + n0;
@@ -803,21 +804,26 @@ __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, i
   const unsigned tid = threadIdx.x;
 #if MQ_FR_ASM_STAMP
   unsigned long long* dbg = args.dbg_ts + ((size_t)bid * 8 + wave) * 16;
+  const int te_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)t_entry), te_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(t_entry >> 32));
 #endif
   asm volatile(MQ_FR_ASM_BODY
                :
                : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [alpha] "s"(alpha_p),
-                 [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),
+                 [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr),
                  [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [xorv] "s"(xorv),
 #if MQ_FR_ASM_STAMP
-                 [dbg] "s"(dbg),
+                 [dbg] "s"(dbg), [tentry_lo] "s"(te_lo), [tentry_hi] "s"(te_hi),
 #endif
                  [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [sw2] "v"(sw[2]), [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid),
                  [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
                : MQ_FR_ASM_CLOBBERS);
+  if (args.zero_buf != nullptr) {                                   // (gated pair, first launch: 512 ints per workgroup)
+    const int zi = bid * 512 + (int)threadIdx.x;
+    if (zi < args.zero_count) args.zero_buf[zi] = 0;
+  }
 }
 
-__global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) { gemm_i8_fr_body(args, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) { gemm_i8_fr_body(args, blockIdx.x, args.grid_m * args.grid_n); }
 
 // ---- the free-running program on 128-column tiles (tools/gen_fr_asm.py variants fr128 / fr128r / fr128r8) ------------------------------
 // N = 2048 / 2560 outputs do not tile by 176.  FR128: 256 x 128 tiles, eight waves, 8-bit unsigned output grid PER COLUMN (the q | k | v
@@ -831,14 +837,10 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
   constexpr int BMT = 32 * NWV;
   constexpr int BNT = VAR == FR160 ? 160 : 128;
   constexpr int PCS = BNT / 8 / NWV;            // W LDS-DMA pieces (8 rows x 128 B) per wave and stage
-  if (args.zero_buf != nullptr) {               // (gated pair, first launch)
-    const int zi = (int)blockIdx.x * (64 * NWV) + (int)threadIdx.x;
-    if (zi < args.zero_count) args.zero_buf[zi] = 0;
-  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
+  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn);
   const int m0 = tm * BMT, n0 = tn * BNT;
   const int M = args.M, N = args.N, K = args.K;
   const int KT = K / BK;
@@ -900,18 +902,16 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
     }
 #undef MQ_FR128U_OPERANDS
   } else {
-    const float so = args.out_scale[0], oo = args.out_offset[0];
-    const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
-    const int so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(so));
-    const int oo_bits = __builtin_amdgcn_readfirstlane(__float_as_int(oo));
+    const float* so_ptr = args.out_scale;
+    const float* oo_ptr = args.out_offset;
     const int qmin_bits = __builtin_amdgcn_readfirstlane(__float_as_int(args.out_qmin));
     const int qmax_bits = __builtin_amdgcn_readfirstlane(__float_as_int(args.out_qmax));
     float* outw = reinterpret_cast<float*>(args.out) + (size_t)m0w * N + n0;
     const float* resid = args.resid + (size_t)m0w * N + n0;
 #define MQ_FR128R_OPERANDS                                                                                                          \
     [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [resid] "s"(resid), [alpha] "s"(alpha_p), \
-        [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),       \
-        [so] "s"(so_bits), [qmin] "s"(qmin_bits), [qmax] "s"(qmax_bits), [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags),      \
+        [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr),       \
+        [qmin] "s"(qmin_bits), [qmax] "s"(qmax_bits), [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags),      \
         [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [sw0] "v"(sw[0]), [sw1] "v"(sw[1])
     if constexpr (VAR == FR128R) {
       asm volatile(MQ_FR128R_ASM_BODY : : MQ_FR128R_OPERANDS, [sw2] "v"(sw[2]), [sw3] "v"(sw[3]) : MQ_FR128R_ASM_CLOBBERS);
@@ -919,6 +919,10 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
       asm volatile(MQ_FR128R8_ASM_BODY : : MQ_FR128R_OPERANDS : MQ_FR128R8_ASM_CLOBBERS);
     }
 #undef MQ_FR128R_OPERANDS
+  }
+  if (args.zero_buf != nullptr) {               // (gated pair, first launch)
+    const int zi = (int)blockIdx.x * (64 * NWV) + (int)threadIdx.x;
+    if (zi < args.zero_count) args.zero_buf[zi] = 0;
   }
 }
 
@@ -962,7 +966,7 @@ __global__ void __launch_bounds__(512) gemm_i8_frg_kernel(const GemmArgs args) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, args.grid_m, args.grid_n, tm, tn);
+  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * BNT;
   const int M = args.M, N = args.N, K = args.K;
   const int KT = K / BK;
@@ -987,9 +991,8 @@ __global__ void __launch_bounds__(512) gemm_i8_frg_kernel(const GemmArgs args) {
     m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
     rsofs[i] = (unsigned)m * 4u;
   }
-  const float so = args.out_scale[0], oo = args.out_offset[0];
-  const int inv_so_bits = __builtin_amdgcn_readfirstlane(__float_as_int(__fdiv_rn(1.0f, so)));
-  const int oo_bits = __builtin_amdgcn_readfirstlane(__float_as_int(oo));
+  const float* so_ptr = args.out_scale;
+  const float* oo_ptr = args.out_offset;
   const int8_t* a_ptr = args.a;
   const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
   const float* alpha_p = args.alpha + n0;
@@ -1008,7 +1011,7 @@ __global__ void __launch_bounds__(512) gemm_i8_frg_kernel(const GemmArgs args) {
   const unsigned tid = threadIdx.x;
 #define MQ_FRG_OPERANDS                                                                                                            \
   [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [aidx] "s"(aidx), [alpha] "s"(alpha_p),                    \
-      [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [inv_so] "s"(inv_so_bits), [oo] "s"(oo_bits),       \
+      [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr),       \
       [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [table] "s"(table), [qout] "s"(qout), [rsout] "s"(rsout),              \
       [cg0] "s"(cg0), [mb0] "s"(mb0), [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [av0] "v"(av0), [av1] "v"(av1),                          \
       [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
@@ -1046,7 +1049,7 @@ struct GemmPairArgs {
   GemmArgs p[2];
 };
 __global__ void __launch_bounds__(512) gemm_i8_fr_pair_kernel(const GemmPairArgs args) {
-  const int nblk = (int)(gridDim.x >> 1);
+  const int nblk = args.p[0].grid_m * args.p[0].grid_n;      // (= gridDim.x / 2, without the hidden-argument load)
   const int which = __builtin_amdgcn_readfirstlane(blockIdx.x >= (unsigned)nblk ? 1 : 0);
   if (which) gemm_i8_fr_body(args.p[1], (int)blockIdx.x - nblk, nblk);
   else gemm_i8_fr_body(args.p[0], (int)blockIdx.x, nblk);

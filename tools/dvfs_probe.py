@@ -112,6 +112,11 @@ def launch_gap():
     print(f"launch N+1 : first wave start {(b[:, 4].min() - a[:, 4].min()) / 100:.2f} us after launch N's first, i.e. "
           f"{(b[:, 4].min() - a[:, 5].max()) / 100:.2f} us after launch N's LAST wave ended; its last wave ends at "
           f"{(b[:, 5].max() - a[:, 4].min()) / 100:.2f}", flush=True)
+    if a[:, 6].any():          # round-4 stamp builds: s_memrealtime at the kernel's first instruction (before the C++ preamble)
+        pre_a, pre_b = (a[:, 4] - a[:, 6]) / 100, (b[:, 4] - b[:, 6]) / 100
+        print(f"entry stamps: preamble (kernel entry -> first instruction of the generated program) mean {pre_b.mean():.2f} max {pre_b.max():.2f} us; "
+              f"launch N+1's first ENTRY {(b[:, 6].min() - a[:, 5].max()) / 100:.2f} us after launch N's last wave ended "
+              f"(last entry {(b[:, 6].max() - a[:, 5].max()) / 100:.2f}); launch N: preamble mean {pre_a.mean():.2f}", flush=True)
     lib.mq_gemm_set_debug_buffer_(dbg.data_ptr())
 
 

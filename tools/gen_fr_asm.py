@@ -53,8 +53,9 @@ VARIANTS = {
 
 def configure(name):
     """binds the module-level tile constants of one variant (the emitters read them at call time)"""
-    global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF, RING_BASE
+    global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF, RING_BASE, SCALAR_GRID
     BN, NW, EPI, PREFIX, FILE = VARIANTS[name]
+    SCALAR_GRID = (BN == 176 or EPI != "u8")      # ONE output grid per launch (scalars); otherwise per-column grids (q | k | v segments)
     BM = 32 * NW
     FN = BN // 16
     W_BYTES = BN * BK                 # 22528 / 16384
@@ -105,6 +106,7 @@ S_EXEC = 72                       # pair
 S_TS = 74                         # 74..81: four s_memtime stamps (stamp builds)
 S_MR = 82
 S_RT = 84                         # 84..87: s_memrealtime (constant 100 MHz) at kernel start / end (stamp builds)
+S_SO, S_OO, S_ISO = 96, 97, 98    # the output grid: scale, offset (s_load at the top of the program), 1 / scale (IEEE divide, prologue step 3)
 
 # what-if switches for profiling builds (results are wrong): MQ_FR_NO_A / _NO_W / _NO_READ / _NO_MFMA drop the in-loop activation
 # loads / W LDS-DMA / W fragment reads / MFMAs
@@ -266,6 +268,12 @@ def prologue(q, nw, stamp):
         emit(f"s_memtime s[{S_TS}:{S_TS + 1}]")
         emit(f"s_memrealtime s[{S_RT}:{S_RT + 1}]")
         emit("s_waitcnt lgkmcnt(0)")
+    # the output grid lives in device memory (no host read-back): both scalar loads leave before anything else and are waited for in
+    # step (3), behind the first stages' requests -- never in front of them (round 4: the C++ preamble used to dereference and divide
+    # BEFORE the first LDS-DMA could be issued: two dependent cold scalar loads ahead of every launch's first byte)
+    if SCALAR_GRID:
+        emit(f"s_load_dword s{S_SO}, %[soptr], 0x0")
+        emit(f"s_load_dword s{S_OO}, %[ooptr], 0x0")
     # loop state
     emit(f"s_mov_b64 s[{S_ABASE}:{S_ABASE + 1}], %[aptr]")
     emit(f"s_mov_b64 s[{S_WBASE}:{S_WBASE + 1}], %[wptr]")
@@ -341,6 +349,26 @@ def prologue(q, nw, stamp):
     # (3) parameters: park alpha' = alpha/so, bias' = bias/so + oo, -w_zp, col_term in LDS (same expressions as the C++ prologue
     # of the other variants: one multiply, one multiply + one add, no contraction)
     q.wait_for("P")
+    if SCALAR_GRID:
+        # 1 / so, correctly rounded: the IEEE divide sequence hipcc emits for __fdiv_rn(1.0f, so) (the C++ epilogues of the other
+        # variants divide the same way: identical alpha' / bias' bits)
+        emit("s_waitcnt lgkmcnt(0)")
+        vs, v1, v2, v0, v3, v4 = 122, 123, 124, 125, 126, V_TMP
+        emit(f"v_mov_b32 v{vs}, s{S_SO}")
+        emit(f"v_div_scale_f32 v{v1}, vcc, v{vs}, v{vs}, 1.0")
+        emit(f"v_rcp_f32 v{v2}, v{v1}")
+        emit("s_nop 0")
+        emit(f"v_fma_f32 v{v0}, -v{v1}, v{v2}, 1.0")
+        emit(f"v_fma_f32 v{v2}, v{v0}, v{v2}, v{v2}")
+        emit(f"v_div_scale_f32 v{v0}, vcc, 1.0, v{vs}, 1.0")
+        emit(f"v_mul_f32 v{v3}, v{v0}, v{v2}")
+        emit(f"v_fma_f32 v{v4}, -v{v1}, v{v3}, v{v0}")
+        emit(f"v_fma_f32 v{v3}, v{v4}, v{v2}, v{v3}")
+        emit(f"v_fma_f32 v{v0}, -v{v1}, v{v3}, v{v0}")
+        emit(f"v_div_fmas_f32 v{v0}, v{v0}, v{v2}, v{v3}")
+        emit(f"v_div_fixup_f32 v{v0}, v{v0}, v{vs}, 1.0")
+        emit("s_nop 0")
+        emit(f"v_readfirstlane_b32 s{S_ISO}, v{v0}")
     emit("s_bitcmp1_b32 %[flags], 1")                                        # bit 1: row sums present
     l = label("rs")
     emit(f"s_cbranch_scc1 {l}")
@@ -356,7 +384,7 @@ def prologue(q, nw, stamp):
     emit(f"{l}:")
     # 176: one output grid (scalars);  128 / u8: this column's grid (per-lane operands: q | k | v segments);  f32r: 16-bit grid,
     # the offset stays outside the fma (added after the rounding, as in the C++ epilogue)
-    inv, oo = ("%[inv_so]", "%[oo]") if (BN == 176 or EPI != "u8") else ("%[invc]", "%[ooc]")
+    inv, oo = (f"s{S_ISO}", f"s{S_OO}") if SCALAR_GRID else ("%[invc]", "%[ooc]")
     emit(f"v_mul_f32 v{V_P0}, {inv}, v{V_P0}")
     emit(f"v_mul_f32 v{V_P0 + 1}, {inv}, v{V_P0 + 1}")
     if EPI in ("u8", "gate"):
@@ -613,6 +641,9 @@ def epilogue(stamp):
             emit(f"v_mov_b32 v0, s{src}")
             emit(f"v_mov_b32 v1, s{src + 1}")
             emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:{8 * k}")
+        emit("v_mov_b32 v0, %[tentry_lo]")                                   # s_memrealtime at the kernel's first instruction (C++)
+        emit("v_mov_b32 v1, %[tentry_hi]")
+        emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:48")
         emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
     emit("s_waitcnt vmcnt(0)")
 
@@ -708,13 +739,13 @@ def epilogue_f32r():
             for x in regs:
                 emit(f"v_rndne_f32 {x}, {x}")
             for x in regs:
-                emit(f"v_add_f32 {x}, %[oo], {x}")
+                emit(f"v_add_f32 {x}, s{S_OO}, {x}")
             for x in regs:
                 emit(f"v_med3_f32 {x}, {x}, v{V_QMIN}, v{V_QMAX}")
             for x in regs:
-                emit(f"v_subrev_f32 {x}, %[oo], {x}")
+                emit(f"v_subrev_f32 {x}, s{S_OO}, {x}")
             for x in regs:
-                emit(f"v_mul_f32 {x}, %[so], {x}")
+                emit(f"v_mul_f32 {x}, s{S_SO}, {x}")
             emit(f"ds_write_b128 v{V_STW}, {acc(i, j)} offset:{n * 64}")
 
     issue_resid(0)
@@ -816,7 +847,8 @@ def main(path=None, variant="fr"):
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
     vregs = [f'"v{r}"' for r in list(range(0, 88 if EPI == "gate" else 8 * FN)) + list(range(V_T if (8 * FN > 78 or EPI == "gate") else 78, 128))]
     aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32)]
-    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)] + (['"m0"'] if EPI == "gate" else [])
+    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + \
+        (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")
         f.write(f"#define {PREFIX}_ASM_STAMP {1 if stamp else 0}\n")
