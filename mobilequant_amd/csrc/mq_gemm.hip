@@ -1287,6 +1287,27 @@ static int check_common(const char* fn, const void* a, const void* w, int64_t M,
 
 using namespace mq;
 
+#ifdef MQ_GEMM_ABLATE
+// tools/hole_probe.py: a do-nothing kernel with a chosen footprint (threads, LDS bytes, register count), duration (busy-wait on the
+// 100 MHz s_memrealtime) and amount of dirty L2 data; block b stamps [entry, exit] realtime into out[2 b .. 2 b + 1].  What does a kernel
+// boundary cost behind a kernel of the GEMM's footprint?
+namespace mq {
+template <bool FAT>
+__global__ void __launch_bounds__(FAT ? 512 : 1024) debug_stamp_kernel(unsigned long long* out, int spin_ticks, int* dirty, int dirty_words) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if constexpr (FAT) asm volatile("v_mov_b32 v127, 0\n\tv_accvgpr_write_b32 a119, 0" ::: "v127", "a119");
+  extern __shared__ int lds_probe[];
+  if (spin_ticks < 0) lds_probe[threadIdx.x] = (int)t0;      // (never: keeps the dynamic LDS referenced)
+  for (int i = (int)threadIdx.x; i < dirty_words; i += (int)blockDim.x) dirty[(size_t)blockIdx.x * dirty_words + i] = i;
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)spin_ticks) __builtin_amdgcn_s_sleep(4);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = t0;
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+}  // namespace mq
+#endif
+
 extern "C" {
 
 int mq_gemm_set_variant(int variant) {
@@ -1304,6 +1325,22 @@ int mq_gemm_set_debug(int flags) {
 extern "C" int mq_gemm_set_debug_buffer_(void* p) {
   g_dbg_ts = reinterpret_cast<unsigned long long*>(p);
   return 0;
+}
+
+extern "C" int mq_debug_stamp_(void* out, int blocks, int threads, int lds_bytes, int fat, int spin_ticks, void* dirty, int dirty_words,
+                               void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto o = reinterpret_cast<unsigned long long*>(out);
+  auto d = reinterpret_cast<int*>(dirty);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)mq::debug_stamp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mq::debug_stamp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (fat) mq::debug_stamp_kernel<true><<<blocks, threads, lds_bytes, st>>>(o, spin_ticks, d, dirty_words);
+  else mq::debug_stamp_kernel<false><<<blocks, threads, lds_bytes, st>>>(o, spin_ticks, d, dirty_words);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 #endif
 

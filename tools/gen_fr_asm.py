@@ -56,6 +56,9 @@ def configure(name):
     global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF, RING_BASE, SCALAR_GRID
     BN, NW, EPI, PREFIX, FILE = VARIANTS[name]
     SCALAR_GRID = (BN == 176 or EPI != "u8")      # ONE output grid per launch (scalars); otherwise per-column grids (q | k | v segments)
+    # round 4: the u8 epilogue is interleaved with the MFMAs of the LAST TWO stages (final_block) unless MQ_FR_TAIL=0
+    global TAIL
+    TAIL = EPI == "u8" and os.environ.get("MQ_FR_TAIL", "1") != "0"
     BM = 32 * NW
     FN = BN // 16
     W_BYTES = BN * BK                 # 22528 / 16384
@@ -106,6 +109,9 @@ S_EXEC = 72                       # pair
 S_TS = 74                         # 74..81: four s_memtime stamps (stamp builds)
 S_MR = 82
 S_RT = 84                         # 84..87: s_memrealtime (constant 100 MHz) at kernel start / end (stamp builds)
+S_FM = 88                         # final block: 88..95 exec masks of the group stores (row block i, last group?)
+S_OB1 = 82                        # final block: output pointer of row block 1 (pair; = S_MR of the classic epilogue)
+V_LDSG, V_GOG, V_RD3 = 103, 104, 105   # final block: staging read-back address / global offset of a lane's 16-byte piece; 4th W read address
 S_SO, S_OO, S_ISO = 96, 97, 98    # the output grid: scale, offset (s_load at the top of the program), 1 / scale (IEEE divide, prologue step 3)
 
 # what-if switches for profiling builds (results are wrong): MQ_FR_NO_A / _NO_W / _NO_READ / _NO_MFMA drop the in-loop activation
@@ -147,6 +153,12 @@ def wreg(set_, j):
 
 def areg(set_, ks, i):
     b = 8 * FN + 16 * set_ + 8 * ks + 4 * i
+    return f"a[{b}:{b + 3}]"
+
+
+def areg_spare(i):
+    """A(KT-1).ks1 of the final block: the eight AGPRs behind the two stage sets (requested while both sets are still in use)"""
+    b = 8 * FN + 32 + 4 * i
     return f"a[{b}:{b + 3}]"
 
 
@@ -260,6 +272,271 @@ def stage(q, t, nw, kt=None, sym=None):
         v1 += [("a", a_load(q, t + 2, 0, 0, set_, 2048)), ("a", a_load(q, t + 2, 0, 1, set_, 2048))]
     kstep(1, set_, 1, S_NXT, V_WOFF0, 0, v1, read=more1)
     rotate()
+
+
+# ---- round 4: the u8 epilogue inside the last two stages ---------------------------------------------------------------------------------
+# Classic tail: ... stage KT-2, stage KT-1 (k outer: every accumulator is final only at the very end), then ~330 VALU / LDS instructions
+# of epilogue per wave with the matrix pipe idle, then the stores, then the L2 write-back at the kernel boundary.
+# final_block: the 8 * FN MFMAs of stages KT-2 and KT-1 run COLUMN outer -- for j: 4 k-steps x 2 row blocks on acc(., j) -- so column
+# chunk j is final after its eighth MFMA and its conversion (cvt, fma, cvt_pk_u8, staging write) issues between the MFMAs of column j + 1;
+# a group of four chunks (64 bytes of 16 rows) is read back as 16-byte pieces and stored while later columns still multiply.  Needs both
+# stages' operands resident: W(KT-2), W(KT-1) are in the ring anyway, A(KT-2) and A(KT-1).ks0 in the two register sets, A(KT-1).ks1
+# in the eight spare AGPRs behind them (requested during stage KT-3).  W fragments come from the LDS per column (4 ds_read_b128 per
+# 8 MFMAs: the classic loop's ratio) through a ring of 16-register slots in a[0 : 8 FN), two columns ahead.
+class LQueue:
+    """the wave's LDS queue (lgkmcnt retires LDS operations in issue order)"""
+
+    def __init__(self):
+        self.q = []
+
+    def issue(self, tag):
+        self.q.append(tag)
+
+    def wait_for(self, *tags):
+        idx = max((i for i, t in enumerate(self.q) if t in tags), default=-1)
+        if idx < 0:
+            return
+        n = len(self.q) - 1 - idx
+        assert n <= 15, (n, self.q)
+        emit(f"s_waitcnt lgkmcnt({n})")
+        self.q = self.q[idx + 1:]
+
+
+RDA = (V_WOFF0, V_WOFF1, V_RD, V_RD3)       # LDS read addresses of (stage KT-2, ks0 / ks1), (stage KT-1, ks0 / ks1)
+
+
+def fb_slot(j, f):
+    b = 16 * (j % ((8 * FN) // 16)) + 4 * f
+    return f"a[{b}:{b + 3}]"
+
+
+def fb_read(lq, j):
+    def mk(f):
+        def fn():
+            emit(f"ds_read_b128 {fb_slot(j, f)}, v{RDA[f]} offset:{j * 16 * BK}")
+            lq.issue(("R", j))
+        return fn
+    return [mk(f) for f in range(4)]
+
+
+def a_load_spare(q, t, i, off):
+    def f():
+        emit(f"global_load_dwordx4 {areg_spare(i)}, %[av{i}], s[{S_ABASE}:{S_ABASE + 1}] offset:{off}")
+        q.issue(("A", t, 1))
+    return f
+
+
+def stage_pre_final(q, lq, t, nw):
+    """stage KT-3: classic k-step 0; k-step 1 without the classic read-ahead but with the final block's first two columns of W fragments"""
+    set_ = t & 1
+    emit(f"; ---- stage KT-3 (last classic stage): A set {set_}; A(KT-1).ks1 -> spare AGPRs; columns 0, 1 of the final block are read ahead")
+    q.wait_for(("A", t, 0))
+    v0 = []
+    if not NO_A:
+        v0 += [("a", a_load(q, t + 1, 1, 0, 1 - set_, 1024)), ("a", a_load(q, t + 1, 1, 1, 1 - set_, 1024)),
+               ("a", a_load_spare(q, t + 2, 0, 3072)), ("a", a_load_spare(q, t + 2, 1, 3072))]
+    kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0)
+    q.wait_for(("A", t, 1), ("W", t + 1), ("W", t + 2))
+    emit("s_barrier")                       # W(KT-2) and W(KT-1) of every wave have landed
+    rotate()                                # S_CUR / S_NXT = ring slots of stages KT-2 / KT-1, S_ABASE -> stage KT-2
+    emit(f"v_add_u32 v{V_RD}, s{S_NXT}, v{V_WOFF0}")
+    emit(f"v_add_u32 v{V_RD3}, s{S_NXT}, v{V_WOFF1}")
+    emit(f"v_add_u32 v{V_WOFF0}, s{S_CUR}, v{V_WOFF0}")
+    emit(f"v_add_u32 v{V_WOFF1}, s{S_CUR}, v{V_WOFF1}")
+    fill = []
+    if not NO_A:                            # A(KT-1).ks0 -> this stage's own set (its ks0 registers are free now); S_ABASE = stage KT-1 already
+        fill += [a_load(q, t + 2, 0, 0, set_, 0), a_load(q, t + 2, 0, 1, set_, 0)]
+    fill += fb_read(lq, 0) + fb_read(lq, 1)
+    m = 0
+    for j in range(FN):
+        for i in range(2):
+            if not NO_MFMA:
+                emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, {wreg(1, j)}, {areg(set_, 1, i)}, {acc(i, j)}")
+            if m >= 1 and fill:
+                fill.pop(0)()
+            m += 1
+    assert not fill
+
+
+def final_block(q, lq, stamp):
+    NG = (FN + 3) // 4                                  # store groups of (up to) four 16-byte chunks
+    CAP = 6                                             # fillers behind one MFMA
+    EA = [V_E, V_P0]
+    VP = [122, 123]
+    SD = 124                                            # 124..127: a store's data
+    emit("; ==== final block: stages KT-2 and KT-1 column by column, the epilogue between the MFMAs")
+    if stamp:
+        emit(f"s_memtime s[{S_TS + 4}:{S_TS + 5}]")
+        emit("s_waitcnt lgkmcnt(0)")            # (scalar memory returns out of order: nothing of it may be in flight under counted waits)
+        lq.q = []
+    q.wait_for(("A", 6, 0), ("A", 6, 1), ("A", 7, 0), ("A", 7, 1))
+    assert q.q == [], q.q
+    B = [lambda i: areg(0, 0, i), lambda i: areg(0, 1, i), lambda i: areg(1, 0, i), areg_spare]
+    fill = []
+
+    def F(minidx, fn):
+        fill.append((minidx, fn))
+
+    def E(minidx, text):
+        F(minidx, lambda: emit(text))
+
+    # -- set-up of the group stores (first needed behind column 3)
+    rem = FN - 4 * (NG - 1)
+    for text in (
+            f"v_and_b32 v{V_TMP}, 63, %[tid]",
+            f"v_lshrrev_b32 v{V_GOG}, 2, v{V_TMP}",                                     # row = lane >> 2
+            f"v_and_b32 v{V_TMP}, 3, v{V_TMP}",
+            f"v_lshlrev_b32 v{V_TMP}, 4, v{V_TMP}",                                     # (lane & 3) * 16 bytes
+            f"v_mul_u32_u24 v{V_LDSG}, {ROWP}, v{V_GOG}",
+            f"v_add_u32 v{V_LDSG}, v{V_LDSG}, v{V_TMP}",
+            f"s_mul_i32 s{S_TMP}, %[wave], {STG_WAVE}",
+            f"s_add_u32 s{S_TMP}, s{S_TMP}, {STG}",
+            f"v_add_u32 v{V_LDSG}, s{S_TMP}, v{V_LDSG}",
+            f"v_cmp_gt_i32_e64 s[{S_FM}:{S_FM + 1}], %[mrem], v{V_GOG}",                # row block 0: row < rows left
+            f"v_add_u32 v{SD + 2}, 16, v{V_GOG}",
+            f"v_cmp_gt_i32_e64 s[{S_FM + 2}:{S_FM + 3}], %[mrem], v{SD + 2}",           # row block 1
+            f"v_cmp_gt_u32_e64 s[{S_FM + 4}:{S_FM + 5}], {16 * rem}, v{V_TMP}",         # last group: only `rem` chunks exist
+            f"s_and_b64 s[{S_FM + 6}:{S_FM + 7}], s[{S_FM + 2}:{S_FM + 3}], s[{S_FM + 4}:{S_FM + 5}]",
+            f"s_and_b64 s[{S_FM + 4}:{S_FM + 5}], s[{S_FM}:{S_FM + 1}], s[{S_FM + 4}:{S_FM + 5}]",
+            f"v_mul_lo_u32 v{V_GOG}, v{V_GOG}, %[ldn]",
+            f"v_add_u32 v{V_GOG}, v{V_GOG}, v{V_TMP}",                                  # row * ldn + (lane & 3) * 16
+            f"s_lshl_b32 s{S_TMP2}, %[ldn], 4",
+            f"s_mov_b64 s[{S_OB1}:{S_OB1 + 1}], %[outw]",
+            f"s_add_u32 s{S_OB1}, s{S_OB1}, s{S_TMP2}",
+            f"s_addc_u32 s{S_OB1 + 1}, s{S_OB1 + 1}, 0"):
+        E(0, text)
+
+    def params(j):
+        st = j & 1
+        def fn0():
+            emit(f"ds_read_b128 v[{EA[st]}:{EA[st] + 3}], v{V_PAR} offset:{j * 64}")
+            lq.issue(("P", j))
+        def fn1():
+            emit(f"ds_read_b128 v[{EA[st] + 4}:{EA[st] + 7}], v{V_PAR} offset:{4 * BN + j * 64}")
+            lq.issue(("P", j))
+        return [fn0, fn1]
+
+    def store_pieces(g, regs):
+        """group g (chunks 4g .. 4g+3 of both row blocks) as three filler lists: [read back row block 0], [wait, store, read back row
+        block 1], [wait, store] -- spliced into the NEXT column's conversion so that no wait drains the LDS queue"""
+        last = g == NG - 1 and rem != 4
+        out_ = []
+        for i in range(2):
+            r = regs[i]
+            def rd(i=i, r=r):
+                emit(f"ds_read_b128 v[{r}:{r + 3}], v{V_LDSG} offset:{i * 16 * ROWP + g * 64}")
+                lq.issue(("S", g, i))
+            m = S_FM + 2 * i + (4 if last else 0)
+            base = "%[outw]" if i == 0 else f"s[{S_OB1}:{S_OB1 + 1}]"
+            def st(i=i, base=base, r=r):
+                if STORE_POLICY != "none":
+                    emit(f"global_store_dwordx4 v{V_GOG}, v[{r}:{r + 3}], {base} offset:{g * 64} {STORE_POLICY}".rstrip())
+                    q.issue(("S", g, i))
+            out_.append((rd, [lambda i=i: lq.wait_for(("S", g, i)), (lambda m=m: emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")), st,
+                              lambda: emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")]))
+        return out_
+
+    def convert(minidx, j, group=None, late=False):
+        """conversion of column chunk j; group: a finished store group whose read-back / stores ride along"""
+        st = j & 1
+        pieces = store_pieces(group, (SD, EA[1 - st] if late else SD)) if group is not None else None
+        if pieces and not late:
+            F(minidx, pieces[0][0])                                  # read back row block 0 first: it lands under the conversion
+        F(minidx, lambda: lq.wait_for(("P", j)))
+        for i in range(2):
+            for e in range(4):
+                E(minidx, f"v_cvt_f32_i32 {accr(i, j, e)}, {accr(i, j, e)}")
+        for i in range(2):
+            for e in range(4):
+                E(minidx, f"v_fma_f32 {accr(i, j, e)}, {accr(i, j, e)}, v{EA[st] + e}, v{EA[st] + 4 + e}")
+        if pieces and not late:
+            for fn in pieces[0][1]:
+                F(minidx, fn)
+            F(minidx, pieces[1][0])
+        for i in range(2):
+            for e in range(4):
+                E(minidx, f"v_cvt_pk_u8_f32 v{VP[i]}, {accr(i, j, e)}, {e}, " + (f"v{VP[i]}" if e else "0"))
+        for i in range(2):
+            E(minidx, f"v_xor_b32 v{VP[i]}, %[xorv], v{VP[i]}")
+        for i in range(2):
+            def wr(i=i):
+                emit(f"ds_write_b32 v{V_STW}, v{VP[i]} offset:{i * 16 * ROWP + j * 16}")
+                lq.issue(("WR", j))
+            F(minidx, wr)
+        if pieces and not late:
+            for fn in pieces[1][1]:
+                F(minidx, fn)
+        if pieces and late:                                          # the LAST group holds this very column: both read-backs, then both stores
+            F(minidx, pieces[0][0])
+            F(minidx, pieces[1][0])
+            for k in range(2):
+                for fn in pieces[k][1]:
+                    F(minidx, fn)
+
+    for j in range(FN):
+        base = 8 * j
+        if j + 2 < FN:
+            for fn in fb_read(lq, j + 2):
+                F(base, fn)
+        for fn in params(j):
+            F(base, fn)
+        if j >= 1:
+            # column j - 1 converts now; a group that column j - 2 completed is stored along with it
+            convert(base + 2, j - 1, group=(j - 1) // 4 - 1 if (j - 1) % 4 == 0 and j - 1 >= 4 else None)
+    # behind the last MFMA: the last column; groups still open: the one column FN - 2 may have closed, and the last
+    pend = [(FN - 1) // 4 - 1] if (FN - 1) % 4 == 0 else []
+    convert(8 * FN + 1000, FN - 1, group=pend[0] if pend else None)
+    convert_tail = store_pieces(NG - 1, (SD, EA[0]))
+    for rd, _ in convert_tail:
+        F(8 * FN + 1000, rd)
+    for _, fns in convert_tail:
+        for fn in fns:
+            F(8 * FN + 1000, fn)
+
+    fi = 0
+    n = 0
+    for j in range(FN):
+        lq.wait_for(("R", j))
+        for f in range(4):
+            for i in range(2):
+                if not NO_MFMA:
+                    emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, {fb_slot(j, f)}, {B[f](i)}, {acc(i, j)}")
+                k = 0
+                while fi < len(fill) and fill[fi][0] <= n and k < CAP:
+                    fill[fi][1]()
+                    fi += 1
+                    k += 1
+                n += 1
+    # what is left of column FN - 2 (nothing when CAP is large enough), then the last column: its accumulators are being written by
+    # the last MFMAs -- 19 wait states between an XDL write and a VALU read of the same register
+    while fi < len(fill) and fill[fi][0] < 8 * FN:
+        fill[fi][1]()
+        fi += 1
+    emit("s_nop 15")
+    emit("s_nop 3")
+    while fi < len(fill):
+        fill[fi][1]()
+        fi += 1
+    if stamp:
+        emit("s_waitcnt vmcnt(0)")
+        emit(f"s_memtime s[{S_TS + 6}:{S_TS + 7}]")
+        emit(f"s_memrealtime s[{S_RT + 2}:{S_RT + 3}]")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")
+        emit(f"v_cmp_eq_u32 vcc, 0, v{V_TMP}")
+        emit("s_and_b64 exec, exec, vcc")
+        emit(f"v_mov_b32 v{V_TMP}, 0")
+        for k in range(6):
+            src = S_TS + 2 * k if k < 4 else S_RT + 2 * (k - 4)
+            emit(f"v_mov_b32 v0, s{src}")
+            emit(f"v_mov_b32 v1, s{src + 1}")
+            emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:{8 * k}")
+        emit("v_mov_b32 v0, %[tentry_lo]")
+        emit("v_mov_b32 v1, %[tentry_hi]")
+        emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:48")
+        emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    emit("s_waitcnt vmcnt(0)")
+
 
 
 def prologue(q, nw, stamp):
@@ -809,6 +1086,12 @@ def program(nw, stamp):
     # tail: the last four stages; renumber the queue as if kt = 8 (tags are relative)
     KT = 8
     q.q = [tuple(x[:1]) + (x[1] + 2,) + tuple(x[2:]) if isinstance(x, tuple) else x for x in before]
+    if TAIL:
+        stage(q, 4, nw, kt=KT, sym="KT-4")
+        lq = LQueue()
+        stage_pre_final(q, lq, 5, nw)
+        final_block(q, lq, stamp)
+        return q
     for t in range(4, 8):
         stage(q, t, nw, kt=KT, sym=f"KT-{KT - t}")
     assert q.q == [], q.q
@@ -846,8 +1129,8 @@ def main(path=None, variant="fr"):
     path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", FILE)
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
     vregs = [f'"v{r}"' for r in list(range(0, 88 if EPI == "gate" else 8 * FN)) + list(range(V_T if (8 * FN > 78 or EPI == "gate") else 78, 128))]
-    aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32)]
-    sregs = [f'"s{r}"' for r in range(S0, S_RT + 4 if EPI == "u8" else S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + \
+    aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32 + (8 if TAIL else 0))]
+    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + \
         (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")
