@@ -212,77 +212,6 @@ def a_load(q, t, ks, i, set_, off):
     return f
 
 
-def kstep(cur, aset, ks, rd_slot, rd_woff, nxt, vmem, read=True, mfma_first=0):
-    """22 MFMAs on W register set `cur` x A(aset, ks); 11 ds_reads of slot `rd_slot` (+ per-lane offset register rd_woff) into W
-    register set `nxt`, one after each of the first MFMAs; `vmem`: callables (VMEM issues) spread behind the later MFMAs."""
-    if read:
-        emit(f"v_add_u32 v{V_RD}, s{rd_slot}, v{rd_woff}")
-    places = {}
-    for n, (kind, f) in enumerate(vmem):      # A loads early (their registers are free), DMA pieces in the second half
-        na = sum(1 for k, _ in vmem[:n] if k == kind)
-        nwp = sum(1 for k, _ in vmem if k == "w")
-        wstep = 3 if FN == 11 else max(1, (FN - 1) // max(nwp, 1))
-        places.setdefault(1 + 2 * na if kind == "a" else FN + 1 + wstep * na, []).append(f)
-    m = 0
-    for j in range(FN):
-        for i in range(2):
-            if not NO_MFMA:
-                emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, {wreg(cur, j)}, {areg(aset, ks, i)}, {acc(i, j)}")
-            if read and m < FN and not NO_READ:
-                emit(f"ds_read_b128 {wreg(nxt, m)}, v{V_RD} offset:{m * 16 * BK}")
-            for f in places.get(m, []):
-                f()
-            m += 1
-    if read:
-        emit("s_waitcnt lgkmcnt(0)")
-
-
-def rotate():
-    emit(f"s_mov_b32 s{S_CUR}, s{S_NXT}")
-    for s in (S_NXT, S_DMA):
-        emit(f"s_add_u32 s{s}, s{s}, {W_BYTES}")
-        emit(f"s_cmp_eq_u32 s{s}, {RING * W_BYTES}")
-        emit(f"s_cselect_b32 s{s}, 0, s{s}")
-    emit(f"s_add_u32 s{S_ABASE}, s{S_ABASE}, {2 * 1024}")
-    emit(f"s_addc_u32 s{S_ABASE + 1}, s{S_ABASE + 1}, 0")
-
-
-def stage(q, t, nw, kt=None, sym=None):
-    """One K = 128 stage.  t: stage number used for the queue tags; kt: total stages when the tail conditions apply (None = steady
-    state: everything is issued)."""
-    set_ = t & 1
-    more1 = kt is None or t + 1 < kt
-    more2 = kt is None or t + 2 < kt
-    more3 = kt is None or t + 3 < kt
-    emit(f"; ---- stage {sym or t}: A set {set_}")
-    q.wait_for(("A", t, 0))
-    v0 = []
-    if more1 and not NO_A:      # S_ABASE = activation pointer of stage t+1
-        v0 += [("a", a_load(q, t + 1, 1, 0, 1 - set_, 1024)), ("a", a_load(q, t + 1, 1, 1, 1 - set_, 1024))]
-    if more3 and not NO_W:
-        v0 += [("w", w_piece(q, t + 3, i, S_DMA)) for i in range(nw)]
-    kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0)
-    if more3:
-        emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK}")
-        emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
-    q.wait_for(("A", t, 1), ("W", t + 1))
-    emit("s_barrier")
-    v1 = []
-    if more2 and not NO_A:
-        v1 += [("a", a_load(q, t + 2, 0, 0, set_, 2048)), ("a", a_load(q, t + 2, 0, 1, set_, 2048))]
-    kstep(1, set_, 1, S_NXT, V_WOFF0, 0, v1, read=more1)
-    rotate()
-
-
-# ---- round 4: the u8 epilogue inside the last two stages ---------------------------------------------------------------------------------
-# Classic tail: ... stage KT-2, stage KT-1 (k outer: every accumulator is final only at the very end), then ~330 VALU / LDS instructions
-# of epilogue per wave with the matrix pipe idle, then the stores, then the L2 write-back at the kernel boundary.
-# final_block: the 8 * FN MFMAs of stages KT-2 and KT-1 run COLUMN outer -- for j: 4 k-steps x 2 row blocks on acc(., j) -- so column
-# chunk j is final after its eighth MFMA and its conversion (cvt, fma, cvt_pk_u8, staging write) issues between the MFMAs of column j + 1;
-# a group of four chunks (64 bytes of 16 rows) is read back as 16-byte pieces and stored while later columns still multiply.  Needs both
-# stages' operands resident: W(KT-2), W(KT-1) are in the ring anyway, A(KT-2) and A(KT-1).ks0 in the two register sets, A(KT-1).ks1
-# in the eight spare AGPRs behind them (requested during stage KT-3).  W fragments come from the LDS per column (4 ds_read_b128 per
-# 8 MFMAs: the classic loop's ratio) through a ring of 16-register slots in a[0 : 8 FN), two columns ahead.
 class LQueue:
     """the wave's LDS queue (lgkmcnt retires LDS operations in issue order)"""
 
@@ -302,6 +231,136 @@ class LQueue:
         self.q = self.q[idx + 1:]
 
 
+def kstep(cur, aset, ks, rd_slot, rd_woff, nxt, vmem, read=True, c_zero=False, extra=None, lq=None):
+    """22 MFMAs on W register set `cur` x A(aset, ks); 11 ds_reads of slot `rd_slot` (+ per-lane offset register rd_woff) into W
+    register set `nxt`, one after each of the first MFMAs; `vmem`: callables (VMEM issues) spread behind the later MFMAs.
+    c_zero: the accumulators START here (src2 = 0); extra: {position: [callables]} more fillers (they share the LDS queue `lq`)."""
+    lq = lq or LQueue()
+    if read:
+        emit(f"v_add_u32 v{V_RD}, s{rd_slot}, v{rd_woff}")
+    places = {}
+    for n, (kind, f) in enumerate(vmem):      # A loads early (their registers are free), DMA pieces in the second half
+        na = sum(1 for k, _ in vmem[:n] if k == kind)
+        nwp = sum(1 for k, _ in vmem if k == "w")
+        wstep = 3 if FN == 11 else max(1, (FN - 1) // max(nwp, 1))
+        places.setdefault(1 + 2 * na if kind == "a" else FN + 1 + wstep * na, []).append(f)
+    m = 0
+    for j in range(FN):
+        for i in range(2):
+            if not NO_MFMA:
+                emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, {wreg(cur, j)}, {areg(aset, ks, i)}, " + ("0" if c_zero else acc(i, j)))
+            if read and m < FN and not NO_READ:
+                emit(f"ds_read_b128 {wreg(nxt, m)}, v{V_RD} offset:{m * 16 * BK}")
+                lq.issue(("F", m))
+            for f in places.get(m, []):
+                f()
+            for f in (extra or {}).get(m, []):
+                f()
+            m += 1
+    if lq.q:
+        emit("s_waitcnt lgkmcnt(0)")
+        lq.q = []
+
+
+def deferred_init(lq, ks, phase):
+    """round 4: the zero-point correction acc += -w_zp[n] * row_sum[m] (phase "wz": stage 1) + col_term[n] (phase "ct": stage KT-4) as
+    fillers between the MFMAs -- the accumulators start at 0 in stage 0 (MFMA src2 = 0) instead of being initialised by 88 mads per wave
+    on the prologue's critical path.  Two VALU per gap (a wave hides ~5 issue slots per MFMA beside its partner; four per gap measured
+    +950 cycles): gap m of k-step ks touches elements 2 ks, 2 ks + 1 of the tile 11 MFMAs away -- its last MFMA is long complete, its
+    next far off.  Returns (pre, extra): callables in front of the k-step, {position: [callables]}."""
+    SETS = [V_E, V_E + 4, V_P0, V_P0 + 4, 122]
+    LEAD = int(os.environ.get("MQ_FR_DLEAD", "4"))
+    NT = 2 * FN
+    order = [(m + FN) % NT for m in range(NT)]
+    cols = []
+    for m, t in enumerate(order):
+        if not cols or cols[-1][0] != t // 2:
+            cols.append([t // 2, m, len(cols)])
+    base = (2 if phase == "wz" else 3) * 4 * BN
+    pre, extra = [], {}
+
+    def rd(c, k):
+        def f():
+            t = SETS[k % len(SETS)]
+            emit(f"ds_read_b128 v[{t}:{t + 3}], v{V_PAR} offset:{base + c * 64}")
+            lq.issue(("C", ks, k))
+        return f
+    for c, first, k in cols:
+        at = first - LEAD
+        (pre if at < 0 else extra.setdefault(at, [])).append(rd(c, k))
+    kof = {}
+    for c, first, k in cols:
+        for m in range(first, NT):
+            if order[m] // 2 != c:
+                break
+            kof[m] = k
+    for m, t in enumerate(order):
+        i, j, k = t & 1, t // 2, kof[m]
+        st = SETS[k % len(SETS)]
+        fl = extra.setdefault(m, [])
+        fl.append(lambda k=k: lq.wait_for(("C", ks, k)))
+        for e in (2 * ks, 2 * ks + 1):
+            if phase == "wz":
+                fl.append(lambda i=i, j=j, e=e, st=st: emit(f"v_mad_i32_i24 {accr(i, j, e)}, v{st + e}, v{V_RS0 + i}, {accr(i, j, e)}"))
+            else:
+                fl.append(lambda i=i, j=j, e=e, st=st: emit(f"v_add_u32 {accr(i, j, e)}, {accr(i, j, e)}, v{st + e}"))
+    return pre, extra
+
+
+def rotate():
+    emit(f"s_mov_b32 s{S_CUR}, s{S_NXT}")
+    for s in (S_NXT, S_DMA):
+        emit(f"s_add_u32 s{s}, s{s}, {W_BYTES}")
+        emit(f"s_cmp_eq_u32 s{s}, {RING * W_BYTES}")
+        emit(f"s_cselect_b32 s{s}, 0, s{s}")
+    emit(f"s_add_u32 s{S_ABASE}, s{S_ABASE}, {2 * 1024}")
+    emit(f"s_addc_u32 s{S_ABASE + 1}, s{S_ABASE + 1}, 0")
+
+
+def stage(q, t, nw, kt=None, sym=None, first=False, dinit=False):
+    """One K = 128 stage.  t: stage number used for the queue tags; kt: total stages when the tail conditions apply (None = steady
+    state: everything is issued).  first: the accumulators start in this stage's k-step 0; dinit: "wz" / "ct" = that half of the deferred
+    zero-point correction rides in this stage (deferred_init)."""
+    set_ = t & 1
+    more1 = kt is None or t + 1 < kt
+    more2 = kt is None or t + 2 < kt
+    more3 = kt is None or t + 3 < kt
+    emit(f"; ---- stage {sym or t}: A set {set_}")
+    q.wait_for(("A", t, 0))
+    v0 = []
+    if more1 and not NO_A:      # S_ABASE = activation pointer of stage t+1
+        v0 += [("a", a_load(q, t + 1, 1, 0, 1 - set_, 1024)), ("a", a_load(q, t + 1, 1, 1, 1 - set_, 1024))]
+    if more3 and not NO_W:
+        v0 += [("w", w_piece(q, t + 3, i, S_DMA)) for i in range(nw)]
+    lq0, lq1 = LQueue(), LQueue()
+    pre0, ex0 = deferred_init(lq0, 0, dinit) if dinit else ([], None)
+    pre1, ex1 = deferred_init(lq1, 1, dinit) if dinit else ([], None)
+    for f in pre0:
+        f()
+    kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0, c_zero=first, extra=ex0, lq=lq0)
+    if more3:
+        emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK}")
+        emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
+    q.wait_for(("A", t, 1), ("W", t + 1))
+    emit("s_barrier")
+    v1 = []
+    if more2 and not NO_A:
+        v1 += [("a", a_load(q, t + 2, 0, 0, set_, 2048)), ("a", a_load(q, t + 2, 0, 1, set_, 2048))]
+    for f in pre1:
+        f()
+    kstep(1, set_, 1, S_NXT, V_WOFF0, 0, v1, read=more1, extra=ex1, lq=lq1)
+    rotate()
+
+
+# ---- round 4: the u8 epilogue inside the last two stages ---------------------------------------------------------------------------------
+# Classic tail: ... stage KT-2, stage KT-1 (k outer: every accumulator is final only at the very end), then ~330 VALU / LDS instructions
+# of epilogue per wave with the matrix pipe idle, then the stores, then the L2 write-back at the kernel boundary.
+# final_block: the 8 * FN MFMAs of stages KT-2 and KT-1 run COLUMN outer -- for j: 4 k-steps x 2 row blocks on acc(., j) -- so column
+# chunk j is final after its eighth MFMA and its conversion (cvt, fma, cvt_pk_u8, staging write) issues between the MFMAs of column j + 1;
+# a group of four chunks (64 bytes of 16 rows) is read back as 16-byte pieces and stored while later columns still multiply.  Needs both
+# stages' operands resident: W(KT-2), W(KT-1) are in the ring anyway, A(KT-2) and A(KT-1).ks0 in the two register sets, A(KT-1).ks1
+# in the eight spare AGPRs behind them (requested during stage KT-3).  W fragments come from the LDS per column (4 ds_read_b128 per
+# 8 MFMAs: the classic loop's ratio) through a ring of 16-register slots in a[0 : 8 FN), two columns ahead.
 RDA = (V_WOFF0, V_WOFF1, V_RD, V_RD3)       # LDS read addresses of (stage KT-2, ks0 / ks1), (stage KT-1, ks0 / ks1)
 
 
@@ -358,12 +417,35 @@ def stage_pre_final(q, lq, t, nw):
     assert not fill
 
 
+DINIT = os.environ.get("MQ_FR_DINIT", "1") != "0"       # deferred accumulator initialisation (round 4); 0 = in the prologue
+PRO_SPLIT = bool(os.environ.get("MQ_FR_PRO_SPLIT"))
+PSTAMP = bool(os.environ.get("MQ_FR_PSTAMP"))      # stamp build: five more s_memtime stamps inside the prologue (dbg slots 8..12)
+PST = (88, 90, 92, 94, 100)
+
+
+def pstamp(k, stamp):
+    """diagnostic: stamp k -> lanes 2k, 2k+1 of v105 (unused until stage KT-3); after the fifth, lanes 0..9 store to dbg slots 8..12 and
+    the wave drains its VMEM queue (the store is invisible to the queue simulation): the timeline behind the prologue is perturbed"""
+    if PSTAMP and stamp:
+        emit(f"s_memtime s[{PST[0]}:{PST[0] + 1}]")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit(f"v_writelane_b32 v{V_RD3}, s{PST[0]}, {2 * k}")
+        emit(f"v_writelane_b32 v{V_RD3}, s{PST[0] + 1}, {2 * k + 1}")
+        if k == 4:
+            emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")
+            emit(f"v_cmp_gt_u32 vcc, 10, v{V_TMP}")
+            emit("s_and_b64 exec, exec, vcc")
+            emit(f"v_lshlrev_b32 v{V_TMP}, 2, v{V_TMP}")
+            emit(f"global_store_dword v{V_TMP}, v{V_RD3}, %[dbg] offset:64")
+            emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+            emit("s_waitcnt vmcnt(0)")
+FB_NOCVT, FB_NOP, FB_NOST, FB_NOSWAP = (bool(os.environ.get("MQ_FR_FB_" + k)) for k in ("NOCVT", "NOP", "NOST", "NOSWAP"))   # what-if builds
+
+
 def final_block(q, lq, stamp):
     NG = (FN + 3) // 4                                  # store groups of (up to) four 16-byte chunks
-    CAP = 6                                             # fillers behind one MFMA
+    CAP = 5                                             # fillers behind one MFMA
     EA = [V_E, V_P0]
-    VP = [122, 123]
-    SD = 124                                            # 124..127: a store's data
     emit("; ==== final block: stages KT-2 and KT-1 column by column, the epilogue between the MFMAs")
     if stamp:
         emit(f"s_memtime s[{S_TS + 4}:{S_TS + 5}]")
@@ -380,26 +462,20 @@ def final_block(q, lq, stamp):
     def E(minidx, text):
         F(minidx, lambda: emit(text))
 
-    # -- set-up of the group stores (first needed behind column 3)
+    # -- set-up of the group stores (first needed behind column 3): lane (row = lane & 15, q = lane >> 4) stores chunk 4 G + q of its row
     rem = FN - 4 * (NG - 1)
     for text in (
             f"v_and_b32 v{V_TMP}, 63, %[tid]",
-            f"v_lshrrev_b32 v{V_GOG}, 2, v{V_TMP}",                                     # row = lane >> 2
-            f"v_and_b32 v{V_TMP}, 3, v{V_TMP}",
-            f"v_lshlrev_b32 v{V_TMP}, 4, v{V_TMP}",                                     # (lane & 3) * 16 bytes
-            f"v_mul_u32_u24 v{V_LDSG}, {ROWP}, v{V_GOG}",
-            f"v_add_u32 v{V_LDSG}, v{V_LDSG}, v{V_TMP}",
-            f"s_mul_i32 s{S_TMP}, %[wave], {STG_WAVE}",
-            f"s_add_u32 s{S_TMP}, s{S_TMP}, {STG}",
-            f"v_add_u32 v{V_LDSG}, s{S_TMP}, v{V_LDSG}",
+            f"v_and_b32 v{V_GOG}, 15, v{V_TMP}",                                        # row
+            f"v_lshrrev_b32 v{V_TMP}, 4, v{V_TMP}",                                     # q
             f"v_cmp_gt_i32_e64 s[{S_FM}:{S_FM + 1}], %[mrem], v{V_GOG}",                # row block 0: row < rows left
-            f"v_add_u32 v{SD + 2}, 16, v{V_GOG}",
-            f"v_cmp_gt_i32_e64 s[{S_FM + 2}:{S_FM + 3}], %[mrem], v{SD + 2}",           # row block 1
-            f"v_cmp_gt_u32_e64 s[{S_FM + 4}:{S_FM + 5}], {16 * rem}, v{V_TMP}",         # last group: only `rem` chunks exist
+            f"v_add_u32 v{V_LDSG}, 16, v{V_GOG}",
+            f"v_cmp_gt_i32_e64 s[{S_FM + 2}:{S_FM + 3}], %[mrem], v{V_LDSG}",           # row block 1
+            f"v_cmp_gt_u32_e64 s[{S_FM + 4}:{S_FM + 5}], {rem}, v{V_TMP}",              # last group: only `rem` chunks exist
             f"s_and_b64 s[{S_FM + 6}:{S_FM + 7}], s[{S_FM + 2}:{S_FM + 3}], s[{S_FM + 4}:{S_FM + 5}]",
             f"s_and_b64 s[{S_FM + 4}:{S_FM + 5}], s[{S_FM}:{S_FM + 1}], s[{S_FM + 4}:{S_FM + 5}]",
             f"v_mul_lo_u32 v{V_GOG}, v{V_GOG}, %[ldn]",
-            f"v_add_u32 v{V_GOG}, v{V_GOG}, v{V_TMP}",                                  # row * ldn + (lane & 3) * 16
+            f"v_lshl_add_u32 v{V_GOG}, v{V_TMP}, 4, v{V_GOG}",                          # row * ldn + q * 16
             f"s_lshl_b32 s{S_TMP2}, %[ldn], 4",
             f"s_mov_b64 s[{S_OB1}:{S_OB1 + 1}], %[outw]",
             f"s_add_u32 s{S_OB1}, s{S_OB1}, s{S_TMP2}",
@@ -416,82 +492,71 @@ def final_block(q, lq, stamp):
             lq.issue(("P", j))
         return [fn0, fn1]
 
-    def store_pieces(g, regs):
-        """group g (chunks 4g .. 4g+3 of both row blocks) as three filler lists: [read back row block 0], [wait, store, read back row
-        block 1], [wait, store] -- spliced into the NEXT column's conversion so that no wait drains the LDS queue"""
-        last = g == NG - 1 and rem != 4
-        out_ = []
-        for i in range(2):
-            r = regs[i]
-            def rd(i=i, r=r):
-                emit(f"ds_read_b128 v[{r}:{r + 3}], v{V_LDSG} offset:{i * 16 * ROWP + g * 64}")
-                lq.issue(("S", g, i))
-            m = S_FM + 2 * i + (4 if last else 0)
-            base = "%[outw]" if i == 0 else f"s[{S_OB1}:{S_OB1 + 1}]"
-            def st(i=i, base=base, r=r):
-                if STORE_POLICY != "none":
-                    emit(f"global_store_dwordx4 v{V_GOG}, v[{r}:{r + 3}], {base} offset:{g * 64} {STORE_POLICY}".rstrip())
-                    q.issue(("S", g, i))
-            out_.append((rd, [lambda i=i: lq.wait_for(("S", g, i)), (lambda m=m: emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")), st,
-                              lambda: emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")]))
-        return out_
+    def tbase(g, i):
+        """the four registers that collect group g's packed dwords of row block i: the accumulator tile of the group's FIRST column
+        (dead once that column is converted; a store's data registers must be consecutive)"""
+        return (2 * (4 * g) + i) * 4
 
-    def convert(minidx, j, group=None, late=False):
-        """conversion of column chunk j; group: a finished store group whose read-back / stores ride along"""
+    def convert(minidx, j):
+        """column chunk j: index = cvt_pk_u8(fma(float(acc), alpha', bias')), four bytes per lane -> register j % 4 of the group's tuple"""
         st = j & 1
-        pieces = store_pieces(group, (SD, EA[1 - st] if late else SD)) if group is not None else None
-        if pieces and not late:
-            F(minidx, pieces[0][0])                                  # read back row block 0 first: it lands under the conversion
-        F(minidx, lambda: lq.wait_for(("P", j)))
+        g, k = j // 4, j % 4
+        if not FB_NOP:
+            F(minidx, lambda: lq.wait_for(("P", j)))
+        if not FB_NOCVT:
+            for i in range(2):
+                for e in range(4):
+                    E(minidx, f"v_cvt_f32_i32 {accr(i, j, e)}, {accr(i, j, e)}")
+            for i in range(2):
+                for e in range(4):
+                    E(minidx, f"v_fma_f32 {accr(i, j, e)}, {accr(i, j, e)}, v{EA[st] + e}, v{EA[st] + 4 + e}")
+            for i in range(2):
+                d = tbase(g, i) + k
+                for e in range(4):
+                    E(minidx, f"v_cvt_pk_u8_f32 v{d}, {accr(i, j, e)}, {e}, " + (f"v{d}" if e else "0"))
+        if (k == 3 or j == FN - 1) and not FB_NOST:
+            store_group(minidx, g)
+
+    def store_group(minidx, g):
+        """lane (row, q) holds dword q of chunks 4g .. 4g+3 of its row; a 4 x 4 transpose between the register index and the lane's
+        16-lane row (two v_permlane32_swap + two v_permlane16_swap) gives it the 16 bytes of chunk 4g + q: one 16-byte store per lane,
+        64 contiguous bytes per row -- no LDS staging"""
+        last = g == NG - 1 and rem != 4
         for i in range(2):
-            for e in range(4):
-                E(minidx, f"v_cvt_f32_i32 {accr(i, j, e)}, {accr(i, j, e)}")
-        for i in range(2):
-            for e in range(4):
-                E(minidx, f"v_fma_f32 {accr(i, j, e)}, {accr(i, j, e)}, v{EA[st] + e}, v{EA[st] + 4 + e}")
-        if pieces and not late:
-            for fn in pieces[0][1]:
-                F(minidx, fn)
-            F(minidx, pieces[1][0])
-        for i in range(2):
-            for e in range(4):
-                E(minidx, f"v_cvt_pk_u8_f32 v{VP[i]}, {accr(i, j, e)}, {e}, " + (f"v{VP[i]}" if e else "0"))
-        for i in range(2):
-            E(minidx, f"v_xor_b32 v{VP[i]}, %[xorv], v{VP[i]}")
-        for i in range(2):
-            def wr(i=i):
-                emit(f"ds_write_b32 v{V_STW}, v{VP[i]} offset:{i * 16 * ROWP + j * 16}")
-                lq.issue(("WR", j))
-            F(minidx, wr)
-        if pieces and not late:
-            for fn in pieces[1][1]:
-                F(minidx, fn)
-        if pieces and late:                                          # the LAST group holds this very column: both read-backs, then both stores
-            F(minidx, pieces[0][0])
-            F(minidx, pieces[1][0])
-            for k in range(2):
-                for fn in pieces[k][1]:
-                    F(minidx, fn)
+            t = tbase(g, i)
+            # (gfx950: two wait states between a VALU write of a register and a v_permlane*_swap that reads it)
+            if not FB_NOSWAP:
+                E(minidx, "s_nop 1")
+                E(minidx, f"v_permlane32_swap_b32 v{t}, v{t + 2}")
+                E(minidx, f"v_permlane32_swap_b32 v{t + 1}, v{t + 3}")
+                E(minidx, "s_nop 1")
+                E(minidx, f"v_permlane16_swap_b32 v{t}, v{t + 1}")
+                E(minidx, f"v_permlane16_swap_b32 v{t + 2}, v{t + 3}")
+                E(minidx, "s_nop 1")
+                for k in range(4):
+                    E(minidx, f"v_xor_b32 v{t + k}, %[xorv], v{t + k}")
+            m = S_FM + 2 * i + (4 if last else 0)
+            E(minidx, f"s_mov_b64 exec, s[{m}:{m + 1}]")
+            base = "%[outw]" if i == 0 else f"s[{S_OB1}:{S_OB1 + 1}]"
+            def st(i=i, base=base, t=t):
+                if STORE_POLICY != "none":
+                    pol = STORE_POLICY if g == NG - 1 else os.environ.get("MQ_FR_STORE_EARLY", STORE_POLICY)
+                    emit(f"global_store_dwordx4 v{V_GOG}, v[{t}:{t + 3}], {base} offset:{g * 64} {pol}".rstrip())
+                    q.issue(("S", g, i))
+            F(minidx, st)
+            E(minidx, f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
 
     for j in range(FN):
         base = 8 * j
         if j + 2 < FN:
             for fn in fb_read(lq, j + 2):
                 F(base, fn)
-        for fn in params(j):
-            F(base, fn)
+        if not FB_NOP:
+            for fn in params(j):
+                F(base, fn)
         if j >= 1:
-            # column j - 1 converts now; a group that column j - 2 completed is stored along with it
-            convert(base + 2, j - 1, group=(j - 1) // 4 - 1 if (j - 1) % 4 == 0 and j - 1 >= 4 else None)
-    # behind the last MFMA: the last column; groups still open: the one column FN - 2 may have closed, and the last
-    pend = [(FN - 1) // 4 - 1] if (FN - 1) % 4 == 0 else []
-    convert(8 * FN + 1000, FN - 1, group=pend[0] if pend else None)
-    convert_tail = store_pieces(NG - 1, (SD, EA[0]))
-    for rd, _ in convert_tail:
-        F(8 * FN + 1000, rd)
-    for _, fns in convert_tail:
-        for fn in fns:
-            F(8 * FN + 1000, fn)
+            convert(base + 2, j - 1)
+    convert(8 * FN + 1000, FN - 1)                      # behind the last MFMA
 
     fi = 0
     n = 0
@@ -534,6 +599,10 @@ def final_block(q, lq, stamp):
         emit("v_mov_b32 v0, %[tentry_lo]")
         emit("v_mov_b32 v1, %[tentry_hi]")
         emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:48")
+        if PRO_SPLIT:
+            emit("v_mov_b32 v0, s100")
+            emit("v_mov_b32 v1, s101")
+            emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:56")
         emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
     emit("s_waitcnt vmcnt(0)")
 
@@ -585,6 +654,12 @@ def prologue(q, nw, stamp):
                     a_load(q, 0, ks, i, 0, 1024 * ks)()
             emit(f"s_add_u32 s{S_ABASE}, s{S_ABASE}, {2 * 1024}")       # -> stage 1
             emit(f"s_addc_u32 s{S_ABASE + 1}, s{S_ABASE + 1}, 0")
+            if PRO_SPLIT:        # what-if: how soon does stage 0 ALONE arrive?  (stamp 7; the later stages are requested behind it)
+                emit("s_waitcnt vmcnt(0)")
+                q.q = []
+                if stamp:
+                    emit("s_memtime s[100:101]")
+                    emit("s_waitcnt lgkmcnt(0)")
         if t == 1:
             a_load(q, 1, 0, 0, 1, 0)()
             a_load(q, 1, 0, 1, 1, 0)()
@@ -625,7 +700,9 @@ def prologue(q, nw, stamp):
     emit(f"v_add_u32 v{V_PAR}, {PAR}, v{V_PAR}")
     # (3) parameters: park alpha' = alpha/so, bias' = bias/so + oo, -w_zp, col_term in LDS (same expressions as the C++ prologue
     # of the other variants: one multiply, one multiply + one add, no contraction)
+    pstamp(0, stamp)
     q.wait_for("P")
+    pstamp(1, stamp)
     if SCALAR_GRID:
         # 1 / so, correctly rounded: the IEEE divide sequence hipcc emits for __fdiv_rn(1.0f, so) (the C++ epilogues of the other
         # variants divide the same way: identical alpha' / bias' bits)
@@ -672,19 +749,51 @@ def prologue(q, nw, stamp):
     for k in range(4):
         emit(f"ds_write_b32 v{V_TMP}, v{V_P0 + k} offset:{k * 4 * BN}")
     emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
-    emit("s_waitcnt lgkmcnt(0)")
-    emit("s_barrier")
-    # (4) accumulators = col_term[n] - w_zp[n] * row_sum[m] while the first stage is in flight
-    for j in range(FN):
-        emit(f"ds_read_b128 v[{V_E}:{V_E + 3}], v{V_PAR} offset:{2 * 4 * BN + j * 64}")
-        emit(f"ds_read_b128 v[{V_E + 4}:{V_E + 7}], v{V_PAR} offset:{3 * 4 * BN + j * 64}")
+    if not DINIT:
         emit("s_waitcnt lgkmcnt(0)")
-        for i in range(2):
-            for e in range(4):
-                emit(f"v_mad_i32_i24 {accr(i, j, e)}, v{V_E + e}, v{V_RS0 + i}, v{V_E + 4 + e}")
+        emit("s_barrier")
+    pstamp(2, stamp)
+    # (4) accumulators = col_term[n] - w_zp[n] * row_sum[m] while the first stage is in flight.  Round 4: stage 0 lands ~1.6 k cycles
+    # after the program starts, and the old form of this step (two reads, a full wait, eight mads, eleven times) alone took ~2.2 k cycles
+    # behind it.  Now every -w_zp chunk is read straight into row block 0's accumulator registers (11 reads in flight), the col_term
+    # chunks rotate through five 4-register sets four deep, and each column costs eight mads behind a counted wait.
+    if DINIT:
+        pass                        # stage 0 starts the accumulators at 0, stage 1 adds the correction (deferred_init)
+    elif os.environ.get("MQ_FR_OLD_INIT"):
+        for j in range(FN):
+            emit(f"ds_read_b128 v[{V_E}:{V_E + 3}], v{V_PAR} offset:{2 * 4 * BN + j * 64}")
+            emit(f"ds_read_b128 v[{V_E + 4}:{V_E + 7}], v{V_PAR} offset:{3 * 4 * BN + j * 64}")
+            emit("s_waitcnt lgkmcnt(0)")
+            for i in range(2):
+                for e in range(4):
+                    emit(f"v_mad_i32_i24 {accr(i, j, e)}, v{V_E + e}, v{V_RS0 + i}, v{V_E + 4 + e}")
+    else:
+        lqi = LQueue()
+        CT = [V_E, V_E + 4, V_P0, V_P0 + 4, 122]
+        def rd_ct(j):
+            t = CT[j % 5]
+            emit(f"ds_read_b128 v[{t}:{t + 3}], v{V_PAR} offset:{3 * 4 * BN + j * 64}")
+            lqi.issue(("ct", j))
+        for j in range(FN):
+            emit(f"ds_read_b128 {acc(0, j)}, v{V_PAR} offset:{2 * 4 * BN + j * 64}")
+            lqi.issue(("wz", j))
+        for j in range(min(4, FN)):
+            rd_ct(j)
+        for j in range(FN):
+            lqi.wait_for(("ct", j))
+            t = CT[j % 5]
+            for e in range(4):       # row block 1 first: it reads -w_zp from row block 0's register, which the second mad overwrites
+                emit(f"v_mad_i32_i24 {accr(1, j, e)}, {accr(0, j, e)}, v{V_RS0 + 1}, v{t + e}")
+                emit(f"v_mad_i32_i24 {accr(0, j, e)}, {accr(0, j, e)}, v{V_RS0}, v{t + e}")
+            if j + 4 < FN:
+                rd_ct(j + 4)
     # (5) W(0) of every wave landed -> first fragments
+    pstamp(3, stamp)
     q.wait_for(("W", 0))
+    if DINIT:
+        emit("s_waitcnt lgkmcnt(0)")            # this wave's parameter writes are in the LDS: the barrier publishes them with W(0)
     emit("s_barrier")
+    pstamp(4, stamp)
     emit(f"v_add_u32 v{V_RD}, s{S_CUR}, v{V_WOFF0}")
     for j in range(FN):
         emit(f"ds_read_b128 {wreg(0, j)}, v{V_RD} offset:{j * 16 * BK}")
@@ -1056,8 +1165,8 @@ def epilogue_f32r():
 def program(nw, stamp):
     q = Queue()
     prologue(q, nw, stamp)
-    stage(q, 0, nw)
-    stage(q, 1, nw)
+    stage(q, 0, nw, first=DINIT)
+    stage(q, 1, nw, dinit="wz" if DINIT else None)
     # steady state: pairs (t, t+1), t = 2, 4, ..., kt - 6;  pairs = (kt - 6) / 2  (>= 0)
     emit(f"s_sub_u32 s{S_CNT}, %[kt], 6")
     emit(f"s_lshr_b32 s{S_CNT}, s{S_CNT}, 1")
@@ -1087,13 +1196,13 @@ def program(nw, stamp):
     KT = 8
     q.q = [tuple(x[:1]) + (x[1] + 2,) + tuple(x[2:]) if isinstance(x, tuple) else x for x in before]
     if TAIL:
-        stage(q, 4, nw, kt=KT, sym="KT-4")
+        stage(q, 4, nw, kt=KT, sym="KT-4", dinit="ct" if DINIT else None)
         lq = LQueue()
         stage_pre_final(q, lq, 5, nw)
         final_block(q, lq, stamp)
         return q
     for t in range(4, 8):
-        stage(q, t, nw, kt=KT, sym=f"KT-{KT - t}")
+        stage(q, t, nw, kt=KT, sym=f"KT-{KT - t}", dinit="ct" if DINIT and t == 4 else None)
     assert q.q == [], q.q
     if EPI in ("u8", "gate"):
         epilogue(stamp)
@@ -1130,7 +1239,7 @@ def main(path=None, variant="fr"):
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
     vregs = [f'"v{r}"' for r in list(range(0, 88 if EPI == "gate" else 8 * FN)) + list(range(V_T if (8 * FN > 78 or EPI == "gate") else 78, 128))]
     aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32 + (8 if TAIL else 0))]
-    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + \
+    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + (['"s100"', '"s101"'] if (PRO_SPLIT or PSTAMP) else []) + \
         (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")

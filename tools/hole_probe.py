@@ -100,9 +100,9 @@ def chain(kernels, label):
     print(f"   period of the sequence {period:.2f} us", flush=True)
 
 
-def per_xcd(fill="gauss"):
+def per_xcd(fill="gauss", K=2048):
     """per-XCD anatomy of one steady-state GEMM launch: do the XCDs run at one clock?  (block b runs on XCD b % 8)"""
-    g = G(fill)
+    g = G(fill, K)
     bufs = [torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev) for _ in range(2)]
     for rep in range(NL):
         g.launch(bufs[rep & 1])
@@ -130,6 +130,11 @@ def per_xcd(fill="gauss"):
               f"epilogue {(e[:, 3] - e[:, 2]).mean():5.0f}) | clock {clk:5.0f} MHz", flush=True)
 
 
+if os.environ.get("HOLE_KSWEEP"):
+    for K in (768, 1024, 1280, 1536, 2048, 4096):
+        per_xcd("gauss", K)
+    lib.mq_gemm_set_variant(-1)
+    sys.exit(0)
 per_xcd("gauss")
 per_xcd("zero")
 if os.environ.get("HOLE_ONLY") == "xcd":
