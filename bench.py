@@ -15,8 +15,9 @@ exercised by `--workload calibration`).
 The JSON line also carries
   roofline     : the dominant kernel (the int8 GEMM) against the dense int8 MFMA peak, from HIP-event timing
                  of that kernel alone on the stream it is launched on;
-  cpu_baseline : the numpy oracle of the reference's simulated QLinear (oracle/mq_oracle.py, "port") timed
-                 on this box's host cores on the same shape -- a reported baseline, not a target;
+  cpu_baseline : the torch-CPU restatement of the reference's simulated QLinear (oracle/mq_oracle_torch.py, "port": the
+                 reference's op sequence on torch CPU kernels, bit-checked against the numpy oracle) timed on this box's
+                 physical host cores on the same shape -- a reported baseline, not a target;
   variants     : the same step with fp16 / fp32 outputs, and the drop-in nn.Module forward (fp32 in/out).
 """
 from __future__ import annotations
@@ -198,47 +199,76 @@ class Step:
 REPEATS = 7
 
 
+MAX_GRAPH_STEPS = 400      # steps captured in one hipGraph; longer runs replay several graphs back to back
+PREROLL_STEPS = 100        # untimed steps replayed in front of the first event of every repeat (~3 ms: behind a barrier + synchronize the
+                           # chip needs about a millisecond to settle at its sustained clock; a 20-step region is 0.6 ms)
+
+
 def run_steps(fn, steps, warmup, world, use_graph=True, pipelined=False):
-    """W untimed warmup steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize.
-    Steps are replayed from hipGraphs of GRAPH_STEPS steps each (the step is ~30 us: launch-bound from
-    Python otherwise); a remainder runs eagerly inside the same timed region."""
+    """W untimed warmup steps, then EXACTLY `steps` timed steps.
+
+    Round 4: the timed region is delimited by two HIP events on the stream the steps run on, around hipGraph(s) that
+    contain exactly `steps` steps -- no host clock, no Python between the first and the last timed kernel.  An untimed pre-roll graph
+    (PREROLL_STEPS steps) runs in front of the first event: the host has then already enqueued the event and the timed graph(s) when the
+    GPU reaches them (otherwise one graph-launch latency, 10-16 us, sits inside a 0.6-ms region), and the chip is at its sustained clock
+    (measured: without it a 20-step region reads 9 % slower than a 200-step one).  Every repeat is still bracketed by barrier +
+    torch.cuda.synchronize() on both sides and the maximum over ranks is taken by the caller; `--steps 20` and `--steps 200` now agree.
+    The host-clock figure of the same bracket (pre-roll excluded by subtraction is not possible, so it is the old method on its own
+    repeat) is kept in run_steps.host_wall for reference."""
     for i in range(warmup):
         fn(i)
     torch.cuda.synchronize()
-    graph = None
-    if use_graph and steps >= GRAPH_STEPS:
+    graphs = []
+    preroll = None
+    if use_graph:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for i in range(3):
                 fn(i)
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
-        with torch.cuda.graph(graph):
-            if pipelined:
-                fn.pipelined(GRAPH_STEPS, side)
-            else:
-                for i in range(GRAPH_STEPS):
-                    fn(i)
-        graph.replay()
+
+        def capture(n, first):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if pipelined:
+                    fn.pipelined(n, side)
+                else:
+                    for i in range(first, first + n):
+                        fn(i)
+            return g
+        done = 0
+        while done < steps:
+            n = min(MAX_GRAPH_STEPS, steps - done)
+            graphs.append(capture(n, done))
+            done += n
+        preroll = capture(PREROLL_STEPS, 0)
+        for g in graphs + [preroll]:
+            g.replay()
         torch.cuda.synchronize()
-    # The timed region -- EXACTLY `steps` steps between two barriers -- is a fraction of a millisecond at the driver's default
-    # --steps 20, so it is measured REPEATS times back to back and the median is reported (all values go into the line).
-    times = []
-    for _ in range(REPEATS):
+    times, host = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(REPEATS + 1):
         barrier(world)
         t0 = time.perf_counter()
-        done = 0
-        if graph is not None:
-            for _ in range(steps // GRAPH_STEPS):
-                graph.replay()
-            done = (steps // GRAPH_STEPS) * GRAPH_STEPS
-        for i in range(done, steps):
-            fn(i)
+        if preroll is not None and rep > 0:
+            preroll.replay()                     # untimed: the GPU is busy while the host enqueues e0 and the timed graphs
+        e0.record()
+        if graphs:
+            for g in graphs:
+                g.replay()
+        else:
+            for i in range(steps):
+                fn(i)
+        e1.record()
         barrier(world)
-        times.append((time.perf_counter() - t0) / steps)
+        if rep == 0:                             # repeat 0: the old host-clock bracket around the same K steps (no pre-roll), for reference
+            host.append((time.perf_counter() - t0) / steps)
+        else:
+            times.append(e0.elapsed_time(e1) * 1e-3 / steps)
     run_steps.last = sorted(times)
+    run_steps.host_wall = host[0]
     return run_steps.last[len(times) // 2]
 
 
@@ -1060,6 +1090,7 @@ def main():
         pipelined = args.overlap and not args.no_graph
         sec = run_steps(step, args.steps, args.warmup, world, use_graph=not args.no_graph, pipelined=pipelined)
         spread = [round(t * 1e3, 5) for t in getattr(run_steps, "last", [sec])]
+        run_steps.host_wall_main = run_steps.host_wall
         sec = max_over_ranks(sec, world)
         value = world * OPS_PER_STEP / sec / 1e12
 
@@ -1133,13 +1164,18 @@ def main():
             "metric": "W8A8 QuantLinear GEMM TOPS (% int8 MFMA peak) + TinyLlama-1.1B decode tok/s",
             "value": round(value, 1), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "timing": {"what": f"the {args.steps}-step timed region measured {REPEATS} times back to back; value / ms_per_step = the median (max over ranks)",
-                       "ms_per_step_rank0_sorted": spread},
+            "timing": {"what": f"exactly {args.steps} steps inside hipGraph(s) between two HIP events on their stream, behind an untimed pre-roll graph of {PREROLL_STEPS} steps, "
+                               f"each repeat bracketed by barrier + synchronize; measured {REPEATS} times, value / ms_per_step = the median "
+                               "(max over ranks)",
+                       "ms_per_step_rank0_sorted": spread,
+                       "host_clock_ms_per_step": round(getattr(run_steps, "host_wall_main", 0.0) * 1e3, 5),
+                       "host_clock_note": "perf_counter around barrier | the same graphs | barrier (round 3's method): it carries the graph-launch "
+                                          "and synchronize latency of the host, amortised over only --steps steps"},
             "dtype": "i8", "data": "synthetic",
             "config": {"workload": "TinyLlama-1.1B W8A8 real-int8 QLinear step (BASELINE.json configs[1]): fp32 x[2048,2048] "
                                    "-> int8 quantize(+row sums) -> MFMA i8 GEMM 2048->5632 with fused dequant + 8-bit output "
                                    "quantizer -> u8 indices; per-tensor asymmetric activation ranges, per-tensor asymmetric weights",
-                       "M": M, "K": K, "N": N, "parallelism": f"replicas x{world}", "graph_steps": 0 if args.no_graph else GRAPH_STEPS,
+                       "M": M, "K": K, "N": N, "parallelism": f"replicas x{world}", "graph_steps": 0 if args.no_graph else min(args.steps, MAX_GRAPH_STEPS),
                        "schedule": "quantize(batch i+1) overlapped with GEMM(batch i) on a second stream" if pipelined else "serial",
                        "pct_int8_mfma_peak": round(100 * value / world / INT8_MFMA_PEAK_TOPS, 2),
                        "decode_tok_s": decode["decode_tok_s"] if decode else None, "device": info},
