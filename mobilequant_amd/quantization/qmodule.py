@@ -329,11 +329,26 @@ class Quantizer(nn.Module):
             mn, mx = self._tensor_range(x2)
             transient = self.qcfg.is_dynamic or self.lwc
             self.set_scale_offset_from_minmax(mn, mx, None if transient else use_scale_offset_as, x2.device)
-            self._auto_grid = True            # derived from the tensor itself (first forward), not loaded / calibrated / trained
+            # derived from the tensor itself (first forward), not loaded / calibrated / trained.  The stamp lets a later reader tell an
+            # untouched auto grid from one the optimizer stepped or load_state_dict copied into IN PLACE (same Parameter objects, new
+            # versions): only the former may be re-derived (auto_grid_untouched)
+            self._auto_grid = (self._gen, _ver(self.scale), _ver(self.offset))
         if self.scale.device != x2.device:
             self.scale.data = self.scale.to(x2.device)
         if self.offset.device != x2.device:
             self.offset.data = self.offset.to(x2.device)
+
+    def auto_grid_untouched(self) -> bool:
+        """True while (scale, offset) are exactly what the first forward derived from the tensor it quantised: not set from ranges, not
+        loaded (load_state_dict copies into the existing tensors and bumps their versions), not stepped by an optimizer."""
+        st = getattr(self, "_auto_grid", False)
+        return bool(st) and self._has_grid() and st == (self._gen, _ver(self.scale), _ver(self.offset))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # a grid that arrives from a checkpoint is the caller's, whatever produced the tensors it lands in
+        if any(k in state_dict for k in (prefix + "scale", prefix + "offset")):
+            self._auto_grid = False
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def bypassed(self) -> bool:
         return (not self.enable) or self.qcfg.bitwidth > 16
@@ -409,6 +424,13 @@ def _apply(q: Optional[Quantizer], x):
 def _static_per_tensor(q: Optional[Quantizer], max_bits: int) -> bool:
     return (q is not None and not q.bypassed() and q.qcfg.bitwidth <= max_bits and not q.qcfg.is_dynamic
             and not q.lwc and not q.qcfg.is_per_channel and q._has_grid() and q.scale.numel() == 1)
+
+
+def _dynamic_per_tensor(q: Optional[Quantizer], max_bits: int) -> bool:
+    """A per-tensor grid that is re-derived from the tensor on every call (qmodule.py:262-277, `is_dynamic`): min / max, scale and offset
+    stay on the device (mq_minmax_tensor -> mq_scale_offset_from_minmax), so the integer kernels take it by pointer like a static one."""
+    return (q is not None and not q.bypassed() and q.qcfg.bitwidth <= max_bits and q.qcfg.is_dynamic and not q.lwc
+            and not q.qcfg.is_per_channel)
 
 
 class _SharedActivation:
@@ -512,7 +534,7 @@ class QLinear(nn.Linear, _QuantizedOp):
         # reference folds first and quantises after (smoothquant.py:64-69), so the grid of W * s must come from W * s.  A grid that
         # was loaded, calibrated or trained is the caller's: left alone.
         wq = self.weight_quantizer
-        if wq is not None and wq._has_grid() and getattr(wq, "_auto_grid", False):
+        if wq is not None and wq._has_grid() and wq.auto_grid_untouched():
             wq._gen = getattr(wq, "_gen", 0) + 1
             for name in ("scale", "offset"):
                 delattr(wq, name)
@@ -532,39 +554,71 @@ class QLinear(nn.Linear, _QuantizedOp):
             self._scaled_weight = (key, weakref.ref(weight), w)
         return w
 
-    def _activation_grid(self, x=None) -> Optional[Quantizer]:
+    def _activation_grid(self, x=None, refresh=False) -> Optional[Quantizer]:
         """The grid the int8 image of x is formed on: the own input quantizer; else the LIVE output quantizer of the module
         that produced x (tag left on the tensor object); else the grid declared by wire_integer_inputs (for inputs whose tag
-        is lost on the way, e.g. o_proj behind a transpose / reshape).  None -> simulated path (e.g. a 16-bit producer)."""
+        is lost on the way, e.g. o_proj behind a transpose / reshape).  None -> simulated path (e.g. a 16-bit producer).
+        A DYNAMIC own input quantizer (round 4) is served too: refresh=True re-derives its grid from x on the device (once per
+        forward, by _input_image); a dynamic producer's grid is the one its forward has just set."""
         iq = self.input_quantizer
         if iq is not None and not iq.bypassed():
-            return iq if _static_per_tensor(iq, 8) else None
+            if _static_per_tensor(iq, 8):
+                return iq
+            if _dynamic_per_tensor(iq, 8) and x is not None:
+                if refresh:
+                    xin = _materialize(x)
+                    if self.input_chan_scale is not None:
+                        xin = xin / self.input_chan_scale.to(xin.dtype)          # the grid of x / s comes from x / s
+                    iq._prepare(xin.reshape(-1, xin.shape[-1]), None)
+                return iq
+            return None
         prod = _producer_grid(x) if x is not None else None
         if prod is not None:
-            return prod if _static_per_tensor(prod, 8) else None
+            ok = _static_per_tensor(prod, 8) or (_dynamic_per_tensor(prod, 8) and prod._has_grid() and prod.scale.numel() == 1)
+            return prod if ok else None
         return self._input_grid
 
-    def _int8_ready(self, x, weight) -> bool:
-        if self.int8_mode == "off" or not x.is_cuda or x.dtype not in (torch.float32, torch.float16) or x.numel() == 0:
-            return False                    # (an empty batch takes the simulated path: every op of it handles empties)
+    def _int8_reason(self, x, weight) -> Optional[str]:
+        """None when this call can run on the integer kernels, else WHY it takes the simulated path (HIP fake-quant around the
+        fp32 library GEMM: the reference's semantics, ~10x slower) -- recorded per module, read by int8_coverage()."""
+        if self.int8_mode == "off":
+            return "int8_mode off"
+        if not x.is_cuda:
+            return "not a device tensor"
+        if x.dtype not in (torch.float32, torch.float16):
+            return f"activation dtype {x.dtype}"
+        if x.numel() == 0:
+            return "empty batch"              # (every op of the simulated path handles empties)
         wq = self.weight_quantizer
-        if wq is None or wq.bypassed() or wq.qcfg.bitwidth > 8 or wq.qcfg.is_dynamic or wq.lwc:
-            return False
+        if wq is None or wq.bypassed():
+            return "no weight quantizer"
+        if wq.qcfg.bitwidth > 8:
+            return f"{wq.qcfg.bitwidth}-bit weights"
+        if wq.qcfg.is_dynamic:
+            return "dynamic weight quantizer"
+        if wq.lwc:
+            return "learnable weight clipping active"
         if wq.qcfg.is_per_channel and wq.qcfg.group_size != -1:
-            return False
+            return "per-group weight grid"
         K, N = weight.shape[1], weight.shape[0]
         M = x.numel() // max(K, 1)
         if K % 128 or N % 4 or K > 65536 or M * K >= 2 ** 31 or N * K >= 2 ** 31 or M * N >= 2 ** 40:
-            return False                    # the C ABI's shape limits (mq_w8a8_linear): outside them, the simulated path
+            return f"shape M={M} K={K} N={N} outside mq_w8a8_linear's limits"
         if (x.data_ptr() % 16 and x.is_contiguous()) or (self.bias is not None and self.bias.data_ptr() % 16):
-            return False                    # 16-byte alignment of the operands the kernels read directly
+            return "operand not 16-byte aligned"
         if self._activation_grid(x) is None:
-            return False
-        oq = self.output_quantizer
-        if oq is not None and not oq.bypassed() and not _static_per_tensor(oq, 16):
-            return False
+            iq = self.input_quantizer
+            if iq is not None and not iq.bypassed():
+                return (f"input quantizer: {iq.qcfg.bitwidth}-bit" + (" per-channel" if iq.qcfg.is_per_channel else "")
+                        + (" lwc" if iq.lwc else "") + (" without a range" if not iq._has_grid() and not iq.qcfg.is_dynamic else ""))
+            return "no 8-bit per-tensor grid on the input (16-bit / per-channel / untagged producer)"
         params = [x, weight, self.bias, getattr(wq, "scale", None)]
-        return not _needs_grad(*params)
+        if _needs_grad(*params):
+            return "gradient required"
+        return None
+
+    def _int8_ready(self, x, weight) -> bool:
+        return self._int8_reason(x, weight) is None
 
     def _weight_plan(self, weight):
         """Integer weights + column sums, cached until the weight or its quantizer changes (SURVEY 8a' item 5)."""
@@ -608,7 +662,7 @@ class QLinear(nn.Linear, _QuantizedOp):
         """int8 image of the activation on this linear's input grid: (grid, a_q, a_rs, a_shift, tiled_rows, decode).  An image
         left by a producer (fused norm) or a sibling linear wins: no quantize launch at all; the large FFN shapes want the
         fragment-blocked layout of the generated-ISA GEMM kernels.  decode (M <= 8): no image, the GEMV quantises itself."""
-        grid = self._activation_grid(x)
+        grid = self._activation_grid(x, refresh=True)
         plan = self._weight_plan(weight)
         K, N = weight.shape[1], weight.shape[0]
         if grid.scale.device != x.device:
@@ -654,6 +708,9 @@ class QLinear(nn.Linear, _QuantizedOp):
         return self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=decode)
 
     def _epilogue_vectors(self, plan, grid, a_shift, K):
+        """per-n dequantisation vectors of (activation grid, weight grid); every integer GEMM of this module -- its own forward or a
+        fused block's -- passes through here: counted for int8_coverage()"""
+        self._count_path(None)
         wq = self.weight_quantizer
         epi_key = (grid.grid_token(), a_shift)
         if plan["epi_key"] != epi_key:
@@ -663,15 +720,25 @@ class QLinear(nn.Linear, _QuantizedOp):
             plan["epi_key"] = epi_key
         return plan
 
-    def _int8_from_image(self, x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=False, lead_shape=None, resid=None):
+    def _int8_from_image(self, x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=False, lead_shape=None, resid=None,
+                         skip_oq=False):
         """The GEMM half of the integer path: a ready int8 image of the activation (row-major, or fragment-blocked with
         tiled_rows) on `grid` -> this linear's output.  x only supplies dtype / leading shape (and the fp32 values for the
         fused decode GEMV); it may be None when lead_shape is given.  resid (fp32, the output's shape): returns
         resid + output -- fused into the GEMM's store where the kernel allows (no launch, no pass), a plain add elsewhere."""
-        oq = self.output_quantizer
+        oq = None if skip_oq else self.output_quantizer
         K, N = weight.shape[1], weight.shape[0]
+        active = oq is not None and not oq.bypassed()
+        fused = active and _static_per_tensor(oq, 16)
+        if active and not fused:
+            # an output grid the GEMM epilogue cannot take by pointer BEFORE it has the values (dynamic: its range is the output's own
+            # min / max, qmodule.py:262-277; per-channel; learnable clipping): integer GEMM -> fp values -> the HIP Quantizer, as the
+            # reference orders it (qmodule.py:353-357)
+            out = self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode=decode, lead_shape=lead_shape,
+                                        skip_oq=True)
+            out = oq(out)
+            return out if resid is None else resid + out
         plan = self._epilogue_vectors(self._weight_plan(weight), grid, a_shift, K)
-        fused = oq is not None and not oq.bypassed()
         dev = a_q.device if a_q is not None else x.device
         if fused and oq.scale.device != dev:
             oq.scale.data, oq.offset.data = oq.scale.to(dev), oq.offset.to(dev)
@@ -708,12 +775,20 @@ class QLinear(nn.Linear, _QuantizedOp):
         out = out.reshape(*lead, N)
         return _tag_grid(out, oq) if fused else out
 
+    def _count_path(self, reason):
+        c = self.__dict__.setdefault("_path_counts", {})
+        key = "int8" if reason is None else "simulated: " + reason
+        c[key] = c.get(key, 0) + 1
+
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, input_):
         weight = self.temp_weight if self.use_temporary_parameter else self.weight
         bias = self.temp_bias if self.use_temporary_parameter else self.bias
         weight = self._effective_weight(weight)
-        if self._int8_ready(input_, weight):
+        reason = self._int8_reason(input_, weight)
+        if reason is not None:
+            self._count_path(reason)
+        if reason is None:
             return self._forward_int8(input_, weight, bias)
         input_ = _materialize(input_)
         # simulated path: HIP fake-quant kernels around the library GEMM
@@ -1276,6 +1351,35 @@ def _gated_table_of(block, act, silu, o1, o3, iq2, device):
                                 act_grid=QRMSNorm._grid_or_none(act.output_quantizer), q_shift=128)
         cached = block._gated_lut = (key, table)
     return cached[1]
+
+
+def int8_coverage(model, reset=False):
+    """Which QLinear modules of `model` ran on the integer kernels, and which took the simulated path (HIP fake-quant around the fp32
+    library GEMM) and why -- since the last reset.  Returns {"modules": {name: {path: calls}}, "int8_calls", "simulated_calls",
+    "simulated_modules": [names], "summary": str}.  The simulated path is correct by the reference's semantics but ~10x slower; an
+    evaluation that silently lands on it (a 16-bit producer in front of q/k/v, a per-group recipe, grad mode) shows up here.
+    Modules executed inside a fused block (fuse_gated_mlp / fuse_attention / fuse_decoder_layer) count as "int8 (fused block)"."""
+    mods, n_int, n_sim, sim_names = {}, 0, 0, []
+    for name, mod in model.named_modules():
+        if isinstance(mod, QLinear):
+            c = dict(mod.__dict__.get("_path_counts", {}))
+            mods[name] = c
+            i = sum(v for k, v in c.items() if k.startswith("int8"))
+            sm = sum(v for k, v in c.items() if k.startswith("simulated"))
+            n_int, n_sim = n_int + i, n_sim + sm
+            if sm:
+                sim_names.append(name)
+            if reset:
+                mod.__dict__["_path_counts"] = {}
+    why = {}
+    for name in sim_names:
+        for k, v in mods[name].items():
+            if k.startswith("simulated"):
+                why[k] = why.get(k, 0) + v
+    summary = f"{n_int} integer-path calls, {n_sim} simulated-path calls in {len(sim_names)} of {len(mods)} QLinear modules"
+    if why:
+        summary += "; " + "; ".join(f"{v} x {k}" for k, v in sorted(why.items(), key=lambda kv: -kv[1]))
+    return {"modules": mods, "int8_calls": n_int, "simulated_calls": n_sim, "simulated_modules": sim_names, "summary": summary}
 
 
 def fuse_gated_mlp(model) -> int:

@@ -42,7 +42,7 @@ import torch
 import torch.nn as nn
 
 REF = os.environ.get("MQ_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.environ.get("MQ_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")   # (tools/check_golden.py regenerates into a temp dir)
 sys.path.insert(0, REF)
 sys.dont_write_bytecode = True
 
@@ -399,6 +399,51 @@ def gen_qlinear_cases():
     run(8, 64, 32, 8, False, False, dict(bitwidth=8, is_symmetric=True), 8, False, "a8_sym_in")
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "qlinear_cases.npz"), **out)
+
+
+def gen_qlinear_dynamic_cases():
+    """QLinear.forward with DYNAMIC activation quantizers (qmodule.py:262-277: the range is the tensor's own min / max on every call;
+    CLI: ptq/mobilequant.py:50,166,205, ptq/generate_qcfg.py:33,78): dynamic input, dynamic output, both (+ bias, per-channel weights),
+    and a dynamic 16-bit output.  The integer path serves them with device-resident grids (round 4)."""
+    g = torch.Generator().manual_seed(4242)
+    out, meta = {}, []
+    for cid, (M, K, N, wpc, in_dyn, out_dyn, out_bits, bias, tag) in enumerate((
+            (32, 128, 64, False, True, False, 8, False, "dyn_in"),
+            (32, 128, 64, False, False, True, 8, False, "dyn_out"),
+            (48, 256, 96, True, True, True, 8, True, "dyn_in_out_bias_perch"),
+            (32, 128, 64, False, True, True, 16, False, "dyn_in_out16"))):
+        lin = nn.Linear(K, N, bias=bias)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(N, K, generator=g) * 0.05)
+            if bias:
+                lin.bias.copy_(torch.randn(N, generator=g) * 0.1)
+        x = torch.randn(2, M // 2, K, generator=g) * 1.5
+        ql = Q.QLinear.from_float(lin, Q.QuantConfig(bitwidth=8, is_dynamic=in_dyn), Q.QuantConfig(bitwidth=8, is_per_channel=wpc),
+                                  Q.QuantConfig(bitwidth=out_bits, is_dynamic=out_dyn))
+        y_fp = nn.functional.linear(x, ql.weight, ql.bias)
+        act = {}
+        if not in_dyn:
+            act["input"] = [float(x.min()), float(x.max())]
+        if not out_dyn:
+            act["output"] = [float(y_fp.min()), float(y_fp.max())]
+        if act:
+            if "input" not in act:          # set_scale_offset wants both keys: set the static side by hand
+                ql.output_quantizer.set_scale_offset_from_minmax(*act["output"], "buffer")
+            elif "output" not in act:
+                ql.input_quantizer.set_scale_offset_from_minmax(*act["input"], "buffer")
+            else:
+                ql.set_scale_offset(act, "buffer")
+        with torch.no_grad():
+            y = ql(x)
+        k = f"c{cid}"
+        out[k + "_x"], out[k + "_w"], out[k + "_y"] = npf(x), npf(ql.weight), npf(y)
+        if bias:
+            out[k + "_b"] = npf(ql.bias)
+        out[k + "_oscale"] = npf(ql.output_quantizer.scale)
+        meta.append(dict(id=k, tag=tag, M=M, K=K, N=N, wpc=wpc, in_dyn=in_dyn, out_dyn=out_dyn, out_bits=out_bits, bias=bias, act=act))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "qlinear_dynamic_cases.npz"), **out)
+    print("qlinear_dynamic_cases:", [m["tag"] for m in meta])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1189,6 +1234,97 @@ def gen_layer_case():
     print("layer_case: logits", out["logits_w8a8"].shape, "max |w8a8 - fp| %.4f of span %.3f" % (np.abs(d).max(), np.ptp(out["logits_fp"])))
 
 
+def gen_full_depth_case(S=256, V=512, layers=22):
+    """Model-DEPTH parity ("quantized perplexity within 0.05 of reference" is a full-model bar, eval/harness_eval.py:
+    75-108): the REAL reference HFForCausalLM at TinyLlama-1.1B's geometry -- 22 layers, hidden 2048, 32 heads / 4 KV heads, head_dim 64,
+    FFN 5632 (mobilellm/model/sim_model.py:43-44) -- with a reduced vocabulary, on a 256-token sequence; ranges from the reference's own
+    get_act_range; then BOTH deployment recipes on the same calibrated model: W8A8 (per-tensor weights, ptq/mobilequant.py:175-201 mixed
+    precision) and W4A8 (4-bit per-channel asymmetric weights, experiments/w4a8/main/e2e_llama-s1024-ep60.sh:23).  Weights come from
+    tests/seeded.py (regenerated on the test side).  Stored: ids, ranges, qcfg, and per recipe the next-token NLL of every position
+    (float64), the argmax of every position and the logits of every 8th position over the whole vocabulary -- how index flips accumulate
+    over 22 layers is what this fixture pins -- and the same quantities of a SECOND reference run with three BLAS threads (`*_self3`): the
+    reference's own reproducibility floor, which is what an implementation can be held to."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import copy
+    import time as _t
+    from seeded import seeded_parameters_
+    from mobilellm.model.hf_config import HFConfig
+    from mobilellm.model.hf_model import HFForCausalLM
+    cfg = HFConfig(vocab_size=V, hidden_size=2048, intermediate_size=5632, num_hidden_layers=layers, num_attention_heads=32,
+                   num_key_value_heads=4, max_position_embeddings=S, hidden_act="silu", use_matmul_as_module=True)
+    cfg._attn_implementation = "eager"
+    m = HFForCausalLM(cfg).eval()
+    seeded_parameters_(m, std=0.02, strip="model.")
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(0, V, (1, S), generator=g)
+    calib = [torch.randint(0, V, (1, S), generator=g), torch.randint(0, V, (1, S), generator=g), ids]
+    out = {"ids": npf(ids[0])}
+
+    def stats(logits, tag):
+        lg = logits[0].double()
+        nll = -(torch.log_softmax(lg[:-1], -1).gather(1, ids[0, 1:, None])[:, 0])
+        out["nll_" + tag] = nll.numpy()
+        out["argmax_" + tag] = lg.argmax(-1).numpy().astype(np.int32)
+        out["logits_" + tag] = npf(logits[0, ::8])
+        print(f"full_depth_case[{tag}]: NLL {float(nll.mean()):.6f}  ppl {float(nll.mean().exp()):.4f}", flush=True)
+    t0 = _t.time()
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        stats(m(ids, use_cache=False).logits, "fp")
+    rng_mod = _load_script(os.path.join(REF, "ptq", "generate_act_range.py"), ["x", "--hf_path", "none"])
+    rng_mod.args.per_channel = False
+
+    class _Tk:
+        bos_token_id, vocab_size = 1, V
+        def __call__(s_, line, return_tensors="pt", max_length=None, truncation=True):
+            return types.SimpleNamespace(input_ids=calib[int(line)])
+    _orig = m.forward
+    m.forward = lambda x_, **kw: _orig(x_, use_cache=False)
+    act = rng_mod.get_act_range(m, _Tk(), [{"text": str(i)} for i in range(len(calib))], len(calib), S)
+    m.forward = _orig
+    print(f"full_depth_case: fp forward + calibration {_t.time() - t0:.0f} s", flush=True)
+    for tag, wcfg in (("w8a8", Q.QuantConfig(bitwidth=8)), ("w4a8", Q.QuantConfig(bitwidth=4, is_per_channel=True))):
+        mq_ = copy.deepcopy(m)
+        Q.create_sim_qmodel(mq_, wcfg, Q.QuantConfig(bitwidth=8))
+        for name, mod in mq_.named_modules():          # ptq/mobilequant.py:175-201
+            if isinstance(mod, Q.QLinear):
+                if "w2" in name:
+                    mod.weight_quantizer.qcfg.is_per_channel = True
+                    mod.output_quantizer.qcfg.bitwidth = 16
+                elif "o_proj" in name:
+                    mod.output_quantizer.qcfg.bitwidth = 16
+            elif isinstance(mod, Q.QRMSNorm):
+                mod.input_quantizer.qcfg.bitwidth = 16
+                mod.weight_quantizer.qcfg.bitwidth = 16
+                mod.weight_quantizer.qcfg.is_symmetric = False
+                mod.weight_quantizer.qcfg.is_per_channel = False
+            elif isinstance(mod, Q.QMatMul):
+                if "qk_bmm" in name:
+                    mod.output_quantizer.qcfg.bitwidth = 16
+                if "pv_bmm" in name:
+                    mod.input_quantizer.qcfg.bitwidth = 16
+        a_ = {k_: v_ for k_, v_ in act.items() if any(k_ == n for n, mm in mq_.named_modules()
+                                                      if isinstance(mm, (Q.QLinear, Q.QRMSNorm, Q.QMatMul, Q.QSiLU)))}
+        Q.set_scale_and_offset(mq_, a_, "buffer")
+        t0 = _t.time()
+        prev = torch.get_num_threads()
+        with torch.no_grad():
+            torch.set_num_threads(1)                 # the canonical run: one thread = one summation order
+            stats(mq_(ids, use_cache=False).logits, tag)
+            # the reference against ITSELF: the same forward with the BLAS splitting its dot products differently.  Fake-quant behind
+            # fp32 matmuls is not reproducible to the index (K = 2048 ... 5632 sums carry ~1e-5 of the output scale, an 8-bit LSB is
+            # 4e-3: ~0.25 % of all 8-bit indices flip), and 22 layers amplify that: this spread is the floor any implementation sits on
+            torch.set_num_threads(3)
+            stats(mq_(ids, use_cache=False).logits, tag + "_self3")
+            torch.set_num_threads(prev)
+        print(f"full_depth_case[{tag}]: simulated forwards {_t.time() - t0:.0f} s", flush=True)
+        out["qcfg_" + tag] = np.array(json.dumps(Q.export_qcfg(mq_)))
+        out["act"] = np.array(json.dumps(a_))
+        del mq_
+    np.savez_compressed(os.path.join(OUT, "full_depth_case.npz"), **out)
+    print("full_depth_case: %.0f KiB" % (os.path.getsize(os.path.join(OUT, "full_depth_case.npz")) / 1024))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
@@ -1209,6 +1345,7 @@ if __name__ == "__main__":
     gen_decode_case_stablelm()
     gen_decode_case_gemma()
     gen_layer_case()
+    gen_full_depth_case()
     gen_scale_offset_grid()
     gen_quantizer_cases()
     gen_nonfinite()
@@ -1216,6 +1353,7 @@ if __name__ == "__main__":
     gen_qact_cases()
     gen_quantizer_grads()
     gen_qlinear_cases()
+    gen_qlinear_dynamic_cases()
     gen_calib_stream()
     gen_checksums()
     gen_api_surface()

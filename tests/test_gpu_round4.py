@@ -1,0 +1,247 @@
+"""Round-4 GPU parity tests (through the C ABI): model-DEPTH parity against the reference's real 22-layer simulated model, the weight
+grid life cycle fixed in round 4, and the kernels that changed shape this round."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    import mobilequant_amd._lib as L
+    assert L.device_info()["arch"].startswith("gfx950")
+    return torch.device("cuda:0")
+
+
+def _full_depth_model(dev, tag):
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    from seeded import seeded_parameters_
+    z = load_npz("full_depth_case.npz")
+    S = int(z["ids"].shape[0])
+    m = LlamaForCausalLM(LlamaShape(hidden=2048, layers=22, heads=32, kv_heads=4, head_dim=64, ffn=5632, vocab=512, eps=1e-5, max_pos=S)).eval()
+    seeded_parameters_(m, std=0.02)
+    m = m.to(dev)
+    strip = lambda d: {(k[len("model."):] if k.startswith("model.") else k): v for k, v in d.items()}      # noqa: E731
+    wcfg = mq.QuantConfig(bitwidth=8) if tag == "w8a8" else mq.QuantConfig(bitwidth=4, is_per_channel=True)
+    mq.create_sim_qmodel(m, wcfg, mq.QuantConfig(bitwidth=8))
+    mq.update_qcfg(m, strip(json.loads(str(z["qcfg_" + tag]))))
+    mq.set_scale_and_offset(m, strip(json.loads(str(z["act"]))), "buffer")
+    mq.wire_integer_inputs(m)
+    return m.requires_grad_(False), z
+
+
+def _stats(logits, ids):
+    lg = logits.double()
+    nll = -(torch.log_softmax(lg[:-1], -1).gather(1, ids[1:, None])[:, 0])
+    _stats.last_nll = nll.cpu().numpy()
+    return float(nll.mean()), float(nll.mean().exp()), lg.argmax(-1).cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["w8a8", "w4a8"])
+def test_full_depth_22_layer_model_perplexity_and_argmax_vs_the_reference(dev, tag):
+    """BASELINE.json: "quantized perplexity within 0.05 of reference".  The reference's acceptance is a whole-model evaluation
+    (eval/harness_eval.py:75-108); offline there are no checkpoints, so depth is pinned on the REAL reference HFForCausalLM at
+    TinyLlama-1.1B's geometry (22 layers, hidden 2048, 32 / 4 heads, FFN 5632; weights from tests/seeded.py, 512-word vocabulary, 256
+    tokens; tests/golden/full_depth_case.npz): its simulated W8A8 and W4A8 forwards give the next-token NLL / perplexity, the argmax of
+    every position and every 8th position's logits.
+
+    What the fixture also shows: on this random-weight model the reference does not reproduce ITSELF to 0.05.  The same simulated forward
+    with three BLAS threads instead of one (`*_self3`) moves the perplexity by whole units, agrees on the argmax of ~75-80 % of the
+    positions and moves the logits by a median 1 % of their span -- fake-quant behind fp32 matmuls flips ~0.25 % of all 8-bit indices
+    when the summation order changes, and 22 layers amplify it.  So does the reference's own op sequence executed on this GPU (every
+    QLinear on the simulated path: bit-exact fake-quant kernels around the fp32 library GEMM).  An implementation can therefore be held to
+    being one more such sample: the chain of Q-modules on the integer kernels, the fused prefill (9 launches per layer) and the decode
+    engine fed token by token must each sit as close to the canonical reference run as those two yardsticks do (logit deviations within
+    1.25 x the larger median / max, argmax agreement within 0.08 of the smaller, per-position NLL scatter within 1.25 x), and their
+    perplexity inside three standard errors of that scatter (0.05 where the scatter allows it -- here it does not: DESIGN.md 3)."""
+    from mobilequant_amd import llama
+    from mobilequant_amd.decode import DecodeEngine
+    m, z = _full_depth_model(dev, tag)
+    ids = torch.from_numpy(z["ids"]).long().to(dev)
+    ref_nll = z["nll_" + tag]
+    ref_ppl = float(np.exp(ref_nll.mean()))
+    fp_ppl = float(np.exp(z["nll_fp"].mean()))
+    ref_arg, ref_lg = z["argmax_" + tag], z["logits_" + tag]
+    span = float(np.ptp(z["logits_fp"]))
+    # the reference against itself
+    sd = np.abs(z["logits_" + tag + "_self3"] - ref_lg) / span
+    self_ = dict(dppl=float(np.exp(z["nll_" + tag + "_self3"].mean()) - ref_ppl), argmax=float((z["argmax_" + tag + "_self3"] == ref_arg).mean()),
+                 logit_max=float(sd.max()), logit_median=float(np.median(sd)), nll_scatter=float(np.std(z["nll_" + tag + "_self3"] - ref_nll)))
+    res = {}
+    import mobilequant_amd as mq
+    with torch.no_grad():
+        # a second yardstick: the reference's op sequence on THIS machine -- every QLinear on the simulated path (bit-exact HIP fake-quant
+        # around the fp32 library GEMM), i.e. the reference with rocBLAS instead of MKL summing its dot products
+        for mod in m.modules():
+            if isinstance(mod, mq.QLinear):
+                mod.int8_mode = "off"
+        lg = m(ids.view(1, -1))[0]
+        sim = (_stats(lg, ids), lg[::8].float().cpu().numpy(), _stats.last_nll)
+        for mod in m.modules():
+            if isinstance(mod, mq.QLinear):
+                mod.int8_mode = "auto"
+        lg = m(ids.view(1, -1))[0]
+        res["module chain"] = (_stats(lg, ids), lg[::8].float().cpu().numpy(), _stats.last_nll)
+        assert llama.fuse_decoder_layer(m) == 22
+        lg = m(ids.view(1, -1))[0]
+        res["fused prefill"] = (_stats(lg, ids), lg[::8].float().cpu().numpy(), _stats.last_nll)
+        eng = DecodeEngine(m, cache_len=int(ids.numel()))
+        rows = []
+        for t in ids.tolist():
+            eng.step(t)
+            rows.append(eng.logits.clone())
+        lg = torch.stack(rows)
+        res["decode engine"] = (_stats(lg, ids), lg[::8].float().cpu().numpy(), _stats.last_nll)
+    def measure(entry):
+        (nll, ppl, arg), sub, nlls = entry
+        d = np.abs(sub - ref_lg) / span
+        return dict(ppl=round(ppl, 4), dppl=round(ppl - ref_ppl, 4), argmax=round(float((arg == ref_arg).mean()), 4),
+                    logit_max=round(float(d.max()), 4), logit_median=round(float(np.median(d)), 5),
+                    nll_scatter=round(float(np.std(nlls - ref_nll)), 5))
+    report = {name: measure(e) for name, e in res.items()}
+    gsim = measure(sim)
+    yard = {k: max(self_[k], gsim[k]) for k in ("logit_max", "logit_median", "nll_scatter")}
+    yard["argmax"] = min(self_["argmax"], gsim["argmax"])
+    ppl_bar = max(0.05, 3.0 * ref_ppl * yard["nll_scatter"] / np.sqrt(ref_nll.size))
+    print(f"full depth [{tag}]: reference ppl {ref_ppl:.4f} (fp {fp_ppl:.4f}: quantisation moves it by {ref_ppl - fp_ppl:+.3f}); the reference's own "
+          f"second run (3 BLAS threads): {({k: round(v, 5) for k, v in self_.items()})}; the reference's op sequence on this GPU's library GEMM: "
+          f"{gsim}; perplexity bar {ppl_bar:.3f};", report)
+    for name, r in report.items():
+        assert abs(r["dppl"]) <= ppl_bar, (tag, name, r, ppl_bar)
+        assert r["argmax"] >= yard["argmax"] - 0.08, (tag, name, r, yard)
+        assert r["logit_median"] <= 1.25 * yard["logit_median"] and r["logit_max"] <= 1.25 * yard["logit_max"], (tag, name, r, yard)
+        assert r["nll_scatter"] <= 1.25 * yard["nll_scatter"], (tag, name, r, yard)
+
+
+def test_trained_or_loaded_weight_grid_survives_a_run_time_channel_scale(dev):
+    """the first forward derives the weight grid and caches it as nn.Parameters; an optimizer step or
+    load_state_dict then changes those SAME tensors in place.  set_input_channel_scale() must re-derive only a grid nobody touched
+    since -- a trained or loaded grid is the caller's (qmodule.py:262-277 caches, algorithm.py:239-282 trains `quantizer.scale`)."""
+    import mobilequant_amd as mq
+    torch.manual_seed(5)
+    w = torch.randn(64, 128, device=dev) * 0.05
+    s = (torch.rand(128, device=dev) + 0.5)
+    x = torch.randn(4, 128, device=dev)
+
+    def make():
+        lin = torch.nn.Linear(128, 64, bias=False).to(dev)
+        lin.weight.data.copy_(w)
+        q = mq.QLinear.from_float(lin, mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8))
+        q.set_scale_offset({"input": [-4.0, 4.0], "output": [-2.0, 2.0]}, "buffer")
+        return q
+    # (1) untouched auto grid: re-derived from W * s
+    a = make()
+    with torch.no_grad():
+        a(x)
+    auto = float(a.weight_quantizer.scale)
+    a.set_input_channel_scale(s)
+    assert not a.weight_quantizer._has_grid()
+    with torch.no_grad():
+        a(x)
+    assert float(a.weight_quantizer.scale) != auto
+    # (2) stepped in place (what an optimizer does to `weight_quantizer.scale`): kept
+    b = make()
+    with torch.no_grad():
+        b(x)
+        b.weight_quantizer.scale.mul_(1.25)
+    stepped = float(b.weight_quantizer.scale)
+    b.set_input_channel_scale(s)
+    assert b.weight_quantizer._has_grid() and float(b.weight_quantizer.scale) == stepped
+    # (3) loaded into the existing tensors: kept
+    c, src = make(), make()
+    with torch.no_grad():
+        c(x)
+        src(x)
+        src.weight_quantizer.scale.mul_(0.5)
+    c.load_state_dict(src.state_dict())
+    loaded = float(c.weight_quantizer.scale)
+    assert loaded == float(src.weight_quantizer.scale)
+    c.set_input_channel_scale(s)
+    assert c.weight_quantizer._has_grid() and float(c.weight_quantizer.scale) == loaded
+
+
+def test_dynamic_activation_quantizers_run_on_the_integer_kernels(dev):
+    """`is_dynamic` activation quantizers (qmodule.py:262-277; ptq/mobilequant.py:50,166,205) used to send the whole
+    QLinear to the simulated path.  Now: a dynamic INPUT grid is min / max -> scale / offset on the device (mq_minmax_tensor ->
+    mq_scale_offset_from_minmax, no host read-back) and the quantize / GEMM kernels take it by pointer; a dynamic OUTPUT grid needs the
+    output's own range, so the integer GEMM returns fp32 values and the HIP Quantizer follows (the reference's order, qmodule.py:353-357).
+    Against the reference's frozen outputs (tests/golden/qlinear_dynamic_cases.npz): every element within one output LSB, > 99.5 %
+    (8-bit) / > 90 % (16-bit) identical -- and int8_coverage() must show the integer path was taken, not the fallback."""
+    import mobilequant_amd as mq
+    from conftest import load_meta, load_npz
+    z = load_npz("qlinear_dynamic_cases.npz")
+    T = lambda a: torch.from_numpy(a).to(dev)       # noqa: E731
+    for m in load_meta(z):
+        k = m["id"]
+        lin = torch.nn.Linear(m["K"], m["N"], bias=m["bias"]).to(dev)
+        with torch.no_grad():
+            lin.weight.copy_(T(z[k + "_w"]))
+            if m["bias"]:
+                lin.bias.copy_(T(z[k + "_b"]))
+        ql = mq.QLinear.from_float(lin, mq.QuantConfig(bitwidth=8, is_dynamic=m["in_dyn"]), mq.QuantConfig(bitwidth=8, is_per_channel=m["wpc"]),
+                                   mq.QuantConfig(bitwidth=m["out_bits"], is_dynamic=m["out_dyn"])).requires_grad_(False)
+        if "input" in m["act"]:
+            ql.input_quantizer.set_scale_offset_from_minmax(*m["act"]["input"], "buffer", dev)
+        if "output" in m["act"]:
+            ql.output_quantizer.set_scale_offset_from_minmax(*m["act"]["output"], "buffer", dev)
+        x = T(z[k + "_x"])
+        with torch.no_grad():
+            assert ql._int8_reason(x, ql.weight) is None, (m["tag"], ql._int8_reason(x, ql.weight))
+            y = ql(x)
+            y2 = ql(x * 0.5)                      # a second call re-derives the dynamic grids from ITS tensor
+        cov = mq.int8_coverage(ql)
+        assert cov["simulated_calls"] == 0 and cov["int8_calls"] == 2, (m["tag"], cov["summary"])
+        lsb = float(z[k + "_oscale"])
+        d = np.abs(y.cpu().numpy() - z[k + "_y"])
+        # a dynamic OUTPUT grid is derived from this implementation's own fp32 outputs: its scale may differ from the reference's in the
+        # last bit, so "identical" means the same index on a grid that agrees to fp32 rounding (1e-6 of the value range), not equal bits
+        same = d <= (1e-6 * float(np.abs(z[k + "_y"]).max()) if m["out_dyn"] else 0.0)
+        assert d.max() <= lsb * 1.01, (m["tag"], d.max(), lsb)
+        assert same.mean() > (0.995 if m["out_bits"] == 8 else 0.90), (m["tag"], same.mean())
+        if m["in_dyn"] and m["out_dyn"] and not m["bias"]:
+            # both grids scale with the tensor: the half-scale call gives half the values (power-of-two scaling is exact in fp32)
+            assert torch.allclose(y2, 0.5 * y, rtol=0, atol=0.51 * 0.5 * lsb), m["tag"]
+        # the simulated path of the same module (int8_mode off) agrees within the same bars, and is what coverage reports then
+        ql.int8_mode = "off"
+        with torch.no_grad():
+            ys = ql(x)
+        cov = mq.int8_coverage(ql, reset=True)
+        assert cov["simulated_calls"] == 1 and "int8_mode off" in cov["summary"], cov["summary"]
+        ds = (ys - y).abs()
+        tol = 1e-6 * float(y.abs().max()) if m["out_dyn"] else 0.0
+        assert float(ds.max()) <= lsb * 1.01 and float((ds <= tol).float().mean()) > (0.99 if m["out_bits"] == 8 else 0.85), m["tag"]
+
+
+def test_int8_coverage_names_the_modules_that_fell_back_and_why(dev):
+    """VERDICT r03 "What's weak" 10: an evaluation can land on the simulated path (HIP fake-quant + fp32 library GEMM, ~10x slower)
+    without anyone noticing.  int8_coverage(model) lists, per QLinear, how often each path ran and the reason for every fallback."""
+    import mobilequant_amd as mq
+    a8 = mq.QuantConfig(bitwidth=8)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            mk = lambda k, n, w: mq.QLinear.from_float(torch.nn.Linear(k, n, bias=False).to(dev), a8, w, a8)      # noqa: E731
+            self.ok = mk(128, 64, mq.QuantConfig(bitwidth=8))
+            self.group = mk(128, 64, mq.QuantConfig(bitwidth=4, is_per_channel=True, group_size=32))
+            self.odd = mk(96, 64, mq.QuantConfig(bitwidth=8))
+
+        def forward(self, x):
+            return self.ok(x) + self.group(x), self.odd(x[..., :96].contiguous())
+    net = Net().requires_grad_(False)
+    for m in (net.ok, net.group, net.odd):
+        m.set_scale_offset({"input": [-4.0, 4.0], "output": [-3.0, 3.0]}, "buffer")
+    x = torch.randn(2, 16, 128, device=dev)
+    with torch.no_grad():
+        net(x)
+        net(x)
+    cov = mq.int8_coverage(net)
+    assert cov["int8_calls"] == 2 and cov["simulated_calls"] == 4 and cov["simulated_modules"] == ["group", "odd"], cov
+    assert "per-group weight grid" in cov["summary"] and "outside mq_w8a8_linear's limits" in cov["summary"], cov["summary"]
+    assert mq.int8_coverage(net, reset=True)["int8_calls"] == 2 and mq.int8_coverage(net)["int8_calls"] == 0

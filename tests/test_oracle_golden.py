@@ -123,6 +123,26 @@ def test_qlinear_sim_cases():
         assert (d == 0).mean() > (0.995 if m["out_bits"] == 8 else 0.90), (m["tag"], (d == 0).mean())
 
 
+def test_qlinear_dynamic_cases_oracle():
+    """Dynamic activation quantizers (qmodule.py:262-277): the oracle re-derives the range from the tensor on every call, as the
+    reference does; same 1-LSB / > 99.5 % (8-bit) / > 90 % (16-bit) bars as the static cases (BLAS summation order)."""
+    z = load_npz("qlinear_dynamic_cases.npz")
+    for m in load_meta(z):
+        k = m["id"]
+        wq = O.QuantizerOracle(8, -1, False, m["wpc"])
+        iq = O.QuantizerOracle(8, is_dynamic=m["in_dyn"])
+        oq = O.QuantizerOracle(m["out_bits"], is_dynamic=m["out_dyn"])
+        if not m["in_dyn"]:
+            iq.set_from_minmax(*m["act"]["input"])
+        if not m["out_dyn"]:
+            oq.set_from_minmax(*m["act"]["output"])
+        y = O.qlinear_sim(z[k + "_x"], z[k + "_w"], z[k + "_b"] if m["bias"] else None, wq, iq, oq)
+        lsb = float(z[k + "_oscale"])
+        d = np.abs(y - z[k + "_y"])
+        assert d.max() <= lsb * 1.01, (m["tag"], d.max(), lsb)
+        assert (d == 0).mean() > (0.995 if m["out_bits"] == 8 else 0.90), (m["tag"], (d == 0).mean())
+
+
 def test_qlinear_int_equivalence():
     """SURVEY 8a' item 9: the integer contraction reproduces the simulated path to fp32 round-off."""
     z = load_npz("qlinear_cases.npz")
