@@ -299,6 +299,30 @@ def event_time(fn, iters):
     return best * 1e-3
 
 
+def sustained_clock(fn, dev, launches=40):
+    """Shader clock sustained inside mq::gemm_i8_fr_kernel during a graph of `launches` back-to-back launches of `fn`: every wave stores
+    [s_memtime cycles, s_memrealtime 100-MHz ticks] of its generated program (include/mobilequant_amd_tuning.h: mq_gemm_set_clock_probe);
+    clock = 100 MHz x sum(cycles) / sum(ticks) over the 2 048 waves of the last launch; also per XCD (workgroup b runs on XCD b % 8).
+    None when the probe is not in the library or the launch is not the generated kernel."""
+    import mobilequant_amd._lib as L
+    lib = L.load()
+    if not hasattr(lib, "mq_gemm_set_clock_probe"):
+        return None
+    buf = torch.zeros(256 * 8 * 2, dtype=torch.int32, device=dev)
+    lib.mq_gemm_set_clock_probe(buf.data_ptr())
+    try:
+        event_time(fn, launches)
+    finally:
+        lib.mq_gemm_set_clock_probe(None)
+    d = buf.cpu().numpy().astype(np.int64).reshape(256, 8, 2)
+    if not d[..., 1].all():
+        return None
+    mhz = 100.0 * d[..., 0].sum() / d[..., 1].sum()
+    xcd = [100.0 * d[x::8, :, 0].sum() / d[x::8, :, 1].sum() for x in range(8)]
+    return {"mhz": round(float(mhz), 1), "xcd": [round(float(min(xcd)), 1), round(float(max(xcd)), 1)],
+            "cycles_per_wave": round(float(d[..., 0].mean()), 1)}
+
+
 def cold_time(fn, flush_bytes=768 << 20, reps=10):
     """Average duration of `fn` with the operand caches flushed in front of every launch (the L2-flushing variant): a
     768 MiB fill (3x the 256 MB Infinity Cache, far beyond the 8 x 4 MB L2s) precedes each launch inside one hipGraph; the same graph
@@ -1120,11 +1144,13 @@ def main():
             t_quant = event_time(lambda: step.quantize(0), 50)
             achieved = OPS_PER_STEP / t_gemm / 1e12
             t_cold = cold_time(step.gemm)
+            clock = sustained_clock(step.gemm, dev)
             # the same launch on zero-filled operands: the chip clocks to the load, so this is the binary's time at
             # the clock an idle datapath sustains -- the gap to avg_launch_us is power / clock, not schedule
             keep_a, keep_w = step.a8s[0].clone(), step.w8.clone()
             step.a8s[0].zero_(); step.w8.zero_()
             t_zero = event_time(step.gemm, 50)
+            clock_zero = sustained_clock(step.gemm, dev)
             step.a8s[0].copy_(keep_a); step.w8.copy_(keep_w)
             del keep_a, keep_w
             traffic, traffic_src = pmc_traffic()
@@ -1132,16 +1158,24 @@ def main():
                                                 "activations)" if step.tiled else "mq::gemm_i8_kernel (mq_w8a8_linear)"), "achieved": round(achieved, 1),
                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOPS", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
                     "avg_launch_us": round(t_gemm * 1e6, 2),
+                    # the clock the chip SUSTAINED inside this kernel, read by the kernel itself (s_memtime cycles / s_memrealtime ticks of
+                    # every wave, mq_gemm_set_clock_probe): the dense peak is quoted at 2.4 GHz, the chip clocks to its power budget
+                    "sustained_mhz": clock and clock["mhz"], "sustained_mhz_xcd_min_max": clock and clock["xcd"],
+                    "frac_clock_adjusted": clock and round(achieved / (INT8_MFMA_PEAK_TOPS * clock["mhz"] / 2400.0), 4),
+                    "clock_note": "frac_clock_adjusted = achieved / (peak x sustained_mhz / 2400): what the schedule reaches of the MFMA rate at "
+                                  "the clock the silicon holds under this data; frac (against the nominal 2.4 GHz peak) is the headline figure",
                     "cold_caches": {"avg_launch_us": round(t_cold * 1e6, 2), "frac": round(OPS_PER_STEP / t_cold / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
                                     "how": "768 MiB fill in front of every launch in one hipGraph, minus the same graph without the GEMM"},
                     "zero_filled_operands": {"avg_launch_us": round(t_zero * 1e6, 2), "frac": round(OPS_PER_STEP / t_zero / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                             "sustained_mhz": clock_zero and clock_zero["mhz"],
                                              "how": "the same launch with all-zero int8 operands (no data-dependent switching power)"},
                     "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": M * K + N * K + M * N,
                     "algorithmic_ops_per_launch": OPS_PER_STEP,
-                    "notes": "MFMA busy 22 528 cycles per SIMD of ~31 k wave cycles; the chip clocks ~1.8 GHz under this load (s_memtime / "
-                             "s_memrealtime inside the kernel, profiles/r02) and ~5 us of each launch period lie outside the waves' "
-                             "lifetime (dispatch + end-of-kernel release): DESIGN.md 4.2",
+                    "cycles_per_wave": clock and clock["cycles_per_wave"],
+                    "notes": "MFMA busy 22 528 cycles per SIMD of cycles_per_wave (the program's own s_memtime span; two waves share a SIMD); "
+                             "~2.5 us of each launch period lie outside the waves' lifetime (kernel boundary 1.2 us + write-back of the "
+                             "11.5 MB of outputs): DESIGN.md 4.2, profiles/r04",
                     "quantize_kernel": {"bound": "hbm", "avg_launch_us": round(t_quant * 1e6, 2),
                                         "achieved_GBps": round((M * K * 5 + M * 4) / t_quant / 1e9, 1), "peak_GBps": 8000.0}}
             if pipelined:

@@ -18,6 +18,12 @@ const char* mq_gemm_variant_name(int variant);
  * first stage, 2 = no MFMA loop, 4 = no epilogue, 16 = s_memtime stamps.  0 = normal operation; ignored by production
  * builds. */
 int mq_gemm_set_debug(int flags);
+/* Clock probe of the headline GEMM kernel (mq::gemm_i8_fr_kernel): with a device buffer of (workgroups x 8) x 8 bytes set, lane 0 of
+ * every wave stores [uint32 shader-clock cycles (s_memtime), uint32 ticks of the constant 100-MHz counter (s_memrealtime)] spent inside
+ * the generated program; sum(cycles) / sum(ticks) x 100 MHz is the clock the chip SUSTAINED under this launch (it clocks to its power
+ * budget: random int8 operands ~1.75 GHz, zero-filled ~2.1 GHz of the nominal 2.4).  NULL (default) = no stores; the two counter reads
+ * per wave stay in the kernel either way.  Pair launches share the buffer (second problem's workgroups write behind the first's). */
+int mq_gemm_set_clock_probe(void* buf);
 /* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
 /* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */

@@ -802,6 +802,10 @@ __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, i
   const int xorv = __builtin_amdgcn_readfirstlane(args.out_dtype == MQ_I8 ? (int)0x80808080u : 0);
   const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
   const unsigned tid = threadIdx.x;
+#if MQ_FR_ASM_PROBE
+  // clock probe (mq_gemm_set_clock_probe): 8 bytes per wave = [shader cycles, 100-MHz real-time ticks] of the generated program
+  unsigned long long* dbg = args.dbg_ts ? args.dbg_ts + ((size_t)bid * 8 + wave) : nullptr;
+#endif
 #if MQ_FR_ASM_STAMP
   unsigned long long* dbg = args.dbg_ts + ((size_t)bid * 8 + wave) * 16;
   const int te_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)t_entry), te_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(t_entry >> 32));
@@ -813,6 +817,9 @@ __device__ __forceinline__ void gemm_i8_fr_body(const GemmArgs& args, int bid, i
                  [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [xorv] "s"(xorv),
 #if MQ_FR_ASM_STAMP
                  [dbg] "s"(dbg), [tentry_lo] "s"(te_lo), [tentry_hi] "s"(te_hi),
+#endif
+#if MQ_FR_ASM_PROBE
+                 [dbg] "s"(dbg),
 #endif
                  [sw0] "v"(sw[0]), [sw1] "v"(sw[1]), [sw2] "v"(sw[2]), [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid),
                  [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
@@ -1313,6 +1320,11 @@ extern "C" {
 int mq_gemm_set_variant(int variant) {
   g_forced_variant = (variant >= 0 && variant < kNumVariants) ? variant : -1;
   return kNumVariants;
+}
+
+int mq_gemm_set_clock_probe(void* buf) {
+  g_dbg_ts = reinterpret_cast<unsigned long long*>(buf);
+  return 0;
 }
 
 int mq_gemm_set_debug(int flags) {

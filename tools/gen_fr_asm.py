@@ -417,6 +417,7 @@ def stage_pre_final(q, lq, t, nw):
     assert not fill
 
 
+PROBE = False      # set per variant in main(): the headline kernel ("fr") always stamps its start / end clocks and stores them when asked
 DINIT = os.environ.get("MQ_FR_DINIT", "1") != "0"       # deferred accumulator initialisation (round 4); 0 = in the prologue
 PRO_SPLIT = bool(os.environ.get("MQ_FR_PRO_SPLIT"))
 PSTAMP = bool(os.environ.get("MQ_FR_PSTAMP"))      # stamp build: five more s_memtime stamps inside the prologue (dbg slots 8..12)
@@ -604,6 +605,28 @@ def final_block(q, lq, stamp):
             emit("v_mov_b32 v1, s101")
             emit(f"global_store_dwordx2 v{V_TMP}, v[0:1], %[dbg] offset:56")
         emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    if PROBE and not stamp:
+        # the probe's end: both counters, and -- only when a probe buffer is set -- lane 0 of every wave stores [cycles, real-time ticks]
+        lskip = label("np")
+        emit(f"s_memtime s[{S_TS + 6}:{S_TS + 7}]")
+        emit(f"s_memrealtime s[{S_RT + 2}:{S_RT + 3}]")
+        emit("s_cmp_eq_u64 %[dbg], 0")
+        emit(f"s_cbranch_scc1 {lskip}")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit(f"s_sub_u32 s{S_TS + 6}, s{S_TS + 6}, s{S_TS}")
+        emit(f"s_subb_u32 s{S_TS + 7}, s{S_TS + 7}, s{S_TS + 1}")
+        emit(f"s_sub_u32 s{S_RT + 2}, s{S_RT + 2}, s{S_RT}")
+        emit(f"s_subb_u32 s{S_RT + 3}, s{S_RT + 3}, s{S_RT + 1}")
+        emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")
+        emit(f"v_cmp_eq_u32 vcc, 0, v{V_TMP}")
+        emit("s_and_b64 exec, exec, vcc")
+        emit(f"v_mov_b32 v{V_TMP}, 0")
+        emit(f"v_mov_b32 v{V_LDSG}, s{S_TS + 6}")
+        emit(f"v_mov_b32 v{V_GOG}, s{S_RT + 2}")
+        emit(f"global_store_dword v{V_TMP}, v{V_LDSG}, %[dbg]")
+        emit(f"global_store_dword v{V_TMP}, v{V_GOG}, %[dbg] offset:4")
+        emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+        emit(f"{lskip}:")
     emit("s_waitcnt vmcnt(0)")
 
 
@@ -614,6 +637,11 @@ def prologue(q, nw, stamp):
         emit(f"s_memtime s[{S_TS}:{S_TS + 1}]")
         emit(f"s_memrealtime s[{S_RT}:{S_RT + 1}]")
         emit("s_waitcnt lgkmcnt(0)")
+    elif PROBE:
+        # clock probe (mq_gemm_set_clock_probe): shader-clock and 100-MHz real-time counters at the program's start; they return with the
+        # output grid's scalar loads (waited for in step 3, before any counted LDS wait)
+        emit(f"s_memtime s[{S_TS}:{S_TS + 1}]")
+        emit(f"s_memrealtime s[{S_RT}:{S_RT + 1}]")
     # the output grid lives in device memory (no host read-back): both scalar loads leave before anything else and are waited for in
     # step (3), behind the first stages' requests -- never in front of them (round 4: the C++ preamble used to dereference and divide
     # BEFORE the first LDS-DMA could be issued: two dependent cold scalar loads ahead of every launch's first byte)
@@ -1233,6 +1261,8 @@ def main(path=None, variant="fr"):
     del out[:]
     _uid[0] = 0
     stamp = bool(os.environ.get("MQ_FR_STAMP")) and variant == "fr"
+    global PROBE
+    PROBE = variant == "fr" and TAIL
     generate(stamp)
     here = os.path.dirname(os.path.abspath(__file__))
     path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", FILE)
@@ -1244,6 +1274,7 @@ def main(path=None, variant="fr"):
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")
         f.write(f"#define {PREFIX}_ASM_STAMP {1 if stamp else 0}\n")
+        f.write(f"#define {PREFIX}_ASM_PROBE {1 if PROBE and not stamp else 0}\n")
         f.write(f"#define {PREFIX}_LDS_BYTES {LDS_BYTES}\n")
         f.write(f"#define {PREFIX}_ASM_BODY \\\n")
         for line in out:
