@@ -444,6 +444,20 @@ int mq_w8a8_linear_tiled_segmented(const int8_t* a_tiled, const int8_t* w, int64
                                    const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
                                    const int64_t* seg_end, const mq_grid* grids, uint8_t* out, mq_stream_t stream);
 
+/* Packed 4-bit weights on the PRODUCTION prefill path (round 4; BASELINE.json configs[3]: "packed 4-bit weights, in-register unpack ->
+ * MFMA_I32_16x16x64_I8"): QLinear.forward with a 4-bit weight quantizer (qmodule.py:341-358 under the W4A8 recipes,
+ * experiments/w4a8/main/e2e_gemma-s1024-ep60-sym.sh:17-23) on fragment-blocked activations (mq_quantize_tiled) and the mq_pack_w4 image
+ * [N, K/2] -- the SAME image the decode kernels stream.  Whole-kernel generated gfx950 ISA (tools/gen_fr_asm.py: frw4 / frw4_128): the
+ * packed rows go through the LDS ring by LDS-DMA, one ds_read_b128 per 16 output columns and K = 128 stage, nibbles split with v_and /
+ * v_lshrrev under the MFMAs.  1..3 column segments with their own 8-bit unsigned output grids (n_segments = 1: seg_end may be NULL);
+ * out = uint8 indices (MQ_U8) or index - 128 (MQ_I8), [M, N] row-major; w_zp / col_term in the unsigned-nibble domain as for
+ * mq_w4a8_linear.  Shapes: mq_gemm_tiled_w4_supported (N % 176 == 0, or N % 128 == 0 -- required for more than one segment; K % 256 == 0,
+ * K >= 768).  Indices are exactly those of mq_w4a8_linear / mq_w4a8_linear_segmented. */
+int mq_gemm_tiled_w4_supported(int64_t M, int64_t N, int64_t K);
+int mq_w4a8_linear_tiled(const int8_t* a_tiled, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                         const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                         const int64_t* seg_end, const mq_grid* grids, void* out, int out_dtype, mq_stream_t stream);
+
 typedef struct mq_attention_args {
   const float* q;
   const float* k;

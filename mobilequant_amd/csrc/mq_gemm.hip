@@ -35,6 +35,8 @@
 #include "mq_gemm_fr160_asm.inc"
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
+#include "mq_gemm_frw4_asm.inc"
+#include "mq_gemm_frw4_128_asm.inc"
 
 namespace mq {
 
@@ -965,6 +967,118 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
   return MQ_OK;
 }
 
+// ---- packed 4-bit weights on the free-running program (tools/gen_fr_asm.py variants frw4 / frw4_128, round 4) --------------------------
+// mq_pack_w4's image (two unsigned nibbles per byte; 16 bytes = 32 consecutive k, element p low / p + 16 high in byte p) goes through the
+// LDS ring as it is (LDS-DMA pieces of 16 rows x 64 B); a lane's single ds_read_b128 per 16 columns and stage holds both of its MFMA
+// operands of that stage, split in registers.  The activation fragments are gathered to match (type A = k 32 q + 0..15, type B = + 16..31
+// of the stage: per-lane offsets below).  256 x BNT tiles, eight waves, 8-bit unsigned output grid (BNT = 176: one grid; 128: per column).
+template <int BNT>
+__global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) {
+  constexpr int FNT = BNT / 16;
+  constexpr int PCS = (FNT + 7) / 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * BNT;
+  const int M = args.M, N = args.N, K = args.K;
+  const int KT = K / BK;
+  unsigned sw[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    const int r = lane >> 2;                                   // row of the piece (16 rows x 64 B)
+    int piece = wave + i * 8;
+    piece = piece < FNT ? piece : FNT - 1;
+    int row = n0 + piece * 16 + r;
+    row = row < N ? row : N - 1;
+    const int g = (4 - ((r >> 2) & 3)) & 3;                    // {0, 3, 2, 1}[(r >> 2) & 3]
+    sw[i] = (unsigned)row * (unsigned)(K >> 1) + (unsigned)((((lane & 3) ^ g)) << 4);
+  }
+  const int m0w = m0 + wave * 32;
+  const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+  unsigned rb0 = (unsigned)(m0w >> 4), rb1 = rb0 + 1;
+  rb0 = rb0 < rb_max ? rb0 : rb_max;
+  rb1 = rb1 < rb_max ? rb1 : rb_max;
+  // type-A fragment of lane (frow, kq): x[row, 128 s + 32 kq + 0..15] = k block 2 s + (kq >> 1), quarter 2 (kq & 1); type B: + 256 bytes
+  const unsigned frow = (unsigned)lane & 15u, kq = (unsigned)lane >> 4;
+  const unsigned lofs = (kq >> 1) * 1024u + ((2u * (kq & 1u)) * 16u + frow) * 16u;
+  const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + lofs;
+  const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + lofs;
+  unsigned rsofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0w + i * 16 + (lane & 15);
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
+    rsofs[i] = (unsigned)m * 4u;
+  }
+  const int8_t* a_ptr = args.a;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  const float* alpha_p = args.alpha + n0;
+  const float* bias_p = args.bias + n0;
+  const int32_t* wzp_p = args.w_zp + n0;
+  const int32_t* ct_p = args.col_term + n0;
+  const int32_t* rs_p = args.a_rowsum;
+  uint8_t* outw = reinterpret_cast<uint8_t*>(args.out) + (size_t)m0w * N + n0;
+  const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int xorv = __builtin_amdgcn_readfirstlane(args.out_dtype == MQ_I8 ? (int)0x80808080u : 0);
+  const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
+  const unsigned tid = threadIdx.x;
+#define MQ_FRW4_OPERANDS                                                                                                          \
+  [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [alpha] "s"(alpha_p), [bias] "s"(bias_p),  \
+      [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [xorv] "s"(xorv),   \
+      [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
+  if constexpr (BNT == 176) {
+    const float* so_ptr = args.out_scale;
+    const float* oo_ptr = args.out_offset;
+    asm volatile(MQ_FRW4_ASM_BODY
+                 : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
+                 : MQ_FRW4_OPERANDS, [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr)
+                 : MQ_FRW4_ASM_CLOBBERS);
+  } else {
+    const int n = n0 + (int)(tid < (unsigned)BNT ? tid : (unsigned)BNT - 1u);
+    float sc = args.out_scale[0], ooc = args.out_offset[0];
+    if (args.seg_scale[0] != nullptr) {
+      const int sg = (n >= args.seg_end[0]) + (args.seg_scale[1] != nullptr && n >= args.seg_end[1]);
+      if (sg > 0) {
+        sc = args.seg_scale[sg - 1][0];
+        ooc = args.seg_offset[sg - 1][0];
+      }
+    }
+    const float invc = __fdiv_rn(1.0f, sc);
+    asm volatile(MQ_FRW4_128_ASM_BODY
+                 : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
+                 : MQ_FRW4_OPERANDS, [invc] "v"(invc), [ooc] "v"(ooc)
+                 : MQ_FRW4_128_ASM_CLOBBERS);
+  }
+#undef MQ_FRW4_OPERANDS
+}
+
+static bool gemm_frw4_shape(int64_t M, int64_t N, int64_t K) { return M > 0 && (N % 176 == 0 || N % 128 == 0) && K % 256 == 0 && K >= 768; }
+
+template <int BNT>
+static int launch_frw4(GemmArgs a, hipStream_t st) {
+  constexpr int LDS = BNT == 176 ? MQ_FRW4_LDS_BYTES : MQ_FRW4_128_LDS_BYTES;
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frw4_kernel<BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  a.has_rowsum = a.a_rowsum != nullptr;
+  if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;
+  if (a.bias == nullptr) a.bias = a.alpha;
+  a.grid_m = (a.M + 255) / 256;
+  a.grid_n = a.N / BNT;
+  gemm_i8_frw4_kernel<BNT><<<a.grid_m * a.grid_n, 512, LDS, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
+}
+
 // ---- w3 of a gated FFN with the gate in its epilogue (tools/gen_fr_asm.py variant frg) ------------------------------------------------
 // The free-running 256 x 176 program; its epilogue turns the tile's 8-bit output indices and w1's (gate_aidx, written by the launch
 // before) into w2's int8 input image through the LDS-resident 64-KiB gated table: no index tensor of w3, no lookup launch.
@@ -1446,6 +1560,43 @@ int mq_w8a8_linear_tiled(const int8_t* a_tiled, const int8_t* w, int64_t M, int6
   GemmArgs g{a_tiled, w, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
              out_qmin, out_qmax, out, out_dtype, 0, 0, bias != nullptr, 1, 0, g_dbg_ts};
   return run_gemm<false>(g, as_stream(stream));
+}
+
+int mq_gemm_tiled_w4_supported(int64_t M, int64_t N, int64_t K) { return gemm_frw4_shape(M, N, K) ? 1 : 0; }
+
+int mq_w4a8_linear_tiled(const int8_t* a_tiled, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                         const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias, int n_segments,
+                         const int64_t* seg_end, const mq_grid* grids, void* out, int out_dtype, mq_stream_t stream) {
+  const char* fn = "mq_w4a8_linear_tiled";
+  MQ_REQUIRE(n_segments >= 1 && n_segments <= 3 && grids != nullptr && (n_segments == 1 || seg_end != nullptr), "%s: 1..3 segments", fn);
+  int rc = check_common(fn, a_tiled, w_packed, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset, out, 2);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32), "%s: activation too large", fn);
+  MQ_REQUIRE(out_dtype == MQ_U8 || out_dtype == MQ_I8, "%s: u8 (indices) or i8 (index - 128) output", fn);
+  int64_t prev = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    MQ_REQUIRE(grids[i].scale && grids[i].offset && grids[i].qmin == 0.f && grids[i].qmax == 255.f,
+               "%s: segment %d needs an 8-bit unsigned output grid", fn, i);
+    if (n_segments > 1) {
+      MQ_REQUIRE(seg_end[i] > prev && seg_end[i] <= N && seg_end[i] % 4 == 0, "%s: segment ends must increase, be multiples of 4, <= N", fn);
+      prev = seg_end[i];
+    }
+  }
+  MQ_REQUIRE(n_segments == 1 || prev == N, "%s: the last segment must end at N", fn);
+  if (!gemm_frw4_shape(M, N, K) || (n_segments > 1 && N % 128 != 0)) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled_w4_supported: N %% 176 == 0 or N %% 128 == 0 (segments: 128), K %% 256 == 0, "
+              "K >= 768)", fn, (long long)M, (long long)N, (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  GemmArgs g{a_tiled, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, grids[0].scale, grids[0].offset,
+             0.f, 255.f, out, out_dtype, 0, 0, bias != nullptr, 1, 0, g_dbg_ts, nullptr, {0, 0}, {nullptr, nullptr}, {nullptr, nullptr}};
+  for (int i = 1; i < n_segments; ++i) {
+    g.seg_end[i - 1] = (int)seg_end[i - 1];
+    g.seg_scale[i - 1] = grids[i].scale;
+    g.seg_offset[i - 1] = grids[i].offset;
+  }
+  if (n_segments == 1 && N % 176 == 0) return launch_frw4<176>(g, as_stream(stream));
+  return launch_frw4<128>(g, as_stream(stream));
 }
 
 int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,

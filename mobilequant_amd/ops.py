@@ -302,6 +302,36 @@ def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.
     return out
 
 
+def gemm_tiled_w4_supported(M: int, N: int, K: int) -> bool:
+    """Shapes served by the packed-4-bit generated kernels on fragment-blocked activations (mq_w4a8_linear_tiled)."""
+    return bool(_lib.load().mq_gemm_tiled_w4_supported(int(M), int(N), int(K)))
+
+
+def w4a8_linear_tiled(a_tiled: torch.Tensor, M: int, w_packed: torch.Tensor, a_rowsum: Optional[torch.Tensor], alpha: torch.Tensor,
+                      w_zp: torch.Tensor, col_term: torch.Tensor, bias: Optional[torch.Tensor], grids, seg_ends=None,
+                      out_dtype: int = MQ_U8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Packed 4-bit weights [N, K/2] (pack_w4) x fragment-blocked int8 activations (quantize_tiled, M rows) on the generated-ISA kernels
+    (mq_w4a8_linear_tiled): 8-bit unsigned output grid(s) -> uint8 indices (or int8 = index - 128) [M, N].  grids: [(scale, offset)] per
+    column segment; seg_ends: cumulative column ends when there is more than one."""
+    _dev(a_tiled, "a_tiled"); _dev(w_packed, "w_packed")
+    N, K = int(w_packed.shape[0]), 2 * int(w_packed.shape[1])
+    n = len(grids)
+    if out is None:
+        out = torch.empty((int(M), N), dtype=_OUT_TORCH[out_dtype], device=a_tiled.device)
+    b = _f32(bias, "bias") if bias is not None else None
+    ends = (ctypes.c_int64 * n)(*[int(e) for e in (seg_ends if seg_ends is not None else [N])])
+    keep, gs = [], (_lib.MqGrid * n)()
+    for i, g in enumerate(grids):
+        sc, of = _f32(g[0], "scale"), _f32(g[1], "offset")
+        keep += [sc, of]
+        gs[i] = _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0)
+    with _on(a_tiled, w_packed, a_rowsum, alpha, w_zp, col_term, b, out, *keep):
+        _lib.call("mq_w4a8_linear_tiled", a_tiled.data_ptr(), w_packed.data_ptr(), int(M), N, K,
+                  a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
+                  b.data_ptr() if b is not None else None, n, ends, gs, out.data_ptr(), out_dtype, _stream())
+    return out
+
+
 def gemm_tiled128_supported(M: int, N: int, K: int) -> bool:
     """Shapes served by the 128-column generated kernels on fragment-blocked activations (o_proj / w2 with the residual, q | k | v)."""
     return bool(_lib.load().mq_gemm_tiled128_supported(int(M), int(N), int(K)))

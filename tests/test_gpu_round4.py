@@ -245,3 +245,68 @@ def test_int8_coverage_names_the_modules_that_fell_back_and_why(dev):
     assert cov["int8_calls"] == 2 and cov["simulated_calls"] == 4 and cov["simulated_modules"] == ["group", "odd"], cov
     assert "per-group weight grid" in cov["summary"] and "outside mq_w8a8_linear's limits" in cov["summary"], cov["summary"]
     assert mq.int8_coverage(net, reset=True)["int8_calls"] == 2 and mq.int8_coverage(net)["int8_calls"] == 0
+
+
+@pytest.mark.parametrize("M,N,K,per_row,with_bias,segs", [
+    (2048, 5632, 2048, True, False, None),        # TinyLlama w1 / w3 under the W4A8 recipe: 256 x 176 tiles (frw4)
+    (2000, 5632, 768, True, True, None),          # ragged M, the shortest K (KT = 6)
+    (2048, 16384, 2048, True, False, None),       # Gemma-2B w1 / w3 (BASELINE.json configs[3]): 256 x 128 tiles (frw4_128)
+    (2048, 2560, 2048, True, True, (2048, 2304, 2560)),     # q | k | v as one segmented GEMM, three output grids
+    (1024, 2048, 5632, False, False, None),       # long K (44 stages), per-tensor 4-bit grid
+])
+def test_packed_w4_generated_isa_gemm_vs_exact_oracle_every_output(dev, M, N, K, per_row, with_bias, segs):
+    """VERDICT r03 item 3 / BASELINE.json configs[3]: packed 4-bit weights on generated ISA (mq_w4a8_linear_tiled: LDS-DMA of the
+    mq_pack_w4 image, one ds_read_b128 per 16 columns and stage, nibbles split in registers under MFMA_I32_16x16x64_I8).  The kernel
+    consumes a numpy-built packed image (oracle.pack_w4: the documented layout, NOT the pack kernel) and a numpy-built fragment-blocked
+    activation image; EVERY output index is compared with the exact integer oracle, and with what the C++ tile kernel (mq_w4a8_linear)
+    writes from the same operands."""
+    from oracle import mq_oracle as O
+    from test_gpu_round2 import T, exact_u8, tiled_image
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_I8, MQ_U8
+    F32 = np.float32
+    assert ops.gemm_tiled_w4_supported(M, N, K)
+    rng = np.random.default_rng(M + N + K)
+    qa = rng.integers(0, 256, size=(M, K))
+    qw = rng.integers(0, 16, size=(N, K))                       # unsigned nibbles (index - qmin)
+    za = int(rng.integers(0, 256))
+    zw = rng.integers(0, 16, size=N) if per_row else np.full(N, int(rng.integers(0, 16)))
+    sa = F32(0.02)
+    sw = (rng.random(N, dtype=F32) * F32(1e-2) + F32(1e-3)) if per_row else np.full(N, F32(7e-3), F32)
+    bias = rng.standard_normal(N, dtype=F32) if with_bias else None
+    a8 = (qa - 128).astype(np.int8)
+    a_t = T(tiled_image(a8), dev)
+    packed = T(O.pack_w4(qw, 0), dev)
+    rs = T(a8.sum(1).astype(np.int32), dev)
+    colsum = T(qw.sum(1).astype(np.int32), dev)
+    wsc = T(sw, dev) if per_row else T(sw[:1], dev)
+    wof = T(zw.astype(F32), dev) if per_row else T(zw[:1].astype(F32), dev)
+    alpha, wzp, ct = ops.linear_epilogue_prepare(T(np.array([sa], F32), dev), T(np.array([za], F32), dev), 128, wsc, wof, 0, colsum, K)
+    b = T(bias, dev) if bias is not None else None
+    acc, pre = O.qlinear_int_exact(qa, za, sa, qw, zw, sw, bias, blas=True)
+    ends = list(segs) if segs else [N]
+    grids, want, exact = [], np.empty((M, N), np.uint8), np.empty((M, N))
+    lo = 0
+    for i, hi in enumerate(ends):
+        p = pre[:, lo:hi]
+        so = F32((np.percentile(p, 99.5) - np.percentile(p, 0.5)) / 255.0 * (1.0 + 0.1 * i))
+        oo = F32(np.rint(-np.percentile(p, 0.5) / so))
+        grids.append((torch.tensor([float(so)], device=dev), torch.tensor([float(oo)], device=dev)))
+        want[:, lo:hi], exact[:, lo:hi] = exact_u8(qa, za, sa, qw[lo:hi], zw[lo:hi], sw[lo:hi], None if bias is None else bias[lo:hi], so, oo)
+        lo = hi
+    got = ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, seg_ends=ends if segs else None).cpu().numpy()
+    assert got.shape == (M, N)
+    bad = got != want
+    assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:8].tolist(), got[bad][:8].tolist(), want[bad][:8].tolist())
+    assert np.abs(got.astype(np.float64) - exact).max() <= 1 and (got == exact).mean() > 0.999
+    if not segs:
+        got_i8 = ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, out_dtype=MQ_I8).cpu().numpy()
+        assert np.array_equal(got_i8.astype(np.int16) + 128, want.astype(np.int16))
+        # the C++ tile kernel on the same operands (row-major activations)
+        ref = ops.int8_linear(T(a8, dev), packed, rs, alpha, wzp, ct, b, out_scale=grids[0][0], out_offset=grids[0][1], out_qmin=0.0,
+                              out_qmax=255.0, out_dtype=MQ_U8, w4=True).cpu().numpy()
+        assert np.array_equal(ref, got)
+    # rows past a ragged M are never written
+    canary = torch.full((M + 16, N), 77, dtype=torch.uint8, device=dev)
+    ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, seg_ends=ends if segs else None, out=canary[:M])
+    assert np.array_equal(canary[:M].cpu().numpy(), want) and bool((canary[M:] == 77).all())

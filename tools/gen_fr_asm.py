@@ -48,6 +48,10 @@ VARIANTS = {
     # output) go through the 256 x 256 gated table (64 KiB, LDS-resident) -> w2's int8 input image, fragment-blocked, + row sums
     "frg":     (176, 8, "gate", "MQ_FRG",     "mq_gemm_frg_asm.inc"),
     "frg128":  (128, 8, "gate", "MQ_FRG128",  "mq_gemm_frg128_asm.inc"),     # the same on 256 x 128 tiles (Gemma's FFN: N = 16384)
+    # round 4: PACKED 4-bit weights (mq_pack_w4: two unsigned nibbles per byte) -- LDS-DMA of the packed rows, ONE ds_read_b128 per 16
+    # output columns and K = 128 stage, nibbles split in registers (v_and / v_lshrrev) under the MFMAs (program_w4 below)
+    "frw4":     (176, 8, "u8w4", "MQ_FRW4",    "mq_gemm_frw4_asm.inc"),       # 256 x 176 tiles, one output grid (TinyLlama / StableLM w1, w3)
+    "frw4_128": (128, 8, "u8w4", "MQ_FRW4_128", "mq_gemm_frw4_128_asm.inc"),  # 256 x 128 tiles, per-column grids (q | k | v; Gemma's FFN)
 }
 
 
@@ -55,12 +59,26 @@ def configure(name):
     """binds the module-level tile constants of one variant (the emitters read them at call time)"""
     global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF, RING_BASE, SCALAR_GRID
     BN, NW, EPI, PREFIX, FILE = VARIANTS[name]
-    SCALAR_GRID = (BN == 176 or EPI != "u8")      # ONE output grid per launch (scalars); otherwise per-column grids (q | k | v segments)
+    SCALAR_GRID = (BN == 176 or EPI not in ("u8", "u8w4"))      # ONE output grid per launch (scalars); otherwise per-column grids (q | k | v segments)
     # round 4: the u8 epilogue is interleaved with the MFMAs of the LAST TWO stages (final_block) unless MQ_FR_TAIL=0
     global TAIL
     TAIL = EPI == "u8" and os.environ.get("MQ_FR_TAIL", "1") != "0"
     BM = 32 * NW
     FN = BN // 16
+    global W4
+    W4 = EPI == "u8w4"
+    if W4:
+        EPI = "u8"
+        W_BYTES = BN * BK // 2        # packed: 64 bytes per row and stage
+        RING_BASE = 0
+        PAR = RING * W_BYTES
+        STG = PAR + 16 * BN
+        ROWP, STG_WAVE = BN, 0
+        LDS_BYTES = STG
+        PIECES = (FN + NW - 1) // NW  # W LDS-DMA pieces are 16 rows x 64 B
+        SCALAR_GRID = BN == 176
+        TAIL = True
+        return
     W_BYTES = BN * BK                 # 22528 / 16384
     RING_BASE = 65536 if EPI == "gate" else 0     # gate: the table sits at LDS offset 0 (ds_read_u8 addresses = ia * 256 + ib)
     PAR = RING_BASE + RING * W_BYTES  # alpha' | bias' | -w_zp | col_term
@@ -537,15 +555,17 @@ def final_block(q, lq, stamp):
                 for k in range(4):
                     E(minidx, f"v_xor_b32 v{t + k}, %[xorv], v{t + k}")
             m = S_FM + 2 * i + (4 if last else 0)
-            E(minidx, f"s_mov_b64 exec, s[{m}:{m + 1}]")
             base = "%[outw]" if i == 0 else f"s[{S_OB1}:{S_OB1 + 1}]"
-            def st(i=i, base=base, t=t):
+            def st(i=i, base=base, t=t, m=m):
+                # ONE filler: no MFMA may issue under the store's exec mask (a ragged row block masks lanes off -- all of them when
+                # the block lies past M -- and an MFMA issued under EXEC = 0 is dropped)
+                emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")
                 if STORE_POLICY != "none":
                     pol = STORE_POLICY if g == NG - 1 else os.environ.get("MQ_FR_STORE_EARLY", STORE_POLICY)
                     emit(f"global_store_dwordx4 v{V_GOG}, v[{t}:{t + 3}], {base} offset:{g * 64} {pol}".rstrip())
                     q.issue(("S", g, i))
+                emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
             F(minidx, st)
-            E(minidx, f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
 
     for j in range(FN):
         base = 8 * j
@@ -1240,6 +1260,452 @@ def program(nw, stamp):
     return q
 
 
+# ---- round 4: packed 4-bit weights ---------------------------------------------------------------------------------------------------
+# mq_pack_w4's image: row n = K / 2 bytes; 16 bytes = 32 consecutive k, element p in the low and p + 16 in the high nibble of byte p.
+# A K = 128 stage of a row is four such chunks.  Lane (frow = lane & 15, kq = lane >> 4) reads chunk kq of row 16 j + frow with ONE
+# ds_read_b128 and owns 32 k of the stage: its low nibbles are its 16 bytes of the stage's FIRST MFMA (k = 32 kq + 0..15), its high
+# nibbles those of the SECOND (k = 32 kq + 16..31).  The activation fragments follow that split: the fragment-blocked image holds x[row,
+# 64 kb + 16 q + p] at block kb, lane 16 q + row, so "type A" (low) fragments are gathered at per-lane offset (kq >> 1) KiB + (2 (kq & 1)
+# 16 + row) 16 and "type B" (high) 256 bytes further (C++ forms av0 / av1 accordingly) -- the same 2 KiB per stage as the int8 kernel,
+# as 256-byte runs.  LDS image of a stage: BN rows x 64 B, DMA pieces of 16 rows (lane -> row = lane >> 2, stored chunk lane & 3 holds
+# logical chunk (lane & 3) ^ g(row), g = {0, 3, 2, 1}[(row >> 2) & 3]: conflict-free ds_read_b128 at the 64-byte pitch).
+# Every stage runs COLUMN outer (for j: unpack, 4 MFMAs), so only two raw quads and one low-nibble quad live in VGPRs:
+#   v98 read address | v99 per-lane read offset | v100 parameter address | v101 / v102 row sums (until stage 1) | v103 temporary
+#   v[104:111] deferred-init chunk sets (prologue: parameter loads, divide temporaries 108..115) | v[116:119] / v[120:123] raw quads
+#   (high nibbles in place) | v[124:127] low nibbles.  Final block: parameter sets v[100:107] / v[108:115]; the second read address, the
+#   parameter address and the store offset move into the (dead) LDS-DMA source operands sw0 / sw1 / sw2 ("+v" operands).
+#   AGPR a[0:31] activation sets (set, type, row block), a[32:47] the last stage's activations (final block).
+W_RD, W_WOFF, W_PAR, W_RS0, W_RS1, W_TMP = 98, 99, 100, 101, 102, 103
+W_D = (104, 108)
+W_R = (116, 120)
+W_L = 124
+S_M4 = 99                          # 0x0f0f0f0f
+
+
+def wa(set_, typ, i):
+    b = (32 if set_ == 2 else 16 * set_) + 8 * typ + 4 * i
+    return f"a[{b}:{b + 3}]"
+
+
+def w4_a_load(q, t, typ, i, set_, off, base=None):
+    def f():
+        o = off + 256 * typ
+        assert o < 4096
+        b = base if base is not None else S_ABASE
+        emit(f"global_load_dwordx4 {wa(set_, typ, i)}, %[av{i}], s[{b}:{b + 1}]" + (f" offset:{o}" if o else ""))
+        q.issue(("A", t))
+    return f
+
+
+def w4_piece(q, t, i, slot_sgpr):
+    def f():
+        emit(f"s_add_u32 m0, s{slot_sgpr}, s{S_WK[i]}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 %[sw{i}], s[{S_WBASE}:{S_WBASE + 1}]")
+        q.issue(("W", t))
+    return f
+
+
+def w4_unpack_mfma(j, r, aset, fill=()):
+    """column j of one stage from raw quad r: low nibbles -> W_L, 2 MFMAs; high nibbles in place, 2 MFMAs.  fill: callables spread
+    behind the four MFMAs (one list per MFMA)."""
+    fill = list(fill) + [[]] * 4
+    for e in range(4):
+        emit(f"v_and_b32 v{W_L + e}, s{S_M4}, v{r + e}")
+    emit("s_nop 1")
+    for i in range(2):
+        emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, v[{W_L}:{W_L + 3}], {wa(aset, 0, i)}, {acc(i, j)}" if not w4_unpack_mfma.zero else
+             f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, v[{W_L}:{W_L + 3}], {wa(aset, 0, i)}, 0")
+        if i == 0:
+            for e in range(4):
+                emit(f"v_lshrrev_b32 v{r + e}, 4, v{r + e}")
+        else:
+            for e in range(4):
+                emit(f"v_and_b32 v{r + e}, s{S_M4}, v{r + e}")
+        for f in fill[i]:
+            f()
+    emit("s_nop 1")
+    for i in range(2):
+        emit(f"v_mfma_i32_16x16x64_i8 {acc(i, j)}, v[{r}:{r + 3}], {wa(aset, 1, i)}, {acc(i, j)}")
+        for f in fill[2 + i]:
+            f()
+
+
+w4_unpack_mfma.zero = False
+
+
+def w4_rotate():
+    emit(f"s_mov_b32 s{S_CUR}, s{S_NXT}")
+    for sg in (S_NXT, S_DMA):
+        emit(f"s_add_u32 s{sg}, s{sg}, {W_BYTES}")
+        emit(f"s_cmp_eq_u32 s{sg}, {RING * W_BYTES}")
+        emit(f"s_cselect_b32 s{sg}, 0, s{sg}")
+    emit(f"s_add_u32 s{S_ABASE}, s{S_ABASE}, 2048")
+    emit(f"s_addc_u32 s{S_ABASE + 1}, s{S_ABASE + 1}, 0")
+
+
+def w4_stage(q, lq, t, nw, kt=None, sym=None, first=False, dinit=None, pre_final=False):
+    """one K = 128 stage, column outer.  At entry raw(t, column 0) is in flight into W_R[0] (address register W_RD = slot(t) + W_WOFF);
+    at exit raw(t + 1, 0) is (unless pre_final: the final block prefetches its own)."""
+    set_ = t & 1
+    more1 = kt is None or t + 1 < kt
+    more3 = kt is None or t + 3 < kt
+    emit(f"; ---- W4 stage {sym or t}: A set {set_}")
+    q.wait_for(("A", t))
+    vm = {}
+    if more1 and not NO_A:                       # A(t + 1): both types of both row blocks -> the other set
+        for n, (typ, i) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            vm.setdefault(n, []).append(w4_a_load(q, t + 1, typ, i, 1 - set_, 2048))
+        if pre_final:                            # and A(KT - 1) -> the third set (both register sets are in use until the final block)
+            def base2():                         # (two stages ahead is beyond the 12-bit offset field: a second base in s[74:75])
+                emit(f"s_add_u32 s{S_TS}, s{S_ABASE}, 4096")
+                emit(f"s_addc_u32 s{S_TS + 1}, s{S_ABASE + 1}, 0")
+            vm.setdefault(4, []).append(base2)
+            for n, (typ, i) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                vm.setdefault(4 + n, []).append(w4_a_load(q, t + 2, typ, i, 2, 0, base=S_TS))
+    if more3 and not NO_W:
+        for i in range(nw):
+            vm.setdefault(FN // 2 + 1 + i, []).append(w4_piece(q, t + 3, i, S_DMA))
+    # deferred zero-point correction: at column j the tiles of column (j + FN // 2) % FN, chunk read one column ahead
+    base = (2 if dinit == "wz" else 3) * 4 * BN
+    def chunk_read(c, k):
+        def f():
+            emit(f"ds_read_b128 v[{W_D[k]}:{W_D[k] + 3}], v{W_PAR} offset:{base + c * 64}")
+            lq.issue(("C", k, c))
+        return f
+    if dinit:
+        chunk_read((FN // 2) % FN, 0)()
+    w4_unpack_mfma.zero = first
+    par = (t * FN) % 2                           # FN odd: the raw-quad parity of column 0 alternates from stage to stage
+    for j in range(FN):
+        r, rn = W_R[(j + par) % 2], W_R[(j + 1 + par) % 2]
+        last = j == FN - 1
+        if not last:
+            emit(f"ds_read_b128 v[{rn}:{rn + 3}], v{W_RD} offset:{(j + 1) * 1024}")
+            lq.issue(("R", t, j + 1))
+        elif more1:
+            q.wait_for(("W", t + 1), *((("W", t + 2),) if pre_final else ()))
+            emit("s_barrier")                    # W(t + 1) of every wave has landed (and nobody still reads the slot W(t + 4) will take)
+            if not pre_final:
+                emit(f"v_add_u32 v{W_RD}, s{S_NXT}, v{W_WOFF}")
+                emit(f"ds_read_b128 v[{rn}:{rn + 3}], v{W_RD} offset:0")
+                lq.issue(("R", t + 1, 0))
+        fill = [[], [], [], []]
+        if dinit:
+            c = (j + FN // 2) % FN
+            k = j % 2
+            if not last:
+                fill[0].append(chunk_read((j + 1 + FN // 2) % FN, 1 - k))
+            fill[0].append(lambda k=k, c=c: lq.wait_for(("C", k, c)))
+            ops_ = []
+            for i in range(2):
+                for e in range(4):
+                    if dinit == "wz":
+                        ops_.append(f"v_mad_i32_i24 {accr(i, c, e)}, v{W_D[k] + e}, v{W_RS0 + i}, {accr(i, c, e)}")
+                    else:
+                        ops_.append(f"v_add_u32 {accr(i, c, e)}, {accr(i, c, e)}, v{W_D[k] + e}")
+            for n, text in enumerate(ops_):
+                fill[n // 2].append(lambda text=text: emit(text))
+        for n, fs in vm.items():
+            if n == j:
+                fill[3] = fill[3] + fs
+        lq.wait_for(("R", t, j))
+        w4_unpack_mfma(j, r, set_, fill)
+        if first:
+            pass
+    w4_unpack_mfma.zero = False
+    if more3:
+        emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK // 2}")
+        emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
+    w4_rotate()
+
+
+def w4_prologue(q, lq, nw):
+    emit("; ==== W4 prologue")
+    if SCALAR_GRID:
+        emit(f"s_load_dword s{S_SO}, %[soptr], 0x0")
+        emit(f"s_load_dword s{S_OO}, %[ooptr], 0x0")
+    emit(f"s_mov_b32 s{S_M4}, 0x0f0f0f0f")
+    emit(f"s_mov_b64 s[{S_ABASE}:{S_ABASE + 1}], %[aptr]")
+    emit(f"s_mov_b64 s[{S_WBASE}:{S_WBASE + 1}], %[wptr]")
+    emit(f"s_lshl_b32 s{S_WK[0]}, %[wave], 10")
+    for i in range(1, PIECES):
+        emit(f"s_add_u32 s{S_WK[i]}, s{S_WK[0]}, {i * NW * 1024}")
+    emit(f"s_mov_b32 s{S_CUR}, 0")
+    emit(f"s_mov_b32 s{S_NXT}, {W_BYTES}")
+    emit(f"s_mov_b32 s{S_DMA}, {3 * W_BYTES}")
+    emit(f"global_load_dword v{W_RS0}, %[rsofs0], %[rsptr]")
+    q.issue("P")
+    emit(f"global_load_dword v{W_RS1}, %[rsofs1], %[rsptr]")
+    q.issue("P")
+    emit(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
+    emit(f"v_cmp_gt_u32 vcc, {BN}, %[tid]")
+    emit("s_and_b64 exec, exec, vcc")
+    emit(f"v_lshlrev_b32 v{W_TMP}, 2, %[tid]")
+    P0 = W_D[0]
+    for k, ptr in enumerate(("alpha", "bias", "wzp", "ct")):
+        emit(f"global_load_dword v{P0 + k}, v{W_TMP}, %[{ptr}]")
+        q.issue("P")
+    emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    for t, slot in ((0, 0), (1, W_BYTES), (2, 2 * W_BYTES)):
+        emit(f"s_mov_b32 s{S_TMP}, {slot}")
+        for i in range(nw):
+            w4_piece(q, t, i, S_TMP)()
+        emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK // 2}")
+        emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
+        if t == 0:
+            for typ in range(2):
+                for i in range(2):
+                    w4_a_load(q, 0, typ, i, 0, 0)()
+    # per-lane constants: read offset = frow * 64 + ((kq ^ g(frow)) << 4), g = (4 - (frow >> 2)) & 3;  parameter address = PAR + kq * 16
+    emit(f"v_and_b32 v{W_TMP}, 63, %[tid]")
+    emit(f"v_and_b32 v{W_WOFF}, 15, v{W_TMP}")                     # frow
+    emit(f"v_lshrrev_b32 v{W_PAR}, 4, v{W_TMP}")                   # kq
+    emit(f"v_lshrrev_b32 v{W_RD}, 2, v{W_WOFF}")                   # frow >> 2
+    emit(f"v_sub_u32 v{W_RD}, 4, v{W_RD}")
+    emit(f"v_and_b32 v{W_RD}, 3, v{W_RD}")                         # g
+    emit(f"v_xor_b32 v{W_RD}, v{W_RD}, v{W_PAR}")                  # kq ^ g
+    emit(f"v_lshlrev_b32 v{W_RD}, 4, v{W_RD}")
+    emit(f"v_lshl_add_u32 v{W_WOFF}, v{W_WOFF}, 6, v{W_RD}")
+    emit(f"v_lshlrev_b32 v{W_PAR}, 4, v{W_PAR}")
+    emit(f"v_add_u32 v{W_PAR}, {PAR}, v{W_PAR}")
+    q.wait_for("P")
+    if SCALAR_GRID:
+        emit("s_waitcnt lgkmcnt(0)")
+        vs, v1, v2, v0, v3, v4 = 108, 109, 110, 111, 112, 113
+        emit(f"v_mov_b32 v{vs}, s{S_SO}")
+        emit(f"v_div_scale_f32 v{v1}, vcc, v{vs}, v{vs}, 1.0")
+        emit(f"v_rcp_f32 v{v2}, v{v1}")
+        emit("s_nop 0")
+        emit(f"v_fma_f32 v{v0}, -v{v1}, v{v2}, 1.0")
+        emit(f"v_fma_f32 v{v2}, v{v0}, v{v2}, v{v2}")
+        emit(f"v_div_scale_f32 v{v0}, vcc, 1.0, v{vs}, 1.0")
+        emit(f"v_mul_f32 v{v3}, v{v0}, v{v2}")
+        emit(f"v_fma_f32 v{v4}, -v{v1}, v{v3}, v{v0}")
+        emit(f"v_fma_f32 v{v3}, v{v4}, v{v2}, v{v3}")
+        emit(f"v_fma_f32 v{v0}, -v{v1}, v{v3}, v{v0}")
+        emit(f"v_div_fmas_f32 v{v0}, v{v0}, v{v2}, v{v3}")
+        emit(f"v_div_fixup_f32 v{v0}, v{v0}, v{vs}, 1.0")
+        emit("s_nop 0")
+        emit(f"v_readfirstlane_b32 s{S_ISO}, v{v0}")
+    emit("s_bitcmp1_b32 %[flags], 1")
+    l = label("rs")
+    emit(f"s_cbranch_scc1 {l}")
+    emit(f"v_mov_b32 v{W_RS0}, 0")
+    emit(f"v_mov_b32 v{W_RS1}, 0")
+    emit(f"{l}:")
+    emit(f"v_cmp_gt_u32 vcc, {BN}, %[tid]")
+    emit("s_and_b64 exec, exec, vcc")
+    emit("s_bitcmp1_b32 %[flags], 0")
+    l = label("nb")
+    emit(f"s_cbranch_scc1 {l}")
+    emit(f"v_mov_b32 v{P0 + 1}, 0")
+    emit(f"{l}:")
+    inv, oo = (f"s{S_ISO}", f"s{S_OO}") if SCALAR_GRID else ("%[invc]", "%[ooc]")
+    emit(f"v_mul_f32 v{P0}, {inv}, v{P0}")
+    emit(f"v_mul_f32 v{P0 + 1}, {inv}, v{P0 + 1}")
+    emit(f"v_add_f32 v{P0 + 1}, {oo}, v{P0 + 1}")
+    emit(f"v_sub_u32 v{P0 + 2}, 0, v{P0 + 2}")
+    emit(f"v_lshlrev_b32 v{W_TMP}, 2, %[tid]")
+    emit(f"v_add_u32 v{W_TMP}, {PAR}, v{W_TMP}")
+    for k in range(4):
+        emit(f"ds_write_b32 v{W_TMP}, v{P0 + k} offset:{k * 4 * BN}")
+    emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+    q.wait_for(("W", 0))
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    emit(f"v_add_u32 v{W_RD}, s{S_CUR}, v{W_WOFF}")
+    emit(f"ds_read_b128 v[{W_R[0]}:{W_R[0] + 3}], v{W_RD} offset:0")
+    lq.issue(("R", 0, 0))
+
+
+def w4_final_block(q, lq):
+    """stages KT-2 (A set 0, slot S_CUR) and KT-1 (A in the third set, slot S_NXT) column by column: per column two raw quads -> 8 MFMAs;
+    the u8 conversion of column j - 1 and the group stores ride between them (as final_block does for the int8 kernels)."""
+    NG = (FN + 3) // 4
+    EA = [100, 108]
+    RDB, PARV, GOG = "%[sw0]", "%[sw1]", "%[sw2]"
+    emit("; ==== W4 final block")
+    q.wait_for(("A", 6), ("A", 7))
+    assert q.q == [], q.q
+    # the second read address, the parameter address (v100 is about to hold parameters): into the dead LDS-DMA source operands
+    emit(f"v_mov_b32 {PARV}, v{W_PAR}")
+    emit(f"v_add_u32 {RDB}, s{S_NXT}, v{W_WOFF}")
+    emit(f"v_add_u32 v{W_RD}, s{S_CUR}, v{W_WOFF}")
+    emit(f"ds_read_b128 v[{W_R[0]}:{W_R[0] + 3}], v{W_RD} offset:0")
+    lq.issue(("R", 6, 0))
+    emit(f"ds_read_b128 v[{W_R[1]}:{W_R[1] + 3}], {RDB} offset:0")
+    lq.issue(("R", 7, 0))
+    rem = FN - 4 * (NG - 1)
+    fill = []
+
+    def F(minidx, fn):
+        fill.append((minidx, fn))
+
+    def E(minidx, text):
+        F(minidx, lambda: emit(text))
+    T = W_WOFF                    # v99: free now
+    for text in (
+            f"v_and_b32 v{T}, 63, %[tid]",
+            f"v_and_b32 {GOG}, 15, v{T}",
+            f"v_lshrrev_b32 v{T}, 4, v{T}",
+            f"v_cmp_gt_i32_e64 s[{S_FM}:{S_FM + 1}], %[mrem], {GOG}",
+            f"v_add_u32 v{W_TMP}, 16, {GOG}",
+            f"v_cmp_gt_i32_e64 s[{S_FM + 2}:{S_FM + 3}], %[mrem], v{W_TMP}",
+            f"v_cmp_gt_u32_e64 s[{S_FM + 4}:{S_FM + 5}], {rem}, v{T}",
+            f"s_and_b64 s[{S_FM + 6}:{S_FM + 7}], s[{S_FM + 2}:{S_FM + 3}], s[{S_FM + 4}:{S_FM + 5}]",
+            f"s_and_b64 s[{S_FM + 4}:{S_FM + 5}], s[{S_FM}:{S_FM + 1}], s[{S_FM + 4}:{S_FM + 5}]",
+            f"v_mul_lo_u32 {GOG}, {GOG}, %[ldn]",
+            f"v_lshl_add_u32 {GOG}, v{T}, 4, {GOG}",
+            f"s_lshl_b32 s{S_TMP2}, %[ldn], 4",
+            f"s_mov_b64 s[{S_OB1}:{S_OB1 + 1}], %[outw]",
+            f"s_add_u32 s{S_OB1}, s{S_OB1}, s{S_TMP2}",
+            f"s_addc_u32 s{S_OB1 + 1}, s{S_OB1 + 1}, 0"):
+        E(0, text)
+
+    def params(j):
+        st = j & 1
+        def fn0():
+            emit(f"ds_read_b128 v[{EA[st]}:{EA[st] + 3}], {PARV} offset:{j * 64}")
+            lq.issue(("P", j))
+        def fn1():
+            emit(f"ds_read_b128 v[{EA[st] + 4}:{EA[st] + 7}], {PARV} offset:{4 * BN + j * 64}")
+            lq.issue(("P", j))
+        return [fn0, fn1]
+
+    def tbase(g, i):
+        return (2 * (4 * g) + i) * 4
+
+    def store_group(minidx, g):
+        last = g == NG - 1 and rem != 4
+        for i in range(2):
+            t = tbase(g, i)
+            E(minidx, "s_nop 1")
+            E(minidx, f"v_permlane32_swap_b32 v{t}, v{t + 2}")
+            E(minidx, f"v_permlane32_swap_b32 v{t + 1}, v{t + 3}")
+            E(minidx, "s_nop 1")
+            E(minidx, f"v_permlane16_swap_b32 v{t}, v{t + 1}")
+            E(minidx, f"v_permlane16_swap_b32 v{t + 2}, v{t + 3}")
+            E(minidx, "s_nop 1")
+            for k in range(4):
+                E(minidx, f"v_xor_b32 v{t + k}, %[xorv], v{t + k}")
+            m = S_FM + 2 * i + (4 if last else 0)
+            base = "%[outw]" if i == 0 else f"s[{S_OB1}:{S_OB1 + 1}]"
+            def st(base=base, t=t, g=g, m=m):
+                emit(f"s_mov_b64 exec, s[{m}:{m + 1}]")       # (one filler: no MFMA under the store's exec mask)
+                emit(f"global_store_dwordx4 {GOG}, v[{t}:{t + 3}], {base} offset:{g * 64}")
+                q.issue(("S", g))
+                emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+            F(minidx, st)
+
+    def convert(minidx, j):
+        st = j & 1
+        g, k = j // 4, j % 4
+        F(minidx, lambda: lq.wait_for(("P", j)))
+        for i in range(2):
+            for e in range(4):
+                E(minidx, f"v_cvt_f32_i32 {accr(i, j, e)}, {accr(i, j, e)}")
+        for i in range(2):
+            for e in range(4):
+                E(minidx, f"v_fma_f32 {accr(i, j, e)}, {accr(i, j, e)}, v{EA[st] + e}, v{EA[st] + 4 + e}")
+        for i in range(2):
+            d = tbase(g, i) + k
+            for e in range(4):
+                E(minidx, f"v_cvt_pk_u8_f32 v{d}, {accr(i, j, e)}, {e}, " + (f"v{d}" if e else "0"))
+        if k == 3 or j == FN - 1:
+            store_group(minidx, g)
+
+    for j in range(FN):
+        base = 8 * j
+        for fn in params(j):
+            F(base, fn)
+        if j >= 1:
+            convert(base + 2, j - 1)
+    convert(8 * FN + 1000, FN - 1)
+
+    CAP = 4
+    fi = [0]
+    n = [0]
+
+    def drain(cap):
+        k = 0
+        out_ = []
+        while fi[0] < len(fill) and fill[fi[0]][0] <= n[0] and k < cap:
+            out_.append(fill[fi[0]][1])
+            fi[0] += 1
+            k += 1
+        return out_
+
+    for j in range(FN):
+        for half, (tt, aset, r, rd) in enumerate(((6, 0, W_R[0], f"v{W_RD}"), (7, 2, W_R[1], RDB))):
+            lq.wait_for(("R", tt, j))
+            fl = []
+            for m_ in range(4):
+                fl.append(drain(CAP))
+                n[0] += 1
+            if j + 1 < FN:                        # the quad is free once its high-nibble MFMAs have issued: re-read it for column j + 1
+                def rr(tt=tt, r=r, rd=rd, j=j):
+                    emit(f"ds_read_b128 v[{r}:{r + 3}], {rd} offset:{(j + 1) * 1024}")
+                    lq.issue(("R", tt, j + 1))
+                fl[3] = [rr] + fl[3]
+            w4_unpack_mfma(j, r, aset, fl)
+    while fi[0] < len(fill) and fill[fi[0]][0] < 8 * FN:
+        fill[fi[0]][1]()
+        fi[0] += 1
+    emit("s_nop 15")
+    emit("s_nop 3")
+    while fi[0] < len(fill):
+        fill[fi[0]][1]()
+        fi[0] += 1
+    emit("s_waitcnt vmcnt(0)")
+
+
+def program_w4(nw):
+    q, lq = Queue(), LQueue()
+    w4_prologue(q, lq, nw)
+    w4_stage(q, lq, 0, nw, first=DINIT)
+    w4_stage(q, lq, 1, nw, dinit="wz")
+    emit(f"s_sub_u32 s{S_CNT}, %[kt], 6")
+    emit(f"s_lshr_b32 s{S_CNT}, s{S_CNT}, 1")
+    lend, lloop = label("tail"), label("loop")
+    emit(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    emit(f"s_cbranch_scc1 {lend}")
+    emit(f"{lloop}:")
+    before, lbefore = list(q.q), list(lq.q)
+    w4_stage(q, lq, 2, nw, sym="T")
+    w4_stage(q, lq, 3, nw, sym="T+1")
+    shift = lambda x, d: (tuple(x[:1]) + (x[1] + d,) + tuple(x[2:]) if isinstance(x, tuple) and isinstance(x[1], int) else x)   # noqa: E731
+    assert [shift(x, -2) for x in q.q] == before, (before, q.q)
+    assert [shift(x, -2) for x in lq.q] == lbefore, (lbefore, lq.q)
+    emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    emit(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    emit(f"s_cbranch_scc1 {lloop}")
+    emit(f"{lend}:")
+    KT = 8
+    q.q = [shift(x, 2) for x in before]
+    lq.q = [shift(x, 2) for x in lbefore]
+    w4_stage(q, lq, 4, nw, kt=KT, sym="KT-4", dinit="ct")
+    w4_stage(q, lq, 5, nw, kt=KT, sym="KT-3", pre_final=True)
+    w4_final_block(q, lq)
+
+
+def generate_w4():
+    emit("; generated by tools/gen_fr_asm.py -- do not edit")
+    assert DINIT
+    if FN % NW == 0:
+        program_w4(FN // NW)
+        return
+    full = FN - (PIECES - 1) * NW             # waves that own PIECES pieces
+    l2, lend = label("w1"), label("done")
+    emit(f"s_cmp_lt_u32 %[wave], {full}")
+    emit(f"s_cbranch_scc0 {l2}")
+    program_w4(PIECES)
+    emit(f"s_branch {lend}")
+    emit(f"{l2}:")
+    program_w4(PIECES - 1)
+    emit(f"{lend}:")
+
+
 def generate(stamp=False):
     emit("; generated by tools/gen_fr_asm.py -- do not edit")
     if (BN // 8) % NW == 0:          # every wave owns the same number of W pieces: one program
@@ -1263,13 +1729,19 @@ def main(path=None, variant="fr"):
     stamp = bool(os.environ.get("MQ_FR_STAMP")) and variant == "fr"
     global PROBE
     PROBE = variant == "fr" and TAIL
-    generate(stamp)
+    if W4:
+        generate_w4()
+    else:
+        generate(stamp)
     here = os.path.dirname(os.path.abspath(__file__))
     path = path or os.path.join(here, "..", "mobilequant_amd", "csrc", FILE)
     # VGPRs between the accumulators and the temporaries are left to hipcc for the asm statement's vector operands
     vregs = [f'"v{r}"' for r in list(range(0, 88 if EPI == "gate" else 8 * FN)) + list(range(V_T if (8 * FN > 78 or EPI == "gate") else 78, 128))]
     aregs = [f'"a{r}"' for r in range(0, 8 * FN + 32 + (8 if TAIL else 0))]
-    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + (['"s100"', '"s101"'] if (PRO_SPLIT or PSTAMP) else []) + \
+    if W4:
+        vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(98, 128))]
+        aregs = [f'"a{r}"' for r in range(0, 48)]
+    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + (['"s100"', '"s101"'] if (PRO_SPLIT or PSTAMP) else []) + (['"s99"'] if W4 else []) + \
         (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel trace (+ PMC passes) of bench.py on the GPU box; keeps only text summaries (the rocpd
 # databases are tens of MB).  usage: prof_bench.sh <tag> [pmc]     (run through gpurun)
-TAG=${1:-r02}; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_bench_$TAG; mkdir -p $OUT
+TAG=${1:-r04}; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_bench_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
 # PMC passes profile the headline legs only (timed steps + the GEMM / quantize kernels alone): counter collection over the
