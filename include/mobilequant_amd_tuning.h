@@ -24,6 +24,10 @@ int mq_gemm_set_debug(int flags);
  * budget: random int8 operands ~1.75 GHz, zero-filled ~2.1 GHz of the nominal 2.4).  NULL (default) = no stores; the two counter reads
  * per wave stay in the kernel either way.  Pair launches share the buffer (second problem's workgroups write behind the first's). */
 int mq_gemm_set_clock_probe(void* buf);
+/* mq_w4a8_linear_tiled: 1 (default) = the packed pieces are expanded ONCE per workgroup into the int8 W ring (generated variants frw4x /
+ * frw4x_128: the int8 kernel's loop), 0 = every wave splits the nibbles of its own fragments in registers (frw4 / frw4_128: one LDS read
+ * per 16 columns and stage, 12 VALU per 4 MFMAs in every wave; measured 30 % slower).  Identical results. */
+int mq_gemm_set_w4_mode(int mode);
 /* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
 /* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "mq_gemm_variant_name": (c_char_p, [c_int]),
     "mq_gemm_set_debug": (c_int, [c_int]),
     "mq_gemm_set_clock_probe": (c_int, [_P]),
+    "mq_gemm_set_w4_mode": (c_int, [c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

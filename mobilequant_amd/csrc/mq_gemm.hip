@@ -37,6 +37,8 @@
 #include "mq_gemm_fr128r8_asm.inc"
 #include "mq_gemm_frw4_asm.inc"
 #include "mq_gemm_frw4_128_asm.inc"
+#include "mq_gemm_frw4x_asm.inc"
+#include "mq_gemm_frw4x_128_asm.inc"
 
 namespace mq {
 
@@ -972,7 +974,9 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
 // LDS ring as it is (LDS-DMA pieces of 16 rows x 64 B); a lane's single ds_read_b128 per 16 columns and stage holds both of its MFMA
 // operands of that stage, split in registers.  The activation fragments are gathered to match (type A = k 32 q + 0..15, type B = + 16..31
 // of the stage: per-lane offsets below).  256 x BNT tiles, eight waves, 8-bit unsigned output grid (BNT = 176: one grid; 128: per column).
-template <int BNT>
+// X (frw4x / frw4x_128): the packed pieces go wave-privately through registers, are expanded ONCE per workgroup into the int8 W ring, and
+// the loop is the int8 kernel's (standard activation fragments); !X (frw4 / frw4_128): every wave unpacks its own fragments.
+template <int BNT, bool X>
 __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) {
   constexpr int FNT = BNT / 16;
   constexpr int PCS = (FNT + 7) / 8;
@@ -991,7 +995,7 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
     piece = piece < FNT ? piece : FNT - 1;
     int row = n0 + piece * 16 + r;
     row = row < N ? row : N - 1;
-    const int g = (4 - ((r >> 2) & 3)) & 3;                    // {0, 3, 2, 1}[(r >> 2) & 3]
+    const int g = X ? 0 : (4 - ((r >> 2) & 3)) & 3;            // LDS image of the packed rows: {0, 3, 2, 1}[(r >> 2) & 3]; X: no LDS image
     sw[i] = (unsigned)row * (unsigned)(K >> 1) + (unsigned)((((lane & 3) ^ g)) << 4);
   }
   const int m0w = m0 + wave * 32;
@@ -1001,7 +1005,7 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
   rb1 = rb1 < rb_max ? rb1 : rb_max;
   // type-A fragment of lane (frow, kq): x[row, 128 s + 32 kq + 0..15] = k block 2 s + (kq >> 1), quarter 2 (kq & 1); type B: + 256 bytes
   const unsigned frow = (unsigned)lane & 15u, kq = (unsigned)lane >> 4;
-  const unsigned lofs = (kq >> 1) * 1024u + ((2u * (kq & 1u)) * 16u + frow) * 16u;
+  const unsigned lofs = X ? ((unsigned)lane << 4) : (kq >> 1) * 1024u + ((2u * (kq & 1u)) * 16u + frow) * 16u;
   const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + lofs;
   const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + lofs;
   unsigned rsofs[2];
@@ -1031,10 +1035,17 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
   if constexpr (BNT == 176) {
     const float* so_ptr = args.out_scale;
     const float* oo_ptr = args.out_offset;
-    asm volatile(MQ_FRW4_ASM_BODY
-                 : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
-                 : MQ_FRW4_OPERANDS, [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr)
-                 : MQ_FRW4_ASM_CLOBBERS);
+    if constexpr (X) {
+      asm volatile(MQ_FRW4X_ASM_BODY
+                   : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
+                   : MQ_FRW4_OPERANDS, [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr)
+                   : MQ_FRW4X_ASM_CLOBBERS);
+    } else {
+      asm volatile(MQ_FRW4_ASM_BODY
+                   : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
+                   : MQ_FRW4_OPERANDS, [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr)
+                   : MQ_FRW4_ASM_CLOBBERS);
+    }
   } else {
     const int n = n0 + (int)(tid < (unsigned)BNT ? tid : (unsigned)BNT - 1u);
     float sc = args.out_scale[0], ooc = args.out_offset[0];
@@ -1046,23 +1057,32 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
       }
     }
     const float invc = __fdiv_rn(1.0f, sc);
-    asm volatile(MQ_FRW4_128_ASM_BODY
-                 : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
-                 : MQ_FRW4_OPERANDS, [invc] "v"(invc), [ooc] "v"(ooc)
-                 : MQ_FRW4_128_ASM_CLOBBERS);
+    if constexpr (X) {
+      asm volatile(MQ_FRW4X_128_ASM_BODY
+                   : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
+                   : MQ_FRW4_OPERANDS, [invc] "v"(invc), [ooc] "v"(ooc)
+                   : MQ_FRW4X_128_ASM_CLOBBERS);
+    } else {
+      asm volatile(MQ_FRW4_128_ASM_BODY
+                   : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
+                   : MQ_FRW4_OPERANDS, [invc] "v"(invc), [ooc] "v"(ooc)
+                   : MQ_FRW4_128_ASM_CLOBBERS);
+    }
   }
 #undef MQ_FRW4_OPERANDS
 }
 
 static bool gemm_frw4_shape(int64_t M, int64_t N, int64_t K) { return M > 0 && (N % 176 == 0 || N % 128 == 0) && K % 256 == 0 && K >= 768; }
 
-template <int BNT>
+static std::atomic<int> g_w4_mode{1};           // mobilequant_amd_tuning.h: 1 = expand once per workgroup (frw4x), 0 = per-wave unpack (frw4)
+
+template <int BNT, bool X>
 static int launch_frw4(GemmArgs a, hipStream_t st) {
-  constexpr int LDS = BNT == 176 ? MQ_FRW4_LDS_BYTES : MQ_FRW4_128_LDS_BYTES;
+  constexpr int LDS = X ? (BNT == 176 ? MQ_FRW4X_LDS_BYTES : MQ_FRW4X_128_LDS_BYTES) : (BNT == 176 ? MQ_FRW4_LDS_BYTES : MQ_FRW4_128_LDS_BYTES);
   static PerDeviceOnce attr_set;
   const int dev = current_device();
   if (!attr_set.done(dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frw4_kernel<BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frw4_kernel<BNT, X>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
       return MQ_EHIP;
@@ -1074,7 +1094,7 @@ static int launch_frw4(GemmArgs a, hipStream_t st) {
   if (a.bias == nullptr) a.bias = a.alpha;
   a.grid_m = (a.M + 255) / 256;
   a.grid_n = a.N / BNT;
-  gemm_i8_frw4_kernel<BNT><<<a.grid_m * a.grid_n, 512, LDS, st>>>(a);
+  gemm_i8_frw4_kernel<BNT, X><<<a.grid_m * a.grid_n, 512, LDS, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
 }
@@ -1436,6 +1456,11 @@ int mq_gemm_set_variant(int variant) {
   return kNumVariants;
 }
 
+int mq_gemm_set_w4_mode(int mode) {
+  g_w4_mode = mode;
+  return 0;
+}
+
 int mq_gemm_set_clock_probe(void* buf) {
   g_dbg_ts = reinterpret_cast<unsigned long long*>(buf);
   return 0;
@@ -1595,8 +1620,9 @@ int mq_w4a8_linear_tiled(const int8_t* a_tiled, const uint8_t* w_packed, int64_t
     g.seg_scale[i - 1] = grids[i].scale;
     g.seg_offset[i - 1] = grids[i].offset;
   }
-  if (n_segments == 1 && N % 176 == 0) return launch_frw4<176>(g, as_stream(stream));
-  return launch_frw4<128>(g, as_stream(stream));
+  const bool x = g_w4_mode.load() != 0;
+  if (n_segments == 1 && N % 176 == 0) return x ? launch_frw4<176, true>(g, as_stream(stream)) : launch_frw4<176, false>(g, as_stream(stream));
+  return x ? launch_frw4<128, true>(g, as_stream(stream)) : launch_frw4<128, false>(g, as_stream(stream));
 }
 
 int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,

@@ -234,7 +234,9 @@ def _qkv_indices(self, x):
     grid = grids_in[0]
     t_shift = 128 if grid.qmax > 127 else 0
     t_hit = None
-    if all(not m._weight_plan(w)["w4"] for m, w in zip(lins, ws)) and ops.gemm_tiled128_supported(M, sum(w.shape[0] for w in ws), K):
+    n_all = sum(w.shape[0] for w in ws)
+    all_w4 = all(m._weight_plan(w)["w4"] for m, w in zip(lins, ws)) and n_all % 128 == 0 and ops.gemm_tiled_w4_supported(M, n_all, K)
+    if (all(not m._weight_plan(w)["w4"] for m, w in zip(lins, ws)) and ops.gemm_tiled128_supported(M, n_all, K)) or all_w4:
         t_hit = Q._shared_activation.get(x, grid, ("tiled", t_shift, None))
     if t_hit is not None:
         (a_q, a_rs, a_shift), tiled_rows = t_hit, M
@@ -260,6 +262,9 @@ def _qkv_indices(self, x):
         if oq.scale.device != x.device:
             oq.scale.data, oq.offset.data = oq.scale.to(x.device), oq.offset.to(x.device)
         out_grids.append((oq.scale.detach(), oq.offset.detach()))
+    if all_w4 and tiled_rows is not None:       # packed 4-bit weights on the generated kernels (QLinear.w4_prefill = "packed")
+        idx = ops.w4a8_linear_tiled(a_q, M, cat["w"], a_rs, cat["alpha"], cat["w_zp"], cat["col_term"], cat["bias"], out_grids, seg_ends=ends)
+        return idx, out_grids
     idx = ops.int8_linear_segmented(a_q, cat["w"], a_rs, cat["alpha"], cat["w_zp"], cat["col_term"], cat["bias"], ends, out_grids,
                                     w4=plans[0]["w4"], a_tiled_rows=tiled_rows)
     return idx, out_grids

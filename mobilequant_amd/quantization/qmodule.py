@@ -578,6 +578,10 @@ class QLinear(nn.Linear, _QuantizedOp):
             return prod if ok else None
         return self._input_grid
 
+    # 4-bit weights at prefill (M > 8): "image" = one byte per nibble on the int8 kernels (+ the packed image, built on first decode use);
+    # "packed" = the packed image only, for every kernel (include/mobilequant_amd.h: mq_w4a8_linear_tiled / mq_w4a8_linear)
+    w4_prefill = "image"
+
     def _int8_reason(self, x, weight) -> Optional[str]:
         """None when this call can run on the integer kernels, else WHY it takes the simulated path (HIP fake-quant around the
         fp32 library GEMM: the reference's semantics, ~10x slower) -- recorded per module, read by int8_coverage()."""
@@ -625,8 +629,9 @@ class QLinear(nn.Linear, _QuantizedOp):
         wq = self.weight_quantizer
         if not wq._has_grid():
             wq._prepare(weight, "parameter")           # first forward: range from the weight itself
+        packed_only = wq.qcfg.bitwidth == 4 and QLinear.w4_prefill == "packed" and weight.shape[1] % 32 == 0
         key = (weight.data_ptr(), _ver(weight), tuple(weight.shape), wq.grid_token(), wq.qcfg.bitwidth, wq.qcfg.is_symmetric,
-               wq.qcfg.is_per_channel)
+               wq.qcfg.is_per_channel, packed_only)
         plan = self._plan
         if plan is not None and plan["key"] == key and plan["wref"]() is weight:
             return plan
@@ -642,10 +647,16 @@ class QLinear(nn.Linear, _QuantizedOp):
             q, colsum = ops.quantize(w32, wq.scale.detach(), wq.offset.detach(), wq.qmin, wq.qmax, q_dtype=MQ_U8,
                                      shift=wq.qmin, rows=weight.shape[0], want_row_sum=True)
             wint, shift = q.view(torch.int8), wq.qmin
+            if packed_only:
+                # QLinear.w4_prefill = "packed" (round 4): ONE image, two nibbles per byte (0.5 B / weight), for prefill and decode alike --
+                # mq_w4a8_linear_tiled (generated ISA: the pieces are expanded once per workgroup into the int8 W ring) where a fused block
+                # asks for 8-bit indices, mq_w4a8_linear elsewhere.  Measured 5-10 % behind the int8 image on the GEMMs it serves, so the
+                # image stays the default.
+                wint = ops.pack_w4(q)
         else:
             wint, colsum, shift = wq.quantize_to_int(w32, MQ_I8, want_row_sum=True, rows=weight.shape[0])
-        plan = {"key": key, "wref": weakref.ref(weight), "w": wint, "colsum": colsum, "shift": shift, "w4": False, "bits4": bits4,
-                "packed": None, "epi_key": None}
+        plan = {"key": key, "wref": weakref.ref(weight), "w": wint, "colsum": colsum, "shift": shift, "w4": packed_only, "bits4": bits4,
+                "packed": wint if packed_only else None, "epi_key": None}
         self._plan = plan
         return plan
 
@@ -1269,8 +1280,11 @@ def _gated_mlp_forward(self, x, resid=None):
             or _needs_grad(wt2, w2.bias, getattr(wq2, "scale", None))):
         return plain(x)
     any_w4 = w1._weight_plan(wt1)["w4"] or w3._weight_plan(wt3)["w4"]
+    both_w4 = w1._weight_plan(wt1)["w4"] and w3._weight_plan(wt3)["w4"] and ops.gemm_tiled_w4_supported(M, N, K)
+    if any_w4:
+        pair = False
     t_hit = None
-    if not pair and not any_w4 and M > 8 and ops.gemm_tiled128_supported(M, N, K):
+    if (not pair and not any_w4 and M > 8 and ops.gemm_tiled128_supported(M, N, K)) or both_w4:
         # N does not tile by 176 (Gemma: 16384): w1 / w3 run one by one on the 128-column generated kernel, reading the
         # fragment-blocked image the norm left (index outputs only -- which is all this block needs)
         t_hit = _shared_activation.get(x, g1, ("tiled", 128 if g1.qmax > 127 else 0, None))
@@ -1280,7 +1294,7 @@ def _gated_mlp_forward(self, x, resid=None):
         grid, a_q, a_rs, a_shift, tiled_rows, decode = w1._input_image(x, wt1)
     if decode:
         return plain(x)
-    if any_w4 and tiled_rows is not None:
+    if any_w4 and tiled_rows is not None and not both_w4:
         return plain(x)                     # (a 4-bit sibling of an int8 linear that chose the fragment-blocked image: not a real recipe)
     pair = pair and tiled_rows is not None and not any_w4
     halves = []
@@ -1306,6 +1320,9 @@ def _gated_mlp_forward(self, x, resid=None):
                                    lead_shape=x.shape[:-1], resid=resid)
     if pair:
         a_idx, b_idx = ops.int8_linear_pair(a_q, M, a_rs, halves[0], halves[1], out_dtype=MQ_U8)
+    elif both_w4 and tiled_rows is not None:        # packed weights on the generated kernels (mq_w4a8_linear_tiled), indices out
+        a_idx, b_idx = (ops.w4a8_linear_tiled(a_q, M, h["w"], a_rs, h["alpha"], h["w_zp"], h["col_term"], h["bias"],
+                                              [(h["out_scale"], h["out_offset"])]) for h in halves)
     else:
         a_idx, b_idx = (ops.int8_linear(a_q, h["w"], a_rs, h["alpha"], h["w_zp"], h["col_term"], h["bias"], out_scale=h["out_scale"],
                                         out_offset=h["out_offset"], out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8, w4=m._weight_plan(wt)["w4"],

@@ -294,10 +294,18 @@ def test_packed_w4_generated_isa_gemm_vs_exact_oracle_every_output(dev, M, N, K,
         grids.append((torch.tensor([float(so)], device=dev), torch.tensor([float(oo)], device=dev)))
         want[:, lo:hi], exact[:, lo:hi] = exact_u8(qa, za, sa, qw[lo:hi], zw[lo:hi], sw[lo:hi], None if bias is None else bias[lo:hi], so, oo)
         lo = hi
-    got = ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, seg_ends=ends if segs else None).cpu().numpy()
-    assert got.shape == (M, N)
-    bad = got != want
-    assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:8].tolist(), got[bad][:8].tolist(), want[bad][:8].tolist())
+    import mobilequant_amd._lib as L
+    lib = L.load()
+    try:
+        # mode 1 (default): packed pieces expanded once per workgroup into the int8 W ring (frw4x); mode 0: per-wave in-register unpack (frw4)
+        for mode in (0, 1):
+            lib.mq_gemm_set_w4_mode(mode)
+            got = ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, seg_ends=ends if segs else None).cpu().numpy()
+            assert got.shape == (M, N)
+            bad = got != want
+            assert not bad.any(), (mode, int(bad.sum()), np.argwhere(bad)[:8].tolist(), got[bad][:8].tolist(), want[bad][:8].tolist())
+    finally:
+        lib.mq_gemm_set_w4_mode(1)
     assert np.abs(got.astype(np.float64) - exact).max() <= 1 and (got == exact).mean() > 0.999
     if not segs:
         got_i8 = ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, out_dtype=MQ_I8).cpu().numpy()
@@ -310,3 +318,33 @@ def test_packed_w4_generated_isa_gemm_vs_exact_oracle_every_output(dev, M, N, K,
     canary = torch.full((M + 16, N), 77, dtype=torch.uint8, device=dev)
     ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, seg_ends=ends if segs else None, out=canary[:M])
     assert np.array_equal(canary[:M].cpu().numpy(), want) and bool((canary[M:] == 77).all())
+
+
+def test_packed_only_w4_mode_is_the_image_mode_bit_for_bit_at_full_depth(dev):
+    """QLinear.w4_prefill = "packed": every 4-bit module holds ONLY the mq_pack_w4 image (0.5 B / weight, shared by prefill and decode).
+    In the fused 22-layer W4A8 model q | k | v (one segmented launch) and w1 / w3 then run mq_w4a8_linear_tiled (generated ISA, pieces
+    expanded once per workgroup), o_proj / w2 the packed tile kernel mq_w4a8_linear -- the same integer contraction and the same epilogue
+    arithmetic as the int8-image kernels of the default mode, so the logits must be IDENTICAL, and no module may fall back to the
+    simulated path."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    res = {}
+    try:
+        for mode in ("image", "packed"):
+            mq.QLinear.w4_prefill = mode
+            m, z = _full_depth_model(dev, "w4a8")
+            ids = torch.from_numpy(z["ids"]).long().to(dev)
+            assert llama.fuse_decoder_layer(m) == 22
+            with torch.no_grad():
+                res[mode] = m(ids.view(1, -1))[0].clone()
+            cov = mq.int8_coverage(m)
+            assert cov["simulated_calls"] == 0, cov["summary"]
+            if mode == "packed":
+                lin = m.layers[0].mlp.w1
+                plan = lin._weight_plan(lin.weight)
+                assert plan["w4"] and plan["w"].dtype == torch.uint8 and plan["w"].shape == (5632, 1024)
+            del m
+            torch.cuda.empty_cache()
+    finally:
+        mq.QLinear.w4_prefill = "image"
+    assert torch.equal(res["image"], res["packed"]), float((res["image"] - res["packed"]).abs().max())

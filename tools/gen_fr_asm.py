@@ -52,6 +52,11 @@ VARIANTS = {
     # output columns and K = 128 stage, nibbles split in registers (v_and / v_lshrrev) under the MFMAs (program_w4 below)
     "frw4":     (176, 8, "u8w4", "MQ_FRW4",    "mq_gemm_frw4_asm.inc"),       # 256 x 176 tiles, one output grid (TinyLlama / StableLM w1, w3)
     "frw4_128": (128, 8, "u8w4", "MQ_FRW4_128", "mq_gemm_frw4_128_asm.inc"),  # 256 x 128 tiles, per-column grids (q | k | v; Gemma's FFN)
+    # the same packed image, expanded ONCE per workgroup instead of once per wave: every wave loads the 16-row pieces it owns straight into
+    # registers (no LDS-DMA), splits the nibbles and writes the int8 rows into the W ring; the loop, the deferred init and the final block
+    # are the int8 kernel's (frw4 spends 12 VALU per 4 MFMAs in EVERY wave on the unpack and measured 30 % slower than the int8 image)
+    "frw4x":     (176, 8, "u8w4x", "MQ_FRW4X",     "mq_gemm_frw4x_asm.inc"),
+    "frw4x_128": (128, 8, "u8w4x", "MQ_FRW4X_128", "mq_gemm_frw4x_128_asm.inc"),
 }
 
 
@@ -59,13 +64,18 @@ def configure(name):
     """binds the module-level tile constants of one variant (the emitters read them at call time)"""
     global BN, NW, EPI, PREFIX, FILE, BM, W_BYTES, PAR, STG, ROWP, STG_WAVE, LDS_BYTES, FN, PIECES, HALF, RING_BASE, SCALAR_GRID
     BN, NW, EPI, PREFIX, FILE = VARIANTS[name]
-    SCALAR_GRID = (BN == 176 or EPI not in ("u8", "u8w4"))      # ONE output grid per launch (scalars); otherwise per-column grids (q | k | v segments)
+    SCALAR_GRID = (BN == 176 or EPI not in ("u8", "u8w4", "u8w4x"))      # ONE output grid per launch (scalars); otherwise per-column grids (q | k | v segments)
     # round 4: the u8 epilogue is interleaved with the MFMAs of the LAST TWO stages (final_block) unless MQ_FR_TAIL=0
     global TAIL
     TAIL = EPI == "u8" and os.environ.get("MQ_FR_TAIL", "1") != "0"
     BM = 32 * NW
     FN = BN // 16
-    global W4
+    global W4, W4X
+    W4X = EPI == "u8w4x"
+    if W4X:
+        EPI = "u8"
+        SCALAR_GRID = BN == 176
+        TAIL = True
     W4 = EPI == "u8w4"
     if W4:
         EPI = "u8"
@@ -103,6 +113,8 @@ def configure(name):
         STG_WAVE = 16 * ROWP
     LDS_BYTES = STG + NW * STG_WAVE
     PIECES = (BN // 8 + NW - 1) // NW   # most W LDS-DMA pieces (8 rows x 128 B) a wave owns per stage
+    if W4X:
+        PIECES = (FN + NW - 1) // NW    # packed pieces are 16 rows x 64 B
     assert LDS_BYTES <= 160 * 1024
 
 
@@ -286,7 +298,8 @@ def deferred_init(lq, ks, phase):
     on the prologue's critical path.  Two VALU per gap (a wave hides ~5 issue slots per MFMA beside its partner; four per gap measured
     +950 cycles): gap m of k-step ks touches elements 2 ks, 2 ks + 1 of the tile 11 MFMAs away -- its last MFMA is long complete, its
     next far off.  Returns (pre, extra): callables in front of the k-step, {position: [callables]}."""
-    SETS = [V_E, V_E + 4, V_P0, V_P0 + 4, 122]
+    # a k-step touches elements 2 ks, 2 ks + 1 of a chunk only: 8-byte reads into two-register sets
+    SETS = [106, 108, 124, 126] if W4X else [V_E, V_E + 2, V_E + 4, V_E + 6, V_P0, V_P0 + 2, V_P0 + 4, V_P0 + 6]
     LEAD = int(os.environ.get("MQ_FR_DLEAD", "4"))
     NT = 2 * FN
     order = [(m + FN) % NT for m in range(NT)]
@@ -300,7 +313,7 @@ def deferred_init(lq, ks, phase):
     def rd(c, k):
         def f():
             t = SETS[k % len(SETS)]
-            emit(f"ds_read_b128 v[{t}:{t + 3}], v{V_PAR} offset:{base + c * 64}")
+            emit(f"ds_read_b64 v[{t}:{t + 1}], v{V_PAR} offset:{base + c * 64 + 8 * ks}")
             lq.issue(("C", ks, k))
         return f
     for c, first, k in cols:
@@ -317,11 +330,11 @@ def deferred_init(lq, ks, phase):
         st = SETS[k % len(SETS)]
         fl = extra.setdefault(m, [])
         fl.append(lambda k=k: lq.wait_for(("C", ks, k)))
-        for e in (2 * ks, 2 * ks + 1):
+        for d, e in enumerate((2 * ks, 2 * ks + 1)):
             if phase == "wz":
-                fl.append(lambda i=i, j=j, e=e, st=st: emit(f"v_mad_i32_i24 {accr(i, j, e)}, v{st + e}, v{V_RS0 + i}, {accr(i, j, e)}"))
+                fl.append(lambda i=i, j=j, e=e, d=d, st=st: emit(f"v_mad_i32_i24 {accr(i, j, e)}, v{st + d}, v{V_RS0 + i}, {accr(i, j, e)}"))
             else:
-                fl.append(lambda i=i, j=j, e=e, st=st: emit(f"v_add_u32 {accr(i, j, e)}, {accr(i, j, e)}, v{st + e}"))
+                fl.append(lambda i=i, j=j, e=e, d=d, st=st: emit(f"v_add_u32 {accr(i, j, e)}, {accr(i, j, e)}, v{st + d}"))
     return pre, extra
 
 
@@ -333,6 +346,57 @@ def rotate():
         emit(f"s_cselect_b32 s{s}, 0, s{s}")
     emit(f"s_add_u32 s{S_ABASE}, s{S_ABASE}, {2 * 1024}")
     emit(f"s_addc_u32 s{S_ABASE + 1}, s{S_ABASE + 1}, 0")
+
+
+# ---- round 4: packed 4-bit weights expanded once per workgroup (variants frw4x / frw4x_128) ------------------------------------------------
+# A wave owns the packed pieces wave + NW i (16 rows x 64 B of a K = 128 stage): lane l loads 16 bytes = chunk c = l & 3 (32 consecutive k:
+# element p low, p + 16 high nibble of byte p) of row r = l >> 2 with a plain global_load_dwordx4, and one stage later writes the int8
+# row pieces k = 32 c .. + 15 (low nibbles) and + 16 .. + 31 (high) into the W ring at the int8 kernels' XOR-swizzled positions (chunks
+# 2 c, 2 c + 1 of the 128-byte row).  Loads of W(t + 2) are issued in k-step 1 of stage t, expanded in k-step 0 of stage t + 1 (before
+# the mid-stage barrier that publishes W(t + 2) to the other waves' fragment reads); everything else is the int8 program.
+X_P = (110, 114)                   # packed quads of the wave's (up to two) pieces
+X_P2 = (106, 124)                  # a second set (pre-final stage only: W(KT-1) next to W(KT-2))
+X_L = 118                          # low nibbles of the piece being expanded
+X_A0, X_A1, X_T = 122, 123, 105    # per-lane ring offsets of the low / high 16 bytes, address temporary
+S_M4 = 99                          # 0x0f0f0f0f (shared with program_w4)
+
+
+def w4x_load(q, t, i, regs):
+    def f():
+        emit(f"global_load_dwordx4 v[{regs[i]}:{regs[i] + 3}], %[sw{i}], s[{S_WBASE}:{S_WBASE + 1}]")
+        q.issue(("W", t))
+    return f
+
+
+def w4x_advance():
+    emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK // 2}")
+    emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
+
+
+def w4x_expand(q, lq, t, nw, slot_sgpr, regs):
+    """callables (small groups of instructions) that turn the packed pieces of W(t) in `regs` into int8 rows of ring slot `slot_sgpr`"""
+    out_ = [lambda: q.wait_for(("W", t))]
+    for i in range(nw):
+        x = regs[i]
+        off = i * NW * 16 * BK
+
+        def lo(x=x, off=off):
+            for e in range(4):
+                emit(f"v_and_b32 v{X_L + e}, s{S_M4}, v{x + e}")
+            emit(f"v_add_u32 v{X_T}, s{slot_sgpr}, v{X_A0}")
+            emit(f"ds_write_b128 v{X_T}, v[{X_L}:{X_L + 3}] offset:{off}")
+            lq.issue(("X", t))
+
+        def hi(x=x, off=off):
+            for e in range(4):
+                emit(f"v_lshrrev_b32 v{x + e}, 4, v{x + e}")
+            for e in range(4):
+                emit(f"v_and_b32 v{x + e}, s{S_M4}, v{x + e}")
+            emit(f"v_add_u32 v{X_T}, s{slot_sgpr}, v{X_A1}")
+            emit(f"ds_write_b128 v{X_T}, v[{x}:{x + 3}] offset:{off}")
+            lq.issue(("X", t))
+        out_ += [lo, hi]
+    return out_
 
 
 def stage(q, t, nw, kt=None, sym=None, first=False, dinit=False):
@@ -348,15 +412,19 @@ def stage(q, t, nw, kt=None, sym=None, first=False, dinit=False):
     v0 = []
     if more1 and not NO_A:      # S_ABASE = activation pointer of stage t+1
         v0 += [("a", a_load(q, t + 1, 1, 0, 1 - set_, 1024)), ("a", a_load(q, t + 1, 1, 1, 1 - set_, 1024))]
-    if more3 and not NO_W:
+    if more3 and not NO_W and not W4X:
         v0 += [("w", w_piece(q, t + 3, i, S_DMA)) for i in range(nw)]
     lq0, lq1 = LQueue(), LQueue()
     pre0, ex0 = deferred_init(lq0, 0, dinit) if dinit else ([], None)
     pre1, ex1 = deferred_init(lq1, 1, dinit) if dinit else ([], None)
+    if W4X and more1:            # W(t + 1): packed pieces (loaded a stage ago) -> int8 rows of slot(t + 1), behind the later MFMAs of k-step 0
+        ex0 = dict(ex0 or {})
+        for n, f in enumerate(w4x_expand(q, lq0, t + 1, nw, S_NXT, X_P)):
+            ex0.setdefault(FN + 1 + n, []).append(f)
     for f in pre0:
         f()
     kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0, c_zero=first, extra=ex0, lq=lq0)
-    if more3:
+    if more3 and not W4X:
         emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK}")
         emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
     q.wait_for(("A", t, 1), ("W", t + 1))
@@ -364,9 +432,13 @@ def stage(q, t, nw, kt=None, sym=None, first=False, dinit=False):
     v1 = []
     if more2 and not NO_A:
         v1 += [("a", a_load(q, t + 2, 0, 0, set_, 2048)), ("a", a_load(q, t + 2, 0, 1, set_, 2048))]
+    if W4X and more2:            # W(t + 2): this wave's packed pieces -> registers (free since k-step 0's expansion)
+        v1 += [("w", w4x_load(q, t + 2, i, X_P)) for i in range(nw)]
     for f in pre1:
         f()
     kstep(1, set_, 1, S_NXT, V_WOFF0, 0, v1, read=more1, extra=ex1, lq=lq1)
+    if W4X and more2:
+        w4x_advance()
     rotate()
 
 
@@ -412,7 +484,21 @@ def stage_pre_final(q, lq, t, nw):
     if not NO_A:
         v0 += [("a", a_load(q, t + 1, 1, 0, 1 - set_, 1024)), ("a", a_load(q, t + 1, 1, 1, 1 - set_, 1024)),
                ("a", a_load_spare(q, t + 2, 0, 3072)), ("a", a_load_spare(q, t + 2, 1, 3072))]
-    kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0)
+    ex0 = None
+    if W4X:
+        # W(KT-2) (packed pieces loaded in stage KT-4) and W(KT-1) (requested at the head of this k-step into a second register set)
+        # both become int8 rows before the barrier: the final block reads both slots
+        emit(f"s_add_u32 s{S_TMP2}, s{S_NXT}, {W_BYTES}")
+        emit(f"s_cmp_eq_u32 s{S_TMP2}, {RING * W_BYTES}")
+        emit(f"s_cselect_b32 s{S_TMP2}, 0, s{S_TMP2}")
+        for i in range(nw):
+            v0.insert(i, ("a", w4x_load(q, t + 2, i, X_P2)))
+        ex0 = {}
+        for n, f in enumerate(w4x_expand(q, lq, t + 1, nw, S_NXT, X_P)):
+            ex0.setdefault(4 + n, []).append(f)
+        for n, f in enumerate(w4x_expand(q, lq, t + 2, nw, S_TMP2, X_P2)):
+            ex0.setdefault(2 * FN - 5 + n, []).append(f)
+    kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0, extra=ex0, lq=lq if W4X else None)
     q.wait_for(("A", t, 1), ("W", t + 1), ("W", t + 2))
     emit("s_barrier")                       # W(KT-2) and W(KT-1) of every wave have landed
     rotate()                                # S_CUR / S_NXT = ring slots of stages KT-2 / KT-1, S_ABASE -> stage KT-2
@@ -693,9 +779,17 @@ def prologue(q, nw, stamp):
         q.issue("P")
     emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
     # (2) the first stages, in the order they are needed: W(0), A(0), W(1), A(1).ks0, W(2)
+    if W4X:
+        emit(f"s_mov_b32 s{S_M4}, 0x0f0f0f0f")
     for t, slot in ((0, 0), (1, W_BYTES), (2, 2 * W_BYTES)):
         emit(f"s_mov_b32 s{S_TMP}, {slot}")
-        issue_w(q, t, nw, S_TMP)
+        if W4X:                 # packed pieces of W(0) -> registers; W(1) follows once W(0) is expanded (step 5)
+            if t == 0:
+                for i in range(nw):
+                    w4x_load(q, 0, i, X_P)()
+                w4x_advance()
+        else:
+            issue_w(q, t, nw, S_TMP)
         if t == 0:
             for ks in range(2):
                 for i in range(2):
@@ -837,6 +931,27 @@ def prologue(q, nw, stamp):
                 rd_ct(j + 4)
     # (5) W(0) of every wave landed -> first fragments
     pstamp(3, stamp)
+    if W4X:
+        # ring offsets of this lane's two 16-byte pieces: row = 16 wave + (lane >> 2), chunks 2 c and 2 c + 1 (c = lane & 3) at the
+        # int8 image's swizzled positions (chunk ^ (row & 7)); then W(0) -> slot 0, and W(1)'s packed pieces are requested
+        emit(f"v_and_b32 v{V_TMP}, 63, %[tid]")
+        emit(f"v_lshrrev_b32 v{X_T}, 2, v{V_TMP}")                             # r
+        emit(f"v_and_b32 v{V_TMP}, 3, v{V_TMP}")                               # c
+        emit(f"v_lshlrev_b32 v{V_TMP}, 1, v{V_TMP}")                           # 2 c
+        emit(f"v_and_b32 v{X_A1}, 7, v{X_T}")                                  # row & 7
+        emit(f"v_xor_b32 v{X_A0}, v{V_TMP}, v{X_A1}")                          # p0
+        emit(f"v_xor_b32 v{X_A1}, 1, v{X_A0}")                                 # p1
+        emit(f"s_lshl_b32 s{S_TMP}, %[wave], 4")
+        emit(f"v_add_u32 v{X_T}, s{S_TMP}, v{X_T}")                            # tile row
+        emit(f"v_lshlrev_b32 v{X_T}, 7, v{X_T}")                               # * 128
+        emit(f"v_lshl_add_u32 v{X_A0}, v{X_A0}, 4, v{X_T}")
+        emit(f"v_lshl_add_u32 v{X_A1}, v{X_A1}, 4, v{X_T}")
+        lqx = LQueue()
+        for f in w4x_expand(q, lqx, 0, nw, S_CUR, X_P):
+            f()
+        for i in range(nw):
+            w4x_load(q, 1, i, X_P)()
+        w4x_advance()
     q.wait_for(("W", 0))
     if DINIT:
         emit("s_waitcnt lgkmcnt(0)")            # this wave's parameter writes are in the LDS: the barrier publishes them with W(0)
@@ -1708,6 +1823,20 @@ def generate_w4():
 
 def generate(stamp=False):
     emit("; generated by tools/gen_fr_asm.py -- do not edit")
+    if W4X:
+        if FN % NW == 0:
+            program(FN // NW, stamp)
+            return
+        full = FN - (PIECES - 1) * NW
+        l2, lend = label("w1"), label("done")
+        emit(f"s_cmp_lt_u32 %[wave], {full}")
+        emit(f"s_cbranch_scc0 {l2}")
+        program(PIECES, stamp)
+        emit(f"s_branch {lend}")
+        emit(f"{l2}:")
+        program(PIECES - 1, stamp)
+        emit(f"{lend}:")
+        return
     if (BN // 8) % NW == 0:          # every wave owns the same number of W pieces: one program
         program(BN // 8 // NW, stamp)
         return
@@ -1741,7 +1870,7 @@ def main(path=None, variant="fr"):
     if W4:
         vregs = [f'"v{r}"' for r in list(range(0, 8 * FN)) + list(range(98, 128))]
         aregs = [f'"a{r}"' for r in range(0, 48)]
-    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + (['"s100"', '"s101"'] if (PRO_SPLIT or PSTAMP) else []) + (['"s99"'] if W4 else []) + \
+    sregs = [f'"s{r}"' for r in range(S0, S_MASK + 16)] + [f'"s{r}"' for r in (S_SO, S_OO, S_ISO)] + (['"s100"', '"s101"'] if (PRO_SPLIT or PSTAMP) else []) + (['"s99"'] if (W4 or W4X) else []) + \
         (['"m0"'] if EPI == "gate" else [])
     with open(path, "w") as f:
         f.write("// Generated by tools/gen_fr_asm.py -- do not edit (see that file for the register map, the LDS map and the schedule).\n")
