@@ -346,7 +346,7 @@ def pmc_traffic():
     (profiles/r03/pmc_fetch + pmc_write, else r02's; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
     streams on gfx950).  Counters cannot be read from inside the bench, so this is the last profiled value."""
     import re
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         d = os.path.join(ROOT, "profiles", rnd)
         vals = {}
         for fn, key in (("pmc_fetch.summary.txt", "FETCH_SIZE"), ("pmc_write.summary.txt", "WRITE_SIZE")):
@@ -1031,8 +1031,55 @@ def bench_other_configs(dev):
             del ql, lin
             torch.cuda.empty_cache()
         out[cfg] = rows
-    out["scope"] = "QLinear.forward (quantize + int8 GEMM, fp32 out) per linear shape at M = 2048, hipGraph"
+    out["scope"] = ("QLinear.forward (quantize + int8 GEMM, fp32 out) per linear shape at M = 2048, hipGraph; the configs[3] rows above run the "
+                    "4-bit weights as their one-byte-per-nibble int8 image (QLinear.w4_prefill = 'image', the default)")
+    out["configs[3] packed 4-bit weights, generated ISA"] = bench_packed_w4(dev)
     return out
+
+
+def bench_packed_w4(dev):
+    """BASELINE.json configs[3] as it names it: PACKED 4-bit weights (mq_pack_w4: two nibbles per byte) -> int8 MFMA.  The GEMM alone on the
+    index-output shapes the generated kernels serve (mq_w4a8_linear_tiled; fragment-blocked int8 activations, 8-bit output indices),
+    next to the int8-image kernel on the SAME numbers: `expanded` = pieces split once per workgroup into the int8 W ring (frw4x, default),
+    `per_wave` = every wave splits its own fragments in registers (frw4), `int8_image` = one byte per nibble on the int8 kernels."""
+    import mobilequant_amd._lib as L
+    from mobilequant_amd import ops
+    from mobilequant_amd._lib import MQ_U8
+    lib = L.load()
+    res = {}
+    for name, n, k in (("gemma w1/w3 16384<-2048", 16384, 2048), ("tinyllama w1/w3 5632<-2048", 5632, 2048), ("tinyllama q|k|v 2560<-2048", 2560, 2048)):
+        g = torch.Generator().manual_seed(n)
+        qw = torch.randint(0, 16, (n, k), generator=g, dtype=torch.uint8).to(dev)
+        x = torch.randn(M, k, generator=g).to(dev)
+        sc, of = torch.tensor([8.0 / 255], device=dev), torch.tensor([128.0], device=dev)
+        a_t, rs = ops.quantize_tiled(x, sc, of, 0.0, 255.0, 128)
+        packed, w8 = ops.pack_w4(qw), qw.view(torch.int8)
+        colsum = qw.to(torch.int32).sum(1).to(torch.int32)
+        wsc = torch.rand(n, generator=g).to(dev) * 1e-2 + 1e-3
+        wof = torch.randint(0, 16, (n,), generator=g).float().to(dev)
+        alpha, wzp, ct = ops.linear_epilogue_prepare(sc, of, 128, wsc, wof, 0, colsum, k)
+        so, oo = torch.tensor([0.05], device=dev), torch.tensor([128.0], device=dev)
+        out = torch.empty(M, n, dtype=torch.uint8, device=dev)
+        row = {}
+        try:
+            for key, mode in (("per_wave", 0), ("expanded", 1)):
+                lib.mq_gemm_set_w4_mode(mode)
+                t = event_time(lambda: ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, None, [(so, oo)], out=out), 20)
+                row[key + "_us"] = round(t * 1e6, 2)
+        finally:
+            lib.mq_gemm_set_w4_mode(1)
+        ref = out.clone()
+        t8 = event_time(lambda: ops.int8_linear(a_t, w8, rs, alpha, wzp, ct, None, out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=255.0,
+                                                out_dtype=MQ_U8, out=out, a_tiled_rows=M), 20)
+        row["int8_image_us"] = round(t8 * 1e6, 2)
+        row["identical_indices"] = bool(torch.equal(ref, out))
+        row["frac_of_int8_peak_expanded"] = round(2.0 * M * n * k / (row["expanded_us"] * 1e-6) / 1e12 / INT8_MFMA_PEAK_TOPS, 4)
+        row["weight_bytes"] = {"packed": n * k // 2, "int8_image": n * k}
+        res[name] = row
+        del qw, x, a_t, packed, w8, out, ref
+        torch.cuda.empty_cache()
+    res["kernel"] = "mq::gemm_i8_frw4_kernel<.., true> (tools/gen_fr_asm.py frw4x / frw4x_128) via mq_w4a8_linear_tiled"
+    return res
 
 
 def bench_variants(dev, step, args):
@@ -1074,7 +1121,16 @@ def bench_variants(dev, step, args):
     extras["layer_prefill"] = bench_layer(dev)
     extras["layer_prefill_full"] = bench_layer_full(dev)
     torch.cuda.empty_cache()
-    extras["layer_prefill_full_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4)     # packed 4-bit per-channel weights
+    extras["layer_prefill_full_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4)     # 4-bit per-channel weights (int8 image at prefill)
+    import mobilequant_amd as _mq
+    _mq.QLinear.w4_prefill = "packed"          # ONE packed image per module (0.5 B / weight): q | k | v and w1 / w3 on mq_w4a8_linear_tiled
+    try:
+        r = bench_layer_full(dev, modes=("fused",), wbits=4)
+        extras["layer_prefill_full_w4a8_packed_only"] = {"fused_us": r.get("fused_us"), "note": "QLinear.w4_prefill = 'packed': every 4-bit module "
+                                                         "holds only the mq_pack_w4 image; q | k | v and w1 / w3 run the generated packed kernels, "
+                                                         "o_proj / w2 the packed tile kernel + a separate residual add"}
+    finally:
+        _mq.QLinear.w4_prefill = "image"
     # BASELINE.json configs[2] / [3] on their own leaf graphs (LayerNorm + biased q|k|v + 25 % rotary; head_dim 256 / MQA / GeGLU / FFN 16384)
     extras["layer_prefill_full_stablelm_2_1_6b"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=8, family="stablelm_2_1_6b")
     extras["layer_prefill_full_gemma_2b_w4a8"] = bench_layer_full(dev, modes=("fused", "composite"), wbits=4, family="gemma_2b")

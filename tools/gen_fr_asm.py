@@ -549,7 +549,7 @@ FB_NOCVT, FB_NOP, FB_NOST, FB_NOSWAP = (bool(os.environ.get("MQ_FR_FB_" + k)) fo
 
 def final_block(q, lq, stamp):
     NG = (FN + 3) // 4                                  # store groups of (up to) four 16-byte chunks
-    CAP = 5                                             # fillers behind one MFMA
+    CAP = int(os.environ.get("MQ_FR_CAP", "5"))         # fillers behind one MFMA
     EA = [V_E, V_P0]
     emit("; ==== final block: stages KT-2 and KT-1 column by column, the epilogue between the MFMAs")
     if stamp:
@@ -1328,6 +1328,12 @@ def epilogue_f32r():
 def program(nw, stamp):
     q = Queue()
     prologue(q, nw, stamp)
+    if os.environ.get("MQ_FR_PRIO"):       # what-if: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md)
+        lp = label("prio")
+        emit(f"s_cmp_lt_u32 %[wave], {NW // 2}")
+        emit(f"s_cbranch_scc1 {lp}")
+        emit("s_setprio 1")
+        emit(f"{lp}:")
     stage(q, 0, nw, first=DINIT)
     stage(q, 1, nw, dinit="wz" if DINIT else None)
     # steady state: pairs (t, t+1), t = 2, 4, ..., kt - 6;  pairs = (kt - 6) / 2  (>= 0)
