@@ -59,6 +59,23 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float inv_s) {
   const float q0 = __fmul_rn(x, inv_s);
   return __builtin_fmaf(__builtin_fmaf(-q0, s, x), inv_s, q0);
 }
+// The fast form needs a NORMAL reciprocal and no over / underflow in its intermediates.  tools/div_check.cpp sweeps every dividend for
+// divisors drawn over +-[2^-60, 2^60] (profiles/r04/div_check.log): inside that range it is the IEEE quotient on the quantizer's
+// domain; outside (a scale of 0, a denormal, inf, NaN, |s| beyond 2^+-60 -- nothing set_scale_offset_from_minmax's [1e-5, 1e6] clamp
+// (qmodule.py:58) produces, but a trained scale parameter or a C-ABI caller is not bound by it) the reciprocal is inf / denormal and
+// the fast form returns NaN where x / s is +-inf or finite.  The PUBLIC element-wise entry points (mq_fake_quant / mq_quantize and the
+// per-row weight grids of training: HBM-bound kernels, the select is free) therefore take the IEEE divide for such a scale
+// (div_by_scale_guarded, a per-tensor / per-row uniform choice).  The fused image kernels (norm, GEMV, decode, attention, tiled
+// quantize) are reached through static calibrated grids only and keep the unguarded form: with a scale outside the range their
+// indices saturate to qmin (NaN -> qmin) where the reference saturates to qmin or qmax -- a degenerate grid either way
+// (dequantised values are (q - o) * s with s = 0 / inf / NaN).
+__device__ __forceinline__ bool scale_in_fast_range(float s) {
+  const float a = __builtin_fabsf(s);
+  return a >= 0x1p-60f && a <= 0x1p60f;          // false for NaN
+}
+__device__ __forceinline__ float div_by_scale_guarded(float x, float s, float inv_s, bool fast) {
+  return fast ? div_by_scale(x, s, inv_s) : __fdiv_rn(x, s);
+}
 
 // Four activations -> the dword of their int8 image bytes (index - shift), for the image-only kernels.  index = clamp(rint(x / s) + o):
 // (rint(t) - t) + t, the reference's round_ste, IS rint(t) in fp32 for every t (|t| >= 0.5: rint(t) and t are within a factor of two,

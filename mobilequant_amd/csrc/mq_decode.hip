@@ -719,7 +719,10 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.ticket + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // RELEASE at agent scope: the partials above are already write-through (8-byte agent atomics, drained by the vmcnt wait
+    // and ordered for the whole workgroup by the barrier), which is what makes this correct on gfx950; the release gives the formal
+    // release -> acquire edge to the last split's fence below as well.  One L2 write-back per split workgroup, on the long-context path only.
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.ticket + h, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != (unsigned)(nsplit - 1)) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

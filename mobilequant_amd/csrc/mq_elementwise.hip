@@ -27,8 +27,8 @@ void set_error(const char* fmt, ...) {
 
 // ---- the reference's scalar expression tree ---------------------------------------------------
 // qmodule.py:286-287
-__device__ __forceinline__ float q_index(float x, float s, float inv_s, float o, float qmin, float qmax) {
-  float t = div_by_scale(x, s, inv_s);
+__device__ __forceinline__ float q_index(float x, float s, float inv_s, float o, float qmin, float qmax, bool fast = true) {
+  float t = div_by_scale_guarded(x, s, inv_s, fast);
   float r = rintf(t);
   float q = __fadd_rn(r, o);
   return fminf(fmaxf(q, qmin), qmax);          // NaN saturates to qmin: integer storage has no NaN
@@ -40,16 +40,16 @@ __device__ __forceinline__ float clamp_nan(float q, float lo, float hi) {
 }
 // round_ste (qmodule.py:17-21) is (round(t) - t) + t: exact for finite t, NaN for t = +-inf (inf - inf)
 __device__ __forceinline__ float round_ste(float t) { return __fadd_rn(__fsub_rn(rintf(t), t), t); }
-__device__ __forceinline__ float q_index_fq(float x, float s, float inv_s, float o, float qmin, float qmax) {
-  return clamp_nan(__fadd_rn(round_ste(div_by_scale(x, s, inv_s)), o), qmin, qmax);
+__device__ __forceinline__ float q_index_fq(float x, float s, float inv_s, float o, float qmin, float qmax, bool fast = true) {
+  return clamp_nan(__fadd_rn(round_ste(div_by_scale_guarded(x, s, inv_s, fast)), o), qmin, qmax);
 }
 // qmodule.py:290
 __device__ __forceinline__ float q_dequant(float q, float s, float o) { return __fmul_rn(__fsub_rn(q, o), s); }
 
 // fp16 tensor with 0-dim fp32 scale/offset: result rounded to half after every op (SURVEY 8a' item 4)
 __device__ __forceinline__ float h_round(float v) { return __half2float(__float2half_rn(v)); }
-__device__ __forceinline__ float q_index_hmath(float x, float s, float inv_s, float o, float qmin, float qmax) {
-  float t = h_round(div_by_scale(x, s, inv_s));
+__device__ __forceinline__ float q_index_hmath(float x, float s, float inv_s, float o, float qmin, float qmax, bool fast = true) {
+  float t = h_round(div_by_scale_guarded(x, s, inv_s, fast));
   float r = h_round(__fadd_rn(h_round(__fsub_rn(h_round(rintf(t)), t)), t));   // round_ste, one half rounding per op
   float q = h_round(__fadd_rn(r, o));
   return clamp_nan(q, qmin, qmax);      // qmin/qmax are exactly representable in half for <= 8 bits
@@ -119,10 +119,12 @@ __global__ void __launch_bounds__(256) fake_quant_vec_kernel(const T* __restrict
   using V = Vec16<T>;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float s = 0.f, o = 0.f, inv_s = 0.f;
+  bool fast = true;                               // mq_common.h: IEEE divide for a scale outside the fast form's range
   if (!PER_ROW) {
     s = scale[0];
     o = offset[0];
     inv_s = __fdiv_rn(1.0f, s);
+    fast = scale_in_fast_range(s);
   }
   const V* xv = reinterpret_cast<const V*>(x);
   V* yv = reinterpret_cast<V*>(y);
@@ -133,12 +135,13 @@ __global__ void __launch_bounds__(256) fake_quant_vec_kernel(const T* __restrict
       s = scale[row];
       o = offset[row];
       inv_s = __fdiv_rn(1.0f, s);
+      fast = scale_in_fast_range(s);
     }
     V r;
 #pragma unroll
     for (int j = 0; j < V::N; ++j) {
       float f = V::get(a, j);
-      float q = HMATH ? q_index_hmath(f, s, inv_s, o, qmin, qmax) : q_index_fq(f, s, inv_s, o, qmin, qmax);
+      float q = HMATH ? q_index_hmath(f, s, inv_s, o, qmin, qmax, fast) : q_index_fq(f, s, inv_s, o, qmin, qmax, fast);
       V::set(r, j, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
     }
     yv[i] = r;
@@ -156,8 +159,9 @@ __global__ void __launch_bounds__(256) fake_quant_scalar_kernel(const T* __restr
     int64_t row = PER_ROW ? i / cols : 0;
     float s = scale[row], o = offset[row];
     const float inv_s = __fdiv_rn(1.0f, s);
+    const bool fast = scale_in_fast_range(s);
     float f = ld<T>(x, i);
-    float q = HMATH ? q_index_hmath(f, s, inv_s, o, qmin, qmax) : q_index_fq(f, s, inv_s, o, qmin, qmax);
+    float q = HMATH ? q_index_hmath(f, s, inv_s, o, qmin, qmax, fast) : q_index_fq(f, s, inv_s, o, qmin, qmax, fast);
     st<T>(y, i, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
   }
 }
@@ -182,6 +186,7 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
   const float s = scale[PER_ROW ? row : 0];
   const float o = offset[PER_ROW ? row : 0];
   const float inv_s = __fdiv_rn(1.0f, s);
+  const bool fast = scale_in_fast_range(s);
   const T* xr = x + row * cols;
   QT* qr = q + row * cols;
   int acc = 0;
@@ -195,7 +200,7 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
       for (int j = 0; j < V::N; ++j) {
         float xv = V::get(a, j);
         if constexpr (CS) xv = __fdiv_rn(xv, chan_scale[i * V::N + j]);
-        float qi = q_index(xv, s, inv_s, o, qmin, qmax);
+        float qi = q_index(xv, s, inv_s, o, qmin, qmax, fast);
         int st_v = static_cast<int>(qi) - shift;
         acc += st_v;
         out[j] = static_cast<QT>(st_v);
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(256) quantize_rows_kernel(const T* __restrict_
     for (int64_t i = threadIdx.x; i < cols; i += 256) {
       float xv = ld<T>(xr, i);
       if constexpr (CS) xv = __fdiv_rn(xv, chan_scale[i]);
-      float qi = q_index(xv, s, inv_s, o, qmin, qmax);
+      float qi = q_index(xv, s, inv_s, o, qmin, qmax, fast);
       int st_v = static_cast<int>(qi) - shift;
       acc += st_v;
       qr[i] = static_cast<QT>(st_v);
@@ -244,6 +249,7 @@ __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float*
     const float s = scale[PER_ROW ? row : 0];
     const float o = offset[PER_ROW ? row : 0];
     const float inv_s = __fdiv_rn(1.0f, s);
+    const bool fast = scale_in_fast_range(s);
     const float* xr = x + row * cols;
     QT* qr = q + row * cols;
     int acc = 0;
@@ -264,7 +270,7 @@ __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float*
         uint32_t pk = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int st_v = static_cast<int>(q_index(f[d * 4 + e], s, inv_s, o, qmin, qmax)) - shift;
+          const int st_v = static_cast<int>(q_index(f[d * 4 + e], s, inv_s, o, qmin, qmax, fast)) - shift;
           acc += st_v;
           pk |= (static_cast<uint32_t>(st_v) & 0xffu) << (8 * e);
         }

@@ -35,7 +35,21 @@ def _grid(q: Optional[Q.Quantizer], keep: list) -> MqGrid:
         raise RuntimeError("DecodeEngine needs static per-tensor activation grids (set_scale_and_offset first)")
     s, o = q.scale.detach().float().contiguous(), q.offset.detach().float().contiguous()
     keep += [s, o]
+    if isinstance(keep, _Keep):
+        keep.sources.append((q, q.grid_token()))
     return MqGrid(s.data_ptr(), o.data_ptr(), float(q.qmin), float(q.qmax))
+
+
+class _Keep(list):
+    """Tensors the launch records point into, plus what they were derived from: (quantizer, grid_token) for every grid packed into a
+    constants line and (weight, version) for every weight image, so that the engine can tell when the model moved under it."""
+
+    def __init__(self):
+        super().__init__()
+        self.sources, self.weights = [], []
+
+    def stale(self) -> bool:
+        return any(q.grid_token() != t for q, t in self.sources) or any(Q._ver(w) != v for w, v in self.weights)
 
 
 class _Linear:
@@ -87,6 +101,8 @@ class _Linear:
                              for b, l in zip(biases, linears)]).contiguous()
         self.N, self.K = self.w.shape[0], linears[0].weight.shape[1]
         self.rows = [l.weight.shape[0] for l in linears]
+        self.sources = [(l.weight_quantizer, l.weight_quantizer.grid_token()) for l in linears]
+        self.weights = [(l.weight, Q._ver(l.weight)) for l in linears]
 
 
 class DecodeEngine:
@@ -99,7 +115,7 @@ class DecodeEngine:
         s = self.shape
         dev = next(model.parameters()).device
         self.dev, self.cache_len = dev, int(cache_len)
-        self._keep: list = []
+        self._prefetch = (prefetch, prefetch_delay_us)
         self.x = torch.zeros(s.hidden, device=dev)
         self.qkv = torch.zeros((s.heads + 2 * s.kv_heads) * s.head_dim, device=dev)
         self.attn_q = torch.zeros(s.heads * s.head_dim, dtype=torch.int8, device=dev)     # pv_bmm's output as o_proj's int8 image
@@ -129,6 +145,16 @@ class DecodeEngine:
         self.norm_b = model.norm.bias.detach().float().contiguous() if getattr(model.norm, "bias", None) is not None else None
         self.lm_w = model.lm_head.weight.detach().float().contiguous()
         self.lm_b = model.lm_head.bias.detach().float().contiguous() if model.lm_head.bias is not None else None
+        self.graph = None
+        self.graph_long = None
+        self._lower()
+
+    def _lower(self):
+        """Build the launch records from the model as it is now: weight images, epilogue vectors and one constants line per launch
+        (_pack) are SNAPSHOTS of the quantizers -- the kernels do not read through the module's scale / offset tensors."""
+        model, dev, s = self.model, self.dev, self.shape
+        prefetch, prefetch_delay_us = self._prefetch
+        self._keep = _Keep()
         self.phases = []          # (kind, ctypes struct) in launch order
         for q in model.modules():                 # grids set from act_dict.json sit on the host until a forward moves them
             if isinstance(q, Q.Quantizer) and q._has_grid() and q.scale.device != dev:
@@ -150,8 +176,27 @@ class DecodeEngine:
                 at.prefetch_delay = int(prefetch_delay_us * 100)
         self.weight_bytes = sum(p[1]._mq_bytes for p in self.phases if p[0] == "gemv")
         self.head_bytes = self.lm_w.numel() * 4
-        self.graph = None
-        self.graph_long = None
+
+    def grids_stale(self) -> bool:
+        """True when a quantizer grid or a weight the engine snapshotted has been changed since (in place or replaced)."""
+        return self._keep.stale()
+
+    def refresh_grids(self):
+        """Re-derive every weight image, epilogue vector and constants line from the model's current quantizers and re-record the
+        graph(s) if there were any.  The cached keys / values stay as they are: they are indices on the OLD qk_bmm / pv_bmm input
+        grids, so after a recalibration start the sequence again (reset() / prefill())."""
+        had_graph = self.graph is not None
+        self.graph = self.graph_long = None
+        self._lower()
+        if had_graph:
+            self.capture()
+        return self
+
+    def _sync_grids(self):
+        # checked where a sequence starts (capture / reset / prefill), not per step(): a token is 0.65 ms, the walk over ~500 grids
+        # is about as long.  A grid changed in the middle of a sequence is the caller's to announce with refresh_grids().
+        if self._keep.stale():
+            self.refresh_grids()
 
     # -- lowering ----------------------------------------------------------------------------------------------------------
     def _norm_args(self, norm, a: MqDecodeGemvArgs):
@@ -164,6 +209,9 @@ class DecodeEngine:
             raise RuntimeError("DecodeEngine: QRMSNorm (plain RMS form, no bias) or QLayerNorm layers only")
         wfq = Q._apply(norm.weight_quantizer, norm.weight.detach()).float().contiguous()
         self._keep.append(wfq)
+        self._keep.weights.append((norm.weight, Q._ver(norm.weight)))
+        if norm.weight_quantizer is not None and norm.weight_quantizer._has_grid():
+            self._keep.sources.append((norm.weight_quantizer, norm.weight_quantizer.grid_token()))
         a.norm_w, a.norm_in, a.eps = wfq.data_ptr(), _grid(norm.input_quantizer, self._keep), float(norm.eps)
         a.layernorm = int(ln)
         if ln and norm.bias is not None:
@@ -186,6 +234,8 @@ class DecodeEngine:
         a.w4 = int(lin.w4)
         a._mq_bytes = lin.N * lin.K // (2 if lin.w4 else 1)
         self._keep.append(lin)
+        self._keep.sources += lin.sources
+        self._keep.weights += lin.weights
         return a
 
     def _pack(self, grids) -> int:
@@ -284,7 +334,10 @@ class DecodeEngine:
 
     def capture(self):
         """Record one decode step (incl. the position increment) as a hipGraph; replay it with step().  With attn_splits=None and a
-        cache longer than LONG_FROM a second graph with the split attention launch is recorded; step() picks by position."""
+        cache longer than LONG_FROM a second graph with the split attention launch is recorded; step() picks by position.
+        Quantizers changed since the engine was built (recalibration, scale.copy_) are picked up here, in reset() and in prefill()."""
+        if self._keep.stale():
+            self._lower()
         tok0, pos0, hp0 = self.tok.clone(), self.pos.clone(), self._host_pos
         graphs = []
         for splits in ([self.attn_splits, self.LONG_SPLITS] if self.auto_splits and self.cache_len > self.LONG_FROM else [self.attn_splits]):
@@ -321,6 +374,7 @@ class DecodeEngine:
         self.set_position(n)
 
     def reset(self):
+        self._sync_grids()
         self.set_position(0)
         self.attn_ticket.zero_()
         for c in self.k_cache + self.v_cache:
@@ -353,6 +407,7 @@ class DecodeEngine:
         ids = torch.as_tensor([int(t) for t in context_ids], dtype=torch.long, device=self.dev).view(1, -1)
         S = ids.shape[1]
         assert 0 < S <= self.cache_len
+        self._sync_grids()
         raw = self.model.new_cache(1, S, device=self.dev)
         logits = self.model(ids, cache=raw)
         for li, layer in enumerate(self.model.layers):

@@ -147,6 +147,18 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         return out if resid is None else resid + out
     qk, pv = self.qk_bmm, self.pv_bmm
     B, S, _ = x.shape
+    if isinstance(cache, ImageCache):
+        # the kernel pads a chunk to a multiple of 64 rows and writes the padded K / vT rows into the cache: only the LAST chunk of a
+        # sequence may be ragged, and a chunk may only go where the previous one ended -- anything else would attend pad rows as keys
+        if pos != cache.filled:
+            raise RuntimeError(f"mobilequant_amd: image cache holds {cache.filled} positions, the chunk was fed at pos={pos} "
+                               "(chunks go in order, each where the previous one ended; new_image_cache() starts a new sequence)")
+        if pos % 64:
+            raise RuntimeError(f"mobilequant_amd: the previous chunk ended at position {pos}, not a multiple of 64: only the final chunk "
+                               "of a sequence may be ragged (its pad rows sit in the image cache behind it)")
+        if S < 2:
+            raise RuntimeError("mobilequant_amd: a one-token chunk is not served by the fused attention; feed it together with the "
+                               "chunk before it (65 tokens: one chunk of 65, not 64 + 1)")
     if (getattr(self, "fused_mode", "auto") == "off" or not x.is_cuda or x.dtype != torch.float32 or s.head_dim not in (64, 128, 256) or S < 2
             or (pos != 0 and not isinstance(cache, ImageCache)) or pos % 64 or not getattr(mask, "_mq_causal", False)
             or not isinstance(qk, Q.QMatMul) or not isinstance(pv, Q.QMatMul)
@@ -170,6 +182,7 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         cache = None
         if len(img.per_sequence) != B or pos + S > img.per_sequence[0]["rows"]:
             raise RuntimeError("mobilequant_amd: image cache built for another batch size or too short for this position")
+        img.filled = pos + S
     akw = [dict(head_dim=s.head_dim) if img is None else dict(head_dim=s.head_dim, cache=img.per_sequence[b], pos0=pos) for b in range(B)]
     fused_qkv = _qkv_indices(self, x) if cache is None and getattr(self, "fuse_qkv", True) else None
     if fused_qkv is not None:
@@ -366,6 +379,7 @@ class ImageCache:
 
     def __init__(self, per_sequence):
         self.per_sequence = per_sequence
+        self.filled = 0          # positions written so far (true length, without the pad rows of a ragged final chunk)
 
 
 class LlamaForCausalLM(nn.Module):
@@ -415,7 +429,9 @@ class LlamaForCausalLM(nn.Module):
     def new_image_cache(self, batch: int, length: int, device=None):
         """Cache for CHUNKED prefill through the fused attention (llama.fuse_attention / fuse_decoder_layer): per layer and sequence the
         int8 K / vT images the attention kernel keeps (ops.attention_image_cache).  Feed chunks with `model(ids[:, a:b], cache=c, pos=a)`,
-        a % 64 == 0; every chunk attends to all earlier ones.  (No counterpart in the reference: its context encoding is one forward.)"""
+        a % 64 == 0; every chunk attends to all earlier ones.  Chunks go in order, each at the position the previous one ended (checked: the cache
+        tracks its filled length); every chunk but the last has a length that is a multiple of 64, and no chunk is a single token (feed a
+        trailing token together with the chunk before it).  (No counterpart in the reference: its context encoding is one forward.)"""
         from . import ops
         s = self.shape
         device = device if device is not None else self.embed_tokens.weight.device

@@ -348,3 +348,104 @@ def test_packed_only_w4_mode_is_the_image_mode_bit_for_bit_at_full_depth(dev):
     finally:
         mq.QLinear.w4_prefill = "image"
     assert torch.equal(res["image"], res["packed"]), float((res["image"] - res["packed"]).abs().max())
+
+
+def test_decode_engine_notices_quantizers_changed_under_it(dev):
+    """The engine snapshots every grid into per-launch constants lines and every weight into an integer image: a grid
+    changed in place after the engine was built makes grids_stale() true, and the next reset() / prefill() / capture() re-lowers,
+    so that generate() is that of an engine built after the change, token for token and logit for logit."""
+    from conftest import load_npz
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd.decode import DecodeEngine
+    m, _ = _decode_model(dev)
+    ctx = load_npz("generate_case.npz")["context"].tolist()
+    eng = DecodeEngine(m, cache_len=64).capture()
+    before = eng.generate(ctx, 6)
+    logits_before = eng.logits.clone()
+    assert not eng.grids_stale()
+    with torch.no_grad():
+        m.layers[0].mlp.w2.input_quantizer.scale.mul_(1.7)           # in place: same tensor object, new version
+        q = m.layers[1].self_attn.qk_bmm.input2_quantizer            # replaced: the keys' cache grid
+        q.set_scale_offset_from_minmax(-3.0, 2.5)
+    assert eng.grids_stale()
+    after = eng.generate(ctx, 6)                                      # reset() inside picks the change up and re-records the graph
+    assert not eng.grids_stale() and eng.graph is not None
+    fresh = DecodeEngine(m, cache_len=64)
+    assert fresh.generate(ctx, 6) == after
+    assert torch.equal(fresh.logits, eng.logits)
+    assert not torch.equal(eng.logits, logits_before) or after != before
+    with torch.no_grad():
+        m.layers[0].mlp.w1.weight.mul_(1.01)                          # a weight image is a snapshot too
+    assert eng.grids_stale()
+    eng.refresh_grids()
+    assert not eng.grids_stale()
+
+
+def test_image_cache_rejects_out_of_order_and_ragged_non_final_chunks(dev):
+    """ImageCache tracks its filled length: a chunk goes where the previous one ended, only the final chunk may be ragged
+    (its pad rows sit in the cache behind it) and a one-token chunk is refused with a message instead of a wrong answer; a ragged
+    FINAL chunk (128 + 37) still reproduces the single forward bit for bit."""
+    import dataclasses
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd import llama
+    m, _ = _decode_model(dev)
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=256))
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    ids = torch.randint(3, m.shape.vocab, (1, 165), generator=torch.Generator().manual_seed(9)).to(dev)
+    with torch.no_grad():
+        assert llama.fuse_decoder_layer(m) == 2
+        whole = m(ids)
+        cache = m.new_image_cache(1, 192)
+        parts = [m(ids[:, :128], cache=cache, pos=0), m(ids[:, 128:], cache=cache, pos=128)]
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(parts, dim=1), whole)
+        assert cache[0].filled == 165
+        with pytest.raises(RuntimeError, match="only the final chunk"):
+            m(ids[:, :8], cache=cache, pos=165)                                  # behind a ragged chunk
+        cache = m.new_image_cache(1, 192)
+        m(ids[:, :64], cache=cache, pos=0)
+        with pytest.raises(RuntimeError, match="holds 64 positions"):
+            m(ids[:, 64:128], cache=cache, pos=128)                              # a hole
+        with pytest.raises(RuntimeError, match="one-token chunk"):
+            m(ids[:, 64:65], cache=cache, pos=64)
+
+
+def test_reciprocal_division_is_the_ieee_quotient_over_the_admitted_scale_range(dev, tmp_path):
+    """tools/div_check.cpp on this GPU: the one-correction reciprocal form every quantizer kernel uses (mq_common.h div_by_scale) gives
+    the IEEE quotient's bits on the quantizer's domain for 48 scales in [1e-5, 1e6] and 54 drawn over +-[2^-60, 2^60] (the range
+    scale_in_fast_range admits), every 251st fp32 dividend (the full 2^32 sweep is profiles/r04/div_check.log)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "div_check")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                    os.path.join(root, "tools", "div_check.cpp"), "-o", exe], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe, "251", "48"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "two corrections 0 mismatches, one correction 0" in r.stdout
+
+
+@pytest.mark.parametrize("scale", [0.0, 1e-41, 3e-20, 5e19, 1e30, float("inf"), float("nan"), -0.05, -2e-25])
+def test_public_quantizer_entry_points_take_the_ieee_divide_for_scales_outside_the_fast_range(dev, scale):
+    """mq_fake_quant / mq_quantize with a scale the reciprocal form cannot serve (0, denormal, beyond 2^+-60, inf, NaN): the
+    result is the reference expression's, evaluated by torch on the CPU in fp32 -- clamp(round_ste(x / s) + o) and its dequantised
+    value, NaN where the reference makes NaN -- per tensor and per row, vector and scalar kernels."""
+    from mobilequant_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 80, generator=g) * 3
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1e30, -1e30, 65504.0, 1.0])
+    for shape, sc in (((6, 80), torch.tensor([scale])), ((6, 80), torch.tensor([scale, 0.02, scale, 1.0, 0.5, scale])),
+                      ((6, 77), torch.tensor([scale]))):
+        xs = x[:, :shape[1]].contiguous()
+        off = torch.full_like(sc, 7.0)
+        s2, o2 = (sc.view(-1, 1), off.view(-1, 1)) if sc.numel() > 1 else (sc, off)
+        t = xs / s2
+        idx = torch.clamp((torch.round(t) - t) + t + o2, 0.0, 255.0)                     # qmodule.py:286-287 (clamp keeps NaN)
+        want = (idx - o2) * s2
+        got = ops.fake_quant(xs.to(dev), sc.to(dev), off.to(dev), 0.0, 255.0).cpu()
+        assert torch.equal(torch.nan_to_num(got, nan=12345.0), torch.nan_to_num(want, nan=12345.0)), (scale, shape, sc.numel())
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        q = ops.quantize(xs.to(dev), sc.to(dev), off.to(dev), 0.0, 255.0, q_dtype=ops.MQ_U8)
+        q = (q[0] if isinstance(q, tuple) else q).cpu()
+        # integer storage has no NaN: the index saturates (rint(t) + o clamped; an overflowed quotient -> qmin / qmax, NaN -> qmin)
+        want_i = torch.nan_to_num(torch.clamp(torch.round(t) + o2, 0.0, 255.0), nan=0.0).to(torch.uint8)
+        assert torch.equal(q, want_i), (scale, shape, sc.numel())
