@@ -111,6 +111,21 @@ int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, in
                            float qmax, float* grad_x, float* grad_scale, float* grad_offset,
                            mq_stream_t stream);
 
+/* f3: learnable weight clipping + per-row fake-quant of a weight, one pass per direction (fp32, rows of up to 16384 columns, a
+ * multiple of 4).  Replaces, per training forward of a weight quantizer in LWC mode (mobilellm/quantization/qmodule.py:133-185,
+ * :259-295 under algorithm.py:381 / :587): torch.amin / amax per output row (:263-268), sigmoid(bound factor) * range (:271-273; the
+ * caller passes sig_lo = sigmoid(lowbound_factor), sig_hi = sigmoid(upbound_factor), [rows]), compute_scale_offset_from_min_max
+ * (:40-61) and the fake-quant (:286-290) -- the same fp32 operations in the same order, bit-identical values.  Writes the row ranges
+ * and the grid ([rows] each) for the backward / for Quantizer.scale, .offset. */
+int mq_lwc_fake_quant(const float* w, int64_t rows, int64_t cols, const float* sig_lo, const float* sig_hi, int bitwidth,
+                      int is_symmetric, float* out, float* row_min, float* row_max, float* scale, float* offset, mq_stream_t stream);
+/* Backward of the above, what torch autograd derives for that chain: grad_w = the straight-through gradient (clamp mask) + the range
+ * gradients sent to each row's extreme element(s) (ties share evenly, as amin / amax do); grad_sig_lo / grad_sig_hi [rows].  The
+ * offset is -round(beta / scale) and carries no gradient (torch.round has none). */
+int mq_lwc_fake_quant_backward(const float* w, const float* grad_out, int64_t rows, int64_t cols, const float* sig_lo,
+                               const float* sig_hi, const float* row_min, const float* row_max, int bitwidth, int is_symmetric,
+                               float* grad_w, float* grad_sig_lo, float* grad_sig_hi, mq_stream_t stream);
+
 /* The integer index itself (qmodule.py:286-287) written as integers instead of being dequantised.
  * q_dtype MQ_I8: i8 storage (index - shift, see top);  MQ_U8 / MQ_I16 / MQ_U16 / MQ_I32: the plain
  * index.  row_sum (nullable, [rows] int32): sum over the row of the STORED values -- the

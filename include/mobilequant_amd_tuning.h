@@ -28,6 +28,9 @@ int mq_gemm_set_clock_probe(void* buf);
  * frw4x_128: the int8 kernel's loop), 0 = every wave splits the nibbles of its own fragments in registers (frw4 / frw4_128: one LDS read
  * per 16 columns and stage, 12 VALU per 4 MFMAs in every wave; measured 30 % slower).  Identical results. */
 int mq_gemm_set_w4_mode(int mode);
+/* Tile order of the 128-column generated kernels (residual / segmented GEMMs): M-tiles per group of the grouped order each XCD walks
+ * (0 = the built-in 4).  Traffic experiment of DESIGN.md 4.2.1 (L2 fetch bytes per XCD footprint); results do not depend on it. */
+int mq_gemm_set_group_m(int group_m);
 /* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
 /* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "mq_minmax_cols": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "mq_fake_quant": (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, _P]),
     "mq_fake_quant_backward": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, _P, _P, _P, _P]),
+    "mq_lwc_fake_quant": (c_int, [_P, c_int64, c_int64, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "mq_lwc_fake_quant_backward": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "mq_quantize": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, c_int, _P, _P, c_int, _P, _P]),
     "mq_linear_epilogue_prepare": (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "mq_w8a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
@@ -116,6 +118,7 @@ _SIGNATURES = {
     "mq_gemm_set_debug": (c_int, [c_int]),
     "mq_gemm_set_clock_probe": (c_int, [_P]),
     "mq_gemm_set_w4_mode": (c_int, [c_int]),
+    "mq_gemm_set_group_m": (c_int, [c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

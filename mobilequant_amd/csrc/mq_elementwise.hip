@@ -79,6 +79,8 @@ __global__ void scale_offset_kernel(const float* __restrict__ mn, const float* _
   offset[i] = -rintf(__fdiv_rn(beta, s));      // qmodule.py:60 ; symmetric -> -0.0f
 }
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
 // ---- a5: fake-quant, vectorised 16 B per lane ---------------------------------------------------
 template <typename T>
 struct Vec16;
@@ -163,6 +165,198 @@ __global__ void __launch_bounds__(256) fake_quant_scalar_kernel(const T* __restr
     float f = ld<T>(x, i);
     float q = HMATH ? q_index_hmath(f, s, inv_s, o, qmin, qmax, fast) : q_index_fq(f, s, inv_s, o, qmin, qmax, fast);
     st<T>(y, i, HMATH ? q_dequant_hmath(q, s, o) : q_dequant(q, s, o));
+  }
+}
+
+// ---- f3: learnable weight clipping + per-row fake-quant of a weight in ONE pass per direction -------------------------------
+// The e2equant / omniquant inner step (algorithm.py:187-233, :381, :587) re-derives every weight's grid from the weight itself on
+// every forward: amin / amax per output row (qmodule.py:263-268), sigmoid(bound factor) * range (:271-273), scale / offset (:40-61),
+// fake-quant (:286-290) -- as modules: a row reduction, ~12 [rows, 1]-sized launches, the fake-quant pass, and in the backward the
+// per-row STE pass, ~25 [rows, 1]-sized launches and EIGHT weight-sized passes that scatter the range gradients into the extreme
+// elements.  Here a workgroup owns a row, holds it in registers and does all of it: one read + one write of the weight forward, two
+// reads + one write backward.  Same fp32 operations in the same order as the module chain (scale_offset_kernel, q_index_fq,
+// fake_quant_bwd_kernel above), so forward values are bit-identical; the row sums of the backward associate differently (float4 per
+// thread) -- inside every gradient tolerance the goldens use.
+template <int VPT>
+struct LwcRow {
+  vf4 v[VPT];
+};
+
+__device__ __forceinline__ float block_reduce4(float v, float* s_part, int slot) {      // 256 threads; every thread gets the result
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_part[slot * 4 + w] = v;
+  __syncthreads();
+  return (s_part[slot * 4 + 0] + s_part[slot * 4 + 1]) + (s_part[slot * 4 + 2] + s_part[slot * 4 + 3]);
+}
+
+struct LwcGrid {
+  float lo, hi, scale, offset, alpha;
+};
+// sigmoid(bound) * range -> grid: qmodule.py:271-273 then :40-61 (scale_offset_kernel's expression)
+__device__ __forceinline__ LwcGrid lwc_grid(float mn, float mx, float sig_lo, float sig_hi, float qmax, int symmetric) {
+  LwcGrid g;
+  g.lo = __fmul_rn(sig_lo, mn);
+  g.hi = __fmul_rn(sig_hi, mx);
+  float beta;
+  if (symmetric) {
+    g.alpha = (g.lo != g.lo || g.hi != g.hi) ? __fadd_rn(g.lo, g.hi) : fmaxf(fabsf(g.lo), fabsf(g.hi));
+    beta = 0.0f;
+  } else {
+    g.alpha = __fsub_rn(g.hi, g.lo);
+    beta = g.lo;
+  }
+  g.scale = clamp_nan(__fdiv_rn(g.alpha, qmax), 1e-5f, 1e6f);
+  g.offset = -rintf(__fdiv_rn(beta, g.scale));
+  return g;
+}
+
+template <int VPT>
+__global__ void __launch_bounds__(256) lwc_fake_quant_kernel(const float* __restrict__ w, int cols, const float* __restrict__ sig_lo,
+                                                             const float* __restrict__ sig_hi, float qmin, float qmax, int symmetric,
+                                                             float* __restrict__ out, float* __restrict__ row_min,
+                                                             float* __restrict__ row_max, float* __restrict__ scale,
+                                                             float* __restrict__ offset) {
+  __shared__ float s_mn[4], s_mx[4];
+  __shared__ int s_nan[4];
+  const int64_t row = blockIdx.x;
+  const int nvec = cols >> 2;
+  const vf4* wr = reinterpret_cast<const vf4*>(w + row * cols);
+  LwcRow<VPT> r;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < nvec) r.v[k] = __builtin_nontemporal_load(wr + i);
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  int nan = 0;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (threadIdx.x + 256 * k < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = r.v[k][e];
+        mn = fminf(mn, x);
+        mx = fmaxf(mx, x);
+        nan |= (x != x);
+      }
+    }
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  nan = __builtin_amdgcn_ballot_w64(nan != 0) != 0;
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_mn[wv] = mn;
+    s_mx[wv] = mx;
+    s_nan[wv] = nan;
+  }
+  __syncthreads();
+  mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+  mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+  if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");         // amin / amax propagate NaN
+  const LwcGrid g = lwc_grid(mn, mx, sig_lo[row], sig_hi[row], qmax, symmetric);
+  if (threadIdx.x == 0) {
+    row_min[row] = mn;
+    row_max[row] = mx;
+    scale[row] = g.scale;
+    offset[row] = g.offset;
+  }
+  const float inv_s = __fdiv_rn(1.0f, g.scale);
+  const bool fast = scale_in_fast_range(g.scale);
+  vf4* orow = reinterpret_cast<vf4*>(out + row * cols);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < nvec) {
+      vf4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = q_dequant(q_index_fq(r.v[k][e], g.scale, inv_s, g.offset, qmin, qmax, fast), g.scale, g.offset);
+      orow[i] = y;                                     // read back by the GEMM that follows: a normal store
+    }
+  }
+}
+
+// Backward: grad_w = STE-masked grad_out + the range gradients scattered into the row's extreme elements (ties share evenly: what
+// torch's amin / amax backward does); grad_sig_lo / grad_sig_hi [rows] for sigmoid(lowbound_factor) / sigmoid(upbound_factor).
+// The offset is -round(beta / scale): no gradient reaches the range through it (torch.round has none).
+template <int VPT>
+__global__ void __launch_bounds__(256) lwc_fake_quant_bwd_kernel(const float* __restrict__ w, const float* __restrict__ gy, int cols,
+                                                                 const float* __restrict__ sig_lo, const float* __restrict__ sig_hi,
+                                                                 const float* __restrict__ row_min, const float* __restrict__ row_max,
+                                                                 float qmin, float qmax, int symmetric, float* __restrict__ gw,
+                                                                 float* __restrict__ g_sig_lo, float* __restrict__ g_sig_hi) {
+  __shared__ float s_part[12];
+  const int64_t row = blockIdx.x;
+  const int nvec = cols >> 2;
+  const vf4* wr = reinterpret_cast<const vf4*>(w + row * cols);
+  const vf4* gr = reinterpret_cast<const vf4*>(gy + row * cols);
+  LwcRow<VPT> x, g;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < nvec) {
+      x.v[k] = __builtin_nontemporal_load(wr + i);
+      g.v[k] = __builtin_nontemporal_load(gr + i);
+    }
+  }
+  const float mn = row_min[row], mx = row_max[row], slo = sig_lo[row], shi = sig_hi[row];
+  const LwcGrid gd = lwc_grid(mn, mx, slo, shi, qmax, symmetric);
+  const float s = gd.scale, o = gd.offset;
+  float acc_s = 0.f, n_mn = 0.f, n_mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (threadIdx.x + 256 * k < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xv = x.v[k][e], gv = g.v[k][e];
+        const float t = __fdiv_rn(xv, s);
+        const float r = round_ste(t);
+        const float q = __fadd_rn(r, o);
+        const bool inside = q >= qmin && q <= qmax;
+        const float qc = clamp_nan(q, qmin, qmax);
+        acc_s += inside ? gv * (r - t) : gv * (qc - o);
+        g.v[k][e] = inside ? __fdiv_rn(__fmul_rn(gv, s), s) : 0.f;
+        n_mn += (xv == mn) ? 1.f : 0.f;
+        n_mx += (xv == mx) ? 1.f : 0.f;
+      }
+    }
+  }
+  const float g_scale = block_reduce4(wave_sum_f32_dpp(acc_s), s_part, 0);
+  n_mn = block_reduce4(wave_sum_f32_dpp(n_mn), s_part, 1);
+  n_mx = block_reduce4(wave_sum_f32_dpp(n_mx), s_part, 2);
+  // scale = clamp(alpha / qmax): the clamp passes the gradient inside [CLIPMIN, CLIPMAX] (bounds included, as torch.clamp does)
+  const float raw = __fdiv_rn(gd.alpha, qmax);
+  const float g_alpha = (raw >= 1e-5f && raw <= 1e6f) ? __fdiv_rn(g_scale, qmax) : 0.f;
+  float g_lo, g_hi;
+  if (symmetric) {                                     // alpha = maximum(|lo|, |hi|): the larger takes it, a tie halves it; d|v| = sign(v)
+    const float alo = fabsf(gd.lo), ahi = fabsf(gd.hi);
+    const float share_lo = alo > ahi ? 1.f : (alo == ahi ? 0.5f : 0.f), share_hi = ahi > alo ? 1.f : (alo == ahi ? 0.5f : 0.f);
+    const float sg_lo = gd.lo > 0.f ? 1.f : (gd.lo < 0.f ? -1.f : 0.f), sg_hi = gd.hi > 0.f ? 1.f : (gd.hi < 0.f ? -1.f : 0.f);
+    g_lo = __fmul_rn(__fmul_rn(g_alpha, share_lo), sg_lo);
+    g_hi = __fmul_rn(__fmul_rn(g_alpha, share_hi), sg_hi);
+  } else {                                             // alpha = hi - lo
+    g_lo = -g_alpha;
+    g_hi = g_alpha;
+  }
+  if (threadIdx.x == 0) {
+    g_sig_lo[row] = __fmul_rn(g_lo, mn);               // lo = sig_lo * mn
+    g_sig_hi[row] = __fmul_rn(g_hi, mx);
+  }
+  const float add_mn = __fdiv_rn(__fmul_rn(g_lo, slo), n_mn), add_mx = __fdiv_rn(__fmul_rn(g_hi, shi), n_mx);
+  vf4* orow = reinterpret_cast<vf4*>(gw + row * cols);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < nvec) {
+      vf4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xv = x.v[k][e];
+        const float scat = __fadd_rn(xv == mn ? add_mn : 0.f, xv == mx ? add_mx : 0.f);   // is_mn * (g_mn / n_mn) + is_mx * (g_mx / n_mx)
+        y[e] = __fadd_rn(g.v[k][e], scat);
+      }
+      orow[i] = y;
+    }
   }
 }
 
@@ -289,6 +483,65 @@ __global__ void __launch_bounds__(256) quantize_rows_f32_b16_kernel(const float*
 // One workgroup per row (per-row grids) or a grid-stride slab (per-tensor); grad_scale / grad_offset are
 // accumulated with float atomics into zero-initialised outputs (one pair of atomics per workgroup).
 __device__ __forceinline__ float wave_sum_f(float v) { return wave_sum_f32_dpp(v); }
+
+// Per-tensor grid, 16-byte loads / stores, four vectors per thread in flight: the training step's largest tensors (the [heads, S, S]
+// scores and probabilities, 0.5 GB each at S = 2048) go through this pass, which is HBM-bound only if enough loads are outstanding
+// (the scalar kernel below, capped at 512 workgroups, reached 2.3 TB/s).  Same per-element expression tree as the scalar kernel.
+__global__ void __launch_bounds__(256) fake_quant_bwd_vec_kernel(const vf4* __restrict__ x, const vf4* __restrict__ gy, int64_t nvec,
+                                                                 const float* __restrict__ scale, const float* __restrict__ offset,
+                                                                 float qmin, float qmax, vf4* __restrict__ gx,
+                                                                 float* __restrict__ gscale, float* __restrict__ goffset) {
+  __shared__ float s_gs[4], s_go[4];
+  const float s = scale[0], o = offset[0];
+  float acc_s = 0.f, acc_o = 0.f;
+  auto one = [&](float xv, float g) -> float {
+    const float t = __fdiv_rn(xv, s);
+    const float r = round_ste(t);
+    const float q = __fadd_rn(r, o);
+    const bool inside = q >= qmin && q <= qmax;
+    const float qc = clamp_nan(q, qmin, qmax);
+    acc_s += inside ? g * (r - t) : g * (qc - o);
+    acc_o += inside ? 0.f : -g * s;
+    return inside ? __fdiv_rn(__fmul_rn(g, s), s) : 0.f;            // (g*s) * mask / s, as autograd chains it
+  };
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < nvec; i0 += stride * U) {
+    vf4 xv[U], gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < nvec) {
+        xv[u] = __builtin_nontemporal_load(x + i);
+        gv[u] = __builtin_nontemporal_load(gy + i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < nvec) {
+        vf4 r;
+        r.x = one(xv[u].x, gv[u].x);
+        r.y = one(xv[u].y, gv[u].y);
+        r.z = one(xv[u].z, gv[u].z);
+        r.w = one(xv[u].w, gv[u].w);
+        __builtin_nontemporal_store(r, gx + i);
+      }
+    }
+  }
+  acc_s = wave_sum_f(acc_s);
+  acc_o = wave_sum_f(acc_o);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_gs[w] = acc_s;
+    s_go[w] = acc_o;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(gscale, (s_gs[0] + s_gs[1]) + (s_gs[2] + s_gs[3]));
+    atomicAdd(goffset, (s_go[0] + s_go[1]) + (s_go[2] + s_go[3]));
+  }
+}
 
 template <bool PER_ROW>
 __global__ void __launch_bounds__(256) fake_quant_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
@@ -658,13 +911,72 @@ int mq_fake_quant_backward(const float* x, const float* grad_y, int64_t rows, in
     fake_quant_bwd_kernel<true><<<(unsigned)rows, 256, 0, as_stream(stream)>>>(x, grad_y, rows, cols, scale, offset, qmin,
                                                                              qmax, grad_x, grad_scale, grad_offset);
   } else {
-    int64_t g = (rows * cols + 1023) / 1024;
+    const int64_t numel = rows * cols;
+    if (numel >= (1 << 16) && numel % 4 == 0 && aligned(x, 16) && aligned(grad_y, 16) && aligned(grad_x, 16)) {
+      int64_t gv = (numel / 4 + 1023) / 1024;      // four 16-byte vectors per thread and sweep
+      if (gv > 2048) gv = 2048;                    // 8 workgroups per CU; 2 048 pairs of same-address atomics at most
+      fake_quant_bwd_vec_kernel<<<(unsigned)gv, 256, 0, as_stream(stream)>>>((const vf4*)x, (const vf4*)grad_y, numel / 4, scale, offset,
+                                                                            qmin, qmax, (vf4*)grad_x, grad_scale, grad_offset);
+      MQ_LAUNCH_CHECK("mq_fake_quant_backward");
+      return MQ_OK;
+    }
+    int64_t g = (numel + 1023) / 1024;
     if (g < 1) g = 1;
     if (g > 512) g = 512;     // 512 pairs of same-address atomics at most
     fake_quant_bwd_kernel<false><<<(unsigned)g, 256, 0, as_stream(stream)>>>(x, grad_y, rows, cols, scale, offset, qmin,
                                                                            qmax, grad_x, grad_scale, grad_offset);
   }
   MQ_LAUNCH_CHECK("mq_fake_quant_backward");
+  return MQ_OK;
+}
+
+int mq_lwc_fake_quant(const float* w, int64_t rows, int64_t cols, const float* sig_lo, const float* sig_hi, int bitwidth,
+                      int is_symmetric, float* out, float* row_min, float* row_max, float* scale, float* offset, mq_stream_t stream) {
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && rows < (int64_t)0x7fffffff, "mq_lwc_fake_quant: bad shape %lld x %lld", (long long)rows, (long long)cols);
+  MQ_REQUIRE(bitwidth >= 2 && bitwidth <= 16, "mq_lwc_fake_quant: bitwidth=%d", bitwidth);
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(w && sig_lo && sig_hi && out && row_min && row_max && scale && offset, "mq_lwc_fake_quant: null pointer");
+  MQ_REQUIRE(cols % 4 == 0 && cols <= 16384 && aligned(w, 16) && aligned(out, 16),
+             "mq_lwc_fake_quant: rows of up to 16384 columns, a multiple of 4, 16-byte aligned (cols=%lld)", (long long)cols);
+  const float qmin = is_symmetric ? -(float)(1 << (bitwidth - 1)) : 0.0f;
+  const float qmax = is_symmetric ? (float)((1 << (bitwidth - 1)) - 1) : (float)((1 << bitwidth) - 1);
+  hipStream_t st = as_stream(stream);
+#define MQ_LWC(V)                                                                                                              \
+  lwc_fake_quant_kernel<V><<<(unsigned)rows, 256, 0, st>>>(w, (int)cols, sig_lo, sig_hi, qmin, qmax, is_symmetric, out, row_min, \
+                                                         row_max, scale, offset)
+  if (cols <= 2048) MQ_LWC(2);
+  else if (cols <= 4096) MQ_LWC(4);
+  else if (cols <= 6144) MQ_LWC(6);
+  else if (cols <= 8192) MQ_LWC(8);
+  else MQ_LWC(16);
+#undef MQ_LWC
+  MQ_LAUNCH_CHECK("mq_lwc_fake_quant");
+  return MQ_OK;
+}
+
+int mq_lwc_fake_quant_backward(const float* w, const float* grad_out, int64_t rows, int64_t cols, const float* sig_lo,
+                               const float* sig_hi, const float* row_min, const float* row_max, int bitwidth, int is_symmetric,
+                               float* grad_w, float* grad_sig_lo, float* grad_sig_hi, mq_stream_t stream) {
+  MQ_REQUIRE(rows >= 0 && cols >= 0 && rows < (int64_t)0x7fffffff, "mq_lwc_fake_quant_backward: bad shape");
+  MQ_REQUIRE(bitwidth >= 2 && bitwidth <= 16, "mq_lwc_fake_quant_backward: bitwidth=%d", bitwidth);
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(w && grad_out && sig_lo && sig_hi && row_min && row_max && grad_w && grad_sig_lo && grad_sig_hi,
+             "mq_lwc_fake_quant_backward: null pointer");
+  MQ_REQUIRE(cols % 4 == 0 && cols <= 16384 && aligned(w, 16) && aligned(grad_out, 16) && aligned(grad_w, 16),
+             "mq_lwc_fake_quant_backward: rows of up to 16384 columns, a multiple of 4, 16-byte aligned (cols=%lld)", (long long)cols);
+  const float qmin = is_symmetric ? -(float)(1 << (bitwidth - 1)) : 0.0f;
+  const float qmax = is_symmetric ? (float)((1 << (bitwidth - 1)) - 1) : (float)((1 << bitwidth) - 1);
+  hipStream_t st = as_stream(stream);
+#define MQ_LWC(V)                                                                                                               \
+  lwc_fake_quant_bwd_kernel<V><<<(unsigned)rows, 256, 0, st>>>(w, grad_out, (int)cols, sig_lo, sig_hi, row_min, row_max, qmin, qmax, \
+                                                             is_symmetric, grad_w, grad_sig_lo, grad_sig_hi)
+  if (cols <= 2048) MQ_LWC(2);
+  else if (cols <= 4096) MQ_LWC(4);
+  else if (cols <= 6144) MQ_LWC(6);
+  else if (cols <= 8192) MQ_LWC(8);
+  else MQ_LWC(16);
+#undef MQ_LWC
+  MQ_LAUNCH_CHECK("mq_lwc_fake_quant_backward");
   return MQ_OK;
 }
 

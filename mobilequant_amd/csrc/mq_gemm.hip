@@ -81,6 +81,7 @@ struct GemmArgs {
   const int8_t* gate_table;     // [256][256] (mq_gated_table)
   int8_t* gate_q;               // w2's input image, fragment-blocked [ceil16(M), N]
   int32_t* gate_rowsum;         // [M], zeroed by the first launch
+  int group_m;                  // tile order: M-tiles per group (0 = 4); mq_gemm_set_group_m, fr128 family only (traffic experiments)
 };
 
 #ifndef MQ_PP_PRIO
@@ -88,13 +89,14 @@ struct GemmArgs {
 #endif
 
 constexpr int BK = 128;   // bytes of K per LDS stage (two MFMA k-steps of 64)
+static std::atomic<int> g_group_m{0};   // mobilequant_amd_tuning.h: M-tiles per group of the fr128 family's tile order (0 = 4)
 
 // Bijective XCD-aware remap of the linear block id, then grouped (GROUP_M tall) tile order.
-__device__ __forceinline__ void tile_of_block(int bid, int nblk, int grid_m, int grid_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_of_block(int bid, int nblk, int grid_m, int grid_n, int& tm, int& tn, int group_m = 0) {
   const int q = nblk >> 3, r = nblk & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  constexpr int GROUP_M = 4;
+  const int GROUP_M = group_m > 0 ? group_m : 4;
   const int per_group = GROUP_M * grid_n;
   const int g = L / per_group;
   const int first_m = g * GROUP_M;
@@ -851,7 +853,7 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
-  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn);
+  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn, args.group_m);
   const int m0 = tm * BMT, n0 = tn * BNT;
   const int M = args.M, N = args.N, K = args.K;
   const int KT = K / BK;
@@ -964,6 +966,7 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
   if (a.bias == nullptr) a.bias = a.alpha;
   a.grid_m = (a.M + BMT - 1) / BMT;
   a.grid_n = a.N / BNT;
+  a.group_m = g_group_m.load();
   gemm_i8_fr128_kernel<VAR><<<a.grid_m * a.grid_n, (VAR == FR128R || VAR == FR160) ? 256 : 512, LDS, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
@@ -1454,6 +1457,11 @@ extern "C" {
 int mq_gemm_set_variant(int variant) {
   g_forced_variant = (variant >= 0 && variant < kNumVariants) ? variant : -1;
   return kNumVariants;
+}
+
+int mq_gemm_set_group_m(int group_m) {
+  g_group_m = group_m;
+  return 0;
 }
 
 int mq_gemm_set_w4_mode(int mode) {

@@ -183,6 +183,40 @@ def _chan(chan_scale, cols: int, x: torch.Tensor):
     return cs
 
 
+def lwc_fake_quant_supported(w: torch.Tensor) -> bool:
+    return (w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] % 4 == 0 and 0 < w.shape[1] <= 16384
+            and w.is_contiguous() and w.data_ptr() % 16 == 0)
+
+
+def lwc_fake_quant(w: torch.Tensor, sig_lo: torch.Tensor, sig_hi: torch.Tensor, bitwidth: int, is_symmetric: bool):
+    """Per-row range -> sigmoid(bound) * range -> grid -> fake-quant of a weight [N, K] in one pass (mq_lwc_fake_quant).
+    Returns (w_q, row_min, row_max, scale, offset), the last four [N]."""
+    w = _f32(_dev(w, "w"), "w")
+    N, K = w.shape
+    lo, hi = _f32(sig_lo, "sig_lo").reshape(-1), _f32(sig_hi, "sig_hi").reshape(-1)
+    if lo.numel() != N or hi.numel() != N:
+        raise RuntimeError("mobilequant_amd: lwc_fake_quant needs one bound factor per output row")
+    out = torch.empty_like(w)
+    mn, mx, sc, of = (torch.empty(N, dtype=torch.float32, device=w.device) for _ in range(4))
+    with _on(w, lo, hi):
+        _lib.call("mq_lwc_fake_quant", w.data_ptr(), N, K, lo.data_ptr(), hi.data_ptr(), int(bitwidth), int(bool(is_symmetric)),
+                  out.data_ptr(), mn.data_ptr(), mx.data_ptr(), sc.data_ptr(), of.data_ptr(), _stream())
+    return out, mn, mx, sc, of
+
+
+def lwc_fake_quant_backward(w, grad_out, sig_lo, sig_hi, row_min, row_max, bitwidth: int, is_symmetric: bool):
+    """(grad_w, grad_sig_lo, grad_sig_hi) of lwc_fake_quant (mq_lwc_fake_quant_backward)."""
+    w, g = _f32(_dev(w, "w"), "w"), _f32(_dev(grad_out, "grad_out"), "grad_out")
+    N, K = w.shape
+    lo, hi = _f32(sig_lo, "sig_lo").reshape(-1), _f32(sig_hi, "sig_hi").reshape(-1)
+    gw = torch.empty_like(w)
+    glo, ghi = torch.empty(N, dtype=torch.float32, device=w.device), torch.empty(N, dtype=torch.float32, device=w.device)
+    with _on(w, g, lo, hi, row_min, row_max):
+        _lib.call("mq_lwc_fake_quant_backward", w.data_ptr(), g.data_ptr(), N, K, lo.data_ptr(), hi.data_ptr(), row_min.data_ptr(),
+                  row_max.data_ptr(), int(bitwidth), int(bool(is_symmetric)), gw.data_ptr(), glo.data_ptr(), ghi.data_ptr(), _stream())
+    return gw, glo, ghi
+
+
 def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, *,
              q_dtype: int = MQ_I8, shift: int = 0, rows: Optional[int] = None, want_row_sum: bool = False,
              chan_scale: Optional[torch.Tensor] = None):

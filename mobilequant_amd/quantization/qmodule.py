@@ -176,6 +176,29 @@ class _FakeQuantFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None), gs, go, None, None
 
 
+class _LwcFakeQuantFn(torch.autograd.Function):
+    """A weight quantizer in LWC mode, per output row, as ONE HIP pass per direction (mq_lwc_fake_quant / _backward): the row
+    ranges (qmodule.py:263-268), sigmoid(bound factor) * range (:271-273), the grid (:40-61) and the fake-quant (:286-290)
+    forward; the straight-through gradient plus the range gradients scattered into the extreme elements backward -- what
+    ``_RangeFn`` + the [rows, 1]-sized torch chain + ``_FakeQuantFn`` compute in ~40 launches and eight weight-sized passes
+    (the e2equant inner step re-derives seven such grids per layer and step, algorithm.py:187-233, :742-747)."""
+
+    @staticmethod
+    def forward(ctx, w, sig_lo, sig_hi, bitwidth, is_symmetric):
+        y, mn, mx, scale, offset = ops.lwc_fake_quant(w.detach(), sig_lo.detach(), sig_hi.detach(), bitwidth, is_symmetric)
+        ctx.save_for_backward(w, sig_lo, sig_hi, mn, mx)
+        ctx.cfg = (bitwidth, is_symmetric)
+        ctx.mark_non_differentiable(scale, offset)
+        return y, scale, offset
+
+    @staticmethod
+    def backward(ctx, grad_y, _gs, _go):
+        w, sig_lo, sig_hi, mn, mx = ctx.saved_tensors
+        gw, glo, ghi = ops.lwc_fake_quant_backward(w.detach(), grad_y.contiguous(), sig_lo.detach(), sig_hi.detach(), mn, mx, *ctx.cfg)
+        return (gw if ctx.needs_input_grad[0] else None, glo.reshape(sig_lo.shape) if ctx.needs_input_grad[1] else None,
+                ghi.reshape(sig_hi.shape) if ctx.needs_input_grad[2] else None, None, None)
+
+
 class _RangeFn(torch.autograd.Function):
     """min / max of a weight as the reference's ``torch.amin`` / ``torch.amax`` (qmodule.py:263-268) with their gradient:
     the forward is the single-pass HIP reduction; the backward sends the gradient of a row's (or the tensor's) min / max to
@@ -214,6 +237,7 @@ class Quantizer(nn.Module):
         super().__init__()
         self.qcfg = deepcopy(qcfg)
         self.lwc = False
+        self.lwc_fused = True         # LWC forward / backward as one HIP pass each where the shape allows (False: the module chain, for A/B)
         self.enable = True
         self._gen = 0                 # bumped whenever (scale, offset) are re-created: cache keys never rely on addresses
 
@@ -338,6 +362,17 @@ class Quantizer(nn.Module):
         if self.offset.device != x2.device:
             self.offset.data = self.offset.to(x2.device)
 
+    def _set_transient_grid(self, scale, offset):
+        """What _prepare leaves behind in LWC mode (set_scale_offset_from_minmax with cache_mode None): plain tensors, a new generation."""
+        self.qmin, self.qmax = _grid_limits(self.qcfg.bitwidth, self.qcfg.is_symmetric)
+        self._gen = getattr(self, "_gen", 0) + 1
+        for name in ("scale", "offset"):
+            if hasattr(self, name):
+                delattr(self, name)
+        self.scale, self.offset = scale, offset
+        self._host_range = None
+        self._auto_grid = (self._gen, _ver(self.scale), _ver(self.offset))
+
     def auto_grid_untouched(self) -> bool:
         """True while (scale, offset) are exactly what the first forward derived from the tensor it quantised: not set from ranges, not
         loaded (load_state_dict copies into the existing tensors and bumps their versions), not stepped by an optimizer."""
@@ -359,6 +394,13 @@ class Quantizer(nn.Module):
             return input_
         grouped = self.qcfg.is_per_channel and self.qcfg.group_size != -1
         x = input_.reshape(-1, self.qcfg.group_size) if grouped else input_
+        if (self.lwc and getattr(self, "lwc_fused", True) and self.qcfg.is_per_channel and x.dim() == 2 and x.shape[1] >= 64
+                and self.upbound_factor.numel() == x.shape[0] and ops.lwc_fake_quant_supported(x)):
+            # one pass per direction instead of range reduction + ~12 [rows, 1]-sized launches + fake-quant (and ~35 launches backward)
+            y, scale, offset = _LwcFakeQuantFn.apply(x, torch.sigmoid(self.lowbound_factor), torch.sigmoid(self.upbound_factor),
+                                                     int(self.qcfg.bitwidth), bool(self.qcfg.is_symmetric))
+            self._set_transient_grid(scale.view(-1, 1), offset.view(-1, 1))
+            return y.reshape(input_.shape) if grouped else _tag_grid(y, self)
         self._prepare(x, use_scale_offset_as)
         if _needs_grad(x, self.scale, self.offset):
             y = _FakeQuantFn.apply(x, self.scale, self.offset, self.qmin, self.qmax)

@@ -449,3 +449,75 @@ def test_public_quantizer_entry_points_take_the_ieee_divide_for_scales_outside_t
         # integer storage has no NaN: the index saturates (rint(t) + o clamped; an overflowed quotient -> qmin / qmax, NaN -> qmin)
         want_i = torch.nan_to_num(torch.clamp(torch.round(t) + o2, 0.0, 255.0), nan=0.0).to(torch.uint8)
         assert torch.equal(q, want_i), (scale, shape, sc.numel())
+
+
+@pytest.mark.parametrize("rows,cols,bits,sym", [(64, 2048, 4, False), (33, 5632, 4, False), (16, 1024, 8, False), (48, 2048, 4, True),
+                                                 (8, 16384, 4, False), (20, 3072, 8, True), (12, 64, 4, False)])
+def test_fused_lwc_pass_is_the_reference_expression_forward_bit_for_bit_and_its_autograd(dev, rows, cols, bits, sym):
+    """mq_lwc_fake_quant / _backward (one HIP pass per direction) against the reference's expression evaluated by torch on the CPU in
+    fp32 with autograd -- amin / amax per row (qmodule.py:263-268), sigmoid(bound) * range (:271-273), the grid (:40-61), round_ste
+    and the fake-quant (:17-21, :286-290): forward values and the grid bit-identical; gradients of the weight (and so of a LET
+    scale upstream), and of both sigmoid(bound factor) vectors equal up to the association of the row sums.  Rows with tied extremes,
+    an all-zero row (scale at CLIPMIN: the clamp blocks the gradient) and a constant row included.  (The module chain the pass
+    replaces evaluated alpha / q_max on the GPU as torch does for a Python scalar divisor -- alpha * (1 / q_max) -- and so sat one ulp
+    off the reference's CPU arithmetic on some rows; the pass uses the true quotient, like mq_scale_offset_from_minmax.)"""
+    from mobilequant_amd.quantization import qmodule as Q
+    g = torch.Generator().manual_seed(rows * 7 + cols + bits)
+    w0 = (torch.randn(rows, cols, generator=g) * 0.05)
+    w0[1, 5] = w0[1, 9] = w0[1].max() + 0.01                       # tie at the maximum
+    w0[2, 3] = w0[2, 40] = w0[2, 41] = w0[2].min() - 0.02          # three-way tie at the minimum
+    w0[3] = 0.0                                                    # degenerate range
+    w0[4] = 0.037                                                  # constant row: every element is both extreme
+    col0 = 1.0 + 0.2 * torch.randn(cols, generator=g)              # a LET scale upstream of the quantizer
+    gy = torch.randn(rows, cols, generator=g)
+    sig_lo0 = torch.sigmoid(torch.linspace(4.5, 0.5, rows)).view(-1, 1)
+    sig_hi0 = torch.sigmoid(torch.linspace(1.0, 5.0, rows)).view(-1, 1)
+    qmin, qmax = Q._grid_limits(bits, sym)
+
+    def leaves(device):
+        return [t.clone().to(device).requires_grad_(True) for t in (col0, sig_lo0, sig_hi0)]
+    # the reference's expression, CPU fp32
+    col, slo, shi = leaves("cpu")
+    temp = w0 * col.view(1, -1)
+    lo, hi = slo * temp.amin(-1, keepdim=True), shi * temp.amax(-1, keepdim=True)
+    alpha, beta = (torch.maximum(lo.abs(), hi.abs()), 0 * lo) if sym else (hi - lo, lo)
+    scale = (alpha / qmax).clamp(min=1e-5, max=1e6)
+    offset = -(beta / scale).round()
+    t = temp / scale
+    want = ((((t.round() - t).detach() + t) + offset).clamp(qmin, qmax) - offset) * scale
+    (want * gy).sum().backward()
+    # the HIP pass
+    colg, slog, shig = leaves(dev)
+    y, sc, of = Q._LwcFakeQuantFn.apply(w0.to(dev) * colg.view(1, -1), slog, shig, bits, sym)
+    (y * gy.to(dev)).sum().backward()
+    assert torch.equal(sc.cpu().view(-1), scale.detach().view(-1)) and torch.equal(of.cpu().view(-1), offset.detach().view(-1) + 0.0)
+    assert torch.equal(y.detach().cpu(), want.detach())
+    for a, b, name in ((colg.grad, col.grad, "LET scale"), (slog.grad, slo.grad, "sigmoid(lowbound)"), (shig.grad, shi.grad, "sigmoid(upbound)")):
+        tol = 3e-5 * float(b.abs().max()) + 1e-7
+        assert float((a.cpu() - b).abs().max()) <= tol, (name, float((a.cpu() - b).abs().max()), tol)
+    assert float(shig.grad.abs().max()) > 0 and float(colg.grad.abs().max()) > 0
+
+
+def test_quantizer_in_lwc_mode_takes_the_fused_pass_and_agrees_with_the_module_chain(dev):
+    """Quantizer.forward in LWC mode routes per-channel 2-D weights through the fused pass (lwc_fused, default on): same grid
+    attributes left behind as the module chain (plain [rows, 1] tensors, a new generation), values within one grid step of the
+    chain's (the one-ulp scale difference described above), gradients of the bound factors within 1e-3 relative."""
+    import mobilequant_amd as mq
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(96, 2048, generator=g) * 0.05).to(dev)
+    gy = torch.randn(96, 2048, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        q = mq.Quantizer(mq.QuantConfig(bitwidth=4, is_per_channel=True))
+        q.enable_lwc(w)
+        q.lwc_fused = fused
+        y = q(w)
+        (y * gy).sum().backward()
+        assert q.scale.shape == (96, 1) and q.offset.shape == (96, 1) and not isinstance(q.scale, torch.nn.Parameter)
+        res.append((y.detach(), q.scale.detach(), q.upbound_factor.grad.clone(), q.lowbound_factor.grad.clone()))
+    (yf, sf, guf, glf), (ym, sm, gum, glm) = res
+    assert float(((sf - sm).abs() / sm).max()) <= 2.5e-7
+    assert float((yf - ym).abs().max()) <= float(sm.max()) * 1.001
+    assert float(((yf - ym).abs() > 1e-6 * float(ym.abs().max())).float().mean()) < 1e-3      # index flips; the rest moves by an ulp of the scale
+    for a, b in ((guf, gum), (glf, glm)):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
