@@ -126,6 +126,23 @@ int mq_lwc_fake_quant_backward(const float* w, const float* grad_out, int64_t ro
                                const float* sig_hi, const float* row_min, const float* row_max, int bitwidth, int is_symmetric,
                                float* grad_w, float* grad_sig_lo, float* grad_sig_hi, mq_stream_t stream);
 
+/* f3: what a training-mode attention block does to the [rows = batch * heads * S, cols = keys] scores between its two matmuls
+ * (mobilellm/model/hf_model.py:511-520 with the QMatMuls of qmodule.py:408-466, under algorithm.py:381 / :587), in one pass:
+ *   out = Q2( softmax( Q1(raw) / sqrt_d + mask ) )
+ * Q1 = qk_bmm's output quantizer (s1, o1, [qmin1, qmax1]), Q2 = pv_bmm's input quantizer, both static per-tensor grids read by
+ * pointer (learnable ranges), fake-quant arithmetic of mq_fake_quant; softmax in fp32 as torch computes it (max, expf, sum, divide).
+ * mask: additive fp32 [mask_rows, cols] (row r uses mask row r % mask_rows) or NULL.  fp32, cols % 4 == 0, cols <= 4096. */
+int mq_attention_probs_train(const float* raw, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows, const float* s1,
+                             const float* o1, float qmin1, float qmax1, const float* s2, const float* o2, float qmin2, float qmax2,
+                             float sqrt_d, float* out, mq_stream_t stream);
+/* Backward of the above from the raw scores and the incoming gradient (nothing else is kept): grad_raw, and grad_grids[4] =
+ * d s1, d o1, d s2, d o2 accumulated with float atomics into a ZERO-INITIALISED buffer -- the gradients torch autograd derives for
+ * the module chain (straight-through rounding, clamp masks, softmax backward p * (g - sum(g p))). */
+int mq_attention_probs_train_backward(const float* raw, const float* grad_out, int64_t rows, int64_t cols, const float* mask,
+                                      int64_t mask_rows, const float* s1, const float* o1, float qmin1, float qmax1, const float* s2,
+                                      const float* o2, float qmin2, float qmax2, float sqrt_d, float* grad_raw, float* grad_grids,
+                                      mq_stream_t stream);
+
 /* The integer index itself (qmodule.py:286-287) written as integers instead of being dequantised.
  * q_dtype MQ_I8: i8 storage (index - shift, see top);  MQ_U8 / MQ_I16 / MQ_U16 / MQ_I32: the plain
  * index.  row_sum (nullable, [rows] int32): sum over the row of the STORED values -- the

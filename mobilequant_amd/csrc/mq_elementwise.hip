@@ -360,6 +360,236 @@ __global__ void __launch_bounds__(256) lwc_fake_quant_bwd_kernel(const float* __
   }
 }
 
+// ---- f3: the [heads, S, S] chain of a training-mode attention block in one pass per direction --------------------------------
+// HFAttention.forward (hf_model.py:511-520) between the two matmuls, as the PTQ training loops run it (algorithm.py:381 / :587):
+//   qk_bmm's output quantizer (16-bit, learnable grid) -> / sqrt(d) -> + mask -> softmax (fp32) -> pv_bmm's input quantizer (16-bit)
+// is five score-sized launches forward (each reads and writes 0.5 GB at S = 2048, 32 heads) and five backward, with four
+// score-sized tensors kept for autograd.  A WAVE owns a row (up to 4096 keys in registers), reads the raw scores once and writes the
+// quantised probabilities once; the backward re-derives everything from the raw scores and the incoming gradient: two reads, one
+// write, and the four grid gradients as one atomic each per workgroup.  Per-element expressions are those of fake_quant_vec_kernel /
+// fake_quant_bwd_kernel and of torch's softmax (max, expf(a - max), sum, e / sum; backward p * (g - sum(g p))); the row sums associate
+// as a wave reduction (torch's own order differs between its CPU and GPU kernels as well).
+struct AttnProbsArgs {
+  const float* raw;        // [rows, cols] q.k^T before the output quantizer
+  const float* mask;       // [mask_rows, cols] additive (row r uses mask row r % mask_rows), or NULL
+  const float* s1; const float* o1; const float* s2; const float* o2;
+  float qmin1, qmax1, qmin2, qmax2, sqrt_d;
+  int64_t rows;
+  int cols, mask_rows;
+};
+
+struct FqPoint {            // the fake-quant expression tree at one element (fake_quant_bwd_kernel's names)
+  float t, r, qc, y;
+  bool inside;
+};
+
+// FAST: both scales inside the reciprocal form's range (mq_common.h scale_in_fast_range) and sqrt(d) a power of two -- decided ONCE per
+// kernel (a wave-uniform branch at the top; a guard per element would put a branch between every two instructions): x / s through
+// div_by_scale (the IEEE quotient's bits for |t| >= 2^-2, within an ulp below, where r = 0 and t's last bit only enters the scale
+// gradient's g * (r - t), a relative 6e-8 of a term summed in unspecified order), x / sqrt(d) as an exact multiplication, and the
+// straight-through (g * s) / s within an ulp of the IEEE quotient.  !FAST: IEEE divides throughout.  (The per-tensor / per-row
+// backward kernels above keep the IEEE divide: they are the ones quantizer_grads.npz pins bit for bit.)
+template <bool FAST>
+__device__ __forceinline__ float uquot(float x, float s, float inv_s) { return FAST ? div_by_scale(x, s, inv_s) : __fdiv_rn(x, s); }
+
+template <bool FAST>
+__device__ __forceinline__ FqPoint fq_point(float x, float s, float inv_s, float o, float qmin, float qmax) {
+  FqPoint f;
+  f.t = uquot<FAST>(x, s, inv_s);
+  f.r = round_ste(f.t);
+  const float q = __fadd_rn(f.r, o);
+  f.inside = q >= qmin && q <= qmax;
+  f.qc = clamp_nan(q, qmin, qmax);
+  f.y = q_dequant(f.qc, s, o);
+  return f;
+}
+__device__ __forceinline__ bool is_pow2f(float v) { return (__float_as_uint(v) & 0x007FFFFFu) == 0u; }
+
+// A lane holds elements 4 * (lane + TPR k) + e of the row, k < VPT (TPR threads per row: a wave, or the whole workgroup); lanes past
+// the row's end hold clamped duplicates that are excluded from the statistics by selects and never stored (no divergent control flow
+// around the arithmetic).
+template <int VPT, int TPR = 64>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, int lane, int nvec, float (&v)[VPT * 4]) {
+  const vf4* r = reinterpret_cast<const vf4*>(base);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = lane + TPR * k;
+    const vf4 t = __builtin_nontemporal_load(r + (i < nvec ? i : nvec - 1));
+    v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+  }
+}
+
+struct AttnGrids {
+  float s1, o1, s2, o2, is1, is2, isd;
+};
+__device__ __forceinline__ AttnGrids attn_grids(const AttnProbsArgs& a, bool& fast) {
+  AttnGrids g;
+  g.s1 = a.s1[0]; g.o1 = a.o1[0]; g.s2 = a.s2[0]; g.o2 = a.o2[0];
+  g.is1 = __fdiv_rn(1.0f, g.s1); g.is2 = __fdiv_rn(1.0f, g.s2); g.isd = __fdiv_rn(1.0f, a.sqrt_d);
+  fast = scale_in_fast_range(g.s1) && scale_in_fast_range(g.s2) && is_pow2f(a.sqrt_d);
+  return g;
+}
+
+// scores of one row after Q1, / sqrt(d), + mask -> v[]; returns the lane's running maximum
+template <int VPT, bool FAST, int TPR = 64>
+__device__ __forceinline__ float attn_logits(const AttnProbsArgs& a, const AttnGrids& g, int64_t row, int lane, int nvec, float (&v)[VPT * 4]) {
+  const vf4* mr = a.mask ? reinterpret_cast<const vf4*>(a.mask + (row % a.mask_rows) * a.cols) : nullptr;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = lane + TPR * k;
+    const bool valid = i < nvec;
+    vf4 m = {0.f, 0.f, 0.f, 0.f};
+    if (mr) m = mr[valid ? i : nvec - 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y = fq_point<FAST>(v[4 * k + e], g.s1, g.is1, g.o1, a.qmin1, a.qmax1).y;
+      float x = FAST ? __fmul_rn(y, g.isd) : __fdiv_rn(y, a.sqrt_d);
+      if (mr) x = __fadd_rn(x, m[e]);
+      v[4 * k + e] = x;
+      mx = fmaxf(mx, valid ? x : -INFINITY);
+    }
+  }
+  return mx;
+}
+
+template <int VPT, int TPR = 64>
+__device__ __forceinline__ float attn_exp(float mx, int lane, int nvec, float (&v)[VPT * 4]) {
+  float l = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const bool valid = lane + TPR * k < nvec;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ex = expf(__fsub_rn(v[4 * k + e], mx));
+      v[4 * k + e] = ex;
+      l += valid ? ex : 0.f;
+    }
+  }
+  return l;
+}
+
+template <int VPT, bool FAST>
+__device__ __forceinline__ void attn_probs_fwd_body(const AttnProbsArgs& a, const AttnGrids& g, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, nvec = a.cols >> 2;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < a.rows; row += nw) {
+    float v[VPT * 4];
+    load_row<VPT>(a.raw + row * a.cols, lane, nvec, v);
+    const float mx = wave_max(attn_logits<VPT, FAST>(a, g, row, lane, nvec, v));
+    const float l = wave_sum_f32_dpp(attn_exp<VPT>(mx, lane, nvec, v));
+    vf4* orow = reinterpret_cast<vf4*>(out + row * a.cols);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      vf4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = fq_point<FAST>(__fdiv_rn(v[4 * k + e], l), g.s2, g.is2, g.o2, a.qmin2, a.qmax2).y;
+      if (lane + 64 * k < nvec) orow[lane + 64 * k] = y;
+    }
+  }
+}
+
+template <int VPT>
+__global__ void __launch_bounds__(256) attn_probs_fwd_kernel(const AttnProbsArgs a, float* __restrict__ out) {
+  bool fast;
+  const AttnGrids g = attn_grids(a, fast);
+  if (fast) attn_probs_fwd_body<VPT, true>(a, g, out);
+  else attn_probs_fwd_body<VPT, false>(a, g, out);
+}
+
+// Row reductions of the backward: TPR = 64 -> the wave's; TPR = 256 -> the four waves of the workgroup meet through the LDS (slot =
+// reduction number, double-buffered over the row loop: a slot is rewritten two iterations, i.e. at least three barriers, later).
+template <int TPR, class Op>
+__device__ __forceinline__ float row_reduce(float v, Op op, float* s_red, int slot) {
+  v = wave_reduce_f(v, op);
+  if (TPR == 64) return v;
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_red[slot * 4 + w] = v;
+  __syncthreads();
+  return op(op(s_red[slot * 4 + 0], s_red[slot * 4 + 1]), op(s_red[slot * 4 + 2], s_red[slot * 4 + 3]));
+}
+
+// The backward keeps three values per element (raw score, incoming gradient, probability): with a wave per 2048-key row that is 96
+// registers of state plus the division chains of 32 elements in flight -- hipcc allocates 256 VGPRs + 142 AGPRs (one wave per SIMD,
+// 0.9 ms).  Rows of more than 512 keys are therefore spread over the WHOLE workgroup (8 elements per thread at 2048 keys).
+template <int VPT, bool FAST, int TPR>
+__device__ __forceinline__ void attn_probs_bwd_body(const AttnProbsArgs& a, const AttnGrids& gd, const float* __restrict__ gy,
+                                                    float* __restrict__ graw, float (&acc)[4], float* s_red) {
+  constexpr int RPW = 256 / TPR;                      // rows per workgroup and iteration
+  const int lane = threadIdx.x & (TPR - 1), nvec = a.cols >> 2;
+  const float s1 = gd.s1, o1 = gd.o1, s2 = gd.s2, o2 = gd.o2;
+  const int64_t nr = (int64_t)gridDim.x * RPW;
+  const int64_t iters = (a.rows + nr - 1) / nr;       // the same trip count for every thread (barriers inside when TPR = 256)
+  auto fmax_op = [](float x, float y) { return fmaxf(x, y); };
+  auto add_op = [](float x, float y) { return x + y; };
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t row_raw = it * nr + (int64_t)blockIdx.x * RPW + threadIdx.x / TPR;
+    const bool live = row_raw < a.rows;
+    const int64_t row = live ? row_raw : a.rows - 1;
+    float* red = s_red + (it & 1) * 12;
+    float x[VPT * 4], g[VPT * 4], p[VPT * 4];
+    load_row<VPT, TPR>(a.raw + row * a.cols, lane, nvec, x);
+    load_row<VPT, TPR>(gy + row * a.cols, lane, nvec, g);
+#pragma unroll
+    for (int i = 0; i < VPT * 4; ++i) p[i] = x[i];
+    const float mx = row_reduce<TPR>(attn_logits<VPT, FAST, TPR>(a, gd, row, lane, nvec, p), fmax_op, red, 0);
+    const float l = row_reduce<TPR>(attn_exp<VPT, TPR>(mx, lane, nvec, p), add_op, red, 1);
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const bool valid = live && lane + TPR * k < nvec;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = __fdiv_rn(p[4 * k + e], l), gv = valid ? g[4 * k + e] : 0.f;
+        const FqPoint f = fq_point<FAST>(pv, s2, gd.is2, o2, a.qmin2, a.qmax2);
+        acc[2] += f.inside ? gv * (f.r - f.t) : gv * (f.qc - o2);
+        acc[3] += f.inside ? 0.f : -gv * s2;
+        const float gp = f.inside ? uquot<FAST>(__fmul_rn(gv, s2), s2, gd.is2) : 0.f;     // (g * s) / s, as autograd chains it
+        p[4 * k + e] = pv;
+        g[4 * k + e] = gp;
+        dot += gp * pv;
+      }
+    }
+    dot = row_reduce<TPR>(dot, add_op, red, 2);
+    vf4* orow = reinterpret_cast<vf4*>(graw + row * a.cols);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const bool valid = live && lane + TPR * k < nvec;
+      vf4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ga = valid ? __fmul_rn(p[4 * k + e], __fsub_rn(g[4 * k + e], dot)) : 0.f;       // softmax backward: p * (g - sum(g p))
+        const float gs = FAST ? __fmul_rn(ga, gd.isd) : __fdiv_rn(ga, a.sqrt_d);
+        const FqPoint f = fq_point<FAST>(x[4 * k + e], s1, gd.is1, o1, a.qmin1, a.qmax1);
+        acc[0] += f.inside ? gs * (f.r - f.t) : gs * (f.qc - o1);
+        acc[1] += f.inside ? 0.f : -gs * s1;
+        y[e] = f.inside ? uquot<FAST>(__fmul_rn(gs, s1), s1, gd.is1) : 0.f;
+      }
+      if (valid) __builtin_nontemporal_store(y, orow + lane + TPR * k);
+    }
+  }
+}
+
+template <int VPT, int TPR>
+__global__ void __launch_bounds__(256) attn_probs_bwd_kernel(const AttnProbsArgs a, const float* __restrict__ gy, float* __restrict__ graw,
+                                                             float* __restrict__ ggrid /* [4]: d s1, d o1, d s2, d o2; zero-initialised */) {
+  __shared__ float s_acc[4][4];
+  __shared__ float s_red[24];
+  bool fast;
+  const AttnGrids gd = attn_grids(a, fast);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fast) attn_probs_bwd_body<VPT, true, TPR>(a, gd, gy, graw, acc, s_red);
+  else attn_probs_bwd_body<VPT, false, TPR>(a, gd, gy, graw, acc, s_red);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = wave_sum_f32_dpp(acc[i]);
+    if (lane == 0) s_acc[i][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(ggrid + threadIdx.x, (s_acc[threadIdx.x][0] + s_acc[threadIdx.x][1]) + (s_acc[threadIdx.x][2] + s_acc[threadIdx.x][3]));
+}
+
 // ---- quantize to integers, one workgroup per row, optional row sum ------------------------------
 template <typename QT>
 __device__ __forceinline__ QT to_store(float q, int shift) {
@@ -979,6 +1209,70 @@ int mq_lwc_fake_quant_backward(const float* w, const float* grad_out, int64_t ro
   MQ_LAUNCH_CHECK("mq_lwc_fake_quant_backward");
   return MQ_OK;
 }
+
+static int attn_probs_check(const char* fn, const float* raw, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows,
+                            const float* s1, const float* o1, const float* s2, const float* o2, float sqrt_d) {
+  MQ_REQUIRE(rows >= 0 && cols >= 0, "%s: negative shape", fn);
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(raw && s1 && o1 && s2 && o2, "%s: null pointer", fn);
+  MQ_REQUIRE(cols % 4 == 0 && cols <= 4096 && aligned(raw, 16) && (mask == nullptr || aligned(mask, 16)),
+             "%s: rows of up to 4096 columns, a multiple of 4, 16-byte aligned (cols=%lld)", fn, (long long)cols);
+  MQ_REQUIRE(mask == nullptr || (mask_rows >= 1 && rows % mask_rows == 0), "%s: rows=%lld is not a multiple of mask_rows=%lld", fn,
+             (long long)rows, (long long)mask_rows);
+  MQ_REQUIRE(sqrt_d > 0.f, "%s: sqrt_d=%g", fn, sqrt_d);
+  return MQ_OK;
+}
+
+#define MQ_ATTN_PROBS_DISPATCH(KERNEL, GRID, ...)                         \
+  do {                                                                    \
+    if (cols <= 256) KERNEL<1><<<GRID, 256, 0, st>>>(__VA_ARGS__);        \
+    else if (cols <= 512) KERNEL<2><<<GRID, 256, 0, st>>>(__VA_ARGS__);   \
+    else if (cols <= 1024) KERNEL<4><<<GRID, 256, 0, st>>>(__VA_ARGS__);  \
+    else if (cols <= 2048) KERNEL<8><<<GRID, 256, 0, st>>>(__VA_ARGS__);  \
+    else KERNEL<16><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
+  } while (0)
+
+int mq_attention_probs_train(const float* raw, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows, const float* s1,
+                             const float* o1, float qmin1, float qmax1, const float* s2, const float* o2, float qmin2, float qmax2,
+                             float sqrt_d, float* out, mq_stream_t stream) {
+  const int rc = attn_probs_check("mq_attention_probs_train", raw, rows, cols, mask, mask_rows, s1, o1, s2, o2, sqrt_d);
+  if (rc != MQ_OK || rows == 0 || cols == 0) return rc;
+  MQ_REQUIRE(out && aligned(out, 16), "mq_attention_probs_train: out must be 16-byte aligned");
+  AttnProbsArgs a{raw, mask, s1, o1, s2, o2, qmin1, qmax1, qmin2, qmax2, sqrt_d, rows, (int)cols, (int)(mask ? mask_rows : 1)};
+  hipStream_t st = as_stream(stream);
+  int64_t grid = (rows + 3) / 4;
+  if (grid > 256 * 32) grid = 256 * 32;
+  MQ_ATTN_PROBS_DISPATCH(attn_probs_fwd_kernel, (unsigned)grid, a, out);
+  MQ_LAUNCH_CHECK("mq_attention_probs_train");
+  return MQ_OK;
+}
+
+int mq_attention_probs_train_backward(const float* raw, const float* grad_out, int64_t rows, int64_t cols, const float* mask,
+                                      int64_t mask_rows, const float* s1, const float* o1, float qmin1, float qmax1, const float* s2,
+                                      const float* o2, float qmin2, float qmax2, float sqrt_d, float* grad_raw, float* grad_grids,
+                                      mq_stream_t stream) {
+  const int rc = attn_probs_check("mq_attention_probs_train_backward", raw, rows, cols, mask, mask_rows, s1, o1, s2, o2, sqrt_d);
+  if (rc != MQ_OK || rows == 0 || cols == 0) return rc;
+  MQ_REQUIRE(grad_out && grad_raw && grad_grids && aligned(grad_out, 16) && aligned(grad_raw, 16),
+             "mq_attention_probs_train_backward: null or unaligned pointer");
+  AttnProbsArgs a{raw, mask, s1, o1, s2, o2, qmin1, qmax1, qmin2, qmax2, sqrt_d, rows, (int)cols, (int)(mask ? mask_rows : 1)};
+  hipStream_t st = as_stream(stream);
+  // rows of up to 512 keys: a wave per row; longer rows: the workgroup per row.  At most 2 048 workgroups (4 same-address atomics each).
+  if (cols <= 512) {
+    int64_t grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    if (cols <= 256) attn_probs_bwd_kernel<1, 64><<<(unsigned)grid, 256, 0, st>>>(a, grad_out, grad_raw, grad_grids);
+    else attn_probs_bwd_kernel<2, 64><<<(unsigned)grid, 256, 0, st>>>(a, grad_out, grad_raw, grad_grids);
+  } else {
+    const int64_t grid = rows > 2048 ? 2048 : rows;
+    if (cols <= 1024) attn_probs_bwd_kernel<1, 256><<<(unsigned)grid, 256, 0, st>>>(a, grad_out, grad_raw, grad_grids);
+    else if (cols <= 2048) attn_probs_bwd_kernel<2, 256><<<(unsigned)grid, 256, 0, st>>>(a, grad_out, grad_raw, grad_grids);
+    else attn_probs_bwd_kernel<4, 256><<<(unsigned)grid, 256, 0, st>>>(a, grad_out, grad_raw, grad_grids);
+  }
+  MQ_LAUNCH_CHECK("mq_attention_probs_train_backward");
+  return MQ_OK;
+}
+#undef MQ_ATTN_PROBS_DISPATCH
 
 int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const float* scale, const float* offset,
                 int64_t n_scale, float qmin, float qmax, int shift, const float* chan_scale, void* q, int q_dtype,

@@ -121,7 +121,13 @@ class Attention(nn.Module):
         if rep > 1:   # repeat_kv (hf_model.py:509-510)
             k = k[:, :, None].expand(B, s.kv_heads, rep, k.shape[-2], s.head_dim).reshape(B, s.heads, -1, s.head_dim)
             v = v[:, :, None].expand(B, s.kv_heads, rep, v.shape[-2], s.head_dim).reshape(B, s.heads, -1, s.head_dim)
-        att = self.qk_bmm(q, k.transpose(2, 3)) / math.sqrt(s.head_dim)
+        from .quantization import qmodule as Q
+        fused = Q.attention_probs_for_training(self.qk_bmm, self.pv_bmm, q, k.transpose(2, 3), mask, math.sqrt(s.head_dim))
+        if fused is not None and fused[1]:    # training: the score-sized chain between the two matmuls as one pass per direction
+            pv = self.pv_bmm
+            out = Q._apply(pv.output_quantizer, torch.matmul(fused[0], Q._apply(pv.input2_quantizer, v)))
+            return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
+        att = (fused[0] if fused is not None else self.qk_bmm(q, k.transpose(2, 3))) / math.sqrt(s.head_dim)
         if mask is not None:
             att = att + mask
         att = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)

@@ -217,6 +217,49 @@ def lwc_fake_quant_backward(w, grad_out, sig_lo, sig_hi, row_min, row_max, bitwi
     return gw, glo, ghi
 
 
+def attention_probs_train_supported(raw: torch.Tensor, mask: Optional[torch.Tensor]) -> bool:
+    if not (raw.is_cuda and raw.dtype == torch.float32 and raw.dim() >= 2 and raw.is_contiguous() and raw.shape[-1] % 4 == 0
+            and 0 < raw.shape[-1] <= 4096 and raw.data_ptr() % 16 == 0):
+        return False
+    if mask is None:
+        return True
+    return (mask.is_cuda and mask.dtype == torch.float32 and mask.dim() >= 2 and all(d == 1 for d in mask.shape[:-2])
+            and mask.shape[-1] == raw.shape[-1] and mask.shape[-2] == raw.shape[-2])
+
+
+def _attn_probs_args(raw, mask, g1, g2):
+    cols = raw.shape[-1]
+    rows = raw.numel() // cols
+    m = None if mask is None else _f32(mask, "mask").reshape(-1, cols)
+    s1, o1, s2, o2 = (_f32(t, "grid") for t in (g1[0], g1[1], g2[0], g2[1]))
+    return rows, cols, m, (s1, o1, s2, o2)
+
+
+def attention_probs_train(raw, mask, grid1, grid2, sqrt_d: float):
+    """Q2(softmax(Q1(raw) / sqrt_d + mask)) over the last dimension (mq_attention_probs_train); grid = (scale, offset, qmin, qmax)."""
+    raw = _f32(_dev(raw, "raw"), "raw")
+    rows, cols, m, (s1, o1, s2, o2) = _attn_probs_args(raw, mask, grid1, grid2)
+    out = torch.empty_like(raw)
+    with _on(raw, m, s1, o1, s2, o2):
+        _lib.call("mq_attention_probs_train", raw.data_ptr(), rows, cols, m.data_ptr() if m is not None else None, m.shape[0] if m is not None else 1,
+                  s1.data_ptr(), o1.data_ptr(), float(grid1[2]), float(grid1[3]), s2.data_ptr(), o2.data_ptr(), float(grid2[2]), float(grid2[3]),
+                  float(sqrt_d), out.data_ptr(), _stream())
+    return out
+
+
+def attention_probs_train_backward(raw, grad_out, mask, grid1, grid2, sqrt_d: float):
+    """(grad_raw, [d s1, d o1, d s2, d o2]) of attention_probs_train."""
+    raw, g = _f32(_dev(raw, "raw"), "raw"), _f32(_dev(grad_out, "grad_out"), "grad_out")
+    rows, cols, m, (s1, o1, s2, o2) = _attn_probs_args(raw, mask, grid1, grid2)
+    graw = torch.empty_like(raw)
+    gg = torch.zeros(4, dtype=torch.float32, device=raw.device)
+    with _on(raw, g, m, s1, o1, s2, o2):
+        _lib.call("mq_attention_probs_train_backward", raw.data_ptr(), g.data_ptr(), rows, cols, m.data_ptr() if m is not None else None,
+                  m.shape[0] if m is not None else 1, s1.data_ptr(), o1.data_ptr(), float(grid1[2]), float(grid1[3]), s2.data_ptr(), o2.data_ptr(),
+                  float(grid2[2]), float(grid2[3]), float(sqrt_d), graw.data_ptr(), gg.data_ptr(), _stream())
+    return graw, gg
+
+
 def quantize(x: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor, qmin: float, qmax: float, *,
              q_dtype: int = MQ_I8, shift: int = 0, rows: Optional[int] = None, want_row_sum: bool = False,
              chan_scale: Optional[torch.Tensor] = None):

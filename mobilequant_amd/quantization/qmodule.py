@@ -199,6 +199,53 @@ class _LwcFakeQuantFn(torch.autograd.Function):
                 ghi.reshape(sig_hi.shape) if ctx.needs_input_grad[2] else None, None, None)
 
 
+class _AttnProbsFn(torch.autograd.Function):
+    """qk_bmm's output quantizer -> / sqrt(d) -> + mask -> softmax -> pv_bmm's input quantizer over the [.., S, keys] scores as ONE
+    HIP pass per direction (mq_attention_probs_train / _backward; hf_model.py:511-520 under the PTQ training loops): the module chain
+    moves the score tensor through HBM ten times per step and keeps four copies for autograd; here the raw scores are the only
+    saved tensor.  Gradients: the raw scores and the four learnable grid parameters (--lrl)."""
+
+    @staticmethod
+    def forward(ctx, raw, s1, o1, s2, o2, mask, lim1, lim2, sqrt_d):
+        ctx.save_for_backward(raw, s1, o1, s2, o2, mask)
+        ctx.cfg = (lim1, lim2, sqrt_d)
+        return ops.attention_probs_train(raw.detach(), mask, (s1.detach(), o1.detach(), *lim1), (s2.detach(), o2.detach(), *lim2), sqrt_d)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raw, s1, o1, s2, o2, mask = ctx.saved_tensors
+        lim1, lim2, sqrt_d = ctx.cfg
+        graw, gg = ops.attention_probs_train_backward(raw.detach(), grad_out.contiguous(), mask, (s1.detach(), o1.detach(), *lim1),
+                                                      (s2.detach(), o2.detach(), *lim2), sqrt_d)
+        need = ctx.needs_input_grad
+        return (graw if need[0] else None, gg[0].reshape(s1.shape) if need[1] else None, gg[1].reshape(o1.shape) if need[2] else None,
+                gg[2].reshape(s2.shape) if need[3] else None, gg[3].reshape(o2.shape) if need[4] else None, None, None, None, None)
+
+
+def attention_probs_for_training(qk: "QMatMul", pv: "QMatMul", q, k_t, mask, sqrt_d: float):
+    """The probabilities pv_bmm multiplies with v, on ITS input grid -- Q_pv_in(softmax(qk_bmm(q, k^T) / sqrt_d + mask)) -- through
+    the fused pass above, or None when the block is not in that situation (no gradient wanted, a grid that is not a static per-tensor
+    one, another dtype / mask shape): the caller then runs the module chain.  ``train_fused = False`` on either QMatMul opts out."""
+    if not (isinstance(qk, QMatMul) and isinstance(pv, QMatMul)) or not (getattr(qk, "train_fused", True) and getattr(pv, "train_fused", True)):
+        return None
+    oq, iq = qk.output_quantizer, pv.input_quantizer
+    if not (_static_per_tensor(oq, 16) and _static_per_tensor(iq, 16)) or q.dtype != torch.float32:
+        return None
+    if not _needs_grad(q, k_t, oq.scale, oq.offset, iq.scale, iq.offset):
+        return None
+    raw = torch.matmul(_apply(qk.input_quantizer, q), _apply(qk.input2_quantizer, k_t))
+    if not raw.is_contiguous():
+        raw = raw.contiguous()
+    if mask is not None and (mask.requires_grad or not ops.attention_probs_train_supported(raw, mask)) or not ops.attention_probs_train_supported(raw, None):
+        return _apply(oq, raw), False                      # the caller continues the chain from qk_bmm's output
+    for qz in (oq, iq):
+        if qz.scale.device != raw.device:
+            qz.scale.data, qz.offset.data = qz.scale.to(raw.device), qz.offset.to(raw.device)
+    p = _AttnProbsFn.apply(raw, oq.scale, oq.offset, iq.scale, iq.offset, mask, (float(oq.qmin), float(oq.qmax)),
+                           (float(iq.qmin), float(iq.qmax)), float(sqrt_d))
+    return _tag_grid(p, iq), True
+
+
 class _RangeFn(torch.autograd.Function):
     """min / max of a weight as the reference's ``torch.amin`` / ``torch.amax`` (qmodule.py:263-268) with their gradient:
     the forward is the single-pass HIP reduction; the backward sends the gradient of a row's (or the tensor's) min / max to

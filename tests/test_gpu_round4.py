@@ -521,3 +521,94 @@ def test_quantizer_in_lwc_mode_takes_the_fused_pass_and_agrees_with_the_module_c
     assert float(((yf - ym).abs() > 1e-6 * float(ym.abs().max())).float().mean()) < 1e-3      # index flips; the rest moves by an ulp of the scale
     for a, b in ((guf, gum), (glf, glm)):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("heads,S,T,masked", [(2, 64, 64, True), (3, 40, 100, False), (1, 96, 2048, True), (1, 24, 4096, False), (2, 16, 260, True)])
+def test_training_attention_probabilities_pass_vs_the_reference_expression_and_its_autograd(dev, heads, S, T, masked):
+    """mq_attention_probs_train / _backward -- Q_pv_in(softmax(Q_qk_out(raw) / sqrt(d) + mask)) with learnable 16-bit grids
+    (hf_model.py:511-520, qmodule.py:286-290) -- against the same expression evaluated by torch on the CPU with autograd: values
+    within one step of the probability grid on < 0.1 % of the elements and identical elsewhere up to an ulp of the softmax (row sums
+    associate differently), the gradient of the raw scores within 1e-4 of its maximum, the four grid gradients within 2 %."""
+    from mobilequant_amd.quantization import qmodule as Q
+    g = torch.Generator().manual_seed(heads * 100 + S + T)
+    raw0 = torch.randn(1, heads, S, T, generator=g) * 6.0
+    gy = torch.randn(1, heads, S, T, generator=g)
+    mask = None
+    if masked:
+        mask = torch.zeros(S, T)
+        mask[torch.arange(S).view(-1, 1) + (T - S) < torch.arange(T).view(1, -1)] = float("-inf")       # causal, last S of T positions
+    lim1, lim2 = (0.0, 65535.0), (0.0, 65535.0)
+    grids0 = [torch.tensor(v) for v in (48.0 / 65535, 32768.0, 1.0 / 65535 * 0.9, 0.0)]                  # p above 0.9 clamps: both masks exercised
+    sqrt_d = 8.0
+
+    def fq(x, s, o, lim):
+        t = x / s
+        return ((((t.round() - t).detach() + t) + o).clamp(*lim) - o) * s
+
+    def run(device, fused):
+        raw = raw0.clone().to(device).requires_grad_(True)
+        gr = [t.clone().to(device).requires_grad_(True) for t in grids0]
+        m = None if mask is None else mask.to(device)
+        if fused:
+            p = Q._AttnProbsFn.apply(raw, gr[0], gr[1], gr[2], gr[3], m, lim1, lim2, sqrt_d)
+        else:
+            a = fq(raw, gr[0], gr[1], lim1) / sqrt_d
+            p = fq(torch.softmax(a if m is None else a + m, dim=-1, dtype=torch.float32), gr[2], gr[3], lim2)
+        (p * gy.to(device)).sum().backward()
+        return p.detach().cpu(), raw.grad.cpu(), [t.grad.cpu() for t in gr]
+    p_ref, graw_ref, gg_ref = run("cpu", False)
+    p, graw, gg = run(dev, True)
+    step = float(grids0[2])
+    d = (p - p_ref).abs()
+    assert float(d.max()) <= step * 1.001 and float((d > step * 1e-3).float().mean()) < 1e-3
+    assert float((graw - graw_ref).abs().max()) <= 1e-4 * float(graw_ref.abs().max())
+    for a, b, name in zip(gg, gg_ref, ("d s1", "d o1", "d s2", "d o2")):
+        assert abs(float(a) - float(b)) <= 2e-2 * abs(float(b)) + 1e-6 * float(graw_ref.abs().max()) * raw0.numel() ** 0.5, (name, float(a), float(b))
+    assert float(gg_ref[2].abs()) > 0 and float(gg_ref[0].abs()) > 0 and float(graw_ref.abs().max()) > 0
+
+
+def test_training_mode_attention_block_uses_the_fused_probabilities_pass(dev):
+    """Attention.forward with gradients wanted runs the score-sized chain as _AttnProbsFn (one saved score tensor instead of four):
+    output and every gradient (input, learnable grids of both QMatMuls) agree with the module chain (train_fused = False) within
+    the noise of a different softmax summation order; without gradients the module chain runs as before (bit-identical output)."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import get_act_range
+    shape = llama.LlamaShape(vocab=64, hidden=256, ffn=512, layers=1, heads=4, kv_heads=2, head_dim=64, max_pos=128)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=5, std=0.08)
+    model = model.to(dev).eval()
+    ids = torch.randint(0, 64, (1, 96), generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        act = get_act_range(model, [ids])
+    mq.create_sim_qmodel(model, mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8))
+    attn = model.layers[0].self_attn
+    attn.qk_bmm.output_quantizer.qcfg.bitwidth = 16
+    attn.pv_bmm.input_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(model, act, "parameter")
+    x0 = model.embed_tokens(ids).detach()
+    cos, sin = model.cos[:96], model.sin[:96]
+    mask = torch.full((96, 96), float("-inf"), device=dev).triu(1)
+    grids = [attn.qk_bmm.output_quantizer.scale, attn.qk_bmm.output_quantizer.offset, attn.pv_bmm.input_quantizer.scale, attn.pv_bmm.input_quantizer.offset]
+    gy = torch.randn(1, 96, 256, generator=torch.Generator().manual_seed(4)).to(dev)
+    res = []
+    for fused in (True, False):
+        attn.qk_bmm.train_fused = fused
+        x = x0.clone().requires_grad_(True)
+        for p in grids:
+            p.grad = None
+        y = attn(x, cos, sin, mask)
+        (y * gy).sum().backward()
+        res.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in grids]))
+    attn.qk_bmm.train_fused = True
+    (yf, gxf, ggf), (ym, gxm, ggm) = res
+    assert float((yf - ym).abs().max()) <= 2e-2 * float(ym.abs().max())
+    assert float((gxf - gxm).abs().max()) <= 2e-2 * float(gxm.abs().max())
+    for a, b in zip(ggf, ggm):
+        assert abs(float(a) - float(b)) <= 5e-2 * abs(float(b)) + 1e-4
+    with torch.no_grad():
+        a = attn(x0, cos, sin, mask)
+        attn.qk_bmm.train_fused = False
+        b = attn(x0, cos, sin, mask)
+        attn.qk_bmm.train_fused = True
+    assert torch.equal(a, b)

@@ -38,6 +38,8 @@ if __name__ == "__main__":
         unique = M * K + N * K + M * N * 4
         for g in (1, 2, 4, 8, 16):
             lib.mq_gemm_set_group_m(g)
-            panels = (g + 32 // g) * 128 * K * 8 + M * N * 4
-            print(f"{name:7s} group_m {g:2d}: XCD block {g:2d} x {32 // g:2d} tiles, model fetch {panels / 1e6:6.1f} MB (unique {unique / 1e6:5.1f} MB)  {timed(fn):6.2f} us", flush=True)
+            bn = min(32 // g, N // 128)                # an XCD's 32 consecutive tiles: bm x bn of the 16 x 16 tile grid
+            bm = 32 // bn
+            panels = (bm + bn) * 128 * K * 8 + M * N * 4
+            print(f"{name:7s} group_m {g:2d}: XCD block {bm:2d} x {bn:2d} tiles, model fetch {panels / 1e6:6.1f} MB (unique {unique / 1e6:5.1f} MB)  {timed(fn):6.2f} us", flush=True)
     lib.mq_gemm_set_group_m(0)
