@@ -727,8 +727,10 @@ def bench_train_step(dev, S=2048):
     """SURVEY 8(f) rank 3, measured: ONE inner step of e2equant (algorithm.py:692-760 under the deployment recipe's flags --lwc --let
     --lrl --deactive_amp: fp32, 4-bit per-channel weights, learnable activation ranges, LET scales, LWC bound factors) on one
     TinyLlama-shaped decoder layer at S tokens: smooth_lm_temporary -> quantized forward -> MSE against the fp layer's output ->
-    backward.  Every Quantizer.forward / backward in it is the HIP fake-quant pair (STE, clamp mask, LSQ gradients); the GEMMs and
-    the softmax are torch's fp32 library kernels, as in the reference.  (Parity of exactly this step: tests/golden/train_step.npz.)"""
+    backward.  Every Quantizer.forward / backward in it is a HIP pass (STE, clamp mask, LSQ gradients): the per-tensor / per-row
+    fake-quant pair, the LWC weight grids as mq_lwc_fake_quant (range + bound factors + grid + fake-quant in one pass per direction)
+    and the score-sized chain of the attention block as mq_attention_probs_train; the GEMMs are torch's fp32 library kernels, as in
+    the reference.  (Parity of exactly this step: tests/golden/train_step.npz.)"""
     import mobilequant_amd as mq
     from mobilequant_amd import llama
     from mobilequant_amd.calibration import get_act_range

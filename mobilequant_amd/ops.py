@@ -167,7 +167,8 @@ def fake_quant_backward(x: torch.Tensor, grad_y: torch.Tensor, scale: torch.Tens
     s, o = _f32(scale, "scale"), _f32(offset, "offset")
     rows, cols = _rows_cols(x, s.numel())
     gx = torch.empty_like(x)
-    gs, go = torch.zeros_like(s), torch.zeros_like(o)
+    acc = torch.zeros(2 * s.numel(), dtype=torch.float32, device=x.device)      # one fill for both accumulators
+    gs, go = acc[:s.numel()].view(s.shape), acc[s.numel():].view(o.shape)
     with _on(x, g, s, o):
         _lib.call("mq_fake_quant_backward", x.data_ptr(), g.data_ptr(), rows, cols, s.data_ptr(), o.data_ptr(), s.numel(),
                   float(qmin), float(qmax), gx.data_ptr(), gs.data_ptr(), go.data_ptr(), _stream())

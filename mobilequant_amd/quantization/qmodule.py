@@ -189,11 +189,14 @@ class _LwcFakeQuantFn(torch.autograd.Function):
         ctx.save_for_backward(w, sig_lo, sig_hi, mn, mx)
         ctx.cfg = (bitwidth, is_symmetric)
         ctx.mark_non_differentiable(scale, offset)
+        ctx.set_materialize_grads(False)          # no zero tensors for the two grid outputs on every backward
         return y, scale, offset
 
     @staticmethod
     def backward(ctx, grad_y, _gs, _go):
         w, sig_lo, sig_hi, mn, mx = ctx.saved_tensors
+        if grad_y is None:
+            return None, None, None, None, None
         gw, glo, ghi = ops.lwc_fake_quant_backward(w.detach(), grad_y.contiguous(), sig_lo.detach(), sig_hi.detach(), mn, mx, *ctx.cfg)
         return (gw if ctx.needs_input_grad[0] else None, glo.reshape(sig_lo.shape) if ctx.needs_input_grad[1] else None,
                 ghi.reshape(sig_hi.shape) if ctx.needs_input_grad[2] else None, None, None)
