@@ -25,10 +25,22 @@ LOG_CAPTIONS = {
     "decode_stamps_before.log": "`tools/decode_stamps.py` (`-DMQ_DECODE_STAMPS` build): per-launch gap / ramp / in-kernel `s_memrealtime` stamps of the decode step at the START of round 3",
     "decode_stamps_roles_fastdiv.log": "the same after the wave-role split and `div_by_scale`",
     "latency_probe.log": "`tools/latency_probe.cpp`: kernel boundary, kernarg and first-load latencies inside a hipGraph",
-    "div_check.log": "`tools/div_check.cpp`: `div_by_scale` against the IEEE divide, every fp32 dividend, 16 divisors",
+    "div_check.log": "`tools/div_check.cpp`: `div_by_scale` against the IEEE divide, every fp32 dividend, for the divisors the log lists (round 3: 16; round 4: 48 in [1e-5, 1e6] + 54 over +-[2^-60, 2^60])",
     "div_check_wide.log": "the same, 32 more divisors (scale clamps, all-ones significands)",
     "fr128_ab.log": "`tools/bench_fr128.py`: the 128-column generated GEMMs against the C++ tile kernels they replace",
     "decode_context_sweep.log": "`tools/decode_context_sweep.py`: ms per token against cached positions for 1 / 2 / 4 / 8 attention workgroups per head and the by-position default",
+    # round 4 (everything below is rewritten by tools/evidence_r04.sh)
+    "boundary_probe.log": "`tools/hole_probe.py` on the stamped build (`tools/build_stamped.sh`): kernel boundary behind the headline GEMM from in-kernel `s_memrealtime` stamps, per-XCD anatomy and clock, K sweep",
+    "grid_barrier_probe.log": "`tools/barrier_probe.cpp 2000`: software grid barriers among 256 resident workgroups -- single counter, round 2's hierarchy, and the microarchitecture guide's XCD-hierarchical recipe",
+    "decode_stamps_w8.log": "`tools/decode_stamps.py` (`-DMQ_DECODE_STAMPS` build, 6 layers, context 256): per-launch gap / ramp / in-kernel stamps of the decode step, int8 weights",
+    "decode_stamps_w4.log": "the same with packed 4-bit weights (`WBITS=4`)",
+    "groupm_traffic.log": "`tools/groupm_probe.py` + `rocprofv3 --pmc FETCH_SIZE` per setting: tile order of the N = 2048 residual GEMMs (`mq_gemm_set_group_m`) against time and L2 fetch bytes",
+    "train_step_kernels_before.log": "`tools/train_prof.py` (torch.profiler, device time per kernel over 6 e2equant inner steps + set-up) at the START of round 4",
+    "train_step_kernels.log": "the same at the end of the round (fused LWC pass, training attention-probabilities pass, vectorised STE backward)",
+    "bench_w4.log": "`tools/bench_w4.py`: packed-W4 generated-ISA GEMMs (expanded per workgroup / per-wave unpack) against the int8-image kernel, identical indices",
+    "gpu_tests.log": "result line of `python -m pytest tests -m gpu -q` on the box that produced this directory",
+    "bench_final.json": "un-profiled `python bench.py --steps 20 --warmup 5` (the driver's settings) at the end of the round",
+    "bench_steps200.json": "`python bench.py --steps 200 --warmup 20 --headline-only --no-cpu-baseline` on the same box, minutes later (agreement of the step time with the 20-step run)",
 }
 
 
