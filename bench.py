@@ -538,10 +538,13 @@ def bench_decode_linears(dev, w4=False):
             "scope": "linears only (22 layers x [qkv, o, w1|w3, w2] %s GEMV with the activation quantize fused in), batch 1, hipGraph" % ("W4A8" if w4 else "W8A8")}
 
 
+PAIR_MODE_DEFAULT = 0      # mq_gemm_set_pair_mode's built-in (mobilequant_amd_tuning.h)
+
+
 def bench_pair(step):
     """w1 and w3 of the FFN in ONE launch (mq_w8a8_linear_tiled_pair: 512 tiles, two per CU, same activation panel): the
     headline GEMM as the layer actually runs it.  Both halves use the headline problem's operands."""
-    from mobilequant_amd import ops
+    from mobilequant_amd import ops, _lib
     from mobilequant_amd._lib import MQ_U8
     if not step.tiled:
         return None
@@ -549,9 +552,19 @@ def bench_pair(step):
     step.quantize(0)
     t = event_time(lambda: ops.int8_linear_pair(step.a8s[0], M, step.rss[0], half, half, out_dtype=MQ_U8), 30)
     tops = 2 * OPS_PER_STEP / t / 1e12
-    return {"avg_launch_us": round(t * 1e6, 2), "us_per_gemm": round(t * 1e6 / 2, 2), "achieved_TOPS": round(tops, 1),
-            "frac_of_int8_peak": round(tops / INT8_MFMA_PEAK_TOPS, 4),
-            "note": "2 x (2048 x 2048 -> 5632) in one launch; allocates its two [M, N] outputs inside the timed call"}
+    out = {"avg_launch_us": round(t * 1e6, 2), "us_per_gemm": round(t * 1e6 / 2, 2), "achieved_TOPS": round(tops, 1),
+           "frac_of_int8_peak": round(tops / INT8_MFMA_PEAK_TOPS, 4),
+           "note": "2 x (2048 x 2048 -> 5632) in one launch; allocates its two [M, N] outputs inside the timed call"}
+    lib = _lib.load()
+    if hasattr(lib, "mq_gemm_set_pair_mode"):          # A/B: one workgroup per tile runs both problems (tuning header)
+        other = 1 - PAIR_MODE_DEFAULT
+        lib.mq_gemm_set_pair_mode(other)
+        try:
+            t2 = event_time(lambda: ops.int8_linear_pair(step.a8s[0], M, step.rss[0], half, half, out_dtype=MQ_U8), 30)
+        finally:
+            lib.mq_gemm_set_pair_mode(PAIR_MODE_DEFAULT)
+        out["persistent_over_the_pair_us" if other == 1 else "one_workgroup_per_tile_and_problem_us"] = round(t2 * 1e6, 2)
+    return out
 
 
 def bench_layer(dev):

@@ -31,6 +31,9 @@ int mq_gemm_set_w4_mode(int mode);
 /* Tile order of the 128-column generated kernels (residual / segmented GEMMs): M-tiles per group of the grouped order each XCD walks
  * (0 = the built-in 4).  Traffic experiment of DESIGN.md 4.2.1 (L2 fetch bytes per XCD footprint); results do not depend on it. */
 int mq_gemm_set_group_m(int group_m);
+/* mq_w8a8_linear_tiled_pair: 0 (default) = one workgroup per tile and problem (2 x tiles workgroups), 1 = one workgroup per tile runs
+ * problem 0 then problem 1 (persistent over the pair).  Identical results. */
+int mq_gemm_set_pair_mode(int mode);
 /* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
 /* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */

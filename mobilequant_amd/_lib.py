@@ -122,6 +122,7 @@ _SIGNATURES = {
     "mq_gemm_set_clock_probe": (c_int, [_P]),
     "mq_gemm_set_w4_mode": (c_int, [c_int]),
     "mq_gemm_set_group_m": (c_int, [c_int]),
+    "mq_gemm_set_pair_mode": (c_int, [c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1199,6 +1199,19 @@ __global__ void __launch_bounds__(512) gemm_i8_fr_pair_kernel(const GemmPairArgs
   else gemm_i8_fr_body(args.p[0], (int)blockIdx.x, nblk);
 }
 
+// The same two problems on HALF the workgroups: a workgroup runs its tile of problem 0, then the same tile of problem 1 (same rows
+// of the activation image, L2-warm).  What it saves is the dispatcher's hand-over of the CU from one 512-thread / 138-KiB workgroup to
+// the next; the two programs still run back to back (mq_gemm_set_pair_mode, A/B in bench.py's ffn_pair_gemm).
+__global__ void __launch_bounds__(512) gemm_i8_fr_pair_persistent_kernel(const GemmPairArgs args) {
+  const int nblk = args.p[0].grid_m * args.p[0].grid_n;
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    gemm_i8_fr_body(args.p[t], (int)blockIdx.x, nblk);
+    __syncthreads();                                     // the next program's first LDS-DMA pieces land in the ring the slow waves still read
+  }
+}
+static std::atomic<int> g_pair_mode{0};
+
 static bool gemm_fr_supported(const GemmArgs& a) {
   return a.a_tiled && (a.out_dtype == MQ_U8 || a.out_dtype == MQ_I8) && a.out_scale != nullptr && a.out_qmin == 0.0f &&
          a.out_qmax == 255.0f && a.K % 256 == 0 && a.K >= 768 && a.N % 176 == 0;
@@ -1218,7 +1231,20 @@ static int launch_fr_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t st
   GemmPairArgs pa;
   pa.p[0] = a0;
   pa.p[1] = a1;
-  gemm_i8_fr_pair_kernel<<<2 * a0.grid_m * a0.grid_n, 512, MQ_FR_LDS_BYTES, st>>>(pa);
+  if (g_pair_mode.load() == 1) {
+    static PerDeviceOnce attr_set_p;
+    if (!attr_set_p.done(dev)) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_fr_pair_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_FR_LDS_BYTES);
+      if (e != hipSuccess) {
+        set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", MQ_FR_LDS_BYTES, hipGetErrorString(e));
+        return MQ_EHIP;
+      }
+      attr_set_p.mark(dev);
+    }
+    gemm_i8_fr_pair_persistent_kernel<<<a0.grid_m * a0.grid_n, 512, MQ_FR_LDS_BYTES, st>>>(pa);
+  } else {
+    gemm_i8_fr_pair_kernel<<<2 * a0.grid_m * a0.grid_n, 512, MQ_FR_LDS_BYTES, st>>>(pa);
+  }
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
 }
@@ -1457,6 +1483,11 @@ extern "C" {
 int mq_gemm_set_variant(int variant) {
   g_forced_variant = (variant >= 0 && variant < kNumVariants) ? variant : -1;
   return kNumVariants;
+}
+
+int mq_gemm_set_pair_mode(int mode) {
+  g_pair_mode = mode;
+  return 0;
 }
 
 int mq_gemm_set_group_m(int group_m) {

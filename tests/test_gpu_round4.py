@@ -612,3 +612,39 @@ def test_training_mode_attention_block_uses_the_fused_probabilities_pass(dev):
         b = attn(x0, cos, sin, mask)
         attn.qk_bmm.train_fused = True
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,K", [(2048, 2048), (1900, 768), (1552, 5632)])
+def test_pair_gemm_persistent_over_the_pair_is_the_two_workgroup_launch_bit_for_bit(dev, M, K):
+    """mq_gemm_set_pair_mode(1): one workgroup per tile runs problem 0 then problem 1 (half the workgroups) -- the indices of both
+    outputs equal those of the default launch (one workgroup per tile and problem) and of the two single GEMMs, ragged M included."""
+    from mobilequant_amd import ops, _lib
+    from mobilequant_amd._lib import MQ_U8
+    N = 5632
+    g = torch.Generator().manual_seed(M + K)
+    Mp = (M + 15) // 16 * 16
+    a_rm = torch.randint(-128, 128, (Mp, K), generator=g, dtype=torch.int8)
+    a_rm[M:] = 0
+    a_t = a_rm.view(Mp // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().view(Mp, K).to(dev)
+    rs = a_rm[:M].to(torch.int32).sum(1, dtype=torch.int32).to(dev)
+    halves = []
+    for i in range(2):
+        halves.append(dict(w=torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(dev),
+                           alpha=(torch.rand(N, generator=g) * 2e-4 + 1e-5).to(dev), w_zp=torch.randint(-3, 4, (N,), generator=g, dtype=torch.int32).to(dev),
+                           col_term=torch.randint(-50000, 50000, (N,), generator=g, dtype=torch.int32).to(dev),
+                           bias=(torch.randn(N, generator=g) * 0.1).to(dev) if i else None,
+                           out_scale=torch.tensor([0.011 * (i + 1)], device=dev), out_offset=torch.tensor([100.0 + 20 * i], device=dev)))
+    lib = _lib.load()
+    res = []
+    for mode in (0, 1):
+        lib.mq_gemm_set_pair_mode(mode)
+        try:
+            res.append([t.clone() for t in ops.int8_linear_pair(a_t, M, rs, halves[0], halves[1], out_dtype=MQ_U8)])
+        finally:
+            lib.mq_gemm_set_pair_mode(0)
+    torch.cuda.synchronize()
+    for a, b, h in zip(res[0], res[1], halves):
+        assert torch.equal(a, b)
+        single = ops.int8_linear(a_t, h["w"], rs, h["alpha"], h["w_zp"], h["col_term"], h["bias"], out_scale=h["out_scale"], out_offset=h["out_offset"],
+                                 out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8, a_tiled_rows=M)
+        assert torch.equal(single, a)
