@@ -91,6 +91,22 @@ __device__ __forceinline__ float image_idxf(float x, float s, float inv_s, float
 __device__ __forceinline__ float image_u8f(float x, float s, float inv_s, float o, float qmin, float qmax, float bias) {
   return __fadd_rn(image_idxf(x, s, inv_s, o, qmin, qmax), bias);
 }
+// Two elements per instruction: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 are IEEE fp32 operations on register pairs (full rate on
+// CDNA3 / 4), so the packed forms below return the bits of the scalar ones; rint, med3 and the u8 conversion have no packed form.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float v) { return (v2f)(v); }
+__device__ __forceinline__ v2f div_by_scale2(v2f x, float s, float inv_s) {
+  const v2f q0 = x * splat2(inv_s);
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, splat2(s), x), splat2(inv_s), q0);
+}
+__device__ __forceinline__ v2f image_u8f2(v2f x, float s, float inv_s, float o, float qmin, float qmax, float bias) {
+  const v2f t = div_by_scale2(x, s, inv_s);
+  v2f r = {rintf(t.x), rintf(t.y)};
+  r = r + splat2(o);
+  r.x = __builtin_amdgcn_fmed3f(r.x, qmin, qmax);
+  r.y = __builtin_amdgcn_fmed3f(r.y, qmin, qmax);
+  return r + splat2(bias);
+}
 __device__ __forceinline__ uint32_t image_pack4(float u0, float u1, float u2, float u3, uint32_t& usum) {
   uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(u0, 0u, 0u);
   pk = __builtin_amdgcn_cvt_pk_u8_f32(u1, 1u, pk);

@@ -1052,8 +1052,9 @@ __global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __re
       const int i = lane + 256 * k;
       if (i < nvec) {
         const float4 f = xs[j][k];
-        const uint32_t pk = image_pack4(image_u8f(f.x, s, inv_s, o, qmin, qmax, ubias), image_u8f(f.y, s, inv_s, o, qmin, qmax, ubias),
-                                        image_u8f(f.z, s, inv_s, o, qmin, qmax, ubias), image_u8f(f.w, s, inv_s, o, qmin, qmax, ubias), usum);
+        // two elements per VALU instruction where a packed form exists (mq_common.h image_u8f2: the same bits)
+        const v2f u01 = image_u8f2((v2f){f.x, f.y}, s, inv_s, o, qmin, qmax, ubias), u23 = image_u8f2((v2f){f.z, f.w}, s, inv_s, o, qmin, qmax, ubias);
+        const uint32_t pk = image_pack4(u01.x, u01.y, u23.x, u23.y, usum);
         *reinterpret_cast<uint32_t*>(stage8 + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
       }
     }

@@ -248,14 +248,21 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
   }
   const float so = a.out_scale[0], oo = a.out_offset[0];
   const float isi = __fdiv_rn(1.0f, si), iso = __fdiv_rn(1.0f, so);
+  // The arithmetic runs on register PAIRS (v_pk_mul / v_pk_fma / v_pk_add: mq_common.h): the kernel spent ~480 VALU instructions per
+  // wave on 16 elements per thread -- as much time as its memory round trip -- and two thirds of them have a packed form with the
+  // same bits.  The row statistics keep their element-by-element association (the sums must be those of rmsnorm_quant_kernel).
   // input quantizer, value form.  A NaN / inf element must still poison its row (the reference's clamp propagates NaN): the clamp is a
   // v_med3 (NaN -> qmin) and `probe` = fma(v, 0, probe) turns NaN for such an element; it is added to the row statistic (+ 0.0 otherwise).
-  float probe = 0.f;
-  auto qin = [&](float v) {
+  v2f probe2 = {0.f, 0.f};
+  auto qin2 = [&](v2f v) -> v2f {
     if (!has_in) return v;
-    probe = __builtin_fmaf(v, 0.f, probe);
-    const float t = div_by_scale(v, si, isi);
-    return nq_dequant(__builtin_amdgcn_fmed3f(__fadd_rn(rintf(t), oi), a.in_qmin, a.in_qmax), si, oi);
+    probe2 = __builtin_elementwise_fma(v, splat2(0.f), probe2);
+    const v2f t = div_by_scale2(v, si, isi);
+    v2f q = {rintf(t.x), rintf(t.y)};
+    q = q + splat2(oi);
+    q.x = __builtin_amdgcn_fmed3f(q.x, a.in_qmin, a.in_qmax);
+    q.y = __builtin_amdgcn_fmed3f(q.y, a.in_qmin, a.in_qmax);
+    return (q - splat2(oi)) * splat2(si);                           // nq_dequant
   };
   const float ubias = (float)(128 - a.q_shift);                    // image_u8f / image_pack4 (mq_common.h)
   float4 xs[2][V];
@@ -282,19 +289,21 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
   for (int j = 0; j < 2; ++j) {
     const int64_t row = row0 + grp * 2 + j;
     float ss = 0.f;
-    probe = 0.f;
+    probe2 = splat2(0.f);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       if (lane + 256 * k < nvec) {
-        float4 v = xs[j][k];
-        v.x = qin(v.x); v.y = qin(v.y); v.z = qin(v.z); v.w = qin(v.w);
-        xs[j][k] = v;
-        ss += v.x * v.x;
-        ss += v.y * v.y;
-        ss += v.z * v.z;
-        ss += v.w * v.w;
+        const float4 v = xs[j][k];
+        const v2f lo = qin2((v2f){v.x, v.y}), hi = qin2((v2f){v.z, v.w});
+        xs[j][k] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        const v2f sl = lo * lo, sh = hi * hi;
+        ss += sl.x;
+        ss += sl.y;
+        ss += sh.x;
+        ss += sh.y;
       }
     }
+    const float probe = probe2.x + probe2.y;                        // 0 or NaN
     float r, shiftv = 0.f;
     if constexpr (LN) {
       float s1 = 0.f;
@@ -308,11 +317,12 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
       for (int k = 0; k < V; ++k)
         if (lane + 256 * k < nvec) {
           const float4 v = xs[j][k];
-          const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
-          s2 += d0 * d0;
-          s2 += d1 * d1;
-          s2 += d2 * d2;
-          s2 += d3 * d3;
+          const v2f d01 = (v2f){v.x, v.y} - splat2(mu), d23 = (v2f){v.z, v.w} - splat2(mu);
+          const v2f q01 = d01 * d01, q23 = d23 * d23;
+          s2 += q01.x;
+          s2 += q01.y;
+          s2 += q23.x;
+          s2 += q23.y;
         }
       const float var = __fdiv_rn(group_sum(s2, j, 1), (float)cols);
       r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var, a.eps)));
@@ -328,20 +338,21 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
       const int i = lane + 256 * k;
       if (i < nvec) {
         const float4 v = xs[j][k], w = wreg[k];
-        float y0, y1, y2, y3;
+        v2f y01 = (v2f){v.x, v.y} * splat2(r), y23 = (v2f){v.z, v.w} * splat2(r);
         if constexpr (LN) {
-          y0 = __fmul_rn(__fadd_rn(__fmul_rn(v.x, r), shiftv), w.x); y1 = __fmul_rn(__fadd_rn(__fmul_rn(v.y, r), shiftv), w.y);
-          y2 = __fmul_rn(__fadd_rn(__fmul_rn(v.z, r), shiftv), w.z); y3 = __fmul_rn(__fadd_rn(__fmul_rn(v.w, r), shiftv), w.w);
+          y01 = (y01 + splat2(shiftv)) * (v2f){w.x, w.y};
+          y23 = (y23 + splat2(shiftv)) * (v2f){w.z, w.w};
         } else {
-          y0 = __fmul_rn(w.x, __fmul_rn(v.x, r)); y1 = __fmul_rn(w.y, __fmul_rn(v.y, r));
-          y2 = __fmul_rn(w.z, __fmul_rn(v.z, r)); y3 = __fmul_rn(w.w, __fmul_rn(v.w, r));
+          y01 = (v2f){w.x, w.y} * y01;
+          y23 = (v2f){w.z, w.w} * y23;
         }
         if (bv) {
           const float4 b = bv[i];
-          y0 = __fadd_rn(y0, b.x); y1 = __fadd_rn(y1, b.y); y2 = __fadd_rn(y2, b.z); y3 = __fadd_rn(y3, b.w);
+          y01 = y01 + (v2f){b.x, b.y};
+          y23 = y23 + (v2f){b.z, b.w};
         }
-        const uint32_t pk = image_pack4(image_u8f(y0, so, iso, oo, a.out_qmin, a.out_qmax, ubias), image_u8f(y1, so, iso, oo, a.out_qmin, a.out_qmax, ubias),
-                                        image_u8f(y2, so, iso, oo, a.out_qmin, a.out_qmax, ubias), image_u8f(y3, so, iso, oo, a.out_qmin, a.out_qmax, ubias), usum);
+        const v2f u01 = image_u8f2(y01, so, iso, oo, a.out_qmin, a.out_qmax, ubias), u23 = image_u8f2(y23, so, iso, oo, a.out_qmin, a.out_qmax, ubias);
+        const uint32_t pk = image_pack4(u01.x, u01.y, u23.x, u23.y, usum);
         // staging: piece (k >> 4) = 16-byte chunk column, then the row of the eight, then the byte:  k = 4 i
         *reinterpret_cast<unsigned*>(stage + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
       }
