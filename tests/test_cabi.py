@@ -127,3 +127,16 @@ def test_argument_checks_fail_before_any_launch():
     assert b"mq_gemm_tiled_supported" in lib.mq_last_error()
     # fresh min/max needs its scratch
     assert lib.mq_minmax_tensor_fresh(p, L.MQ_F32, 100, p, p, p, 10, None) == 1
+    # round 4: the training-step passes -- row lengths, bit widths, mask periodicity; empty tensors are a no-op
+    assert lib.mq_lwc_fake_quant(p, 8, 30, p, p, 4, 0, p, p, p, p, p, None) == 1 and b"multiple of 4" in lib.mq_last_error()
+    assert lib.mq_lwc_fake_quant(p, 8, 32768, p, p, 4, 0, p, p, p, p, p, None) == 1
+    assert lib.mq_lwc_fake_quant(p, 8, 64, p, p, 17, 0, p, p, p, p, p, None) == 1 and b"bitwidth" in lib.mq_last_error()
+    assert lib.mq_lwc_fake_quant(None, 0, 64, None, None, 4, 0, None, None, None, None, None, None) == 0
+    assert lib.mq_lwc_fake_quant_backward(p, p, 8, 64, p, p, p, p, 4, 0, p, p, None, None) == 1 and b"null pointer" in lib.mq_last_error()
+    assert lib.mq_attention_probs_train(p, 64, 8192, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 8.0, p, None) == 1
+    assert b"4096 columns" in lib.mq_last_error()
+    assert lib.mq_attention_probs_train(p, 64, 128, p, 48, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 8.0, p, None) == 1
+    assert b"mask_rows" in lib.mq_last_error()
+    assert lib.mq_attention_probs_train(p, 64, 128, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 0.0, p, None) == 1
+    assert lib.mq_attention_probs_train_backward(p, p, 0, 128, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 8.0, None, None, None) == 0
+    assert lib.mq_attention_probs_train_backward(p, p, 64, 128, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 8.0, p, None, None) == 1
