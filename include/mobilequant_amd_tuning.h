@@ -34,7 +34,9 @@ int mq_gemm_set_group_m(int group_m);
 /* mq_w8a8_linear_tiled_pair: 0 (default) = one workgroup per tile and problem (2 x tiles workgroups), 1 = one workgroup per tile runs
  * problem 0 then problem 1 (persistent over the pair).  Identical results. */
 int mq_gemm_set_pair_mode(int mode);
-/* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); anything else = by shape. */
+/* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); 512 = 256-row tiles with the K loop split over two
+ * workgroups that swap partial sums through a per-device scratch buffer (experimental, measured slower, one launch at a time per device;
+ * falls back to the unsplit tile when both halves of every tile cannot be resident at once); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
 /* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */
 int mq_gemm_set_segmented_tile(int cols);

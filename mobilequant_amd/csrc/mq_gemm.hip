@@ -20,6 +20,7 @@
 //   * blockIdx -> tile mapping is XCD aware: the eight XCDs (block b runs on XCD b % 8) each get a
 //     contiguous run of the grouped tile order, so the tiles sharing an A panel / W panel hit the
 //     same private L2.
+#include <mutex>
 #include <hip/hip_fp16.h>
 
 #include <type_traits>
@@ -35,6 +36,7 @@
 #include "mq_gemm_fr160_asm.inc"
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
+#include "mq_gemm_fr128rs_asm.inc"
 #include "mq_gemm_frw4_asm.inc"
 #include "mq_gemm_frw4_128_asm.inc"
 #include "mq_gemm_frw4x_asm.inc"
@@ -843,7 +845,7 @@ __global__ void __launch_bounds__(512) gemm_i8_fr_kernel(const GemmArgs args) { 
 // segments of mq_w8a8_linear_tiled_segmented).  FR128R: 128 x 128 tiles, FOUR waves (one per SIMD; 2048 x 2048 outputs = 256 tiles = one
 // per CU), fp32 output x + Q16(linear) with the residual add in the store (o_proj / w2).  FR128R8: that epilogue on 256 x 128 tiles.
 // FR160: 128 x 160 tiles, four waves, per-column 8-bit grids: q | k | v at M = 2048 is 16 x 16 = 256 tiles, one per CU (256 x 128 tiles: 160).
-enum { FR128 = 1, FR128R = 2, FR128R8 = 3, FR160 = 4 };
+enum { FR128 = 1, FR128R = 2, FR128R8 = 3, FR160 = 4, FR128RS = 5 };   // FR128RS: FR128R8's tile with the K loop split over two workgroups
 template <int VAR>
 __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
   constexpr int NWV = (VAR == FR128R || VAR == FR160) ? 4 : 8;
@@ -853,10 +855,15 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tm, tn;
-  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn, args.group_m);
+  const int ntiles = args.grid_m * args.grid_n;
+  // split-K (FR128RS): blocks [0, tiles) take the first half of K, blocks [tiles, 2 tiles) the second (dispatched after every first-half
+  // workgroup: the partner a wave waits for is always resident or finished)
+  const int role = VAR == FR128RS ? __builtin_amdgcn_readfirstlane((int)blockIdx.x >= ntiles ? 1 : 0) : 0;
+  const int tile = (int)blockIdx.x - role * ntiles;
+  tile_of_block(tile, ntiles, args.grid_m, args.grid_n, tm, tn, args.group_m);
   const int m0 = tm * BMT, n0 = tn * BNT;
   const int M = args.M, N = args.N, K = args.K;
-  const int KT = K / BK;
+  const int KT = (VAR == FR128RS ? K / 2 : K) / BK;
   unsigned sw[5] = {0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < PCS; ++i) {
@@ -878,15 +885,16 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
     m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
     rsofs[i] = (unsigned)m * 4u;
   }
-  const int8_t* a_ptr = args.a;
-  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  // second K half: k blocks K / 128 .. of the fragment-blocked image (1 KiB each), byte K / 2 of every weight row
+  const int8_t* a_ptr = args.a + (size_t)role * (size_t)(K >> 7) * 1024u;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w) + (size_t)role * (size_t)(K >> 1);
   const float* alpha_p = args.alpha + n0;
   const float* bias_p = args.bias + n0;
   const int32_t* wzp_p = args.w_zp + n0;
   const int32_t* ct_p = args.col_term + n0;
   const int32_t* rs_p = args.a_rowsum;
   const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
-  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0) | (role ? 4 : 0));
   const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
   const unsigned tid = threadIdx.x;
   if constexpr (VAR == FR128 || VAR == FR160) {
@@ -928,6 +936,11 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
         [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [sw0] "v"(sw[0]), [sw1] "v"(sw[1])
     if constexpr (VAR == FR128R) {
       asm volatile(MQ_FR128R_ASM_BODY : : MQ_FR128R_OPERANDS, [sw2] "v"(sw[2]), [sw3] "v"(sw[3]) : MQ_FR128R_ASM_CLOBBERS);
+    } else if constexpr (VAR == FR128RS) {
+      // the tile's exchange area: 2 x 8 x 8 KiB of partial sums, 2 x 8 flags (gemm_splitk_scratch)
+      const char* xch = reinterpret_cast<const char*>(args.gate_q) + (size_t)tile * 131072u;
+      const int* xfl = reinterpret_cast<const int*>(args.gate_rowsum) + (size_t)tile * 16u;
+      asm volatile(MQ_FR128RS_ASM_BODY : : MQ_FR128R_OPERANDS, [xch] "s"(xch), [xfl] "s"(xfl) : MQ_FR128RS_ASM_CLOBBERS);
     } else {
       asm volatile(MQ_FR128R8_ASM_BODY : : MQ_FR128R_OPERANDS : MQ_FR128R8_ASM_CLOBBERS);
     }
@@ -945,10 +958,48 @@ __global__ void __launch_bounds__((VAR == FR128R || VAR == FR160) ? 256 : 512) g
 // shapes the 128-column generated kernels serve (fragment-blocked activations, int8 weights)
 static bool gemm_fr128_shape(int64_t M, int64_t N, int64_t K) { return M > 0 && N % 128 == 0 && K % 256 == 0 && K >= 768; }
 
+static int device_cu_count() {
+  static std::atomic<int> cus[64];
+  const int dev = current_device();
+  if (dev < 0 || dev >= 64) return 0;
+  int c = cus[dev].load();
+  if (c == 0) {
+    hipDeviceProp_t prop;
+    c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+    cus[dev] = c;
+  }
+  return c;
+}
+
+// Exchange area of the split-K residual GEMM: per device, grown on demand, never freed (128 tiles = 16.8 MB at M = 2048).  The flags
+// are zero between launches (every wave clears the flag it consumed).
+static int gemm_splitk_scratch(int tiles, char** xch, int** xfl) {
+  static std::mutex mu;
+  static char* buf[64] = {};
+  static int cap[64] = {};
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 0 || dev >= 64) return MQ_EHIP;
+  if (cap[dev] < tiles) {
+    const size_t bytes = (size_t)tiles * (131072u + 64u);
+    char* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      set_error("mq_gemm: split-K exchange buffer (%zu bytes): allocation failed", bytes);
+      return MQ_EHIP;
+    }
+    buf[dev] = p;                       // (an older, smaller buffer may still be in use by a launch in flight: it is leaked, once per growth)
+    cap[dev] = tiles;
+  }
+  *xch = buf[dev];
+  *xfl = reinterpret_cast<int*>(buf[dev] + (size_t)cap[dev] * 131072u);
+  return MQ_OK;
+}
+
 template <int VAR>
 static int launch_fr128(GemmArgs a, hipStream_t st) {
   constexpr int LDS = VAR == FR128 ? MQ_FR128_LDS_BYTES
-                                   : (VAR == FR128R ? MQ_FR128R_LDS_BYTES : (VAR == FR160 ? MQ_FR160_LDS_BYTES : MQ_FR128R8_LDS_BYTES));
+                                   : (VAR == FR128R ? MQ_FR128R_LDS_BYTES
+                                                    : (VAR == FR160 ? MQ_FR160_LDS_BYTES : (VAR == FR128RS ? MQ_FR128RS_LDS_BYTES : MQ_FR128R8_LDS_BYTES)));
   constexpr int BMT = (VAR == FR128R || VAR == FR160) ? 128 : 256;
   constexpr int BNT = VAR == FR160 ? 160 : 128;
   static PerDeviceOnce attr_set;
@@ -967,6 +1018,17 @@ static int launch_fr128(GemmArgs a, hipStream_t st) {
   a.grid_m = (a.M + BMT - 1) / BMT;
   a.grid_n = a.N / BNT;
   a.group_m = g_group_m.load();
+  if constexpr (VAR == FR128RS) {
+    char* xch = nullptr;
+    int* xfl = nullptr;
+    const int rc = gemm_splitk_scratch(a.grid_m * a.grid_n, &xch, &xfl);
+    if (rc != MQ_OK) return rc;
+    a.gate_q = reinterpret_cast<int8_t*>(xch);            // (fields of the gated pair, unused by the residual GEMMs)
+    a.gate_rowsum = reinterpret_cast<int32_t*>(xfl);
+    gemm_i8_fr128_kernel<VAR><<<2 * a.grid_m * a.grid_n, 512, LDS, st>>>(a);
+    MQ_LAUNCH_CHECK("mq_gemm");
+    return MQ_OK;
+  }
   gemm_i8_fr128_kernel<VAR><<<a.grid_m * a.grid_n, (VAR == FR128R || VAR == FR160) ? 256 : 512, LDS, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
@@ -1707,7 +1769,7 @@ int mq_gemm_set_segmented_tile(int cols) {
 
 static std::atomic<int> g_fr128r_tile{0};     // tuning hook (mobilequant_amd_tuning.h): 0 = by shape, 128 / 256 = force the tile height
 int mq_gemm_set_residual_tile(int rows) {
-  g_fr128r_tile = (rows == 128 || rows == 256) ? rows : 0;
+  g_fr128r_tile = (rows == 128 || rows == 256 || rows == 512) ? rows : 0;     // 512: 256-row tiles, K split over two workgroups
   return 0;
 }
 
@@ -1731,6 +1793,11 @@ int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_
   // 128-row tiles while they give every CU at most ~two rounds of work; taller tiles (twice the MFMAs per W fragment) beyond
   const int forced = g_fr128r_tile.load();
   const int64_t tiles128 = ((M + 127) / 128) * (N / 128);
+  // split-K on 256-row tiles (mq_gemm_set_residual_tile(512)): both halves of every tile resident at once (2 x tiles <= CUs), the two
+  // workgroups of a tile on one XCD (tiles % 8 == 0), each half a valid K for the program (multiple of 256, >= 768)
+  const int64_t tiles256 = ((M + 255) / 256) * (N / 128);
+  const bool can_split = K % 512 == 0 && K / 2 >= 768 && tiles256 % 8 == 0 && 2 * tiles256 <= (int64_t)device_cu_count();
+  if (forced == 512 && can_split) return launch_fr128<FR128RS>(g, as_stream(stream));
   const bool tall = forced ? forced == 256 : tiles128 > 512;
   return tall ? launch_fr128<FR128R8>(g, as_stream(stream)) : launch_fr128<FR128R>(g, as_stream(stream));
 }

@@ -432,7 +432,11 @@ def _gemm_operands(dev, M, N, K, seed, w_zp_zero=False, bias=True):
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(2048, 2048, 2048, 0), (2048, 2048, 5632, 128), (2048, 2048, 2048, 256), (300, 256, 768, 128),
-                                        (300, 256, 768, 256), (129, 384, 1024, 0), (4096, 2048, 1024, 0)])
+                                        (300, 256, 768, 256), (129, 384, 1024, 0), (4096, 2048, 1024, 0),
+                                        # 512 = 256-row tiles with the K loop split over two workgroups (round 4; served when both halves
+                                        # of every tile are resident at once, otherwise the call falls back to the unsplit tile)
+                                        (2048, 2048, 5632, 512), (2048, 2048, 2048, 512), (1900, 2048, 1536, 512), (300, 1024, 2048, 512),
+                                        (2048, 2048, 16384, 512), (4096, 2048, 2048, 512)])
 def test_tiled_residual_gemm_is_the_rowmajor_residual_gemm_bit_for_bit(dev, M, N, K, tile):
     """mq_w8a8_linear_tiled_residual (generated ISA, 128 x 128 / 256 x 128 tiles, fragment-blocked activations) against
     mq_w8a8_linear_residual (the C++ kernel the golden decode / layer cases pin): x + Q16(linear), same bits."""

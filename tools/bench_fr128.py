@@ -51,10 +51,10 @@ if __name__ == "__main__":
         kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0, resid=resid, out=out)
         t_old = timed(lambda: ops.int8_linear(a_q, w_q, a_rs, alpha, w_zp, col_term, None, **kw))
         res = [f"rowmajor C++ {t_old:6.2f} us"]
-        for tile in (128, 256):
+        for tile in (128, 256, 512):
             L.load().mq_gemm_set_residual_tile(tile)
             t = timed(lambda: ops.int8_linear(a_t, w_q, a_rs, alpha, w_zp, col_term, None, a_tiled_rows=M, **kw))
-            res.append(f"tiled {tile}-row {t:6.2f} us ({2.0 * M * N * K / t / 1e6:7.1f} TOPS)")
+            res.append(f"tiled {tile if tile < 512 else '256-row split-K'}{'-row' if tile < 512 else ''} {t:6.2f} us ({2.0 * M * N * K / t / 1e6:7.1f} TOPS)")
         L.load().mq_gemm_set_residual_tile(0)
         print(f"{name:10s} {M}x{N}x{K}: " + " | ".join(res), flush=True)
 

@@ -43,6 +43,10 @@ VARIANTS = {
     "fr128":   (128, 8, "u8",   "MQ_FR128",   "mq_gemm_fr128_asm.inc"),      # q|k|v (N = 2560): 256 x 128 tiles, per-column output grids
     "fr128r":  (128, 4, "f32r", "MQ_FR128R",  "mq_gemm_fr128r_asm.inc"),     # o_proj / w2 (N = 2048): 128 x 128 tiles, x + Q16(linear) in fp32
     "fr128r8": (128, 8, "f32r", "MQ_FR128R8", "mq_gemm_fr128r8_asm.inc"),    # the same epilogue on 256 x 128 tiles
+    # round 4: 256 x 128 tiles with the K loop SPLIT over two workgroups (2 x tiles workgroups, each half of K): twice the MFMAs per
+    # operand byte and two waves per SIMD where "fr128r" has one, on all 256 CUs at M = 2048.  The two workgroups of a tile swap half of
+    # their int32 partial sums through a scratch buffer (wave to wave, one flag each way) and each finishes one 16-row block per wave
+    "fr128rs": (128, 8, "f32rs", "MQ_FR128RS", "mq_gemm_fr128rs_asm.inc"),
     "fr160":   (160, 4, "u8",   "MQ_FR160",   "mq_gemm_fr160_asm.inc"),      # q|k|v at M = 2048: 128 x 160 tiles = 16 x 16 = one per CU
     # w3 of a gated FFN with the rest of the chain in its epilogue: its 8-bit output index and w1's (read back from the first launch's
     # output) go through the 256 x 256 gated table (64 KiB, LDS-resident) -> w2's int8 input image, fragment-blocked, + row sums
@@ -70,6 +74,10 @@ def configure(name):
     TAIL = EPI == "u8" and os.environ.get("MQ_FR_TAIL", "1") != "0"
     BM = 32 * NW
     FN = BN // 16
+    global SPLITK
+    SPLITK = EPI == "f32rs"
+    if SPLITK:
+        EPI = "f32r"
     global W4, W4X
     W4X = EPI == "u8w4x"
     if W4X:
@@ -885,6 +893,13 @@ def prologue(q, nw, stamp):
     emit(f"v_mul_f32 v{V_P0 + 1}, {inv}, v{V_P0 + 1}")
     if EPI in ("u8", "gate"):
         emit(f"v_add_f32 v{V_P0 + 1}, {oo}, v{V_P0 + 1}")
+    if SPLITK:                       # the second K half starts from zero: the zero-point correction is the first half's
+        emit("s_bitcmp1_b32 %[flags], 2")
+        l = label("nz")
+        emit(f"s_cbranch_scc0 {l}")
+        emit(f"v_mov_b32 v{V_P0 + 2}, 0")
+        emit(f"v_mov_b32 v{V_P0 + 3}, 0")
+        emit(f"{l}:")
     emit(f"v_sub_u32 v{V_P0 + 2}, 0, v{V_P0 + 2}")
     emit(f"v_lshlrev_b32 v{V_TMP}, 2, %[tid]")
     emit(f"v_add_u32 v{V_TMP}, {PAR}, v{V_TMP}")
@@ -1209,7 +1224,94 @@ S_OB, S_RB, S_STEP = 74, 76, 78     # output / residual pointers of the current 
 S_MASK = 80                         # 80..95: exec masks of (i, r)
 
 
+def splitk_exchange(keep):
+    """fr128rs: this wave sends its int32 partial sums of row block 1 - keep to the same wave of the partner workgroup and adds the
+    partner's sums of row block `keep` to its own.  %[xch] -> the tile's scratch [2 (destination role)][8 waves][8 quads][64 lanes x 16 B],
+    %[xfl] -> its flags [2][8] (zero when the launch starts, zero again when it ends).  The partner is resident: the first-half
+    workgroups have the lower block ids (dispatched first), and 2 x tiles <= the number of CUs.  System-scope accesses: the two
+    workgroups need not share an L2."""
+    send = 1 - keep
+    if os.environ.get("MQ_FR_XNOX"):       # what-if (wrong sums): no exchange at all -- what the halved loop + half an epilogue cost alone
+        return
+    VX, VF, VT = 98, 99, 100
+    XB, FL, SC = 74, 76, 78
+    # cache policies: the partner runs on the SAME XCD (block ids t and t + tiles, tiles % 8 == 0: round-robin dispatch), so the partial
+    # sums travel through that XCD's L2 -- plain stores (the vector L1 writes through), loads that miss the L1 (sc1); system-scope
+    # accesses (sc0 sc1 both ways) cost ~11 us per launch at 16.8 MB each way
+    POL_ST = os.environ.get("MQ_FR_XPOL_ST", "")
+    POL_LD = os.environ.get("MQ_FR_XPOL_LD", "sc1")
+    emit(f"; ---- split-K exchange: keep row block {keep}, send row block {send}")
+    emit(f"v_and_b32 v{VX}, 63, %[tid]")
+    emit(f"v_lshlrev_b32 v{VX}, 4, v{VX}")                                   # lane * 16
+    emit(f"s_lshl_b32 s{S_TMP}, %[wave], 13")                                # wave * 8 KiB
+    emit(f"s_mov_b64 s[{XB}:{XB + 1}], %[xch]")
+    emit(f"s_add_u32 s{XB}, s{XB}, s{S_TMP}")
+    emit(f"s_addc_u32 s{XB + 1}, s{XB + 1}, 0")
+    emit(f"s_mov_b64 s[{FL}:{FL + 1}], s[{XB}:{XB + 1}]")                    # (FL doubles as the read base until the flags are needed)
+    if send:
+        emit(f"s_add_u32 s{XB}, s{XB}, 65536")
+        emit(f"s_addc_u32 s{XB + 1}, s{XB + 1}, 0")
+    else:
+        emit(f"s_add_u32 s{FL}, s{FL}, 65536")
+        emit(f"s_addc_u32 s{FL + 1}, s{FL + 1}, 0")
+    for j in range(FN):
+        if j == 4:
+            emit(f"s_add_u32 s{XB}, s{XB}, 4096")
+            emit(f"s_addc_u32 s{XB + 1}, s{XB + 1}, 0")
+        emit(f"global_store_dwordx4 v{VX}, {acc(send, j)}, s[{XB}:{XB + 1}] offset:{(j % 4) * 1024} {POL_ST}".rstrip())
+    emit("s_waitcnt vmcnt(0)")
+    # flags: mine to raise = [send][wave], mine to wait for = [keep][wave]
+    emit(f"s_lshl_b32 s{S_TMP}, %[wave], 2")
+    emit(f"s_add_u32 s{S_TMP2}, s{S_TMP}, {32 * keep}")
+    emit(f"s_add_u32 s{S_TMP}, s{S_TMP}, {32 * send}")
+    emit(f"v_mov_b32 v{VF}, s{S_TMP}")
+    emit(f"v_mov_b32 v{VT}, 1")
+    emit(f"global_store_dword v{VF}, v{VT}, %[xfl] {POL_ST}".rstrip())
+    emit(f"v_mov_b32 v{VF}, s{S_TMP2}")
+    emit(f"s_mov_b32 s{SC}, 0")
+    lp, ld = label("xw"), label("xd")
+    emit(f"{lp}:")
+    emit(f"global_load_dword v{VT}, v{VF}, %[xfl] {POL_LD}".rstrip())
+    emit("s_waitcnt vmcnt(0)")
+    emit(f"v_readfirstlane_b32 s{S_TMP}, v{VT}")
+    emit(f"s_cmp_eq_u32 s{S_TMP}, 1")
+    emit(f"s_cbranch_scc1 {ld}")
+    emit("s_sleep 1")
+    emit(f"s_add_u32 s{SC}, s{SC}, 1")
+    emit(f"s_cmp_lt_u32 s{SC}, {1 << 21}")                                   # a lost partner must not hang the device: wrong sums, caught by the tests
+    emit(f"s_cbranch_scc1 {lp}")
+    emit(f"{ld}:")
+    emit(f"v_mov_b32 v{VT}, 0")
+    emit(f"global_store_dword v{VF}, v{VT}, %[xfl] {POL_ST}".rstrip())                   # consumed: the flag is zero again for the next launch
+    for j in range(FN):
+        if j == 4:
+            emit(f"s_add_u32 s{FL}, s{FL}, 4096")
+            emit(f"s_addc_u32 s{FL + 1}, s{FL + 1}, 0")
+        emit(f"global_load_dwordx4 {acc(send, j)}, v{VX}, s[{FL}:{FL + 1}] offset:{(j % 4) * 1024} {POL_LD}".rstrip())
+    emit("s_waitcnt vmcnt(0)")
+    for j in range(FN):
+        for e in range(4):
+            emit(f"v_add_u32 {accr(keep, j, e)}, {accr(keep, j, e)}, {accr(send, j, e)}")
+
+
 def epilogue_f32r():
+    if not SPLITK:
+        return epilogue_f32r_units((0, 1, 2, 3))
+    emit("s_nop 15")
+    emit("s_nop 3")
+    l1, lend = label("role"), label("xend")
+    emit("s_bitcmp1_b32 %[flags], 2")
+    emit(f"s_cbranch_scc1 {l1}")
+    splitk_exchange(0)
+    epilogue_f32r_units((0, 1))
+    emit(f"s_branch {lend}")
+    emit(f"{l1}:")
+    splitk_exchange(1)
+    epilogue_f32r_units((2, 3))
+    emit(f"{lend}:")
+
+
+def epilogue_f32r_units(units):
     emit("; ==== epilogue: fp32 x + Qout16(linear), unit by unit")
     emit("s_nop 15")
     emit("s_nop 3")
@@ -1238,6 +1340,10 @@ def epilogue_f32r():
     emit(f"s_mov_b64 s[{S_OB}:{S_OB + 1}], %[outw]")
     emit(f"s_mov_b64 s[{S_RB}:{S_RB + 1}], %[resid]")
     emit(f"s_lshl_b32 s{S_TMP2}, %[ldn], 6")                                 # 16 rows ...
+    if units[0] == 2:                                                        # (split-K, second role: row block 1 only)
+        for sp in (S_OB, S_RB):
+            emit(f"s_add_u32 s{sp}, s{sp}, s{S_TMP2}")
+            emit(f"s_addc_u32 s{sp + 1}, s{sp + 1}, 0")
     emit(f"s_sub_u32 s{S_TMP2}, s{S_TMP2}, {HALF * 4}")                      # ... minus the half row already advanced
     for i in range(2):
         for r in range(4):
@@ -1297,14 +1403,14 @@ def epilogue_f32r():
                 emit(f"v_mul_f32 {x}, s{S_SO}, {x}")
             emit(f"ds_write_b128 v{V_STW}, {acc(i, j)} offset:{n * 64}")
 
-    issue_resid(0)
-    for u in range(4):
+    issue_resid(units[0])
+    for u in units:
         i = u >> 1
-        if u:
+        if u != units[0]:
             emit("s_nop 2")                                                  # the stores of unit u - 1 have taken their data (D = the parameter registers)
         convert(u)
-        if u + 1 < 4 and u == 0:
-            issue_resid(1)                                                   # set 1 = accumulators unit 0 has just released
+        if u == units[0]:
+            issue_resid(u + 1)                                               # set 1 = accumulators unit 0 has just released (split-K: sent away)
         for r in range(4):
             emit(f"ds_read_b128 v[{D[r]}:{D[r] + 3}], v{V_RDB} offset:{r * 4 * ROWP}")
         emit("s_waitcnt lgkmcnt(0)")
@@ -1320,7 +1426,7 @@ def epilogue_f32r():
             q.issue(("S", u))
         emit(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
         advance(S_OB, u)
-        if u + 2 < 4:
+        if u + 2 <= units[-1]:
             issue_resid(u + 2)                                               # its register set was consumed by the adds above
     emit("s_waitcnt vmcnt(0)")
 
