@@ -211,6 +211,18 @@ int mq_w8a8_linear_tiled(const int8_t* a_tiled, const int8_t* w, int64_t M, int6
                          const float* out_offset, float out_qmin, float out_qmax, void* out,
                          int out_dtype, mq_stream_t stream);
 
+/* QLinear.forward (mobilellm/quantization/qmodule.py:341-358) with PER-GROUP weight grids (Quantizer with group_size != -1,
+ * qmodule.py:259-260, :292-293; --group_size of ptq/mobilequant.py:41, :157) on the int8 MFMA units:
+ *   out[m, n] = sum_g alpha[g, n] * float( sum_{k in g} a_q[m, k] w_q[n, k] + cw[g, n] * a_gsum[g, m] + t[g, n] ) + bias[n]
+ * a_q [M, K], w_q [N, K]: stored int8 values (index - shift); group g = input channels [g group_size, (g + 1) group_size);
+ * a_gsum [G, M]: per-group sums of the stored activations; alpha [G, N] = s_a s_w; cw [G, N] = w_shift - o_w; t [G, N] =
+ * c_a W_g + group_size c_a cw with c_a = a_shift - z_a and W_g the per-group sums of the stored weights (all exact integers: the
+ * bracket is the reference's sum of (ia - z_a)(iw - o_w) over the group).  fp32 output (an output quantizer follows as its own
+ * kernel).  group_size % 64 == 0, K % group_size == 0, N % 128 == 0. */
+int mq_w8a8_linear_grouped(const int8_t* a_q, const int8_t* w_q, int64_t M, int64_t N, int64_t K, int64_t group_size,
+                           const int32_t* a_gsum, const float* alpha, const int32_t* cw, const int32_t* t, const float* bias,
+                           float* out, mq_stream_t stream);
+
 /* The same fragment-blocked path for outputs that do not tile by 176 (N = 2048: o_proj / w2; N = 2560: q | k | v): generated gfx950
  * ISA on 128-column tiles.  mq_gemm_tiled128_supported(M, N, K) != 0: N % 128 == 0, K % 256 == 0, K >= 768.
  *   mq_w8a8_linear_tiled_residual  = mq_w8a8_linear_residual on fragment-blocked activations, for a 16-bit output grid

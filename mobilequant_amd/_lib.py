@@ -73,6 +73,7 @@ _SIGNATURES = {
     "mq_attention_probs_train": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, _P, c_float, c_float, _P, _P, c_float, c_float, c_float, _P, _P]),
     "mq_attention_probs_train_backward": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_float, c_float, _P, _P, c_float, c_float,
                                                   c_float, _P, _P, _P]),
+    "mq_w8a8_linear_grouped": (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "mq_quantize": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_int64, c_float, c_float, c_int, _P, _P, c_int, _P, _P]),
     "mq_linear_epilogue_prepare": (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "mq_w8a8_linear": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),

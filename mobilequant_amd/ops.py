@@ -349,6 +349,22 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     return out
 
 
+def int8_linear_grouped(a_q: torch.Tensor, w_q: torch.Tensor, group_size: int, a_gsum: torch.Tensor, alpha: torch.Tensor, cw: torch.Tensor,
+                        t: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """QLinear with per-group weight grids as an int8 MFMA GEMM (mq_w8a8_linear_grouped): a_q [M, K] / w_q [N, K] stored int8 values,
+    a_gsum [G, M] int32, alpha [G, N] fp32, cw / t [G, N] int32 (include/mobilequant_amd.h); fp32 [M, N] out."""
+    _dev(a_q, "a_q"); _dev(w_q, "w_q")
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a_q.device)
+    b = _f32(bias, "bias") if bias is not None else None
+    al = _f32(alpha, "alpha")
+    with _on(a_q, w_q, a_gsum, al, cw, t, b):
+        _lib.call("mq_w8a8_linear_grouped", a_q.data_ptr(), w_q.data_ptr(), M, N, K, int(group_size), a_gsum.data_ptr(), al.data_ptr(),
+                  cw.data_ptr(), t.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(), _stream())
+    return out
+
+
 def int8_linear_segmented(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: torch.Tensor, alpha: torch.Tensor, w_zp: torch.Tensor,
                           col_term: torch.Tensor, bias: Optional[torch.Tensor], seg_ends, grids, w4: bool = False,
                           a_tiled_rows: Optional[int] = None) -> torch.Tensor:

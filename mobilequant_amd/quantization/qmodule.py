@@ -716,6 +716,68 @@ class QLinear(nn.Linear, _QuantizedOp):
     def _int8_ready(self, x, weight) -> bool:
         return self._int8_reason(x, weight) is None
 
+    # -- per-group weight grids (Quantizer.group_size != -1; qmodule.py:259-260, :292-293) on the integer path -----------------------
+    def _grouped_reason(self, x, weight) -> Optional[str]:
+        """None when mq_w8a8_linear_grouped serves this call, else why the per-group recipe stays simulated."""
+        wq = self.weight_quantizer
+        gs, (N, K) = int(wq.qcfg.group_size), weight.shape
+        M = x.numel() // max(K, 1)
+        if gs % 64 or K % gs or N % 128:
+            return f"per-group weight grid: group_size {gs} / K {K} / N {N} outside mq_w8a8_linear_grouped (group_size % 64, K % group_size, N % 128)"
+        if M * K >= 2 ** 31 or N * K >= 2 ** 31 or M * N >= 2 ** 31:
+            return "per-group weight grid: operand too large"
+        if self._activation_grid(x) is None:
+            return "per-group weight grid: no 8-bit per-tensor grid on the input"
+        if _needs_grad(x, weight, self.bias, getattr(wq, "scale", None)):
+            return "gradient required"
+        return None
+
+    def _grouped_plan(self, weight):
+        """stored int8 weights [N, K], per-group sums, scales, offsets [N, G]; cached like _weight_plan"""
+        wq = self.weight_quantizer
+        if not wq._has_grid():
+            wq._prepare(weight.reshape(-1, wq.qcfg.group_size), "parameter")
+        key = ("grouped", weight.data_ptr(), _ver(weight), tuple(weight.shape), wq.grid_token(), wq.qcfg.bitwidth, wq.qcfg.is_symmetric,
+               wq.qcfg.group_size)
+        plan = getattr(self, "_gplan", None)
+        if plan is not None and plan["key"] == key and plan["wref"]() is weight:
+            return plan
+        N, K = weight.shape
+        gs = int(wq.qcfg.group_size)
+        G = K // gs
+        shift = 128 if wq.qmax > 127 else 0
+        w32 = weight.detach().to(torch.float32).reshape(N * G, gs)
+        q, gsum = ops.quantize(w32, wq.scale.detach().reshape(-1), wq.offset.detach().reshape(-1), wq.qmin, wq.qmax, q_dtype=MQ_I8,
+                               shift=shift, rows=N * G, want_row_sum=True)
+        cw = (shift - wq.offset.detach().reshape(N, G)).round().to(torch.int32)
+        plan = {"key": key, "wref": weakref.ref(weight), "w": q.view(N, K), "wsum_t": gsum.view(N, G).t().contiguous(),
+                "cw_t": cw.t().contiguous(), "sw_t": wq.scale.detach().reshape(N, G).t().contiguous().float(), "G": G, "gs": gs}
+        self._gplan = plan
+        return plan
+
+    def _forward_int8_grouped(self, x, weight, bias):
+        """x -> int8 image on the input grid (+ its per-group row sums) -> mq_w8a8_linear_grouped -> fp32 -> output quantizer.  The
+        group vectors follow the activation grid by device arithmetic (no host read-back: dynamic input grids work the same way)."""
+        grid = self._activation_grid(x, refresh=True)
+        plan = self._grouped_plan(weight)
+        N, K = weight.shape
+        if grid.scale.device != x.device:
+            grid.scale.data, grid.offset.data = grid.scale.to(x.device), grid.offset.to(x.device)
+        x2d = _materialize(x).reshape(-1, K)
+        M = x2d.shape[0]
+        a_q, _, a_shift = grid.quantize_to_int(x2d, MQ_I8, want_row_sum=False, chan_scale=self.input_chan_scale)
+        a_gsum = a_q.view(M, plan["G"], plan["gs"]).sum(-1, dtype=torch.int32).t().contiguous()
+        epi_key = (grid.grid_token(), a_shift)
+        if plan.get("epi_key") != epi_key:               # static grids: once; dynamic grids: per call (a handful of [G, N]-sized launches)
+            c_a = (a_shift - grid.offset.detach().reshape(())).round().to(torch.int32)
+            plan["t"] = (c_a * plan["wsum_t"] + (plan["gs"] * c_a) * plan["cw_t"]).contiguous()
+            plan["alpha"] = (grid.scale.detach().reshape(()).float() * plan["sw_t"]).contiguous()
+            plan["epi_key"] = epi_key
+        y = ops.int8_linear_grouped(a_q, plan["w"], plan["gs"], a_gsum, plan["alpha"], plan["cw_t"], plan["t"],
+                                    None if bias is None else bias.detach().float())
+        y = y.reshape(*x.shape[:-1], N).to(x.dtype)
+        return _apply(self.output_quantizer, y)
+
     def _weight_plan(self, weight):
         """Integer weights + column sums, cached until the weight or its quantizer changes (SURVEY 8a' item 5)."""
         wq = self.weight_quantizer
@@ -889,6 +951,11 @@ class QLinear(nn.Linear, _QuantizedOp):
         bias = self.temp_bias if self.use_temporary_parameter else self.bias
         weight = self._effective_weight(weight)
         reason = self._int8_reason(input_, weight)
+        if reason == "per-group weight grid":          # its own integer kernel (mq_w8a8_linear_grouped); the fused blocks stay away
+            reason = self._grouped_reason(input_, weight)
+            if reason is None:
+                self._count_path(None)
+                return self._forward_int8_grouped(input_, weight, bias)
         if reason is not None:
             self._count_path(reason)
         if reason is None:

@@ -13,6 +13,7 @@ Fixtures written (all data, no reference source text):
   quantizer_cases.npz     a5     Quantizer.forward outputs + integer indices, all qcfg combos
   quantizer_grads.npz     a5     autograd of Quantizer.forward: grad x / scale / offset (STE + clamp mask)
   qlinear_cases.npz       a8     QLinear.forward on small shapes (W8A8 / W4A8 / per-channel / bias)
+  qlinear_grouped_cases.npz  a8  QLinear.forward with per-group weight grids (group_size 64 / 128 / 256), the per-group scale / offset
   calib_stream.npz        a12/a13 real get_act_range / get_act_scales on a toy module stack
   checksums.json          sha256 of full-size index tensors (inputs re-creatable from numpy seeds)
   qrmsnorm_cases.npz      a10    QRMSNorm.forward (16-bit input / weight grids, 8- or 16-bit output, mixed-precision rules)
@@ -444,6 +445,42 @@ def gen_qlinear_dynamic_cases():
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, "qlinear_dynamic_cases.npz"), **out)
     print("qlinear_dynamic_cases:", [m["tag"] for m in meta])
+
+
+def gen_qlinear_grouped_cases():
+    """QLinear.forward with PER-GROUP weight grids (Quantizer.group_size != -1: qmodule.py:259-260, :292-293; CLI --group_size,
+    ptq/mobilequant.py:41, :157): 4- and 8-bit, asymmetric and symmetric, group sizes 64 / 128 / 256, with and without bias.  The weight
+    quantizer's per-group scale / offset the reference derived are kept too.  Served on the integer path by mq_w8a8_linear_grouped (round 4)."""
+    g = torch.Generator().manual_seed(777)
+    out, meta = {}, []
+    for cid, (M, K, N, gs, wbits, sym, bias, tag) in enumerate((
+            (48, 512, 128, 128, 4, False, True, "w4_g128_bias"),
+            (40, 256, 256, 64, 8, False, False, "w8_g64"),
+            (64, 1024, 128, 256, 4, True, True, "w4_g256_sym_bias"),
+            (33, 384, 128, 128, 8, True, False, "w8_g128_sym_ragged"))):
+        lin = nn.Linear(K, N, bias=bias)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(N, K, generator=g) * 0.05 * (1 + torch.rand(N, 1, generator=g)))
+            if bias:
+                lin.bias.copy_(torch.randn(N, generator=g) * 0.1)
+        x = torch.randn(1, M, K, generator=g) * 1.5
+        ql = Q.QLinear.from_float(lin, Q.QuantConfig(bitwidth=8), Q.QuantConfig(bitwidth=wbits, is_per_channel=True, group_size=gs, is_symmetric=sym),
+                                  Q.QuantConfig(bitwidth=8))
+        y_fp = nn.functional.linear(x, ql.weight, ql.bias)
+        act = {"input": [float(x.min()), float(x.max())], "output": [float(y_fp.min()), float(y_fp.max())]}
+        ql.set_scale_offset(act, "buffer")
+        with torch.no_grad():
+            y = ql(x)
+        k = f"c{cid}"
+        out[k + "_x"], out[k + "_w"], out[k + "_y"] = npf(x), npf(ql.weight), npf(y)
+        if bias:
+            out[k + "_b"] = npf(ql.bias)
+        out[k + "_wscale"], out[k + "_woffset"] = npf(ql.weight_quantizer.scale), npf(ql.weight_quantizer.offset)
+        out[k + "_oscale"] = npf(ql.output_quantizer.scale)
+        meta.append(dict(id=k, tag=tag, M=M, K=K, N=N, gs=gs, wbits=wbits, sym=sym, bias=bias, act=act))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "qlinear_grouped_cases.npz"), **out)
+    print("qlinear_grouped_cases:", [m["tag"] for m in meta])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1354,6 +1391,7 @@ if __name__ == "__main__":
     gen_quantizer_grads()
     gen_qlinear_cases()
     gen_qlinear_dynamic_cases()
+    gen_qlinear_grouped_cases()
     gen_calib_stream()
     gen_checksums()
     gen_api_surface()

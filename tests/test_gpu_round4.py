@@ -648,3 +648,83 @@ def test_pair_gemm_persistent_over_the_pair_is_the_two_workgroup_launch_bit_for_
         single = ops.int8_linear(a_t, h["w"], rs, h["alpha"], h["w_zp"], h["col_term"], h["bias"], out_scale=h["out_scale"], out_offset=h["out_offset"],
                                  out_qmin=0.0, out_qmax=255.0, out_dtype=MQ_U8, a_tiled_rows=M)
         assert torch.equal(single, a)
+
+
+@pytest.mark.parametrize("M,N,K,gs,wbits,sym", [(256, 256, 1024, 128, 4, False), (300, 384, 768, 64, 8, False), (2048, 2048, 2048, 128, 4, True),
+                                                 (77, 128, 512, 256, 8, True), (130, 5632, 2048, 128, 4, False)])
+def test_per_group_weight_grids_on_the_integer_path_exact_and_vs_the_simulated_module(dev, M, N, K, gs, wbits, sym):
+    """mq_w8a8_linear_grouped: QLinear with group_size != -1 (qmodule.py:259-260, :292-293).  (i) The kernel against the reference's
+    expression evaluated from the SAME integer indices in float64 -- sum_g s_a s_w[n, g] sum_{k in g} (ia - z_a)(iw - o_w[n, g]) + bias --
+    to fp32 accumulation accuracy (the integer brackets are exact).  (ii) The module on the integer path against the module on the
+    simulated path (fake-quant + fp32 library GEMM): within one step of the 8-bit output grid on < 1 % of the outputs, identical
+    elsewhere; int8_coverage() counts the call as integer."""
+    import mobilequant_amd as mq
+    g = torch.Generator().manual_seed(M + N + K + gs)
+    lin = torch.nn.Linear(K, N, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(N, K, generator=g) * 0.05 * (1 + torch.rand(N, 1, generator=g)))
+        lin.bias.copy_(torch.randn(N, generator=g) * 0.1)
+    q = mq.QLinear.from_float(lin.to(dev), mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=wbits, is_per_channel=True, group_size=gs, is_symmetric=sym),
+                              mq.QuantConfig(bitwidth=8)).requires_grad_(False)
+    x = (torch.randn(1, M, K, generator=g) * 1.3).to(dev)
+    y_fp = torch.nn.functional.linear(x, q.weight, q.bias)
+    q.set_scale_offset({"input": [float(x.min()), float(x.max())], "output": [float(y_fp.min()), float(y_fp.max())]}, "buffer")
+    assert q._int8_reason(x, q.weight) == "per-group weight grid" and q._grouped_reason(x, q.weight) is None
+    mq.int8_coverage(q, reset=True) if hasattr(mq, "int8_coverage") else None
+    y_int = q(x)
+    q.int8_mode = "off"
+    y_sim = q(x)
+    q.int8_mode = "auto"
+    oq = q.output_quantizer
+    step = float(oq.scale)
+    d = (y_int - y_sim).abs()
+    assert float(d.max()) <= step * 1.001 and float((d > step * 1e-3).float().mean()) < 1e-2, (float(d.max()) / step, float((d > step * 1e-3).float().mean()))
+    # (i) exact: rebuild the indices the kernel used and evaluate the reference expression in float64
+    plan, grid = q._grouped_plan(q.weight), q._activation_grid(x)
+    a_q, _, a_shift = grid.quantize_to_int(x.reshape(-1, K), mq.quantization.qmodule.MQ_I8)
+    ia = a_q.double() + a_shift
+    wq = q.weight_quantizer
+    G = K // gs
+    shift_w = 128 if wq.qmax > 127 else 0
+    iw = plan["w"].double() + shift_w
+    sw, ow = wq.scale.double().reshape(N, G), wq.offset.double().reshape(N, G)
+    a_deq = (ia - grid.offset.double()) * grid.scale.double()
+    w_deq = ((iw.reshape(N, G, gs) - ow[:, :, None]) * sw[:, :, None]).reshape(N, K)
+    want = a_deq @ w_deq.t() + q.bias.double()
+    q.output_quantizer.enable = False
+    got = q(x).reshape(M, N).double()
+    q.output_quantizer.enable = True
+    err = (got - want).abs().max()
+    assert float(err) <= 2e-5 * float(want.abs().max()) + 1e-6, float(err)
+
+
+def test_per_group_weight_grids_vs_the_reference_outputs(dev):
+    """tests/golden/qlinear_grouped_cases.npz: the reference's QLinear with group_size 64 / 128 / 256, 4- / 8-bit, symmetric / asymmetric
+    weight grids.  The module takes the integer path (mq_w8a8_linear_grouped), derives the reference's per-group scale / offset bit for
+    bit, and lands within one output LSB of the reference's outputs on every element, > 99 % identical."""
+    import mobilequant_amd as mq
+    from conftest import load_meta, load_npz
+    z = load_npz("qlinear_grouped_cases.npz")
+    T = lambda a: torch.from_numpy(a).to(dev)       # noqa: E731
+    for m in load_meta(z):
+        k = m["id"]
+        lin = torch.nn.Linear(m["K"], m["N"], bias=m["bias"]).to(dev)
+        with torch.no_grad():
+            lin.weight.copy_(T(z[k + "_w"]))
+            if m["bias"]:
+                lin.bias.copy_(T(z[k + "_b"]))
+        ql = mq.QLinear.from_float(lin, mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=m["wbits"], is_per_channel=True, group_size=m["gs"],
+                                                                                   is_symmetric=m["sym"]), mq.QuantConfig(bitwidth=8)).requires_grad_(False)
+        ql.set_scale_offset(m["act"], "buffer")
+        x = T(z[k + "_x"])
+        with torch.no_grad():
+            y = ql(x)
+        cov = mq.int8_coverage(ql, reset=True)
+        assert cov["simulated_calls"] == 0 and cov["int8_calls"] == 1, (m["tag"], cov["summary"])
+        wq = ql.weight_quantizer
+        assert np.array_equal(wq.scale.detach().cpu().numpy().reshape(-1), z[k + "_wscale"].reshape(-1)), m["tag"]
+        assert np.array_equal(wq.offset.detach().cpu().numpy().reshape(-1) + 0.0, z[k + "_woffset"].reshape(-1) + 0.0), m["tag"]
+        lsb = float(z[k + "_oscale"])
+        d = np.abs(y.cpu().numpy() - z[k + "_y"])
+        assert d.max() <= lsb * 1.01, (m["tag"], d.max(), lsb)
+        assert (d == 0).mean() > 0.99, (m["tag"], (d == 0).mean())

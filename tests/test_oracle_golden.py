@@ -143,6 +143,25 @@ def test_qlinear_dynamic_cases_oracle():
         assert (d == 0).mean() > (0.995 if m["out_bits"] == 8 else 0.90), (m["tag"], (d == 0).mean())
 
 
+def test_qlinear_grouped_cases_oracle():
+    """Per-group weight grids (qmodule.py:259-260, :292-293): the oracle's weight quantizer reshapes to [-1, group_size] as the reference
+    does and reproduces its per-group scale / offset bit for bit; outputs within one LSB, > 99.5 % identical (BLAS summation order)."""
+    z = load_npz("qlinear_grouped_cases.npz")
+    for m in load_meta(z):
+        k = m["id"]
+        wq = O.QuantizerOracle(m["wbits"], m["gs"], m["sym"], True)
+        iq, oq = O.QuantizerOracle(8), O.QuantizerOracle(8)
+        iq.set_from_minmax(*m["act"]["input"])
+        oq.set_from_minmax(*m["act"]["output"])
+        y = O.qlinear_sim(z[k + "_x"], z[k + "_w"], z[k + "_b"] if m["bias"] else None, wq, iq, oq)
+        assert np.array_equal(np.asarray(wq.scale, dtype=np.float32).reshape(-1), z[k + "_wscale"].reshape(-1)), m["tag"]
+        assert np.array_equal(np.asarray(wq.offset, dtype=np.float32).reshape(-1) + 0.0, z[k + "_woffset"].reshape(-1) + 0.0), m["tag"]
+        lsb = float(z[k + "_oscale"])
+        d = np.abs(y - z[k + "_y"])
+        assert d.max() <= lsb * 1.01, (m["tag"], d.max(), lsb)
+        assert (d == 0).mean() > 0.995, (m["tag"], (d == 0).mean())
+
+
 def test_qlinear_int_equivalence():
     """SURVEY 8a' item 9: the integer contraction reproduces the simulated path to fp32 round-off."""
     z = load_npz("qlinear_cases.npz")
