@@ -140,3 +140,7 @@ def test_argument_checks_fail_before_any_launch():
     assert lib.mq_attention_probs_train(p, 64, 128, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 0.0, p, None) == 1
     assert lib.mq_attention_probs_train_backward(p, p, 0, 128, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 8.0, None, None, None) == 0
     assert lib.mq_attention_probs_train_backward(p, p, 64, 128, None, 1, p, p, 0.0, 65535.0, p, p, 0.0, 65535.0, 8.0, p, None, None) == 1
+    # per-group weight grids: group size, N
+    assert lib.mq_w8a8_linear_grouped(p, p, 64, 128, 1024, 100, p, p, p, p, None, p, None) == 1 and b"group_size" in lib.mq_last_error()
+    assert lib.mq_w8a8_linear_grouped(p, p, 64, 100, 1024, 128, p, p, p, p, None, p, None) == 1 and b"multiple of 128" in lib.mq_last_error()
+    assert lib.mq_w8a8_linear_grouped(p, p, 0, 128, 1024, 128, None, None, None, None, None, None, None) == 0

@@ -179,5 +179,5 @@ def test_committed_fixtures_are_what_the_generator_writes():
     spec = importlib.util.spec_from_file_location("check_golden", os.path.join(root, "tools", "check_golden.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(["gen_scale_offset_grid", "gen_qlinear_dynamic_cases", "gen_decode_case_w4", "gen_decode_case_w8pc_mha", "gen_decode_case_gelu"],
+    assert mod.run(["gen_scale_offset_grid", "gen_qlinear_dynamic_cases", "gen_qlinear_grouped_cases", "gen_decode_case_w4", "gen_decode_case_w8pc_mha", "gen_decode_case_gelu"],
                    ref) == 0
