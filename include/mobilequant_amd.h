@@ -234,6 +234,12 @@ int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_
                                   const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
                                   const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
                                   const float* resid, float* out, mq_stream_t stream);
+/* The same with PACKED 4-bit weights (mq_pack_w4's image, [N, K / 2] bytes): the packed pieces are expanded once per workgroup into the
+ * int8 ring of the generated 128 x 128 program (tools/gen_fr_asm.py frw4x_128r).  One weight image for prefill and decode. */
+int mq_w4a8_linear_tiled_residual(const int8_t* a_tiled, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                                  const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                                  const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
+                                  const float* resid, float* out, mq_stream_t stream);
 
 /* Two QLinears over the SAME activation in one launch -- w1 / w3 of a gated FFN receive the same tensor (hf_model.py:1057:
  * w2(act(w1(x)) * w3(x))).  Both problems have the shape M x N x K (mq_gemm_tiled_supported, K % 256 == 0, K >= 768), their

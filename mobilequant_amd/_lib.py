@@ -83,6 +83,7 @@ _SIGNATURES = {
     "mq_w4a8_linear_tiled": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, c_int, _P]),
     "mq_w8a8_linear_tiled_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
     "mq_w8a8_linear_tiled_residual": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
+    "mq_w4a8_linear_tiled_residual": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
     "mq_gemm_tiled128_supported": (c_int, [c_int64, c_int64, c_int64]),
     "mq_gemm_set_residual_tile": (c_int, [c_int]),
     "mq_gemm_set_segmented_tile": (c_int, [c_int]),

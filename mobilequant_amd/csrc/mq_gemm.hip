@@ -37,6 +37,7 @@
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
 #include "mq_gemm_fr128rs_asm.inc"
+#include "mq_gemm_frw4x_128r_asm.inc"
 #include "mq_gemm_frw4_asm.inc"
 #include "mq_gemm_frw4_128_asm.inc"
 #include "mq_gemm_frw4x_asm.inc"
@@ -1137,6 +1138,86 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
 #undef MQ_FRW4_OPERANDS
 }
 
+// Packed 4-bit weights in front of the RESIDUAL epilogue (tools/gen_fr_asm.py variant frw4x_128r): o_proj / w2 from the mq_pack_w4 image
+// on 128 x 128 tiles, four waves -- fr128r's program with the W pieces (16 rows x 64 B, two per wave and stage) loaded into registers,
+// split and written into the int8 ring once per workgroup.  fp32 out = resid + Q16(linear).
+__global__ void __launch_bounds__(256) gemm_i8_frw4r_kernel(const GemmArgs args) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn, args.group_m);
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int M = args.M, N = args.N, K = args.K;
+  const int KT = K / BK;
+  unsigned sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = n0 + (wave + i * 4) * 16 + (lane >> 2);          // piece wave + 4 i: 16 rows x 64 packed bytes per stage
+    row = row < N ? row : N - 1;
+    sw[i] = (unsigned)row * (unsigned)(K >> 1) + (unsigned)((lane & 3) << 4);
+  }
+  const int m0w = m0 + wave * 32;
+  const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+  unsigned rb0 = (unsigned)(m0w >> 4), rb1 = rb0 + 1;
+  rb0 = rb0 < rb_max ? rb0 : rb_max;
+  rb1 = rb1 < rb_max ? rb1 : rb_max;
+  const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  unsigned rsofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0w + i * 16 + (lane & 15);
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
+    rsofs[i] = (unsigned)m * 4u;
+  }
+  const int8_t* a_ptr = args.a;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  const float* alpha_p = args.alpha + n0;
+  const float* bias_p = args.bias + n0;
+  const int32_t* wzp_p = args.w_zp + n0;
+  const int32_t* ct_p = args.col_term + n0;
+  const int32_t* rs_p = args.a_rowsum;
+  const float* so_ptr = args.out_scale;
+  const float* oo_ptr = args.out_offset;
+  const int qmin_bits = __builtin_amdgcn_readfirstlane(__float_as_int(args.out_qmin));
+  const int qmax_bits = __builtin_amdgcn_readfirstlane(__float_as_int(args.out_qmax));
+  float* outw = reinterpret_cast<float*>(args.out) + (size_t)m0w * N + n0;
+  const float* resid = args.resid + (size_t)m0w * N + n0;
+  const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
+  const unsigned tid = threadIdx.x;
+  asm volatile(MQ_FRW4X_128R_ASM_BODY
+               : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1])
+               : [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [outw] "s"(outw), [resid] "s"(resid), [alpha] "s"(alpha_p),
+                 [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr),
+                 [qmin] "s"(qmin_bits), [qmax] "s"(qmax_bits), [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [av0] "v"(av0), [av1] "v"(av1),
+                 [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
+               : MQ_FRW4X_128R_ASM_CLOBBERS);
+}
+
+static int launch_frw4r(GemmArgs a, hipStream_t st) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frw4r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_FRW4X_128R_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", MQ_FRW4X_128R_LDS_BYTES, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  a.has_rowsum = a.a_rowsum != nullptr;
+  if (a.a_rowsum == nullptr) a.a_rowsum = a.col_term;
+  if (a.bias == nullptr) a.bias = a.alpha;
+  a.grid_m = (a.M + 127) / 128;
+  a.grid_n = a.N / 128;
+  a.group_m = g_group_m.load();
+  gemm_i8_frw4r_kernel<<<a.grid_m * a.grid_n, 256, MQ_FRW4X_128R_LDS_BYTES, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
+}
+
 static bool gemm_frw4_shape(int64_t M, int64_t N, int64_t K) { return M > 0 && (N % 176 == 0 || N % 128 == 0) && K % 256 == 0 && K >= 768; }
 
 static std::atomic<int> g_w4_mode{1};           // mobilequant_amd_tuning.h: 1 = expand once per workgroup (frw4x), 0 = per-wave unpack (frw4)
@@ -1800,6 +1881,26 @@ int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_
   if (forced == 512 && can_split) return launch_fr128<FR128RS>(g, as_stream(stream));
   const bool tall = forced ? forced == 256 : tiles128 > 512;
   return tall ? launch_fr128<FR128R8>(g, as_stream(stream)) : launch_fr128<FR128R>(g, as_stream(stream));
+}
+
+int mq_w4a8_linear_tiled_residual(const int8_t* a_tiled, const uint8_t* w_packed, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                                  const float* alpha, const int32_t* w_zp, const int32_t* col_term, const float* bias,
+                                  const float* out_scale, const float* out_offset, float out_qmin, float out_qmax,
+                                  const float* resid, float* out, mq_stream_t stream) {
+  const char* fn = "mq_w4a8_linear_tiled_residual";
+  int rc = check_common(fn, a_tiled, w_packed, M, N, K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset, out, 2);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32) && M * N * 4 < (1ll << 32), "%s: operand too large", fn);
+  MQ_REQUIRE(resid != nullptr && aligned(resid, 16), "%s: resid must be non-null and 16-byte aligned", fn);
+  MQ_REQUIRE(out_scale != nullptr && out_qmax - out_qmin > 255.0f, "%s: a 16-bit output grid is required", fn);
+  if (!gemm_fr128_shape(M, N, K)) {
+    set_error("%s: shape %lldx%lldx%lld is not served (mq_gemm_tiled128_supported: N %% 128 == 0, K %% 256 == 0, K >= 768)", fn, (long long)M,
+              (long long)N, (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  GemmArgs g{a_tiled, w_packed, (int)M, (int)N, (int)K, a_rowsum, alpha, w_zp, col_term, bias, out_scale, out_offset,
+             out_qmin, out_qmax, out, MQ_F32, 0, 0, bias != nullptr, 1, 0, g_dbg_ts, resid};
+  return launch_frw4r(g, as_stream(stream));
 }
 
 int mq_w8a8_linear_tiled_segmented(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,

@@ -324,8 +324,10 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
     os_ = _f32(out_scale, "out_scale") if out_scale is not None else None
     oo_ = _f32(out_offset, "out_offset") if out_offset is not None else None
     if resid is not None:
-        if w4 or out_dtype != MQ_F32 or M <= 8:
-            raise RuntimeError("mobilequant_amd: int8_linear(resid=...) needs int8 operands, fp32 output and M > 8")
+        if w4 and a_tiled_rows is None:
+            raise RuntimeError("mobilequant_amd: int8_linear(resid=..., w4=True) needs the fragment-blocked activation image (a_tiled_rows)")
+        if out_dtype != MQ_F32 or M <= 8:
+            raise RuntimeError("mobilequant_amd: int8_linear(resid=...) needs fp32 output and M > 8")
         if a_tiled_rows is not None and not (os_ is not None and out_qmax - out_qmin > 255.0 and gemm_tiled128_supported(M, N, K)):
             raise RuntimeError("mobilequant_amd: int8_linear(resid=..., a_tiled_rows=...) needs a 16-bit output grid and a "
                                "gemm_tiled128_supported shape")
@@ -333,7 +335,8 @@ def int8_linear(a_q: torch.Tensor, w_q: torch.Tensor, a_rowsum: Optional[torch.T
         if resid.numel() != M * N or resid.data_ptr() == out.data_ptr():
             raise RuntimeError("mobilequant_amd: resid must be [M, N] and must not alias the output")
         with _on(a_q, w_q, a_rowsum, alpha, w_zp, col_term, b, os_, oo_, out, resid):
-            _lib.call("mq_w8a8_linear_tiled_residual" if a_tiled_rows is not None else "mq_w8a8_linear_residual", a_q.data_ptr(), w_q.data_ptr(), M, N, K,
+            _lib.call(("mq_w4a8_linear_tiled_residual" if w4 else "mq_w8a8_linear_tiled_residual") if a_tiled_rows is not None else "mq_w8a8_linear_residual",
+                      a_q.data_ptr(), w_q.data_ptr(), M, N, K,
                       a_rowsum.data_ptr() if a_rowsum is not None else None, alpha.data_ptr(), w_zp.data_ptr(), col_term.data_ptr(),
                       b.data_ptr() if b is not None else None, os_.data_ptr() if os_ is not None else None,
                       oo_.data_ptr() if oo_ is not None else None, float(out_qmin), float(out_qmax), resid.data_ptr(), out.data_ptr(),

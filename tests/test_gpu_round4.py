@@ -728,3 +728,41 @@ def test_per_group_weight_grids_vs_the_reference_outputs(dev):
         d = np.abs(y.cpu().numpy() - z[k + "_y"])
         assert d.max() <= lsb * 1.01, (m["tag"], d.max(), lsb)
         assert (d == 0).mean() > 0.99, (m["tag"], (d == 0).mean())
+
+
+@pytest.mark.parametrize("M,N,K,per_row,with_bias", [(2048, 2048, 2048, True, False), (2048, 2048, 5632, True, True), (300, 256, 768, False, False),
+                                                      (129, 384, 1024, True, True), (1024, 2048, 16384, True, False)])
+def test_packed_w4_residual_gemm_is_the_int8_image_residual_gemm_bit_for_bit(dev, M, N, K, per_row, with_bias):
+    """mq_w4a8_linear_tiled_residual (generated ISA frw4x_128r: the packed pieces of o_proj / w2 expanded once per workgroup into the int8
+    ring, 128 x 128 tiles, x + Q16(linear) in the store) fed a numpy-built packed image (oracle.pack_w4) against
+    mq_w8a8_linear_tiled_residual on the one-byte-per-nibble image of the same numbers: the same fp32 bits, ragged M included."""
+    from oracle import mq_oracle as O
+    from test_gpu_round2 import T, tiled_image
+    from mobilequant_amd import ops
+    F32 = np.float32
+    rng = np.random.default_rng(M + N + K + 1)
+    qa = rng.integers(0, 256, size=(M, K))
+    qw = rng.integers(0, 16, size=(N, K))
+    za = int(rng.integers(0, 256))
+    zw = rng.integers(0, 16, size=N) if per_row else np.full(N, int(rng.integers(0, 16)))
+    sw = (rng.random(N, dtype=F32) * F32(1e-2) + F32(1e-3)) if per_row else np.full(N, F32(7e-3), F32)
+    a8 = (qa - 128).astype(np.int8)
+    a_t = T(tiled_image(a8), dev)
+    rs = T(a8.sum(1).astype(np.int32), dev)
+    colsum = T(qw.sum(1).astype(np.int32), dev)
+    wsc = T(sw, dev) if per_row else T(sw[:1], dev)
+    wof = T(zw.astype(F32), dev) if per_row else T(zw[:1].astype(F32), dev)
+    alpha, wzp, ct = ops.linear_epilogue_prepare(T(np.array([0.02], F32), dev), T(np.array([za], F32), dev), 128, wsc, wof, 0, colsum, K)
+    b = T(rng.standard_normal(N, dtype=F32), dev) if with_bias else None
+    resid = torch.randn(M, N, device=dev)
+    pre = (qa - za).astype(np.float64) @ ((qw - zw[:, None]) * sw[:, None]).astype(np.float64).T * 0.02
+    span = float(np.percentile(pre, 99.9) - np.percentile(pre, 0.1))
+    step = span / 50000.0
+    so, oo = torch.tensor([step], device=dev), torch.tensor([float(np.rint(32768.0 - np.median(pre) / step))], device=dev)
+    kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0, resid=resid, a_tiled_rows=M)
+    want = ops.int8_linear(a_t, T(qw.astype(np.int8), dev), rs, alpha, wzp, ct, b, **kw)
+    got = ops.int8_linear(a_t, T(O.pack_w4(qw, 0), dev), rs, alpha, wzp, ct, b, w4=True, **kw)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.equal(got, want), float((got - want).abs().max())
+    q = torch.round((want - resid) / so + oo)
+    assert float(q.min()) < 20000 and float(q.max()) > 45000            # the 16-bit grid is exercised, not saturated

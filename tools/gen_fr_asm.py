@@ -61,6 +61,8 @@ VARIANTS = {
     # are the int8 kernel's (frw4 spends 12 VALU per 4 MFMAs in EVERY wave on the unpack and measured 30 % slower than the int8 image)
     "frw4x":     (176, 8, "u8w4x", "MQ_FRW4X",     "mq_gemm_frw4x_asm.inc"),
     "frw4x_128": (128, 8, "u8w4x", "MQ_FRW4X_128", "mq_gemm_frw4x_128_asm.inc"),
+    # ... and in front of the residual epilogue: o_proj / w2 (N = 2048) from packed nibbles on 128 x 128 tiles, four waves
+    "frw4x_128r": (128, 4, "f32rw4x", "MQ_FRW4X_128R", "mq_gemm_frw4x_128r_asm.inc"),
 }
 
 
@@ -79,8 +81,12 @@ def configure(name):
     if SPLITK:
         EPI = "f32r"
     global W4, W4X
-    W4X = EPI == "u8w4x"
-    if W4X:
+    W4X = EPI in ("u8w4x", "f32rw4x")
+    if EPI == "f32rw4x":
+        EPI = "f32r"
+        SCALAR_GRID = True
+        TAIL = False
+    elif W4X:
         EPI = "u8"
         SCALAR_GRID = BN == 176
         TAIL = True
