@@ -1143,7 +1143,7 @@ def bench_variants(dev, step, args):
         r = bench_layer_full(dev, modes=("fused",), wbits=4)
         extras["layer_prefill_full_w4a8_packed_only"] = {"fused_us": r.get("fused_us"), "note": "QLinear.w4_prefill = 'packed': every 4-bit module "
                                                          "holds only the mq_pack_w4 image; q | k | v and w1 / w3 run the generated packed kernels, "
-                                                         "o_proj / w2 the packed tile kernel + a separate residual add"}
+                                                         "o_proj / w2 the generated packed residual kernel (mq_w4a8_linear_tiled_residual)"}
     finally:
         _mq.QLinear.w4_prefill = "image"
     # BASELINE.json configs[2] / [3] on their own leaf graphs (LayerNorm + biased q|k|v + 25 % rotary; head_dim 256 / MQA / GeGLU / FFN 16384)

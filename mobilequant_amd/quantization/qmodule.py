@@ -923,13 +923,14 @@ class QLinear(nn.Linear, _QuantizedOp):
             return _tag_grid(out, oq) if fused else out
         if resid is not None:
             rows = a_q.shape[0] if tiled_rows is None else tiled_rows
-            if (not plan["w4"] and not f16 and rows > 8 and resid.dtype == torch.float32 and resid.is_contiguous()
+            # packed-only 4-bit weights: the generated residual kernel expands them from the packed image (mq_w4a8_linear_tiled_residual)
+            if ((not plan["w4"] or tiled_rows is not None) and not f16 and rows > 8 and resid.dtype == torch.float32 and resid.is_contiguous()
                     and (tiled_rows is None or self._tiled_residual_ok(rows, N, K))):
                 out = ops.int8_linear(
                     a_q, plan["w"], a_rs, plan["alpha"], plan["w_zp"], plan["col_term"], bias,
                     out_scale=oq.scale.detach() if fused else None, out_offset=oq.offset.detach() if fused else None,
                     out_qmin=oq.qmin if fused else 0.0, out_qmax=oq.qmax if fused else 0.0, out_dtype=MQ_F32, resid=resid,
-                    a_tiled_rows=tiled_rows)
+                    a_tiled_rows=tiled_rows, w4=plan["w4"])
                 return out.reshape(*lead, N)
             return resid + self._int8_from_image(x, weight, bias, grid, a_q, a_rs, a_shift, tiled_rows, decode, lead_shape)
         out = ops.int8_linear(
@@ -1496,7 +1497,7 @@ def _gated_mlp_forward(self, x, resid=None):
         cached = (None, _gated_table_of(self, act, silu, o1, o3, iq2, x.device))
         # w2 with the residual: the fragment-blocked image its generated kernel reads
         w2_tiled = (resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and N % 64 == 0
-                    and not w2._weight_plan(wt2)["w4"] and w2._tiled_residual_ok(M, wt2.shape[0], N))
+                    and w2._tiled_residual_ok(M, wt2.shape[0], N))
         p_q, p_rs = ops.gated_lookup(a_idx, b_idx, cached[1], tiled=w2_tiled)
         if w2_tiled:
             return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q, p_rs, 128, M,
