@@ -264,6 +264,14 @@ int mq_w8a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int6
                                const int8_t* w1, const float* alpha1, const int32_t* w_zp1, const int32_t* col_term1,
                                const float* bias1, const float* out_scale1, const float* out_offset1,
                                const int8_t* table, uint8_t* idx_scratch, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream);
+/* The same from PACKED 4-bit weights (two mq_pack_w4 images, [N, K / 2] bytes each): w1 on the packed index kernel, w3 on the packed
+ * gate-epilogue kernel (tools/gen_fr_asm.py frw4x / frgw4x and their 128-column forms).  Identical bytes. */
+int mq_w4a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                               const uint8_t* w0, const float* alpha0, const int32_t* w_zp0, const int32_t* col_term0,
+                               const float* bias0, const float* out_scale0, const float* out_offset0,
+                               const uint8_t* w1, const float* alpha1, const int32_t* w_zp1, const int32_t* col_term1,
+                               const float* bias1, const float* out_scale1, const float* out_offset1,
+                               const int8_t* table, uint8_t* idx_scratch, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream);
 
 /* Decode shapes (M <= 8 tokens, M*K < 64 KiB, K % 256 == 0): the activation quantizer (qmodule.py:349-351) fused
  * into the weight-streaming GEMV -- x is the fp32 [M,K] activation, quantised on the fly to its grid

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "mq_w8a8_linear_tiled": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P]),
     "mq_w8a8_linear_tiled_pair": (c_int, [_P, c_int64, c_int64, c_int64, _P] + [_P] * 16 + [c_int, _P]),
     "mq_w8a8_linear_tiled_gated": (c_int, [_P, c_int64, c_int64, c_int64, _P] + [_P] * 14 + [_P, _P, _P, _P, _P]),
+    "mq_w4a8_linear_tiled_gated": (c_int, [_P, c_int64, c_int64, c_int64, _P] + [_P] * 14 + [_P, _P, _P, _P, _P]),
     "mq_w8a8_linear_f32in": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P,
                                      c_float, c_float, _P, c_int, _P]),
     "mq_w4a8_linear_f32in": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P,

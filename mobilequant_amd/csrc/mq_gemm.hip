@@ -38,6 +38,8 @@
 #include "mq_gemm_fr128r8_asm.inc"
 #include "mq_gemm_fr128rs_asm.inc"
 #include "mq_gemm_frw4x_128r_asm.inc"
+#include "mq_gemm_frgw4x_asm.inc"
+#include "mq_gemm_frgw4x_128_asm.inc"
 #include "mq_gemm_frw4_asm.inc"
 #include "mq_gemm_frw4_128_asm.inc"
 #include "mq_gemm_frw4x_asm.inc"
@@ -1136,6 +1138,10 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
     }
   }
 #undef MQ_FRW4_OPERANDS
+  if (args.zero_buf != nullptr) {               // (packed gated pair, first launch: 512 ints per workgroup)
+    const int zi = (int)blockIdx.x * 512 + (int)threadIdx.x;
+    if (zi < args.zero_count) args.zero_buf[zi] = 0;
+  }
 }
 
 // Packed 4-bit weights in front of the RESIDUAL epilogue (tools/gen_fr_asm.py variant frw4x_128r): o_proj / w2 from the mq_pack_w4 image
@@ -1324,6 +1330,90 @@ static int launch_frg(const GemmArgs& a, hipStream_t st) {
     attr_set.mark(dev);
   }
   gemm_i8_frg_kernel<BNT><<<a.grid_m * a.grid_n, 512, LDS, st>>>(a);
+  MQ_LAUNCH_CHECK("mq_gemm");
+  return MQ_OK;
+}
+
+// w3 of a gated FFN from PACKED 4-bit weights with the gate in its epilogue (tools/gen_fr_asm.py variants frgw4x / frgw4x_128): frg's
+// program with the W pieces (16 rows x 64 packed bytes) loaded into registers and expanded once per workgroup into the int8 ring.
+template <int BNT>
+__global__ void __launch_bounds__(512) gemm_i8_frgw4_kernel(const GemmArgs args) {
+  constexpr int FNT = BNT / 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_of_block(blockIdx.x, args.grid_m * args.grid_n, args.grid_m, args.grid_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * BNT;
+  const int M = args.M, N = args.N, K = args.K;
+  const int KT = K / BK;
+  unsigned sw[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < (BNT == 176 ? 2 : 1); ++i) {
+    int piece = wave + i * 8;
+    piece = piece < FNT ? piece : FNT - 1;
+    int row = n0 + piece * 16 + (lane >> 2);
+    row = row < N ? row : N - 1;
+    sw[i] = (unsigned)row * (unsigned)(K >> 1) + (unsigned)((lane & 3) << 4);
+  }
+  const int m0w = m0 + wave * 32;
+  const unsigned rb_max = (unsigned)((M + 15) >> 4) - 1;
+  unsigned rb0 = (unsigned)(m0w >> 4), rb1 = rb0 + 1;
+  rb0 = rb0 < rb_max ? rb0 : rb_max;
+  rb1 = rb1 < rb_max ? rb1 : rb_max;
+  const unsigned av0 = (rb0 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  const unsigned av1 = (rb1 * (unsigned)(K >> 6)) * 1024u + ((unsigned)lane << 4);
+  unsigned rsofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0w + i * 16 + (lane & 15);
+    m = args.has_rowsum ? (m < M ? m : M - 1) : 0;
+    rsofs[i] = (unsigned)m * 4u;
+  }
+  const float* so_ptr = args.out_scale;
+  const float* oo_ptr = args.out_offset;
+  const int8_t* a_ptr = args.a;
+  const int8_t* w_ptr = reinterpret_cast<const int8_t*>(args.w);
+  const float* alpha_p = args.alpha + n0;
+  const float* bias_p = args.bias + n0;
+  const int32_t* wzp_p = args.w_zp + n0;
+  const int32_t* ct_p = args.col_term + n0;
+  const int32_t* rs_p = args.a_rowsum;
+  const uint8_t* aidx = args.gate_aidx + (size_t)m0w * N + n0;
+  const int8_t* table = args.gate_table;
+  int8_t* qout = args.gate_q;
+  int32_t* rsout = args.gate_rowsum + m0w;
+  const int mrem = __builtin_amdgcn_readfirstlane(M - m0w);
+  const int flags = __builtin_amdgcn_readfirstlane((args.has_bias ? 1 : 0) | (args.has_rowsum ? 2 : 0));
+  const int ldn = __builtin_amdgcn_readfirstlane(N), kt = __builtin_amdgcn_readfirstlane(KT);
+  const int cg0 = __builtin_amdgcn_readfirstlane(tn * (BNT / 16)), mb0 = __builtin_amdgcn_readfirstlane(m0w >> 4);
+  const unsigned tid = threadIdx.x;
+#define MQ_FRGW4_OPERANDS                                                                                                          \
+  [kt] "s"(kt), [wave] "s"(wave), [aptr] "s"(a_ptr), [wptr] "s"(w_ptr), [aidx] "s"(aidx), [alpha] "s"(alpha_p),                    \
+      [bias] "s"(bias_p), [wzp] "s"(wzp_p), [ct] "s"(ct_p), [rsptr] "s"(rs_p), [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr),       \
+      [ldn] "s"(ldn), [mrem] "s"(mrem), [flags] "s"(flags), [table] "s"(table), [qout] "s"(qout), [rsout] "s"(rsout),              \
+      [cg0] "s"(cg0), [mb0] "s"(mb0), [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1])
+  if constexpr (BNT == 176) {
+    asm volatile(MQ_FRGW4X_ASM_BODY : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]) : MQ_FRGW4_OPERANDS : MQ_FRGW4X_ASM_CLOBBERS);
+  } else {
+    asm volatile(MQ_FRGW4X_128_ASM_BODY : [sw0] "+v"(sw[0]) : MQ_FRGW4_OPERANDS : MQ_FRGW4X_128_ASM_CLOBBERS);
+  }
+#undef MQ_FRGW4_OPERANDS
+}
+
+template <int BNT>
+static int launch_frgw4(const GemmArgs& a, hipStream_t st) {
+  constexpr int LDS = BNT == 176 ? MQ_FRGW4X_LDS_BYTES : MQ_FRGW4X_128_LDS_BYTES;
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.done(dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_frgw4_kernel<BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("mq_gemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return MQ_EHIP;
+    }
+    attr_set.mark(dev);
+  }
+  gemm_i8_frgw4_kernel<BNT><<<a.grid_m * a.grid_n, 512, LDS, st>>>(a);
   MQ_LAUNCH_CHECK("mq_gemm");
   return MQ_OK;
 }
@@ -1987,6 +2077,46 @@ int mq_w8a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int6
   rc = launch_fr(g0, as_stream(stream));
   if (rc != MQ_OK) return rc;
   return launch_frg<176>(g1, as_stream(stream));
+}
+
+int mq_w4a8_linear_tiled_gated(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
+                               const uint8_t* w0, const float* alpha0, const int32_t* w_zp0, const int32_t* col_term0,
+                               const float* bias0, const float* out_scale0, const float* out_offset0,
+                               const uint8_t* w1, const float* alpha1, const int32_t* w_zp1, const int32_t* col_term1,
+                               const float* bias1, const float* out_scale1, const float* out_offset1,
+                               const int8_t* table, uint8_t* idx_scratch, int8_t* q_tiled, int32_t* row_sum, mq_stream_t stream) {
+  const char* fn = "mq_w4a8_linear_tiled_gated";
+  int rc = check_common(fn, a_tiled, w0, M, N, K, a_rowsum, alpha0, w_zp0, col_term0, bias0, out_scale0, out_offset0, idx_scratch, 2);
+  if (rc != MQ_OK) return rc;
+  rc = check_common(fn, a_tiled, w1, M, N, K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1, q_tiled, 2);
+  if (rc != MQ_OK) return rc;
+  MQ_REQUIRE(((M + 15) / 16) * 16 * K < (1ll << 32) && ((M + 15) / 16) * 16 * N < (1ll << 32), "%s: operand too large", fn);
+  MQ_REQUIRE(out_scale0 && out_scale1 && table && row_sum && aligned(table, 16) && aligned(idx_scratch, 16) && aligned(q_tiled, 16),
+             "%s: both linears carry an 8-bit unsigned output grid; table / scratch / image must be non-null and 16-byte aligned", fn);
+  GemmArgs g0{a_tiled, w0, (int)M, (int)N, (int)K, a_rowsum, alpha0, w_zp0, col_term0, bias0, out_scale0, out_offset0,
+              0.f, 255.f, idx_scratch, MQ_U8, 0, 0, bias0 != nullptr, 1, 0, g_dbg_ts};
+  GemmArgs g1{a_tiled, w1, (int)M, (int)N, (int)K, a_rowsum, alpha1, w_zp1, col_term1, bias1, out_scale1, out_offset1,
+              0.f, 255.f, q_tiled, MQ_U8, 0, 0, bias1 != nullptr, 1, 0, g_dbg_ts};
+  const bool wide = gemm_tiled_supported(M, N, K) && N % 176 == 0 && N % 64 == 0 && K % 256 == 0 && K >= 768;   // 256 x 176 tiles
+  const bool narrow = !wide && gemm_fr128_shape(M, N, K) && ((M + 255) / 256) * (N / 128) >= 192;                 // 256 x 128 tiles
+  if (!(wide || narrow) || M > 256 * 512) {
+    set_error("%s: shape %lldx%lldx%lld is not served (as mq_w8a8_linear_tiled_gated)", fn, (long long)M, (long long)N, (long long)K);
+    return MQ_EUNSUPPORTED;
+  }
+  g0.zero_buf = row_sum;
+  g0.zero_count = (int)M;
+  g1.gate_aidx = idx_scratch;
+  g1.gate_table = table;
+  g1.gate_q = q_tiled;
+  g1.gate_rowsum = row_sum;
+  rc = wide ? launch_frw4<176, true>(g0, as_stream(stream)) : launch_frw4<128, true>(g0, as_stream(stream));
+  if (rc != MQ_OK) return rc;
+  g1.has_rowsum = g1.a_rowsum != nullptr;
+  if (g1.a_rowsum == nullptr) g1.a_rowsum = g1.col_term;
+  if (g1.bias == nullptr) g1.bias = g1.alpha;
+  g1.grid_m = (g1.M + 255) / 256;
+  g1.grid_n = wide ? g1.N / 176 : g1.N / 128;
+  return wide ? launch_frgw4<176>(g1, as_stream(stream)) : launch_frgw4<128>(g1, as_stream(stream));
 }
 
 static int linear_f32in(const char* fn, int w4, const float* x, const float* a_scale, const float* a_offset, float a_qmin,

@@ -570,10 +570,12 @@ def int8_linear_pair(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch.
     return outs[0], outs[1]
 
 
-def int8_linear_gated(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch.Tensor], first: dict, second: dict, table: torch.Tensor):
+def int8_linear_gated(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch.Tensor], first: dict, second: dict, table: torch.Tensor,
+                      w4: bool = False):
     """w1, w3 and the gate of a gated FFN in TWO launches (mq_w8a8_linear_tiled_gated): `first` (w1) writes its 8-bit indices, `second`
     (w3) looks (w1 index, w3 index) up in `table` (gated_table) inside its epilogue.  Returns (w2's int8 input image, fragment-blocked
     [ceil16(rows), N]; its row sums [rows]) -- the bits of int8_linear_pair + gated_lookup(tiled=True)."""
+    # w4: both weights are mq_pack_w4 images ([N, K / 2] bytes) and the packed kernels run (mq_w4a8_linear_tiled_gated: identical bytes)
     M, K = int(rows), a_tiled.shape[1]
     N = first["w"].shape[0]
     dev = a_tiled.device
@@ -590,7 +592,8 @@ def int8_linear_gated(a_tiled: torch.Tensor, rows: int, a_rowsum: Optional[torch
         ptrs += [p["w"].data_ptr(), p["alpha"].data_ptr(), p["w_zp"].data_ptr(), p["col_term"].data_ptr(),
                  b.data_ptr() if b is not None else None, os_.data_ptr(), oo_.data_ptr()]
     with _on(a_tiled, a_rowsum, first["w"], second["w"], first["alpha"], second["alpha"], table, *[k for k in keep if k is not None]):
-        _lib.call("mq_w8a8_linear_tiled_gated", a_tiled.data_ptr(), M, N, K, a_rowsum.data_ptr() if a_rowsum is not None else None,
+        _lib.call("mq_w4a8_linear_tiled_gated" if w4 else "mq_w8a8_linear_tiled_gated", a_tiled.data_ptr(), M, N, K,
+                  a_rowsum.data_ptr() if a_rowsum is not None else None,
                   *ptrs, table.data_ptr(), idx.data_ptr(), q.data_ptr(), rs.data_ptr(), _stream())
     return q, rs
 

@@ -1472,10 +1472,10 @@ def _gated_mlp_forward(self, x, resid=None):
     narrow = (not pair) and t_hit is not None and ((M + 255) // 256) * (N // 128) >= 192     # 256 x 128 tiles (Gemma's FFN width)
     gate_fused = ((pair or narrow) and N % 64 == 0 and getattr(self, "gated_table", True) and getattr(self, "gated_epilogue", True)
                   and resid is not None and resid.dtype == torch.float32 and resid.is_contiguous()
-                  and not w2._weight_plan(wt2)["w4"] and w2._tiled_residual_ok(M, wt2.shape[0], N))
-    if gate_fused:
+                  and (both_w4 or not any_w4) and w2._tiled_residual_ok(M, wt2.shape[0], N))
+    if gate_fused:              # (packed-only 4-bit weights: the packed forms of both kernels, mq_w4a8_linear_tiled_gated)
         table = _gated_table_of(self, act, silu, w1.output_quantizer, w3.output_quantizer, iq2, x.device)
-        p_q, p_rs = ops.int8_linear_gated(a_q, M, a_rs, halves[0], halves[1], table)
+        p_q, p_rs = ops.int8_linear_gated(a_q, M, a_rs, halves[0], halves[1], table, w4=both_w4)
         return w2._int8_from_image(None, wt2, w2.temp_bias if w2.use_temporary_parameter else w2.bias, iq2, p_q, p_rs, 128, M,
                                    lead_shape=x.shape[:-1], resid=resid)
     if pair:

@@ -146,3 +146,4 @@ def test_argument_checks_fail_before_any_launch():
     assert lib.mq_w8a8_linear_grouped(p, p, 0, 128, 1024, 128, None, None, None, None, None, None, None) == 0
     assert lib.mq_w4a8_linear_tiled_residual(p, p, 2048, 2048, 2048, None, p, p, p, None, p, p, 0.0, 255.0, p, p, None) == 1 and b"16-bit output grid" in lib.mq_last_error()
     assert lib.mq_w4a8_linear_tiled_residual(p, p, 2048, 2000, 2048, None, p, p, p, None, p, p, 0.0, 65535.0, p, p, None) == 3
+    assert lib.mq_w4a8_linear_tiled_gated(p, 2048, 2000, 2048, None, p, p, p, p, None, p, p, p, p, p, p, None, p, p, p, p, p, p, None) == 3

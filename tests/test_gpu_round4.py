@@ -766,3 +766,37 @@ def test_packed_w4_residual_gemm_is_the_int8_image_residual_gemm_bit_for_bit(dev
     assert got.shape == want.shape and torch.equal(got, want), float((got - want).abs().max())
     q = torch.round((want - resid) / so + oo)
     assert float(q.min()) < 20000 and float(q.max()) > 45000            # the 16-bit grid is exercised, not saturated
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 5632, 2048), (1900, 5632, 768), (2048, 16384, 2048)])
+def test_packed_w4_gated_pair_is_the_int8_image_gated_pair_bit_for_bit(dev, M, N, K):
+    """mq_w4a8_linear_tiled_gated (w1 on frw4x, w3 on frgw4x: the gate's table lookup in the epilogue of the packed kernel) against
+    mq_w8a8_linear_tiled_gated on the one-byte-per-nibble images of the same numbers: w2's input image and its row sums, same bytes."""
+    from oracle import mq_oracle as O
+    from test_gpu_round2 import T, tiled_image
+    from mobilequant_amd import ops
+    F32 = np.float32
+    rng = np.random.default_rng(M + N + K + 5)
+    qa = rng.integers(0, 256, size=(M, K))
+    a8 = (qa - 128).astype(np.int8)
+    a_t, rs = T(tiled_image(a8), dev), T(a8.sum(1).astype(np.int32), dev)
+    za = int(rng.integers(100, 156))
+    halves_i8, halves_w4 = [], []
+    for i in range(2):
+        qw = rng.integers(0, 16, size=(N, K))
+        zw = rng.integers(0, 16, size=N)
+        sw = rng.random(N, dtype=F32) * F32(1e-2) + F32(1e-3)
+        alpha, wzp, ct = ops.linear_epilogue_prepare(T(np.array([0.02], F32), dev), T(np.array([za], F32), dev), 128, T(sw, dev), T(zw.astype(F32), dev), 0,
+                                                     T(qw.sum(1).astype(np.int32), dev), K)
+        common = dict(alpha=alpha, w_zp=wzp, col_term=ct, bias=T(rng.standard_normal(N, dtype=F32), dev) if i else None,
+                      out_scale=torch.tensor([0.9 + 0.3 * i], device=dev), out_offset=torch.tensor([120.0 + 10 * i], device=dev))
+        halves_i8.append(dict(w=T(qw.astype(np.int8), dev), **common))
+        halves_w4.append(dict(w=T(O.pack_w4(qw, 0), dev), **common))
+    table = torch.from_numpy(rng.integers(-128, 128, size=65536).astype(np.int8)).to(dev)
+    want_q, want_rs = ops.int8_linear_gated(a_t, M, rs, halves_i8[0], halves_i8[1], table)
+    got_q, got_rs = ops.int8_linear_gated(a_t, M, rs, halves_w4[0], halves_w4[1], table, w4=True)
+    torch.cuda.synchronize()
+    Mp = (M + 15) // 16 * 16
+    back = lambda t: t.view(Mp // 16, N // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, N)[:M]      # noqa: E731  (rows past M are padding)
+    assert torch.equal(back(got_q), back(want_q)) and torch.equal(got_rs, want_rs)
+    assert int(want_q.to(torch.int32).abs().max()) > 100

@@ -61,6 +61,9 @@ VARIANTS = {
     # are the int8 kernel's (frw4 spends 12 VALU per 4 MFMAs in EVERY wave on the unpack and measured 30 % slower than the int8 image)
     "frw4x":     (176, 8, "u8w4x", "MQ_FRW4X",     "mq_gemm_frw4x_asm.inc"),
     "frw4x_128": (128, 8, "u8w4x", "MQ_FRW4X_128", "mq_gemm_frw4x_128_asm.inc"),
+    # ... in front of the gate epilogue (w3 of a gated FFN, packed): 256 x 176 and 256 x 128 tiles
+    "frgw4x":     (176, 8, "gatew4x", "MQ_FRGW4X",     "mq_gemm_frgw4x_asm.inc"),
+    "frgw4x_128": (128, 8, "gatew4x", "MQ_FRGW4X_128", "mq_gemm_frgw4x_128_asm.inc"),
     # ... and in front of the residual epilogue: o_proj / w2 (N = 2048) from packed nibbles on 128 x 128 tiles, four waves
     "frw4x_128r": (128, 4, "f32rw4x", "MQ_FRW4X_128R", "mq_gemm_frw4x_128r_asm.inc"),
 }
@@ -81,8 +84,12 @@ def configure(name):
     if SPLITK:
         EPI = "f32r"
     global W4, W4X
-    W4X = EPI in ("u8w4x", "f32rw4x")
-    if EPI == "f32rw4x":
+    W4X = EPI in ("u8w4x", "f32rw4x", "gatew4x")
+    if EPI == "gatew4x":
+        EPI = "gate"
+        SCALAR_GRID = True
+        TAIL = False
+    elif EPI == "f32rw4x":
         EPI = "f32r"
         SCALAR_GRID = True
         TAIL = False
@@ -113,7 +120,7 @@ def configure(name):
         STG_WAVE = 2 * 16 * ROWP
         STG = RING_BASE
         LDS_BYTES = PAR + 16 * BN
-        PIECES = (BN // 8 + NW - 1) // NW
+        PIECES = (FN + NW - 1) // NW if W4X else (BN // 8 + NW - 1) // NW
         assert LDS_BYTES <= 160 * 1024
         return
     if EPI == "u8":
@@ -967,6 +974,9 @@ def prologue(q, nw, stamp):
         emit(f"v_lshlrev_b32 v{X_T}, 7, v{X_T}")                               # * 128
         emit(f"v_lshl_add_u32 v{X_A0}, v{X_A0}, 4, v{X_T}")
         emit(f"v_lshl_add_u32 v{X_A1}, v{X_A1}, 4, v{X_T}")
+        if RING_BASE:            # gate variants: the table sits in front of the ring
+            emit(f"v_add_u32 v{X_A0}, {RING_BASE}, v{X_A0}")
+            emit(f"v_add_u32 v{X_A1}, {RING_BASE}, v{X_A1}")
         lqx = LQueue()
         for f in w4x_expand(q, lqx, 0, nw, S_CUR, X_P):
             f()
