@@ -227,8 +227,10 @@ class _AttnProbsFn(torch.autograd.Function):
 
 def attention_probs_for_training(qk: "QMatMul", pv: "QMatMul", q, k_t, mask, sqrt_d: float):
     """The probabilities pv_bmm multiplies with v, on ITS input grid -- Q_pv_in(softmax(qk_bmm(q, k^T) / sqrt_d + mask)) -- through
-    the fused pass above, or None when the block is not in that situation (no gradient wanted, a grid that is not a static per-tensor
-    one, another dtype / mask shape): the caller then runs the module chain.  ``train_fused = False`` on either QMatMul opts out."""
+    the fused pass above.  Returns ``(probabilities, True)``; ``None`` when the block is not in that situation at all (no gradient
+    wanted, a grid that is not a static per-tensor one, another dtype): the caller runs the module chain; or ``(qk_bmm's output,
+    False)`` when the scores were already formed but their shape / the mask's is outside the kernel: the caller continues the chain
+    from there.  ``train_fused = False`` on either QMatMul opts out."""
     if not (isinstance(qk, QMatMul) and isinstance(pv, QMatMul)) or not (getattr(qk, "train_fused", True) and getattr(pv, "train_fused", True)):
         return None
     oq, iq = qk.output_quantizer, pv.input_quantizer
