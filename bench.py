@@ -1078,7 +1078,8 @@ def bench_packed_w4(dev):
         row = {}
         try:
             for key, mode in (("per_wave", 0), ("expanded", 1)):
-                lib.mq_gemm_set_w4_mode(mode)
+                if lib.mq_gemm_set_w4_mode(mode) != 0:      # per-wave unpack: experiment builds only (build.py --experiments)
+                    continue
                 t = event_time(lambda: ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, None, [(so, oo)], out=out), 20)
                 row[key + "_us"] = round(t * 1e6, 2)
         finally:

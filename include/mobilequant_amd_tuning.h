@@ -26,7 +26,9 @@ int mq_gemm_set_debug(int flags);
 int mq_gemm_set_clock_probe(void* buf);
 /* mq_w4a8_linear_tiled: 1 (default) = the packed pieces are expanded ONCE per workgroup into the int8 W ring (generated variants frw4x /
  * frw4x_128: the int8 kernel's loop), 0 = every wave splits the nibbles of its own fragments in registers (frw4 / frw4_128: one LDS read
- * per 16 columns and stage, 12 VALU per 4 MFMAs in every wave; measured 30 % slower).  Identical results. */
+ * per 16 columns and stage, 12 VALU per 4 MFMAs in every wave; measured 30 % slower).  Identical results.  Mode 0 is compiled into
+ * experiment builds only (-DMQ_BUILD_EXPERIMENTS, `python -m mobilequant_amd.build --experiments`): the production library returns 1
+ * (= not built) and stays in mode 1. */
 int mq_gemm_set_w4_mode(int mode);
 /* Tile order of the 128-column generated kernels (residual / segmented GEMMs): M-tiles per group of the grouped order each XCD walks
  * (0 = the built-in 4).  Traffic experiment of DESIGN.md 4.2.1 (L2 fetch bytes per XCD footprint); results do not depend on it. */
@@ -36,7 +38,8 @@ int mq_gemm_set_group_m(int group_m);
 int mq_gemm_set_pair_mode(int mode);
 /* Tile height of mq_w8a8_linear_tiled_residual: 128 (four waves) / 256 (eight waves); 512 = 256-row tiles with the K loop split over two
  * workgroups that swap partial sums through a per-device scratch buffer (experimental, measured slower, one launch at a time per device;
- * falls back to the unsplit tile when both halves of every tile cannot be resident at once); anything else = by shape. */
+ * falls back to the unsplit tile when both halves of every tile cannot be resident at once; experiment builds only -- the production
+ * library returns 1 for 512 and keeps choosing by shape); anything else = by shape. */
 int mq_gemm_set_residual_tile(int rows);
 /* mq_w8a8_linear_tiled_segmented: 128 = always the 256 x 128 tile; anything else = 128 x 160 tiles where they fit one per CU. */
 int mq_gemm_set_segmented_tile(int cols);

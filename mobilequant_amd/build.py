@@ -2,6 +2,7 @@
 
     python -m mobilequant_amd.build          # build if sources are newer than the library
     python -m mobilequant_amd.build --force
+    python -m mobilequant_amd.build --experiments   # + the measured-negative kernel variants, into lib/experiments/ (MQ_LIB_PATH)
 
 The library has a C ABI (include/mobilequant_amd.h) and no torch dependency; it is built in-tree at
 mobilequant_amd/lib/ so it travels to the GPU box with the source snapshot.  hipcc cross-compiles
@@ -94,7 +95,12 @@ def build_probe(tag: str = "") -> str:
 
 if __name__ == "__main__":
     tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")
-    path = build(force="--force" in sys.argv, verbose=True, tag=tag)
+    # --experiments: also compile the measured-negative kernel variants (split-K residual tiles, per-wave W4 unpack) that the production
+    # library leaves out; goes to lib/experiments/ unless a tag is given, never loaded by default (MQ_LIB_PATH selects it)
+    exp = "--experiments" in sys.argv
+    if exp and not tag:
+        tag = "experiments"
+    path = build(force="--force" in sys.argv, verbose=True, tag=tag, extra_flags=["-DMQ_BUILD_EXPERIMENTS"] if exp else ())
     print("built", path)
     if tag:
         print("built", build_probe(tag))

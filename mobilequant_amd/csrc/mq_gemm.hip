@@ -36,12 +36,20 @@
 #include "mq_gemm_fr160_asm.inc"
 #include "mq_gemm_fr128r_asm.inc"
 #include "mq_gemm_fr128r8_asm.inc"
+// measured negatives (DESIGN.md 7 / NOTES.md): compiled only into experiment builds (`python -m mobilequant_amd.build --experiments`,
+// -DMQ_BUILD_EXPERIMENTS); the production library answers their knobs with 1 (= not built) and keeps the production kernel
+#ifdef MQ_BUILD_EXPERIMENTS
 #include "mq_gemm_fr128rs_asm.inc"
+#include "mq_gemm_frw4_asm.inc"
+#include "mq_gemm_frw4_128_asm.inc"
+#else
+#define MQ_FR128RS_LDS_BYTES 0
+#define MQ_FRW4_LDS_BYTES 0
+#define MQ_FRW4_128_LDS_BYTES 0
+#endif
 #include "mq_gemm_frw4x_128r_asm.inc"
 #include "mq_gemm_frgw4x_asm.inc"
 #include "mq_gemm_frgw4x_128_asm.inc"
-#include "mq_gemm_frw4_asm.inc"
-#include "mq_gemm_frw4_128_asm.inc"
 #include "mq_gemm_frw4x_asm.inc"
 #include "mq_gemm_frw4x_128_asm.inc"
 
@@ -939,11 +947,13 @@ __device__ __forceinline__ void gemm_i8_fr128_body(const GemmArgs& args) {
         [av0] "v"(av0), [av1] "v"(av1), [tid] "v"(tid), [rsofs0] "v"(rsofs[0]), [rsofs1] "v"(rsofs[1]), [sw0] "v"(sw[0]), [sw1] "v"(sw[1])
     if constexpr (VAR == FR128R) {
       asm volatile(MQ_FR128R_ASM_BODY : : MQ_FR128R_OPERANDS, [sw2] "v"(sw[2]), [sw3] "v"(sw[3]) : MQ_FR128R_ASM_CLOBBERS);
+#ifdef MQ_BUILD_EXPERIMENTS
     } else if constexpr (VAR == FR128RS) {
       // the tile's exchange area: 2 x 8 x 8 KiB of partial sums, 2 x 8 flags (gemm_splitk_scratch)
       const char* xch = reinterpret_cast<const char*>(args.gate_q) + (size_t)tile * 131072u;
       const int* xfl = reinterpret_cast<const int*>(args.gate_rowsum) + (size_t)tile * 16u;
       asm volatile(MQ_FR128RS_ASM_BODY : : MQ_FR128R_OPERANDS, [xch] "s"(xch), [xfl] "s"(xfl) : MQ_FR128RS_ASM_CLOBBERS);
+#endif
     } else {
       asm volatile(MQ_FR128R8_ASM_BODY : : MQ_FR128R_OPERANDS : MQ_FR128R8_ASM_CLOBBERS);
     }
@@ -1109,10 +1119,12 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
                    : MQ_FRW4_OPERANDS, [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr)
                    : MQ_FRW4X_ASM_CLOBBERS);
     } else {
+#ifdef MQ_BUILD_EXPERIMENTS
       asm volatile(MQ_FRW4_ASM_BODY
                    : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
                    : MQ_FRW4_OPERANDS, [soptr] "s"(so_ptr), [ooptr] "s"(oo_ptr)
                    : MQ_FRW4_ASM_CLOBBERS);
+#endif
     }
   } else {
     const int n = n0 + (int)(tid < (unsigned)BNT ? tid : (unsigned)BNT - 1u);
@@ -1131,10 +1143,12 @@ __global__ void __launch_bounds__(512) gemm_i8_frw4_kernel(const GemmArgs args) 
                    : MQ_FRW4_OPERANDS, [invc] "v"(invc), [ooc] "v"(ooc)
                    : MQ_FRW4X_128_ASM_CLOBBERS);
     } else {
+#ifdef MQ_BUILD_EXPERIMENTS
       asm volatile(MQ_FRW4_128_ASM_BODY
                    : [sw0] "+v"(sw[0]), [sw1] "+v"(sw[1]), [sw2] "+v"(sw[2])
                    : MQ_FRW4_OPERANDS, [invc] "v"(invc), [ooc] "v"(ooc)
                    : MQ_FRW4_128_ASM_CLOBBERS);
+#endif
     }
   }
 #undef MQ_FRW4_OPERANDS
@@ -1729,8 +1743,13 @@ int mq_gemm_set_group_m(int group_m) {
 }
 
 int mq_gemm_set_w4_mode(int mode) {
+#ifdef MQ_BUILD_EXPERIMENTS
   g_w4_mode = mode;
   return 0;
+#else
+  g_w4_mode = 1;                    // the per-wave unpack kernels (frw4 / frw4_128) exist in experiment builds only
+  return mode != 0 ? 0 : 1;         // 1 = asked for a variant this library was not built with
+#endif
 }
 
 int mq_gemm_set_clock_probe(void* buf) {
@@ -1892,9 +1911,14 @@ int mq_w4a8_linear_tiled(const int8_t* a_tiled, const uint8_t* w_packed, int64_t
     g.seg_scale[i - 1] = grids[i].scale;
     g.seg_offset[i - 1] = grids[i].offset;
   }
+#ifdef MQ_BUILD_EXPERIMENTS
   const bool x = g_w4_mode.load() != 0;
   if (n_segments == 1 && N % 176 == 0) return x ? launch_frw4<176, true>(g, as_stream(stream)) : launch_frw4<176, false>(g, as_stream(stream));
   return x ? launch_frw4<128, true>(g, as_stream(stream)) : launch_frw4<128, false>(g, as_stream(stream));
+#else
+  if (n_segments == 1 && N % 176 == 0) return launch_frw4<176, true>(g, as_stream(stream));
+  return launch_frw4<128, true>(g, as_stream(stream));
+#endif
 }
 
 int mq_w8a8_linear_tiled_pair(const int8_t* a_tiled, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
@@ -1940,8 +1964,13 @@ int mq_gemm_set_segmented_tile(int cols) {
 
 static std::atomic<int> g_fr128r_tile{0};     // tuning hook (mobilequant_amd_tuning.h): 0 = by shape, 128 / 256 = force the tile height
 int mq_gemm_set_residual_tile(int rows) {
+#ifdef MQ_BUILD_EXPERIMENTS
   g_fr128r_tile = (rows == 128 || rows == 256 || rows == 512) ? rows : 0;     // 512: 256-row tiles, K split over two workgroups
   return 0;
+#else
+  g_fr128r_tile = (rows == 128 || rows == 256) ? rows : 0;                    // (the split-K variant exists in experiment builds only)
+  return rows == 512 ? 1 : 0;
+#endif
 }
 
 int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_t M, int64_t N, int64_t K, const int32_t* a_rowsum,
@@ -1968,7 +1997,11 @@ int mq_w8a8_linear_tiled_residual(const int8_t* a_tiled, const int8_t* w, int64_
   // workgroups of a tile on one XCD (tiles % 8 == 0), each half a valid K for the program (multiple of 256, >= 768)
   const int64_t tiles256 = ((M + 255) / 256) * (N / 128);
   const bool can_split = K % 512 == 0 && K / 2 >= 768 && tiles256 % 8 == 0 && 2 * tiles256 <= (int64_t)device_cu_count();
+#ifdef MQ_BUILD_EXPERIMENTS
   if (forced == 512 && can_split) return launch_fr128<FR128RS>(g, as_stream(stream));
+#else
+  (void)can_split;
+#endif
   const bool tall = forced ? forced == 256 : tiles128 > 512;
   return tall ? launch_fr128<FR128R8>(g, as_stream(stream)) : launch_fr128<FR128R>(g, as_stream(stream));
 }

@@ -137,14 +137,6 @@ class DecodeEngine:
         self._host_pos = 0                                   # mirror of self.pos for the cache-overflow guard (no device read-back)
         self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
         assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
-        self.embed = model.embed_tokens.weight.detach()
-        if s.embed_scale:                                    # normalize_embed (Gemma; hf_model.py:1555-1556): x = embed * hidden ** 0.5
-            self.embed = self.embed * (s.hidden ** 0.5)      # the same fp32 product the module graph forms per token
-        self.norm_ln = isinstance(model.norm, torch.nn.LayerNorm)
-        self.norm_w = model.norm.weight.detach().float().contiguous()
-        self.norm_b = model.norm.bias.detach().float().contiguous() if getattr(model.norm, "bias", None) is not None else None
-        self.lm_w = model.lm_head.weight.detach().float().contiguous()
-        self.lm_b = model.lm_head.bias.detach().float().contiguous() if model.lm_head.bias is not None else None
         self.graph = None
         self.graph_long = None
         self._lower()
@@ -156,6 +148,19 @@ class DecodeEngine:
         prefetch, prefetch_delay_us = self._prefetch
         self._keep = _Keep()
         self.phases = []          # (kind, ctypes struct) in launch order
+        # embedding table, final norm and lm_head (fp32, unquantised: qmodule.py:843) are snapshots like every weight image: re-derived
+        # here and tracked for grids_stale()
+        self.embed = model.embed_tokens.weight.detach()
+        if s.embed_scale:                                    # normalize_embed (Gemma; hf_model.py:1555-1556): x = embed * hidden ** 0.5
+            self.embed = self.embed * (s.hidden ** 0.5)      # the same fp32 product the module graph forms per token
+        self.norm_ln = isinstance(model.norm, torch.nn.LayerNorm)
+        self.norm_w = model.norm.weight.detach().float().contiguous()
+        self.norm_b = model.norm.bias.detach().float().contiguous() if getattr(model.norm, "bias", None) is not None else None
+        self.lm_w = model.lm_head.weight.detach().float().contiguous()
+        self.lm_b = model.lm_head.bias.detach().float().contiguous() if model.lm_head.bias is not None else None
+        for w in (model.embed_tokens.weight, model.norm.weight, getattr(model.norm, "bias", None), model.lm_head.weight, model.lm_head.bias):
+            if w is not None:
+                self._keep.weights.append((w, Q._ver(w)))
         for q in model.modules():                 # grids set from act_dict.json sit on the host until a forward moves them
             if isinstance(q, Q.Quantizer) and q._has_grid() and q.scale.device != dev:
                 q.scale.data, q.offset.data = q.scale.to(dev), q.offset.to(dev)

@@ -210,11 +210,13 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         M, K = B * S, s.heads * D
         probe = Q._tag_grid(torch.empty(1, dtype=torch.float32, device=x.device).expand(B, S, K), oq)
         w_o = o_proj._effective_weight(o_proj.weight)
-        w4o = o_proj._weight_plan(w_o)["w4"]                  # packed-only 4-bit weights: served from the image by the tiled residual kernel
-        resid_tiled = (resid is not None and resid.dtype == torch.float32 and resid.is_contiguous()
+        # _int8_ready FIRST: _weight_plan quantizes the weight, which only the integer path's configurations allow (per-group,
+        # 16-bit, bypassed or absent weight quantizers fall through to o_proj(out) below, untouched)
+        ready = o_proj.input_quantizer is None and M > 8 and o_proj._int8_ready(probe, w_o) and o_proj._activation_grid(probe) is oq
+        w4o = ready and o_proj._weight_plan(w_o)["w4"]        # packed-only 4-bit weights: served from the image by the tiled residual kernel
+        resid_tiled = (ready and resid is not None and resid.dtype == torch.float32 and resid.is_contiguous()
                        and o_proj._tiled_residual_ok(M, w_o.shape[0], K))
-        if (o_proj.input_quantizer is None and o_proj._int8_ready(probe, w_o) and (not w4o or resid_tiled)
-                and M > 8 and o_proj._activation_grid(probe) is oq):
+        if ready and (not w4o or resid_tiled):
             tiled = (not w4o and ops.gemm_tiled_supported(M, w_o.shape[0], K)) or resid_tiled
             q_i8 = torch.empty(((M + 15) // 16 * 16 if tiled else M, K), dtype=torch.int8, device=x.device)
             rs = torch.empty(M, dtype=torch.int32, device=x.device)

@@ -752,8 +752,13 @@ class QLinear(nn.Linear, _QuantizedOp):
         q, gsum = ops.quantize(w32, wq.scale.detach().reshape(-1), wq.offset.detach().reshape(-1), wq.qmin, wq.qmax, q_dtype=MQ_I8,
                                shift=shift, rows=N * G, want_row_sum=True)
         cw = (shift - wq.offset.detach().reshape(N, G)).round().to(torch.int32)
+        # the kernel folds acc + mul24(cw, a_gsum) + t in int32 (mq_gemm_grouped.hip): |cw| must fit 24 bits and the bracket 31.  A
+        # narrow group far from zero (scale at CLIPMIN, offset = -round(min / scale)) breaks that: ONE host read per weight version
+        # decides, the forward falls back to the simulated path (the activation side of the bound is checked on the device, below)
+        cw_max = int(cw.abs().max())
         plan = {"key": key, "wref": weakref.ref(weight), "w": q.view(N, K), "wsum_t": gsum.view(N, G).t().contiguous(),
-                "cw_t": cw.t().contiguous(), "sw_t": wq.scale.detach().reshape(N, G).t().contiguous().float(), "G": G, "gs": gs}
+                "cw_t": cw.t().contiguous(), "sw_t": wq.scale.detach().reshape(N, G).t().contiguous().float(), "G": G, "gs": gs,
+                "cw_max": cw_max, "fold_ok": cw_max < 2 ** 23 and (cw_max + 128) * 128 * gs < 2 ** 30}
         self._gplan = plan
         return plan
 
@@ -771,9 +776,14 @@ class QLinear(nn.Linear, _QuantizedOp):
         a_gsum = a_q.view(M, plan["G"], plan["gs"]).sum(-1, dtype=torch.int32).t().contiguous()
         epi_key = (grid.grid_token(), a_shift)
         if plan.get("epi_key") != epi_key:               # static grids: once; dynamic grids: per call (a handful of [G, N]-sized launches)
-            c_a = (a_shift - grid.offset.detach().reshape(())).round().to(torch.int32)
-            plan["t"] = (c_a * plan["wsum_t"] + (plan["gs"] * c_a) * plan["cw_t"]).contiguous()
-            plan["alpha"] = (grid.scale.detach().reshape(()).float() * plan["sw_t"]).contiguous()
+            c_a = (a_shift - grid.offset.detach().reshape(())).round().to(torch.int64)
+            t64 = c_a * plan["wsum_t"] + (plan["gs"] * c_a) * plan["cw_t"]
+            # int32 bracket of the kernel: |P_g| <= 2^14 gs, |cw A_g| <= cw_max 128 gs, |T|.  An activation grid far from zero (c_a huge)
+            # would wrap it: decided on the device (dynamic grids have no host copy) -- alpha becomes NaN, the output is loudly wrong
+            fits = (t64.abs().max() + (plan["cw_max"] + 128) * 128 * plan["gs"]) < 2 ** 31
+            plan["t"] = t64.to(torch.int32).contiguous()
+            alpha = grid.scale.detach().reshape(()).float() * plan["sw_t"]
+            plan["alpha"] = torch.where(fits, alpha, torch.full_like(alpha, float("nan"))).contiguous()
             plan["epi_key"] = epi_key
         y = ops.int8_linear_grouped(a_q, plan["w"], plan["gs"], a_gsum, plan["alpha"], plan["cw_t"], plan["t"],
                                     None if bias is None else bias.detach().float())
@@ -956,6 +966,8 @@ class QLinear(nn.Linear, _QuantizedOp):
         reason = self._int8_reason(input_, weight)
         if reason == "per-group weight grid":          # its own integer kernel (mq_w8a8_linear_grouped); the fused blocks stay away
             reason = self._grouped_reason(input_, weight)
+            if reason is None and not self._grouped_plan(weight)["fold_ok"]:
+                reason = "per-group weight grid: a group's offset exceeds the kernel's 24-bit fold (narrow range far from zero)"
             if reason is None:
                 self._count_path(None)
                 return self._forward_int8_grouped(input_, weight, bias)
@@ -1432,7 +1444,10 @@ def _gated_mlp_forward(self, x, resid=None):
     if mid is False or aout is False or act.fused_mode == "off":
         return plain(x)
     g1, g3 = w1._activation_grid(x), w3._activation_grid(x)
-    if g1.grid_token() != g3.grid_token():
+    # a DYNAMIC own input quantizer has no grid before its first refresh and a stale one afterwards: the module chain re-derives it
+    # per forward (_input_image), the fused block does not -- it stays on the chain
+    if (any(_dynamic_per_tensor(m.input_quantizer, 8) for m in (w1, w3)) or g1 is None or g3 is None
+            or g1.grid_token() != g3.grid_token()):
         return plain(x)
     # w2: what _int8_ready would check on the product tensor, which never exists here
     wq2, oq2 = w2.weight_quantizer, w2.output_quantizer

@@ -449,7 +449,9 @@ def test_tiled_residual_gemm_is_the_rowmajor_residual_gemm_bit_for_bit(dev, M, N
         oo = torch.tensor([32768.0 if variant == 0 else 30111.0], device=dev)
         kw = dict(out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0)
         want = ops.int8_linear(a_q, w_q, None if zp0 else a_rs, alpha, w_zp, col_term, b, resid=resid, **kw)
-        L.load().mq_gemm_set_residual_tile(tile)
+        if L.load().mq_gemm_set_residual_tile(tile) != 0:       # 512 (split-K, a measured negative): experiment builds only
+            L.load().mq_gemm_set_residual_tile(0)
+            pytest.skip("split-K residual tiles are compiled with `python -m mobilequant_amd.build --experiments` only")
         try:
             got = ops.int8_linear(_to_tiled(a_q), w_q, None if zp0 else a_rs, alpha, w_zp, col_term, b, resid=resid, a_tiled_rows=M, **kw)
         finally:

@@ -299,7 +299,8 @@ def test_packed_w4_generated_isa_gemm_vs_exact_oracle_every_output(dev, M, N, K,
     try:
         # mode 1 (default): packed pieces expanded once per workgroup into the int8 W ring (frw4x); mode 0: per-wave in-register unpack (frw4)
         for mode in (0, 1):
-            lib.mq_gemm_set_w4_mode(mode)
+            if lib.mq_gemm_set_w4_mode(mode) != 0:          # the per-wave unpack kernels (a measured negative): experiment builds only
+                continue
             got = ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, b, grids, seg_ends=ends if segs else None).cpu().numpy()
             assert got.shape == (M, N)
             bad = got != want

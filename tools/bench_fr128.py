@@ -52,7 +52,8 @@ if __name__ == "__main__":
         t_old = timed(lambda: ops.int8_linear(a_q, w_q, a_rs, alpha, w_zp, col_term, None, **kw))
         res = [f"rowmajor C++ {t_old:6.2f} us"]
         for tile in (128, 256, 512):
-            L.load().mq_gemm_set_residual_tile(tile)
+            if L.load().mq_gemm_set_residual_tile(tile) != 0:
+                continue                                  # split-K: `python -m mobilequant_amd.build --experiments`
             t = timed(lambda: ops.int8_linear(a_t, w_q, a_rs, alpha, w_zp, col_term, None, a_tiled_rows=M, **kw))
             res.append(f"tiled {tile if tile < 512 else '256-row split-K'}{'-row' if tile < 512 else ''} {t:6.2f} us ({2.0 * M * N * K / t / 1e6:7.1f} TOPS)")
         L.load().mq_gemm_set_residual_tile(0)

@@ -22,8 +22,10 @@ for M, N, K in ((2048, 5632, 2048), (2048, 16384, 2048), (2048, 2560, 2048), (20
     so, oo = torch.tensor([0.05], device=dev), torch.tensor([128.0], device=dev)
     out = torch.empty(M, N, dtype=torch.uint8, device=dev)
     import mobilequant_amd._lib as L
-    L.load().mq_gemm_set_w4_mode(0)
-    t4r = timed(lambda: ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, None, [(so, oo)], out=out))
+    if L.load().mq_gemm_set_w4_mode(0) == 0:                # per-wave unpack: experiment builds only (build.py --experiments)
+        t4r = timed(lambda: ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, None, [(so, oo)], out=out))
+    else:
+        t4r = float("nan")
     L.load().mq_gemm_set_w4_mode(1)
     t4 = timed(lambda: ops.w4a8_linear_tiled(a_t, M, packed, rs, alpha, wzp, ct, None, [(so, oo)], out=out))
     o4 = out.clone()
