@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 200 /* 0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h */
+#define MQ_VERSION 210 /* 0.2.1: + mq_qmatmul (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -554,6 +554,20 @@ typedef struct mq_attention_args {
   int pos0, cache_seq;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
+
+/* ---- QMatMul as a module: quantized batched matmul of two activations ------------------------ */
+/* Replaces QMatMul.forward (mobilellm/quantization/qmodule.py:453-466): out = Qout(matmul(Q1(x1), Q2(x2))) -- two fake-quant passes
+ * per operand, an fp32 library bmm and two more passes over the product in the reference -- by ONE launch: both fp32 operands are
+ * quantised on load (the exact index arithmetic of qmodule.py:286-287), contracted as int8 on the matrix pipe (a 9 ... 16-bit x1,
+ * pv_bmm's probabilities, as two byte planes), corrected for the zero points in 64-bit integers, scaled once and passed through the
+ * output quantizer (IEEE quotient).  x1 [batch, M, K] dense; x2 [batch, K, N] held either as [batch, N, K] (x2_k_contiguous = 1: what
+ * hf_model.py:513's k.transpose(2, 3) view is in memory) or as [batch, K, N] (0: pv_bmm's v); out [batch, M, N] fp32, the
+ * fake-quantised values the module returns.  grid1 / grid2: static per-tensor grids of at most 16 / 8 bits (integral offsets);
+ * grid_out NULL or scale == NULL: no output quantizer.  Any M / N / K; with x2_k_contiguous == 0, N % 4 == 0 and a 16-byte aligned
+ * x2 are required (MQ_EUNSUPPORTED / MQ_EINVAL otherwise).  16-byte aligned bases with K % 4 == 0 take the vector loads.  No mask or causality assumption (the fused causal attention is
+ * mq_attention_quant).  Non-finite inputs saturate like every integer image (NaN -> qmin). */
+int mq_qmatmul(const float* x1, const float* x2, float* out, int64_t batch, int64_t M, int64_t N, int64_t K, int x2_k_contiguous,
+               const mq_grid* grid1, const mq_grid* grid2, const mq_grid* grid_out, mq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmobilequant_amd.so")
-SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemm_grouped.hip", "mq_gemv.hip", "mq_norm.hip", "mq_decode.hip", "mq_attention.hip"]
+SOURCES = ["mq_elementwise.hip", "mq_reduce.hip", "mq_gemm.hip", "mq_gemm_grouped.hip", "mq_gemv.hip", "mq_norm.hip", "mq_decode.hip", "mq_attention.hip", "mq_qmatmul.hip"]
 # per-file additions: the attention kernel is VALU-bound and consumes every MFMA result with VALU instructions -- keep the MFMA
 # results in VGPRs (no v_accvgpr_read per score element)
 # mq_decode.hip: no SLP vectorisation -- a v_pk_mul_f32 names a register PAIR although op_sel reads one half; when the other half

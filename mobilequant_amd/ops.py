@@ -658,6 +658,57 @@ def gated_lookup(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, tiled: b
     return q, rs
 
 
+def qmatmul(x1: torch.Tensor, x2: torch.Tensor, grid1, grid2, grid_out=None) -> torch.Tensor:
+    """QMatMul.forward (qmodule.py:453-466) in one launch (include/mobilequant_amd.h: mq_qmatmul): x1 [..., M, K] @ x2 [..., K, N] with
+    both input quantizers and the output quantizer fused around an exact int8 contraction.  Grids are (scale, offset, qmin, qmax) with
+    1-element device tensors (static per-tensor), grid_out may be None.  x2 is read in place when it is a dense [..., K, N] tensor with
+    N % 4 == 0 or a transposed view of a dense [..., N, K] one (hf_model.py:513 passes k.transpose(2, 3)); anything else is copied
+    K-contiguous first.
+    Leading dims must match (no broadcasting).  Returns fp32 [..., M, N]."""
+    _dev(x1, "x1"), _dev(x2, "x2")
+    if x1.dtype != torch.float32 or x2.dtype != torch.float32:
+        raise RuntimeError("mobilequant_amd: qmatmul takes float32 operands")
+    if x1.dim() < 2 or x2.dim() != x1.dim() or x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-2]:
+        raise RuntimeError(f"mobilequant_amd: qmatmul shapes {tuple(x1.shape)} @ {tuple(x2.shape)} (equal leading dims, no broadcasting)")
+    lead = tuple(x1.shape[:-2])
+    M, K, N = x1.shape[-2], x1.shape[-1], x2.shape[-1]
+    batch = 1
+    for d in lead:
+        batch *= d
+    a = x1 if x1.is_contiguous() else x1.contiguous()
+    if x2.is_contiguous() and N % 4 == 0 and x2.data_ptr() % 16 == 0:
+        b, kc = x2, 0
+    else:                       # a transposed view of a dense [..., N, K] tensor is read in place; anything else is copied into that order
+        t = x2.transpose(-1, -2)
+        b, kc = (t if t.is_contiguous() else t.contiguous()), 1
+    out = torch.empty(lead + (M, N), dtype=torch.float32, device=x1.device)
+    keep = [a, b]
+
+    def struct(g):
+        if g is None:
+            return None
+        sc, of = _f32(g[0], "grid scale").reshape(-1), _f32(g[1], "grid offset").reshape(-1)
+        if sc.numel() != 1 or of.numel() != 1:
+            raise RuntimeError("mobilequant_amd: qmatmul takes per-tensor grids")
+        keep.extend((sc, of))
+        return _lib.MqGrid(sc.data_ptr(), of.data_ptr(), float(g[2]), float(g[3]))
+    g1, g2, go = struct(grid1), struct(grid2), struct(grid_out)
+    with _on(a, b, *keep):
+        _lib.call("mq_qmatmul", a.data_ptr(), b.data_ptr(), out.data_ptr(), batch, M, N, K, kc, ctypes.byref(g1), ctypes.byref(g2),
+                  ctypes.byref(go) if go is not None else None, _stream())
+    return out
+
+
+def qmatmul_supported(x1: torch.Tensor, x2: torch.Tensor) -> bool:
+    """Shapes mq_qmatmul serves (the grids are the caller's to check): fp32 device tensors with equal leading dims (no broadcasting);
+    any M / N / K."""
+    if not (x1.is_cuda and x2.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32):
+        return False
+    if x1.dim() < 2 or x2.dim() != x1.dim() or x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-2] or x1.numel() == 0 or x2.numel() == 0:
+        return False
+    return x1.shape[-1] <= (1 << 20)
+
+
 def attention_image_cache(kv_heads: int, head_dim: int, max_len: int, device) -> dict:
     """Caller-owned K / vT image caches for attention_quant(cache=..., pos0=...): one per attention block and sequence."""
     rows = (int(max_len) + 63) // 64 * 64

@@ -1015,8 +1015,39 @@ class QMatMul(nn.Module, _QuantizedOp):
         super().__init__()
         self._init_quantizers(input=input_quant_cfg, input2=input2_quant_cfg, output=output_quant_cfg)
 
+    int8_mode = "auto"          # "off": always the simulated path (HIP fake-quant kernels around the library matmul)
+
+    def _int8_reason(self, x1, x2) -> Optional[str]:
+        """None when mq_qmatmul serves this call (one launch, exact integer contraction), else why the simulated path runs."""
+        if self.int8_mode == "off":
+            return "int8_mode off"
+        q1, q2, qo = self.input_quantizer, self.input2_quantizer, self.output_quantizer
+        if not _static_per_tensor(q1, 16) or not _static_per_tensor(q2, 8):
+            return "input grids: static per-tensor, at most 16 (input) / 8 (input2) bits"
+        if qo is not None and not qo.bypassed() and not _static_per_tensor(qo, 16):
+            return "output grid: static per-tensor, at most 16 bits (or none)"
+        if not (torch.is_tensor(x1) and torch.is_tensor(x2)) or not ops.qmatmul_supported(x1, x2):
+            return "operands outside mq_qmatmul (fp32 device tensors with equal leading dims)"
+        if _needs_grad(x1, x2, q1.scale, q2.scale, None if qo is None or qo.bypassed() else qo.scale):
+            return "gradient required"
+        return None
+
     def forward(self, x1, x2):
-        out = torch.matmul(_apply(self.input_quantizer, x1), _apply(self.input2_quantizer, x2))
+        reason = self._int8_reason(x1, x2)
+        c = self.__dict__.setdefault("_path_counts", {})
+        key = "int8" if reason is None else "simulated: " + reason
+        c[key] = c.get(key, 0) + 1
+        if reason is None:
+            q1, q2, qo = self.input_quantizer, self.input2_quantizer, self.output_quantizer
+            if qo is not None and qo.bypassed():
+                qo = None
+            for q in (q1, q2, qo):
+                if q is not None and q.scale.device != x1.device:
+                    q.scale.data, q.offset.data = q.scale.to(x1.device), q.offset.to(x1.device)
+            grid = lambda q: None if q is None else (q.scale.detach(), q.offset.detach(), q.qmin, q.qmax)      # noqa: E731
+            out = ops.qmatmul(_materialize(x1), _materialize(x2), grid(q1), grid(q2), grid(qo))
+            return out if qo is None else _tag_grid(out, qo)
+        out = torch.matmul(_apply(self.input_quantizer, _materialize(x1)), _apply(self.input2_quantizer, _materialize(x2)))
         return _apply(self.output_quantizer, out)
 
 
@@ -1548,14 +1579,14 @@ def _gated_table_of(block, act, silu, o1, o3, iq2, device):
 
 
 def int8_coverage(model, reset=False):
-    """Which QLinear modules of `model` ran on the integer kernels, and which took the simulated path (HIP fake-quant around the fp32
-    library GEMM) and why -- since the last reset.  Returns {"modules": {name: {path: calls}}, "int8_calls", "simulated_calls",
+    """Which QLinear / QMatMul modules of `model` ran on the integer kernels, and which took the simulated path (HIP fake-quant around the fp32
+    library GEMM / bmm) and why -- since the last reset.  Returns {"modules": {name: {path: calls}}, "int8_calls", "simulated_calls",
     "simulated_modules": [names], "summary": str}.  The simulated path is correct by the reference's semantics but ~10x slower; an
     evaluation that silently lands on it (a 16-bit producer in front of q/k/v, a per-group recipe, grad mode) shows up here.
     Modules executed inside a fused block (fuse_gated_mlp / fuse_attention / fuse_decoder_layer) count as "int8 (fused block)"."""
     mods, n_int, n_sim, sim_names = {}, 0, 0, []
     for name, mod in model.named_modules():
-        if isinstance(mod, QLinear):
+        if isinstance(mod, (QLinear, QMatMul)):
             c = dict(mod.__dict__.get("_path_counts", {}))
             mods[name] = c
             i = sum(v for k, v in c.items() if k.startswith("int8"))
@@ -1570,7 +1601,7 @@ def int8_coverage(model, reset=False):
         for k, v in mods[name].items():
             if k.startswith("simulated"):
                 why[k] = why.get(k, 0) + v
-    summary = f"{n_int} integer-path calls, {n_sim} simulated-path calls in {len(sim_names)} of {len(mods)} QLinear modules"
+    summary = f"{n_int} integer-path calls, {n_sim} simulated-path calls in {len(sim_names)} of {len(mods)} QLinear / QMatMul modules"
     if why:
         summary += "; " + "; ".join(f"{v} x {k}" for k, v in sorted(why.items(), key=lambda kv: -kv[1]))
     return {"modules": mods, "int8_calls": n_int, "simulated_calls": n_sim, "simulated_modules": sim_names, "summary": summary}

@@ -1290,10 +1290,10 @@ def gen_full_depth_stable_case(S=256, V=512, layers=22):
     dominates, the logits are flat).  A trained checkpoint is contractive where that model is not -- the residual stream carries the
     token identity, every branch adds a small correction, the unembedding is peaked -- and no checkpoint is reachable offline, so
     this fixture BUILDS such a model at TinyLlama-1.1B's geometry (tests/seeded.py: seeded_contractive_parameters_): unit-variance
-    embeddings, o_proj / w2 scaled so a branch adds ~0.1 of the stream's RMS, row-wise decaying projections, and an unembedding
+    embeddings, o_proj / w2 scaled so a branch adds ~0.25 of the stream's RMS, row-wise decaying projections, and an unembedding
     that reads the embedding of the PREDECESSOR under a fixed vocabulary permutation (a bigram model: the token after t is pi(t)).
     The evaluated sequence follows pi with probability 0.7 and jumps otherwise, so the fp perplexity sits where a small LM's does
-    (5 ... 10) and responds to every logit.  Same reference calls as full_depth_case (get_act_range, create_sim_qmodel, the
+    (fp 12.7) and responds to every logit.  Same reference calls as full_depth_case (get_act_range, create_sim_qmodel, the
     mixed-precision rules of ptq/mobilequant.py:175-201, W8A8 and W4A8), same stored quantities, and again the reference's own second
     run with three BLAS threads: here the two runs agree to < 0.01 perplexity, so `|delta ppl| <= 0.05` is a HARD bar for the module
     chain, the fused prefill and the decode engine (tests/test_gpu_round5.py), with no self-calibrated yardstick."""

@@ -533,6 +533,13 @@ def _qmatmul_exact(a, b, q1: QuantizerOracle, q2: QuantizerOracle, out_q: Quanti
     return out_q.forward(out) if out_q is not None else out
 
 
+def qmatmul_exact(a, b, q1: QuantizerOracle, q2: QuantizerOracle, out_q: QuantizerOracle | None):
+    """What mq_qmatmul (the standalone integer QMatMul, qmodule.py:453-466) computes: the exact contraction over the indices, one
+    rounding -- single-precision scale for operands of at most 8 bits, the rounded double product when the first operand is wider
+    (its integer sums exceed 2^24) -- then the output quantizer."""
+    return _qmatmul_exact(a, b, q1, q2, out_q, double_scale=q1.bitwidth > 8)
+
+
 def attention_sim(q, k, v, cos, sin, heads, kv_heads, qk: tuple, pv: tuple, exact_int: bool = False):
     """Causal prefill attention of one sequence as the reference computes it: q [S, heads*D], k / v [S, kv_heads*D] projection
     outputs; RoPE (cos / sin [S, rot_dim]: full or partial, hf_model.py:486-500); repeat_kv (hf_model.py:509-510); qk_bmm (a QMatMul:

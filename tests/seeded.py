@@ -27,7 +27,7 @@ def bigram_permutation(vocab: int):
 
 def bigram_sequence(vocab: int, length: int, generator, follow: float = 0.8):
     """[1, length] token ids: the next token is pi(previous) with probability `follow`, else uniform -- text the contractive model
-    predicts the way a small LM predicts real text (perplexity 5 ... 10), every logit counting."""
+    predicts the way a small LM predicts real text (perplexity ~13), every logit counting."""
     import torch
     pi = bigram_permutation(vocab)
     jump = torch.rand(length, generator=generator) >= follow
@@ -39,10 +39,10 @@ def bigram_sequence(vocab: int, length: int, generator, follow: float = 0.8):
     return ids.view(1, -1)
 
 
-def seeded_contractive_parameters_(model, strip: str = "", beta: float = 9.0, branch_o: float = 0.5, branch_w2: float = 0.35):
+def seeded_contractive_parameters_(model, strip: str = "", beta: float = 12.0, branch_o: float = 1.25, branch_w2: float = 0.9):
     """Deterministic weights of a CONTRACTIVE decoder (oracle/gen_golden.py: gen_full_depth_stable_case; the GPU tests rebuild them):
     what a trained checkpoint has and seeded_parameters_' random model lacks.  Unit-variance embeddings own the residual stream;
-    o_proj / w2 are scaled down so a branch adds ~0.1 of the stream's RMS (a perturbation is carried along, not amplified); the
+    o_proj / w2 are scaled down so a branch adds ~0.25 of the stream's RMS (a perturbation is carried along, not amplified); the
     other projections decay row-wise (singular values fall off instead of sitting on a Marchenko-Pastur bulk); the unembedding row of
     pi(t) is beta / hidden x the embedding of t -- a peaked next-token distribution.  Drawn per parameter from a generator seeded with
     the crc32 of its (stripped) name, like seeded_parameters_."""

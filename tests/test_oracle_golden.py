@@ -426,6 +426,23 @@ def test_qmatmul_oracle_matches_reference():
         assert d.max() <= float(qs[2].scale) * 1.001 and (d == 0).mean() > 0.99, (t, d.max(), (d == 0).mean())
 
 
+def test_exact_integer_qmatmul_oracle_sits_within_one_step_of_the_reference():
+    """oracle.qmatmul_exact -- the arithmetic of the standalone integer QMatMul kernel (mq_qmatmul: exact contraction over the
+    indices, ONE rounding) -- against the reference's QMatMul.forward outputs (fp32 matmul of the dequantised operands, rounding per
+    product; qmodule.py:453-466): never more than one step of the output grid apart, identical on > 99 % of the outputs."""
+    z = load_npz("qmatmul_cases.npz")
+    for m in load_meta(z):
+        t = m["id"]
+        qs = []
+        for bits, rng in zip(m["bits"], (m["act"]["input"], m["act"]["input2"], m["act"]["output"])):
+            q = O.QuantizerOracle(bits)
+            q.set_from_minmax(*rng)
+            qs.append(q)
+        y = O.qmatmul_exact(z[t + "_a"], z[t + "_b"], *qs)
+        d = np.abs(y - z[t + "_y"])
+        assert d.max() <= float(qs[2].scale) * 1.001 and (d == 0).mean() > 0.99, (t, d.max(), (d == 0).mean())
+
+
 def test_attention_sim_without_quantizers_is_causal_sdpa():
     """oracle.attention_sim (hf_model.py:486-534 restated) with every quantizer absent == torch's causal attention on the RoPE'd heads."""
     import torch
