@@ -448,5 +448,6 @@ class LlamaForCausalLM(nn.Module):
 
     def new_cache(self, batch: int, length: int, device=None, dtype=torch.float32):
         s = self.shape
+        device = device if device is not None else self.embed_tokens.weight.device
         return [(torch.zeros(batch, s.kv_heads, length, s.head_dim, device=device, dtype=dtype),
                  torch.zeros(batch, s.kv_heads, length, s.head_dim, device=device, dtype=dtype)) for _ in self.layers]

@@ -777,7 +777,7 @@ class QLinear(nn.Linear, _QuantizedOp):
         epi_key = (grid.grid_token(), a_shift)
         if plan.get("epi_key") != epi_key:               # static grids: once; dynamic grids: per call (a handful of [G, N]-sized launches)
             c_a = (a_shift - grid.offset.detach().reshape(())).round().to(torch.int64)
-            t64 = c_a * plan["wsum_t"] + (plan["gs"] * c_a) * plan["cw_t"]
+            t64 = c_a * plan["wsum_t"].to(torch.int64) + (plan["gs"] * c_a) * plan["cw_t"].to(torch.int64)   # (a 0-dim int64 does not promote)
             # int32 bracket of the kernel: |P_g| <= 2^14 gs, |cw A_g| <= cw_max 128 gs, |T|.  An activation grid far from zero (c_a huge)
             # would wrap it: decided on the device (dynamic grids have no host copy) -- alpha becomes NaN, the output is loudly wrong
             fits = (t64.abs().max() + (plan["cw_max"] + 128) * 128 * plan["gs"]) < 2 ** 31

@@ -171,3 +171,86 @@ def test_four_rank_merge_with_rank_divergent_observations(mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(r, True if mode == "verify" else "raised") for r in range(4)], res
+
+
+def _cpu_reductions():
+    """Test stand-ins for the three HIP reductions get_act_range launches (mq_minmax_init / _tensor / _cols: covered on the GPU box):
+    the same running update with torch's amin / amax, so that the WHOLE data-parallel path -- hooks on a real model, round-robin shards,
+    the duplicate of a sample-less rank, packing, the layout checksum, the one collective, unpacking -- runs on CPU ranks."""
+    from mobilequant_amd import ops
+
+    def new(n, device):
+        return torch.full((n,), float("inf")), torch.full((n,), float("-inf"))
+
+    def tensor_(x, mn, mx):
+        mn.copy_(torch.minimum(mn, x.amin().reshape(1).float()))
+        mx.copy_(torch.maximum(mx, x.amax().reshape(1).float()))
+
+    def cols_(x2d, mn, mx):
+        mn.copy_(torch.minimum(mn, x2d.amin(0).float()))
+        mx.copy_(torch.maximum(mx, x2d.amax(0).float()))
+    ops.minmax_new, ops.minmax_tensor_, ops.minmax_cols_ = new, tensor_, cols_
+
+
+def _toy_llama():
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    m = LlamaForCausalLM(LlamaShape(hidden=64, layers=2, heads=4, kv_heads=2, head_dim=16, ffn=128, vocab=50, max_pos=32))
+    m.reset_parameters(seed=11, std=0.2)
+    return m.eval().requires_grad_(False)
+
+
+def _toy_samples(n):
+    g = torch.Generator().manual_seed(5)
+    return [torch.randint(0, 50, (1, 24), generator=g) for _ in range(n)]
+
+
+def _full_path_worker(rank, world, port, per_channel, n_samples, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _cpu_reductions()
+        from mobilequant_amd.calibration import get_act_range
+        calls = {"all_reduce": 0, "other": 0}
+        real, real_gather = dist.all_reduce, dist.all_gather_object
+
+        def counting(*a, **k):
+            calls["all_reduce"] += 1
+            return real(*a, **k)
+
+        def counting_gather(*a, **k):
+            calls["other"] += 1
+            return real_gather(*a, **k)
+        dist.all_reduce, dist.all_gather_object = counting, counting_gather
+        act = get_act_range(_toy_llama(), _toy_samples(n_samples), per_channel=per_channel)
+        dist.all_reduce, dist.all_gather_object = real, real_gather
+        flat = {f"{n}|{f}": (v.numpy().tolist() if torch.is_tensor(v) else [float(v[0]), float(v[1])]) for n, d in act.items() for f, v in d.items()}
+        q.put((rank, flat, calls["all_reduce"], calls["other"], dist.get_world_size()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("per_channel,n_samples", [(False, 12), (True, 12), (False, 5)])
+def test_eight_rank_get_act_range_on_a_real_model_equals_the_single_process_run(per_channel, n_samples):
+    """the first real 8-GPU run must not fail on plumbing.  EIGHT gloo ranks run the full get_act_range path
+    (ptq/generate_act_range.py:49-122's data-parallel counterpart) on the toy llama graph -- forward hooks on every calibrated leaf
+    incl. both matmuls, samples round-robin (12 samples: ranks own 2 or 1; 5 samples: three ranks own none and re-run a duplicate),
+    ONE all-reduce of the packed statistics and no other collective -- and every rank ends with exactly the act_dict a single
+    process computes over all samples (min / max are exact and order independent)."""
+    _cpu_reductions()
+    from mobilequant_amd.calibration import get_act_range
+    want = get_act_range(_toy_llama(), _toy_samples(n_samples), per_channel=per_channel)
+    want = {f"{n}|{f}": (v.numpy().tolist() if torch.is_tensor(v) else [float(v[0]), float(v[1])]) for n, d in want.items() for f, v in d.items()}
+    assert len(want) >= 40                      # 2 layers x (7 linears + 2 norms + 2 matmuls + act) x (input, output[, input2]) + final norm
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_full_path_worker, args=(r, 8, port, per_channel, n_samples, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, flat, n_ar, n_other, size in res:
+        assert size == 8 and n_ar == 1 and n_other == 0, (rank, n_ar, n_other, size)
+        assert flat == want, (rank, [k for k in want if flat.get(k) != want[k]][:5])
