@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 210 /* 0.2.1: + mq_qmatmul (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
+#define MQ_VERSION 211 /* 0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -554,6 +554,16 @@ typedef struct mq_attention_args {
   int pos0, cache_seq;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
+
+/* ---- calibration: the score chain of an attention block with its two statistics ------------------ */
+/* ptq/generate_act_range.py:55-69 hooks qk_bmm's output (raw scores) and pv_bmm's input (probabilities); the graph between them is
+ * hf_model.py:513-530: att / sqrt(head_dim) [+ mask] -> softmax(dim = -1, fp32).  One pass per row: running [min, max] of the raw scores,
+ * the probabilities written to `probs` (may alias `raw`), running [min, max] of the probabilities -- instead of two hook reductions and
+ * ~five elementwise passes over [heads, S, S].  raw / probs [rows, cols] fp32, cols % 4 == 0, cols <= 4096 (else MQ_EUNSUPPORTED);
+ * mask: NULL or additive fp32 [mask_rows, cols], row r uses mask row r % mask_rows; the four statistics are 1-float running values
+ * as mq_minmax_tensor keeps them (initialise with mq_minmax_init; NaN is sticky). */
+int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows, double sqrt_d,
+                             float* raw_min, float* raw_max, float* probs_min, float* probs_max, mq_stream_t stream);
 
 /* ---- QMatMul as a module: quantized batched matmul of two activations ------------------------ */
 /* Replaces QMatMul.forward (mobilellm/quantization/qmodule.py:453-466): out = Qout(matmul(Q1(x1), Q2(x2))) -- two fake-quant passes

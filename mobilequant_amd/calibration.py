@@ -70,7 +70,9 @@ class ActRangeCollector:
             self._mn = torch.full((n,), float("inf"), dtype=torch.float32, device=self.device)
             self._mx = torch.full((n,), float("-inf"), dtype=torch.float32, device=self.device)
         self._hooks = []
+        self._aware = []               # attention blocks that take their score-chain statistics from attention_probs()
         self.bytes_seen = 0            # bytes of hooked tensors reduced so far (host-side bookkeeping for the benchmark)
+        self.bytes_fused = 0           # bytes of tensors whose statistics were folded into the pass that produced them
         self.n_collectives = 0
 
     # -- hooks -------------------------------------------------------------------------------------
@@ -102,22 +104,51 @@ class ActRangeCollector:
         def fn(m, xx, yy):
             x = xx[0] if isinstance(xx, tuple) else xx
             y = yy[0] if isinstance(yy, tuple) else yy
-            self._update(name, "input", x)
-            self._update(name, "output", y)
+            skip = m.__dict__.get("_mq_calib_skip", ())          # fields whose statistic the fused score chain takes (below)
+            if "input" not in skip:
+                self._update(name, "input", x)
+            if "output" not in skip:
+                self._update(name, "output", y)
             if matmul:
                 self._update(name, "input2", xx[1])
         return fn
 
+    # statistics where the tensors are PRODUCED (round 5): an attention block of this package's leaf graph (llama.Attention) asks the
+    # collector for its score chain -- raw scores -> / sqrt(d) -> + mask -> softmax -- and gets the probabilities back with
+    # qk_bmm.output's and pv_bmm.input's statistics already folded in (ops.calib_attention_probs_: one pass over [heads, S, S] instead
+    # of two hook reductions and five elementwise passes).  Per-tensor mode only; any other graph keeps the hooks.
+    fuse_attention_statistics = True
+
+    def attention_probs(self, qk_name: str, pv_name: str, raw: torch.Tensor, mask, sqrt_d: float) -> torch.Tensor:
+        i, j = self.slots[(qk_name, "output")], self.slots[(pv_name, "input")]
+        self.bytes_fused += 2 * raw.numel() * raw.element_size()
+        return ops.calib_attention_probs_(raw, mask, sqrt_d, self._mn[i:i + 1], self._mx[i:i + 1], self._mn[j:j + 1], self._mx[j:j + 1])
+
+    def can_fuse_attention(self, raw_shape, dtype, device, mask) -> bool:
+        return (self.fuse_attention_statistics and not self.per_channel and dtype == torch.float32 and device == self.device
+                and device.type == "cuda" and raw_shape[-1] % 4 == 0 and raw_shape[-1] <= 4096
+                and (mask is None or (mask.dim() == 2 and mask.dtype == torch.float32 and mask.is_contiguous()
+                                      and tuple(mask.shape) == tuple(raw_shape[-2:]))))
+
     def attach(self) -> "ActRangeCollector":
+        names = {id(m): name for name, m in self.model.named_modules()}
         for name, m in self.model.named_modules():
             if is_calibrated_leaf(name, m):
                 self._hooks.append(m.register_forward_hook(self._hook(name, _is_matmul(m))))
+            qk, pv = getattr(m, "qk_bmm", None), getattr(m, "pv_bmm", None)
+            if (getattr(m, "_mq_calibration_aware", False) and qk is not None and pv is not None
+                    and (names.get(id(qk)), "output") in self.slots and (names.get(id(pv)), "input") in self.slots):
+                m._mq_calib = (self, names[id(qk)], names[id(pv)])
+                self._aware.append(m)
         return self
 
     def detach(self) -> None:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for m in self._aware:
+            m.__dict__.pop("_mq_calib", None)
+        self._aware = []
 
     # -- merge -------------------------------------------------------------------------------------
     def _layout(self) -> Dict[int, int]:

@@ -347,6 +347,81 @@ static int launch_cols(const T* x, int64_t rows, int64_t cols, float* mn, float*
   return MQ_OK;
 }
 
+
+// ---- calibration-mode score chain of an attention block (round 5) -------------------------------------------------------------------
+// generate_act_range.py:55-69 hooks qk_bmm's OUTPUT (the raw scores) and pv_bmm's INPUT (the probabilities): at S = 2048 two 537-MB
+// tensors per layer, which the reference's graph (hf_model.py:513-530) also walks for `/ sqrt(d)`, `+ mask` and the softmax -- about nine
+// passes over [heads, S, S] per layer, three quarters of a calibration sample's time.  Both statistics can be taken where the values
+// exist: ONE pass reads a row of raw scores, folds its min / max into qk_bmm.output's running statistic, forms the reference's
+// probabilities (x = raw * (1 / sqrt_d) [+ mask]; torch.softmax(dim = -1, fp32): max, exp(x - max), sum, quotient), folds THEIR min / max
+// into pv_bmm.input's statistic and writes them over the scores.  A wave owns a row (up to 4096 keys in registers); the four
+// running statistics are committed once per workgroup through the filtered bit-pattern atomics above (NaN sticky, as torch's amin / amax).
+template <int VPT>
+__global__ void __launch_bounds__(256) calib_probs_kernel(const float* __restrict__ raw, float* __restrict__ out, const int64_t rows, const int cols,
+                                                          const float* __restrict__ mask, const int mask_rows, const float inv_sqrt_d,
+                                                          float* mn_raw, float* mx_raw, float* mn_p, float* mx_p) {
+  const int lane = threadIdx.x & 63, nvec = cols >> 2;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  float rlo = __int_as_float(0x7f800000), rhi = __int_as_float(0xff800000), plo = rlo, phi = rhi;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+    const float4* rr = reinterpret_cast<const float4*>(raw + row * cols);
+    const float4* mr = mask ? reinterpret_cast<const float4*>(mask + (row % mask_rows) * (int64_t)cols) : nullptr;
+    float v[VPT * 4];
+    float mx = __int_as_float(0xff800000);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int i = lane + 64 * k;
+      const bool valid = i < nvec;
+      const float4 x4 = rr[valid ? i : nvec - 1];
+      float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mr) m4 = mr[valid ? i : nvec - 1];
+      const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (valid) {
+          rlo = min_p(rlo, xs[e]);
+          rhi = max_p(rhi, xs[e]);
+        }
+        float x = __fmul_rn(xs[e], inv_sqrt_d);                   // torch: tensor / python scalar == tensor * (1 / scalar)
+        if (mr) x = __fadd_rn(x, ms[e]);
+        v[4 * k + e] = x;
+        mx = valid ? max_p(mx, x) : mx;
+      }
+    }
+    mx = wave_max_p(mx);
+    float l = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const bool valid = lane + 64 * k < nvec;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ex = expf(__fsub_rn(v[4 * k + e], mx));
+        v[4 * k + e] = ex;
+        l += valid ? ex : 0.f;
+      }
+    }
+    l = wave_sum_f32_dpp(l);
+    float4* orow = reinterpret_cast<float4*>(out + row * cols);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = __fdiv_rn(v[4 * k + e], l);
+      if (lane + 64 * k < nvec) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          plo = min_p(plo, y[e]);
+          phi = max_p(phi, y[e]);
+        }
+        orow[lane + 64 * k] = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    }
+  }
+  block_commit(rlo, rhi, mn_raw, mx_raw);
+  __syncthreads();                                                // (block_commit's LDS slots are reused)
+  block_commit(plo, phi, mn_p, mx_p);
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -413,6 +488,35 @@ int mq_minmax_cols(const void* x, int dtype, int64_t rows, int64_t cols, float* 
   if (dtype == MQ_F16) return launch_cols<__half>((const __half*)x, rows, cols, min_out, max_out, as_stream(stream));
   set_error("mq_minmax_cols: dtype %d not supported", dtype);
   return MQ_EUNSUPPORTED;
+}
+
+int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows, double sqrt_d,
+                             float* raw_min, float* raw_max, float* probs_min, float* probs_max, mq_stream_t stream) {
+  const char* fn = "mq_calib_attention_probs";
+  MQ_REQUIRE(rows >= 0 && cols >= 0, "%s: negative shape", fn);
+  if (rows == 0 || cols == 0) return MQ_OK;
+  MQ_REQUIRE(raw && probs && raw_min && raw_max && probs_min && probs_max, "%s: null pointer", fn);
+  MQ_REQUIRE(sqrt_d > 0.0, "%s: sqrt_d=%g", fn, sqrt_d);
+  MQ_REQUIRE(mask == nullptr || (mask_rows >= 1 && rows % mask_rows == 0), "%s: rows=%lld is not a multiple of mask_rows=%lld", fn,
+             (long long)rows, (long long)mask_rows);
+  if (cols % 4 != 0 || cols > 4096 || !aligned(raw, 16) || !aligned(probs, 16) || (mask && !aligned(mask, 16))) {
+    set_error("%s: rows of up to 4096 keys, a multiple of 4, 16-byte aligned (cols=%lld)", fn, (long long)cols);
+    return MQ_EUNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  int64_t grid = (rows + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  const float inv = (float)(1.0 / sqrt_d);             // torch: tensor / python float == tensor * float(1 / scalar)
+#define MQ_CALIB(V) calib_probs_kernel<V><<<(unsigned)grid, 256, 0, st>>>(raw, probs, rows, (int)cols, mask, (int)(mask ? mask_rows : 1), inv, \
+                                                                         raw_min, raw_max, probs_min, probs_max)
+  if (cols <= 256) MQ_CALIB(1);
+  else if (cols <= 512) MQ_CALIB(2);
+  else if (cols <= 1024) MQ_CALIB(4);
+  else if (cols <= 2048) MQ_CALIB(8);
+  else MQ_CALIB(16);
+#undef MQ_CALIB
+  MQ_LAUNCH_CHECK(fn);
+  return MQ_OK;
 }
 
 }  // extern "C"

@@ -95,6 +95,8 @@ def apply_rope(x, cos, sin):
 
 
 class Attention(nn.Module):
+    _mq_calibration_aware = True        # forward() hands its score chain to an attached ActRangeCollector (calibration.py)
+
     def __init__(self, s: LlamaShape):
         super().__init__()
         self.s = s
@@ -126,6 +128,20 @@ class Attention(nn.Module):
         if fused is not None and fused[1]:    # training: the score-sized chain between the two matmuls as one pass per direction
             pv = self.pv_bmm
             out = Q._apply(pv.output_quantizer, torch.matmul(fused[0], Q._apply(pv.input2_quantizer, v)))
+            return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
+        calib = self.__dict__.get("_mq_calib")            # set by ActRangeCollector.attach() while a calibration pass runs
+        if (calib is not None and fused is None and not torch.is_grad_enabled()
+                and calib[0].can_fuse_attention((B, s.heads, S, k.shape[-2]), q.dtype, q.device, mask)):
+            # calibration: the two [heads, S, T]-sized statistics (qk_bmm.output, pv_bmm.input) are taken inside the ONE pass that turns
+            # the raw scores into probabilities, in place (calibration.ActRangeCollector.attention_probs); the module hooks skip them
+            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = ("output",), ("input",)
+            try:
+                raw = self.qk_bmm(q, k.transpose(2, 3))
+                att = calib[0].attention_probs(calib[1], calib[2], raw if raw.is_contiguous() else raw.contiguous(), mask, math.sqrt(s.head_dim))
+                out = self.pv_bmm(att, v)
+            finally:
+                self.qk_bmm.__dict__.pop("_mq_calib_skip", None)
+                self.pv_bmm.__dict__.pop("_mq_calib_skip", None)
             return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
         att = (fused[0] if fused is not None else self.qk_bmm(q, k.transpose(2, 3))) / math.sqrt(s.head_dim)
         if mask is not None:

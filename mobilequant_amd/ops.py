@@ -113,6 +113,29 @@ def minmax_cols_(x2d: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor) -> None:
         _lib.call("mq_minmax_cols", x2d.data_ptr(), _fdt(x2d), rows, cols, mn.data_ptr(), mx.data_ptr(), _stream())
 
 
+def calib_attention_probs_(raw: torch.Tensor, mask: Optional[torch.Tensor], sqrt_d: float, raw_min: torch.Tensor, raw_max: torch.Tensor,
+                           probs_min: torch.Tensor, probs_max: torch.Tensor) -> torch.Tensor:
+    """Calibration-mode score chain (mq_calib_attention_probs): raw [..., S, T] fp32 scores are replaced IN PLACE by
+    softmax(raw / sqrt_d + mask, -1) while the running [min, max] of the raw scores and of the probabilities (1-element fp32 device
+    tensors, ActRangeCollector's slots) are updated -- hf_model.py:513-530 between generate_act_range.py's two hooks.  mask: None or an
+    additive fp32 [S, T] tensor.  Returns `raw` (now the probabilities)."""
+    raw = _dev(raw, "raw")
+    if raw.dtype != torch.float32 or not raw.is_contiguous():
+        raise RuntimeError("mobilequant_amd: calib_attention_probs_ takes a contiguous float32 score tensor")
+    cols = raw.shape[-1]
+    rows = raw.numel() // max(cols, 1)
+    mrows = 0
+    if mask is not None:
+        mask = _dev(mask, "mask")
+        if mask.dtype != torch.float32 or not mask.is_contiguous() or mask.dim() != 2 or mask.shape[1] != cols or raw.shape[-2] != mask.shape[0]:
+            raise RuntimeError("mobilequant_amd: calib_attention_probs_ mask must be a contiguous float32 [S, T] tensor")
+        mrows = mask.shape[0]
+    with _on(raw, mask, raw_min, raw_max, probs_min, probs_max):
+        _lib.call("mq_calib_attention_probs", raw.data_ptr(), raw.data_ptr(), rows, cols, mask.data_ptr() if mask is not None else None, mrows,
+                  float(sqrt_d), raw_min.data_ptr(), raw_max.data_ptr(), probs_min.data_ptr(), probs_max.data_ptr(), _stream())
+    return raw
+
+
 def minmax_tensor(x: torch.Tensor):
     """(min, max) of one tensor as 1-element device tensors: partials + fold, no atomics, no init launch."""
     x = _dev(x, "x").contiguous()

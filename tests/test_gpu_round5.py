@@ -305,3 +305,76 @@ def test_no_qmatmul_of_the_three_model_families_runs_on_the_library_bmm(dev, tag
             m(ids[None, 8:9].to(dev), cache=cache, pos=8)
         cov = mq.int8_coverage(m, reset=True)
         assert all(list(c) == ["int8"] for n, c in cov["modules"].items() if n.endswith("_bmm")), cov["summary"]
+
+
+# ---- calibration: statistics where the tensors are produced -----------------------------------------------------
+@pytest.mark.parametrize("H,S,T,masked", [(4, 96, 96, True), (3, 130, 2048, False), (2, 64, 4096, True), (1, 1, 36, False), (2, 257, 512, True)])
+def test_calibration_score_chain_is_the_torch_chain_and_its_statistics_are_exact(dev, H, S, T, masked):
+    """mq_calib_attention_probs against the graph it replaces (hf_model.py:513-530 between generate_act_range.py:55-69's two hooks):
+    probabilities within 8 ulp / 1.2e-7 of torch's `softmax(raw / sqrt(d) + mask)` (another exp and another summation order than torch's
+    softmax kernel), written in place; the raw-score statistic is EXACTLY
+    torch's min / max of the scores, the probability statistic exactly the min / max of the probabilities the kernel wrote (and within
+    2 ulp of torch's); running statistics accumulate over calls; a NaN score makes both statistics NaN, as amin / amax do."""
+    from mobilequant_amd import ops
+    torch.manual_seed(S + T)
+    raw = torch.randn(1, H, S, T, device=dev) * 3.0
+    mask = None
+    if masked:
+        mask = torch.full((S, T), float("-inf"), device=dev).triu(T - S + 1)
+    sqrt_d = 8.0 if T != 2048 else float(np.sqrt(128.0))
+    want = torch.softmax(raw / sqrt_d + (mask if mask is not None else 0.0), dim=-1, dtype=torch.float32)
+    stats = [ops.minmax_new(1, dev) for _ in range(2)]
+    keep = raw.clone()
+    got = ops.calib_attention_probs_(raw, mask, sqrt_d, stats[0][0], stats[0][1], stats[1][0], stats[1][1])
+    assert got.data_ptr() == raw.data_ptr()
+    ulp = torch.abs(got.view(torch.int32) - want.view(torch.int32))
+    assert int(ulp.max()) <= 8 and float((got - want).abs().max()) <= 1.2e-7, (int(ulp.max()), float((got - want).abs().max()))
+    assert float(stats[0][0]) == float(keep.min()) and float(stats[0][1]) == float(keep.max())
+    assert float(stats[1][0]) == float(got.min()) and float(stats[1][1]) == float(got.max())
+    assert abs(float(stats[1][1]) - float(want.max())) <= 3e-7 * float(want.max())
+    # running: a second tensor can only widen them
+    raw2 = keep * 0.5
+    ops.calib_attention_probs_(raw2, mask, sqrt_d, stats[0][0], stats[0][1], stats[1][0], stats[1][1])
+    assert float(stats[0][0]) == float(keep.min()) and float(stats[0][1]) == float(keep.max())
+    raw3 = keep.clone()
+    raw3[0, 0, 0, 0] = float("nan")
+    ops.calib_attention_probs_(raw3, mask, sqrt_d, stats[0][0], stats[0][1], stats[1][0], stats[1][1])
+    assert all(np.isnan(float(t)) for pair in stats for t in pair)
+
+
+@pytest.mark.parametrize("family", ["tinyllama", "stablelm", "gemma"])
+def test_get_act_range_with_fused_attention_statistics_equals_the_hook_path(dev, family):
+    """get_act_range on this package's leaf graphs takes qk_bmm.output / pv_bmm.input from the fused score chain (llama.Attention asks
+    the attached ActRangeCollector): everything in front of the first softmax (layer 0's norm, q / k / v, qk_bmm incl. the raw-score statistic)
+    equals the all-hooks run exactly; what depends on the probabilities downstream agrees to summation-order tolerance (the fused
+    chain's probabilities sit a few ulp from torch's softmax kernel); the hooks re-read two thirds fewer bytes."""
+    from mobilequant_amd.calibration import ActRangeCollector, get_act_range
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    from test_llama_host import FAMILY_SHAPES
+    kw = FAMILY_SHAPES.get(family) or dict(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=96, eps=1e-5, max_pos=128)
+    kw = dict(kw, max_pos=128)
+    m = LlamaForCausalLM(LlamaShape(**kw))
+    m.reset_parameters(seed=4, std=0.08)
+    m = m.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(9)
+    samples = [torch.randint(0, kw["vocab"], (1, 100), generator=g) for _ in range(3)]
+    fused = get_act_range(m, samples)
+    ActRangeCollector.fuse_attention_statistics = False
+    try:
+        hooks = get_act_range(m, samples)
+    finally:
+        ActRangeCollector.fuse_attention_statistics = True
+    assert fused.keys() == hooks.keys()
+    exact = 0
+    for name in hooks:
+        for field, (lo, hi) in hooks[name].items():
+            flo, fhi = fused[name][field]
+            if name.startswith("layers.0.") and (name.endswith("qk_bmm") or "input_layernorm" in name or name.endswith(("q_proj", "k_proj", "v_proj"))
+                                                 or (name.endswith("pv_bmm") and field == "input2")):
+                assert (flo, fhi) == (lo, hi), (name, field)          # everything in front of the first softmax is the same arithmetic
+                exact += 1
+            else:
+                tol = 2e-5 * max(abs(lo), abs(hi), 1e-6)
+                assert abs(flo - lo) <= tol and abs(fhi - hi) <= tol, (name, field, (flo, fhi), (lo, hi))
+    assert exact >= 12
+    assert any(n.endswith("pv_bmm") and fused[n]["input"][0] == 0.0 and 0.0 < fused[n]["input"][1] <= 1.0 for n in fused)

@@ -40,27 +40,29 @@ template <> __device__ inline void lds_wait<10>(v4i (&f)[10]) {
 
 // One k-step of 64 over a 32 x 176 wave tile = 22 MFMAs of 16x16x64 (the production tile).  NB W fragments and 2 A fragments per
 // k-step; POOL k-steps of distinct operands cycle through (so consecutive MFMAs see different data, as in a real loop).
-template <int POOL, bool LDS>
-__global__ __launch_bounds__(512) void probe16(const v4i* __restrict__ src, int ksteps, int* __restrict__ sink, Stamp* __restrict__ stamps) {
+// ROWS = A fragments per wave: 2 = the production layout (8 waves x 32 rows, two waves per SIMD); 4 = FOUR waves x 64 rows (one wave
+// per SIMD, 176 accumulators): every W fragment read from the LDS then feeds four MFMAs instead of two -- half the LDS reads per MAC.
+template <int POOL, bool LDS, int ROWS = 2>
+__global__ __launch_bounds__(ROWS == 2 ? 512 : 256) void probe16(const v4i* __restrict__ src, int ksteps, int* __restrict__ sink, Stamp* __restrict__ stamps) {
   extern __shared__ v4i lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v4i a[POOL][2], w[POOL][11];
-  if (LDS) {       // W fragments live in the LDS (11 per pool slot, shared by the 8 waves), A in registers
-    for (int i = threadIdx.x; i < POOL * 11 * 64; i += 512) lds[i] = src[i];
+  v4i a[POOL][ROWS], w[POOL][11];
+  if (LDS) {       // W fragments live in the LDS (11 per pool slot, shared by the waves), A in registers
+    for (int i = threadIdx.x; i < POOL * 11 * 64; i += blockDim.x) lds[i] = src[i];
     __syncthreads();
   }
 #pragma unroll
   for (int p = 0; p < POOL; ++p) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[p][i] = src[((p * 2 + i) * 8 + wave) * 64 + lane + 4096];
+    for (int i = 0; i < ROWS; ++i) a[p][i] = src[((p * ROWS + i) * 8 + wave) * 64 + lane + 4096];
     if (!LDS) {
 #pragma unroll
       for (int j = 0; j < 11; ++j) w[p][j] = src[(p * 11 + j) * 64 + lane];
     }
   }
-  v4i acc[2][11];
+  v4i acc[ROWS][11];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < ROWS; ++i)
 #pragma unroll
     for (int j = 0; j < 11; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
   const unsigned lbase = (unsigned)(lane * 16);
@@ -84,18 +86,21 @@ __global__ __launch_bounds__(512) void probe16(const v4i* __restrict__ src, int 
 #pragma unroll
       for (int j = 0; j < 11; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[p & 1][j], a[p][i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < ROWS; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[p & 1][j], a[p][i], acc[i][j], 0, 0, 0);
       if (LDS) lds_wait<11>(wf[(p + 1) & 1]);
     }
   }
   const unsigned long long c1 = memtime(), t1 = realtime();
   int x = 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < ROWS; ++i)
 #pragma unroll
     for (int j = 0; j < 11; ++j) x ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
   if (x == 0x5a5a5a5a) sink[0] = x;
-  if (lane == 0) stamps[blockIdx.x * 8 + wave] = Stamp{c1 - c0, t1 - t0};
+  if (lane == 0) {
+    stamps[blockIdx.x * 8 + wave] = Stamp{c1 - c0, t1 - t0};
+    if (ROWS == 4) stamps[blockIdx.x * 8 + wave + 4] = Stamp{c1 - c0, t1 - t0};       // (the host averages 8 slots per workgroup)
+  }
 }
 
 // The same MAC count per k-step on 32x32x32: a 32 x 160 wave tile = 5 column blocks x 2 k-halves = 10 MFMAs of 32 K MACs (+ the
@@ -159,13 +164,14 @@ __global__ __launch_bounds__(512) void probe32(const v4i* __restrict__ src, int 
 }
 
 template <typename K>
-static void run(const char* name, K kernel, double macs_per_kstep_wave, const v4i* src, int ksteps, int reps, int* sink, Stamp* stamps, size_t lds_bytes) {
+static void run(const char* name, K kernel, double macs_per_kstep_wave, const v4i* src, int ksteps, int reps, int* sink, Stamp* stamps, size_t lds_bytes,
+                int threads = 512) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kernel, dim3(256), dim3(512), lds_bytes, 0, src, ksteps, sink, stamps);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), lds_bytes, 0, src, ksteps, sink, stamps);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kernel, dim3(256), dim3(512), lds_bytes, 0, src, ksteps, sink, stamps);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), lds_bytes, 0, src, ksteps, sink, stamps);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -177,9 +183,9 @@ static void run(const char* name, K kernel, double macs_per_kstep_wave, const v4
   for (auto& s : h) { mhz.push_back(double(s.cycles) / double(s.ticks) * 100.0); cyc += double(s.cycles); }
   std::sort(mhz.begin(), mhz.end());
   const double us = ms * 1e3 / reps;
-  const double ops = 2.0 * macs_per_kstep_wave * ksteps * 2048;
+  const double ops = 2.0 * macs_per_kstep_wave * ksteps * (threads / 64) * 256;
   const double loop_us = (cyc / 2048) / (mhz[1024] * 1e6) * 1e6;
-  printf("%-34s %8.2f us/launch  %7.1f TOPS (launch)  %7.1f TOPS (in-loop)  clock median %6.0f MHz (min %6.0f max %6.0f)  cycles/kstep %7.1f\n", name, us,
+  printf("%-42s %8.2f us/launch  %7.1f TOPS (launch)  %7.1f TOPS (mean wave window: the older wave of a SIMD gets the pipe first)  clock median %6.0f MHz (min %6.0f max %6.0f)  cycles/kstep %7.1f\n", name, us,
          ops / us * 1e-6, ops / loop_us * 1e-6, mhz[1024], mhz.front(), mhz.back(), cyc / 2048 / ksteps);
   CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -223,6 +229,8 @@ int main(int argc, char** argv) {
     run("16x16x64 W from LDS gaussian", probe16<POOL, true>, 22 * 16384.0, gauss, ksteps, reps, sink, stamps, lds16);
     run("32x32x32 W from LDS gaussian", probe32<POOL, true>, 10 * 32768.0, gauss, ksteps, reps, sink, stamps, lds32);
     run("16x16x64 W from LDS zeros", probe16<POOL, true>, 22 * 16384.0, zero, ksteps, reps, sink, stamps, lds16);
+    run("16x16x64 4 waves x 64 rows, LDS, gaussian", probe16<POOL, true, 4>, 44 * 16384.0, gauss, ksteps, reps, sink, stamps, lds16, 256);
+    run("16x16x64 4 waves x 64 rows, LDS, zeros", probe16<POOL, true, 4>, 44 * 16384.0, zero, ksteps, reps, sink, stamps, lds16, 256);
     run("32x32x32 W from LDS zeros", probe32<POOL, true>, 10 * 32768.0, zero, ksteps, reps, sink, stamps, lds32);
   }
   return 0;
