@@ -396,7 +396,12 @@ def cpu_baseline():
     from oracle import mq_oracle_torch as T
     cores = T.physical_cores()
     prev = torch.get_num_threads()
-    torch.set_num_threads(cores)
+    # best of >= 5 runs after warm-up, the thread count stated -- and swept (on a 128-core
+    # host the all-cores figure of a 47-GOP problem scattered 0.08 ... 0.42 TOPS between rounds: thread wake-up and NUMA placement, not
+    # arithmetic).  Every candidate count gets the same bounded budget; `value` is the best single call of the best count, the spread of
+    # that count's calls travels with it.
+    counts = sorted({c for c in (cores, max(cores // 2, 1), max(cores // 4, 1), 16, 8) if 1 <= c <= cores})
+    sweep = {}
     try:
         g = torch.Generator().manual_seed(1337)
         x = torch.randn(M, K, generator=g)
@@ -406,31 +411,42 @@ def cpu_baseline():
         oq.set_range(float(y.min()), float(y.max()))
         del y
         with torch.no_grad():
-            T.qlinear(x, w, None, wq, iq, oq)              # warm-up; fixes the weight grid like the reference's first forward
-            t0 = time.perf_counter()
-            reps = 0
-            while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 200):
+            for n in counts:
+                torch.set_num_threads(n)
+                T.qlinear(x, w, None, wq, iq, oq)          # warm-up; fixes the weight grid like the reference's first forward
                 T.qlinear(x, w, None, wq, iq, oq)
-                reps += 1
-            dt = (time.perf_counter() - t0) / reps
+                times, t0 = [], time.perf_counter()
+                while len(times) < 5 or (time.perf_counter() - t0 < 3.0 and len(times) < 60):
+                    t1 = time.perf_counter()
+                    T.qlinear(x, w, None, wq, iq, oq)
+                    times.append(time.perf_counter() - t1)
+                times.sort()
+                sweep[n] = {"best_s": round(times[0], 4), "median_s": round(times[len(times) // 2], 4), "worst_s": round(times[-1], 4), "calls": len(times)}
+            best_n = min(sweep, key=lambda n: sweep[n]["best_s"])
+            dt, reps = sweep[best_n]["best_s"], sweep[best_n]["calls"]
+            torch.set_num_threads(best_n)
             layer = T.SimLayer()
             xl = torch.randn(M, K, generator=g)
             layer.forward(xl)
-            t1 = time.perf_counter()
-            lreps = 0
-            while lreps < 2 or (time.perf_counter() - t1 < 8.0 and lreps < 50):
+            ltimes, t1 = [], time.perf_counter()
+            while len(ltimes) < 5 or (time.perf_counter() - t1 < 8.0 and len(ltimes) < 50):
+                t2 = time.perf_counter()
                 layer.forward(xl)
-                lreps += 1
-            dtl = (time.perf_counter() - t1) / lreps
+                ltimes.append(time.perf_counter() - t2)
+            ltimes.sort()
+            dtl, lreps = ltimes[0], len(ltimes)
     finally:
         torch.set_num_threads(prev)
     layer_ops = 2.0 * M * (2048 * 2048 * 2 + 2048 * 256 * 2 + 2048 * 5632 * 3) + 2.0 * 2 * 32 * M * M * 64
-    return {"value": round(OPS_PER_STEP / dt / 1e12, 4), "unit": "TOPS", "cores": int(cores), "kind": "port",
-            "seconds_per_step": round(dt, 4), "threads": int(cores),
-            "sample": f"{reps} calls of the torch-CPU restatement of QLinear.forward (weight fake-quant + input fake-quant + fp32 "
-                      f"F.linear + output fake-quant) at M={M},K={K},N={N}, torch.set_num_threads({cores}) = physical cores",
-            "layer": {"seconds_per_layer": round(dtl, 4), "value": round(layer_ops / dtl / 1e12, 4), "unit": "TOPS-equivalent",
-                      "sample": f"{lreps} forwards of one TinyLlama-shaped W8A8 decoder layer (2 QRMSNorm, 7 QLinear, 2 QMatMul, QSiLU; "
+    return {"value": round(OPS_PER_STEP / dt / 1e12, 4), "unit": "TOPS", "cores": int(best_n), "kind": "port",
+            "seconds_per_step": round(dt, 4), "threads": int(best_n), "physical_cores": int(cores),
+            "value_median": round(OPS_PER_STEP / sweep[best_n]["median_s"] / 1e12, 4), "value_worst": round(OPS_PER_STEP / sweep[best_n]["worst_s"] / 1e12, 4),
+            "thread_sweep_seconds": {str(n): v for n, v in sweep.items()},
+            "sample": f"best of {reps} calls (after 2 warm-up calls) of the torch-CPU restatement of QLinear.forward (weight fake-quant + input "
+                      f"fake-quant + fp32 F.linear + output fake-quant) at M={M},K={K},N={N}, torch.set_num_threads({best_n}) -- the fastest of "
+                      f"the swept counts {counts} on {cores} physical cores; median / worst of the same calls beside it",
+            "layer": {"seconds_per_layer": round(dtl, 4), "value": round(layer_ops / dtl / 1e12, 4), "unit": "TOPS-equivalent", "threads": int(best_n),
+                      "sample": f"best of {lreps} forwards of one TinyLlama-shaped W8A8 decoder layer (2 QRMSNorm, 7 QLinear, 2 QMatMul, QSiLU; "
                                 "mixed-precision rules of ptq/mobilequant.py:175-201) at S=2048"}}
 
 
