@@ -378,3 +378,78 @@ def test_get_act_range_with_fused_attention_statistics_equals_the_hook_path(dev,
                 assert abs(flo - lo) <= tol and abs(fhi - hi) <= tol, (name, field, (flo, fhi), (lo, hi))
     assert exact >= 12
     assert any(n.endswith("pv_bmm") and fused[n]["input"][0] == 0.0 and 0.0 < fused[n]["input"][1] <= 1.0 for n in fused)
+
+
+# ---- ADVICE r04 --------------------------------------------------------------------------------------------------------------------
+def _small_sim_llama(dev, seed=6):
+    import mobilequant_amd as mq
+    from mobilequant_amd.calibration import get_act_range
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    from toy_models import apply_mixed_precision
+    m = LlamaForCausalLM(LlamaShape(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=64, max_pos=128))
+    m.reset_parameters(seed=seed, std=0.08)
+    m = m.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 64, (1, 96), generator=g)
+    act = get_act_range(m, [ids, torch.randint(0, 64, (1, 96), generator=g)])
+    mq.create_sim_qmodel(m, mq.QuantConfig(bitwidth=8), mq.QuantConfig(bitwidth=8))
+    apply_mixed_precision(m, mq)
+    return m, act, ids.to(dev)
+
+
+def test_per_group_o_proj_under_the_fused_decoder_layer_falls_through_to_its_own_kernel(dev):
+    """the fused attention asked o_proj for its integer weight plan BEFORE asking whether o_proj is on the integer
+    path at all -- a per-group weight grid (round 4's mq_w8a8_linear_grouped recipe) then raised (grid already loaded) or registered a
+    per-ROW grid on a per-group quantizer (first forward).  Now the guard comes first: under fuse_decoder_layer a per-group o_proj is
+    handed the attention output as a tensor and runs its own grouped kernel -- with no weight grid yet (first forward derives the
+    per-group grid: [N * G] scales) and again with the grid in place -- and the layer agrees with the unfused module chain."""
+    import mobilequant_amd as mq
+    from mobilequant_amd import llama
+    m, act, ids = _small_sim_llama(dev)
+    for name, mod in m.named_modules():
+        if name.endswith("o_proj"):
+            mod.weight_quantizer.qcfg.is_per_channel, mod.weight_quantizer.qcfg.group_size = True, 64
+    mq.set_scale_and_offset(m, act, "buffer")
+    mq.wire_integer_inputs(m)
+    with torch.no_grad():
+        chain = m(ids)[0]
+    o0 = m.layers[0].self_attn.o_proj
+    assert o0.weight_quantizer.scale.numel() == 256 * (256 // 64)          # a per-GROUP grid came out of the first forward
+    for mod in m.modules():                                                   # start again without weight grids: the fused pass sees none
+        if isinstance(mod, mq.QLinear) and hasattr(mod.weight_quantizer, "scale"):
+            del mod.weight_quantizer.scale, mod.weight_quantizer.offset
+    mq.int8_coverage(m, reset=True)
+    with torch.no_grad():
+        assert llama.fuse_decoder_layer(m) == 2
+        first = m(ids)[0]
+        assert o0.weight_quantizer.scale.numel() == 256 * (256 // 64)
+        second = m(ids)[0]
+    assert torch.equal(first, second)
+    cov = mq.int8_coverage(m)
+    assert cov["simulated_calls"] == 0, cov["summary"]
+    span = float(chain.max() - chain.min())
+    d = (first - chain).abs() / span
+    assert float(d.max()) <= 0.05 and float(d.median()) <= 1e-3, (float(d.max()), float(d.median()))
+
+
+def test_fused_gated_mlp_leaves_dynamic_own_input_quantizers_to_the_module_chain(dev):
+    """w1 / w3 carrying their OWN dynamic input quantizers have no grid before the first refresh (and a stale one
+    after it); the fused FFN block used to read g1.grid_token() there -- AttributeError on the first forward.  It now stays on the
+    module chain, whose per-call refresh is the reference's `is_dynamic` behaviour (qmodule.py:262-277)."""
+    import mobilequant_amd as mq
+    m, act, ids = _small_sim_llama(dev, seed=8)
+    mq.set_scale_and_offset(m, act, "buffer")
+    mq.wire_integer_inputs(m)
+    dyn = mq.QuantConfig(bitwidth=8, is_dynamic=True)
+    for layer in m.layers:
+        for lin in (layer.mlp.w1, layer.mlp.w3):
+            lin.input_quantizer = mq.Quantizer(dyn)
+    with torch.no_grad():
+        chain = m(ids)[0]
+        assert mq.fuse_gated_mlp(m) == 2
+        for lin in (m.layers[0].mlp.w1, m.layers[0].mlp.w3):             # back to "never ran": no scale attribute at all
+            for attr in ("scale", "offset"):
+                if hasattr(lin.input_quantizer, attr):
+                    delattr(lin.input_quantizer, attr)
+        fused = m(ids)[0]
+    assert torch.equal(fused, chain)
