@@ -1,0 +1,36 @@
+#!/bin/bash
+# Regenerates the round-5 evidence under gpurun_out/evidence_r05/ on an MI355X (run through gpurun; ~20 min).  The files kept under
+# profiles/r05/ are copies of what this and tools/r05_run_*.sh write (captions: tools/profiles_readme.py).   usage: evidence_r05.sh [quick]
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/evidence_r05; mkdir -p $OUT; cd $R
+# 1. parity: the whole GPU suite, then the smoke entry
+timeout 1800 python -m pytest tests -m gpu -q > $OUT/gpu_tests_full.log 2>&1; tail -1 $OUT/gpu_tests_full.log > $OUT/gpu_tests.log; cat $OUT/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+# 2. the bench line at the driver's settings and at 10 x the steps
+timeout 1500 python bench.py --steps 20 --warmup 5 2> $OUT/bench_final.err | grep '^{"metric"' > $OUT/bench_final.json
+timeout 600 python bench.py --steps 200 --warmup 20 --headline-only --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/bench_steps200.json
+python - <<'PY'
+import json, os
+o = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "evidence_r05")
+for f in ("bench_final.json", "bench_steps200.json"):
+    try:
+        d = json.load(open(os.path.join(o, f)))
+        r = d["roofline"]
+        print(f, "value", d["value"], "ms/step", d["ms_per_step"], "host-clock ms/step", d["timing"].get("host_clock_ms_per_step"), "gemm us", r["avg_launch_us"], "frac", r["frac"],
+              "MHz", r.get("sustained_mhz"), "ceiling", r.get("ceiling_at_sustained_clock"), "adj", r.get("frac_clock_adjusted"))
+        if d.get("decode"):
+            print("  decode", d["decode"].get("decode_tok_s"), d["decode"].get("decode_tok_s_by_context"), "cpu", (d.get("cpu_baseline") or {}).get("value"),
+                  (d.get("cpu_baseline") or {}).get("thread_sweep_seconds"))
+            v = d["variants"]
+            print("  calib stub", v.get("calibration_512_stub_gemm", {}).get("samples_per_s"), "pair", v.get("ffn_pair_gemm", {}).get("frac_of_int8_peak"),
+                  "layer", v.get("layer_prefill_full", {}).get("fused_us"), "multi_gpu", d.get("multi_gpu", {}).get("all_ranks_agree"))
+    except Exception as e:
+        print(f, "unreadable:", e)
+PY
+[ "$1" = quick ] && exit 0
+# 3. rocprofv3: kernel trace of every bench leg + the four PMC passes of the headline legs (tools/prof_bench.sh)
+bash tools/prof_bench.sh r05 pmc > $OUT/prof_bench.log 2>&1; cp gpurun_out/prof_bench_r05/*.summary.txt gpurun_out/prof_bench_r05/*.bench.json $OUT/ 2>/dev/null
+head -30 $OUT/trace.summary.txt
+# 4. decode timeline (stamped build)
+python -c "from mobilequant_amd import build; build.build(force=True, tag='stamps', extra_flags=['-DMQ_DECODE_STAMPS'])" > /dev/null 2>&1
+MQ_LIB_PATH=mobilequant_amd/lib/stamps/libmobilequant_amd.so LAYERS=6 CONTEXT=256 WBITS=8 timeout 300 python tools/decode_stamps.py > $OUT/decode_stamps_w8.log 2>&1
+ls -la $OUT

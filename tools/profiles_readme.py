@@ -41,6 +41,16 @@ LOG_CAPTIONS = {
     "gpu_tests.log": "result line of `python -m pytest tests -m gpu -q` on the box that produced this directory",
     "bench_final.json": "un-profiled `python bench.py --steps 20 --warmup 5` (the driver's settings) at the end of the round",
     "bench_steps200.json": "`python bench.py --steps 200 --warmup 20 --headline-only --no-cpu-baseline` on the same box, minutes later (agreement of the step time with the 20-step run)",
+    # round 5 (tools/evidence_r05.sh, tools/r05_run_*.sh)
+    "mfma_energy_probe.log": "`tools/mfma_energy_probe.cpp 256 200`: NOTHING but int8 MFMAs on all 256 CUs -- 16x16x64 against 32x32x32, operands in registers or W re-read from the LDS every k-step, 8 waves x 32 rows against 4 waves x 64 rows, quantised-Gaussian / uniform-random / zero operands: us per launch, TOPS, the clock each variant holds",
+    "mfma_energy_probe_k32.log": "the same at 32 k-steps per wave (= the headline K = 2048): the difference to the 256-k-step run gives the steady-state time per k-step without launch overhead",
+    "stable_depth_diag.log": "`tools/stable_depth_diag.py`: the contractive 22-layer model of `full_depth_stable_case.npz` over 8 sequences (2 040 predicted tokens) -- perplexity difference to the reference per execution path (the reference's op sequence on rocBLAS, integer linears, all-integer module chain, fused prefill), per sequence",
+    "stable_depth_diag_one_sequence.log": "the same diagnostic on the first (one-sequence, 255-position) form of the fixture: every path, incl. the reference's own op sequence on rocBLAS, 0.03-0.075 off for W4A8 -- position-correlated summation-order noise, the reason the fixture grew to eight sequences",
+    "stable_ppl.log": "the report line of `test_quantized_perplexity_within_0_05_of_the_reference_at_22_layers` (module chain, fused prefill, decode engine; W8A8 and W4A8)",
+    "bench_qmatmul.log": "`tools/bench_qmatmul.py`: `mq_qmatmul` against the simulated QMatMul path (HIP fake-quant kernels around the fp32 library bmm) at the attention block's shapes",
+    "calibration64.json": "`python bench.py --workload calibration --calib-samples 64`: configs[4]'s per-sample cost with the fp32 library GEMMs in (the score chain of every attention block takes its two statistics in one pass)",
+    "calibration64_stub_gemm.json": "the same with `--calib-stub-gemm` (the timed region is the hot path: hooked reductions + the fused score chain)",
+    "decode_stamps_w8.log": "`tools/decode_stamps.py` (`-DMQ_DECODE_STAMPS` build, 6 layers, context 256): per-launch gap / ramp / in-kernel stamps of the decode step, int8 weights",
 }
 
 
