@@ -66,8 +66,14 @@ __device__ __forceinline__ void quant4(const v4f x, int nlive, float s, float in
 
 template <bool A16, bool BKM>
 __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
-  __shared__ __attribute__((aligned(16))) char sA[A16 ? 2 : 1][64 * QP];
-  __shared__ __attribute__((aligned(16))) char sB[64 * QP];
+  // one LDS block: the int8 operand tiles of the K loop, then (behind the loop's last barrier) the fp32 output tile, staged so that
+  // the stores are whole 256-byte rows instead of the MFMA layout's 64-byte pieces of 16 different rows
+  constexpr int OP = 68;                                         // output staging pitch in floats (272 B: float4 writes of 16 rows spread over the banks)
+  constexpr int A_BYTES = (A16 ? 2 : 1) * 64 * QP, SMEM = 64 * OP * 4 > A_BYTES + 64 * QP ? 64 * OP * 4 : A_BYTES + 64 * QP;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  char (*sA)[64 * QP] = reinterpret_cast<char (*)[64 * QP]>(smem);
+  char* sB = smem + A_BYTES;
+  float* sO = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
   // XCD-aware order: consecutive logical tiles (n fastest: they share the A rows) go to ONE XCD's L2 (block b runs on XCD b % 8)
@@ -186,7 +192,6 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   }
 
   // epilogue: exact integer bracket -> one rounding -> the output quantizer (qmodule.py:286-290 op for op) -> fp32
-  const int m = m0 + 16 * wave + frow;
   const float zaf = rintf(oa), zbf = rintf(ob);
   const bool sane = __builtin_fabsf(zaf) < 1048576.f && __builtin_fabsf(zbf) < 1048576.f;     // else: NaN out (a grid far from zero)
   const long long ca = (long long)g.a_shift - (long long)zaf, cb = (long long)g.b_shift - (long long)zbf;
@@ -196,10 +201,8 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   const float so = has_q ? g.go.scale[0] : 1.f, oo = has_q ? g.go.offset[0] : 0.f;
   const float inv_so = __fdiv_rn(1.0f, so);
   const bool fast = scale_in_fast_range(so);
-  float* orow = g.out + (long long)bi * g.o_bs + (long long)m * N;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int n = n0 + 16 * j + 4 * fq;
     v4f y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -215,7 +218,17 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
       }
       y[e] = v;
     }
-    if (m < M) {
+    *reinterpret_cast<v4f*>(&sO[(16 * wave + frow) * OP + 16 * j + 4 * fq]) = y;        // (rows of this wave only: no workgroup barrier)
+  }
+  // copy-out: the wave's 16 rows x 64 columns, 16 lanes per row
+  float* obase = g.out + (long long)bi * g.o_bs;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = lane + 64 * i, r = idx >> 4, c4 = (idx & 15) * 4;
+    const int mm = m0 + 16 * wave + r, n = n0 + c4;
+    const v4f y = *reinterpret_cast<const v4f*>(&sO[(16 * wave + r) * OP + c4]);
+    if (mm < M) {
+      float* orow = obase + (long long)mm * N;
       if (n + 4 <= N && g.o_vec) {
         *reinterpret_cast<v4f*>(orow + n) = y;
       } else {
