@@ -370,7 +370,7 @@ def pmc_traffic():
     (profiles/r03/pmc_fetch + pmc_write, else r02's; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
     streams on gfx950).  Counters cannot be read from inside the bench, so this is the last profiled value."""
     import re
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         d = os.path.join(ROOT, "profiles", rnd)
         vals = {}
         for fn, key in (("pmc_fetch.summary.txt", "FETCH_SIZE"), ("pmc_write.summary.txt", "WRITE_SIZE")):
@@ -1305,7 +1305,7 @@ def main():
                     "cycles_per_wave": clock and clock["cycles_per_wave"],
                     "notes": "MFMA busy 22 528 cycles per SIMD of cycles_per_wave (the program's own s_memtime span; two waves share a SIMD); "
                              "~2.5 us of each launch period lie outside the waves' lifetime (kernel boundary 1.2 us + write-back of the "
-                             "11.5 MB of outputs): DESIGN.md 4.2, profiles/r04",
+                             "11.5 MB of outputs): DESIGN.md 4.2, profiles/r05",
                     "quantize_kernel": {"bound": "hbm", "avg_launch_us": round(t_quant * 1e6, 2),
                                         "achieved_GBps": round((M * K * 5 + M * 4) / t_quant / 1e9, 1), "peak_GBps": 8000.0}}
             if pipelined:

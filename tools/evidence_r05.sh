@@ -3,7 +3,7 @@
 # profiles/r05/ are copies of what this and tools/r05_run_*.sh write (captions: tools/profiles_readme.py).   usage: evidence_r05.sh [quick]
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/evidence_r05; mkdir -p $OUT; cd $R
 # 1. parity: the whole GPU suite, then the smoke entry
-timeout 1800 python -m pytest tests -m gpu -q > $OUT/gpu_tests_full.log 2>&1; tail -1 $OUT/gpu_tests_full.log > $OUT/gpu_tests.log; cat $OUT/gpu_tests.log
+timeout 1800 python -m pytest tests -m gpu -q > $OUT/gpu_tests_full.log 2>&1; grep -E "passed|failed" $OUT/gpu_tests_full.log > $OUT/gpu_tests.log; cat $OUT/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 # 2. the bench line at the driver's settings and at 10 x the steps
 timeout 1500 python bench.py --steps 20 --warmup 5 2> $OUT/bench_final.err | grep '^{"metric"' > $OUT/bench_final.json
