@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   const float* A = g.a + (long long)bi * g.a_bs;
   const float* B = g.b + (long long)bi * g.b_bs;
 
-  const float sa = g.ga.scale[0], oa = g.ga.offset[0], sb = g.gb.scale[0], ob = g.gb.offset[0];
+  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };   // -> SGPR
+  const float sa = uniform(g.ga.scale[0]), oa = uniform(g.ga.offset[0]), sb = uniform(g.gb.scale[0]), ob = uniform(g.gb.offset[0]);
   const float inv_sa = __fdiv_rn(1.0f, sa), inv_sb = __fdiv_rn(1.0f, sb);
   // 8-bit: stored u8 = index + (128 - shift), byte ^ 0x80 = index - shift.  16-bit: u = index - qmin, planes hi / lo ^ 0x80
   const float a_bias = A16 ? -g.ga.qmin : (float)(128 - g.a_shift);
@@ -198,17 +199,28 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   const long long rs = A16 ? 256ll * rs_hi[0] + rs_lo[0] : (long long)rs_lo[0];
   const float alpha = __fmul_rn(sa, sb);
   const bool has_q = g.go.scale != nullptr;
-  const float so = has_q ? g.go.scale[0] : 1.f, oo = has_q ? g.go.offset[0] : 0.f;
+  const float so = has_q ? uniform(g.go.scale[0]) : 1.f, oo = has_q ? uniform(g.go.offset[0]) : 0.f;
   const float inv_so = __fdiv_rn(1.0f, so);
   const bool fast = scale_in_fast_range(so);
+  // <= 8-bit operands whose whole bracket provably fits 32 bits (K (255 + |ca|)(255 + |cb|) < 2^31: every real grid) take 32-bit
+  // integer arithmetic and ONE v_cvt_f32_i32 -- the same rounding of the same integer as the 64-bit / double route, which costs ~2 x the
+  // instructions of this VALU-bound epilogue (wave-uniform choice)
+  const bool fits32 = __builtin_amdgcn_readfirstlane(
+      (int)(!A16 && (double)K * (255.0 + (double)(ca < 0 ? -ca : ca)) * (255.0 + (double)(cb < 0 ? -cb : cb)) < 2147483648.0)) != 0;
+  const int ca32 = (int)ca, row32 = (int)(cb * rs + (long long)K * ca * cb);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     v4f y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long p = A16 ? 256ll * acc_hi[j][e] + acc_lo[j][e] : (long long)acc_lo[j][e];
-      const long long t = p + cb * rs + ca * (long long)cs[j][e] + (long long)K * ca * cb;
-      float v = A16 ? (float)((double)t * (double)alpha) : __fmul_rn((float)(double)t, alpha);
+      float v;
+      if (fits32) {
+        v = __fmul_rn((float)(acc_lo[j][e] + ca32 * cs[j][e] + row32), alpha);
+      } else {
+        const long long p = A16 ? 256ll * acc_hi[j][e] + acc_lo[j][e] : (long long)acc_lo[j][e];
+        const long long t = p + cb * rs + ca * (long long)cs[j][e] + (long long)K * ca * cb;
+        v = A16 ? (float)((double)t * (double)alpha) : __fmul_rn((float)(double)t, alpha);
+      }
       if (!sane) v = __builtin_nanf("");
       if (has_q) {
         const float q = div_by_scale_guarded(v, so, inv_so, fast);
