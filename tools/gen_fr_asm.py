@@ -97,6 +97,13 @@ def configure(name):
         EPI = "u8"
         SCALAR_GRID = BN == 176
         TAIL = True
+    # round 5 experiment (MQ_FR_W4X_LDS=1; measured NEGATIVE, not built by default): frw4x / frw4x_128 (u8 epilogue inside the final block:
+    # the output staging area is unused) park the PACKED pieces in the LDS by LDS-DMA three stages ahead -- the int8 ring's lead -- and
+    # read them back when they are expanded, instead of holding them in registers for one stage.  Bit-identical outputs; TinyLlama w1
+    # 22.7 us against 21.3 (registers) / 21.0 (int8 image), Gemma w1 68.4 against 62.5 / 59.5: one more LDS-DMA issue (60-185 cycles
+    # beside MFMAs), an LDS write and an LDS read per piece cost more than the deeper lead recovers (profiles/r05/bench_w4_lds.log)
+    global W4XL
+    W4XL = W4X and EPI == "u8" and os.environ.get("MQ_FR_W4X_LDS", "0") == "1"
     W4 = EPI == "u8w4"
     if W4:
         EPI = "u8"
@@ -277,7 +284,9 @@ class LQueue:
         if idx < 0:
             return
         n = len(self.q) - 1 - idx
-        assert n <= 15, (n, self.q)
+        if n > 15:                                 # (the counter has four bits: wait for the oldest of the younger operations too)
+            idx += n - 15
+            n = 15
         emit(f"s_waitcnt lgkmcnt({n})")
         self.q = self.q[idx + 1:]
 
@@ -394,14 +403,60 @@ def w4x_advance():
     emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
 
 
-def w4x_expand(q, lq, t, nw, slot_sgpr, regs):
-    """callables (small groups of instructions) that turn the packed pieces of W(t) in `regs` into int8 rows of ring slot `slot_sgpr`"""
+# W4XL: the packed image of a stage (BN rows x 64 B) goes through a four-slot ring in the (otherwise unused) output staging area:
+# piece wave + NW i of W(t) is written by THIS wave's LDS-DMA (lane-linear: lane l = row l >> 2, chunk l & 3 -- the register path's
+# layout) in stage t - 3 and read back by the same wave (ds_read_b128 of its own 16 bytes: no barrier) when it is expanded in stage t - 1.
+S_PKR, S_PKD, S_PK2, S_PKT = 76, 77, 78, 79      # packed-ring slot offsets: expansion source of this stage, DMA target, pre-final's second source; scratch
+
+
+def pk_bytes():
+    return BN * BK // 2
+
+
+def w4xl_dma(q, t, i, slot_sgpr):
+    def f():
+        emit(f"s_add_u32 m0, s{slot_sgpr}, s{S_WK[i]}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 %[sw{i}], s[{S_WBASE}:{S_WBASE + 1}]")
+        q.issue(("W", t))
+    return f
+
+
+def w4x_readback(q, lq, t, nw, regs, pk):
+    """callables in FRONT of a k-step: this wave's packed pieces of W(t) (its own LDS-DMA of three stages ago) -> `regs`"""
+    def rd():
+        q.wait_for(("W", t))
+        emit(f"s_add_u32 s{S_PKT}, s{pk}, s{S_WK[0]}")
+        emit(f"v_and_b32 v{X_T}, 63, %[tid]")
+        emit(f"v_lshl_add_u32 v{X_T}, v{X_T}, 4, s{S_PKT}")
+        for i in range(nw):
+            emit(f"ds_read_b128 v[{regs[i]}:{regs[i] + 3}], v{X_T} offset:{i * NW * 1024}")
+            lq.issue(("PK", t, i))
+    return [rd]
+
+
+def w4xl_rotate():
+    for s_ in (S_PKR, S_PKD):
+        emit(f"s_add_u32 s{s_}, s{s_}, {pk_bytes()}")
+        emit(f"s_cmp_eq_u32 s{s_}, {STG + RING * pk_bytes()}")
+        emit(f"s_cselect_b32 s{s_}, {STG}, s{s_}")
+
+
+def w4x_expand(q, lq, t, nw, slot_sgpr, regs, pk=None):
+    """callables (small groups of instructions) that turn the packed pieces of W(t) in `regs` into int8 rows of ring slot `slot_sgpr`.
+    pk: SGPR with the packed-ring slot of W(t) (W4XL): the pieces are first read back from the LDS into `regs`."""
     out_ = [lambda: q.wait_for(("W", t))]
+    if pk is not None:
+        # the read-back goes FIRST in its k-step (w4x_readback, in front of the W fragment reads): LDS operations return in order, so a
+        # counted wait for a packed piece issued BEHIND the eleven fragment reads would drain them mid-k-step (measured: Gemma w1 62 -> 74 us)
+        out_ = []
     for i in range(nw):
         x = regs[i]
         off = i * NW * 16 * BK
 
-        def lo(x=x, off=off):
+        def lo(x=x, off=off, i=i):
+            if pk is not None:
+                lq.wait_for(("PK", t, i))
             for e in range(4):
                 emit(f"v_and_b32 v{X_L + e}, s{S_M4}, v{x + e}")
             emit(f"v_add_u32 v{X_T}, s{slot_sgpr}, v{X_A0}")
@@ -438,9 +493,13 @@ def stage(q, t, nw, kt=None, sym=None, first=False, dinit=False):
     lq0, lq1 = LQueue(), LQueue()
     pre0, ex0 = deferred_init(lq0, 0, dinit) if dinit else ([], None)
     pre1, ex1 = deferred_init(lq1, 1, dinit) if dinit else ([], None)
+    if W4XL and more3 and not NO_W:       # packed pieces of W(t + 3) -> packed ring (LDS-DMA, as the int8 kernel's W pieces)
+        v0 += [("w", w4xl_dma(q, t + 3, i, S_PKD)) for i in range(nw)]
     if W4X and more1:            # W(t + 1): packed pieces (loaded a stage ago) -> int8 rows of slot(t + 1), behind the later MFMAs of k-step 0
         ex0 = dict(ex0 or {})
-        for n, f in enumerate(w4x_expand(q, lq0, t + 1, nw, S_NXT, X_P)):
+        if W4XL:
+            pre0 = list(pre0) + w4x_readback(q, lq0, t + 1, nw, X_P, S_PKR)
+        for n, f in enumerate(w4x_expand(q, lq0, t + 1, nw, S_NXT, X_P, pk=S_PKR if W4XL else None)):
             ex0.setdefault(FN + 1 + n, []).append(f)
     for f in pre0:
         f()
@@ -448,19 +507,23 @@ def stage(q, t, nw, kt=None, sym=None, first=False, dinit=False):
     if more3 and not W4X:
         emit(f"s_add_u32 s{S_WBASE}, s{S_WBASE}, {BK}")
         emit(f"s_addc_u32 s{S_WBASE + 1}, s{S_WBASE + 1}, 0")
+    if more3 and W4XL:
+        w4x_advance()
     q.wait_for(("A", t, 1), ("W", t + 1))
     emit("s_barrier")
     v1 = []
     if more2 and not NO_A:
         v1 += [("a", a_load(q, t + 2, 0, 0, set_, 2048)), ("a", a_load(q, t + 2, 0, 1, set_, 2048))]
-    if W4X and more2:            # W(t + 2): this wave's packed pieces -> registers (free since k-step 0's expansion)
+    if W4X and more2 and not W4XL:            # W(t + 2): this wave's packed pieces -> registers (free since k-step 0's expansion)
         v1 += [("w", w4x_load(q, t + 2, i, X_P)) for i in range(nw)]
     for f in pre1:
         f()
     kstep(1, set_, 1, S_NXT, V_WOFF0, 0, v1, read=more1, extra=ex1, lq=lq1)
-    if W4X and more2:
+    if W4X and more2 and not W4XL:
         w4x_advance()
     rotate()
+    if W4XL:
+        w4xl_rotate()
 
 
 # ---- round 4: the u8 epilogue inside the last two stages ---------------------------------------------------------------------------------
@@ -512,13 +575,24 @@ def stage_pre_final(q, lq, t, nw):
         emit(f"s_add_u32 s{S_TMP2}, s{S_NXT}, {W_BYTES}")
         emit(f"s_cmp_eq_u32 s{S_TMP2}, {RING * W_BYTES}")
         emit(f"s_cselect_b32 s{S_TMP2}, 0, s{S_TMP2}")
-        for i in range(nw):
-            v0.insert(i, ("a", w4x_load(q, t + 2, i, X_P2)))
         ex0 = {}
-        for n, f in enumerate(w4x_expand(q, lq, t + 1, nw, S_NXT, X_P)):
-            ex0.setdefault(4 + n, []).append(f)
-        for n, f in enumerate(w4x_expand(q, lq, t + 2, nw, S_TMP2, X_P2)):
-            ex0.setdefault(2 * FN - 5 + n, []).append(f)
+        if W4XL:                 # both stages sit in the packed ring already (DMA of stages KT-6 / KT-5): read back and expand, one after the other
+            emit(f"s_add_u32 s{S_PK2}, s{S_PKR}, {pk_bytes()}")
+            emit(f"s_cmp_eq_u32 s{S_PK2}, {STG + RING * pk_bytes()}")
+            emit(f"s_cselect_b32 s{S_PK2}, {STG}, s{S_PK2}")
+            for f in w4x_readback(q, lq, t + 1, nw, X_P, S_PKR) + w4x_readback(q, lq, t + 2, nw, X_P2, S_PK2):
+                f()
+            for n, f in enumerate(w4x_expand(q, lq, t + 1, nw, S_NXT, X_P, pk=S_PKR)):
+                ex0.setdefault(4 + n, []).append(f)
+            for n, f in enumerate(w4x_expand(q, lq, t + 2, nw, S_TMP2, X_P2, pk=S_PK2)):
+                ex0.setdefault(2 * FN - 5 + n, []).append(f)
+        else:
+            for i in range(nw):
+                v0.insert(i, ("a", w4x_load(q, t + 2, i, X_P2)))
+            for n, f in enumerate(w4x_expand(q, lq, t + 1, nw, S_NXT, X_P)):
+                ex0.setdefault(4 + n, []).append(f)
+            for n, f in enumerate(w4x_expand(q, lq, t + 2, nw, S_TMP2, X_P2)):
+                ex0.setdefault(2 * FN - 5 + n, []).append(f)
     kstep(0, set_, 0, S_CUR, V_WOFF1, 1, v0, extra=ex0, lq=lq if W4X else None)
     q.wait_for(("A", t, 1), ("W", t + 1), ("W", t + 2))
     emit("s_barrier")                       # W(KT-2) and W(KT-1) of every wave have landed
@@ -804,7 +878,12 @@ def prologue(q, nw, stamp):
         emit(f"s_mov_b32 s{S_M4}, 0x0f0f0f0f")
     for t, slot in ((0, 0), (1, W_BYTES), (2, 2 * W_BYTES)):
         emit(f"s_mov_b32 s{S_TMP}, {slot}")
-        if W4X:                 # packed pieces of W(0) -> registers; W(1) follows once W(0) is expanded (step 5)
+        if W4XL:                # packed pieces of W(0), W(1), W(2) -> packed ring slots 0, 1, 2 (1 KiB per wave instruction)
+            emit(f"s_mov_b32 s{S_TMP}, {STG} + {t * pk_bytes()}")
+            for i in range(nw):
+                w4xl_dma(q, t, i, S_TMP)()
+            w4x_advance()
+        elif W4X:               # packed pieces of W(0) -> registers; W(1) follows once W(0) is expanded (step 5)
             if t == 0:
                 for i in range(nw):
                     w4x_load(q, 0, i, X_P)()
@@ -978,11 +1057,18 @@ def prologue(q, nw, stamp):
             emit(f"v_add_u32 v{X_A0}, {RING_BASE}, v{X_A0}")
             emit(f"v_add_u32 v{X_A1}, {RING_BASE}, v{X_A1}")
         lqx = LQueue()
-        for f in w4x_expand(q, lqx, 0, nw, S_CUR, X_P):
-            f()
-        for i in range(nw):
-            w4x_load(q, 1, i, X_P)()
-        w4x_advance()
+        if W4XL:
+            emit(f"s_mov_b32 s{S_PKR}, {STG}")                                  # W(0)'s packed slot; stage 0 expands slot 1, its DMA fills slot 3
+            for f in w4x_readback(q, lqx, 0, nw, X_P, S_PKR) + w4x_expand(q, lqx, 0, nw, S_CUR, X_P, pk=S_PKR):
+                f()
+            emit(f"s_mov_b32 s{S_PKR}, {STG} + {pk_bytes()}")
+            emit(f"s_mov_b32 s{S_PKD}, {STG} + {3 * pk_bytes()}")
+        else:
+            for f in w4x_expand(q, lqx, 0, nw, S_CUR, X_P):
+                f()
+            for i in range(nw):
+                w4x_load(q, 1, i, X_P)()
+            w4x_advance()
     q.wait_for(("W", 0))
     if DINIT:
         emit("s_waitcnt lgkmcnt(0)")            # this wave's parameter writes are in the LDS: the barrier publishes them with W(0)

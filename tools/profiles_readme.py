@@ -45,6 +45,7 @@ LOG_CAPTIONS = {
     "mfma_energy_probe.log": "`tools/mfma_energy_probe.cpp 256 200`: NOTHING but int8 MFMAs on all 256 CUs -- 16x16x64 against 32x32x32, operands in registers or W re-read from the LDS every k-step, 8 waves x 32 rows against 4 waves x 64 rows, quantised-Gaussian / uniform-random / zero operands: us per launch, TOPS, the clock each variant holds",
     "mfma_energy_probe_k32.log": "the same at 32 k-steps per wave (= the headline K = 2048): the difference to the 256-k-step run gives the steady-state time per k-step without launch overhead",
     "whatif_operand_paths.log": "`tools/build_stamped.sh <tag> MQ_FR_NO_READ=1 | MQ_FR_NO_W=1 | MQ_FR_NO_A=1` + `tools/ab_stamped.sh frs frs_nord frs_now frs_noa`: the production GEMM program with one operand path removed (wrong results, same schedule), alternated on one box -- cycles per wave, clock, launch period",
+    "bench_w4_lds.log": "`tools/bench_w4.py` with the generator's `MQ_FR_W4X_LDS=1` experiment (packed pieces parked in the LDS by LDS-DMA three stages ahead and read back at expansion time; two scheduling variants) against the int8-image kernel: slower than the register path of round 4 -- not built by default",
     "stable_depth_diag.log": "`tools/stable_depth_diag.py`: the contractive 22-layer model of `full_depth_stable_case.npz` over 8 sequences (2 040 predicted tokens) -- perplexity difference to the reference per execution path (the reference's op sequence on rocBLAS, integer linears, all-integer module chain, fused prefill), per sequence",
     "stable_depth_diag_one_sequence.log": "the same diagnostic on the first (one-sequence, 255-position) form of the fixture: every path, incl. the reference's own op sequence on rocBLAS, 0.03-0.075 off for W4A8 -- position-correlated summation-order noise, the reason the fixture grew to eight sequences",
     "stable_ppl.log": "the report line of `test_quantized_perplexity_within_0_05_of_the_reference_at_22_layers` (module chain, fused prefill, decode engine; W8A8 and W4A8)",
