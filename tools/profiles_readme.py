@@ -41,7 +41,7 @@ LOG_CAPTIONS = {
     "gpu_tests.log": "result line of `python -m pytest tests -m gpu -q` on the box that produced this directory",
     "bench_final.json": "un-profiled `python bench.py --steps 20 --warmup 5` (the driver's settings) at the end of the round",
     "bench_steps200.json": "`python bench.py --steps 200 --warmup 20 --headline-only --no-cpu-baseline` on the same box, minutes later (agreement of the step time with the 20-step run)",
-    # round 5 (tools/evidence_r05.sh, tools/r05_run_*.sh)
+    # round 5 (tools/evidence_r05.sh, tools/r05_probes.sh)
     "mfma_energy_probe.log": "`tools/mfma_energy_probe.cpp 256 200`: NOTHING but int8 MFMAs on all 256 CUs -- 16x16x64 against 32x32x32, operands in registers or W re-read from the LDS every k-step, 8 waves x 32 rows against 4 waves x 64 rows, quantised-Gaussian / uniform-random / zero operands: us per launch, TOPS, the clock each variant holds",
     "mfma_energy_probe_k32.log": "the same at 32 k-steps per wave (= the headline K = 2048): the difference to the 256-k-step run gives the steady-state time per k-step without launch overhead",
     "whatif_operand_paths.log": "`tools/build_stamped.sh <tag> MQ_FR_NO_READ=1 | MQ_FR_NO_W=1 | MQ_FR_NO_A=1` + `tools/ab_stamped.sh frs frs_nord frs_now frs_noa`: the production GEMM program with one operand path removed (wrong results, same schedule), alternated on one box -- cycles per wave, clock, launch period",

@@ -1,6 +1,7 @@
 #!/bin/bash
-# round 5, GPU call C: whole GPU suite on the 8-sequence stable fixture, the bias-or-noise diagnostic, calibration legs, probe (4-wave variant)
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r05c; mkdir -p $OUT; cd $R
+# round 5 probes (run through gpurun, ~5 min): GPU suite, the stable-depth perplexity report and its bias-or-noise diagnostic, the MFMA
+# energy probe, the calibration legs at 64 samples -> gpurun_out/r05_probes/ (copies kept in profiles/r05/)
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r05_probes; mkdir -p $OUT; cd $R
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; tail -12 $OUT/gpu_tests.log
 timeout 900 python -m pytest tests/test_gpu_round5.py -q -s -k "perplexity" 2>&1 | grep "stable full depth" > $OUT/stable_ppl.log; cat $OUT/stable_ppl.log
 timeout 900 python tools/stable_depth_diag.py 2>&1 | grep -v amdgpu.ids > $OUT/stable_depth_diag.log; cat $OUT/stable_depth_diag.log
