@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the round-5 evidence under gpurun_out/evidence_r05/ on an MI355X (run through gpurun; ~20 min).  The files kept under
-# profiles/r05/ are copies of what this and tools/r05_run_*.sh write (captions: tools/profiles_readme.py).   usage: evidence_r05.sh [quick]
+# profiles/r05/ are copies of what this and tools/r05_probes.sh write (captions: tools/profiles_readme.py).   usage: evidence_r05.sh [quick]
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/evidence_r05; mkdir -p $OUT; cd $R
 # 1. parity: the whole GPU suite, then the smoke entry
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/gpu_tests_full.log 2>&1; grep -E "passed|failed" $OUT/gpu_tests_full.log > $OUT/gpu_tests.log; cat $OUT/gpu_tests.log
