@@ -23,9 +23,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 #pragma clang fp contract(off)
 
+// torch.clamp propagates NaN; so do v_maximum3_f32 / v_minimum3_f32 (gfx950) -- two instructions where fmaxf / fminf + a NaN select
+// cost five (round 5: every quantizer of the decode step sits on a launch's critical path)
 __device__ __forceinline__ float dq_clamp_nan(float q, float lo, float hi) {
-  const float c = fminf(fmaxf(q, lo), hi);
-  return q != q ? q : c;
+  return __builtin_elementwise_minimum(__builtin_elementwise_maximum(q, lo), hi);
 }
 // (x / s: div_by_scale of mq_common.h -- at M = 1 every CU quantises the whole activation row, and that arithmetic is on the
 // launch's critical path)
@@ -41,6 +42,17 @@ struct Grid {          // device view of mq_grid
   float s, o, qmin, qmax, inv_s;
   bool on;
   __device__ __forceinline__ float fq(float v) const { return on ? dq_dequant(dq_index(v, s, inv_s, o, qmin, qmax), s, o) : v; }
+  // two elements per instruction where a packed form exists (v_pk_mul / v_pk_fma / v_pk_add are IEEE fp32 on register pairs: the same
+  // bits as fq on each half; rint and the clamp stay scalar).  q - o == q + (-o) exactly.
+  __device__ __forceinline__ v2f fq2(v2f v) const {
+    if (!on) return v;
+    const v2f t = div_by_scale2(v, s, inv_s);
+    v2f r = {rintf(t.x), rintf(t.y)};
+    r = r + splat2(o);
+    r.x = dq_clamp_nan(r.x, qmin, qmax);
+    r.y = dq_clamp_nan(r.y, qmin, qmax);
+    return (r + splat2(-o)) * splat2(s);
+  }
 };
 __device__ __forceinline__ Grid load_grid(const mq_grid& g) {
   Grid r;
@@ -207,7 +219,8 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         for (int u = 0; u < DG_XPRE; ++u) {
           if (u * DG_PRO * 64 < nvec) {
             float4& v = xv[u];
-            v.x = ng.fq(v.x); v.y = ng.fq(v.y); v.z = ng.fq(v.z); v.w = ng.fq(v.w);
+            const v2f lo2 = ng.fq2((v2f){v.x, v.y}), hi2 = ng.fq2((v2f){v.z, v.w});
+            v = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
             if (p + u * DG_PRO * 64 < nvec) s1 += (v.x + v.y) + (v.z + v.w);
           }
         }
@@ -247,12 +260,14 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         for (int u = 0; u < DG_XPRE; ++u) {
           if (u * DG_PRO * 64 < nvec) {
             float4& v = xv[u];
-            v.x = ng.fq(v.x); v.y = ng.fq(v.y); v.z = ng.fq(v.z); v.w = ng.fq(v.w);
+            const v2f lo2 = ng.fq2((v2f){v.x, v.y}), hi2 = ng.fq2((v2f){v.z, v.w});
+            v = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
             if (p + u * DG_PRO * 64 < nvec) {
-              ss += v.x * v.x;
-              ss += v.y * v.y;
-              ss += v.z * v.z;
-              ss += v.w * v.w;
+              const v2f sl = lo2 * lo2, sh = hi2 * hi2;             // the squares in pairs, the sum in the reference kernel's order
+              ss += sl.x;
+              ss += sl.y;
+              ss += sh.x;
+              ss += sh.y;
             }
           }
         }
@@ -275,8 +290,8 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
           float4 v = xv[u];
           if constexpr (XMODE == XM_NORM) {
             const float4 w = nw[u];
-            v.x = __fmul_rn(w.x, __fmul_rn(v.x, r)); v.y = __fmul_rn(w.y, __fmul_rn(v.y, r));
-            v.z = __fmul_rn(w.z, __fmul_rn(v.z, r)); v.w = __fmul_rn(w.w, __fmul_rn(v.w, r));
+            const v2f a2 = (v2f){w.x, w.y} * ((v2f){v.x, v.y} * splat2(r)), b2 = (v2f){w.z, w.w} * ((v2f){v.z, v.w} * splat2(r));
+            v = make_float4(a2.x, a2.y, b2.x, b2.y);
           }
           if constexpr (XMODE == XM_LNORM) {
             const float4 w = nw[u], b = nb[u];
@@ -285,18 +300,14 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
             v.z = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v.z, r), shiftv), w.z), b.z);
             v.w = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v.w, r), shiftv), w.w), b.w);
           }
-          const float f[4] = {v.x, v.y, v.z, v.w};
-          unsigned pk = 0;
-          int sum4 = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float qi = dq_index(f[e], ag.s, ag.inv_s, ag.o, ag.qmin, ag.qmax);
-            const int st = (qi != qi ? (int)ag.qmin : (int)qi) - 128;
-            sum4 += st;
-            pk |= ((unsigned)st & 0xffu) << (8 * e);
-          }
+          // the 8-bit unsigned activation grid's image bytes (index - 128): mq_common.h's packed form -- NaN -> qmin through v_med3,
+          // v_cvt_pk_u8_f32 converts and packs, v_sad_u8 sums the four indices (as the image-only prefill kernels)
+          const v2f u01 = image_u8f2((v2f){v.x, v.y}, ag.s, ag.inv_s, ag.o, ag.qmin, ag.qmax, 0.f);
+          const v2f u23 = image_u8f2((v2f){v.z, v.w}, ag.s, ag.inv_s, ag.o, ag.qmin, ag.qmax, 0.f);
+          uint32_t usum = 0;
+          const uint32_t pk = image_pack4(u01.x, u01.y, u23.x, u23.y, usum);
           if (i < nvec) {
-            my_sum += sum4;
+            my_sum += (int)usum - 512;
             reinterpret_cast<unsigned*>(smem)[i] = pk;
           }
         }
