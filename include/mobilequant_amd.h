@@ -552,6 +552,12 @@ typedef struct mq_attention_args {
    * all of them.  q / k / v / cos / sin / out describe the chunk only (cos / sin rows of positions pos0 ...).  pos0 % 64 == 0,
    * cache_seq % 64 == 0, pos0 + seq <= cache_seq.  cache_seq = 0: the buffers are scratch of seq rows, pos0 = 0. */
   int pos0, cache_seq;
+  /* head_dim 64 with a 16-bit score grid (the production configuration): optional fp16 images of the CENTRED indices (index - offset,
+   * exact in fp16) -- q_f16 [heads][seq][64] scratch, k_f16 [kv_heads][cache_seq or seq][64] (a cache like k_i8).  With both set the
+   * scores are contracted as v_mfma_f32_16x16x32_f16 (exact: integers below 2^24 in fp32), which yields sum (qi - zq)(ki - zk) as a
+   * float directly -- no zero-point terms, no integer -> float conversion per score.  NULL: the int8 contraction. */
+  uint16_t* q_f16;
+  uint16_t* k_f16;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
 

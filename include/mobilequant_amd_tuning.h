@@ -53,6 +53,8 @@ int mq_attention_set_cache(int mode);
  * own 64 query rows (RoPE + input quantizer in registers: no q image, the prep launch covers k / v only), 0 = the prep kernel writes the
  * q image as for the other shapes (A/B timing; identical results). */
 int mq_attention_set_fused_q(int on);
+/* 0 = int8 score contraction even when mq_attention_args carries the fp16 images (A/B timing); default 1 */
+int mq_attention_set_f16(int on);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ class MqAttentionArgs(ctypes.Structure):
                 ("q_i8", c_void_p), ("k_i8", c_void_p), ("vt_i8", c_void_p), ("q_rowsum", c_void_p), ("k_rowsum", c_void_p),
                 ("out_i8", c_void_p), ("out_rowsum", c_void_p), ("out_row0", c_int64), ("seq_real", c_int),
                 ("out_shift", c_int), ("out_i8_tiled", c_int), ("qkv_idx", c_void_p), ("q_in", MqGrid), ("k_in", MqGrid), ("v_in", MqGrid),
-                ("rot_dim", c_int), ("v_prefix", c_void_p), ("pos0", c_int), ("cache_seq", c_int)]
+                ("rot_dim", c_int), ("v_prefix", c_void_p), ("pos0", c_int), ("cache_seq", c_int), ("q_f16", c_void_p), ("k_f16", c_void_p)]
 
 
 _SIGNATURES = {
@@ -90,6 +90,7 @@ _SIGNATURES = {
     "mq_quantize_tiled_set_staged": (c_int, [c_int]),
     "mq_attention_set_cache": (c_int, [c_int]),
     "mq_attention_set_fused_q": (c_int, [c_int]),
+    "mq_attention_set_f16": (c_int, [c_int]),
     "mq_w4a8_linear_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
     "mq_gated_table": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, c_int, _P, _P]),
     "mq_gated_lookup": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P]),

@@ -24,10 +24,15 @@
 // Arithmetic: integer contractions are exact; quantizers use the reciprocal-multiply form of the GEMM epilogues (index within one grid
 // step of the divide form on a vanishing fraction of elements); softmax in fp32.
 #include "mq_common.h"
+#include <type_traits>
 
 namespace mq {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+// two centred indices (integers of magnitude <= 255: exact in fp16) -> one dword of two halves
+__device__ __forceinline__ unsigned pack_h2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 
 #pragma clang fp contract(off)
 
@@ -37,6 +42,53 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef MQ_ATT_ECACHE
 #define MQ_ATT_ECACHE 4   // key blocks per row block whose sweep-1 exponentials are kept for sweep 2 (16 KiB of LDS each: 64 KiB = two workgroups per CU)
 #endif
+// the f16 form stages K / vT tiles in an LDS ring of MQ_ATT_F16_STAGES x 12 KiB, requested STAGES - 1 blocks ahead: with three stages,
+// two parked blocks in the LDS (32 + 36 = 68 KiB: two workgroups per CU) and, with no K tile living in registers across the quantizer
+// chain, seven in registers
+#ifndef MQ_ATT_PK
+#define MQ_ATT_PK 0       // 1 = v_pk_fma_f32 in the f16 form's quantizer chain (identical bits): measured 2-3 % SLOWER -- a packed fma costs the
+#endif                    // VALU what two scalar ones do (tools/valu_rate_probe.cpp: 4.6 against 2 x 2.5 cycles) and pairs constrain the schedule
+#ifndef MQ_ATT_F16_STAGES
+#define MQ_ATT_F16_STAGES 3
+#endif
+#ifndef MQ_ATT_EREGS_F16
+#define MQ_ATT_EREGS_F16 7
+#endif
+#ifndef MQ_ATT_ECACHE_F16
+#define MQ_ATT_ECACHE_F16 (MQ_ATT_F16_STAGES == 2 ? 3 : 2)
+#endif
+// One LDS-DMA piece (1 KiB per wave: lane l's 16 bytes land at lds_base + 16 l) as inline assembly: hipcc's waitcnt pass cannot tell
+// which LDS bytes a DMA it knows about will write, and puts s_waitcnt vmcnt(0) in front of EVERY later ds_read -- the block being read
+// then waits for the block just requested (measured: 40 % of the wave cycles in s_waitcnt).  The asm form is invisible to that pass;
+// the waits are counted by hand (wait_dma below).
+__device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned keep;                                   // m0 is the compiler's to use: hand it back as found
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_base), "v"(voff), "s"(sbase)
+               : "memory");
+}
+// two consecutive pieces (the instruction offset moves the memory AND the LDS address)
+__device__ __forceinline__ void lds_dma16x2(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_base), "v"(voff), "s"(sbase)
+               : "memory");
+}
+// A fragment read the compiler neither waits for nor moves: issued here, complete after lds_fragments_wait (which names every
+// destination, so no consumer can be scheduled above it)
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(v4i& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_fragments_wait(v4i (&f)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+}
+__device__ __forceinline__ void tie16(float (&x)[16]) {   // an ordering point for the sixteen values (no instruction)
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]),
+               "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+}
 
 struct AGrid {
   float s, o, qmin, qmax, inv_s;
@@ -136,10 +188,32 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   }
   // exact divide form of the quantizer (qmodule.py:286-287), bytes = index - 128 (8-bit unsigned grids: the host checks), NaN -> qmin
   unsigned w[4];
+  float qi[16];
 #pragma unroll
-  for (int d4 = 0; d4 < 4; ++d4)
-    w[d4] = image_pack4(image_idxf(y16[4 * d4], g.s, g.inv_s, g.o, g.qmin, g.qmax), image_idxf(y16[4 * d4 + 1], g.s, g.inv_s, g.o, g.qmin, g.qmax),
-                        image_idxf(y16[4 * d4 + 2], g.s, g.inv_s, g.o, g.qmin, g.qmax), image_idxf(y16[4 * d4 + 3], g.s, g.inv_s, g.o, g.qmin, g.qmax), usum);
+  for (int i = 0; i < 16; ++i) qi[i] = image_idxf(y16[i], g.s, g.inv_s, g.o, g.qmin, g.qmax);
+#pragma unroll
+  for (int d4 = 0; d4 < 4; ++d4) w[d4] = image_pack4(qi[4 * d4], qi[4 * d4 + 1], qi[4 * d4 + 2], qi[4 * d4 + 3], usum);
+  if constexpr (D == 64) {
+    // fp16 images of the centred indices for the f16 score contraction (attention_quant_kernel<.., F16>); index - offset is exact
+    // q: row-major [H][S][64].  k: FRAGMENT-BLOCKED per 64-key block (8 KiB = 8 fragments of 1 KiB): fragment 2 j + hf holds keys
+    // 16 j .. + 15, lane l = (key & 15) + 16 tq at byte 16 l: the eight halves d = 16 tq + 8 hf .. + 7 -- one LDS-DMA instruction of
+    // the attention kernel moves a fragment as 1 KiB of consecutive bytes into the layout its ds_read_b128 feeds the MFMA from.
+    uint16_t* hdst = is_q ? a.q_f16 : (is_k ? a.k_f16 : nullptr);
+    if (hdst != nullptr && a.q_f16 != nullptr && a.k_f16 != nullptr) {
+      unsigned hw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hw[i] = pack_h2(__fsub_rn(qi[2 * i], g.o), __fsub_rn(qi[2 * i + 1], g.o));
+      if (is_q) {
+        hdst += ((size_t)head * S + s) * D + col0;
+        reinterpret_cast<uint4*>(hdst)[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        reinterpret_cast<uint4*>(hdst)[1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+      } else {
+        hdst += (((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * 8 + 2 * (r >> 4)) * 512 + ((r & 15) + 16 * c) * 8;
+        reinterpret_cast<uint4*>(hdst)[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        reinterpret_cast<uint4*>(hdst + 512)[0] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+      }
+    }
+  }
   if (is_q || is_k) {
     int8_t* dst = (is_q ? a.q_i8 + ((size_t)head * S + s) * D : a.k_i8 + ((size_t)head * CS + P0 + s) * D) + col0;
     *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -213,7 +287,18 @@ __global__ void __launch_bounds__(256) attention_vprefix_kernel(int32_t* __restr
 constexpr float kMagic = 12582912.0f;             // 1.5 * 2^23
 constexpr float kLog2e = 1.4426950408889634f;
 
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// MQ_ATT_ABL (what-if builds through tools/build.py tags: WRONG results, timing only): 1 = no sweep 2, 2 = no sweep 1, 3 = no v_exp,
+// 4 = no workgroup barrier in the f16 ring, 5 = no clamp (v_med3) in the score chain
+#ifndef MQ_ATT_ABL
+#define MQ_ATT_ABL 0
+#endif
+__device__ __forceinline__ float fast_exp2(float x) {
+#if MQ_ATT_ABL == 3
+  return x;
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
 
 // D = 64: the tuned kernel (three waves per SIMD).  D = 256 (Gemma: 8 heads / 1 KV head): four MFMA k-steps per score tile, 16 output
 // d-tiles (128 accumulator registers: one wave per SIMD), v tiles loaded per d-tile, and sum_t v[t][d] from the prep kernel's prefix
@@ -225,10 +310,32 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // op, with thread (wave, lane) on row 16 wave + (lane & 15), columns 16 (lane >> 4) .. + 15: exactly the 16 bytes this lane feeds the
 // score MFMAs, so the q image never exists in memory and the prep launch shrinks to the k / v parts (H + 2 KV -> 2 KV workgroups per
 // row block; 80 % of its work at 32 / 4 heads).
-template <int D, bool QK_OUT, bool BIG = false, bool QPREP = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2), D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2))))
+// F16 (head_dim 64, 16-bit score grid, deep cache): the score contraction on v_mfma_f32_16x16x32_f16 over fp16 images of the CENTRED
+// indices (prep kernel / QPREP).  sum_d (qi - zq)(ki - zk) < 2^24 is exact in the fp32 accumulator and arrives as a float: the
+// zero-point terms (an add per score), the int -> float conversion (one per score) and the accumulator initialisation (C = 0 is an
+// inline constant) leave the VALU stream, which is what bounds this kernel; the matrix pipe has the room for twice the MFMAs.
+template <int D, bool QK_OUT, bool BIG = false, bool QPREP = false, bool F16 = false>
+#ifndef MQ_ATT_F16_WAVES
+#define MQ_ATT_F16_WAVES 2   // waves per SIMD of the f16 form (the cache depths above must fit: 512 / WAVES registers, 160 KiB / WAVES of LDS per two... workgroups)
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)), F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)))))
     attention_quant_kernel(const mq_attention_args a) {
   static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
+  static_assert(!F16 || (D == 64 && QK_OUT && BIG), "f16 score contraction: the production configuration only");
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+#ifdef MQ_ATT_STAMPS
+  // timing build (tools/att_stamps.py; results are still right, `out` receives the stamps): cycles per wave spent in
+  // [0] q preparation, [1] sweep-1 waits (DMA + barrier), [2] sweep-1 LDS reads + MFMA issue, [3] sweep-1 quantizer chain,
+  // [4] sweep-2 waits, [5] sweep-2 rest, [6] epilogue, [7] whole wave, [8] key blocks
+  unsigned long long st_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [9] sweep-1 DMA issue, [10] sweep-1 ds_read issue .. data back
+  auto now_ = []() { return (unsigned long long)__builtin_readcyclecounter(); };
+  const unsigned long long st_begin = now_();
+  unsigned long long st_t = st_begin;
+#define MQ_ST(i) do { const unsigned long long n_ = now_(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define MQ_ST(i) do { } while (0)
+#endif
   constexpr int NKS = D / 64, NDT = D / 16;
   constexpr float kInvSqrtD = D == 64 ? 0.125f : (D == 256 ? 0.0625f : 0.08838834764831845f);   // 1 / sqrt(D); D = 128: RN(1 / sqrt(128))
   const int S = a.seq, H = a.heads, KV = a.kv_heads;
@@ -253,7 +360,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
   const float cexp = QK_OUT ? gqo.s * kInvSqrtD * kLog2e : kLog2e;  // exp(value - max) = exp2((f - fmax) * cexp)
 
   v4i qf[NKS];
-  int qconst;                                                       // D zq zk - zk * rowsum(q)
+  v8h qh[2];                                                        // F16: this lane's 16 centred q indices as halves (d = 16 tq .. + 15)
+  int qconst = 0;                                                   // D zq zk - zk * rowsum(q)
   if constexpr (QPREP) {
     static_assert(D == 64 || !QPREP, "in-kernel q preparation: head_dim 64");
     const int col0 = 16 * tq, colp = (col0 + 32) & 63;
@@ -284,19 +392,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
     load16(a.sin + (size_t)s_abs * D + col0, sn);
     const float sign = col0 < D / 2 ? -1.f : 1.f;
     uint32_t usum = 0;
+    unsigned hw[8];
 #pragma unroll
     for (int d4 = 0; d4 < 4; ++d4) {
-      float y[4];
+      float y[4], qi[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(x[4 * d4 + e], cs[4 * d4 + e]), __fmul_rn(sign * pr[4 * d4 + e], sn[4 * d4 + e]));
-      qf[0][d4] = (int)image_pack4(image_idxf(y[0], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax), image_idxf(y[1], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax),
-                                   image_idxf(y[2], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax), image_idxf(y[3], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax), usum);
+      for (int e = 0; e < 4; ++e) {
+        y[e] = __fadd_rn(__fmul_rn(x[4 * d4 + e], cs[4 * d4 + e]), __fmul_rn(sign * pr[4 * d4 + e], sn[4 * d4 + e]));
+        qi[e] = image_idxf(y[e], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax);
+      }
+      if constexpr (F16) {
+        hw[2 * d4] = pack_h2(__fsub_rn(qi[0], gqa.o), __fsub_rn(qi[1], gqa.o));
+        hw[2 * d4 + 1] = pack_h2(__fsub_rn(qi[2], gqa.o), __fsub_rn(qi[3], gqa.o));
+      } else {
+        qf[0][d4] = (int)image_pack4(qi[0], qi[1], qi[2], qi[3], usum);
+      }
     }
-    int sum = (int)usum - 128 * 16;
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const int zq = (int)gqa.o - 128, zk = (int)gqb.o - 128;
-    qconst = D * zq * zk - zk * sum;
+    if constexpr (F16) {
+      qh[0] = __builtin_bit_cast(v8h, v4i{(int)hw[0], (int)hw[1], (int)hw[2], (int)hw[3]});
+      qh[1] = __builtin_bit_cast(v8h, v4i{(int)hw[4], (int)hw[5], (int)hw[6], (int)hw[7]});
+    } else {
+      int sum = (int)usum - 128 * 16;
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const int zq = (int)gqa.o - 128, zk = (int)gqb.o - 128;
+      qconst = D * zq * zk - zk * sum;
+    }
+  } else if constexpr (F16) {
+    const v4i* qp = reinterpret_cast<const v4i*>(reinterpret_cast<const _Float16*>(a.q_f16) + ((size_t)h * S + (size_t)qb * 64 + wave * 16 + srow) * D + tq * 16);
+    qh[0] = __builtin_bit_cast(v8h, qp[0]);
+    qh[1] = __builtin_bit_cast(v8h, qp[1]);
   } else {
     const int8_t* qbase = a.q_i8 + ((size_t)h * S + (size_t)qb * 64 + wave * 16) * D;
 #pragma unroll
@@ -314,6 +439,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
     v4i kf[4][NKS];
     int4 kt[4];
   };
+  const char* khbase = F16 ? reinterpret_cast<const char*>(a.k_f16) + (size_t)kvh * CS * D * 2 : nullptr;   // fragment-blocked halves, 8 KiB per key block
   auto load_k = [&](int kb, KTile& t) {
     const int8_t* kp = kbase + (size_t)kb * 64 * D;
 #pragma unroll
@@ -328,9 +454,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
   // block in the LDS by LDS-DMA, fragment-blocked: fragment f (K: f = 4 j + ks, 16 keys x 64 d;  vT: f = dt, 16 d x 64 keys) is the
   // 1-KiB block whose lane l holds exactly the 16 bytes lane l feeds the MFMA -- conflict-free ds_read_b128, and the DMA's lane-linear
   // destination is that layout when every lane sources its own fragment bytes.  Two buffers, one barrier per block.
-  constexpr int kKBytes = 4 * NKS * 1024;                            // K fragments [0, kKBytes) | vT fragments [kKBytes, 2 kKBytes)
-  constexpr int kTileBytes = D == 64 ? 16 : 2 * kKBytes;
-  __shared__ __attribute__((aligned(16))) char s_tile[2][kTileBytes];
+  constexpr int kKBytes = F16 ? 8192 : 4 * NKS * 1024;               // K fragments [0, kKBytes) | vT fragments [kKBytes, ...)  (F16: 8 KiB of halves + 4 KiB)
+  constexpr int kTileBytes = F16 ? 12288 : (D == 64 ? 16 : 2 * kKBytes);
+  constexpr int NST = F16 ? MQ_ATT_F16_STAGES : 2;                  // ring stages of the F16 form (the D != 64 form: two buffers)
+  __shared__ __attribute__((aligned(16))) char s_tile[NST][kTileBytes];
   const int8_t* vbase = a.vt_i8 + (size_t)kvh * (CS >> 6) * D * 64;
   auto dma_block = [&](int kb, int buf, bool with_v) {
     if constexpr (D != 64) {
@@ -377,15 +504,68 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       ti[4 * j] = acc[0] + t.kt[j].x; ti[4 * j + 1] = acc[1] + t.kt[j].y; ti[4 * j + 2] = acc[2] + t.kt[j].z; ti[4 * j + 3] = acc[3] + t.kt[j].w;
     }
   };
-  // -> f: the score on its 16-bit grid in magic-number form (QK_OUT), or the score value itself
-  auto grid_scores = [&](const int (&ti)[16], bool diag, int kb, float (&f)[16]) {
+  // F16: the same sums as floats, from two k-halves of fp16 products (C = 0: an inline constant, nothing to initialise); the K
+  // fragments come from the workgroup's LDS copy of the block (one fetch per workgroup instead of one per wave: with the VALU
+  // chain trimmed, four private copies per block through the L1 were what bounded the loop)
+  auto f_scores_lds = [&](int buf, float (&tf)[16]) {
+    const char* tb = s_tile[buf] + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, *reinterpret_cast<const v4i*>(tb + (2 * j) * 1024)), qh[0],
+                                                       v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, *reinterpret_cast<const v4i*>(tb + (2 * j + 1) * 1024)), qh[1], acc, 0, 0, 0);
+      tf[4 * j] = acc[0]; tf[4 * j + 1] = acc[1]; tf[4 * j + 2] = acc[2]; tf[4 * j + 3] = acc[3];
+    }
+  };
+  // this wave's share of block kb into buffer buf: K fragments 2 wave, 2 wave + 1 (consecutive KiB of the fragment-blocked image) and
+  // vT fragment dt = wave (rows d = 16 wave .. + 15 of the [d][64] tile, lane (srow, tq) sourcing its own 16 bytes)
+  // (the vT piece first: wait_dma counts on that order)
+  // (scalar bases, one 32-bit lane offset each: no vector address arithmetic per request)
+  const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned voff_k = lane * 16, voff_v = srow * 64 + tq * 16;
+  auto dma_f16 = [&](int kb, int buf, bool with_k, bool with_v) {
+    if constexpr (F16) {
+      if (with_v) lds_dma16(a.vt_i8 + ((size_t)kvh * (CS >> 6) + kb) * D * 64 + wave_s * 1024, voff_v, tile_lds + buf * kTileBytes + kKBytes + wave_s * 1024);
+      if (with_k) lds_dma16x2(khbase + (size_t)kb * 8192 + wave_s * 2048, voff_k, tile_lds + buf * kTileBytes + wave_s * 2048);
+    }
+  };
+  // block kb's pieces have landed for every wave once each wave has at most `pending` later DMA instructions in flight (they return
+  // in order) and the workgroup has met; behind the barrier the stage read one block ago is free
+  auto wait_dma = [](int pending) {
+    if (pending >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (pending == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (pending == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if MQ_ATT_ABL != 4
+    asm volatile("s_barrier" ::: "memory");
+#endif
+  };
+  using Tile = KTile;
+  using SC = int;
+  auto load_t = [&](int kb, Tile& t) { load_k(kb, t); };
+  auto scores_t = [&](const Tile& t, SC (&ti)[16]) { int_scores(t, ti); };
+  // -> f: the score on its 16-bit grid in magic-number form (QK_OUT), or the score value itself.  The causal mask only ever cuts the
+  // LAST key block of a row block (kb == kdiag == nkb - 1): `diag` is a compile-time tag, so the other blocks carry no select.
+  auto grid_scores = [&](const auto (&ti)[16], auto diag, int kb, float (&f)[16]) {
+    if constexpr (F16 && MQ_ATT_PK) {                                // two scores per v_pk_fma_f32 (the same IEEE operation per half)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const v2f v = __builtin_elementwise_fma(v2f{(float)ti[i], (float)ti[i + 1]}, splat2(beta), splat2(fbias));
+        f[i] = __builtin_amdgcn_fmed3f(v.x, flo, fhi);
+        f[i + 1] = __builtin_amdgcn_fmed3f(v.y, flo, fhi);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float v = __builtin_fmaf((float)ti[i], beta, fbias);
+#if MQ_ATT_ABL != 5
       if (QK_OUT) v = __builtin_amdgcn_fmed3f(v, flo, fhi);
+#endif
       f[i] = v;
     }
-    if (diag) {
+    }
+    if constexpr (decltype(diag)::value) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int t_abs = kb * 64 + 16 * (i >> 2) + 4 * tq + (i & 3);
@@ -398,9 +578,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
   // exp(value - max) = exp2(f * cexp - R) with ONE fma per element: R = fl(fmax * cexp) is a per-row constant, so its rounding error
   // shifts every exponent of the row alike and cancels in e / l (softmax is shift invariant); R - R' below is exact (Sterbenz).
   float m = -INFINITY, l = 0.f, R = -INFINITY;
-  auto sweep1 = [&](const int (&ti)[16], int kb) {
+  auto sweep1 = [&](const auto (&ti)[16], int kb, auto diag) {
     float f[16];
-    grid_scores(ti, kb == kdiag, kb, f);
+    grid_scores(ti, diag, kb, f);
     float bm = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
     bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(f[8], f[9]), fmaxf(f[10], f[11])), fmaxf(fmaxf(f[12], f[13]), fmaxf(f[14], f[15]))));
     bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
@@ -423,34 +603,131 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
   // With the grid top as reference exponent the sweep-1 exponentials ARE the sweep-2 ones (no rescale in between): those of a row
   // block's LAST kEC key blocks are parked in the LDS (a thread reads back only what it wrote: no barrier), and sweep 2 takes them from
   // there instead of recomputing scores, grid and exp2 -- ~70 % of a block's sweep-2 instructions for min(kEC, nkb) / nkb of the blocks.
-  constexpr int kEC = D == 64 ? (BIG ? MQ_ATT_ECACHE : 2) : 0;
+  constexpr int kEC = D == 64 ? (F16 ? MQ_ATT_ECACHE_F16 : (BIG ? MQ_ATT_ECACHE : 2)) : 0;
   __shared__ float s_e[kEC > 0 ? kEC : 1][16][kEC > 0 ? 256 : 1];
-  constexpr int kER = D == 64 && BIG ? MQ_ATT_EREGS : 0;                    // ... and those of the kER blocks in front of them in registers
+  constexpr int kER = D == 64 && BIG ? (F16 ? MQ_ATT_EREGS_F16 : MQ_ATT_EREGS) : 0;   // ... and those of the kER blocks in front of them in registers
   const int n_lds0 = nkb - kEC > 0 ? nkb - kEC : 0;                 // first block parked in the LDS
   const int n_reg0 = n_lds0 - kER > 0 ? n_lds0 - kER : 0;           // first block parked in registers (blocks before it are recomputed)
   float ereg[kER > 0 ? kER : 1][16];
-  auto exps = [&](const int (&ti)[16], int kb, float (&ex)[16]) {
+  auto exps = [&](const auto (&ti)[16], int kb, float (&ex)[16], auto diag) {
     float f[16];
-    grid_scores(ti, kb == kdiag, kb, f);
+    grid_scores(ti, diag, kb, f);
     float bs = 0.f;
+    if constexpr (F16 && MQ_ATT_PK) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const v2f t = __builtin_elementwise_fma(v2f{f[i], f[i + 1]}, splat2(cexp), splat2(-R));
+        ex[i] = fast_exp2(t.x);
+        ex[i + 1] = fast_exp2(t.y);
+        bs += ex[i];
+        bs += ex[i + 1];
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       ex[i] = fast_exp2(__builtin_fmaf(f[i], cexp, -R));
       bs += ex[i];
     }
+    }
     l += bs;
   };
-  auto sweep1_fixed = [&](const int (&ti)[16], int kb) {
+  auto sweep1_fixed = [&](const auto (&ti)[16], int kb, auto diag, auto park) {
     float ex[16];
-    exps(ti, kb, ex);
-    if constexpr (kEC > 0) {
-      if (kb >= n_lds0) {
+    exps(ti, kb, ex, diag);
+    if constexpr (kEC > 0 && decltype(park)::value) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s_e[kb - n_lds0][i][threadIdx.x] = ex[i];
-      }
+      for (int i = 0; i < 16; ++i) s_e[kb - n_lds0][i][threadIdx.x] = ex[i];
     }
   };
-  if constexpr (D != 64) {
+  MQ_ST(0);
+  if constexpr (F16 && MQ_ATT_ABL == 2) {
+    R = fhi * cexp;
+    l = 1.f;
+  } else if constexpr (F16) {
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < nkb) dma_f16(i, i, true, false);
+    auto next_scores = [&](int kb, float (&ti)[16]) {              // two DMA instructions per block and wave in this sweep
+      const int ahead = nkb - 1 - kb < NST - 2 ? nkb - 1 - kb : NST - 2;
+      wait_dma(2 * ahead);
+      if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, true, false);
+      f_scores_lds(kb % NST, ti);
+    };
+    if (fixed_ref) {
+      R = fhi * cexp;
+      // Software pipeline: a wave issues in order, and per block the wait at the barrier, the DMA request, the LDS round trip of the
+      // fragments and the MFMAs cost it twice the cycles of the quantizer chain (tools/att_stamps.py).  So block kb + 1's fragment
+      // reads and the ring's next request are issued IN FRONT of block kb's chain, and its MFMAs behind it: the LDS latency lies under
+      // the chain, the MFMA latency under the next block's barrier / request.
+      float sc[16];
+      v4i fr[8];
+      auto fetch = [&](int kb) {                                     // block kb has landed -> its fragments requested, the next DMA request issued
+        const int ahead = nkb - 1 - kb < NST - 2 ? nkb - 1 - kb : NST - 2;
+        MQ_ST(2);
+        wait_dma(2 * ahead);
+        MQ_ST(1);
+        const unsigned tb = tile_lds + (kb % NST) * kTileBytes + lane * 16;
+        lds_read_frag<0>(fr[0], tb); lds_read_frag<1024>(fr[1], tb); lds_read_frag<2048>(fr[2], tb); lds_read_frag<3072>(fr[3], tb);
+        lds_read_frag<4096>(fr[4], tb); lds_read_frag<5120>(fr[5], tb); lds_read_frag<6144>(fr[6], tb); lds_read_frag<7168>(fr[7], tb);
+        if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, true, false);
+        MQ_ST(9);
+      };
+      auto contract = [&](float (&o)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, fr[2 * j]), qh[0], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, fr[2 * j + 1]), qh[1], acc, 0, 0, 0);
+          o[4 * j] = acc[0]; o[4 * j + 1] = acc[1]; o[4 * j + 2] = acc[2]; o[4 * j + 3] = acc[3];
+        }
+      };
+      // one block: the next block's fragments are requested, the ring's next DMA request goes out (its issue time covers the LDS
+      // round trip), then the next block's eight MFMAs are spread through this block's chain (one per ~10 VALU instructions: their
+      // issue and dependency latency, ~500 cycles when issued back to back beside the other wave's, disappears under the chain)
+      auto step = [&](int kb, auto last, auto&& chain) {
+        if constexpr (!decltype(last)::value) {
+          float nx[16];
+          fetch(kb + 1);
+          lds_fragments_wait(fr);
+          tie16(sc);
+          contract(nx);
+          chain();
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          }
+          MQ_ST(3);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sc[i] = nx[i];
+        } else {
+          tie16(sc);
+          chain();
+          MQ_ST(3);
+        }
+      };
+      fetch(0);
+      lds_fragments_wait(fr);
+      contract(sc);
+      for (int kb = 0; kb < n_reg0; ++kb) step(kb, F_{}, [&]() { sweep1_fixed(sc, kb, F_{}, F_{}); });
+#pragma unroll
+      for (int u = 0; u < kER; ++u) {                                // static register indices: unrolled; the guard is workgroup-uniform
+        const int kb = n_reg0 + u;
+        if (kb < n_lds0) step(kb, F_{}, [&]() { exps(sc, kb, ereg[u], F_{}); });
+      }
+      for (int kb = n_lds0; kb < nkb - 1; ++kb) step(kb, F_{}, [&]() { sweep1_fixed(sc, kb, F_{}, T_{}); });
+      step(nkb - 1, T_{}, [&]() { sweep1_fixed(sc, nkb - 1, T_{}, T_{}); });   // the diagonal block: always the last, always parked (kEC >= 1)
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    } else {
+      for (int kb = 0; kb < nkb; ++kb) {
+        float ti[16];
+        next_scores(kb, ti);
+        if (kb == kdiag) sweep1(ti, kb, T_{});
+        else sweep1(ti, kb, F_{});
+      }
+    }
+    __syncthreads();                                               // sweep 2 starts over in buffer 0
+  } else if constexpr (D != 64) {
     if (fixed_ref) R = fhi * cexp;
     dma_block(0, 0, false);
     for (int kb = 0; kb < nkb; ++kb) {
@@ -458,8 +735,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       if (kb + 1 < nkb) dma_block(kb + 1, (kb + 1) & 1, false);
       int ti[16];
       int_scores_lds(kb, kb & 1, ti);
-      if (fixed_ref) sweep1_fixed(ti, kb);
-      else sweep1(ti, kb);
+      if (fixed_ref) {
+        if (kb == kdiag) sweep1_fixed(ti, kb, T_{}, F_{});
+        else sweep1_fixed(ti, kb, F_{}, F_{});
+      } else {
+        if (kb == kdiag) sweep1(ti, kb, T_{});
+        else sweep1(ti, kb, F_{});
+      }
     }
     if (fixed_ref) {
       l += __shfl_xor(l, 16, 64);
@@ -467,46 +749,53 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
     }
     __syncthreads();                                               // sweep 2 starts over in buffer 0
   } else {
-    KTile t;
-    load_k(0, t);
+    Tile t;
+    load_t(0, t);
     if (fixed_ref) {
       R = fhi * cexp;
-      for (int kb = 0; kb < n_reg0; ++kb) {
-        int ti[16];
-        int_scores(t, ti);
-        if (kb + 1 < nkb) load_k(kb + 1, t);
-        sweep1_fixed(ti, kb);
+      for (int kb = 0; kb < n_reg0; ++kb) {                          // n_reg0 <= nkb - kEC: a block follows
+        SC ti[16];
+        scores_t(t, ti);
+        load_t(kb + 1, t);
+        sweep1_fixed(ti, kb, F_{}, F_{});
       }
       if constexpr (kER > 0) {
 #pragma unroll
         for (int u = 0; u < kER; ++u) {                              // static register indices: the loop is unrolled, the guard wave-uniform
           const int kb = n_reg0 + u;
           if (kb < n_lds0) {
-            int ti[16];
-            int_scores(t, ti);
-            if (kb + 1 < nkb) load_k(kb + 1, t);
-            exps(ti, kb, ereg[u]);
+            SC ti[16];
+            scores_t(t, ti);
+            load_t(kb + 1, t);
+            exps(ti, kb, ereg[u], F_{});
           }
         }
       }
-      for (int kb = n_lds0; kb < nkb; ++kb) {
-        int ti[16];
-        int_scores(t, ti);
-        if (kb + 1 < nkb) load_k(kb + 1, t);
-        sweep1_fixed(ti, kb);
+      for (int kb = n_lds0; kb < nkb - 1; ++kb) {
+        SC ti[16];
+        scores_t(t, ti);
+        load_t(kb + 1, t);
+        sweep1_fixed(ti, kb, F_{}, T_{});
+      }
+      {                                                              // the diagonal block: always the last, always parked (kEC >= 1)
+        SC ti[16];
+        scores_t(t, ti);
+        sweep1_fixed(ti, nkb - 1, T_{}, T_{});
       }
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
     } else {
       for (int kb = 0; kb < nkb; ++kb) {
-        int ti[16];
-        int_scores(t, ti);
-        if (kb + 1 < nkb) load_k(kb + 1, t);
-        sweep1(ti, kb);
+        SC ti[16];
+        scores_t(t, ti);
+        if (kb + 1 < nkb) load_t(kb + 1, t);
+        if (kb == kdiag) sweep1(ti, kb, T_{});
+        else sweep1(ti, kb, F_{});
       }
     }
   }
   // p index = clamp(rint((e / l) / s_p) + z_p): g = fma(e, 1 / (l s_p), z_p + magic), index = low mantissa bits of med3(g, ...)
+  MQ_ST(3);
   const float rp = __fdiv_rn(gpa.inv_s, l);
   const float pbias = gpa.o + kMagic, plo = kMagic + gpa.qmin, phi = kMagic + gpa.qmax;
 
@@ -543,9 +832,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
   };
-  auto probs = [&](const int (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo) {
+  auto probs = [&](const auto (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo, auto diag) {
     float f[16];
-    grid_scores(ti, kb == kdiag, kb, f);
+    grid_scores(ti, diag, kb, f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned b[4];
@@ -563,11 +852,73 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
   };
-  if constexpr (D == 64) {
-    KTile t;
+  if constexpr (F16 && MQ_ATT_ABL == 1) {
+    acc_hi[0][0] = (int)l;
+  } else if constexpr (F16) {
+    const int nrec = fixed_ref ? n_reg0 : nkb;                       // blocks whose scores are recomputed
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < nkb) dma_f16(i, i, i < nrec, true);
+    auto next_block = [&](int kb) {                                  // -> stage kb % NST holds block kb's vT tile (and K tile while kb < nrec)
+      int pending = 0;                                               // instructions of the blocks requested after kb: 1 (vT) + 2 (K, recomputed blocks)
+#pragma unroll
+      for (int i = 1; i <= NST - 2; ++i)
+        if (kb + i < nkb) pending += kb + i < nrec ? 3 : 1;
+      MQ_ST(5);
+      wait_dma(pending);
+      MQ_ST(4);
+      if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, kb + NST - 1 < nrec, true);
+    };
+    auto pv_lds = [&](int kb, const v4i& pf_hi, const v4i& pf_lo) {
+      const char* vb = s_tile[kb % NST] + kKBytes + lane * 16;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const v4i vf = *reinterpret_cast<const v4i*>(vb + dt * 1024);
+        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_hi, acc_hi[dt], 0, 0, 0);
+        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_lo, acc_lo[dt], 0, 0, 0);
+        acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, ones, acc_v[dt], 0, 0, 0);
+      }
+    };
+    auto recompute = [&](auto with_diag) {
+      for (int kb = 0; kb < nrec; ++kb) {
+        v4i pf_hi, pf_lo;
+        float ti[16];
+        next_block(kb);
+        f_scores_lds(kb % NST, ti);
+        if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
+        else probs(ti, kb, pf_hi, pf_lo, F_{});
+        pv_lds(kb, pf_hi, pf_lo);
+      }
+    };
+    if (fixed_ref) {
+      recompute(F_{});
+#pragma unroll
+      for (int u = 0; u < kER; ++u) {
+        const int kb = n_reg0 + u;
+        if (kb < n_lds0) {
+          v4i pf_hi, pf_lo;
+          next_block(kb);
+          probs_from(ereg[u], pf_hi, pf_lo);
+          pv_lds(kb, pf_hi, pf_lo);
+        }
+      }
+      for (int kb = n_lds0; kb < nkb; ++kb) {
+        v4i pf_hi, pf_lo;
+        float exv[16];
+        next_block(kb);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
+        probs_from(exv, pf_hi, pf_lo);
+        pv_lds(kb, pf_hi, pf_lo);
+      }
+    } else {
+      recompute(T_{});
+    }
+  } else if constexpr (D == 64) {
+    Tile t;
     VTile vt;
     const int nrec = fixed_ref ? n_reg0 : nkb;                       // blocks whose scores are recomputed
-    if (nrec > 0) load_k(0, t);
+    if (nrec > 0) load_t(0, t);
     load_v(0, vt);
     auto pv_block = [&](int kb, const v4i& pf_hi, const v4i& pf_lo) {
 #pragma unroll
@@ -578,14 +929,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       }
       if (kb + 1 < nkb) load_v(kb + 1, vt);
     };
-    for (int kb = 0; kb < nrec; ++kb) {
-      v4i pf_hi, pf_lo;
-      int ti[16];
-      int_scores(t, ti);
-      if (kb + 1 < nrec) load_k(kb + 1, t);
-      probs(ti, kb, pf_hi, pf_lo);
-      pv_block(kb, pf_hi, pf_lo);
-    }
+    auto recompute = [&](auto with_diag) {                            // (with the grid top as reference the diagonal block is a parked one)
+      for (int kb = 0; kb < nrec; ++kb) {
+        v4i pf_hi, pf_lo;
+        SC ti[16];
+        scores_t(t, ti);
+        if (kb + 1 < nrec) load_t(kb + 1, t);
+        if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
+        else probs(ti, kb, pf_hi, pf_lo, F_{});
+        pv_block(kb, pf_hi, pf_lo);
+      }
+    };
+    if (fixed_ref) recompute(F_{});
+    else recompute(T_{});
     if (fixed_ref) {
       if constexpr (kER > 0) {
 #pragma unroll
@@ -615,7 +971,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       int ti[16];
       int_scores_lds(kb, kb & 1, ti);
       v4i pf_hi, pf_lo;
-      probs(ti, kb, pf_hi, pf_lo);
+      if (kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
+      else probs(ti, kb, pf_hi, pf_lo, F_{});
       const char* vb = s_tile[kb & 1] + kKBytes + lane * 16;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
@@ -625,6 +982,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       }
     }
   }
+  MQ_ST(5);
   long long psum = 256ll * psum_hi + psum_lo;
   psum += __shfl_xor(psum, 16, 64);
   psum += __shfl_xor(psum, 32, 64);
@@ -654,7 +1012,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
       rsum += st;
       opk |= ((unsigned)st & 0xffu) << (8 * e);
     }
+#ifndef MQ_ATT_STAMPS
     if (a.out != nullptr) *reinterpret_cast<float4*>(orow + 16 * dt + 4 * tq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+#endif
     // o_proj's int8 input image, row-major or fragment-blocked (layout: include/mobilequant_amd.h): 1-KiB block (row >> 4, k >> 6 = h), byte
     // 16 * ((row & 15) + 16 * ((k & 63) >> 4)) + (k & 15), k & 63 = 16 dt + 4 tq + e
     if (a.out_i8 != nullptr && s_abs < a.seq_real) {
@@ -670,6 +1030,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 2
     rsum += __shfl_xor(rsum, 32, 64);
     if (tq == 0 && s_abs < a.seq_real) atomicAdd(a.out_rowsum + a.out_row0 + s_abs, rsum);
   }
+#ifdef MQ_ATT_STAMPS
+  MQ_ST(6);
+  st_[7] = now_() - st_begin;
+  st_[8] = (unsigned long long)nkb;
+  if (a.out != nullptr && lane == 0) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out) + ((size_t)blockIdx.x * 4 + wave) * 11;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) dst[i] = st_[i];
+  }
+#endif
 }
 
 }  // namespace mq
@@ -687,9 +1057,19 @@ extern "C" int mq_attention_set_cache(int mode) {
   return 0;
 }
 
+static std::atomic<int> g_att_f16{1};         // tuning hook: 0 = int8 score contraction even when the fp16 images are supplied (A/B timing)
+extern "C" int mq_attention_set_f16(int on) {
+  g_att_f16 = on ? 1 : 0;
+  return 0;
+}
+
 extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_attention_quant: null argument block");
-  const mq_attention_args& a = *args;
+  mq_attention_args a = *args;
+  // the f16 score contraction serves head_dim 64 with a 16-bit score grid and the deep cache; anything else runs the int8 form
+  if (!(a.head_dim == 64 && a.qk_out.scale != nullptr && a.q_f16 != nullptr && a.k_f16 != nullptr && g_att_cache.load() != 1 && g_att_f16.load() != 0))
+    a.q_f16 = a.k_f16 = nullptr;
+  MQ_REQUIRE(a.q_f16 == nullptr || (aligned(a.q_f16, 16) && aligned(a.k_f16, 16)), "mq_attention_quant: q_f16 / k_f16 must be 16-byte aligned");
   MQ_REQUIRE(((a.q && a.k && a.v) || a.qkv_idx) && a.cos && a.sin && (a.out || a.out_i8) && a.q_i8 && a.k_i8 && a.vt_i8 && a.q_rowsum && a.k_rowsum,
              "mq_attention_quant: null pointer");
   MQ_REQUIRE(a.seq <= 65536, "mq_attention_quant: seq = %d exceeds 65536 (int32 accumulators of the p.v products)", a.seq);
@@ -725,7 +1105,10 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
     if (qprep) attention_prep_kernel<64><<<dim3(pgrid.x, (unsigned)(2 * a.kv_heads)), 256, 0, st>>>(a, a.heads);
     else attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a, 0);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
+    const bool f16 = a.q_f16 != nullptr;
     if (a.qk_out.scale == nullptr) attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
+    else if (qprep && f16) attention_quant_kernel<64, true, true, true, true><<<cgrid, 256, 0, st>>>(a);
+    else if (f16) attention_quant_kernel<64, true, true, false, true><<<cgrid, 256, 0, st>>>(a);
     else if (qprep) attention_quant_kernel<64, true, true, true><<<cgrid, 256, 0, st>>>(a);
     else if (big) attention_quant_kernel<64, true, true><<<cgrid, 256, 0, st>>>(a);
     else attention_quant_kernel<64, true><<<cgrid, 256, 0, st>>>(a);

@@ -740,6 +740,7 @@ def attention_image_cache(kv_heads: int, head_dim: int, max_len: int, device) ->
             "k_i8": torch.zeros(kv_heads * rows * head_dim, dtype=torch.int8, device=dev),
             "vt_i8": torch.zeros(kv_heads * rows * head_dim, dtype=torch.int8, device=dev),
             "k_rs": torch.zeros(kv_heads * rows, dtype=torch.int32, device=dev),
+            "k_f16": torch.zeros(kv_heads * rows * head_dim, dtype=torch.float16, device=dev) if head_dim == 64 else None,
             "v_pre": torch.zeros(kv_heads * (rows // 64) * head_dim, dtype=torch.int32, device=dev) if head_dim != 64 else None}
 
 
@@ -813,6 +814,7 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
             raise RuntimeError(f"mobilequant_amd: attention_quant cache continuation needs pos0 % 64 == 0 and pos0 + padded S <= {cache['rows']} "
                                f"(pos0={pos0}, S={S})")
         k_i8, vt_i8, k_rs, v_pre = cache["k_i8"], cache["vt_i8"], cache["k_rs"], cache["v_pre"]
+        k_f16 = cache.get("k_f16")
         a.pos0, a.cache_seq = int(pos0), int(cache["rows"])
     else:
         if pos0:
@@ -821,6 +823,12 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
         vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
         k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
         v_pre = torch.empty(kv_heads * (S // 64) * D, dtype=torch.int32, device=dev) if D != 64 else None
+        k_f16 = torch.empty(kv_heads * S * D, dtype=torch.float16, device=dev) if D == 64 else None
+    if k_f16 is not None and grids.get("qk_out") is not None:
+        # head_dim 64 with a score grid: fp16 images of the centred q / k indices -> the f16 score contraction (mq_attention_args.q_f16)
+        q_f16 = torch.empty(heads * S * D, dtype=torch.float16, device=dev)
+        keep += [q_f16, k_f16]
+        a.q_f16, a.k_f16 = q_f16.data_ptr(), k_f16.data_ptr()
     if v_pre is not None:
         keep.append(v_pre)
         a.v_prefix = v_pre.data_ptr()

@@ -453,3 +453,43 @@ def test_fused_gated_mlp_leaves_dynamic_own_input_quantizers_to_the_module_chain
                     delattr(lin.input_quantizer, attr)
         fused = m(ids)[0]
     assert torch.equal(fused, chain)
+
+
+@pytest.mark.parametrize("S,heads,kv_heads,rot,chunks", [(2048, 8, 2, 64, 1), (704, 4, 1, 64, 1), (130, 2, 2, 64, 1), (320, 4, 4, 16, 1), (448, 4, 2, 64, (128, 256, 64))])
+def test_attention_f16_score_contraction_is_the_int8_one_bit_for_bit(dev, S, heads, kv_heads, rot, chunks):
+    """head_dim 64 with a 16-bit score grid: the scores contracted as v_mfma_f32_16x16x32_f16 over fp16 images of the CENTRED indices
+    (K / vT tiles staged once per workgroup in an LDS ring, software-pipelined) against the int8 MFMA + zero-point terms
+    (mq_attention_set_f16(0)): sum (qi - zq)(ki - zk) < 2^24 is exact in the fp32 accumulator, so fp32 output, int8 image and row
+    sums must be equal bit for bit -- full and partial rotary (the q image from the prep kernel), every mix of recomputed / parked key
+    blocks (S = 2048: 32 key blocks), ragged S, and a chunked prefill over the cached images (the fp16 K cache)."""
+    import mobilequant_amd._lib as L
+    from mobilequant_amd import ops
+    from test_gpu_round2 import _grid_of
+    from test_gpu_round3 import _case
+    q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, 64, rot, seed=S + rot)
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                       # noqa: E731
+    outs = []
+    for f16 in (0, 1):
+        L.load().mq_attention_set_f16(f16)
+        try:
+            img = torch.zeros(S, heads * 64, dtype=torch.int8, device=dev)
+            rs = torch.zeros(S, dtype=torch.int32, device=dev)
+            if chunks == 1:
+                out = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, image=(img, rs, 0, 128, False))
+            else:
+                cache = ops.attention_image_cache(kv_heads, 64, S, dev)
+                parts, a0 = [], 0
+                for n in chunks:
+                    parts.append(ops.attention_quant(t(q[a0:a0 + n]), t(k[a0:a0 + n]), t(v[a0:a0 + n]), t(cos[a0:a0 + n]), t(sin[a0:a0 + n]), heads, kv_heads,
+                                                     grids, image=(img, rs, a0, 128, False), cache=cache, pos0=a0))
+                    a0 += n
+                assert a0 == S
+                out = torch.cat(parts)
+            torch.cuda.synchronize()
+            outs.append((out, img, rs))
+        finally:
+            L.load().mq_attention_set_f16(1)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

@@ -28,6 +28,9 @@ def grid(lo, hi, bits):
 
 grids = dict(qk_a=grid(-6.0, 6.0, 8), qk_b=grid(-6.0, 6.0, 8), qk_out=grid(-60.0, 60.0, 16), pv_a=grid(0.0, 1.0, 16), pv_b=grid(-4.5, 4.5, 8),
              pv_out=grid(-2.0, 2.0, 8))
+if "MQ_ATT_F16" in os.environ:             # A/B: 0 = int8 score contraction, 1 = fp16 over the centred indices (default)
+    import mobilequant_amd._lib as L
+    L.load().mq_attention_set_f16(int(os.environ["MQ_ATT_F16"]))
 if "MQ_ATT_FUSED_Q" in os.environ:         # A/B: 0 = the prep kernel writes the q image, 1 = the attention workgroups prepare their q rows
     import mobilequant_amd._lib as L
     L.load().mq_attention_set_fused_q(int(os.environ["MQ_ATT_FUSED_Q"]))
