@@ -68,6 +68,14 @@ __device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsi
                : "s"(lds_base), "v"(voff), "s"(sbase)
                : "memory");
 }
+// a 256-byte piece: lane l's dword lands at lds_base + 4 l
+__device__ __forceinline__ void lds_dma4(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_base), "v"(voff), "s"(sbase)
+               : "memory");
+}
 // two consecutive pieces (the instruction offset moves the memory AND the LDS address)
 __device__ __forceinline__ void lds_dma16x2(const void* sbase, unsigned voff, unsigned lds_base) {
   unsigned keep;
@@ -455,28 +463,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // 1-KiB block whose lane l holds exactly the 16 bytes lane l feeds the MFMA -- conflict-free ds_read_b128, and the DMA's lane-linear
   // destination is that layout when every lane sources its own fragment bytes.  Two buffers, one barrier per block.
   constexpr int kKBytes = F16 ? 8192 : 4 * NKS * 1024;               // K fragments [0, kKBytes) | vT fragments [kKBytes, ...)  (F16: 8 KiB of halves + 4 KiB)
-  constexpr int kTileBytes = F16 ? 12288 : (D == 64 ? 16 : 2 * kKBytes);
+  constexpr int kTileBytes = F16 ? 12288 : (D == 64 ? 16 : 2 * kKBytes + 256);   // D != 64: + the block's 64 key terms
   constexpr int NST = F16 ? MQ_ATT_F16_STAGES : 2;                  // ring stages of the F16 form (the D != 64 form: two buffers)
   __shared__ __attribute__((aligned(16))) char s_tile[NST][kTileBytes];
   const int8_t* vbase = a.vt_i8 + (size_t)kvh * (CS >> 6) * D * 64;
+  // (asm LDS-DMA, lds_dma16 above: with the builtin, hipcc puts s_waitcnt vmcnt(0) in front of every ds_read that follows a request,
+  // i.e. block kb's reads waited for block kb + 1's transfer -- no overlap at all.  The key terms ride along as a 256-byte piece,
+  // so no compiler-counted vector load sits between the requests and the reads either.)
+  const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   auto dma_block = [&](int kb, int buf, bool with_v) {
     if constexpr (D != 64) {
-      const int8_t* kp = kbase + (size_t)kb * 64 * D;
+      const int8_t* kp = kbase + (size_t)kb * 64 * D + (size_t)(16 * wave_s) * D;
       const int8_t* vp = vbase + (size_t)kb * D * 64;
+      const unsigned base = tile_lds + buf * kTileBytes;
 #pragma unroll
-      for (int u = 0; u < NKS; ++u) {
-        const int f = NKS * wave + u;                                // this wave's K fragments (j = wave, ks = u) ...
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + (16 * wave + srow) * D + u * 64 + tq * 16),
-                                         (__attribute__((address_space(3))) void*)(s_tile[buf] + f * 1024), 16, 0, 0);
-      }
+      for (int u = 0; u < NKS; ++u)                                  // this wave's K fragments (j = wave, ks = u) ...
+        lds_dma16(kp + u * 64, (unsigned)(srow * D + tq * 16), base + (NKS * wave_s + u) * 1024);
       if (with_v) {
 #pragma unroll
-        for (int u = 0; u < NDT / 4; ++u) {
-          const int f = (NDT / 4) * wave + u;                        // ... and its vT fragments (dt = f)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + (16 * f + srow) * 64 + tq * 16),
-                                           (__attribute__((address_space(3))) void*)(s_tile[buf] + kKBytes + f * 1024), 16, 0, 0);
+        for (int u = 0; u < NDT / 4; ++u) {                          // ... and its vT fragments (dt = f)
+          const int f = (NDT / 4) * wave_s + u;
+          lds_dma16(vp + (size_t)(16 * f) * 64, (unsigned)(srow * 64 + tq * 16), base + kKBytes + f * 1024);
         }
       }
+      if (wave_s == 0) lds_dma4(kterm + kb * 64, (unsigned)(lane * 4), base + 2 * kKBytes);
     }
   };
   auto block_ready = []() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -484,7 +495,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     const char* tb = s_tile[buf] + lane * 16;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int4 kt = *reinterpret_cast<const int4*>(kterm + kb * 64 + 16 * j + 4 * tq);
+      const int4 kt = *reinterpret_cast<const int4*>(s_tile[buf] + 2 * kKBytes + (16 * j + 4 * tq) * 4);
       v4i acc = cinit;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
@@ -521,8 +532,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // vT fragment dt = wave (rows d = 16 wave .. + 15 of the [d][64] tile, lane (srow, tq) sourcing its own 16 bytes)
   // (the vT piece first: wait_dma counts on that order)
   // (scalar bases, one 32-bit lane offset each: no vector address arithmetic per request)
-  const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const unsigned voff_k = lane * 16, voff_v = srow * 64 + tq * 16;
   auto dma_f16 = [&](int kb, int buf, bool with_k, bool with_v) {
     if constexpr (F16) {
