@@ -62,6 +62,11 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) { return __builtin
 // then waits for the block just requested (measured: 40 % of the wave cycles in s_waitcnt).  The asm form is invisible to that pass;
 // the waits are counted by hand (wait_dma below).
 __device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsigned lds_base) {
+#if defined(MQ_ATT_ABL) && MQ_ATT_ABL == 8     // what-if: the same bytes as a plain load into registers (nothing reaches the LDS)
+  v4i sink;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sink) : "v"(voff), "s"(sbase) : "memory");
+  return;
+#endif
   unsigned keep;                                   // m0 is the compiler's to use: hand it back as found
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
@@ -78,6 +83,11 @@ __device__ __forceinline__ void lds_dma4(const void* sbase, unsigned voff, unsig
 }
 // two consecutive pieces (the instruction offset moves the memory AND the LDS address)
 __device__ __forceinline__ void lds_dma16x2(const void* sbase, unsigned voff, unsigned lds_base) {
+#if defined(MQ_ATT_ABL) && MQ_ATT_ABL == 8
+  v4i sink0, sink1;
+  asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" : "=v"(sink0), "=v"(sink1) : "v"(voff), "s"(sbase) : "memory");
+  return;
+#endif
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
@@ -296,7 +306,7 @@ constexpr float kMagic = 12582912.0f;             // 1.5 * 2^23
 constexpr float kLog2e = 1.4426950408889634f;
 
 // MQ_ATT_ABL (what-if builds through tools/build.py tags: WRONG results, timing only): 1 = no sweep 2, 2 = no sweep 1, 3 = no v_exp,
-// 4 = no workgroup barrier in the f16 ring, 5 = no clamp (v_med3) in the score chain
+// 4 = no workgroup barrier in the f16 ring, 5 = no clamp (v_med3) in the score chain, 6 = no K fragment reads in sweep 1, 7 = no DMA requests
 #ifndef MQ_ATT_ABL
 #define MQ_ATT_ABL 0
 #endif
@@ -367,6 +377,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   const float flo = kMagic + gqo.qmin, fhi = kMagic + gqo.qmax;
   const float cexp = QK_OUT ? gqo.s * kInvSqrtD * kLog2e : kLog2e;  // exp(value - max) = exp2((f - fmax) * cexp)
 
+  constexpr int kKBytes = F16 ? 8192 : 4 * NKS * 1024;               // K fragments [0, kKBytes) | vT fragments [kKBytes, ...)  (F16: 8 KiB of halves + 4 KiB)
+  constexpr int kTileBytes = F16 ? 12288 : (D == 64 ? 16 : 2 * kKBytes + 256);   // D != 64: + the block's 64 key terms
+  constexpr int NST = F16 ? MQ_ATT_F16_STAGES : 2;                  // ring stages of the F16 form (the D != 64 form: two buffers)
+  __shared__ __attribute__((aligned(16))) char s_tile[NST][kTileBytes];
+  const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const char* khbase = F16 ? reinterpret_cast<const char*>(a.k_f16) + (size_t)kvh * CS * D * 2 : nullptr;   // fragment-blocked halves, 8 KiB per key block
+  if constexpr (F16 && MQ_ATT_ABL != 7 && MQ_ATT_ABL != 2) {         // the ring's first K requests go out in front of the q preparation
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < PB + qb + 1) lds_dma16x2(khbase + (size_t)i * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+  }
   v4i qf[NKS];
   v8h qh[2];                                                        // F16: this lane's 16 centred q indices as halves (d = 16 tq .. + 15)
   int qconst = 0;                                                   // D zq zk - zk * rowsum(q)
@@ -447,7 +469,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     v4i kf[4][NKS];
     int4 kt[4];
   };
-  const char* khbase = F16 ? reinterpret_cast<const char*>(a.k_f16) + (size_t)kvh * CS * D * 2 : nullptr;   // fragment-blocked halves, 8 KiB per key block
   auto load_k = [&](int kb, KTile& t) {
     const int8_t* kp = kbase + (size_t)kb * 64 * D;
 #pragma unroll
@@ -462,16 +483,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // block in the LDS by LDS-DMA, fragment-blocked: fragment f (K: f = 4 j + ks, 16 keys x 64 d;  vT: f = dt, 16 d x 64 keys) is the
   // 1-KiB block whose lane l holds exactly the 16 bytes lane l feeds the MFMA -- conflict-free ds_read_b128, and the DMA's lane-linear
   // destination is that layout when every lane sources its own fragment bytes.  Two buffers, one barrier per block.
-  constexpr int kKBytes = F16 ? 8192 : 4 * NKS * 1024;               // K fragments [0, kKBytes) | vT fragments [kKBytes, ...)  (F16: 8 KiB of halves + 4 KiB)
-  constexpr int kTileBytes = F16 ? 12288 : (D == 64 ? 16 : 2 * kKBytes + 256);   // D != 64: + the block's 64 key terms
-  constexpr int NST = F16 ? MQ_ATT_F16_STAGES : 2;                  // ring stages of the F16 form (the D != 64 form: two buffers)
-  __shared__ __attribute__((aligned(16))) char s_tile[NST][kTileBytes];
   const int8_t* vbase = a.vt_i8 + (size_t)kvh * (CS >> 6) * D * 64;
   // (asm LDS-DMA, lds_dma16 above: with the builtin, hipcc puts s_waitcnt vmcnt(0) in front of every ds_read that follows a request,
   // i.e. block kb's reads waited for block kb + 1's transfer -- no overlap at all.  The key terms ride along as a 256-byte piece,
   // so no compiler-counted vector load sits between the requests and the reads either.)
-  const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   auto dma_block = [&](int kb, int buf, bool with_v) {
     if constexpr (D != 64) {
       const int8_t* kp = kbase + (size_t)kb * 64 * D + (size_t)(16 * wave_s) * D;
@@ -534,7 +549,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // (scalar bases, one 32-bit lane offset each: no vector address arithmetic per request)
   const unsigned voff_k = lane * 16, voff_v = srow * 64 + tq * 16;
   auto dma_f16 = [&](int kb, int buf, bool with_k, bool with_v) {
-    if constexpr (F16) {
+    if constexpr (F16 && MQ_ATT_ABL != 7) {
       if (with_v) lds_dma16(a.vt_i8 + ((size_t)kvh * (CS >> 6) + kb) * D * 64 + wave_s * 1024, voff_v, tile_lds + buf * kTileBytes + kKBytes + wave_s * 1024);
       if (with_k) lds_dma16x2(khbase + (size_t)kb * 8192 + wave_s * 2048, voff_k, tile_lds + buf * kTileBytes + wave_s * 2048);
     }
@@ -653,9 +668,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     R = fhi * cexp;
     l = 1.f;
   } else if constexpr (F16) {
-#pragma unroll
-    for (int i = 0; i < NST - 1; ++i)
-      if (i < nkb) dma_f16(i, i, true, false);
     auto next_scores = [&](int kb, float (&ti)[16]) {              // two DMA instructions per block and wave in this sweep
       const int ahead = nkb - 1 - kb < NST - 2 ? nkb - 1 - kb : NST - 2;
       wait_dma(2 * ahead);
@@ -676,8 +688,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         wait_dma(2 * ahead);
         MQ_ST(1);
         const unsigned tb = tile_lds + (kb % NST) * kTileBytes + lane * 16;
+#if MQ_ATT_ABL == 6
+#pragma unroll
+        for (int f = 0; f < 8; ++f) fr[f] = v4i{(int)tb, kb, f, 1};
+#else
         lds_read_frag<0>(fr[0], tb); lds_read_frag<1024>(fr[1], tb); lds_read_frag<2048>(fr[2], tb); lds_read_frag<3072>(fr[3], tb);
         lds_read_frag<4096>(fr[4], tb); lds_read_frag<5120>(fr[5], tb); lds_read_frag<6144>(fr[6], tb); lds_read_frag<7168>(fr[7], tb);
+#endif
         if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, true, false);
         MQ_ST(9);
       };
@@ -868,7 +885,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
       if (i < nkb) dma_f16(i, i, i < nrec, true);
-    auto next_block = [&](int kb) {                                  // -> stage kb % NST holds block kb's vT tile (and K tile while kb < nrec)
+    // A block of sweep 2: behind the barrier the block's vT fragments (and, for a recomputed block, its K fragments) are requested from
+    // the LDS, THEN the ring's next DMA request goes out -- its issue time (100-400 cycles for one to three pieces) covers the LDS round
+    // trip -- and one counted wait names every fragment register.
+    v4i vf[4], kf[8];
+    auto next_block = [&](int kb, auto rec) {                        // -> vf (and kf) hold block kb's fragments
       int pending = 0;                                               // instructions of the blocks requested after kb: 1 (vT) + 2 (K, recomputed blocks)
 #pragma unroll
       for (int i = 1; i <= NST - 2; ++i)
@@ -876,27 +897,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       MQ_ST(5);
       wait_dma(pending);
       MQ_ST(4);
+      const unsigned tb = tile_lds + (kb % NST) * kTileBytes + lane * 16;
+      lds_read_frag<kKBytes>(vf[0], tb); lds_read_frag<kKBytes + 1024>(vf[1], tb); lds_read_frag<kKBytes + 2048>(vf[2], tb); lds_read_frag<kKBytes + 3072>(vf[3], tb);
+      if constexpr (decltype(rec)::value) {
+        lds_read_frag<0>(kf[0], tb); lds_read_frag<1024>(kf[1], tb); lds_read_frag<2048>(kf[2], tb); lds_read_frag<3072>(kf[3], tb);
+        lds_read_frag<4096>(kf[4], tb); lds_read_frag<5120>(kf[5], tb); lds_read_frag<6144>(kf[6], tb); lds_read_frag<7168>(kf[7], tb);
+      }
       if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, kb + NST - 1 < nrec, true);
+      if constexpr (decltype(rec)::value) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]),
+                     "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
+      }
     };
-    auto pv_lds = [&](int kb, const v4i& pf_hi, const v4i& pf_lo) {
-      const char* vb = s_tile[kb % NST] + kKBytes + lane * 16;
+    auto pv_lds = [&](const v4i& pf_hi, const v4i& pf_lo) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const v4i vf = *reinterpret_cast<const v4i*>(vb + dt * 1024);
-        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_hi, acc_hi[dt], 0, 0, 0);
-        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_lo, acc_lo[dt], 0, 0, 0);
-        acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, ones, acc_v[dt], 0, 0, 0);
+        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_hi, acc_hi[dt], 0, 0, 0);
+        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
+        acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], ones, acc_v[dt], 0, 0, 0);
       }
     };
     auto recompute = [&](auto with_diag) {
       for (int kb = 0; kb < nrec; ++kb) {
         v4i pf_hi, pf_lo;
         float ti[16];
-        next_block(kb);
-        f_scores_lds(kb % NST, ti);
+        next_block(kb, T_{});
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j]), qh[0], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j + 1]), qh[1], acc, 0, 0, 0);
+          ti[4 * j] = acc[0]; ti[4 * j + 1] = acc[1]; ti[4 * j + 2] = acc[2]; ti[4 * j + 3] = acc[3];
+        }
         if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
         else probs(ti, kb, pf_hi, pf_lo, F_{});
-        pv_lds(kb, pf_hi, pf_lo);
+        pv_lds(pf_hi, pf_lo);
       }
     };
     if (fixed_ref) {
@@ -906,19 +942,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         const int kb = n_reg0 + u;
         if (kb < n_lds0) {
           v4i pf_hi, pf_lo;
-          next_block(kb);
+          next_block(kb, F_{});
           probs_from(ereg[u], pf_hi, pf_lo);
-          pv_lds(kb, pf_hi, pf_lo);
+          pv_lds(pf_hi, pf_lo);
         }
       }
       for (int kb = n_lds0; kb < nkb; ++kb) {
         v4i pf_hi, pf_lo;
         float exv[16];
-        next_block(kb);
+        next_block(kb, F_{});
 #pragma unroll
         for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
         probs_from(exv, pf_hi, pf_lo);
-        pv_lds(kb, pf_hi, pf_lo);
+        pv_lds(pf_hi, pf_lo);
       }
     } else {
       recompute(T_{});
