@@ -833,6 +833,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   for (int dt = 0; dt < (D == 64 ? NDT : 1); ++dt) acc_v[dt] = v4i{0, 0, 0, 0};
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   unsigned psum_hi = 0, psum_lo = 0;                                // sums of the unsigned high / low bytes (this lane's share)
+  v4i acc_ph = {0, 0, 0, 0}, acc_pl = {0, 0, 0, 0};                 // F16: the row's sums of the SIGNED high / low bytes, every row of D alike
   struct VTile {
     v4i vf[4];
   };
@@ -852,8 +853,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       }
       const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
       const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u), hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
-      psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
-      psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+      if constexpr (!F16) {                                          // (F16: the byte sums come from two more MFMAs against all-ones, pv_lds)
+        psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
+        psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+      }
       pf_lo[j] = (int)(lo ^ 0x80808080u);
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
@@ -872,8 +875,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       }
       const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
       const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u), hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
-      psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
-      psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+      if constexpr (!F16) {                                          // (F16: the byte sums come from two more MFMAs against all-ones, pv_lds)
+        psum_lo = __builtin_amdgcn_sad_u8(lo, 0u, psum_lo);
+        psum_hi = __builtin_amdgcn_sad_u8(hi, 0u, psum_hi);
+      }
       pf_lo[j] = (int)(lo ^ 0x80808080u);
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
@@ -918,6 +923,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pf_lo, acc_lo[dt], 0, 0, 0);
         acc_v[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], ones, acc_v[dt], 0, 0, 0);
       }
+      // sum over the block's 64 keys of the stored probability bytes, per query: ones (as the 16 x 64 A tile) x p -- the matrix pipe
+      // has the room, the VALU (8 v_sad_u8 per block) does not
+      acc_ph = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, pf_hi, acc_ph, 0, 0, 0);
+      acc_pl = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, pf_lo, acc_pl, 0, 0, 0);
     };
     auto recompute = [&](auto with_diag) {
       for (int kb = 0; kb < nrec; ++kb) {
@@ -1029,8 +1038,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   }
   MQ_ST(5);
   long long psum = 256ll * psum_hi + psum_lo;
-  psum += __shfl_xor(psum, 16, 64);
-  psum += __shfl_xor(psum, 32, 64);
+  if constexpr (F16) {                                              // stored byte = unsigned byte - 128, 64 keys per block
+    psum = 256ll * ((long long)acc_ph[0] + 8192ll * nkb) + ((long long)acc_pl[0] + 8192ll * nkb);
+  } else {
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+  }
   const long long nproc = (long long)nkb * 64;
   // out[s][d] = sp * sv * sum_t (p_idx - zp)(v_st - zv),  p_idx = 256 (hi_s + 128) + (lo_s + 128)
   //           = sp * sv * [ 256 A_hi + A_lo + 32896 V - zv P - zp V + zp zv T' ],  A_* = sum byte * v_st, V = sum v_st, P = sum p_idx
