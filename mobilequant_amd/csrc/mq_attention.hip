@@ -384,10 +384,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const char* khbase = F16 ? reinterpret_cast<const char*>(a.k_f16) + (size_t)kvh * CS * D * 2 : nullptr;   // fragment-blocked halves, 8 KiB per key block
+  // The ring is driven without conditionals: request j carries tile min(j, last) into stage j mod NST (past the end the last tile is
+  // requested again into a stage nobody reads any more), so every wait is the same counted constant and no branch guards a request;
+  // stage offsets are running scalars.  Per block that removes ~20 scalar / branch instructions of ~40 beside ~90 VALU.
   if constexpr (F16 && MQ_ATT_ABL != 7 && MQ_ATT_ABL != 2) {         // the ring's first K requests go out in front of the q preparation
 #pragma unroll
-    for (int i = 0; i < NST - 1; ++i)
-      if (i < PB + qb + 1) lds_dma16x2(khbase + (size_t)i * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+    for (int i = 0; i < NST - 1; ++i) {
+      const int t = i < PB + qb ? i : PB + qb;
+      lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+    }
   }
   v4i qf[NKS];
   v8h qh[2];                                                        // F16: this lane's 16 centred q indices as halves (d = 16 tq .. + 15)
@@ -565,6 +570,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     asm volatile("s_barrier" ::: "memory");
 #endif
   };
+  auto ring_step = [&](unsigned& off) {
+    off += kTileBytes;
+    if (off == NST * kTileBytes) off = 0;
+  };
+  auto ring_wait = [&](auto pieces) {                              // the tile about to be read has landed once at most (NST - 2) later tiles are in flight
+    constexpr int n = (NST - 2) * decltype(pieces)::value;
+    if constexpr (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#if MQ_ATT_ABL != 4
+    asm volatile("s_barrier" ::: "memory");
+#endif
+  };
   using Tile = KTile;
   using SC = int;
   auto load_t = [&](int kb, Tile& t) { load_k(kb, t); };
@@ -668,7 +687,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     R = fhi * cexp;
     l = 1.f;
   } else if constexpr (F16) {
-    auto next_scores = [&](int kb, float (&ti)[16]) {              // two DMA instructions per block and wave in this sweep
+    auto next_scores = [&](int kb, float (&ti)[16]) {              // (the form with a running row maximum: guarded requests, counted per block)
       const int ahead = nkb - 1 - kb < NST - 2 ? nkb - 1 - kb : NST - 2;
       wait_dma(2 * ahead);
       if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, true, false);
@@ -682,12 +701,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       // the chain, the MFMA latency under the next block's barrier / request.
       float sc[16];
       v4i fr[8];
-      auto fetch = [&](int kb) {                                     // block kb has landed -> its fragments requested, the next DMA request issued
-        const int ahead = nkb - 1 - kb < NST - 2 ? nkb - 1 - kb : NST - 2;
+      unsigned rd_off = 0, wr_off = (NST - 1) * kTileBytes;          // the stage the next fetch reads / the next request fills
+      int req = NST - 1 < nkb - 1 ? NST - 1 : nkb - 1;               // the tile the next request carries
+      auto fetch = [&]() {                                           // the next block has landed -> its fragments requested, the next DMA request issued
         MQ_ST(2);
-        wait_dma(2 * ahead);
+        ring_wait(std::integral_constant<int, 2>{});
         MQ_ST(1);
-        const unsigned tb = tile_lds + (kb % NST) * kTileBytes + lane * 16;
+        const unsigned tb = tile_lds + rd_off + lane * 16;
 #if MQ_ATT_ABL == 6
 #pragma unroll
         for (int f = 0; f < 8; ++f) fr[f] = v4i{(int)tb, kb, f, 1};
@@ -695,7 +715,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         lds_read_frag<0>(fr[0], tb); lds_read_frag<1024>(fr[1], tb); lds_read_frag<2048>(fr[2], tb); lds_read_frag<3072>(fr[3], tb);
         lds_read_frag<4096>(fr[4], tb); lds_read_frag<5120>(fr[5], tb); lds_read_frag<6144>(fr[6], tb); lds_read_frag<7168>(fr[7], tb);
 #endif
-        if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, true, false);
+        if constexpr (MQ_ATT_ABL != 7) lds_dma16x2(khbase + (size_t)req * 8192 + wave_s * 2048, voff_k, tile_lds + wr_off + wave_s * 2048);
+        ring_step(rd_off);
+        ring_step(wr_off);
+        req = req + 1 < nkb - 1 ? req + 1 : nkb - 1;
         MQ_ST(9);
       };
       auto contract = [&](float (&o)[16]) {
@@ -712,7 +735,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       auto step = [&](int kb, auto last, auto&& chain) {
         if constexpr (!decltype(last)::value) {
           float nx[16];
-          fetch(kb + 1);
+          fetch();
           lds_fragments_wait(fr);
           tie16(sc);
           contract(nx);
@@ -731,7 +754,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
           MQ_ST(3);
         }
       };
-      fetch(0);
+      fetch();
       lds_fragments_wait(fr);
       contract(sc);
       for (int kb = 0; kb < n_reg0; ++kb) step(kb, F_{}, [&]() { sweep1_fixed(sc, kb, F_{}, F_{}); });
@@ -745,6 +768,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
     } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (restart the ring with guarded requests)
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NST - 1; ++i)
+        if (i < nkb) dma_f16(i, i, true, false);
       for (int kb = 0; kb < nkb; ++kb) {
         float ti[16];
         next_scores(kb, ti);
@@ -752,6 +780,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         else sweep1(ti, kb, F_{});
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the ring's trailing requests
     __syncthreads();                                               // sweep 2 starts over in buffer 0
   } else if constexpr (D != 64) {
     if (fixed_ref) R = fhi * cexp;
@@ -887,28 +916,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     acc_hi[0][0] = (int)l;
   } else if constexpr (F16) {
     const int nrec = fixed_ref ? n_reg0 : nkb;                       // blocks whose scores are recomputed
+    // the ring as in sweep 1: request j = tile min(j, last), its vT piece and -- for a recomputed tile -- its two K pieces
+    auto request = [&](int t, unsigned off) {
+      if constexpr (MQ_ATT_ABL != 7) {
+        lds_dma16(a.vt_i8 + ((size_t)kvh * (CS >> 6) + t) * D * 64 + wave_s * 1024, voff_v, tile_lds + off + kKBytes + wave_s * 1024);
+        if (t < nrec) lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, voff_k, tile_lds + off + wave_s * 2048);
+      }
+    };
 #pragma unroll
-    for (int i = 0; i < NST - 1; ++i)
-      if (i < nkb) dma_f16(i, i, i < nrec, true);
+    for (int i = 0; i < NST - 1; ++i) request(i < nkb - 1 ? i : nkb - 1, i * kTileBytes);
+    unsigned rd_off = 0, wr_off = (NST - 1) * kTileBytes;
+    int req = NST - 1 < nkb - 1 ? NST - 1 : nkb - 1;
     // A block of sweep 2: behind the barrier the block's vT fragments (and, for a recomputed block, its K fragments) are requested from
     // the LDS, THEN the ring's next DMA request goes out -- its issue time (100-400 cycles for one to three pieces) covers the LDS round
-    // trip -- and one counted wait names every fragment register.
+    // trip -- and one counted wait names every fragment register.  `pieces`: DMA instructions of the tile requested after this one.
     v4i vf[4], kf[8];
-    auto next_block = [&](int kb, auto rec) {                        // -> vf (and kf) hold block kb's fragments
-      int pending = 0;                                               // instructions of the blocks requested after kb: 1 (vT) + 2 (K, recomputed blocks)
-#pragma unroll
-      for (int i = 1; i <= NST - 2; ++i)
-        if (kb + i < nkb) pending += kb + i < nrec ? 3 : 1;
+    auto next_block = [&](auto rec, auto pieces) {                   // -> vf (and kf) hold the next block's fragments
       MQ_ST(5);
-      wait_dma(pending);
+      ring_wait(pieces);
       MQ_ST(4);
-      const unsigned tb = tile_lds + (kb % NST) * kTileBytes + lane * 16;
+      const unsigned tb = tile_lds + rd_off + lane * 16;
       lds_read_frag<kKBytes>(vf[0], tb); lds_read_frag<kKBytes + 1024>(vf[1], tb); lds_read_frag<kKBytes + 2048>(vf[2], tb); lds_read_frag<kKBytes + 3072>(vf[3], tb);
       if constexpr (decltype(rec)::value) {
         lds_read_frag<0>(kf[0], tb); lds_read_frag<1024>(kf[1], tb); lds_read_frag<2048>(kf[2], tb); lds_read_frag<3072>(kf[3], tb);
         lds_read_frag<4096>(kf[4], tb); lds_read_frag<5120>(kf[5], tb); lds_read_frag<6144>(kf[6], tb); lds_read_frag<7168>(kf[7], tb);
       }
-      if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, kb + NST - 1 < nrec, true);
+      request(req, wr_off);
+      ring_step(rd_off);
+      ring_step(wr_off);
+      req = req + 1 < nkb - 1 ? req + 1 : nkb - 1;
       if constexpr (decltype(rec)::value) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]),
                      "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
@@ -928,20 +964,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       acc_ph = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, pf_hi, acc_ph, 0, 0, 0);
       acc_pl = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, pf_lo, acc_pl, 0, 0, 0);
     };
-    auto recompute = [&](auto with_diag) {
-      for (int kb = 0; kb < nrec; ++kb) {
-        v4i pf_hi, pf_lo;
-        float ti[16];
-        next_block(kb, T_{});
+    using P1 = std::integral_constant<int, 1>;
+    using P3 = std::integral_constant<int, 3>;
+    auto recomputed_block = [&](int kb, auto with_diag, auto pieces) {
+      v4i pf_hi, pf_lo;
+      float ti[16];
+      next_block(T_{}, pieces);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j]), qh[0], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j + 1]), qh[1], acc, 0, 0, 0);
-          ti[4 * j] = acc[0]; ti[4 * j + 1] = acc[1]; ti[4 * j + 2] = acc[2]; ti[4 * j + 3] = acc[3];
-        }
-        if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
-        else probs(ti, kb, pf_hi, pf_lo, F_{});
-        pv_lds(pf_hi, pf_lo);
+      for (int j = 0; j < 4; ++j) {
+        v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j]), qh[0], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j + 1]), qh[1], acc, 0, 0, 0);
+        ti[4 * j] = acc[0]; ti[4 * j + 1] = acc[1]; ti[4 * j + 2] = acc[2]; ti[4 * j + 3] = acc[3];
+      }
+      if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
+      else probs(ti, kb, pf_hi, pf_lo, F_{});
+      pv_lds(pf_hi, pf_lo);
+    };
+    // the tile requested after a recomputed one is recomputed too (three pieces) -- except after the last of them (one piece; with a
+    // running maximum every tile is recomputed and the last is followed by its own repetition)
+    auto recompute = [&](auto with_diag) {
+      for (int kb = 0; kb + 1 < nrec; ++kb) recomputed_block(kb, with_diag, P3{});
+      if (nrec > 0) {
+        if (nrec < nkb) recomputed_block(nrec - 1, with_diag, P1{});
+        else recomputed_block(nrec - 1, with_diag, P3{});
       }
     };
     if (fixed_ref) {
@@ -951,7 +996,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         const int kb = n_reg0 + u;
         if (kb < n_lds0) {
           v4i pf_hi, pf_lo;
-          next_block(kb, F_{});
+          next_block(F_{}, P1{});
           probs_from(ereg[u], pf_hi, pf_lo);
           pv_lds(pf_hi, pf_lo);
         }
@@ -959,7 +1004,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       for (int kb = n_lds0; kb < nkb; ++kb) {
         v4i pf_hi, pf_lo;
         float exv[16];
-        next_block(kb, F_{});
+        next_block(F_{}, P1{});
 #pragma unroll
         for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
         probs_from(exv, pf_hi, pf_lo);
@@ -968,6 +1013,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     } else {
       recompute(T_{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the ring's trailing requests must not outlive the workgroup's LDS
   } else if constexpr (D == 64) {
     Tile t;
     VTile vt;
