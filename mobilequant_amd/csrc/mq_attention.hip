@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // block's LAST kEC key blocks are parked in the LDS (a thread reads back only what it wrote: no barrier), and sweep 2 takes them from
   // there instead of recomputing scores, grid and exp2 -- ~70 % of a block's sweep-2 instructions for min(kEC, nkb) / nkb of the blocks.
   constexpr int kEC = D == 64 ? (F16 ? MQ_ATT_ECACHE_F16 : (BIG ? MQ_ATT_ECACHE : 2)) : 0;
-  __shared__ float s_e[kEC > 0 ? kEC : 1][16][kEC > 0 ? 256 : 1];
+  __shared__ float4 s_e[kEC > 0 ? kEC : 1][4][kEC > 0 ? 256 : 1];     // [block][quad of keys][thread]: whole-dword-quad rows, ds_*_b128 without bank conflicts
   constexpr int kER = D == 64 && BIG ? (F16 ? MQ_ATT_EREGS_F16 : MQ_ATT_EREGS) : 0;   // ... and those of the kER blocks in front of them in registers
   const int n_lds0 = nkb - kEC > 0 ? nkb - kEC : 0;                 // first block parked in the LDS
   const int n_reg0 = n_lds0 - kER > 0 ? n_lds0 - kER : 0;           // first block parked in registers (blocks before it are recomputed)
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     exps(ti, kb, ex, diag);
     if constexpr (kEC > 0 && decltype(park)::value) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s_e[kb - n_lds0][i][threadIdx.x] = ex[i];
+      for (int i = 0; i < 4; ++i) s_e[kb - n_lds0][i][threadIdx.x] = make_float4(ex[4 * i], ex[4 * i + 1], ex[4 * i + 2], ex[4 * i + 3]);
     }
   };
   MQ_ST(0);
@@ -871,13 +871,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) t.vf[dt] = *reinterpret_cast<const v4i*>(vt + (16 * dt + srow) * 64 + tq * 16);   // rows d, key-permuted
   };
-  auto probs_from = [&](const float (&exv)[16], v4i& pf_hi, v4i& pf_lo) {
+  // The clamp of the probability index is dead when the grid holds [0, 1]: e / l <= 1, so the index stays within
+  // [z_p, rint(1 / s_p) + z_p]; `pcl` (a compile-time tag, chosen per launch from the grid: p_clamp below) keeps or drops the v_med3.
+  auto probs_from = [&](const float (&exv)[16], v4i& pf_hi, v4i& pf_lo, auto pcl) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned b[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(exv[4 * j + e], rp, pbias), plo, phi);
+        float g = __builtin_fmaf(exv[4 * j + e], rp, pbias);
+        if constexpr (decltype(pcl)::value) g = __builtin_amdgcn_fmed3f(g, plo, phi);
         b[e] = __float_as_uint(g);
       }
       const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
@@ -890,7 +893,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       pf_hi[j] = (int)(hi ^ 0x80808080u);
     }
   };
-  auto probs = [&](const auto (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo, auto diag) {
+  auto probs = [&](const auto (&ti)[16], int kb, v4i& pf_hi, v4i& pf_lo, auto diag, auto pcl) {
     float f[16];
     grid_scores(ti, diag, kb, f);
 #pragma unroll
@@ -899,7 +902,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float ex = fast_exp2(__builtin_fmaf(f[4 * j + e], cexp, -R));     // masked keys: exp2(-inf) = 0 -> index z_p -> (z_p - z_p) = 0
-        const float g = __builtin_amdgcn_fmed3f(__builtin_fmaf(ex, rp, pbias), plo, phi);
+        float g = __builtin_fmaf(ex, rp, pbias);
+        if constexpr (decltype(pcl)::value) g = __builtin_amdgcn_fmed3f(g, plo, phi);
         b[e] = __float_as_uint(g);
       }
       const unsigned p01 = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), p23 = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
@@ -966,6 +970,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     };
     using P1 = std::integral_constant<int, 1>;
     using P3 = std::integral_constant<int, 3>;
+    auto sweep2 = [&](auto pcl) {
     auto recomputed_block = [&](int kb, auto with_diag, auto pieces) {
       v4i pf_hi, pf_lo;
       float ti[16];
@@ -976,8 +981,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, kf[2 * j + 1]), qh[1], acc, 0, 0, 0);
         ti[4 * j] = acc[0]; ti[4 * j + 1] = acc[1]; ti[4 * j + 2] = acc[2]; ti[4 * j + 3] = acc[3];
       }
-      if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
-      else probs(ti, kb, pf_hi, pf_lo, F_{});
+      if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{}, pcl);
+      else probs(ti, kb, pf_hi, pf_lo, F_{}, pcl);
       pv_lds(pf_hi, pf_lo);
     };
     // the tile requested after a recomputed one is recomputed too (three pieces) -- except after the last of them (one piece; with a
@@ -997,7 +1002,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         if (kb < n_lds0) {
           v4i pf_hi, pf_lo;
           next_block(F_{}, P1{});
-          probs_from(ereg[u], pf_hi, pf_lo);
+          probs_from(ereg[u], pf_hi, pf_lo, pcl);
           pv_lds(pf_hi, pf_lo);
         }
       }
@@ -1006,13 +1011,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         float exv[16];
         next_block(F_{}, P1{});
 #pragma unroll
-        for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
-        probs_from(exv, pf_hi, pf_lo);
+        for (int i = 0; i < 4; ++i) {
+          const float4 t4 = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
+          exv[4 * i] = t4.x; exv[4 * i + 1] = t4.y; exv[4 * i + 2] = t4.z; exv[4 * i + 3] = t4.w;
+        }
+        probs_from(exv, pf_hi, pf_lo, pcl);
         pv_lds(pf_hi, pf_lo);
       }
     } else {
       recompute(T_{});
     }
+    };
+    // e / l <= 1: the index stays within [z_p, rint(1 / s_p) + z_p] -- inside the grid whenever that holds [0, 1] (the reference's
+    // calibrated softmax range does: its maximum is the first position's p = 1)
+    const bool p_clamp = !(gpa.o >= gpa.qmin && gpa.inv_s * (1.0f + 0x1p-20f) + gpa.o < gpa.qmax + 0.5f);
+    if (p_clamp) sweep2(T_{});
+    else sweep2(F_{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the ring's trailing requests must not outlive the workgroup's LDS
   } else if constexpr (D == 64) {
     Tile t;
@@ -1035,8 +1049,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         SC ti[16];
         scores_t(t, ti);
         if (kb + 1 < nrec) load_t(kb + 1, t);
-        if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
-        else probs(ti, kb, pf_hi, pf_lo, F_{});
+        if (decltype(with_diag)::value && kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{}, T_{});
+        else probs(ti, kb, pf_hi, pf_lo, F_{}, T_{});
         pv_block(kb, pf_hi, pf_lo);
       }
     };
@@ -1049,7 +1063,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
           const int kb = n_reg0 + u;
           if (kb < n_lds0) {
             v4i pf_hi, pf_lo;
-            probs_from(ereg[u], pf_hi, pf_lo);
+            probs_from(ereg[u], pf_hi, pf_lo, T_{});
             pv_block(kb, pf_hi, pf_lo);
           }
         }
@@ -1058,8 +1072,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         v4i pf_hi, pf_lo;
         float exv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) exv[i] = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
-        probs_from(exv, pf_hi, pf_lo);
+        for (int i = 0; i < 4; ++i) {
+          const float4 t4 = s_e[kEC > 0 ? kb - n_lds0 : 0][i][kEC > 0 ? threadIdx.x : 0];
+          exv[4 * i] = t4.x; exv[4 * i + 1] = t4.y; exv[4 * i + 2] = t4.z; exv[4 * i + 3] = t4.w;
+        }
+        probs_from(exv, pf_hi, pf_lo, T_{});
         pv_block(kb, pf_hi, pf_lo);
       }
     }
@@ -1071,8 +1088,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       int ti[16];
       int_scores_lds(kb, kb & 1, ti);
       v4i pf_hi, pf_lo;
-      if (kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{});
-      else probs(ti, kb, pf_hi, pf_lo, F_{});
+      if (kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{}, T_{});
+      else probs(ti, kb, pf_hi, pf_lo, F_{}, T_{});
       const char* vb = s_tile[kb & 1] + kKBytes + lane * 16;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {

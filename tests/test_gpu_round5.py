@@ -455,13 +455,15 @@ def test_fused_gated_mlp_leaves_dynamic_own_input_quantizers_to_the_module_chain
     assert torch.equal(fused, chain)
 
 
-@pytest.mark.parametrize("S,heads,kv_heads,rot,chunks", [(2048, 8, 2, 64, 1), (704, 4, 1, 64, 1), (130, 2, 2, 64, 1), (320, 4, 4, 16, 1), (448, 4, 2, 64, (128, 256, 64))])
-def test_attention_f16_score_contraction_is_the_int8_one_bit_for_bit(dev, S, heads, kv_heads, rot, chunks):
+@pytest.mark.parametrize("S,heads,kv_heads,rot,chunks,p_top", [(2048, 8, 2, 64, 1, 1.0), (704, 4, 1, 64, 1, 1.0), (130, 2, 2, 64, 1, 1.0), (320, 4, 4, 16, 1, 1.0),
+                                                              (448, 4, 2, 64, (128, 256, 64), 1.0), (704, 4, 2, 64, 1, 0.4), (192, 2, 1, 16, 1, 0.05)])
+def test_attention_f16_score_contraction_is_the_int8_one_bit_for_bit(dev, S, heads, kv_heads, rot, chunks, p_top):
     """head_dim 64 with a 16-bit score grid: the scores contracted as v_mfma_f32_16x16x32_f16 over fp16 images of the CENTRED indices
     (K / vT tiles staged once per workgroup in an LDS ring, software-pipelined) against the int8 MFMA + zero-point terms
     (mq_attention_set_f16(0)): sum (qi - zq)(ki - zk) < 2^24 is exact in the fp32 accumulator, so fp32 output, int8 image and row
     sums must be equal bit for bit -- full and partial rotary (the q image from the prep kernel), every mix of recomputed / parked key
-    blocks (S = 2048: 32 key blocks), ragged S, and a chunked prefill over the cached images (the fp16 K cache)."""
+    blocks (S = 2048: 32 key blocks), ragged S, a chunked prefill over the cached images (the fp16 K cache), and a probability grid that
+    does NOT hold [0, 1] (p_top < 1: the f16 form then keeps the index clamp it otherwise drops as dead)."""
     import mobilequant_amd._lib as L
     from mobilequant_amd import ops
     from test_gpu_round2 import _grid_of
@@ -469,6 +471,9 @@ def test_attention_f16_score_contraction_is_the_int8_one_bit_for_bit(dev, S, hea
     q, k, v, cos, sin, qk, pv = _case(S, heads, kv_heads, 64, rot, seed=S + rot)
     grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
                  pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    if p_top != 1.0:
+        from test_gpu_round3 import _mk
+        grids["pv_a"] = _grid_of(_mk(16, 0.0, p_top), dev)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                       # noqa: E731
     outs = []
     for f16 in (0, 1):
