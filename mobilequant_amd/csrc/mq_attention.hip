@@ -1054,8 +1054,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         pv_block(kb, pf_hi, pf_lo);
       }
     };
-    if (fixed_ref) recompute(F_{});
-    else recompute(T_{});
+    recompute(T_{});
     if (fixed_ref) {
       if constexpr (kER > 0) {
 #pragma unroll

@@ -2,7 +2,8 @@
   * the 128-column generated GEMMs on fragment-blocked activations == the C++ tile kernels on the row-major image, bit for bit
     (residual epilogue with a 16-bit grid, both tile heights; segmented 8-bit index outputs);
   * mq_attention_quant at head_dim 64 / 128 / 256 against the oracle, single shot and fed in chunks through an image cache
-    (chunked == single shot, bit for bit); at head_dim 64 the q rows prepared inside the attention workgroups == the prep kernel's image;
+    (chunked == single shot, bit for bit); at head_dim 64 the q rows prepared inside the attention workgroups == the prep kernel's image,
+    and (round 5) the fp16 score contraction == the int8 one;
   * the LDS-staged image-only norm / quantize kernels (packed-convert bytes) == the generic kernels, random shapes, grids, signed and
     unsigned, RMSNorm / LayerNorm, occasional non-finite elements."""
 import os
@@ -88,6 +89,15 @@ for it in range(iters):
         if not torch.equal(ref_q, whole):
             bad += 1
             print("ATTENTION fused q", heads, kv, S, qkb, pvb, float((ref_q - whole).abs().max()))
+        if qkb:                                # round 5: scores on fp16 MFMAs over the centred indices (default) == the int8 contraction
+            L.load().mq_attention_set_f16(0)
+            try:
+                ref_i8 = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv, g, head_dim=D)
+            finally:
+                L.load().mq_attention_set_f16(1)
+            if not torch.equal(ref_i8, whole):
+                bad += 1
+                print("ATTENTION f16 scores", heads, kv, S, qkb, pvb, float((ref_i8 - whole).abs().max()))
     # ---- image-only staged kernels (v_med3 / v_cvt_pk_u8_f32 / v_sad_u8 bytes) == the generic kernels -------------------------------------
     rows = int(rng.choice([64, 65, 100, 333, 1000, 2048]))
     cols = 64 * int(rng.integers(16, 65))

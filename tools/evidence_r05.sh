@@ -34,3 +34,13 @@ head -30 $OUT/trace.summary.txt
 python -c "from mobilequant_amd import build; build.build(force=True, tag='stamps', extra_flags=['-DMQ_DECODE_STAMPS'])" > /dev/null 2>&1
 MQ_LIB_PATH=mobilequant_amd/lib/stamps/libmobilequant_amd.so LAYERS=6 CONTEXT=256 WBITS=8 timeout 300 python tools/decode_stamps.py > $OUT/decode_stamps_w8.log 2>&1
 ls -la $OUT
+# 5. the prefill attention (round 5: f16 score contraction): A/B against the int8 form, counter passes, in-kernel stamps, VALU issue rates
+python tools/att_f16_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/attention_f16_ab.log
+MQ_ATT_ROT=16 MQ_ATT_KV=32 python tools/att_f16_ab.py 2>&1 | grep -v amdgpu.ids >> $OUT/attention_f16_ab.log; cat $OUT/attention_f16_ab.log
+bash tools/prof_attention_pmc.sh att_r05 > /dev/null 2>&1
+for f in sq lds misc; do for v in 0 1; do cp gpurun_out/prof_att_r05/${f}_f$v.summary.txt $OUT/attention_pmc_${f}_f$v.summary.txt; done; done
+python -c "from mobilequant_amd import build; build.build(force=True, tag='attst', extra_flags=['-DMQ_ATT_STAMPS'], only=['mq_attention.hip'])" > /dev/null 2>&1
+MQ_LIB_PATH=mobilequant_amd/lib/attst/libmobilequant_amd.so timeout 300 python tools/att_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/attention_stamps.log; cat $OUT/attention_stamps.log
+hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe.cpp -o /tmp/valu_rate_probe 2> /dev/null && timeout 120 /tmp/valu_rate_probe > $OUT/valu_rate_probe.log 2>&1; cat $OUT/valu_rate_probe.log
+bash tools/prof_cmd.sh layer_r05 -- python $R/tools/prof_layer.py > /dev/null 2>&1; grep "mq::" gpurun_out/prof_layer_r05/trace.summary.txt | cut -c1-170 > $OUT/layer_trace.summary.txt; cat $OUT/layer_trace.summary.txt
+ls -la $OUT

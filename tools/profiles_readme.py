@@ -53,7 +53,17 @@ LOG_CAPTIONS = {
     "calibration64.json": "`python bench.py --workload calibration --calib-samples 64`: configs[4]'s per-sample cost with the fp32 library GEMMs in (the score chain of every attention block takes its two statistics in one pass)",
     "calibration64_stub_gemm.json": "the same with `--calib-stub-gemm` (the timed region is the hot path: hooked reductions + the fused score chain)",
     "decode_stamps_w8.log": "`tools/decode_stamps.py` (`-DMQ_DECODE_STAMPS` build, 6 layers, context 256): per-launch gap / ramp / in-kernel stamps of the decode step, int8 weights",
+    "attention_f16_ab.log": "`tools/att_f16_ab.py` (and with `MQ_ATT_ROT=16 MQ_ATT_KV=32`, the StableLM shape): the prefill attention at head_dim 64 with its scores contracted as int8 MFMA + zero-point terms against fp16 MFMA over the centred indices (`mq_attention_set_f16`): identical fp32 output / int8 image / row sums, and the time of each (prep + core, one hipGraph)",
+    "attention_stamps.log": "`tools/att_stamps.py` on the `-DMQ_ATT_STAMPS` build: `s_memtime` differences accumulated per wave of the f16 attention kernel -- q preparation, the waits / fragment + DMA issue / chain + MFMAs of sweep 1, waits and the rest of sweep 2, epilogue (the stamps themselves cost ~10 %)",
+    "valu_rate_probe.log": "`tools/valu_rate_probe.cpp`: cycles per wave-instruction of the chain's VALU instructions (fma / pk_fma / exp / med3 / add / pk_add and the chain's mix), one and two waves per SIMD",
+    "attention_whatif.log": "`tools/att_ablate.sh` over `MQ_ATT_ABL` builds (wrong results, same box): the attention op without sweep 2 / sweep 1 / v_exp / barrier / K fragment reads / DMA requests, and with plain loads in place of the DMA pieces",
 }
+for _v in ("0", "1"):
+    for _f, _c in (("sq", "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY"),
+                   ("lds", "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_MISC"),
+                   ("misc", "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE")):
+        CAPTIONS[f"attention_pmc_{_f}_f{_v}.summary.txt"] = (f"`tools/prof_attention_pmc.sh`: `rocprofv3 --pmc {_c} --kernel-trace -- python tools/prof_attention.py` with "
+                                                            f"`MQ_ATT_F16={_v}` ({'fp16 over the centred indices' if _v == '1' else 'the int8 score contraction'}); the attention core kernel's rows")
 
 
 def kernel_table(path, only=None, limit=60):
