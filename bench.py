@@ -760,6 +760,13 @@ def bench_layer_full(dev, modes=("fused", "attention_chain", "composite"), wbits
     if rec:                                    # (head_dim != 64: the attention runs as its module chain, no fused op to time)
         (a_args, a_kw), = rec
         res["attention_op_us"] = round(event_time(lambda: real(*a_args, **a_kw), 5) * 1e6, 1)
+        if shape.head_dim == 64:                 # the same op with the int8 score contraction (round 4's form; identical results)
+            import mobilequant_amd._lib as _L
+            _L.load().mq_attention_set_f16(0)
+            try:
+                res["attention_op_int8_scores_us"] = round(event_time(lambda: real(*a_args, **a_kw), 5) * 1e6, 1)
+            finally:
+                _L.load().mq_attention_set_f16(1)
     else:
         res["attention_op_us"] = None
     if "fused" in outs and "attention_chain" in outs:
@@ -1061,6 +1068,13 @@ def bench_model_prefill(dev):
     res["fused_ms"], res["simulated_ms"] = round(t_fused * 1e3, 3), round(t_sim * 1e3, 3)
     res["fused_tokens_per_s"], res["simulated_tokens_per_s"] = round(S / t_fused), round(S / t_sim)
     res["speedup"] = round(t_sim / t_fused, 2)
+
+    def fwd_last():
+        Q._shared_activation.clear()
+        with torch.no_grad():
+            return model(ids, last_logits_only=True)
+    fwd_last()
+    res["fused_last_logits_only_ms"] = round(event_time(fwd_last, 2) * 1e3, 3)     # the context encoding of generation (DecodeEngine.prefill)
     res["scope"] = ("TinyLlama-1.1B shape (22 layers, vocab 32000), one 2048-token sequence, W8A8 recipe, module API, hipGraph; 'simulated' = "
                     "the reference's execution model on this GPU (fake-quant kernels around fp32 library GEMMs, every module on its own)")
     del model

@@ -414,7 +414,7 @@ class DecodeEngine:
         assert 0 < S <= self.cache_len
         self._sync_grids()
         raw = self.model.new_cache(1, S, device=self.dev)
-        logits = self.model(ids, cache=raw)
+        logits = self.model(ids, cache=raw, last_logits_only=True)      # [1, 1, vocab]: only the last position feeds the first new token
         for li, layer in enumerate(self.model.layers):
             att = layer.self_attn
             self.k_cache[li][:, :S] = att.qk_bmm.input2_quantizer.quantize_to_int(raw[li][0][0].contiguous())[0]
