@@ -558,6 +558,10 @@ typedef struct mq_attention_args {
    * float directly -- no zero-point terms, no integer -> float conversion per score.  NULL: the int8 contraction. */
   uint16_t* q_f16;
   uint16_t* k_f16;
+  /* batch > 1: that many sequences of `seq` (padded) rows in ONE launch pair -- q / k / v (or qkv_idx), out and every scratch buffer are
+   * [batch][...] of the single-sequence shapes above, cos / sin are shared, sequence b owns rows out_row0 + b * seq_real ... of the
+   * int8 image.  0 or 1: one sequence.  Not with cache continuation (cache_seq must be 0). */
+  int batch;
 } mq_attention_args;
 int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
 

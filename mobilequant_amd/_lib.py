@@ -52,7 +52,7 @@ class MqAttentionArgs(ctypes.Structure):
                 ("q_i8", c_void_p), ("k_i8", c_void_p), ("vt_i8", c_void_p), ("q_rowsum", c_void_p), ("k_rowsum", c_void_p),
                 ("out_i8", c_void_p), ("out_rowsum", c_void_p), ("out_row0", c_int64), ("seq_real", c_int),
                 ("out_shift", c_int), ("out_i8_tiled", c_int), ("qkv_idx", c_void_p), ("q_in", MqGrid), ("k_in", MqGrid), ("v_in", MqGrid),
-                ("rot_dim", c_int), ("v_prefix", c_void_p), ("pos0", c_int), ("cache_seq", c_int), ("q_f16", c_void_p), ("k_f16", c_void_p)]
+                ("rot_dim", c_int), ("v_prefix", c_void_p), ("pos0", c_int), ("cache_seq", c_int), ("q_f16", c_void_p), ("k_f16", c_void_p), ("batch", c_int)]
 
 
 _SIGNATURES = {

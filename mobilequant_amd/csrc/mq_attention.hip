@@ -127,12 +127,45 @@ __device__ __forceinline__ float a_index_fast(float x, const AGrid& g) {
   return fminf(fmaxf(rintf(x * g.inv_s) + g.o, g.qmin), g.qmax);
 }
 
+// batch > 1 (no cache continuation): sequence b = blockIdx.z of one launch.  Inputs, outputs and scratch are laid out [batch][...] with
+// the per-sequence shapes of the single-sequence call (include/mobilequant_amd.h), cos / sin are shared; the view below is that call's
+// argument block for sequence b.  (By value: a reference would pin the kernel's argument block in scratch.)
+__device__ __forceinline__ mq_attention_args batch_view(mq_attention_args a, const int b) {
+  if (a.batch > 1) {
+    const size_t S = (size_t)a.seq, H = (size_t)a.heads, KV = (size_t)a.kv_heads, D = (size_t)a.head_dim;
+    if (a.qkv_idx) a.qkv_idx += b * S * (H + 2 * KV) * D;
+    if (a.q) { a.q += b * S * H * D; a.k += b * S * KV * D; a.v += b * S * KV * D; }
+    if (a.out) a.out += b * S * H * D;
+    a.out_row0 += (int64_t)b * a.seq_real;
+    a.q_i8 += b * H * S * D; a.k_i8 += b * KV * S * D; a.vt_i8 += b * KV * S * D;
+    a.q_rowsum += b * H * S; a.k_rowsum += b * KV * S;
+    if (a.q_f16) { a.q_f16 += b * H * S * D; a.k_f16 += b * KV * S * D; }
+    if (a.v_prefix) a.v_prefix += b * KV * (S / 64) * D;
+  }
+  return a;
+}
+
 // ---- prep: RoPE + input quantizers -> integer images ----------------------------------------------------------------------------
 // grid: (S / 64, H + 2 KV).  Block b of part p: rows s = 64 b .. 64 b + 63.  256 threads: thread (r = tid >> 2, c = tid & 3) handles
 // row r, 16 columns 64 dc + 16 c .. + 15 of every 64-column slab dc (D = 64: one slab; D = 256: four).
 template <int D>
 __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_args a, const int part0) {
   const int H = a.heads, KV = a.kv_heads, S = a.seq;
+  // batch > 1: sequence blockIdx.z (batch_view's offsets, as plain locals: a modified copy of the argument block would live in scratch here)
+  const size_t bz = a.batch > 1 ? blockIdx.z : 0, bS = bz * (size_t)S;
+  const float* const q_in = a.q ? a.q + bS * H * D : nullptr;
+  const float* const k_in = a.k ? a.k + bS * KV * D : nullptr;
+  const float* const v_in = a.v ? a.v + bS * KV * D : nullptr;
+  const uint8_t* const idx_in = a.qkv_idx ? a.qkv_idx + bS * (H + 2 * KV) * D : nullptr;
+  int8_t* const q_img = a.q_i8 + bz * H * S * D;
+  int8_t* const k_img = a.k_i8 + bz * KV * S * D;
+  int8_t* const vt_img = a.vt_i8 + bz * KV * S * D;
+  int32_t* const q_rs = a.q_rowsum + bz * H * S;
+  int32_t* const k_rs = a.k_rowsum + bz * KV * S;
+  uint16_t* const q_h = a.q_f16 ? a.q_f16 + bz * H * S * D : nullptr;
+  uint16_t* const k_h = a.k_f16 ? a.k_f16 + bz * KV * S * D : nullptr;
+  int32_t* const v_pre = a.v_prefix ? a.v_prefix + bz * KV * (S / 64) * D : nullptr;
+  const int64_t row0 = a.out_row0 + (int64_t)bz * a.seq_real;
   // cache continuation (chunked prefill): the K / vT images, their row sums and the v prefix sums are caller-owned caches of cache_seq
   // rows; this chunk's rows go to positions pos0 .. pos0 + seq - 1 (pos0 % 64 == 0).  cache_seq = 0: scratch of seq rows, pos0 = 0.
   const int CS = a.cache_seq > 0 ? a.cache_seq : S, P0 = a.cache_seq > 0 ? a.pos0 : 0;
@@ -141,11 +174,11 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
   const int s = blockIdx.x * 64 + r;
   __shared__ int8_t s_v[64][64 + 4];
   if (a.out_i8 != nullptr && blockIdx.y == 0 && threadIdx.x < 64 && (int)(blockIdx.x * 64 + threadIdx.x) < a.seq_real)
-    a.out_rowsum[a.out_row0 + blockIdx.x * 64 + threadIdx.x] = 0;          // the core kernel accumulates one share per head
+    a.out_rowsum[row0 + blockIdx.x * 64 + threadIdx.x] = 0;          // the core kernel accumulates one share per head
   __syncthreads();
   const bool is_q = part < H, is_k = !is_q && part < H + KV;
   const int head = is_q ? part : (is_k ? part - H : part - H - KV);
-  const float* src = (is_q ? a.q : (is_k ? a.k : a.v)) + (size_t)s * (is_q ? H : KV) * D + (size_t)head * D;
+  const float* src = (is_q ? q_in : (is_k ? k_in : v_in)) + (size_t)s * (is_q ? H : KV) * D + (size_t)head * D;
   auto load16 = [](const float* p, float (&d)[16]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -154,7 +187,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     }
   };
   // index input: the uint8 output indices of the fused q|k|v GEMM, dequantised as that linear's fp32 output would read
-  const uint8_t* isrc = a.qkv_idx ? a.qkv_idx + ((size_t)s * (H + 2 * KV) + part) * D : nullptr;
+  const uint8_t* isrc = idx_in ? idx_in + ((size_t)s * (H + 2 * KV) + part) * D : nullptr;
   const AGrid gin = a_load_grid(is_q ? a.q_in : (is_k ? a.k_in : a.v_in));
   auto load16_idx = [&](const uint8_t* p, float (&d)[16]) {
     const uint4 t = *reinterpret_cast<const uint4*>(p);
@@ -216,8 +249,8 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     // q: row-major [H][S][64].  k: FRAGMENT-BLOCKED per 64-key block (8 KiB = 8 fragments of 1 KiB): fragment 2 j + hf holds keys
     // 16 j .. + 15, lane l = (key & 15) + 16 tq at byte 16 l: the eight halves d = 16 tq + 8 hf .. + 7 -- one LDS-DMA instruction of
     // the attention kernel moves a fragment as 1 KiB of consecutive bytes into the layout its ds_read_b128 feeds the MFMA from.
-    uint16_t* hdst = is_q ? a.q_f16 : (is_k ? a.k_f16 : nullptr);
-    if (hdst != nullptr && a.q_f16 != nullptr && a.k_f16 != nullptr) {
+    uint16_t* hdst = is_q ? q_h : (is_k ? k_h : nullptr);
+    if (hdst != nullptr && q_h != nullptr && k_h != nullptr) {
       unsigned hw[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) hw[i] = pack_h2(__fsub_rn(qi[2 * i], g.o), __fsub_rn(qi[2 * i + 1], g.o));
@@ -233,7 +266,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
     }
   }
   if (is_q || is_k) {
-    int8_t* dst = (is_q ? a.q_i8 + ((size_t)head * S + s) * D : a.k_i8 + ((size_t)head * CS + P0 + s) * D) + col0;
+    int8_t* dst = (is_q ? q_img + ((size_t)head * S + s) * D : k_img + ((size_t)head * CS + P0 + s) * D) + col0;
     *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
     if (dc == D / 64 - 1) {
       int sum = (int)usum - 32 * D;                    // D / 4 bytes per thread, each stored + 128
@@ -242,8 +275,8 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
       // the zero-point terms of sum_d (qi - zq)(ki - zk) = sum qs ks - zq' rowsum(ks) - zk' rowsum(qs) + D zq' zk'  (primes: - 128)
       const int zq = (int)a_load_grid(a.qk_a).o - 128, zk = (int)a_load_grid(a.qk_b).o - 128;
       if (c == 0) {
-        if (is_q) a.q_rowsum[(size_t)head * S + s] = D * zq * zk - zk * sum;
-        else a.k_rowsum[(size_t)head * CS + P0 + s] = -zq * sum;
+        if (is_q) q_rs[(size_t)head * S + s] = D * zq * zk - zk * sum;
+        else k_rs[(size_t)head * CS + P0 + s] = -zq * sum;
       }
     }
   } else {
@@ -266,12 +299,12 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
       }
       o4[j] = pk;
     }
-    int8_t* dst = a.vt_i8 + (((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * D + 64 * dc + d) * 64 + 16 * c;
+    int8_t* dst = vt_img + (((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * D + 64 * dc + d) * 64 + 16 * c;
     *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     if constexpr (D > 64) {                            // column sums of the stored values over this block's 64 keys (prefix-summed below)
       csum += __shfl_xor(csum, 1, 64);
       csum += __shfl_xor(csum, 2, 64);
-      if (c == 0) a.v_prefix[((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * D + 64 * dc + d] = csum;
+      if (c == 0) v_pre[((size_t)head * (CS >> 6) + (P0 >> 6) + blockIdx.x) * D + 64 * dc + d] = csum;
       __syncthreads();                                 // s_v is rewritten by the next slab
     }
   }
@@ -283,7 +316,7 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
 __global__ void __launch_bounds__(256) attention_vprefix_kernel(int32_t* __restrict__ v_prefix, int first, int nblk, int head_blocks, int D) {
   const int d = blockIdx.y * 256 + threadIdx.x;
   if (d >= D) return;
-  int32_t* p = v_prefix + (size_t)blockIdx.x * head_blocks * D + d;
+  int32_t* p = v_prefix + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * head_blocks * D + d;   // [batch][kv_heads][blocks][D]
   int run = first > 0 ? p[(size_t)(first - 1) * D] : 0;   // blocks before `first` already hold their prefix sums (cache continuation)
   for (int kb0 = first; kb0 < first + nblk; kb0 += 32) {  // 32 independent loads in flight, then the scan in registers
     int v[32];
@@ -337,8 +370,9 @@ template <int D, bool QK_OUT, bool BIG = false, bool QPREP = false, bool F16 = f
 #define MQ_ATT_F16_WAVES 2   // waves per SIMD of the f16 form (the cache depths above must fit: 512 / WAVES registers, 160 KiB / WAVES of LDS per two... workgroups)
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)), F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)))))
-    attention_quant_kernel(const mq_attention_args a) {
+    attention_quant_kernel(const mq_attention_args a_in) {
   static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
+  const mq_attention_args a = batch_view(a_in, (int)blockIdx.z);
   static_assert(!F16 || (D == 64 && QK_OUT && BIG), "f16 score contraction: the production configuration only");
   using T_ = std::true_type;
   using F_ = std::false_type;
@@ -1216,13 +1250,16 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
                "mq_attention_quant: the int8 output image needs an 8-bit pv_out grid that fits int8 after out_shift, out_rowsum, "
                "0 < seq_real <= seq");
   }
+  MQ_REQUIRE(a.batch >= 0 && a.batch <= 65535 && (a.batch <= 1 || a.cache_seq == 0),
+             "mq_attention_quant: batch = %d (0 / 1: one sequence; > 1 only without cache continuation)", a.batch);
   hipStream_t st = as_stream(stream);
-  const dim3 pgrid((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads)), cgrid((unsigned)(a.seq / 64 * a.heads));
+  const unsigned nb = a.batch > 1 ? (unsigned)a.batch : 1u;
+  const dim3 pgrid((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads), nb), cgrid((unsigned)(a.seq / 64 * a.heads), 1, nb);
   if (a.head_dim == 64) {
     const bool big = g_att_cache.load() != 1;
     // production configuration (16-bit score grid, deep cache, full rotary): the core kernel prepares its own q rows
     const bool qprep = big && a.qk_out.scale != nullptr && (a.rot_dim == 0 || a.rot_dim == 64) && g_att_qprep.load() != 0;
-    if (qprep) attention_prep_kernel<64><<<dim3(pgrid.x, (unsigned)(2 * a.kv_heads)), 256, 0, st>>>(a, a.heads);
+    if (qprep) attention_prep_kernel<64><<<dim3(pgrid.x, (unsigned)(2 * a.kv_heads), nb), 256, 0, st>>>(a, a.heads);
     else attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a, 0);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
     const bool f16 = a.q_f16 != nullptr;
@@ -1236,7 +1273,7 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
     if (a.head_dim == 128) attention_prep_kernel<128><<<pgrid, 256, 0, st>>>(a, 0);
     else attention_prep_kernel<256><<<pgrid, 256, 0, st>>>(a, 0);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
-    attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1), 256, 0, st>>>(a.v_prefix, a.cache_seq > 0 ? a.pos0 / 64 : 0, a.seq / 64,
+    attention_vprefix_kernel<<<dim3((unsigned)a.kv_heads, 1, nb), 256, 0, st>>>(a.v_prefix, a.cache_seq > 0 ? a.pos0 / 64 : 0, a.seq / 64,
                                                                                (a.cache_seq > 0 ? a.cache_seq : a.seq) / 64, a.head_dim);
     MQ_LAUNCH_CHECK("mq_attention_quant(prefix)");
     if (a.head_dim == 128) {

@@ -212,9 +212,11 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
         idx = idx.view(B, S, -1)
         q = k = v = [None] * B
         qkv = [(idx[b], in_grids) for b in range(B)]
+        batched, batched_idx = (None, None, None), (idx, in_grids)
     else:
         q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
         qkv = [None] * B
+        batched, batched_idx = (q, k, v), None
     D = s.head_dim
     if cache is not None:
         cache[0][:, :, :S] = apply_rope(k.view(B, S, s.kv_heads, D).transpose(1, 2), cos, sin)
@@ -236,11 +238,18 @@ def _fused_attention_forward(self, x, cos, sin, mask, cache=None, pos: int = 0, 
             tiled = (not w4o and ops.gemm_tiled_supported(M, w_o.shape[0], K)) or resid_tiled
             q_i8 = torch.empty(((M + 15) // 16 * 16 if tiled else M, K), dtype=torch.int8, device=x.device)
             rs = torch.empty(M, dtype=torch.int32, device=x.device)
-            for b in range(B):
-                ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False,
-                                    qkv_idx=qkv[b], **akw[b])
+            if img is None and B > 1:                # the whole batch in one launch pair (sequence b owns image rows b * S ...)
+                ops.attention_quant(*batched, cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, 0, 128, tiled), want_out=False,
+                                    qkv_idx=batched_idx, head_dim=s.head_dim)
+            else:
+                for b in range(B):
+                    ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, image=(q_i8, rs, b * S, 128, tiled), want_out=False,
+                                        qkv_idx=qkv[b], **akw[b])
             return o_proj._int8_from_image(None, w_o, o_proj.bias, oq, q_i8, rs, 128, M if tiled else None, lead_shape=(B, S), resid=resid)
-    out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b], **akw[b]) for b in range(B)])
+    if img is None and B > 1:
+        out = ops.attention_quant(*batched, cos, sin, s.heads, s.kv_heads, grids, qkv_idx=batched_idx, head_dim=s.head_dim)
+    else:
+        out = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, s.heads, s.kv_heads, grids, qkv_idx=qkv[b], **akw[b]) for b in range(B)])
     if oq is not None and not oq.bypassed():
         Q._tag_grid(out, oq)
     out = o_proj(out)

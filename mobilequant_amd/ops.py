@@ -753,6 +753,8 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     image = (q_i8, row_sum [rows] int32, row0, shift, tiled): additionally (want_out=False: only) write the pv_out indices of this
     sequence as rows row0 .. row0+S-1 of the consumer linear's int8 input image: row-major [rows, heads*64], or (tiled) the
     fragment-blocked [ceil16(rows), heads*64] layout of quantize_tiled.
+    Batch: q / k / v [B, S, ...] (or qkv_idx [B, S, ...]) run as ONE launch pair (mq_attention_args.batch; not with a cache); the
+    result is [B, S, heads*64] and sequence b owns rows row0 + b * S of the image.
     cache = attention_image_cache(...) + pos0: cache continuation (chunked prefill).  The cache already holds positions 0 .. pos0 - 1
     from earlier calls (same grids); q / k / v / cos / sin describe positions pos0 .. pos0 + S - 1, which are appended and attend to
     everything before them.  pos0 % 64 == 0 (every chunk but the last is a multiple of 64 long)."""
@@ -767,16 +769,22 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     if qkv_idx is not None:       # (uint8 [S, (heads + 2 kv_heads) * 64] of int8_linear_segmented, ((scale, offset) x 3))
         idx, in_grids = qkv_idx
         idx = _dev(idx, "qkv_idx").contiguous()
-        S = idx.shape[0]
-        if idx.dtype != torch.uint8 or idx.shape != (S, (heads + 2 * kv_heads) * D) or cos.shape != (S, rot):
-            raise RuntimeError("mobilequant_amd: attention_quant qkv_idx must be uint8 [S, (H + 2 KV) * 64], cos / sin [S, 64]")
+        B = idx.shape[0] if idx.dim() == 3 else 0                    # 0: one sequence, 2-D tensors
+        S = idx.shape[-2]
+        if idx.dtype != torch.uint8 or idx.shape[-2:] != (S, (heads + 2 * kv_heads) * D) or idx.dim() not in (2, 3) or cos.shape != (S, rot):
+            raise RuntimeError("mobilequant_amd: attention_quant qkv_idx must be uint8 [(B,) S, (H + 2 KV) * 64], cos / sin [S, 64]")
         q = k = v = None
     else:
         q, k, v = (_dev(t, n).contiguous() for t, n in ((q, "q"), (k, "k"), (v, "v")))
-        S = q.shape[0]
-        if (q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or q.shape != (S, heads * D)
-                or k.shape != (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, rot)):
-            raise RuntimeError("mobilequant_amd: attention_quant needs fp32 q [S, H*64], k / v [S, KV*64], cos / sin [S, 64]")
+        B = q.shape[0] if q.dim() == 3 else 0
+        S = q.shape[-2]
+        lead = (B,) if B else ()
+        if (q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or q.shape != lead + (S, heads * D)
+                or k.shape != lead + (S, kv_heads * D) or v.shape != k.shape or cos.shape != (S, rot)):
+            raise RuntimeError("mobilequant_amd: attention_quant needs fp32 q [(B,) S, H*64], k / v [(B,) S, KV*64], cos / sin [S, 64]")
+    if B and cache is not None:
+        raise RuntimeError("mobilequant_amd: attention_quant serves a batch in one launch only without an image cache (one call per sequence there)")
+    nb = max(B, 1)
     S_real = S
     if S % 64:                    # pad the sequence: under the causal mask a padded key is only ever seen by padded queries
         pad = 64 - S % 64
@@ -804,9 +812,10 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
             sc, of = _f32(g[0], "scale"), _f32(g[1], "offset")
             keep += [sc, of]
             setattr(a, name, _lib.MqGrid(sc.data_ptr(), of.data_ptr(), 0.0, 255.0))
-    out = torch.empty(S, heads * D, dtype=torch.float32, device=dev) if want_out or image is None else None
-    q_i8 = torch.empty(heads * S * D, dtype=torch.int8, device=dev)
-    q_rs = torch.empty(heads * S, dtype=torch.int32, device=dev)
+    out = torch.empty(((B,) if B else ()) + (S, heads * D), dtype=torch.float32, device=dev) if want_out or image is None else None
+    q_i8 = torch.empty(nb * heads * S * D, dtype=torch.int8, device=dev)
+    q_rs = torch.empty(nb * heads * S, dtype=torch.int32, device=dev)
+    a.batch = B
     if cache is not None:
         if (cache["kv_heads"], cache["head_dim"]) != (kv_heads, D) or cache["k_i8"].device != dev:
             raise RuntimeError("mobilequant_amd: attention_quant cache was built for another shape / device")
@@ -819,14 +828,14 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     else:
         if pos0:
             raise RuntimeError("mobilequant_amd: attention_quant(pos0 > 0) needs a cache (attention_image_cache)")
-        k_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
-        vt_i8 = torch.empty(kv_heads * S * D, dtype=torch.int8, device=dev)
-        k_rs = torch.empty(kv_heads * S, dtype=torch.int32, device=dev)
-        v_pre = torch.empty(kv_heads * (S // 64) * D, dtype=torch.int32, device=dev) if D != 64 else None
-        k_f16 = torch.empty(kv_heads * S * D, dtype=torch.float16, device=dev) if D == 64 else None
+        k_i8 = torch.empty(nb * kv_heads * S * D, dtype=torch.int8, device=dev)
+        vt_i8 = torch.empty(nb * kv_heads * S * D, dtype=torch.int8, device=dev)
+        k_rs = torch.empty(nb * kv_heads * S, dtype=torch.int32, device=dev)
+        v_pre = torch.empty(nb * kv_heads * (S // 64) * D, dtype=torch.int32, device=dev) if D != 64 else None
+        k_f16 = torch.empty(nb * kv_heads * S * D, dtype=torch.float16, device=dev) if D == 64 else None
     if k_f16 is not None and grids.get("qk_out") is not None:
         # head_dim 64 with a score grid: fp16 images of the centred q / k indices -> the f16 score contraction (mq_attention_args.q_f16)
-        q_f16 = torch.empty(heads * S * D, dtype=torch.float16, device=dev)
+        q_f16 = torch.empty(nb * heads * S * D, dtype=torch.float16, device=dev)
         keep += [q_f16, k_f16]
         a.q_f16, a.k_f16 = q_f16.data_ptr(), k_f16.data_ptr()
     if v_pre is not None:
@@ -842,9 +851,9 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
     a.seq_real = S_real
     if image is not None:
         q_t, rs_t, row0, shift, tiled = image
-        need = (row0 + S_real + 15) // 16 * 16 if tiled else row0 + S_real
+        need = (row0 + nb * S_real + 15) // 16 * 16 if tiled else row0 + nb * S_real
         if (q_t.dtype != torch.int8 or rs_t.dtype != torch.int32 or not q_t.is_contiguous() or q_t.shape[-1] != heads * D
-                or row0 < 0 or row0 + S_real > rs_t.numel() or need > q_t.shape[0]):
+                or row0 < 0 or row0 + nb * S_real > rs_t.numel() or need > q_t.shape[0]):
             raise RuntimeError("mobilequant_amd: attention_quant image must be int8 [rows (tiled: ceil16), heads*64] + int32 row sums [rows]")
         keep += [q_t, rs_t]
         a.out_i8, a.out_rowsum, a.out_row0, a.out_shift, a.out_i8_tiled = q_t.data_ptr(), rs_t.data_ptr(), int(row0), int(shift), int(bool(tiled))
@@ -852,4 +861,4 @@ def attention_quant(q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Opt
         _lib.call("mq_attention_quant", ctypes.byref(a), _stream())
     if out is None:
         return None
-    return out if S_real == S else out[:S_real].contiguous()
+    return out if S_real == S else out[..., :S_real, :].contiguous()

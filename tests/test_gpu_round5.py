@@ -498,3 +498,64 @@ def test_attention_f16_score_contraction_is_the_int8_one_bit_for_bit(dev, S, hea
             L.load().mq_attention_set_f16(1)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,S,heads,kv_heads,D,rot", [(3, 192, 4, 2, 64, 64), (2, 100, 2, 1, 64, 64), (2, 130, 4, 4, 64, 16), (2, 128, 2, 1, 256, 256), (3, 70, 2, 2, 128, 128)])
+def test_attention_batch_in_one_launch_equals_one_call_per_sequence(dev, B, S, heads, kv_heads, D, rot):
+    """mq_attention_args.batch: B sequences in ONE prep + core launch pair (grid z = sequence; inputs, outputs and scratch laid out
+    [B][...]) give, bit for bit, what B single-sequence calls give -- fp32 output, the int8 image for o_proj (sequence b on rows
+    b * S ...) and its row sums; ragged S (padded per sequence), partial rotary, head_dim 64 / 128 / 256, fp32 and index inputs."""
+    from mobilequant_amd import ops
+    from test_gpu_round2 import _grid_of
+    from test_gpu_round3 import _case
+    cases = [_case(S, heads, kv_heads, D, rot, seed=17 * b + S) for b in range(B)]
+    qk, pv = cases[0][5], cases[0][6]                                # one set of grids for the batch
+    grids = dict(qk_a=_grid_of(qk[0], dev), qk_b=_grid_of(qk[1], dev), qk_out=_grid_of(qk[2], dev), pv_a=_grid_of(pv[0], dev),
+                 pv_b=_grid_of(pv[1], dev), pv_out=_grid_of(pv[2], dev))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                       # noqa: E731
+    q, k, v = (torch.stack([t(c[i]) for c in cases]) for i in (0, 1, 2))
+    cos, sin = t(cases[0][3]), t(cases[0][4])
+    img1, rs1 = torch.zeros(B * S, heads * D, dtype=torch.int8, device=dev), torch.zeros(B * S, dtype=torch.int32, device=dev)
+    img2, rs2 = torch.zeros_like(img1), torch.zeros_like(rs1)
+    one = torch.stack([ops.attention_quant(q[b], k[b], v[b], cos, sin, heads, kv_heads, grids, image=(img1, rs1, b * S, 128, False), head_dim=D) for b in range(B)])
+    all_ = ops.attention_quant(q, k, v, cos, sin, heads, kv_heads, grids, image=(img2, rs2, 0, 128, False), head_dim=D)
+    torch.cuda.synchronize()
+    assert all_.shape == one.shape and torch.equal(all_, one) and torch.equal(img1, img2) and torch.equal(rs1, rs2)
+    # index input (the fused q|k|v GEMM's uint8 output) through the same two routes
+    g = torch.Generator(device="cpu").manual_seed(S)
+    idx = torch.randint(0, 256, (B, S, (heads + 2 * kv_heads) * D), dtype=torch.uint8, generator=g).to(dev)
+    ig = tuple((torch.tensor([0.05], device=dev), torch.tensor([float(z)], device=dev)) for z in (128.0, 120.0, 131.0))
+    one = torch.stack([ops.attention_quant(None, None, None, cos, sin, heads, kv_heads, grids, qkv_idx=(idx[b], ig), head_dim=D) for b in range(B)])
+    all_ = ops.attention_quant(None, None, None, cos, sin, heads, kv_heads, grids, qkv_idx=(idx, ig), head_dim=D)
+    torch.cuda.synchronize()
+    assert torch.equal(all_, one)
+
+
+def test_fused_model_forward_of_a_batch_is_the_forward_of_each_sequence(dev):
+    """The fused decoder layer on ids [3, 160]: the attention of the whole batch is ONE launch pair (no per-sequence Python loop), the
+    linears see 3 x 160 rows; every row's quantized computation is the same as in a forward of its sequence alone (2-layer W8A8 model
+    of decode_case.npz; ragged S: 160 = 2.5 key blocks)."""
+    import dataclasses
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd import llama, ops
+    m, z = _decode_model(dev)
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=256))
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(3, m.shape.vocab, (3, 160), generator=g).to(dev)
+    calls = []
+    real = ops.attention_quant
+    ops.attention_quant = lambda *a, **k: (calls.append(a[0].dim() if a[0] is not None else k["qkv_idx"][0].dim()), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            assert llama.fuse_decoder_layer(m) == 2
+            whole = m(ids)
+            n_batched = len(calls)
+            each = torch.cat([m(ids[b:b + 1]) for b in range(3)])
+    finally:
+        ops.attention_quant = real
+    torch.cuda.synchronize()
+    assert n_batched == 2 and calls[:2] == [3, 3]                  # one call per layer, 3-D (batched) input
+    # (the fp32 lm_head is a library GEMM whose kernel -- and summation order -- depends on the row count: equal up to that; one
+    # flipped 8-bit index anywhere upstream would move a logit by ~1e-2)
+    assert float((whole - each).abs().max()) <= 1e-4
