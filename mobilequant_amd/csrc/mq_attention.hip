@@ -421,13 +421,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // The ring is driven without conditionals: request j carries tile min(j, last) into stage j mod NST (past the end the last tile is
   // requested again into a stage nobody reads any more), so every wait is the same counted constant and no branch guards a request;
   // stage offsets are running scalars.  Per block that removes ~20 scalar / branch instructions of ~40 beside ~90 VALU.
-  if constexpr (F16 && MQ_ATT_ABL != 7 && MQ_ATT_ABL != 2) {         // the ring's first K requests go out in front of the q preparation
-#pragma unroll
-    for (int i = 0; i < NST - 1; ++i) {
-      const int t = i < PB + qb ? i : PB + qb;
-      lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
-    }
-  }
   v4i qf[NKS];
   v8h qh[2];                                                        // F16: this lane's 16 centred q indices as halves (d = 16 tq .. + 15)
   int qconst = 0;                                                   // D zq zk - zk * rowsum(q)
@@ -442,16 +435,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
       }
     };
-    if (a.qkv_idx) {                                                // the fused q|k|v GEMM's uint8 indices, dequantised as that linear's fp32 output would read
-      const AGrid gin = a_load_grid(a.q_in);
+    uint4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+    if (a.qkv_idx) {                                                // the fused q|k|v GEMM's uint8 indices
       const uint8_t* ip = a.qkv_idx + ((size_t)s_abs * (H + 2 * KV) + h) * D;
-      const uint4 t0 = *reinterpret_cast<const uint4*>(ip + col0), t1 = *reinterpret_cast<const uint4*>(ip + colp);
-      const unsigned w0[4] = {t0.x, t0.y, t0.z, t0.w}, w1[4] = {t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        x[i] = __fmul_rn(__fsub_rn((float)((w0[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
-        pr[i] = __fmul_rn(__fsub_rn((float)((w1[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
-      }
+      t0 = *reinterpret_cast<const uint4*>(ip + col0);
+      t1 = *reinterpret_cast<const uint4*>(ip + colp);
     } else {
       const float* src = a.q + (size_t)s_abs * H * D + (size_t)h * D;
       load16(src + col0, x);
@@ -459,6 +447,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     }
     load16(a.cos + (size_t)s_abs * D + col0, cs);
     load16(a.sin + (size_t)s_abs * D + col0, sn);
+    // the ring's first K requests: behind the q LOADS (an asm request fences the compiler's loads), in front of the q arithmetic
+    if constexpr (F16 && MQ_ATT_ABL != 7 && MQ_ATT_ABL != 2) {
+#pragma unroll
+      for (int i = 0; i < NST - 1; ++i) {
+        const int t = i < PB + qb ? i : PB + qb;
+        lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+      }
+    }
+    if (a.qkv_idx) {                                                // ... dequantised as that linear's fp32 output would read
+      const AGrid gin = a_load_grid(a.q_in);
+      const unsigned w0[4] = {t0.x, t0.y, t0.z, t0.w}, w1[4] = {t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = __fmul_rn(__fsub_rn((float)((w0[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
+        pr[i] = __fmul_rn(__fsub_rn((float)((w1[i >> 2] >> (8 * (i & 3))) & 0xffu), gin.o), gin.s);
+      }
+    }
     const float sign = col0 < D / 2 ? -1.f : 1.f;
     uint32_t usum = 0;
     unsigned hw[8];
@@ -491,6 +496,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     const v4i* qp = reinterpret_cast<const v4i*>(reinterpret_cast<const _Float16*>(a.q_f16) + ((size_t)h * S + (size_t)qb * 64 + wave * 16 + srow) * D + tq * 16);
     qh[0] = __builtin_bit_cast(v8h, qp[0]);
     qh[1] = __builtin_bit_cast(v8h, qp[1]);
+  if constexpr (F16 && MQ_ATT_ABL != 7 && MQ_ATT_ABL != 2) {         // the ring's first K requests: behind the q LOADS (an asm request is a fence for the compiler's loads), in front of the q arithmetic
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) {
+      const int t = i < PB + qb ? i : PB + qb;
+      lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+    }
+  }
   } else {
     const int8_t* qbase = a.q_i8 + ((size_t)h * S + (size_t)qb * 64 + wave * 16) * D;
 #pragma unroll
