@@ -49,7 +49,7 @@ int mq_quantize_tiled_set_staged(int on);
 /* mq_attention_quant at head_dim 64: 1 = small exponential cache (two key blocks in the LDS, three waves per SIMD), anything else =
  * the deep cache (four blocks in the LDS + five in registers, two waves per SIMD; default).  Identical results. */
 int mq_attention_set_cache(int mode);
-/* mq_attention_quant at head_dim 64 (16-bit score grid, full rotary, deep cache): 1 (default) = every attention workgroup prepares its
+/* mq_attention_quant at head_dim 64 (16-bit score grid, full rotary or rot_dim 16, deep cache): 1 (default) = every attention workgroup prepares its
  * own 64 query rows (RoPE + input quantizer in registers: no q image, the prep launch covers k / v only), 0 = the prep kernel writes the
  * q image as for the other shapes (A/B timing; identical results). */
 int mq_attention_set_fused_q(int on);

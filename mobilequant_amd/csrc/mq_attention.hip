@@ -435,18 +435,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
       }
     };
+    // rot_dim 16 (StableLM-2: 16 of 64 dims rotate, hf_model.py:489-500): only the lanes of the first 16 dims rotate, and a dim's
+    // partner (d +- 8) lies among the lane's own 16 values -- no partner load, cos / sin [S, 16] read by those lanes only
+    const bool part16 = a.rot_dim == 16;
     uint4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
     if (a.qkv_idx) {                                                // the fused q|k|v GEMM's uint8 indices
       const uint8_t* ip = a.qkv_idx + ((size_t)s_abs * (H + 2 * KV) + h) * D;
       t0 = *reinterpret_cast<const uint4*>(ip + col0);
-      t1 = *reinterpret_cast<const uint4*>(ip + colp);
+      if (!part16) t1 = *reinterpret_cast<const uint4*>(ip + colp);
     } else {
       const float* src = a.q + (size_t)s_abs * H * D + (size_t)h * D;
       load16(src + col0, x);
-      load16(src + colp, pr);
+      if (!part16) load16(src + colp, pr);
     }
-    load16(a.cos + (size_t)s_abs * D + col0, cs);
-    load16(a.sin + (size_t)s_abs * D + col0, sn);
+    if (!part16) {
+      load16(a.cos + (size_t)s_abs * D + col0, cs);
+      load16(a.sin + (size_t)s_abs * D + col0, sn);
+    } else if (tq == 0) {
+      load16(a.cos + (size_t)s_abs * 16, cs);
+      load16(a.sin + (size_t)s_abs * 16, sn);
+    }
     // the ring's first K requests: behind the q LOADS (an asm request fences the compiler's loads), in front of the q arithmetic
     if constexpr (F16 && MQ_ATT_ABL != 7 && MQ_ATT_ABL != 2) {
 #pragma unroll
@@ -465,16 +473,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       }
     }
     const float sign = col0 < D / 2 ? -1.f : 1.f;
+    float ya[16];                                                   // the values the input quantizer sees
+    if (!part16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ya[i] = __fadd_rn(__fmul_rn(x[i], cs[i]), __fmul_rn(sign * pr[i], sn[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ya[i] = x[i];
+      if (tq == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)                                // x * cos + rot(x) * sin, rot(x)[d] = d < 8 ? -x[d + 8] : x[d - 8]
+          ya[i] = __fadd_rn(__fmul_rn(x[i], cs[i]), __fmul_rn((i < 8 ? -1.f : 1.f) * x[i < 8 ? i + 8 : i - 8], sn[i]));
+      }
+    }
     uint32_t usum = 0;
     unsigned hw[8];
 #pragma unroll
     for (int d4 = 0; d4 < 4; ++d4) {
-      float y[4], qi[4];
+      float qi[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        y[e] = __fadd_rn(__fmul_rn(x[4 * d4 + e], cs[4 * d4 + e]), __fmul_rn(sign * pr[4 * d4 + e], sn[4 * d4 + e]));
-        qi[e] = image_idxf(y[e], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax);
-      }
+      for (int e = 0; e < 4; ++e) qi[e] = image_idxf(ya[4 * d4 + e], gqa.s, gqa.inv_s, gqa.o, gqa.qmin, gqa.qmax);
       if constexpr (F16) {
         hw[2 * d4] = pack_h2(__fsub_rn(qi[0], gqa.o), __fsub_rn(qi[1], gqa.o));
         hw[2 * d4 + 1] = pack_h2(__fsub_rn(qi[2], gqa.o), __fsub_rn(qi[3], gqa.o));
@@ -1269,8 +1287,8 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
   const dim3 pgrid((unsigned)(a.seq / 64), (unsigned)(a.heads + 2 * a.kv_heads), nb), cgrid((unsigned)(a.seq / 64 * a.heads), 1, nb);
   if (a.head_dim == 64) {
     const bool big = g_att_cache.load() != 1;
-    // production configuration (16-bit score grid, deep cache, full rotary): the core kernel prepares its own q rows
-    const bool qprep = big && a.qk_out.scale != nullptr && (a.rot_dim == 0 || a.rot_dim == 64) && g_att_qprep.load() != 0;
+    // production configuration (16-bit score grid, deep cache, full rotary or StableLM-2's 16 rotating dims): the core kernel prepares its own q rows
+    const bool qprep = big && a.qk_out.scale != nullptr && (a.rot_dim == 0 || a.rot_dim == 64 || a.rot_dim == 16) && g_att_qprep.load() != 0;
     if (qprep) attention_prep_kernel<64><<<dim3(pgrid.x, (unsigned)(2 * a.kv_heads), nb), 256, 0, st>>>(a, a.heads);
     else attention_prep_kernel<64><<<pgrid, 256, 0, st>>>(a, 0);
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");

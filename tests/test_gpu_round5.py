@@ -498,6 +498,16 @@ def test_attention_f16_score_contraction_is_the_int8_one_bit_for_bit(dev, S, hea
             L.load().mq_attention_set_f16(1)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+    if chunks == 1:        # ... and the q rows prepared inside the attention workgroups (full rotary, and rot_dim 16) == the prep kernel's q image
+        L.load().mq_attention_set_fused_q(0)
+        try:
+            img = torch.zeros(S, heads * 64, dtype=torch.int8, device=dev)
+            rs = torch.zeros(S, dtype=torch.int32, device=dev)
+            out = ops.attention_quant(t(q), t(k), t(v), t(cos), t(sin), heads, kv_heads, grids, image=(img, rs, 0, 128, False))
+            torch.cuda.synchronize()
+        finally:
+            L.load().mq_attention_set_fused_q(1)
+        assert torch.equal(out, outs[1][0]) and torch.equal(img, outs[1][1]) and torch.equal(rs, outs[1][2])
 
 
 @pytest.mark.parametrize("B,S,heads,kv_heads,D,rot", [(3, 192, 4, 2, 64, 64), (2, 100, 2, 1, 64, 64), (2, 130, 4, 4, 64, 16), (2, 128, 2, 1, 256, 256), (3, 70, 2, 2, 128, 128)])
