@@ -230,14 +230,17 @@ __global__ void __launch_bounds__(256) rmsnorm_quant_kernel(const NormArgs a) {
 // row groups (256 threads each, the arithmetic of rmsnorm_quant_kernel<V, LN, 256> op for op) owns EIGHT rows, two per group, all
 // loads issued up front; the int8 results go to an LDS staging tile in the image's order and leave as 128-byte runs (8 rows x 16 B
 // = whole cache lines of a fragment block).
-template <int V, bool LN>
-__global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int8_t stage[];   // [cols / 16 pieces][8 rows][16 B]
-  __shared__ float s_red[2][3][4][4];                               // [row of the pair][statistic][group][wave]
-  __shared__ int s_redi[2][4][4];
+// GRPS: row groups per workgroup (4: eight rows, 1024 threads, one workgroup per CU; 2: four rows, 512 threads, TWO per CU whose load /
+// arithmetic / store phases overlap -- mq_norm_tiled_set_rows).
+template <int V, bool LN, int GRPS = 4>
+__global__ void __launch_bounds__(256 * GRPS) norm_tiled8_kernel(const NormArgs a) {
+  constexpr int RW = 2 * GRPS;                                      // rows per workgroup
+  extern __shared__ __attribute__((aligned(16))) int8_t stage[];   // [cols / 16 pieces][RW rows][16 B]
+  __shared__ float s_red[2][3][GRPS][4];                            // [row of the pair][statistic][group][wave]
+  __shared__ int s_redi[2][GRPS][4];
   const int grp = threadIdx.x >> 8, lane = threadIdx.x & 255, wv_id = (threadIdx.x >> 6) & 3;
   const int cols = a.cols, nvec = cols >> 2;
-  const int64_t row0 = (int64_t)blockIdx.x * 8;
+  const int64_t row0 = (int64_t)blockIdx.x * RW;
   const float4* wv = reinterpret_cast<const float4*>(a.weight);
   const float4* bv = reinterpret_cast<const float4*>(a.bias);
   const bool has_in = a.in_scale != nullptr;
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
         const v2f u01 = image_u8f2(y01, so, iso, oo, a.out_qmin, a.out_qmax, ubias), u23 = image_u8f2(y23, so, iso, oo, a.out_qmin, a.out_qmax, ubias);
         const uint32_t pk = image_pack4(u01.x, u01.y, u23.x, u23.y, usum);
         // staging: piece (k >> 4) = 16-byte chunk column, then the row of the eight, then the byte:  k = 4 i
-        *reinterpret_cast<unsigned*>(stage + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
+        *reinterpret_cast<unsigned*>(stage + (i >> 2) * (RW * 16) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
       }
     }
     if (a.row_sum) {
@@ -363,16 +366,16 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
     }
   }
   __syncthreads();                                                  // the staging tile and the row-sum partials are complete
-  if (a.row_sum && threadIdx.x < 8) {
+  if (a.row_sum && threadIdx.x < RW) {
     const int g = threadIdx.x >> 1, j = threadIdx.x & 1;
     if (row0 + threadIdx.x < a.rows) a.row_sum[row0 + threadIdx.x] = (s_redi[j][g][0] + s_redi[j][g][1]) + (s_redi[j][g][2] + s_redi[j][g][3]) - 128 * cols;
   }
   // copy-out: 16-byte unit p = 8 piece + row;  piece = 4 kb + kq  ->  block (row0 >> 4, kb), byte 256 kq + 16 ((row0 & 15) + row)
-  const int units = cols >> 1;                                      // 8 rows x cols / 16
+  const int units = (cols >> 4) * RW;                               // RW rows x cols / 16
   const int64_t rb = row0 >> 4;
   const int half = (int)(row0 & 15);
-  for (int p = threadIdx.x; p < units; p += 1024) {
-    const int piece = p >> 3, r8 = p & 7;
+  for (int p = threadIdx.x; p < units; p += 256 * GRPS) {
+    const int piece = p / RW, r8 = p % RW;
     if (row0 + r8 < a.rows)
       *reinterpret_cast<uint4*>(a.q_tiled + ((rb * (cols >> 6) + (piece >> 2)) << 10) + ((piece & 3) << 8) + ((half + r8) << 4)) =
           *reinterpret_cast<const uint4*>(stage + (p << 4));
@@ -382,6 +385,14 @@ __global__ void __launch_bounds__(1024) norm_tiled8_kernel(const NormArgs a) {
 }  // namespace mq
 
 using namespace mq;
+
+// rows per workgroup of the image-only tiled norm: 0 = by shape (four rows -- two 512-thread workgroups per CU, whose load / arithmetic /
+// store phases overlap -- up to 2048 columns: 6.9 -> 6.2 us at [2048, 2048]; eight beyond, where it is a wash), 4 / 8 force one (A/B timing)
+static std::atomic<int> g_norm_tiled_rows{0};
+extern "C" int mq_norm_tiled_set_rows(int rows) {
+  g_norm_tiled_rows = rows == 4 ? 4 : (rows == 8 ? 8 : 0);
+  return 0;
+}
 
 static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias,
                        float eps, const float* in_scale, const float* in_offset, float in_qmin, float in_qmax,
@@ -407,11 +418,16 @@ static int launch_norm(const char* fn, bool ln, const float* x, int64_t rows, in
   hipStream_t st = as_stream(stream);
   // image-only, fragment-blocked: eight rows per workgroup, stores as whole lines of the image (norm_tiled8_kernel)
   if (q_tiled && !y && !q_out && out_scale && cols >= 1024 && cols <= 4096 && cols % 64 == 0 && rows >= 64) {
-    const unsigned grid = (unsigned)((rows + 7) / 8);
-    const size_t lds = (size_t)cols * 8;
+    const int rows_knob = g_norm_tiled_rows.load();
+    const bool four = rows_knob == 4 || (rows_knob == 0 && cols <= 2048);
+    const unsigned grid = four ? (unsigned)((rows + 3) / 4) : (unsigned)((rows + 7) / 8);
+    const size_t lds = (size_t)cols * (four ? 4 : 8);
 #define MQ_NORM8(V)                                                                   \
     do {                                                                              \
-      if (ln) norm_tiled8_kernel<V, true><<<grid, 1024, lds, st>>>(a);                \
+      if (four) {                                                                     \
+        if (ln) norm_tiled8_kernel<V, true, 2><<<grid, 512, lds, st>>>(a);            \
+        else norm_tiled8_kernel<V, false, 2><<<grid, 512, lds, st>>>(a);              \
+      } else if (ln) norm_tiled8_kernel<V, true><<<grid, 1024, lds, st>>>(a);         \
       else norm_tiled8_kernel<V, false><<<grid, 1024, lds, st>>>(a);                  \
     } while (0)
     if (cols <= 1024) MQ_NORM8(1);

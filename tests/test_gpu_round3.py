@@ -621,12 +621,18 @@ def test_image_only_tiled_norm_is_the_rowmajor_image_in_the_fragment_blocked_lay
     gi = (torch.tensor([10.0 / 65535], device=dev), torch.tensor([32768.0], device=dev), 0.0, 65535.0)
     go = (torch.tensor([8.0 / 255], device=dev), torch.tensor([128.0], device=dev), 0.0, 255.0)
     _, q, rs, shift, _ = ops.rmsnorm_quant(x, w, b, 1e-5, gi, go, emit_int8=True, layernorm=layernorm, emit_tiled=False, want_y=False, emit_rowmajor=True)
-    _, _, rst, shift_t, qt = ops.rmsnorm_quant(x, w, b, 1e-5, gi, go, emit_int8=True, layernorm=layernorm, emit_tiled=True, want_y=False, emit_rowmajor=False)
-    torch.cuda.synchronize()
-    assert shift == shift_t and torch.equal(rs, rst)
-    Mp = (rows + 15) // 16 * 16
-    back = qt.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
-    assert torch.equal(back, q.view(rows, cols))
+    import mobilequant_amd._lib as L
+    for knob in (0, 4, 8):                     # rows per workgroup: by shape (default) / four (two 512-thread workgroups per CU) / eight
+        L.load().mq_norm_tiled_set_rows(knob)
+        try:
+            _, _, rst, shift_t, qt = ops.rmsnorm_quant(x, w, b, 1e-5, gi, go, emit_int8=True, layernorm=layernorm, emit_tiled=True, want_y=False, emit_rowmajor=False)
+            torch.cuda.synchronize()
+        finally:
+            L.load().mq_norm_tiled_set_rows(0)
+        assert shift == shift_t and torch.equal(rs, rst)
+        Mp = (rows + 15) // 16 * 16
+        back = qt.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
+        assert torch.equal(back, q.view(rows, cols))
 
 
 @pytest.mark.parametrize("rows,cols", [(2048, 2048), (100, 2048), (333, 1024), (64, 4096), (2048, 3072)])
