@@ -46,6 +46,9 @@ int mq_gemm_set_segmented_tile(int cols);
 /* mq_quantize_tiled: 1 (default) = the LDS-staged eight-row kernel where it applies (fp32, 1024 <= cols <= 4096), 0 = the
  * lane-per-fragment kernel for every shape (A/B timing; identical images). */
 int mq_quantize_tiled_set_staged(int on);
+/* the staged kernel's rows per workgroup: 0 (default) = by shape (4 up to 2048 columns: two 512-thread workgroups per CU, 8 beyond),
+ * 4 / 8 = forced (A/B timing; identical images). */
+int mq_quantize_tiled_set_rows(int rows);
 /* image-only tiled norm (mq_rmsnorm_quant / mq_layernorm_quant with only q_tiled): rows per workgroup -- 0 (default) = by shape (4 up to
  * 2048 columns, 8 beyond), 8 = 1024 threads, one workgroup per CU, 4 = 512 threads, two per CU whose load / arithmetic / store phases
  * overlap.  Identical images. */

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "mq_quantize_tiled_set_staged": (c_int, [c_int]),
     "mq_attention_set_cache": (c_int, [c_int]),
     "mq_norm_tiled_set_rows": (c_int, [c_int]),
+    "mq_quantize_tiled_set_rows": (c_int, [c_int]),
     "mq_attention_set_fused_q": (c_int, [c_int]),
     "mq_attention_set_f16": (c_int, [c_int]),
     "mq_w4a8_linear_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),

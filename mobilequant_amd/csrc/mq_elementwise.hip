@@ -1024,15 +1024,18 @@ static int launch_quantize(const T* x, QT* q, int64_t rows, int64_t cols, const 
 // fp32 rows of 1024 .. 4096 columns: loads along the rows (a wave reads 1 KiB runs), the int8 results staged in an LDS tile in the
 // image's order, stores as 128-byte runs (8 rows x 16 B: whole lines of a fragment block).  1024 threads = four groups of 256, two
 // rows each, every load in flight before the first conversion.  Same index arithmetic as quantize_tiled_kernel: identical images.
-template <int V, bool HAS_SUM>
-__global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __restrict__ x, int8_t* __restrict__ q, int64_t rows, int64_t cols,
+// GRPS = 2: four rows per 512-thread workgroup, TWO workgroups per CU -- one's loads fly while the other converts and stores
+// (mq_quantize_tiled_set_rows; the same change as in mq_norm.hip's norm_tiled8_kernel).
+template <int V, bool HAS_SUM, int GRPS = 4>
+__global__ void __launch_bounds__(256 * GRPS) quantize_tiled8_kernel(const float* __restrict__ x, int8_t* __restrict__ q, int64_t rows, int64_t cols,
                                                                const float* __restrict__ scale, const float* __restrict__ offset, float qmin,
                                                                float qmax, int shift, int32_t* __restrict__ row_sum) {
-  extern __shared__ __attribute__((aligned(16))) int8_t stage8[];   // [cols / 16 pieces][8 rows][16 B]
-  __shared__ int s_part[8][4];
+  constexpr int RW = 2 * GRPS;                                      // rows per workgroup
+  extern __shared__ __attribute__((aligned(16))) int8_t stage8[];   // [cols / 16 pieces][RW rows][16 B]
+  __shared__ int s_part[RW][4];
   const int grp = threadIdx.x >> 8, lane = threadIdx.x & 255, wv_id = (threadIdx.x >> 6) & 3;
   const int nvec = (int)(cols >> 2);
-  const int64_t row0 = (int64_t)blockIdx.x * 8;
+  const int64_t row0 = (int64_t)blockIdx.x * RW;
   const float s = scale[0], o = offset[0];
   const float inv_s = __fdiv_rn(1.0f, s);
   const float ubias = (float)(128 - shift);               // image_u8f / image_pack4 (mq_common.h)
@@ -1055,7 +1058,7 @@ __global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __re
         // two elements per VALU instruction where a packed form exists (mq_common.h image_u8f2: the same bits)
         const v2f u01 = image_u8f2((v2f){f.x, f.y}, s, inv_s, o, qmin, qmax, ubias), u23 = image_u8f2((v2f){f.z, f.w}, s, inv_s, o, qmin, qmax, ubias);
         const uint32_t pk = image_pack4(u01.x, u01.y, u23.x, u23.y, usum);
-        *reinterpret_cast<uint32_t*>(stage8 + ((i >> 2) << 7) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
+        *reinterpret_cast<uint32_t*>(stage8 + (i >> 2) * (RW * 16) + ((grp * 2 + j) << 4) + ((i & 3) << 2)) = pk;
       }
     }
     if (HAS_SUM) {
@@ -1064,13 +1067,13 @@ __global__ void __launch_bounds__(1024) quantize_tiled8_kernel(const float* __re
     }
   }
   __syncthreads();
-  if (HAS_SUM && threadIdx.x < 8 && row0 + threadIdx.x < rows)
+  if (HAS_SUM && threadIdx.x < RW && row0 + threadIdx.x < rows)
     row_sum[row0 + threadIdx.x] = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]) - 128 * (int)cols;
-  const int units = (int)(cols >> 1);                               // 8 rows x cols / 16 sixteen-byte units
+  const int units = (int)(cols >> 4) * RW;                          // RW rows x cols / 16 sixteen-byte units
   const int64_t rb = row0 >> 4;
   const int half = (int)(row0 & 15);
-  for (int p = threadIdx.x; p < units; p += 1024) {                 // rows past `rows` are padding of the image: written like the others
-    const int piece = p >> 3, r8 = p & 7;
+  for (int p = threadIdx.x; p < units; p += 256 * GRPS) {           // rows past `rows` are padding of the image: written like the others
+    const int piece = p / RW, r8 = p % RW;
     *reinterpret_cast<uint4*>(q + ((rb * (cols >> 6) + (piece >> 2)) << 10) + ((piece & 3) << 8) + ((half + r8) << 4)) =
         *reinterpret_cast<const uint4*>(stage8 + (p << 4));
   }
@@ -1313,6 +1316,11 @@ int mq_quantize(const void* x, int dtype, int64_t rows, int64_t cols, const floa
   return MQ_EUNSUPPORTED;
 }
 
+static std::atomic<int> g_tiled8_rows{0};       // tuning hook: rows per workgroup of the staged kernel: 0 = by shape (4 up to 2048 columns), 4 / 8 forced
+extern "C" int mq_quantize_tiled_set_rows(int rows) {
+  g_tiled8_rows = rows == 4 ? 4 : (rows == 8 ? 8 : 0);
+  return 0;
+}
 static std::atomic<int> g_tiled8{1};            // tuning hook: 0 = the lane-per-fragment kernel for every shape
 int mq_quantize_tiled_set_staged(int on) {
   g_tiled8 = on ? 1 : 0;
@@ -1343,11 +1351,16 @@ int mq_quantize_tiled(const void* x, int dtype, int64_t rows, int64_t cols, cons
     if (row_sum) quantize_tiled_kernel<float, true, 0, true><<<grid, 512, 0, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum, chan_scale);
     else quantize_tiled_kernel<float, false, 0, true><<<grid, 512, 0, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum, chan_scale);
   } else if (dtype == MQ_F32 && cols >= 1024 && cols <= 4096 && cols % 1024 == 0 && rows >= 64 && g_tiled8.load()) {
-    const unsigned grid8 = (unsigned)(((rows + 15) / 16) * 2);
-    const size_t lds = (size_t)cols * 8;
+    const int rows_knob = g_tiled8_rows.load();
+    const bool four = rows_knob == 4 || (rows_knob == 0 && cols <= 2048);
+    const unsigned grid8 = (unsigned)(((rows + 15) / 16) * (four ? 4 : 2));
+    const size_t lds = (size_t)cols * (four ? 4 : 8);
 #define MQ_QT8(V)                                                                                                                              \
   do {                                                                                                                                         \
-    if (row_sum) quantize_tiled8_kernel<V, true><<<grid8, 1024, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);  \
+    if (four) {                                                                                                                                \
+      if (row_sum) quantize_tiled8_kernel<V, true, 2><<<grid8, 512, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);  \
+      else quantize_tiled8_kernel<V, false, 2><<<grid8, 512, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);        \
+    } else if (row_sum) quantize_tiled8_kernel<V, true><<<grid8, 1024, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);  \
     else quantize_tiled8_kernel<V, false><<<grid8, 1024, lds, st>>>((const float*)x, q_tiled, rows, cols, scale, offset, qmin, qmax, shift, row_sum);        \
   } while (0)
     if (cols == 1024) MQ_QT8(1);

@@ -649,12 +649,17 @@ def test_staged_quantize_tiled_writes_the_same_image(dev, rows, cols):
         q0, rs0 = ops.quantize_tiled(x, sc, of, 0.0, 255.0, 128)
     finally:
         L.load().mq_quantize_tiled_set_staged(1)
-    q1, rs1 = ops.quantize_tiled(x, sc, of, 0.0, 255.0, 128)
-    torch.cuda.synchronize()
-    assert torch.equal(rs0, rs1)
     Mp = q0.shape[0]
     un = lambda q: q.view(Mp // 16, cols // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]      # noqa: E731
-    assert torch.equal(un(q0), un(q1))
+    for knob in (0, 4, 8):                     # rows per workgroup of the staged kernel: by shape (default) / four / eight
+        L.load().mq_quantize_tiled_set_rows(knob)
+        try:
+            q1, rs1 = ops.quantize_tiled(x, sc, of, 0.0, 255.0, 128)
+            torch.cuda.synchronize()
+        finally:
+            L.load().mq_quantize_tiled_set_rows(0)
+        assert torch.equal(rs0, rs1)
+        assert torch.equal(un(q0), un(q1))
 
 
 @pytest.mark.parametrize("signed", [False, True])
