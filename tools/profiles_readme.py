@@ -56,6 +56,7 @@ LOG_CAPTIONS = {
     "attention_f16_ab.log": "`tools/att_f16_ab.py` (and with `MQ_ATT_ROT=16 MQ_ATT_KV=32`, the StableLM shape): the prefill attention at head_dim 64 with its scores contracted as int8 MFMA + zero-point terms against fp16 MFMA over the centred indices (`mq_attention_set_f16`): identical fp32 output / int8 image / row sums, and the time of each (prep + core, one hipGraph)",
     "attention_stamps.log": "`tools/att_stamps.py` on the `-DMQ_ATT_STAMPS` build: `s_memtime` differences accumulated per wave of the f16 attention kernel -- q preparation, the waits / fragment + DMA issue / chain + MFMAs of sweep 1, waits and the rest of sweep 2, epilogue (the stamps themselves cost ~10 %)",
     "valu_rate_probe.log": "`tools/valu_rate_probe.cpp`: cycles per wave-instruction of the chain's VALU instructions (fma / pk_fma / exp / med3 / add / pk_add and the chain's mix), one and two waves per SIMD",
+    "fuzz_round3.log": "`python tests/fuzz_round3.py 120` on the final tree: random shapes / grids -- generated 128-column GEMMs == the C++ tiles, `mq_attention_quant` at head_dim 64 / 128 / 256 against the oracle, chunked == single shot, in-kernel q rows == the prep kernel's image, fp16 score contraction == the int8 one, staged image kernels == the generic ones",
     "attention_whatif.log": "`tools/att_ablate.sh` over `MQ_ATT_ABL` builds (wrong results, same box): the attention op without sweep 2 / sweep 1 / v_exp / barrier / K fragment reads / DMA requests, and with plain loads in place of the DMA pieces",
 }
 for _v in ("0", "1"):
