@@ -62,6 +62,9 @@ int mq_attention_set_cache(int mode);
 int mq_attention_set_fused_q(int on);
 /* 0 = int8 score contraction even when mq_attention_args carries the fp16 images (A/B timing); default 1 */
 int mq_attention_set_f16(int on);
+/* 1 = two heads of a KV group per eight-wave workgroup over one copy of the K / vT tiles (f16 form with in-kernel q rows, even heads per
+ * KV group); default 0.  Identical results, measured slower: built only with -DMQ_BUILD_EXPERIMENTS, otherwise the call returns 1. */
+int mq_attention_set_pair(int on);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "mq_quantize_tiled_set_rows": (c_int, [c_int]),
     "mq_attention_set_fused_q": (c_int, [c_int]),
     "mq_attention_set_f16": (c_int, [c_int]),
+    "mq_attention_set_pair": (c_int, [c_int]),
     "mq_w4a8_linear_segmented": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, POINTER(c_int64), POINTER(MqGrid), _P, _P]),
     "mq_gated_table": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, c_float, c_float, _P, _P, c_float, c_float, c_int, _P, _P]),
     "mq_gated_lookup": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P]),

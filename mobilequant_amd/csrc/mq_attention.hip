@@ -365,15 +365,19 @@ __device__ __forceinline__ float fast_exp2(float x) {
 // indices (prep kernel / QPREP).  sum_d (qi - zq)(ki - zk) < 2^24 is exact in the fp32 accumulator and arrives as a float: the
 // zero-point terms (an add per score), the int -> float conversion (one per score) and the accumulator initialisation (C = 0 is an
 // inline constant) leave the VALU stream, which is what bounds this kernel; the matrix pipe has the room for twice the MFMAs.
-template <int D, bool QK_OUT, bool BIG = false, bool QPREP = false, bool F16 = false>
+// PAIR (with F16): a workgroup of EIGHT waves serves two heads of one KV group (waves 0-3 the even head's 64 query rows, waves 4-7 the odd
+// head's) over ONE copy of every K / vT tile: half the DMA requests per wave (they cost a wave ~130 cycles each), a third parked block
+// (one workgroup of 132 KiB per CU instead of two of 68).  mq_attention_set_pair.
+template <int D, bool QK_OUT, bool BIG = false, bool QPREP = false, bool F16 = false, bool PAIR = false>
 #ifndef MQ_ATT_F16_WAVES
 #define MQ_ATT_F16_WAVES 2   // waves per SIMD of the f16 form (the cache depths above must fit: 512 / WAVES registers, 160 KiB / WAVES of LDS per two... workgroups)
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)), F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)))))
+__global__ void __launch_bounds__(PAIR ? 512 : 256) __attribute__((amdgpu_waves_per_eu(F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)), F16 ? MQ_ATT_F16_WAVES : (D == 256 ? 1 : (D == 64 && !BIG ? 3 : 2)))))
     attention_quant_kernel(const mq_attention_args a_in) {
   static_assert(D == 64 || D == 128 || D == 256, "head_dim 64, 128 or 256");
   const mq_attention_args a = batch_view(a_in, (int)blockIdx.z);
   static_assert(!F16 || (D == 64 && QK_OUT && BIG), "f16 score contraction: the production configuration only");
+  static_assert(!PAIR || F16, "two heads per workgroup: the f16 form");
   using T_ = std::true_type;
   using F_ = std::false_type;
 #ifdef MQ_ATT_STAMPS
@@ -396,9 +400,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // up, so the ids run over ALL heads of the longest query block first, then the next block, ...: a longest-first list schedule.
   // With 2 resident workgroups per CU and H * S/64 = 2 * (2 * 256) of them, slots pair up (S/64 - i) with (i + 1): even finish.
   // (Per-head ordering instead measured 138 us vs the 74 us of perfectly packed wave cycles: the last heads' long blocks started late.)
-  const int h = (int)blockIdx.x % H, kvh = h / (H / KV);
-  const int qb = S / 64 - 1 - (int)blockIdx.x / H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0 .. 3 (PAIR: 0 .. 7)
+  const int wave = PAIR ? wave_s & 3 : wave_s;                      // the 16-row group of the row block this wave serves
+  const int h = PAIR ? 2 * ((int)blockIdx.x % (H / 2)) + (wave_s >> 2) : (int)blockIdx.x % H, kvh = h / (H / KV);
+  const int qb = S / 64 - 1 - (int)blockIdx.x / (PAIR ? H / 2 : H);
   const int srow = lane & 15, tq = lane >> 4;
   const int s_abs = qb * 64 + wave * 16 + srow;                     // this lane's query row
   const AGrid gqa = a_load_grid(a.qk_a), gqb = a_load_grid(a.qk_b), gqo = a_load_grid(a.qk_out);
@@ -416,8 +422,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   constexpr int NST = F16 ? MQ_ATT_F16_STAGES : 2;                  // ring stages of the F16 form (the D != 64 form: two buffers)
   __shared__ __attribute__((aligned(16))) char s_tile[NST][kTileBytes];
   const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_tile[0][0];
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const char* khbase = F16 ? reinterpret_cast<const char*>(a.k_f16) + (size_t)kvh * CS * D * 2 : nullptr;   // fragment-blocked halves, 8 KiB per key block
+  // this wave's pieces of tile t into the stage at byte offset `off`: K = 8 pieces (two per wave; PAIR: one), vT = 4 (one per wave; PAIR:
+  // waves 0-3)
+  constexpr int kKPieces = PAIR ? 1 : 2;
+  const int v_mine = PAIR ? (wave_s < 4 ? 1 : 0) : 1;
+  auto req_k = [&](int t, unsigned off) {
+    if constexpr (F16 && MQ_ATT_ABL != 7) {
+      if constexpr (PAIR) lds_dma16(khbase + (size_t)t * 8192 + wave_s * 1024, (unsigned)(lane * 16), tile_lds + off + wave_s * 1024);
+      else lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + off + wave_s * 2048);
+    }
+  };
+  auto req_v = [&](int t, unsigned off) {
+    if constexpr (F16 && MQ_ATT_ABL != 7) {
+      if (!PAIR || wave_s < 4)
+        lds_dma16(a.vt_i8 + ((size_t)kvh * (CS >> 6) + t) * D * 64 + wave_s * 1024, (unsigned)(srow * 64 + tq * 16), tile_lds + off + kKBytes + wave_s * 1024);
+    }
+  };
   // The ring is driven without conditionals: request j carries tile min(j, last) into stage j mod NST (past the end the last tile is
   // requested again into a stage nobody reads any more), so every wait is the same counted constant and no branch guards a request;
   // stage offsets are running scalars.  Per block that removes ~20 scalar / branch instructions of ~40 beside ~90 VALU.
@@ -460,7 +481,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
 #pragma unroll
       for (int i = 0; i < NST - 1; ++i) {
         const int t = i < PB + qb ? i : PB + qb;
-        lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+        req_k(t, i * kTileBytes);
       }
     }
     if (a.qkv_idx) {                                                // ... dequantised as that linear's fp32 output would read
@@ -518,7 +539,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i) {
       const int t = i < PB + qb ? i : PB + qb;
-      lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, (unsigned)(lane * 16), tile_lds + i * kTileBytes + wave_s * 2048);
+      req_k(t, i * kTileBytes);
     }
   }
   } else {
@@ -619,8 +640,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   const unsigned voff_k = lane * 16, voff_v = srow * 64 + tq * 16;
   auto dma_f16 = [&](int kb, int buf, bool with_k, bool with_v) {
     if constexpr (F16 && MQ_ATT_ABL != 7) {
-      if (with_v) lds_dma16(a.vt_i8 + ((size_t)kvh * (CS >> 6) + kb) * D * 64 + wave_s * 1024, voff_v, tile_lds + buf * kTileBytes + kKBytes + wave_s * 1024);
-      if (with_k) lds_dma16x2(khbase + (size_t)kb * 8192 + wave_s * 2048, voff_k, tile_lds + buf * kTileBytes + wave_s * 2048);
+      if (with_v) req_v(kb, buf * kTileBytes);
+      if (with_k) req_k(kb, buf * kTileBytes);
     }
   };
   // block kb's pieces have landed for every wave once each wave has at most `pending` later DMA instructions in flight (they return
@@ -710,8 +731,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   // With the grid top as reference exponent the sweep-1 exponentials ARE the sweep-2 ones (no rescale in between): those of a row
   // block's LAST kEC key blocks are parked in the LDS (a thread reads back only what it wrote: no barrier), and sweep 2 takes them from
   // there instead of recomputing scores, grid and exp2 -- ~70 % of a block's sweep-2 instructions for min(kEC, nkb) / nkb of the blocks.
-  constexpr int kEC = D == 64 ? (F16 ? MQ_ATT_ECACHE_F16 : (BIG ? MQ_ATT_ECACHE : 2)) : 0;
-  __shared__ float4 s_e[kEC > 0 ? kEC : 1][4][kEC > 0 ? 256 : 1];     // [block][quad of keys][thread]: whole-dword-quad rows, ds_*_b128 without bank conflicts
+  constexpr int kEC = D == 64 ? (F16 ? (PAIR ? 3 : MQ_ATT_ECACHE_F16) : (BIG ? MQ_ATT_ECACHE : 2)) : 0;
+  static_assert(!PAIR || NST == 3, "two heads per workgroup: a three-stage ring");
+  __shared__ float4 s_e[kEC > 0 ? kEC : 1][4][kEC > 0 ? (PAIR ? 512 : 256) : 1];     // [block][quad of keys][thread]: whole-dword-quad rows, ds_*_b128 without bank conflicts
   constexpr int kER = D == 64 && BIG ? (F16 ? MQ_ATT_EREGS_F16 : MQ_ATT_EREGS) : 0;   // ... and those of the kER blocks in front of them in registers
   const int n_lds0 = nkb - kEC > 0 ? nkb - kEC : 0;                 // first block parked in the LDS
   const int n_reg0 = n_lds0 - kER > 0 ? n_lds0 - kER : 0;           // first block parked in registers (blocks before it are recomputed)
@@ -753,7 +775,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
   } else if constexpr (F16) {
     auto next_scores = [&](int kb, float (&ti)[16]) {              // (the form with a running row maximum: guarded requests, counted per block)
       const int ahead = nkb - 1 - kb < NST - 2 ? nkb - 1 - kb : NST - 2;
-      wait_dma(2 * ahead);
+      wait_dma(kKPieces * ahead);
       if (kb + NST - 1 < nkb) dma_f16(kb + NST - 1, (kb + NST - 1) % NST, true, false);
       f_scores_lds(kb % NST, ti);
     };
@@ -769,7 +791,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
       int req = NST - 1 < nkb - 1 ? NST - 1 : nkb - 1;               // the tile the next request carries
       auto fetch = [&]() {                                           // the next block has landed -> its fragments requested, the next DMA request issued
         MQ_ST(2);
-        ring_wait(std::integral_constant<int, 2>{});
+        ring_wait(std::integral_constant<int, kKPieces>{});
         MQ_ST(1);
         const unsigned tb = tile_lds + rd_off + lane * 16;
 #if MQ_ATT_ABL == 6
@@ -779,7 +801,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
         lds_read_frag<0>(fr[0], tb); lds_read_frag<1024>(fr[1], tb); lds_read_frag<2048>(fr[2], tb); lds_read_frag<3072>(fr[3], tb);
         lds_read_frag<4096>(fr[4], tb); lds_read_frag<5120>(fr[5], tb); lds_read_frag<6144>(fr[6], tb); lds_read_frag<7168>(fr[7], tb);
 #endif
-        if constexpr (MQ_ATT_ABL != 7) lds_dma16x2(khbase + (size_t)req * 8192 + wave_s * 2048, voff_k, tile_lds + wr_off + wave_s * 2048);
+        req_k(req, wr_off);
         ring_step(rd_off);
         ring_step(wr_off);
         req = req + 1 < nkb - 1 ? req + 1 : nkb - 1;
@@ -987,8 +1009,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     // the ring as in sweep 1: request j = tile min(j, last), its vT piece and -- for a recomputed tile -- its two K pieces
     auto request = [&](int t, unsigned off) {
       if constexpr (MQ_ATT_ABL != 7) {
-        lds_dma16(a.vt_i8 + ((size_t)kvh * (CS >> 6) + t) * D * 64 + wave_s * 1024, voff_v, tile_lds + off + kKBytes + wave_s * 1024);
-        if (t < nrec) lds_dma16x2(khbase + (size_t)t * 8192 + wave_s * 2048, voff_k, tile_lds + off + wave_s * 2048);
+        req_v(t, off);
+        if (t < nrec) req_k(t, off);
       }
     };
 #pragma unroll
@@ -1001,7 +1023,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F16 ? 
     v4i vf[4], kf[8];
     auto next_block = [&](auto rec, auto pieces) {                   // -> vf (and kf) hold the next block's fragments
       MQ_ST(5);
-      ring_wait(pieces);
+      if constexpr (PAIR) wait_dma(v_mine + (decltype(pieces)::value == 3 ? 1 : 0));   // the next tile's pieces of THIS wave (NST == 3)
+      else ring_wait(pieces);
       MQ_ST(4);
       const unsigned tb = tile_lds + rd_off + lane * 16;
       lds_read_frag<kKBytes>(vf[0], tb); lds_read_frag<kKBytes + 1024>(vf[1], tb); lds_read_frag<kKBytes + 2048>(vf[2], tb); lds_read_frag<kKBytes + 3072>(vf[3], tb);
@@ -1241,6 +1264,19 @@ extern "C" int mq_attention_set_cache(int mode) {
   return 0;
 }
 
+// Two heads of a KV group per eight-wave workgroup (PAIR): identical results, measured SLOWER (70-73 against 66-69 us: one workgroup per
+// CU in lock step at its barriers, 512 instead of 1 024 workgroups to balance) -- built only with -DMQ_BUILD_EXPERIMENTS
+// (python -m mobilequant_amd.build --experiments); the production library answers the knob with 1 (= not built).
+static std::atomic<int> g_att_pair{0};
+extern "C" int mq_attention_set_pair(int on) {
+#ifdef MQ_BUILD_EXPERIMENTS
+  g_att_pair = on ? 1 : 0;
+  return 0;
+#else
+  (void)on;
+  return 1;
+#endif
+}
 static std::atomic<int> g_att_f16{1};         // tuning hook: 0 = int8 score contraction even when the fp16 images are supplied (A/B timing)
 extern "C" int mq_attention_set_f16(int on) {
   g_att_f16 = on ? 1 : 0;
@@ -1294,6 +1330,10 @@ extern "C" int mq_attention_quant(const mq_attention_args* args, mq_stream_t str
     MQ_LAUNCH_CHECK("mq_attention_quant(prep)");
     const bool f16 = a.q_f16 != nullptr;
     if (a.qk_out.scale == nullptr) attention_quant_kernel<64, false><<<cgrid, 256, 0, st>>>(a);
+#ifdef MQ_BUILD_EXPERIMENTS
+    else if (qprep && f16 && g_att_pair.load() != 0 && a.heads % 2 == 0 && (a.heads / a.kv_heads) % 2 == 0)
+      attention_quant_kernel<64, true, true, true, true, true><<<dim3(cgrid.x / 2, 1, nb), 512, 0, st>>>(a);
+#endif
     else if (qprep && f16) attention_quant_kernel<64, true, true, true, true><<<cgrid, 256, 0, st>>>(a);
     else if (f16) attention_quant_kernel<64, true, true, false, true><<<cgrid, 256, 0, st>>>(a);
     else if (qprep) attention_quant_kernel<64, true, true, true><<<cgrid, 256, 0, st>>>(a);

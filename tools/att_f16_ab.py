@@ -57,6 +57,8 @@ def run(f16):
     return out, img, rs, sorted(ts)[len(ts) // 2]
 
 
+if "MQ_ATT_PAIR" in os.environ:            # 1 = two heads of a KV group per eight-wave workgroup (the f16 form)
+    lib.mq_attention_set_pair(int(os.environ["MQ_ATT_PAIR"]))
 o0, i0, r0, t0 = run(0)
 o1, i1, r1, t1 = run(1)
 o0b, i0b, r0b, t0b = run(0)
