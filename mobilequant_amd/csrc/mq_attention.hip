@@ -103,6 +103,17 @@ __device__ __forceinline__ void lds_read_frag(v4i& dst, unsigned addr) {
 __device__ __forceinline__ void lds_fragments_wait(v4i (&f)[8]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
 }
+template <int BASE, int... I>
+__device__ __forceinline__ void lds_read_frags(v4i* dst, unsigned addr, std::integer_sequence<int, I...>) {
+  (lds_read_frag<BASE + I * 1024>(dst[I], addr), ...);
+}
+__device__ __forceinline__ void lds_fragments_wait(v4i (&f)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+}
+__device__ __forceinline__ void lds_fragments_wait(v4i (&f)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]),
+               "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
+}
 __device__ __forceinline__ void tie16(float (&x)[16]) {   // an ordering point for the sixteen values (no instruction)
   asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]),
                "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
@@ -596,16 +607,26 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) __attribute__((amdgpu_waves_
     }
   };
   auto block_ready = []() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // (one wave per SIMD at head_dim 256: a compiler-placed ds_read in front of every MFMA cost an LDS round trip each -- 19 / 27
+  // s_waitcnt per block.  All 4 NKS fragments of the block are requested at once by asm reads the compiler does not wait for, ONE
+  // counted wait names them.)
   auto int_scores_lds = [&](int kb, int buf, int (&ti)[16]) {
-    const char* tb = s_tile[buf] + lane * 16;
+    constexpr int NF = 4 * NKS;
+    v4i kf[NF];
+    if constexpr (D != 64) lds_read_frags<0>(kf, tile_lds + buf * kTileBytes + lane * 16, std::make_integer_sequence<int, NF>{});
+    int4 kt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kt[j] = *reinterpret_cast<const int4*>(s_tile[buf] + 2 * kKBytes + (16 * j + 4 * tq) * 4);
+    if constexpr (NF == 16 || NF == 8) {
+      if constexpr (NF == 16) lds_fragments_wait(kf);
+      else lds_fragments_wait(reinterpret_cast<v4i(&)[8]>(kf));
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int4 kt = *reinterpret_cast<const int4*>(s_tile[buf] + 2 * kKBytes + (16 * j + 4 * tq) * 4);
       v4i acc = cinit;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i*>(tb + (NKS * j + ks) * 1024), qf[ks], acc, 0, 0, 0);
-      ti[4 * j] = acc[0] + kt.x; ti[4 * j + 1] = acc[1] + kt.y; ti[4 * j + 2] = acc[2] + kt.z; ti[4 * j + 3] = acc[3] + kt.w;
+      for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[NKS * j + ks], qf[ks], acc, 0, 0, 0);
+      ti[4 * j] = acc[0] + kt[j].x; ti[4 * j + 1] = acc[1] + kt[j].y; ti[4 * j + 2] = acc[2] + kt[j].z; ti[4 * j + 3] = acc[3] + kt[j].w;
     }
   };
   // integer scores of this lane's row against keys t = 64 kb + 16 j + 4 tq + e: sum_d (qi - zq)(ki - zk), exact (< 2^24).  After this
@@ -1176,12 +1197,25 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) __attribute__((amdgpu_waves_
       v4i pf_hi, pf_lo;
       if (kb == kdiag) probs(ti, kb, pf_hi, pf_lo, T_{}, T_{});
       else probs(ti, kb, pf_hi, pf_lo, F_{}, T_{});
-      const char* vb = s_tile[kb & 1] + kKBytes + lane * 16;
+      // p.v: the vT fragments four at a time by asm reads, the next four requested in front of this batch's eight MFMAs
+      const unsigned vb = tile_lds + (kb & 1) * kTileBytes + kKBytes + lane * 16;
+      v4i vfa[4], vfb[4];
+      lds_read_frags<0>(vfa, vb, std::make_integer_sequence<int, 4>{});
+      auto pv_batch = [&](auto G, v4i (&cur)[4], v4i (&nxt)[4]) {
+        constexpr int g = decltype(G)::value;
+        lds_fragments_wait(cur);
+        if constexpr (4 * (g + 1) < NDT) lds_read_frags<4096 * (g + 1)>(nxt, vb, std::make_integer_sequence<int, 4>{});
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const v4i vf = *reinterpret_cast<const v4i*>(vb + dt * 1024);
-        acc_hi[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_hi, acc_hi[dt], 0, 0, 0);
-        acc_lo[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf_lo, acc_lo[dt], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          acc_hi[4 * g + i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur[i], pf_hi, acc_hi[4 * g + i], 0, 0, 0);
+          acc_lo[4 * g + i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur[i], pf_lo, acc_lo[4 * g + i], 0, 0, 0);
+        }
+      };
+      pv_batch(std::integral_constant<int, 0>{}, vfa, vfb);
+      pv_batch(std::integral_constant<int, 1>{}, vfb, vfa);
+      if constexpr (NDT > 8) {
+        pv_batch(std::integral_constant<int, 2>{}, vfa, vfb);
+        pv_batch(std::integral_constant<int, 3>{}, vfb, vfa);
       }
     }
   }
