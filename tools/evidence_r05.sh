@@ -35,7 +35,7 @@ python -c "from mobilequant_amd import build; build.build(force=True, tag='stamp
 MQ_LIB_PATH=mobilequant_amd/lib/stamps/libmobilequant_amd.so LAYERS=6 CONTEXT=256 WBITS=8 timeout 300 python tools/decode_stamps.py > $OUT/decode_stamps_w8.log 2>&1
 ls -la $OUT
 # 5. the prefill attention (round 5: f16 score contraction): A/B against the int8 form, counter passes, in-kernel stamps, VALU issue rates
-bash tools/build_r04_attention.sh > /dev/null 2>&1
+bash tools/build_r04_attention.sh > /dev/null 2>&1   # (a no-op on the GPU box: build it before gpurun)
 for shape in "MQ_ATT_ROT=64 MQ_ATT_KV=4" "MQ_ATT_ROT=16 MQ_ATT_KV=32"; do
   echo "== the round-4 kernel (lib/r04att: both columns time it)" >> $OUT/attention_f16_ab.log
   env $shape MQ_LIB_PATH=mobilequant_amd/lib/r04att/libmobilequant_amd.so python tools/att_f16_ab.py 2>&1 | grep -v amdgpu.ids | head -1 >> $OUT/attention_f16_ab.log
