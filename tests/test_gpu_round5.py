@@ -569,3 +569,22 @@ def test_fused_model_forward_of_a_batch_is_the_forward_of_each_sequence(dev):
     # (the fp32 lm_head is a library GEMM whose kernel -- and summation order -- depends on the row count: equal up to that; one
     # flipped 8-bit index anywhere upstream would move a logit by ~1e-2)
     assert float((whole - each).abs().max()) <= 1e-4
+
+
+def test_last_logits_only_is_the_last_row_of_the_full_forward(dev):
+    """LlamaForCausalLM.forward(last_logits_only=True) -- what DecodeEngine.prefill runs -- computes final norm + lm_head on the last
+    position only: the same decoder stack, so its logits are the full forward's last row up to the library GEMM's summation order."""
+    import dataclasses
+    from test_gpu_round2 import _decode_model
+    from mobilequant_amd import llama
+    m, z = _decode_model(dev)
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=256))
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    ids = torch.randint(3, m.shape.vocab, (2, 130), generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.no_grad():
+        assert llama.fuse_decoder_layer(m) == 2
+        full = m(ids)
+        last = m(ids, last_logits_only=True)
+    torch.cuda.synchronize()
+    assert last.shape == (2, 1, m.shape.vocab)
+    assert float((last[:, 0] - full[:, -1]).abs().max()) <= 1e-4
