@@ -823,8 +823,8 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) __attribute__((amdgpu_waves_
         lds_read_frag<4096>(fr[4], tb); lds_read_frag<5120>(fr[5], tb); lds_read_frag<6144>(fr[6], tb); lds_read_frag<7168>(fr[7], tb);
 #endif
         req_k(req, wr_off);
+        wr_off = rd_off;                                             // (the stage just read is the one after next to fill: wr = rd + (NST - 1) stages)
         ring_step(rd_off);
-        ring_step(wr_off);
         req = req + 1 < nkb - 1 ? req + 1 : nkb - 1;
         MQ_ST(9);
       };
@@ -1053,9 +1053,10 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) __attribute__((amdgpu_waves_
         lds_read_frag<0>(kf[0], tb); lds_read_frag<1024>(kf[1], tb); lds_read_frag<2048>(kf[2], tb); lds_read_frag<3072>(kf[3], tb);
         lds_read_frag<4096>(kf[4], tb); lds_read_frag<5120>(kf[5], tb); lds_read_frag<6144>(kf[6], tb); lds_read_frag<7168>(kf[7], tb);
       }
-      request(req, wr_off);
+      if constexpr (decltype(rec)::value) request(req, wr_off);
+      else if constexpr (MQ_ATT_ABL != 7) req_v(req, wr_off);        // behind the recomputed tiles every request is a vT piece only
+      wr_off = rd_off;
       ring_step(rd_off);
-      ring_step(wr_off);
       req = req + 1 < nkb - 1 ? req + 1 : nkb - 1;
       if constexpr (decltype(rec)::value) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]),
