@@ -7,7 +7,8 @@ import test_gpu_round2 as T
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 bad = 0
-for it in range(60):
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+for it in range(n_cases):
     S = int(rng.integers(2, 420))
     heads = int(rng.choice([1, 2, 4, 8]))
     kv = int(rng.choice([h for h in (1, 2, 4, 8) if heads % h == 0]))
@@ -30,4 +31,5 @@ for it in range(60):
     if not ok or (pvb == 8 and frac > 0.02):
         bad += 1
         print("BAD", it, S, heads, kv, qkb, pvb, d.max(), step, span, frac)
-print("cases 60 bad", bad)
+print("cases", n_cases, "bad", bad)
+sys.exit(1 if bad else 0)

@@ -15,7 +15,8 @@ from mobilequant_amd._lib import MQ_F32, MQ_I8, MQ_U8  # noqa: E402
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(1)
 bad = 0
-for it in range(40):
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for it in range(n_cases):
     M = int(rng.choice([9, 33, 200, 777, 2048, 4096]))
     K = int(rng.choice([128, 256, 1024, 2048]))
     Ns = [int(rng.choice([4, 36, 64, 128, 256, 1000, 2048])) for _ in range(int(rng.integers(1, 4)))]
@@ -54,4 +55,5 @@ for it in range(40):
     if not torch.equal(got, torch.cat(singles, dim=1)):
         bad += 1
         print("BAD segmented", it, M, K, Ns)
-print("cases 40 bad", bad)
+print("cases", n_cases, "bad", bad)
+sys.exit(1 if bad else 0)

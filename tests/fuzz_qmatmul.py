@@ -34,3 +34,4 @@ for it in range(n_cases):
         bad += 1
         print("BAD", it, lead, M, N, K, kt, (b1, s1), (b2, s2), bo, int(neq.sum()), "of", neq.size, np.abs(got - want).max(), flush=True)
 print("cases", n_cases, "bad", bad)
+sys.exit(1 if bad else 0)

@@ -108,12 +108,20 @@ def test_quantized_perplexity_within_0_05_of_the_reference_at_22_layers(dev, tag
     for name, (nll, arg, sub) in res.items():
         d = np.abs(sub - ref_lg) / span
         ppl = float(np.exp(nll.mean()))
+        per_seq = np.exp(nll.mean(axis=1)) - np.exp(ref_nll.mean(axis=1))          # one number per 255-position sequence
+        worst = int(np.argmax(np.abs(per_seq)))
         report[name] = dict(ppl=round(ppl, 5), dppl=round(ppl - ref_ppl, 5), dppl_first_sequence=round(float(np.exp(nll[0].mean()) - np.exp(ref_nll[0].mean())), 5),
+                            dppl_worst_sequence=round(float(per_seq[worst]), 5), worst_sequence=worst,
+                            dppl_per_sequence=[round(float(v), 4) for v in per_seq],
                             argmax=round(float((arg == ref_arg).mean()), 4), logit_max=round(float(d.max()), 5), logit_median=round(float(np.median(d)), 6))
     print(f"stable full depth [{tag}]: {ref_nll.size} predicted tokens; fp ppl {fp_ppl:.4f}, reference {tag} ppl {ref_ppl:.4f} (quantisation moves it by "
           f"{ref_ppl - fp_ppl:+.4f}), the reference's second run {self_ppl - ref_ppl:+.5f};", report)
     for name, r in report.items():
         assert abs(r["dppl"]) <= 0.05, (tag, name, r)
+        # the mean over eight sequences is the bar; a SINGLE 255-position sequence is also bounded (positions of one
+        # sequence are not independent samples -- a flipped cached key / value index moves every later position the same way -- so the
+        # per-sequence bound is wider: 0.12, stated; the worst sequence is printed above)
+        assert abs(r["dppl_worst_sequence"]) <= 0.12, (tag, name, r)
         assert r["argmax"] >= 0.99, (tag, name, r)
         assert r["logit_median"] <= 4e-3 and r["logit_max"] <= 3e-2, (tag, name, r)
 
