@@ -451,7 +451,7 @@ def cpu_baseline():
 
 
 def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", wsym=False, wpc=None, cache_len=1024, attn_splits=None,
-                      contexts=None, also_contexts=None):
+                      contexts=None, also_contexts=None, launches=4, long_from=None):
     """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
     model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
     one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
@@ -491,7 +491,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
             if "pv_bmm" in name:
                 mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    eng = DecodeEngine(model, cache_len=cache_len, attn_splits=attn_splits)
+    eng = DecodeEngine(model, cache_len=cache_len, attn_splits=attn_splits, launches=launches, long_from=long_from)
     for p in model.parameters():                            # the float weights of the decoder layers are no longer needed
         if p.dim() == 2 and p.shape[0] != shape.vocab:
             p.data = torch.empty(0, device=dev)
@@ -503,7 +503,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
         eng.step()
     torch.cuda.synchronize()
     def timed_at(ctx):
-        graph = eng.graph_long if eng.graph_long is not None and ctx >= eng.LONG_FROM else eng.graph      # what step() replays there
+        graph = eng.graph_long if eng.graph_long is not None and ctx >= eng._long_threshold() else eng.graph      # what step() replays there
         best = float("inf")
         for _ in range(3):
             eng.set_position(ctx)
@@ -529,7 +529,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
             "int8_weight_GB_per_token": round(eng.weight_bytes / 1e9, 4), "lm_head_fp32_GB_per_token": round(eng.head_bytes / 1e9, 4),
             "kv_cache_GB_per_token": round(kv_bytes / 1e9, 4), "achieved_GBps": round(total / t / 1e9, 1),
             "weight_stream_GBps": round(eng.weight_bytes / t / 1e9, 1), "peak_GBps": 8000.0, "frac_of_hbm_peak": round(total / t / 8e12, 4),
-            "kernels_per_token": len(eng.phases) + 2, "decode_tok_s_by_context": by_context,
+            "kernels_per_token": len(eng.phases) + 2, "launches_per_layer": eng.launches, "decode_tok_s_by_context": by_context,
             "scope": f"FULL decode step, {family} shape, W{wbits}A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, {shape.layers} x "
                      "[norm+qkv, attention over the static KV cache, o_proj+residual, norm+w1|w3+SiLU*mul+quantize, w2+residual], final "
                      "norm + fp32 lm_head; batch 1, one hipGraph per token"}

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 211 /* 0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
+#define MQ_VERSION 300 /* 0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -427,6 +427,21 @@ typedef struct mq_decode_gemv_args {
   const float* consts; /* REQUIRED: mq_decode_pack_grids of {norm_in, a_grid, out_grid[0..2], gate_mid, gate_actout, gate_out} into
                         * a 64-float, 16-byte aligned block (unused tail zero): the kernel reads every grid from this one cache line; the mq_grid pointers above only say
                         * which grids are present (scale != NULL) and carry qmin / qmax */
+  /* ---- round 6: four launches per layer.  Every field below may stay zero: the launch is then the one above. ----
+   * zero_acc (nullable): the launch also clears zero_n int32 accumulators (the o_proj sums of mq_decode_attention_oproj, which comes
+   * next in the chain). */
+  int32_t* zero_acc;
+  int zero_n;
+  /* o_proj's epilogue as the prologue of the NEXT linear (o_acc != NULL; needs norm_w and fp32 x, K <= 4096): the activation row is
+   * x[k] + Qo_out(o_alpha[k] * (o_acc[k] + o_ct[k]) + o_bias[k]) -- the residual add of the attention block on o_proj's integer sums
+   * left by mq_decode_attention_oproj (o_out: slot 8 of consts) -- and is also stored to x_mid (each workgroup a share), the
+   * residual input of the w2 launch. */
+  const int32_t* o_acc;
+  const float* o_alpha;
+  const int32_t* o_ct;
+  const float* o_bias;
+  mq_grid o_out;
+  float* x_mid;
 } mq_decode_gemv_args;
 int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream);
 /* How mq_decode_gemv spreads a launch's weight rows over its workgroups: workgroup b reads bytes [b, b + 1) * bytes_per_workgroup of
@@ -468,6 +483,39 @@ typedef struct mq_decode_attention_args {
   int prefetch_wgs, prefetch_delay;
 } mq_decode_attention_args;
 int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream);
+
+/* Round 6: the attention of one query token AND o_proj's contraction in one launch (hf_model.py:486-534 + the o_proj QLinear,
+ * qmodule.py:341-358).  Inputs, cache semantics, grids and arithmetic are mq_decode_attention's (qkv fp32, RoPE at *pos, cache append,
+ * exact integer qk / pv, quantizers in their divide form).  heads x slices workgroups: workgroup (h, c) computes head h's attention
+ * (every slice repeats it: at M = 1 the arithmetic is free, a launch boundary is not; the head's first slice appends to the cache), puts
+ * the head's output on o_proj's input grid (o_in) and adds ITS share of o_proj -- rows [c, c + 1) * N / slices of the K-slice
+ * [h D, (h + 1) D): o_w [heads][N][D] int8 (index - 128; one byte per weight also for 4-bit weights) -- to the int32 accumulators
+ * o_acc [N] with device-scope integer atomics (exact, order free): o_acc[n] += sum_d w[h][n][d] a8[h][d] - o_wzp[n] sum_d a8[h][d].
+ * o_proj's epilogue (col_term, alpha, bias, output quantizer, residual add) runs in the next launch's prologue
+ * (mq_decode_gemv_args.o_acc).  o_acc must be zero at launch (mq_decode_gemv_args.zero_acc).  consts: mq_decode_pack_grids of {qk_a,
+ * qk_b, qk_out, pv_a, pv_b, pv_out, o_in}.  out_q (nullable): the heads' int8 outputs (what mq_decode_attention writes), for tests.
+ * tpr: threads per o_proj row (1, 2 or 4; N / slices * tpr <= 256, head_dim / 16 / tpr <= 8 chunks per thread).  Prefetch rows as in
+ * mq_decode_attention. */
+typedef struct mq_decode_attention_oproj_args {
+  const float* qkv;
+  int8_t* k_cache;
+  int8_t* v_cache;
+  const float* cos;
+  const float* sin;
+  const int* pos;
+  int heads, kv_heads, head_dim, cache_len, rot_dim;
+  mq_grid qk_a, qk_b, qk_out, pv_a, pv_b, pv_out, o_in;
+  const float* consts;
+  const int8_t* o_w;
+  const int32_t* o_wzp;
+  int32_t* o_acc;
+  int N, slices, tpr;
+  int8_t* out_q;
+  const int8_t* prefetch;
+  int64_t prefetch_bytes_per_wg, prefetch_stride, prefetch_total;
+  int prefetch_wgs, prefetch_delay;
+} mq_decode_attention_oproj_args;
+int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_stream_t stream);
 
 /* Final norm (floating point: the surgery skips it, qmodule.py:843) fused in front of the fp32 lm_head stream: logits[v] = sum_k
  * w[v,k] * norm(x)[k] (+ bias[v]).  layernorm = 0: HFRMSNorm (norm_weight NULL = no norm, norm_bias unused); layernorm = 1:

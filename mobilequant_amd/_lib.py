@@ -33,7 +33,20 @@ class MqDecodeGemvArgs(ctypes.Structure):
                 ("eps", c_float), ("a_grid", MqGrid), ("w", c_void_p), ("alpha", c_void_p), ("w_zp", c_void_p),
                 ("col_term", c_void_p), ("bias", c_void_p), ("seg_end", c_int * 2), ("out_grid", MqGrid * 3),
                 ("resid", c_void_p), ("y", c_void_p), ("gate_act", c_int), ("gate_mid", MqGrid), ("gate_actout", MqGrid),
-                ("gate_out", MqGrid), ("gate_q", c_void_p), ("w4", c_int), ("consts", c_void_p)]
+                ("gate_out", MqGrid), ("gate_q", c_void_p), ("w4", c_int), ("consts", c_void_p),
+                # round 6 (MQ_VERSION 300): clears o_proj's accumulators; o_proj's epilogue as a prologue
+                ("zero_acc", c_void_p), ("zero_n", c_int), ("o_acc", c_void_p), ("o_alpha", c_void_p), ("o_ct", c_void_p),
+                ("o_bias", c_void_p), ("o_out", MqGrid), ("x_mid", c_void_p)]
+
+
+class MqDecodeAttentionOprojArgs(ctypes.Structure):
+    _fields_ = [("qkv", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("pos", c_void_p),
+                ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("cache_len", c_int), ("rot_dim", c_int),
+                ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
+                ("pv_b", MqGrid), ("pv_out", MqGrid), ("o_in", MqGrid), ("consts", c_void_p), ("o_w", c_void_p), ("o_wzp", c_void_p),
+                ("o_acc", c_void_p), ("N", c_int), ("slices", c_int), ("tpr", c_int), ("out_q", c_void_p), ("prefetch", c_void_p),
+                ("prefetch_bytes_per_wg", c_int64), ("prefetch_stride", c_int64), ("prefetch_total", c_int64), ("prefetch_wgs", c_int),
+                ("prefetch_delay", c_int)]
 
 
 class MqDecodeAttentionArgs(ctypes.Structure):
@@ -121,6 +134,7 @@ _SIGNATURES = {
     "mq_decode_gemv": (c_int, [POINTER(MqDecodeGemvArgs), _P]),
     "mq_decode_gemv_geometry": (c_int, [POINTER(MqDecodeGemvArgs), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
+    "mq_decode_attention_oproj": (c_int, [POINTER(MqDecodeAttentionOprojArgs), _P]),
     "mq_decode_head": (c_int, [_P, _P, _P, c_int, c_float, _P, _P, c_int64, c_int64, _P, _P]),
     "mq_attention_quant": (c_int, [POINTER(MqAttentionArgs), _P]),
     "mq_calib_attention_probs": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, _P]),
@@ -134,6 +148,7 @@ _SIGNATURES = {
     "mq_gemm_set_pair_mode": (c_int, [c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+HEADER_MAJOR = 3          # MQ_VERSION / 100 of the header the ctypes structs in this file mirror
 
 _lib = None
 
@@ -155,8 +170,11 @@ def load() -> ctypes.CDLL:
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype, fn.argtypes = res, args
-    if lib.mq_version() < 200:
-        raise MobileQuantLibraryError("libmobilequant_amd.so is older than this Python package")
+    # the argument structs above mirror include/mobilequant_amd.h of ONE major version (MQ_VERSION / 100): structs grow at their tails
+    # between majors, so a library of another major would read past (or short of) what this package passes
+    if lib.mq_version() // 100 != HEADER_MAJOR:
+        raise MobileQuantLibraryError(f"libmobilequant_amd.so reports version {lib.mq_version()}, this Python package is built against "
+                                      f"major {HEADER_MAJOR} (include/mobilequant_amd.h MQ_VERSION): rebuild with `python -m mobilequant_amd.build --force`")
     _lib = lib
     return lib
 

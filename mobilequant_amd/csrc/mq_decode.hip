@@ -140,7 +140,8 @@ __device__ __forceinline__ Grid const_grid(const float cv, const int k, const mq
   r.qmax = g.qmax;
   return r;
 }
-enum { CG_NORM_IN = 0, CG_A = 1, CG_OUT0 = 2, CG_OUT1 = 3, CG_OUT2 = 4, CG_GATE_MID = 5, CG_GATE_ACTOUT = 6, CG_GATE_OUT = 7, CG_COUNT = 8 };
+enum { CG_NORM_IN = 0, CG_A = 1, CG_OUT0 = 2, CG_OUT1 = 3, CG_OUT2 = 4, CG_GATE_MID = 5, CG_GATE_ACTOUT = 6, CG_GATE_OUT = 7, CG_COUNT = 8,
+       CG_O_OUT = 8, CG_COUNT_R6 = 9 };   // round 6: slot 8 = o_proj's output grid (OPRE prologue; zero when unused)
 
 __global__ void decode_pack_grids_kernel(const mq_decode_grid_pack p, float* __restrict__ out) {
   const int k = threadIdx.x;
@@ -172,9 +173,21 @@ __global__ void decode_pack_grids_kernel(const mq_decode_grid_pack p, float* __r
 enum { XM_NORM = 0, XM_F32 = 1, XM_I8 = 2, XM_LNORM = 3 };
 constexpr int DG_PRO = 8, DG_STR = DG_WAVES - DG_PRO, DG_XPRE = 4;      // 512 prologue threads x 4 float4 -> K <= 8192 (fp32)
 
-template <int XMODE, bool GATE, bool W4>
+// PAIR_GATE: two consecutive weight rows (w1 row i, w3 row i) -> the gated activation (above).
+// OPRE (round 6; the w1 | w3 stream): the activation row is not x but x + Qo(alpha (acc + ct) + bias): o_proj's epilogue and the
+//   residual add on the integer sums mq_decode_attention_oproj left in o_acc -- the o_proj launch is gone.  Each workgroup also stores
+//   a share of that row to x_mid (the residual input of the w2 launch).
+// zero_acc (round 6; the q | k | v stream): the launch clears the o_proj accumulators the NEXT launch adds into.
+// (Tried and dropped in round 6: RoPE + the QMatMul input quantizers + the cache append as this launch's epilogue on rotation-partner
+// row pairs -- bit-identical, but one row pair per LANE is a 250-instruction serial chain at the launch's tail: +0.9 us on the q | k | v
+// launch against 0.15 us of 64-wide arithmetic in the attention launch; profiles/r06/decode_stamps_L4_rope_epilogue.log.)
+enum { PAIR_NONE = 0, PAIR_GATE = 1 };
+
+template <int XMODE, int PAIR, bool W4, bool OPRE>
 __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode_gemv_args g, const int rows_per_wg, unsigned long long* stamps) {
   DG_STAMP(0);
+  constexpr bool GATE = PAIR == PAIR_GATE, PAIRED = PAIR != PAIR_NONE;
+  constexpr int XPRE = OPRE ? 2 : DG_XPRE;                         // OPRE holds four more vectors per element: K <= 4096 there
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [K] int8 activation image
   __shared__ float s_red[DG_PRO], s_red2[DG_PRO];
   __shared__ int s_redi[DG_PRO];
@@ -198,25 +211,60 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
     } else {
       const int nvec = K >> 2;
       constexpr bool ANYNORM = XMODE == XM_NORM || XMODE == XM_LNORM;
-      float4 xv[DG_XPRE], nw[DG_XPRE], nb[DG_XPRE];
+      float4 xv[XPRE], nw[XPRE], nb[XPRE];
+      typedef int v4i_t __attribute__((ext_vector_type(4)));
+      v4i_t oa[OPRE ? XPRE : 1], oc[OPRE ? XPRE : 1];
+      float4 oal[OPRE ? XPRE : 1], ob[OPRE ? XPRE : 1], hmid[OPRE ? XPRE : 1];
 #pragma unroll
-      for (int u = 0; u < DG_XPRE; ++u) {
+      for (int u = 0; u < XPRE; ++u) {
         if (u * DG_PRO * 64 < nvec) {                              // wave-uniform
           const int i = p + u * DG_PRO * 64;
-          xv[u] = reinterpret_cast<const float4*>(g.x)[i < nvec ? i : nvec - 1];
-          if constexpr (ANYNORM) nw[u] = reinterpret_cast<const float4*>(g.norm_w)[i < nvec ? i : nvec - 1];
+          const int ic = i < nvec ? i : nvec - 1;
+          xv[u] = reinterpret_cast<const float4*>(g.x)[ic];
+          if constexpr (OPRE) {
+            oa[u] = reinterpret_cast<const v4i_t*>(g.o_acc)[ic];
+            oal[u] = reinterpret_cast<const float4*>(g.o_alpha)[ic];
+            oc[u] = reinterpret_cast<const v4i_t*>(g.o_ct)[ic];
+            ob[u] = g.o_bias ? reinterpret_cast<const float4*>(g.o_bias)[ic] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          if constexpr (ANYNORM) nw[u] = reinterpret_cast<const float4*>(g.norm_w)[ic];
           if constexpr (XMODE == XM_LNORM)
-            nb[u] = g.norm_bias ? reinterpret_cast<const float4*>(g.norm_bias)[i < nvec ? i : nvec - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            nb[u] = g.norm_bias ? reinterpret_cast<const float4*>(g.norm_bias)[ic] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       DG_STAMP_ARRIVED(6, 0, xv[0].x);
       const Grid ag = const_grid(cv, CG_A, g.a_grid);            // (the constants were requested before the row: they are here)
+      if constexpr (OPRE) {
+        // o_proj's epilogue, op for op that of the RESID launch it replaces (one row per lane there, four elements per thread here):
+        // tt = sum - zp rs + ct (o_acc already holds sum - zp rs), e = float(tt) alpha + bias, Qo in the GEMV epilogues' reciprocal form,
+        // resid + (.)
+        const Grid oo = const_grid(cv, CG_O_OUT, g.o_out);
+        auto oq1 = [&](float x0, int acc, int ct, float al, float bi) {
+          const int tt = (int)((unsigned)acc + (unsigned)ct);
+          float f = __fadd_rn(__fmul_rn((float)tt, al), bi);
+          if (oo.on) {
+            float v = rintf(f * oo.inv_s) + oo.o;
+            v = fminf(fmaxf(v, oo.qmin), oo.qmax);
+            f = __fmul_rn(__fsub_rn(v, oo.o), oo.s);
+          }
+          return __fadd_rn(x0, f);
+        };
+#pragma unroll
+        for (int u = 0; u < XPRE; ++u) {
+          if (u * DG_PRO * 64 < nvec) {
+            float4& v = xv[u];
+            v = make_float4(oq1(v.x, oa[u][0], oc[u][0], oal[u].x, ob[u].x), oq1(v.y, oa[u][1], oc[u][1], oal[u].y, ob[u].y),
+                            oq1(v.z, oa[u][2], oc[u][2], oal[u].z, ob[u].z), oq1(v.w, oa[u][3], oc[u][3], oal[u].w, ob[u].w));
+            hmid[u] = v;                                           // stored to x_mid at the END of the prologue: a store in front of the norm
+          }                                                        // weights' first use makes hipcc wait vmcnt(0) there, i.e. for the store (+0.8 us)
+        }
+      }
       float r = 1.f, shiftv = 0.f;
       if constexpr (XMODE == XM_LNORM) {                           // QLayerNorm.forward, arithmetic of mq_layernorm_quant (mq_norm.hip)
         const Grid ng = const_grid(cv, CG_NORM_IN, g.norm_in);
         float s1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < DG_XPRE; ++u) {
+        for (int u = 0; u < XPRE; ++u) {
           if (u * DG_PRO * 64 < nvec) {
             float4& v = xv[u];
             const v2f lo2 = ng.fq2((v2f){v.x, v.y}), hi2 = ng.fq2((v2f){v.z, v.w});
@@ -233,7 +281,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         const float mu = __fdiv_rn(tot, (float)K);
         float s2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < DG_XPRE; ++u) {
+        for (int u = 0; u < XPRE; ++u) {
           if (u * DG_PRO * 64 < nvec && p + u * DG_PRO * 64 < nvec) {
             const float4 v = xv[u];
             const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
@@ -257,7 +305,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         const Grid ng = const_grid(cv, CG_NORM_IN, g.norm_in);
         float ss = 0.f;
 #pragma unroll
-        for (int u = 0; u < DG_XPRE; ++u) {
+        for (int u = 0; u < XPRE; ++u) {
           if (u * DG_PRO * 64 < nvec) {
             float4& v = xv[u];
             const v2f lo2 = ng.fq2((v2f){v.x, v.y}), hi2 = ng.fq2((v2f){v.z, v.w});
@@ -284,7 +332,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         DG_STAMP(1);
       }
 #pragma unroll
-      for (int u = 0; u < DG_XPRE; ++u) {
+      for (int u = 0; u < XPRE; ++u) {
         if (u * DG_PRO * 64 < nvec) {
           const int i = p + u * DG_PRO * 64;
           float4 v = xv[u];
@@ -312,6 +360,13 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
           }
         }
       }
+      if constexpr (OPRE) {
+#pragma unroll
+        for (int u = 0; u < XPRE; ++u) {
+          const int i = p + u * DG_PRO * 64;
+          if (u * DG_PRO * 64 < nvec && i < nvec && (unsigned)i % gridDim.x == blockIdx.x) reinterpret_cast<float4*>(g.x_mid)[i] = hmid[u];   // this workgroup's share
+        }
+      }
     }
     DG_STAMP_ARRIVED(10, 0, my_sum);
     const int part = wave_sum_dpp(my_sum);
@@ -329,10 +384,10 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
   }
 #endif
   const int sw = wave - DG_PRO;                                    // 0 .. DG_STR-1
-  const int NL = GATE ? g.N >> 1 : g.N;                            // logical rows
+  const int NL = PAIRED ? g.N >> 1 : g.N;                          // logical rows
   const int kchunks = W4 ? K >> 5 : K >> 4;                        // 16-byte chunks per weight row
   const int wrow = W4 ? K >> 1 : K;                                // bytes per weight row
-  const int lchunks = GATE ? 2 * kchunks : kchunks;                // chunks per logical row
+  const int lchunks = PAIRED ? 2 * kchunks : kchunks;              // chunks per logical row
   const int cpl = (lchunks + 63) >> 6;
   const int row0 = blockIdx.x * rows_per_wg + sw;
   const int row_end = (blockIdx.x + 1) * rows_per_wg < NL ? (blockIdx.x + 1) * rows_per_wg : NL;
@@ -345,25 +400,30 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       const int row = row0 + DG_STR * t;
       const int c = lane + 64 * j;
       if (row < row_end && c < lchunks)
-        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * (GATE ? 2 : 1) * wrow) + c);
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g.w + (size_t)row * (PAIRED ? 2 : 1) * wrow) + c);
       else
         buf[u] = v4i{0, 0, 0, 0};
       if (++j == cpl) { j = 0; ++t; }
     }
   };
   issue_pass(0, 0);
-  float p_alpha[GATE ? 2 : 1], p_bias[GATE ? 2 : 1];
-  int p_zp[GATE ? 2 : 1], p_ct[GATE ? 2 : 1];
+  float p_alpha[PAIRED ? 2 : 1], p_bias[PAIRED ? 2 : 1];
+  int p_zp[PAIRED ? 2 : 1], p_ct[PAIRED ? 2 : 1];
 #pragma unroll
-  for (int h = 0; h < (GATE ? 2 : 1); ++h) {
-    const int wr = GATE ? 2 * prow + h : prow;
+  for (int h = 0; h < (PAIRED ? 2 : 1); ++h) {
+    const int wr = PAIRED ? 2 * prow + h : prow;
     p_alpha[h] = prow_ok ? g.alpha[wr] : 0.f;
     p_zp[h] = prow_ok ? g.w_zp[wr] : 0;
     p_ct[h] = prow_ok ? g.col_term[wr] : 0;
     p_bias[h] = (prow_ok && g.bias) ? g.bias[wr] : 0.f;
   }
   float p_res = 0.f;
-  if (!GATE && g.resid && prow_ok) p_res = g.resid[prow];
+  if (!PAIRED && g.resid && prow_ok) p_res = g.resid[prow];
+  if (g.zero_acc && sw == 0) {                                     // clear this workgroup's share of the o_proj accumulators (the next launch adds)
+    const int per = (g.zero_n + (int)gridDim.x - 1) / (int)gridDim.x, lo = (int)blockIdx.x * per;
+    const int hi = lo + per < g.zero_n ? lo + per : g.zero_n;
+    for (int i = lo + lane; i < hi; i += 64) g.zero_acc[i] = 0;
+  }
   if constexpr (XMODE == XM_LNORM) {                               // the prologue waves' mean and variance reductions
     __syncthreads();
     __syncthreads();
@@ -398,7 +458,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       if (t2 < nslots) {
         int c = lane + 64 * j2;
         c = c < lchunks ? c : lchunks - 1;                       // buf[u] is zero there
-        const int ck = GATE ? (c >= kchunks ? c - kchunks : c) : c;
+        const int ck = PAIRED ? (c >= kchunks ? c - kchunks : c) : c;
         int part;
         if constexpr (W4) {
           const v4i a_lo = *reinterpret_cast<const v4i*>(smem + (size_t)ck * 32), a_hi = *reinterpret_cast<const v4i*>(smem + (size_t)ck * 32 + 16);
@@ -412,10 +472,10 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
         } else {
           part = dot16(buf[u], *reinterpret_cast<const v4i*>(smem + (size_t)ck * 16), 0);
         }
-        if (GATE && c >= kchunks) acc1 += part;
+        if (PAIRED && c >= kchunks) acc1 += part;
         else acc0 += part;
         if (j2 == cpl - 1) {                                     // logical row slot t2 complete
-          const int s0 = wave_sum_dpp(acc0), s1 = GATE ? wave_sum_dpp(acc1) : 0;
+          const int s0 = wave_sum_dpp(acc0), s1 = PAIRED ? wave_sum_dpp(acc1) : 0;
           acc0 = acc1 = 0;
           if (lane == t2) {                                      // lane t keeps the contraction(s) of row slot t
             sum0 = s0;
@@ -438,9 +498,9 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
       const int tt = (int)((unsigned)sum0 - (unsigned)p_zp[0] * (unsigned)rs + (unsigned)p_ct[0]);
       e0 = __fadd_rn(__fmul_rn((float)tt, p_alpha[0]), p_bias[0]);
     }
-    if constexpr (GATE) {
-      const int tt = (int)((unsigned)sum1 - (unsigned)p_zp[GATE ? 1 : 0] * (unsigned)rs + (unsigned)p_ct[GATE ? 1 : 0]);
-      e1 = __fadd_rn(__fmul_rn((float)tt, p_alpha[GATE ? 1 : 0]), p_bias[GATE ? 1 : 0]);
+    if constexpr (PAIRED) {
+      const int tt = (int)((unsigned)sum1 - (unsigned)p_zp[PAIRED ? 1 : 0] * (unsigned)rs + (unsigned)p_ct[PAIRED ? 1 : 0]);
+      e1 = __fadd_rn(__fmul_rn((float)tt, p_alpha[PAIRED ? 1 : 0]), p_bias[PAIRED ? 1 : 0]);
     }
     if constexpr (GATE) {
       const float fa = out_q(og0, e0), fb = out_q(og1, e1);
@@ -760,6 +820,312 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
 #endif
 }
 
+// ---- round 6: attention of one query token + o_proj's contraction in ONE launch ---------------------------------------------------
+// Why.  A layer at M = 1 is a chain of all-to-all dependences; every link costs a kernel boundary (1.35 us) plus a launch's ramp, its
+// dependent first load and its tail -- 4.8 us for the o_proj launch, whose own work (4 MB of weights) is 0.8 us.  o_proj is linear in its
+// input, and its input is the concatenation of the heads' outputs: workgroup (h, c) -- head h, row range c -- holds head h's output
+// and can contract it with the K-slice [h D, (h + 1) D) of ITS rows on the spot.  The partial sums are integers, so adding them across
+// the 32 heads with device-scope atomics is exact and order free (tools/atomic_probe.cpp: 65 536 no-return int32 atomics on 2 048
+// addresses add 0.6-0.7 us to a launch, profiles/r06/atomic_probe.log); o_proj's epilogue -- which needs the COMPLETE sums -- moves into
+// the prologue of the next launch (OPRE above).  The price: all `slices` workgroups of a head repeat the head's attention (they all need
+// the whole output vector and there is no cheaper way to share it than to recompute it: a cross-workgroup hand-off costs ~3 us on this
+// chip): at M = 1 that arithmetic is free, the 256 CUs were idle in the old launch (32 workgroups).
+// Grid: heads * slices workgroups of 256 threads (+ prefetch rows); workgroups that share a KV head sit on the same XCD(s) where the
+// geometry allows (speed only).  RoPE / quantizers / scores / softmax / p.v: the expressions of decode_attention_kernel with nsplit = 1
+// (every result bit is that kernel's).  What differs is the ORDER OF REQUESTS, because this launch is a chain of dependent round trips:
+//   * nothing requested at the top depends on *pos (first-batch addresses are clamped by the cache length), and *pos itself comes
+//     through the scalar cache behind them: as a vector load with an early return hipcc hoisted load + wait + branch in front of
+//     every other request -- one more round trip at the head of the launch;
+//   * TWO batches of values (512 positions) are in registers before the scores start, later batches are refilled a batch ahead;
+//   * o_proj's 16 KB per workgroup are requested behind the scores (hipcc waits vmcnt(0) at the head of the score loop: weights from
+//     HBM in front of it held the scores back by ~1.3 us) and are in registers long before the head's output exists.
+// o_proj: thread (r = tid / tpr, sub = tid % tpr) holds cpt = D / 16 / tpr 16-byte chunks of row c R + r of head h's slice.
+template <int D>
+__global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
+  constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = 256 / LPP, KB = 8 / CH;
+  constexpr int DQ = D / 4, G = 256 / DQ, PPB = 64 / G, VB = 16;
+  constexpr int MAXC = D / 16 < 8 ? D / 16 : 8;                    // 16-byte chunks of an o_proj row slice per thread
+  static_assert(PPB * G == 64 && VB % PPB == 0, "block mapping");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_sc = reinterpret_cast<float*>(smem_raw);              // [cache_len] scores -> exp -> (p index - zp) as int
+  __shared__ __attribute__((aligned(16))) int8_t s_q8[D], s_k8[D], s_v8[D], s_a8[D];
+  __shared__ float s_redf[4];
+  __shared__ int s_redq[4];
+  __shared__ long long s_acc[1024];                              // [G][D] partial p.v sums
+  const int H = a.heads, W = H * a.slices, rot = a.rot_dim;
+  if ((int)blockIdx.x >= W) {                                      // L2 prefetch role (see decode_attention_kernel)
+    const int q = (int)blockIdx.x - W;
+    if (q >= a.prefetch_wgs) return;
+    const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() + (unsigned long long)a.prefetch_delay;
+    while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(8);
+    const int gwg = (q + W) % a.prefetch_wgs;                      // same linear id % 8 as this workgroup when prefetch_wgs % 8 == 0
+    const size_t beg = (size_t)gwg * a.prefetch_stride;
+    const size_t end = beg + a.prefetch_bytes_per_wg < a.prefetch_total ? beg + a.prefetch_bytes_per_wg : a.prefetch_total;
+    const v4i* p = reinterpret_cast<const v4i*>(a.prefetch + beg);
+    const size_t n = end > beg ? (end - beg) >> 4 : 0;
+    v4i acc = {0, 0, 0, 0};
+    for (size_t i = threadIdx.x; i < n; i += 256 * 8) {
+      v4i b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = p[i + (size_t)u * 256 < n ? i + (size_t)u * 256 : i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc |= b[u];
+    }
+    asm volatile("" ::"v"(acc));
+    return;
+  }
+  DG_STAMP(0);
+  // workgroup -> (head, row range).  With kv_heads dividing 8 and W a multiple of 8: XCD x = block % 8 serves KV head x / (8 / kv_heads),
+  // so the slices * (heads / kv_heads) workgroups that sweep the same keys / values share an L2 (observed placement: speed only).
+  int h, c;
+  {
+    const int b = blockIdx.x, kvh_n = a.kv_heads, per_kv = W / kvh_n;                 // workgroups per KV head
+    if (kvh_n <= 8 && 8 % kvh_n == 0 && W % 8 == 0 && per_kv % (8 / kvh_n) == 0) {
+      const int xs = 8 / kvh_n, x = b & 7, i = b >> 3;
+      const int j = (x % xs) * (per_kv / xs) + i;                                     // 0 .. per_kv - 1 inside KV head x / xs
+      h = (x / xs) * (H / kvh_n) + j / a.slices;
+      c = j % a.slices;
+    } else {
+      h = b / a.slices;
+      c = b % a.slices;
+    }
+  }
+  const int kvh = h / (H / a.kv_heads);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float cv = a.consts[lane];
+  // the new token's q / k / v rows (fp32 outputs of the q|k|v launch) and their RoPE partners: independent of the position
+  const float* qp = a.qkv + (size_t)h * D;
+  const float* kp = a.qkv + (size_t)H * D + (size_t)kvh * D;
+  const float* vp = a.qkv + (size_t)(H + a.kv_heads) * D + (size_t)kvh * D;
+  const int dd = tid < D ? tid : D - 1;
+  const int half = rot >> 1;
+  const int dpart = dd < rot ? (dd < half ? dd + half : dd - half) : dd;
+  const float q_raw = qp[dd], q_par = qp[dpart], k_raw = kp[dd], k_par = kp[dpart], v_raw = vp[dd];
+  const int CL = a.cache_len;
+  const int8_t* kc = a.k_cache + (size_t)kvh * CL * D;
+  const int8_t* vc = a.v_cache + (size_t)kvh * CL * D;
+  // ---- key loads of the first batch, value loads of the first TWO batches (addresses clamped by the cache length, masked by T below) ----
+  const int sub = tid & (LPP - 1), slot = tid / LPP;
+  v4i kbuf[KB][CH];
+#pragma unroll
+  for (int u = 0; u < KB; ++u) {
+    const int t = u * PPP + slot;
+    const int tc = t < CL ? t : 0;                                  // position 0 stands in (always valid memory)
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
+  }
+  const int dq = tid & (DQ - 1), grp = tid / DQ;
+  auto item_pos = [&](int i) { return 64 * (i / PPB) + grp + G * (i % PPB); };   // PPB: a power of two (shifts)
+  int vbuf[2][VB];
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int t = item_pos(bb * VB + u);
+      vbuf[bb][u] = *reinterpret_cast<const int*>(vc + (size_t)(t < CL ? t : 0) * D + dq * 4);
+    }
+  int pos;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
+  const bool live = pos >= 0 && pos < CL;                           // a step past the cache: nothing is written (the host raises first)
+  const int T = live ? pos + 1 : 0;
+  const int pc = live ? pos : 0;
+  const int dr = dd < rot ? dd : 0;
+  const float cs = a.cos[(size_t)pc * rot + dr], sn = a.sin[(size_t)pc * rot + dr];
+  // ---- RoPE + the three input quantizers of the new token ---------------------------------------------------------------------------
+  const Grid qa = const_grid(cv, AG_QK_A, a.qk_a), qb = const_grid(cv, AG_QK_B, a.qk_b), qo = const_grid(cv, AG_QK_OUT, a.qk_out);
+  const Grid pa = const_grid(cv, AG_PV_A, a.pv_a), pb = const_grid(cv, AG_PV_B, a.pv_b), po = const_grid(cv, AG_PV_OUT, a.pv_out);
+  const Grid oi = const_grid(cv, AG_O_IN, a.o_in);
+  int qsum_part = 0;
+  if (tid < D) {
+    float qv = q_raw, kv = k_raw;
+    if (tid < rot) {                                               // x * cos + rot(x) * sin, rot(x)[d] = d < rot/2 ? -x[d + rot/2] : x[d - rot/2]
+      const float sg = tid < half ? -1.f : 1.f;                    // (-x) * sin == -(x * sin) exactly
+      qv = __fadd_rn(__fmul_rn(q_raw, cs), __fmul_rn(sg * q_par, sn));
+      kv = __fadd_rn(__fmul_rn(k_raw, cs), __fmul_rn(sg * k_par, sn));
+    }
+    const float iq = dq_index(qv, qa.s, qa.inv_s, qa.o, qa.qmin, qa.qmax), ik = dq_index(kv, qb.s, qb.inv_s, qb.o, qb.qmin, qb.qmax);
+    const float iv = dq_index(v_raw, pb.s, pb.inv_s, pb.o, pb.qmin, pb.qmax);
+    const int sq = (iq != iq ? 0 : (int)iq) - 128, sk = (ik != ik ? 0 : (int)ik) - 128, sv = (iv != iv ? 0 : (int)iv) - 128;
+    s_q8[tid] = (int8_t)sq;
+    s_k8[tid] = (int8_t)sk;
+    s_v8[tid] = (int8_t)sv;
+    qsum_part = sq;
+    if (live && c == 0 && h % (H / a.kv_heads) == 0) {             // the group's first head (its first slice) appends to the cache
+      a.k_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sk;
+      a.v_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sv;
+    }
+  }
+  {
+    const int w = wave_sum_dpp(qsum_part);
+    if (lane == 0) s_redq[wv] = w;
+  }
+  __syncthreads();
+  DG_STAMP(1);
+  const int qsum = (s_redq[0] + s_redq[1]) + (s_redq[2] + s_redq[3]);
+  const int zq = (int)qa.o - 128, zk = (int)qb.o - 128, zv = (int)pb.o - 128, zp = (int)pa.o;
+  const float alpha_qk = __fmul_rn(qa.s, qb.s), alpha_pv = __fmul_rn(pa.s, pb.s);
+  const int qconst = D * zq * zk - zk * qsum;                      // sum (iq - zq)(ik - zk) = sum sq sk - zk sum sq - zq sum sk + D zq zk
+  constexpr bool pow2 = (D == 64 || D == 256);
+  const float sqrt_d = __fsqrt_rn((float)D), inv_sqrt_d = 1.0f / (D == 64 ? 8.0f : 16.0f);
+  v4i qf[CH], kn[CH];                                              // this lane's share of the query / of the NEW key (never via memory)
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    qf[ch] = *reinterpret_cast<const v4i*>(s_q8 + (sub * CH + ch) * 16);
+    kn[ch] = *reinterpret_cast<const v4i*>(s_k8 + (sub * CH + ch) * 16);
+  }
+  const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+  // ---- scores ----------------------------------------------------------------------------------------------------------------------
+  float lmax = -INFINITY;
+  for (int t0 = 0; t0 < T; t0 += KB * PPP) {
+    if (t0 > 0) {                                                   // a later batch of 512 positions (one exposed round trip each: long caches only)
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int t = t0 + u * PPP + slot, tc = t < pos ? t : 0;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      if (t0 + u * PPP >= T) break;                                // (uniform) the rest of the batch lies beyond the sequence
+      const int t = t0 + u * PPP + slot;
+      int dot = 0, ks = 0;
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        const v4i kf = t == pos ? kn[ch] : kbuf[u][ch];
+        dot = dot16(kf, qf[ch], dot);
+        ks = dot16(kf, ones, ks);
+      }
+      dot = quad_sum<LPP>(dot);
+      ks = quad_sum<LPP>(ks);
+      if (t < T && sub == 0) {
+        const int ti = dot - zq * ks + qconst;
+        const float val = __fmul_rn((float)ti, alpha_qk);
+        const float qv = qo.fq(val);
+        const float sc = pow2 ? __fmul_rn(qv, inv_sqrt_d) : __fdiv_rn(qv, sqrt_d);     // qk_bmm(...) / sqrt(head_dim)  (hf_model.py:513)
+        s_sc[t] = sc;
+        lmax = fmaxf(lmax, sc);
+      }
+    }
+  }
+  lmax = wave_max_f(lmax);
+  if (lane == 0) s_redf[wv] = lmax;
+  // o_proj's weights are requested HERE, behind the scores (see the header comment); needed ~3 us from now
+  const int R = a.N / a.slices, tpr = a.tpr, cpt = (D / 16) / tpr;
+  const int orow = tid / tpr, osub = tid % tpr;
+  const bool o_ok = orow < R;
+  const int n_out = c * R + (o_ok ? orow : 0);
+  v4i wbuf[MAXC];
+  {
+    const v4i* wp = reinterpret_cast<const v4i*>(a.o_w + ((size_t)h * a.N + n_out) * D) + osub * cpt;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) wbuf[j] = __builtin_nontemporal_load(wp + (j < cpt ? j : 0));
+  }
+  const int o_zp = a.o_wzp[n_out];
+  __syncthreads();
+  DG_STAMP(2);
+  const float mx = fmaxf(fmaxf(s_redf[0], s_redf[1]), fmaxf(s_redf[2], s_redf[3]));
+  __syncthreads();
+  float lsum = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float e = expf(s_sc[t] - mx);
+    s_sc[t] = e;
+    lsum += e;
+  }
+  lsum = wave_sum_f(lsum);
+  if (lane == 0) s_redf[wv] = lsum;
+  __syncthreads();
+  const float tot_e = (s_redf[0] + s_redf[1]) + (s_redf[2] + s_redf[3]);
+  int* s_pi = reinterpret_cast<int*>(s_sc);
+  for (int t = tid; t < T; t += 256) {
+    const float p = __fdiv_rn(s_sc[t], tot_e);
+    const float ip = dq_index(p, pa.s, pa.inv_s, pa.o, pa.qmin, pa.qmax);
+    s_pi[t] = (ip != ip ? 0 : (int)ip) - zp;
+  }
+  __syncthreads();
+  DG_STAMP(3);
+  // ---- p.v over the cached positions t < pos: exact integers; the new position from registers -----------------------------------------
+  long long acc[4] = {0, 0, 0, 0};
+  long long psum = 0;
+  const int nblk = (pos + 63) >> 6;                                  // blocks of CACHED positions 0 .. pos - 1
+  const int items = live ? nblk * PPB : 0;
+  for (int i0 = 0; i0 < items; i0 += 2 * VB) {
+    if (i0 > 0) {                                                   // later double batches (512 positions each): one exposed round trip each
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+          const int t = item_pos(i0 + bb * VB + u);
+          vbuf[bb][u] = *reinterpret_cast<const int*>(vc + (size_t)(t < pos ? t : 0) * D + dq * 4);
+        }
+    }
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      int a32[4] = {0, 0, 0, 0}, p32 = 0;                            // <= 16 positions x 65535 x 128 < 2^31
+#pragma unroll
+      for (int u = 0; u < VB; ++u) {
+        const int i = i0 + bb * VB + u;
+        const int t = item_pos(i);
+        const bool ok = i < items && t < pos;
+        const int pi = s_pi[ok ? t : 0];
+        const int pim = ok ? pi : 0;
+        p32 += pim;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a32[e] += (int)__builtin_amdgcn_sbfe(vbuf[bb][u], 8 * e, 8) * pim;      // (the builtin returns unsigned)
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += a32[e];
+      psum += p32;
+    }
+  }
+  if (grp == 0 && live) {                                            // the new position: group 0 adds it from registers
+    const int sv4 = *reinterpret_cast<const int*>(s_v8 + dq * 4);
+    const int pi = s_pi[pos];
+    psum += pi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += (long long)((int)__builtin_amdgcn_sbfe(sv4, 8 * e, 8) * pi);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] -= (long long)zv * psum;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s_acc[grp * D + dq * 4 + e] = acc[e];
+  __syncthreads();
+  DG_STAMP(4);
+  int a_byte = 0;
+  if (tid < D) {
+    long long tot = 0;
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) tot += s_acc[gq * D + tid];
+    const float pre = (float)((double)tot * (double)alpha_pv);     // one rounding of the exact sum (as mq_attention.hip)
+    const float y = po.fq(pre);
+    const float qi = dq_index(y, oi.s, oi.inv_s, oi.o, oi.qmin, oi.qmax);
+    a_byte = (qi != qi ? (int)oi.qmin : (int)qi) - 128;
+    s_a8[tid] = (int8_t)a_byte;
+    if (a.out_q && c == 0 && live) a.out_q[(size_t)h * D + tid] = (int8_t)a_byte;
+  }
+  {
+    const int w = wave_sum_dpp(a_byte);                            // (lanes beyond D contribute 0)
+    if (lane == 0) s_redq[wv] = w;
+  }
+  __syncthreads();
+  // ---- o_proj: rows [c R, (c + 1) R) x K-slice [h D, (h + 1) D) ---------------------------------------------------------------------
+  const int rs_h = (s_redq[0] + s_redq[1]) + (s_redq[2] + s_redq[3]);
+  int part = 0;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j)
+    if (j < cpt) part = dot16(wbuf[j], *reinterpret_cast<const v4i*>(s_a8 + (osub * cpt + j) * 16), part);
+  if (tpr >= 2) part += __builtin_amdgcn_update_dpp(0, part, 0xB1, 0xf, 0xf, true);
+  if (tpr == 4) part += __builtin_amdgcn_update_dpp(0, part, 0x4E, 0xf, 0xf, true);
+  if (o_ok && osub == 0 && live) {
+    const int v = (int)((unsigned)part - (unsigned)o_zp * (unsigned)rs_h);
+    __hip_atomic_fetch_add(a.o_acc + n_out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#ifdef MQ_DECODE_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DG_STAMP(5);
+#endif
+}
+
 // ---- final norm (floating point HFRMSNorm) + lm_head (fp32 weights) ----------------------------------------------------------------
 __global__ void __launch_bounds__(256) decode_head_kernel(const float* __restrict__ x, const float* __restrict__ norm_w,
                                                           const float* __restrict__ norm_b, const int layernorm, float eps,
@@ -908,11 +1274,15 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
              "mq_decode_gemv: fp32 activations need an 8-bit unsigned activation grid");
   MQ_REQUIRE(aligned(g.w, 16) && (!g.x || aligned(g.x, 16)) && (!g.xq || aligned(g.xq, 4)) && (!g.norm_w || aligned(g.norm_w, 16)),
              "mq_decode_gemv: pointers must be 16-byte aligned");
-  const bool gate = g.gate_q != nullptr;
+  const bool gate = g.gate_q != nullptr, opre = g.o_acc != nullptr;
   MQ_REQUIRE(gate || g.y, "mq_decode_gemv: no output");
   MQ_REQUIRE(!gate || (g.norm_w && !g.xq), "mq_decode_gemv: gate mode is served for the norm-fused prologue (fp32 x + norm_w)");
   MQ_REQUIRE(!gate || (g.N % 2 == 0 && g.gate_out.scale && g.out_grid[0].scale && g.out_grid[1].scale && (g.gate_act == 0 || g.gate_act == 1)),
              "mq_decode_gemv: gate mode needs an even N (interleaved w1 / w3 rows), both output grids and the w2 input grid");
+  MQ_REQUIRE(!g.zero_acc || (g.zero_n > 0 && aligned(g.zero_acc, 4)), "mq_decode_gemv: zero_acc needs zero_n > 0");
+  MQ_REQUIRE(!opre || (gate && g.o_alpha && g.o_ct && g.x_mid && g.K <= 2 * 4 * DG_PRO * 64 && aligned(g.o_acc, 16) && aligned(g.o_alpha, 16) &&
+                       aligned(g.o_ct, 16) && aligned(g.x_mid, 16) && (!g.o_bias || aligned(g.o_bias, 16))),
+             "mq_decode_gemv: o_acc (o_proj's epilogue as prologue) is served for the gate launch, K <= 4096, with o_alpha / o_ct / x_mid, 16-byte aligned");
   int rows_per_wg;
   unsigned grid;
   decode_gemv_geometry(g, &rows_per_wg, &grid);
@@ -921,27 +1291,29 @@ int mq_decode_gemv(const mq_decode_gemv_args* args, mq_stream_t stream) {
   unsigned long long* stamps = STAMP_SLOT(gate ? 1 : (g.norm_w ? 0 : (g.xq ? 3 : 2)), grid);
   const int xmode = g.xq ? XM_I8 : (g.norm_w ? (g.layernorm ? XM_LNORM : XM_NORM) : XM_F32);
   MQ_REQUIRE(!g.norm_bias || (g.layernorm && aligned(g.norm_bias, 16)), "mq_decode_gemv: norm_bias belongs to the LayerNorm prologue (layernorm = 1), 16-byte aligned");
-#define MQ_DG_LAUNCH(XM, GT, W4)                                                                                   \
-  decode_gemv_kernel<XM, GT, W4><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps)
-  if (gate && xmode == XM_LNORM) {
-    if (g.w4) MQ_DG_LAUNCH(XM_LNORM, true, true);
-    else MQ_DG_LAUNCH(XM_LNORM, true, false);
+#define MQ_DG_LAUNCH(XM, PR, W4, OP)                                                                                   \
+  decode_gemv_kernel<XM, PR, W4, OP><<<grid, DG_THREADS, lds, st>>>(g, rows_per_wg, stamps)
+#define MQ_DG_LAUNCH_W4(XM, PR, OP)                    \
+  do {                                                 \
+    if (g.w4) MQ_DG_LAUNCH(XM, PR, true, OP);          \
+    else MQ_DG_LAUNCH(XM, PR, false, OP);              \
+  } while (0)
+  if (gate && opre) {
+    if (xmode == XM_LNORM) MQ_DG_LAUNCH_W4(XM_LNORM, PAIR_GATE, true);
+    else MQ_DG_LAUNCH_W4(XM_NORM, PAIR_GATE, true);
   } else if (gate) {
-    if (g.w4) MQ_DG_LAUNCH(XM_NORM, true, true);
-    else MQ_DG_LAUNCH(XM_NORM, true, false);
+    if (xmode == XM_LNORM) MQ_DG_LAUNCH_W4(XM_LNORM, PAIR_GATE, false);
+    else MQ_DG_LAUNCH_W4(XM_NORM, PAIR_GATE, false);
   } else if (xmode == XM_LNORM) {
-    if (g.w4) MQ_DG_LAUNCH(XM_LNORM, false, true);
-    else MQ_DG_LAUNCH(XM_LNORM, false, false);
+    MQ_DG_LAUNCH_W4(XM_LNORM, PAIR_NONE, false);
   } else if (xmode == XM_NORM) {
-    if (g.w4) MQ_DG_LAUNCH(XM_NORM, false, true);
-    else MQ_DG_LAUNCH(XM_NORM, false, false);
+    MQ_DG_LAUNCH_W4(XM_NORM, PAIR_NONE, false);
   } else if (xmode == XM_F32) {
-    if (g.w4) MQ_DG_LAUNCH(XM_F32, false, true);
-    else MQ_DG_LAUNCH(XM_F32, false, false);
+    MQ_DG_LAUNCH_W4(XM_F32, PAIR_NONE, false);
   } else {
-    if (g.w4) MQ_DG_LAUNCH(XM_I8, false, true);
-    else MQ_DG_LAUNCH(XM_I8, false, false);
+    MQ_DG_LAUNCH_W4(XM_I8, PAIR_NONE, false);
   }
+#undef MQ_DG_LAUNCH_W4
 #undef MQ_DG_LAUNCH
   MQ_LAUNCH_CHECK("mq_decode_gemv");
   return MQ_OK;
@@ -987,6 +1359,53 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
     default: decode_attention_kernel<256><<<grid, 256, lds, st>>>(a, stamps); break;
   }
   MQ_LAUNCH_CHECK("mq_decode_attention");
+  return MQ_OK;
+}
+
+int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_stream_t stream) {
+  MQ_REQUIRE(args != nullptr, "mq_decode_attention_oproj: null argument block");
+  const mq_decode_attention_oproj_args& a = *args;
+  MQ_REQUIRE(a.qkv && a.k_cache && a.v_cache && a.cos && a.sin && a.pos && a.consts && a.o_w && a.o_wzp && a.o_acc, "mq_decode_attention_oproj: null pointer");
+  MQ_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0 && (a.head_dim == 32 || a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256) &&
+                 a.cache_len > 0 && a.cache_len <= 32768 && a.rot_dim > 0 && a.rot_dim <= a.head_dim && a.rot_dim % 2 == 0,
+             "mq_decode_attention_oproj: heads=%d kv_heads=%d head_dim=%d (32 / 64 / 128 / 256) cache_len=%d (<= 32768) rot_dim=%d", a.heads, a.kv_heads, a.head_dim,
+             a.cache_len, a.rot_dim);
+  MQ_REQUIRE(a.qk_a.scale && a.qk_b.scale && a.pv_a.scale && a.pv_b.scale && a.qk_a.qmin == 0.f && a.qk_a.qmax == 255.f && a.qk_b.qmin == 0.f &&
+                 a.qk_b.qmax == 255.f && a.pv_b.qmin == 0.f && a.pv_b.qmax == 255.f && a.pv_a.qmin == 0.f && a.pv_a.qmax <= 65535.f,
+             "mq_decode_attention_oproj: q / k / v need 8-bit unsigned grids, the probabilities an unsigned grid of at most 16 bits");
+  MQ_REQUIRE(a.o_in.scale && a.o_in.qmin == 0.f && a.o_in.qmax == 255.f, "mq_decode_attention_oproj: o_proj needs an 8-bit unsigned input grid (o_in)");
+  const int chunks = a.head_dim / 16;
+  MQ_REQUIRE(a.N > 0 && a.slices > 0 && a.N % a.slices == 0 && (a.tpr == 1 || a.tpr == 2 || a.tpr == 4) && chunks % a.tpr == 0 && chunks / a.tpr <= 8 &&
+                 (a.N / a.slices) * a.tpr <= 256 && (long long)a.heads * a.slices <= 65535,
+             "mq_decode_attention_oproj: N=%d slices=%d tpr=%d: N %% slices == 0, tpr in {1, 2, 4} dividing head_dim / 16 with <= 8 chunks per thread, "
+             "N / slices * tpr <= 256", a.N, a.slices, a.tpr);
+  MQ_REQUIRE(aligned(a.k_cache, 16) && aligned(a.v_cache, 16) && aligned(a.consts, 16) && aligned(a.qkv, 4) && aligned(a.o_w, 16),
+             "mq_decode_attention_oproj: caches / consts / o_w must be 16-byte aligned");
+  MQ_REQUIRE(a.prefetch_wgs == 0 || (a.prefetch && aligned(a.prefetch, 16) && a.prefetch_bytes_per_wg % 16 == 0 && a.prefetch_wgs > 0 && a.prefetch_wgs <= 4096 &&
+                                    a.prefetch_stride >= a.prefetch_bytes_per_wg && a.prefetch_stride % 16 == 0 && a.prefetch_delay >= 0 && a.prefetch_delay <= 100000),
+             "mq_decode_attention_oproj: prefetch needs a 16-byte aligned range, 1..4096 workgroups, stride >= bytes per workgroup, delay in 0..100000 (10 ns units)");
+  const size_t lds = (size_t)a.cache_len * sizeof(float);
+  const void* fn = a.head_dim == 32 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<32>)
+                   : a.head_dim == 64 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<64>)
+                   : a.head_dim == 128 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<128>)
+                                       : reinterpret_cast<const void*>(decode_attention_oproj_kernel<256>);
+  static std::atomic<size_t> lds_set[kMaxDevices][4];
+  const int dev = current_device(), ki = a.head_dim == 32 ? 0 : a.head_dim == 64 ? 1 : a.head_dim == 128 ? 2 : 3;
+  if (lds > 32768 && lds_set[dev][ki].load(std::memory_order_relaxed) < lds) {
+    MQ_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+               "mq_decode_attention_oproj: %zu bytes of dynamic LDS rejected", lds);
+    lds_set[dev][ki].store(lds, std::memory_order_relaxed);
+  }
+  const unsigned grid = (unsigned)(a.heads * a.slices + a.prefetch_wgs);
+  unsigned long long* stamps = STAMP_SLOT(4, (unsigned)(a.heads * a.slices));
+  hipStream_t st = as_stream(stream);
+  switch (a.head_dim) {
+    case 32: decode_attention_oproj_kernel<32><<<grid, 256, lds, st>>>(a, stamps); break;
+    case 64: decode_attention_oproj_kernel<64><<<grid, 256, lds, st>>>(a, stamps); break;
+    case 128: decode_attention_oproj_kernel<128><<<grid, 256, lds, st>>>(a, stamps); break;
+    default: decode_attention_oproj_kernel<256><<<grid, 256, lds, st>>>(a, stamps); break;
+  }
+  MQ_LAUNCH_CHECK("mq_decode_attention_oproj");
   return MQ_OK;
 }
 

@@ -23,7 +23,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib, ops
-from ._lib import MqDecodeAttentionArgs, MqDecodeGemvArgs, MqGrid
+from ._lib import MQ_U8, MqDecodeAttentionArgs, MqDecodeAttentionOprojArgs, MqDecodeGemvArgs, MqGrid
 from .quantization import qmodule as Q
 
 
@@ -103,19 +103,48 @@ class _Linear:
         self.rows = [l.weight.shape[0] for l in linears]
         self.sources = [(l.weight_quantizer, l.weight_quantizer.grid_token()) for l in linears]
         self.weights = [(l.weight, Q._ver(l.weight)) for l in linears]
+        self._lins = list(linears)
+
+    def byte_rows(self) -> torch.Tensor:
+        """[N, K] int8, ONE byte per weight whatever the stream format: index - 128 of an 8-bit weight, the unsigned nibble of a 4-bit one
+        (the numbers the packed kernels unpack: the same epilogue vectors apply)."""
+        outs = []
+        for lin in self._lins:
+            plan = lin._weight_plan(lin.weight)
+            if plan["bits4"] and plan["w4"]:                     # packed-only module (QLinear.w4_prefill = 'packed'): rebuild the nibbles
+                wq = lin.weight_quantizer
+                q, _ = ops.quantize(lin.weight.detach().float(), wq.scale.detach(), wq.offset.detach(), wq.qmin, wq.qmax, q_dtype=MQ_U8,
+                                    shift=wq.qmin, rows=lin.weight.shape[0], want_row_sum=True)
+                outs.append(q.view(torch.int8))
+            else:
+                outs.append(plan["w"].view(torch.int8).reshape(lin.weight.shape))
+        return torch.cat(outs, dim=0).contiguous()
 
 
 class DecodeEngine:
     LONG_FROM, LONG_SPLITS = 768, 4
 
-    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5):
+    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5,
+                 launches: int = 4, long_from: Optional[int] = None):
+        """launches: 4 (round 6, default) = per layer {norm + q|k|v, RoPE / cache append / attention + o_proj's contraction, o_proj's
+        epilogue + norm + w1|w3 + gate, w2}; 5 = round 2-5's chain with o_proj as a launch of its own.  A geometry the 4-launch kernels
+        do not serve falls back to 5 (self.launches says which).  With launches = 4, positions from `long_from` on (None: never) replay
+        the 5-launch graph with the split attention."""
         from .llama import LlamaForCausalLM
         assert isinstance(model, LlamaForCausalLM)
+        assert launches in (4, 5)
         self.model, self.shape = model, model.shape
         s = self.shape
         dev = next(model.parameters()).device
         self.dev, self.cache_len = dev, int(cache_len)
         self._prefetch = (prefetch, prefetch_delay_us)
+        self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
+        self.oproj_geom = self._oproj_geometry(s, self.cos.shape[1]) if launches == 4 else None
+        self.launches = 4 if self.oproj_geom is not None else 5
+        self.long_from = long_from if self.launches == 4 else None
+        if self.launches == 4:
+            self.o_acc = torch.zeros(s.hidden, dtype=torch.int32, device=dev)              # o_proj's integer sums (split-K over the heads)
+            self.x_mid = torch.zeros(s.hidden, device=dev)                                 # residual stream behind the attention block
         self.x = torch.zeros(s.hidden, device=dev)
         self.qkv = torch.zeros((s.heads + 2 * s.kv_heads) * s.head_dim, device=dev)
         self.attn_q = torch.zeros(s.heads * s.head_dim, dtype=torch.int8, device=dev)     # pv_bmm's output as o_proj's int8 image
@@ -135,11 +164,27 @@ class DecodeEngine:
         self.k_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
         self.v_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
         self._host_pos = 0                                   # mirror of self.pos for the cache-overflow guard (no device read-back)
-        self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
         assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
         self.graph = None
         self.graph_long = None
         self._lower()
+
+    @staticmethod
+    def _oproj_geometry(s, rot_dim):
+        """(slices, threads per row) of mq_decode_attention_oproj for this shape, or None when the 4-launch kernels do not serve it:
+        heads x slices workgroups ~ one per CU; a workgroup's 256 threads hold hidden / slices rows x head_dim bytes of o_proj."""
+        D, H, N = s.head_dim, s.heads, s.hidden
+        if D not in (32, 64, 128, 256) or rot_dim % 2 or rot_dim > min(D, 256) or N > 4096 or N % 4:
+            return None
+        chunks = D // 16
+        for slices in range(max(256 // H, 1), 0, -1):
+            if N % slices:
+                continue
+            R = N // slices
+            for tpr in (4, 2, 1):
+                if chunks % tpr == 0 and chunks // tpr <= 8 and R * tpr <= 256:
+                    return slices, tpr
+        return None
 
     def _lower(self):
         """Build the launch records from the model as it is now: weight images, epilogue vectors and one constants line per launch
@@ -164,22 +209,30 @@ class DecodeEngine:
         for q in model.modules():                 # grids set from act_dict.json sit on the host until a forward moves them
             if isinstance(q, Q.Quantizer) and q._has_grid() and q.scale.device != dev:
                 q.scale.data, q.offset.data = q.scale.to(dev), q.offset.to(dev)
+        self.oproj_images = []
+        self.phases_long = []     # launches = 4 with long_from: the 5-launch chain (split attention) for long caches
         with torch.no_grad():
             for li, layer in enumerate(model.layers):
-                self._lower_layer(li, layer)
+                if self.launches == 4:
+                    self._lower_layer4(li, layer)
+                    if self.long_from is not None:
+                        self._lower_layer(li, layer, self.phases_long)
+                else:
+                    self._lower_layer(li, layer)
         # The attention launch of layer L pulls (a share of) layer L's w1|w3 stream into the L2s with extra workgroups: it keeps 32 of
         # 256 CUs busy and leaves the memory fabric idle, while w1|w3 is the step's biggest stream.  Measured (TinyLlama shape, context
         # 256): share 0 / 0.5 / 0.7 / 1.0 -> 0.678 / 0.656 / 0.665 / 0.690 ms per token: the attention's own dependent loads queue
         # behind the prefetch stream, so half of it, started 1.5 us into the launch, is the optimum.
         if prefetch:
-            for i in range(1, len(self.phases), 5):
-                at, gate = self.phases[i][1], self.phases[i + 2][1]
+            pairs = [(self.phases[i][1], self.phases[i + (1 if self.launches == 4 else 2)][1]) for i in range(1, len(self.phases), self.launches)]
+            pairs += [(self.phases_long[i][1], self.phases_long[i + 2][1]) for i in range(1, len(self.phases_long), 5)]
+            for at, gate in pairs:
                 n, per, tot = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
                 _lib.call("mq_decode_gemv_geometry", ctypes.byref(gate), ctypes.byref(n), ctypes.byref(per), ctypes.byref(tot))
                 at.prefetch, at.prefetch_stride, at.prefetch_total, at.prefetch_wgs = gate.w, per.value, tot.value, n.value
                 at.prefetch_bytes_per_wg = min(per.value, int(per.value * float(prefetch)) // 1024 * 1024)
                 at.prefetch_delay = int(prefetch_delay_us * 100)
-        self.weight_bytes = sum(p[1]._mq_bytes for p in self.phases if p[0] == "gemv")
+        self.weight_bytes = sum(p[1]._mq_bytes for p in self.phases if hasattr(p[1], "_mq_bytes"))
         self.head_bytes = self.lm_w.numel() * 4
 
     def grids_stale(self) -> bool:
@@ -252,10 +305,86 @@ class DecodeEngine:
         return out.data_ptr()
 
     def _finish_gemv(self, a: MqDecodeGemvArgs) -> MqDecodeGemvArgs:
-        a.consts = self._pack([a.norm_in, a.a_grid, a.out_grid[0], a.out_grid[1], a.out_grid[2], a.gate_mid, a.gate_actout, a.gate_out])
+        a.consts = self._pack([a.norm_in, a.a_grid, a.out_grid[0], a.out_grid[1], a.out_grid[2], a.gate_mid, a.gate_actout, a.gate_out, a.o_out])
         return a
 
-    def _lower_layer(self, li, layer):
+    def _attention_grids(self, attn, at, keep):
+        qk, pv = attn.qk_bmm, attn.pv_bmm
+        at.qk_a, at.qk_b, at.qk_out = (_grid(q, keep) for q in (qk.input_quantizer, qk.input2_quantizer, qk.output_quantizer))
+        at.pv_a, at.pv_b, at.pv_out = (_grid(q, keep) for q in (pv.input_quantizer, pv.input2_quantizer, pv.output_quantizer))
+        # o_proj's input sits on pv_bmm's output grid (the live producer), else on its declared / own grid: the attention launch
+        # writes pv_bmm's output straight as o_proj's int8 image on that grid
+        g_o = attn.o_proj.input_quantizer if attn.o_proj.input_quantizer is not None else (
+            pv.output_quantizer if Q._static_per_tensor(pv.output_quantizer, 8) else attn.o_proj._input_grid)
+        if g_o is None or g_o.qmax != 255:
+            raise RuntimeError("DecodeEngine: o_proj needs an 8-bit unsigned input grid (pv_bmm output)")
+        at.o_in = _grid(g_o, keep)
+        at.consts = self._pack([at.qk_a, at.qk_b, at.qk_out, at.pv_a, at.pv_b, at.pv_out, at.o_in])
+        return g_o
+
+    def _lower_layer4(self, li, layer):
+        """Round 6: four launches per layer (csrc/mq_decode.hip: decode_attention_oproj_kernel, OPRE)."""
+        s, keep = self.shape, self._keep
+        attn, mlp = layer.self_attn, layer.mlp
+        for m in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.w1, mlp.w2, mlp.w3):
+            if not isinstance(m, Q.QLinear):
+                raise RuntimeError("DecodeEngine: run create_sim_qmodel first")
+        slices, tpr = self.oproj_geom
+        # (1) input_layernorm + q|k|v stream (the five-launch chain's launch); also clears o_proj's sums
+        a = MqDecodeGemvArgs()
+        g_in = self._norm_args(layer.input_layernorm, a)
+        qkv = _Linear([attn.q_proj, attn.k_proj, attn.v_proj], g_in)
+        p1 = self._gemv(qkv, x=self.x.data_ptr(), norm_w=a.norm_w, norm_bias=a.norm_bias, layernorm=a.layernorm, norm_in=a.norm_in, eps=a.eps,
+                        a_grid=a.a_grid, y=self.qkv.data_ptr(), zero_acc=self.o_acc.data_ptr(), zero_n=s.hidden)
+        p1.seg_end[0], p1.seg_end[1] = qkv.rows[0], qkv.rows[0] + qkv.rows[1]
+        for k, lin in enumerate((attn.q_proj, attn.k_proj, attn.v_proj)):
+            p1.out_grid[k] = _grid(lin.output_quantizer, keep)
+        self.phases.append(("gemv", self._finish_gemv(p1)))
+        # (2) RoPE / cache append / attention + o_proj's contraction (split-K over the heads, exact integer atomics)
+        at = MqDecodeAttentionOprojArgs()
+        at.qkv, at.k_cache, at.v_cache = self.qkv.data_ptr(), self.k_cache[li].data_ptr(), self.v_cache[li].data_ptr()
+        at.cos, at.sin, at.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
+        at.heads, at.kv_heads, at.head_dim, at.cache_len, at.rot_dim = s.heads, s.kv_heads, s.head_dim, self.cache_len, self.cos.shape[1]
+        g_o = self._attention_grids(attn, at, keep)
+        op = _Linear([attn.o_proj], g_o)
+        if op.K != s.heads * s.head_dim or op.N != s.hidden:
+            raise RuntimeError("DecodeEngine: o_proj must map heads * head_dim -> hidden")
+        o_w = op.byte_rows().view(op.N, s.heads, s.head_dim).permute(1, 0, 2).contiguous()          # [heads][N][D]: a head's K-slice of every row
+        keep += [o_w, op]
+        self.oproj_images.append((o_w, op))                   # (per layer; tests read them)
+        keep.sources += op.sources
+        keep.weights += op.weights
+        at.o_w, at.o_wzp, at.o_acc, at.N, at.slices, at.tpr = o_w.data_ptr(), op.w_zp.data_ptr(), self.o_acc.data_ptr(), op.N, slices, tpr
+        at._mq_bytes = o_w.numel()
+        self.phases.append(("attn_oproj", at))
+        # (3) o_proj's epilogue + residual -> post_attention_layernorm + interleaved w1|w3 + gated activation + w2's input quantizer
+        a2 = MqDecodeGemvArgs()
+        g_ffn = self._norm_args(layer.post_attention_layernorm, a2)
+        w13 = _Linear([mlp.w1, mlp.w3], g_ffn, interleave=True)
+        act = mlp.act_fn
+        if not isinstance(act, (Q.QSiLU, Q.QGELU)) or (act.input_quantizer is not None and not act.input_quantizer.bypassed()):
+            raise RuntimeError("DecodeEngine: act_fn must be QSiLU / QGELU without an input quantizer (the reference's surgery)")
+        iq2 = mlp.w2.input_quantizer
+        if iq2 is None or iq2.qmax != 255:
+            raise RuntimeError("DecodeEngine: w2 needs its own 8-bit unsigned input quantizer")
+        p4 = self._gemv(w13, x=self.x.data_ptr(), norm_w=a2.norm_w, norm_bias=a2.norm_bias, layernorm=a2.layernorm, norm_in=a2.norm_in,
+                        eps=a2.eps, a_grid=a2.a_grid,
+                        gate_q=self.gate_q.data_ptr(), gate_act=0 if isinstance(act, Q.QSiLU) else 1,
+                        gate_mid=_grid(act.input2_quantizer if isinstance(act, Q.QSiLU) else None, keep),
+                        gate_actout=_grid(act.output_quantizer, keep), gate_out=_grid(iq2, keep),
+                        o_acc=self.o_acc.data_ptr(), o_alpha=op.alpha.data_ptr(), o_ct=op.col_term.data_ptr(),
+                        o_bias=op.bias.data_ptr() if op.bias is not None else None, o_out=_grid(attn.o_proj.output_quantizer, keep),
+                        x_mid=self.x_mid.data_ptr())
+        p4.out_grid[0], p4.out_grid[1] = _grid(mlp.w1.output_quantizer, keep), _grid(mlp.w3.output_quantizer, keep)
+        self.phases.append(("gemv", self._finish_gemv(p4)))
+        # (4) w2 from the int8 image + residual (the stream behind the attention block)
+        w2 = _Linear([mlp.w2], iq2)
+        p5 = self._gemv(w2, xq=self.gate_q.data_ptr(), a_grid=_grid(iq2, keep), resid=self.x_mid.data_ptr(), y=self.x.data_ptr())
+        p5.out_grid[0] = _grid(mlp.w2.output_quantizer, keep)
+        self.phases.append(("gemv", self._finish_gemv(p5)))
+
+    def _lower_layer(self, li, layer, phases=None):
+        phases = self.phases if phases is None else phases
         s, keep = self.shape, self._keep
         attn, mlp = layer.self_attn, layer.mlp
         for m in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.w1, mlp.w2, mlp.w3):
@@ -270,31 +399,21 @@ class DecodeEngine:
         p1.seg_end[0], p1.seg_end[1] = qkv.rows[0], qkv.rows[0] + qkv.rows[1]
         for k, lin in enumerate((attn.q_proj, attn.k_proj, attn.v_proj)):
             p1.out_grid[k] = _grid(lin.output_quantizer, keep)
-        self.phases.append(("gemv", self._finish_gemv(p1)))
+        phases.append(("gemv", self._finish_gemv(p1)))
         # (2) attention core
         at = MqDecodeAttentionArgs()
         at.qkv, at.k_cache, at.v_cache = self.qkv.data_ptr(), self.k_cache[li].data_ptr(), self.v_cache[li].data_ptr()
         at.cos, at.sin, at.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
         at.heads, at.kv_heads, at.head_dim, at.cache_len = s.heads, s.kv_heads, s.head_dim, self.cache_len
         at.rot_dim, at.nsplit = self.cos.shape[1], self.attn_splits
-        qk, pv = attn.qk_bmm, attn.pv_bmm
-        at.qk_a, at.qk_b, at.qk_out = (_grid(q, keep) for q in (qk.input_quantizer, qk.input2_quantizer, qk.output_quantizer))
-        at.pv_a, at.pv_b, at.pv_out = (_grid(q, keep) for q in (pv.input_quantizer, pv.input2_quantizer, pv.output_quantizer))
-        # o_proj's input sits on pv_bmm's output grid (the live producer), else on its declared / own grid: the attention launch
-        # writes pv_bmm's output straight as o_proj's int8 image on that grid
-        g_o = attn.o_proj.input_quantizer if attn.o_proj.input_quantizer is not None else (
-            pv.output_quantizer if Q._static_per_tensor(pv.output_quantizer, 8) else attn.o_proj._input_grid)
-        if g_o is None or g_o.qmax != 255:
-            raise RuntimeError("DecodeEngine: o_proj needs an 8-bit unsigned input grid (pv_bmm output)")
-        at.o_in = _grid(g_o, keep)
+        g_o = self._attention_grids(attn, at, keep)
         at.out_q, at.part, at.ticket = self.attn_q.data_ptr(), self.attn_part.data_ptr(), self.attn_ticket.data_ptr()
-        at.consts = self._pack([at.qk_a, at.qk_b, at.qk_out, at.pv_a, at.pv_b, at.pv_out, at.o_in])
-        self.phases.append(("attn", at))
+        phases.append(("attn", at))
         # (3) o_proj + residual from the int8 image
         op = _Linear([attn.o_proj], g_o)
         p3 = self._gemv(op, xq=self.attn_q.data_ptr(), a_grid=_grid(g_o, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
         p3.out_grid[0] = _grid(attn.o_proj.output_quantizer, keep)
-        self.phases.append(("gemv", self._finish_gemv(p3)))
+        phases.append(("gemv", self._finish_gemv(p3)))
         # (4) post_attention_layernorm + interleaved w1|w3 + gated activation + w2's input quantizer
         a2 = MqDecodeGemvArgs()
         g_ffn = self._norm_args(layer.post_attention_layernorm, a2)
@@ -311,56 +430,74 @@ class DecodeEngine:
                         gate_mid=_grid(act.input2_quantizer if isinstance(act, Q.QSiLU) else None, keep),
                         gate_actout=_grid(act.output_quantizer, keep), gate_out=_grid(iq2, keep))
         p4.out_grid[0], p4.out_grid[1] = _grid(mlp.w1.output_quantizer, keep), _grid(mlp.w3.output_quantizer, keep)
-        self.phases.append(("gemv", self._finish_gemv(p4)))
+        phases.append(("gemv", self._finish_gemv(p4)))
         # (5) w2 from the int8 image + residual
         w2 = _Linear([mlp.w2], iq2)
         p5 = self._gemv(w2, xq=self.gate_q.data_ptr(), a_grid=_grid(iq2, keep), resid=self.x.data_ptr(), y=self.x.data_ptr())
         p5.out_grid[0] = _grid(mlp.w2.output_quantizer, keep)
-        self.phases.append(("gemv", self._finish_gemv(p5)))
+        phases.append(("gemv", self._finish_gemv(p5)))
 
     # -- running -------------------------------------------------------------------------------------------------------------
-    def _launch(self):
-        """embedding gather + 5 launches per layer + norm / lm_head, on the current stream; reads self.tok / self.pos."""
+    _ENTRY = {"gemv": "mq_decode_gemv", "attn": "mq_decode_attention", "attn_oproj": "mq_decode_attention_oproj"}
+
+    def _launch(self, phases=None):
+        """embedding gather + 4 (or 5) launches per layer + norm / lm_head, on the current stream; reads self.tok / self.pos."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
         torch.index_select(self.embed, 0, self.tok, out=self.x.view(1, -1))
-        for kind, a in self.phases:
-            _lib.call("mq_decode_gemv" if kind == "gemv" else "mq_decode_attention", ctypes.byref(a), st)
+        for kind, a in (self.phases if phases is None else phases):
+            _lib.call(self._ENTRY[kind], ctypes.byref(a), st)
         _lib.call("mq_decode_head", self.x.data_ptr(), self.norm_w.data_ptr(), self.norm_b.data_ptr() if self.norm_b is not None else None,
                   int(self.norm_ln), float(self.model.norm.eps), self.lm_w.data_ptr(),
                   self.lm_b.data_ptr() if self.lm_b is not None else None, self.shape.hidden, self.shape.vocab, self.logits.data_ptr(), st)
 
-    def _set_splits(self, n: int):
-        for kind, a in self.phases:
-            if kind != "gemv":
+    @staticmethod
+    def _set_splits(phases, n: int):
+        for kind, a in phases:
+            if kind == "attn":
                 a.nsplit = int(n)
 
-    def _splits_at(self, pos: int) -> int:
-        return self.LONG_SPLITS if self.auto_splits and pos >= self.LONG_FROM else self.attn_splits
+    def _variants(self):
+        """[(phases, attention splits)]: what runs below / from self._long_threshold() positions on."""
+        if self.launches == 4:
+            v = [(self.phases, 1)]
+            if self.long_from is not None and self.cache_len > self.long_from:
+                v.append((self.phases_long, self.LONG_SPLITS))
+            return v
+        v = [(self.phases, self.attn_splits)]
+        if self.auto_splits and self.cache_len > self.LONG_FROM:
+            v.append((self.phases, self.LONG_SPLITS))
+        return v
+
+    def _long_threshold(self) -> int:
+        return self.long_from if self.launches == 4 else self.LONG_FROM
+
+    def _variant_at(self, pos: int) -> int:
+        return 1 if len(self._variants()) > 1 and pos >= self._long_threshold() else 0
 
     def capture(self):
-        """Record one decode step (incl. the position increment) as a hipGraph; replay it with step().  With attn_splits=None and a
-        cache longer than LONG_FROM a second graph with the split attention launch is recorded; step() picks by position.
+        """Record one decode step (incl. the position increment) as a hipGraph; replay it with step().  Where a second variant exists
+        (5 launches: the split attention from LONG_FROM cached positions on; 4 launches with long_from: the 5-launch chain from there on)
+        a second graph is recorded; step() picks by position.
         Quantizers changed since the engine was built (recalibration, scale.copy_) are picked up here, in reset() and in prefill()."""
         if self._keep.stale():
             self._lower()
         tok0, pos0, hp0 = self.tok.clone(), self.pos.clone(), self._host_pos
         graphs = []
-        for splits in ([self.attn_splits, self.LONG_SPLITS] if self.auto_splits and self.cache_len > self.LONG_FROM else [self.attn_splits]):
-            self._set_splits(splits)
+        for phases, splits in self._variants():
+            self._set_splits(phases, splits)
             self.attn_ticket.zero_()
             with torch.cuda.device(self.dev):
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    self._launch()
+                    self._launch(phases)
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._launch()
+                    self._launch(phases)
                     self.pos.add_(1)
             graphs.append(g)
             self.tok.copy_(tok0); self.pos.copy_(pos0)
-        self._set_splits(self.attn_splits)
         self._host_pos = hp0
         self.graph, self.graph_long = graphs[0], (graphs[1] if len(graphs) > 1 else None)
         return self
@@ -394,11 +531,12 @@ class DecodeEngine:
         if token is not None:
             self.tok.fill_(int(token))
         if self.graph is not None:
-            (self.graph_long if self.graph_long is not None and self._host_pos >= self.LONG_FROM else self.graph).replay()
+            (self.graph_long if self.graph_long is not None and self._host_pos >= self._long_threshold() else self.graph).replay()
         else:
-            self._set_splits(self._splits_at(self._host_pos))
+            phases, splits = self._variants()[self._variant_at(self._host_pos)]
+            self._set_splits(phases, splits)
             with torch.cuda.device(self.dev):
-                self._launch()
+                self._launch(phases)
             self.pos.add_(1)
         self._host_pos += 1
         return self.logits

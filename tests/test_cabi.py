@@ -55,7 +55,10 @@ def test_library_contains_gfx950_code_only(lib_path):
 def test_binding_loads_and_reports_errors_without_a_gpu(lib_path):
     from mobilequant_amd import _lib
     lib = _lib.load()
-    assert lib.mq_version() >= 200
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mobilequant_amd.h")).read()
+    ver = int(re.search(r"#define MQ_VERSION (\d+)", hdr).group(1))
+    assert lib.mq_version() == ver and ver // 100 == _lib.HEADER_MAJOR      # the ctypes structs mirror this major
     nvar = lib.mq_gemm_set_variant(-1)
     assert nvar >= 4 and lib.mq_gemm_variant_name(0).decode().startswith("t")
     # argument validation happens before any HIP call: null pointers -> MQ_EINVAL + a message, no crash

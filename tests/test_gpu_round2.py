@@ -671,7 +671,7 @@ def test_decode_gemv_modes_against_prefill_kernels(dev):
     q/k/v QLinears; GATE == w1 / w3 -> QSiLU -> product -> w2 input quantizer; INT8 + residual == w2 + add."""
     from mobilequant_amd.decode import DecodeEngine
     m, z = _decode_model(dev)
-    eng = DecodeEngine(m, cache_len=64)
+    eng = DecodeEngine(m, cache_len=64, launches=5)          # the five-launch chain: phases[0] / [3] / [4] are its q|k|v, gate and w2 launches
     layer = m.layers[0]
     x = torch.randn(256, device=dev) * 2
     eng.x.copy_(x)

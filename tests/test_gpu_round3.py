@@ -714,8 +714,8 @@ def test_decode_engine_switches_to_the_split_attention_graph_on_a_long_cache(dev
     m, _ = _decode_model(dev)
     cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=1024))
     m.cos, m.sin = cos.to(dev), sin.to(dev)
-    auto = DecodeEngine(m, cache_len=1024)
-    one = DecodeEngine(m, cache_len=1024, attn_splits=1)
+    auto = DecodeEngine(m, cache_len=1024, launches=5)
+    one = DecodeEngine(m, cache_len=1024, attn_splits=1, launches=5)
     assert auto.auto_splits and not one.auto_splits
     for eng in (auto, one):
         eng.fill_cache_random(DecodeEngine.LONG_FROM - 2, seed=3)

@@ -1,0 +1,178 @@
+"""Round 6 (GPU): the four-launch decode step (csrc/mq_decode.hip: PAIR_ROPE epilogue, decode_attention_oproj_kernel, OPRE prologue).
+
+The new launches evaluate the SAME expressions as the five-launch chain of rounds 2-5 -- RoPE and the QMatMul input quantizers one
+launch earlier, o_proj's contraction as exact integer partial sums inside the attention launch, its epilogue one launch later -- so the
+bar is not a tolerance: logits, KV caches and every intermediate the two chains share must be IDENTICAL bit for bit, at every position,
+for every leaf graph of BASELINE.json's configs[1..3] (llama / StableLM-2 / Gemma shapes, W8 and packed W4).  The five-launch chain
+itself is pinned to the reference's real model by tests/test_gpu_round2.py / round3 (decode_case*.npz, generate_case.npz), which now
+run the four-launch engine by default."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+FAMILIES = {
+    # name: (LlamaShape kwargs, weight bits, per-channel weights)
+    "llama_gqa": (dict(hidden=512, layers=2, heads=8, kv_heads=2, head_dim=64, ffn=1024, vocab=128, max_pos=160), 8, False),
+    "llama_gqa_w4": (dict(hidden=512, layers=2, heads=8, kv_heads=2, head_dim=64, ffn=1024, vocab=128, max_pos=160), 4, True),
+    "stablelm": (dict(hidden=256, layers=2, heads=4, kv_heads=4, head_dim=64, ffn=512, vocab=96, max_pos=160, norm="layernorm", qkv_bias=True,
+                      rotary_pct=0.25), 8, True),
+    "gemma_mqa": (dict(hidden=512, layers=2, heads=2, kv_heads=1, head_dim=256, ffn=1024, vocab=128, max_pos=160, hidden_act="gelu",
+                       embed_scale=True, eps=1e-6), 4, True),
+    "head_dim_32": (dict(hidden=256, layers=2, heads=8, kv_heads=2, head_dim=32, ffn=512, vocab=64, max_pos=160), 8, False),
+    "head_dim_128_mha": (dict(hidden=256, layers=1, heads=2, kv_heads=2, head_dim=128, ffn=512, vocab=64, max_pos=160), 8, False),
+}
+
+
+def _model(dev, name):
+    import mobilequant_amd as mq
+    from mobilequant_amd.calibration import get_act_range
+    from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape
+    kw, wbits, wpc = FAMILIES[name]
+    shape = LlamaShape(**kw)
+    m = LlamaForCausalLM(shape)
+    m.reset_parameters(seed=11, std=0.08)
+    m = m.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, shape.vocab, (1, 48), generator=g)
+    act = get_act_range(m, [ids, torch.randint(0, shape.vocab, (1, 48), generator=g)])
+    a8 = mq.QuantConfig(bitwidth=8)
+    mq.create_sim_qmodel(m, mq.QuantConfig(bitwidth=wbits, is_per_channel=wpc), a8)
+    for n, mod in m.named_modules():                          # ptq/mobilequant.py:175-201
+        if isinstance(mod, mq.QLinear):
+            if "w2" in n:
+                mod.weight_quantizer.qcfg.is_per_channel = True
+                mod.output_quantizer.qcfg.bitwidth = 16
+            elif "o_proj" in n:
+                mod.output_quantizer.qcfg.bitwidth = 16
+        elif isinstance(mod, (mq.QRMSNorm, mq.QLayerNorm)):
+            mod.input_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.bitwidth = 16
+            mod.weight_quantizer.qcfg.is_symmetric = False
+            mod.weight_quantizer.qcfg.is_per_channel = False
+        elif isinstance(mod, mq.QMatMul):
+            if "qk_bmm" in n:
+                mod.output_quantizer.qcfg.bitwidth = 16
+            if "pv_bmm" in n:
+                mod.input_quantizer.qcfg.bitwidth = 16
+    mq.set_scale_and_offset(m, act, "buffer")
+    return m, ids[0]
+
+
+@pytest.mark.parametrize("name", list(FAMILIES))
+def test_four_launch_step_is_the_five_launch_step_bit_for_bit(dev, name):
+    from mobilequant_amd.decode import DecodeEngine
+    m, ids = _model(dev, name)
+    e4 = DecodeEngine(m, cache_len=160)
+    e5 = DecodeEngine(m, cache_len=160, launches=5, attn_splits=1)
+    assert e4.launches == 4 and e5.launches == 5, "the four-launch kernels must serve this geometry"
+    assert len(e4.phases) == 4 * len(m.layers) and len(e5.phases) == 5 * len(m.layers)
+    if FAMILIES[name][1] == 4:
+        assert all(p[1].w4 == 1 for p in e4.phases if p[0] == "gemv")
+    for pos, t in enumerate(ids.tolist()):
+        a = e4.step(t).clone()
+        b = e5.step(t).clone()
+        assert torch.equal(a, b), (name, pos, float((a - b).abs().max()))
+    for li in range(len(m.layers)):                            # the RoPE epilogue's cache append == the attention launch's
+        assert torch.equal(e4.k_cache[li], e5.k_cache[li]) and torch.equal(e4.v_cache[li], e5.v_cache[li]), (name, li)
+    assert torch.equal(e4.x, e5.x)
+    # the captured graph replays the same numbers; a second sequence after reset() too (o_proj's accumulators are cleared per step)
+    e4.reset()
+    e4.capture()
+    e5.reset()
+    for pos, t in enumerate(ids.tolist()[:20]):
+        a = e4.step(t).clone()
+        b = e5.step(t).clone()
+        assert torch.equal(a, b), (name, "graph", pos)
+    # and it still IS the module graph's forward (the budget of test_decode_engine_generic_head_dim_matches_module_graph)
+    with torch.no_grad():
+        want = m(ids[None, :20].to(dev))[0].cpu().numpy()
+    e4.reset()
+    got = np.stack([e4.step(int(t)).cpu().numpy().copy() for t in ids[:20]])
+    span = float(np.ptp(want))
+    d = np.abs(got - want)
+    w4 = FAMILIES[name][1] == 4          # (4-bit GeGLU weights on a random model: a flipped nibble-grid index moves a logit further; observed median 0.0015)
+    assert d.max() <= 0.05 * span and np.median(d) <= (0.003 if w4 else 0.001) * span and (d <= 0.01 * span).mean() >= (0.9 if w4 else 0.97), \
+        (name, d.max() / span, np.median(d) / span, (d <= 0.01 * span).mean())
+
+
+def test_attention_oproj_launch_against_the_old_launch_pair_and_an_integer_matmul(dev):
+    """mq_decode_attention_oproj on its own: the heads' int8 outputs (out_q) are those of mq_decode_attention at the same position and
+    cache, and the accumulators hold o_proj's exact integer sums  sum_k w[n, k] a8[k] - w_zp[n] sum_k a8[k]  of that image
+    (int64 numpy matmul), after being cleared by the q | k | v launch -- at several positions, incl. 0 and a cache block boundary."""
+    from mobilequant_amd import _lib
+    from mobilequant_amd.decode import DecodeEngine
+    m, ids = _model(dev, "llama_gqa")
+    e4 = DecodeEngine(m, cache_len=160, prefetch=0.0)
+    e5 = DecodeEngine(m, cache_len=160, launches=5, attn_splits=1, prefetch=0.0)
+    st = torch.cuda.current_stream().cuda_stream
+    s = m.shape
+    out_q = torch.zeros(s.heads * s.head_dim, dtype=torch.int8, device=dev)
+    at = e4.phases[1][1]
+    at.out_q = out_q.data_ptr()
+    o_w, op = e4.oproj_images[0]                                            # [heads][N][D] int8, the o_proj _Linear
+    w_nk = o_w.permute(1, 0, 2).reshape(s.hidden, s.heads * s.head_dim).cpu().numpy().astype(np.int64)
+    op_zp = op.w_zp.cpu().numpy().astype(np.int64)
+    for pos in (0, 1, 63, 64, 65, 130):
+        for eng in (e4, e5):
+            eng.fill_cache_random(pos, seed=pos)
+            eng.x.copy_(torch.randn(s.hidden, generator=torch.Generator().manual_seed(pos)).to(dev) * 2)
+        e4.o_acc.fill_(12345)                                                # must be cleared by the first launch
+        _lib.call("mq_decode_gemv", ctypes.byref(e4.phases[0][1]), st)
+        _lib.call("mq_decode_attention_oproj", ctypes.byref(at), st)
+        _lib.call("mq_decode_gemv", ctypes.byref(e5.phases[0][1]), st)
+        _lib.call("mq_decode_attention", ctypes.byref(e5.phases[1][1]), st)
+        torch.cuda.synchronize()
+        assert torch.equal(out_q, e5.attn_q), pos
+        assert torch.equal(e4.k_cache[0], e5.k_cache[0]) and torch.equal(e4.v_cache[0], e5.v_cache[0]), pos
+        a8 = out_q.cpu().numpy().astype(np.int64)
+        want = w_nk @ a8
+        acc = e4.o_acc.cpu().numpy().astype(np.int64)
+        assert np.array_equal(acc, want - op_zp * a8.sum()), pos
+
+
+def test_four_launch_engine_hands_over_to_the_five_launch_graph_on_a_long_cache(dev):
+    """DecodeEngine(long_from=n): positions >= n replay the five-launch chain with the split attention; the two chains share the cache,
+    the residual stream and the position, so the logits are the one-chain engine's on both sides of the switch, bit for bit."""
+    import dataclasses
+    from mobilequant_amd import llama
+    from mobilequant_amd.decode import DecodeEngine
+    m, ids = _model(dev, "llama_gqa")
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=1024))
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    both = DecodeEngine(m, cache_len=1024, long_from=130)
+    four = DecodeEngine(m, cache_len=1024)
+    assert both.launches == 4 and both.phases_long and not four.phases_long
+    for eng in (both, four):
+        eng.fill_cache_random(128, seed=3)
+        eng.capture()
+    assert both.graph_long is not None and four.graph_long is None
+    for t in (5, 17, 40, 3, 90):                         # two steps below long_from, three from it on
+        a = both.step(t).clone()
+        b = four.step(t).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (both._host_pos, float((a - b).abs().max()))
+    assert both._host_pos == 133
+
+
+def test_a_geometry_the_four_launch_kernels_do_not_serve_falls_back_to_five(dev):
+    from mobilequant_amd.decode import DecodeEngine
+    from mobilequant_amd.llama import LlamaShape
+    assert DecodeEngine._oproj_geometry(LlamaShape.tinyllama(), 64) == (8, 1)
+    assert DecodeEngine._oproj_geometry(LlamaShape.gemma_2b(), 256) == (32, 4)
+    assert DecodeEngine._oproj_geometry(LlamaShape.stablelm_2_1_6b(), 16) == (8, 1)
+    assert DecodeEngine._oproj_geometry(LlamaShape(hidden=8192, heads=64, kv_heads=8, head_dim=128), 128) is None      # K > 4096: OPRE prologue

@@ -36,7 +36,7 @@ def build_engine(dev, layers, wbits=8, cache_len=1024):
             if "qk_bmm" in name: mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name: mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '1')), prefetch_delay_us=float(os.environ.get('PFDELAY', '1.5')))
+    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '0.5')), prefetch_delay_us=float(os.environ.get('PFDELAY', '1.5')), launches=int(os.environ.get('LAUNCHES', '4')))
 
 
 def main():
