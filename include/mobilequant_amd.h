@@ -500,8 +500,7 @@ typedef struct mq_decode_attention_oproj_args {
   const float* qkv;
   int8_t* k_cache;
   int8_t* v_cache;
-  const float* cos;
-  const float* sin;
+  const float* rope_row; /* {cos[*pos][0 .. rot_dim), sin[*pos][0 .. rot_dim)}: staged once per token by mq_decode_embed */
   const int* pos;
   int heads, kv_heads, head_dim, cache_len, rot_dim;
   mq_grid qk_a, qk_b, qk_out, pv_a, pv_b, pv_out, o_in;
@@ -510,12 +509,19 @@ typedef struct mq_decode_attention_oproj_args {
   const int32_t* o_wzp;
   int32_t* o_acc;
   int N, slices, tpr;
+  int lg_slices, lg_group, lg_kv; /* log2 of slices, heads / kv_heads, kv_heads when all three are powers of two (the workgroup -> (head,
+                                   * slice) mapping then needs no integer division in front of the launch's first request); lg_slices = -1: generic */
   int8_t* out_q;
   const int8_t* prefetch;
   int64_t prefetch_bytes_per_wg, prefetch_stride, prefetch_total;
   int prefetch_wgs, prefetch_delay;
 } mq_decode_attention_oproj_args;
 int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_stream_t stream);
+/* Token start (sim_model.py:160-175: embed_tokens of the new token): x [hidden] <- table [vocab, hidden] row *tok, and (rope_row != NULL)
+ * rope_row [2 * rot_dim] <- {cos[*pos], sin[*pos]} of the tables cos / sin [max_pos, rot_dim] -- the one launch of a token that chases
+ * *pos, so that every layer's mq_decode_attention_oproj reads a fixed address. */
+int mq_decode_embed(const float* table, const int64_t* tok, int64_t hidden, int64_t vocab, const float* cos, const float* sin, const int* pos,
+                    int rot_dim, int max_pos, float* x, float* rope_row, mq_stream_t stream);
 
 /* Final norm (floating point: the surgery skips it, qmodule.py:843) fused in front of the fp32 lm_head stream: logits[v] = sum_k
  * w[v,k] * norm(x)[k] (+ bias[v]).  layernorm = 0: HFRMSNorm (norm_weight NULL = no norm, norm_bias unused); layernorm = 1:

@@ -40,11 +40,12 @@ class MqDecodeGemvArgs(ctypes.Structure):
 
 
 class MqDecodeAttentionOprojArgs(ctypes.Structure):
-    _fields_ = [("qkv", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("pos", c_void_p),
+    _fields_ = [("qkv", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p), ("rope_row", c_void_p), ("pos", c_void_p),
                 ("heads", c_int), ("kv_heads", c_int), ("head_dim", c_int), ("cache_len", c_int), ("rot_dim", c_int),
                 ("qk_a", MqGrid), ("qk_b", MqGrid), ("qk_out", MqGrid), ("pv_a", MqGrid),
                 ("pv_b", MqGrid), ("pv_out", MqGrid), ("o_in", MqGrid), ("consts", c_void_p), ("o_w", c_void_p), ("o_wzp", c_void_p),
-                ("o_acc", c_void_p), ("N", c_int), ("slices", c_int), ("tpr", c_int), ("out_q", c_void_p), ("prefetch", c_void_p),
+                ("o_acc", c_void_p), ("N", c_int), ("slices", c_int), ("tpr", c_int), ("lg_slices", c_int), ("lg_group", c_int), ("lg_kv", c_int),
+                ("out_q", c_void_p), ("prefetch", c_void_p),
                 ("prefetch_bytes_per_wg", c_int64), ("prefetch_stride", c_int64), ("prefetch_total", c_int64), ("prefetch_wgs", c_int),
                 ("prefetch_delay", c_int)]
 
@@ -135,6 +136,7 @@ _SIGNATURES = {
     "mq_decode_gemv_geometry": (c_int, [POINTER(MqDecodeGemvArgs), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mq_decode_attention": (c_int, [POINTER(MqDecodeAttentionArgs), _P]),
     "mq_decode_attention_oproj": (c_int, [POINTER(MqDecodeAttentionOprojArgs), _P]),
+    "mq_decode_embed": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     "mq_decode_head": (c_int, [_P, _P, _P, c_int, c_float, _P, _P, c_int64, c_int64, _P, _P]),
     "mq_attention_quant": (c_int, [POINTER(MqAttentionArgs), _P]),
     "mq_calib_attention_probs": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, _P]),

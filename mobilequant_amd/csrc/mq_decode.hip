@@ -840,18 +840,26 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
 //   * o_proj's 16 KB per workgroup are requested behind the scores (hipcc waits vmcnt(0) at the head of the score loop: weights from
 //     HBM in front of it held the scores back by ~1.3 us) and are in registers long before the head's output exists.
 // o_proj: thread (r = tid / tpr, sub = tid % tpr) holds cpt = D / 16 / tpr 16-byte chunks of row c R + r of head h's slice.
+// Threads per workgroup.  256 (one wave per SIMD) is the measured optimum: the phases of this launch are bound by the instructions
+// every WAVE executes (grids, addresses, reductions, barriers), not by per-position work, so 1024 threads quadruple that overhead on
+// the same four SIMDs: 1 668 tok/s at 256 threads against 1 505 at 1 024 (profiles/r06/decode_stamps_L4_1024_threads.log).
+constexpr int AO_THREADS = 256;
 template <int D>
-__global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
-  constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = 256 / LPP, KB = 8 / CH;
-  constexpr int DQ = D / 4, G = 256 / DQ, PPB = 64 / G, VB = 16;
+__global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
+  // Geometry (NT threads).  Scores: LPP lanes per cached position (CH 16-byte chunks of the key row each), PPP positions per pass, KB
+  // passes = 512 positions requested at the top.  p.v: thread (dq = dword of 4 dims, grp) owns one position of every G-position stripe;
+  // BLK positions per block, PPB stripes per block; VB stripes (<= 32 registers: 512 positions at head_dim 64) requested at the top.
+  constexpr int NT = AO_THREADS, NW = NT / 64;
+  constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = NT / LPP, KB = 512 / PPP >= 1 ? 512 / PPP : 1;
+  constexpr int DQ = D / 4, G = NT / DQ, BLK = G > 64 ? G : 64, PPB = BLK / G, VB = 512 / G > 32 ? 32 : (512 / G >= 1 ? 512 / G : 1);
   constexpr int MAXC = D / 16 < 8 ? D / 16 : 8;                    // 16-byte chunks of an o_proj row slice per thread
-  static_assert(PPB * G == 64 && VB % PPB == 0, "block mapping");
+  static_assert(PPB * G == BLK && G * DQ == NT, "block mapping");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_sc = reinterpret_cast<float*>(smem_raw);              // [cache_len] scores -> exp -> (p index - zp) as int
   __shared__ __attribute__((aligned(16))) int8_t s_q8[D], s_k8[D], s_v8[D], s_a8[D];
-  __shared__ float s_redf[4];
-  __shared__ int s_redq[4];
-  __shared__ long long s_acc[1024];                              // [G][D] partial p.v sums
+  __shared__ float s_redf[NW];
+  __shared__ int s_redq[NW];
+  __shared__ long long s_acc[G * D];                             // [G][D] partial p.v sums (32 KB)
   const int H = a.heads, W = H * a.slices, rot = a.rot_dim;
   if ((int)blockIdx.x >= W) {                                      // L2 prefetch role (see decode_attention_kernel)
     const int q = (int)blockIdx.x - W;
@@ -864,10 +872,10 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
     const v4i* p = reinterpret_cast<const v4i*>(a.prefetch + beg);
     const size_t n = end > beg ? (end - beg) >> 4 : 0;
     v4i acc = {0, 0, 0, 0};
-    for (size_t i = threadIdx.x; i < n; i += 256 * 8) {
+    for (size_t i = threadIdx.x; i < n; i += NT * 8) {
       v4i b[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) b[u] = p[i + (size_t)u * 256 < n ? i + (size_t)u * 256 : i];
+      for (int u = 0; u < 8; ++u) b[u] = p[i + (size_t)u * NT < n ? i + (size_t)u * NT : i];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc |= b[u];
     }
@@ -877,60 +885,81 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
   DG_STAMP(0);
   // workgroup -> (head, row range).  With kv_heads dividing 8 and W a multiple of 8: XCD x = block % 8 serves KV head x / (8 / kv_heads),
   // so the slices * (heads / kv_heads) workgroups that sweep the same keys / values share an L2 (observed placement: speed only).
-  int h, c;
+  // (heads per KV head, KV heads and slices are powers of two in every model of the family: the host passes their logarithms, so that
+  // no integer division sits in front of this launch's first request -- eight of them cost ~0.3 us; lg_slices < 0: the generic mapping)
+  int h, c, kvh;
   {
-    const int b = blockIdx.x, kvh_n = a.kv_heads, per_kv = W / kvh_n;                 // workgroups per KV head
-    if (kvh_n <= 8 && 8 % kvh_n == 0 && W % 8 == 0 && per_kv % (8 / kvh_n) == 0) {
-      const int xs = 8 / kvh_n, x = b & 7, i = b >> 3;
-      const int j = (x % xs) * (per_kv / xs) + i;                                     // 0 .. per_kv - 1 inside KV head x / xs
-      h = (x / xs) * (H / kvh_n) + j / a.slices;
-      c = j % a.slices;
+    const int b = blockIdx.x;
+    if (a.lg_slices >= 0) {
+      const int lgs = a.lg_slices, lgg = a.lg_group, lgk = a.lg_kv;             // slices, heads per KV head, KV heads
+      if (lgk <= 3) {
+        const int lgx = 3 - lgk, x = b & 7, i = b >> 3;                          // 2^lgx XCDs per KV head
+        const int lg_per_x = lgs + lgg - lgx;                                     // workgroups of a KV head per XCD (W / 8 >= 1 by the host's check)
+        const int j = ((x & ((1 << lgx) - 1)) << lg_per_x) + i;                   // 0 .. per_kv - 1 inside KV head x >> lgx
+        kvh = x >> lgx;
+        h = (kvh << lgg) + (j >> lgs);
+        c = j & ((1 << lgs) - 1);
+      } else {
+        h = b >> lgs;
+        c = b & ((1 << lgs) - 1);
+        kvh = h >> lgg;
+      }
     } else {
       h = b / a.slices;
       c = b % a.slices;
+      kvh = h / (H / a.kv_heads);
     }
   }
-  const int kvh = h / (H / a.kv_heads);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float cv = a.consts[lane];
-  // the new token's q / k / v rows (fp32 outputs of the q|k|v launch) and their RoPE partners: independent of the position
+  // the new token's q / k / v rows (fp32 outputs of the q|k|v launch), their RoPE partners and the cos / sin row of this position
+  // (rope_row: staged once per token by mq_decode_embed, so that no request of this launch waits for *pos)
   const float* qp = a.qkv + (size_t)h * D;
   const float* kp = a.qkv + (size_t)H * D + (size_t)kvh * D;
   const float* vp = a.qkv + (size_t)(H + a.kv_heads) * D + (size_t)kvh * D;
   const int dd = tid < D ? tid : D - 1;
   const int half = rot >> 1;
   const int dpart = dd < rot ? (dd < half ? dd + half : dd - half) : dd;
+  const int dr = dd < rot ? dd : 0;
   const float q_raw = qp[dd], q_par = qp[dpart], k_raw = kp[dd], k_par = kp[dpart], v_raw = vp[dd];
+  const float cs = a.rope_row[dr], sn = a.rope_row[rot + dr];
   const int CL = a.cache_len;
   const int8_t* kc = a.k_cache + (size_t)kvh * CL * D;
   const int8_t* vc = a.v_cache + (size_t)kvh * CL * D;
-  // ---- key loads of the first batch, value loads of the first TWO batches (addresses clamped by the cache length, masked by T below) ----
+  // ---- keys and values of the first 512 positions: the first 256 before *pos is known (addresses clamped by the cache length, masked by
+  // T below), the rest behind it clamped by the position (beyond it every lane reads position 0: one line) -- requesting all 512
+  // unconditionally made every workgroup pull 64 KB through its L1 at the head of the launch, 0.5 us at context 256
   const int sub = tid & (LPP - 1), slot = tid / LPP;
   v4i kbuf[KB][CH];
-#pragma unroll
-  for (int u = 0; u < KB; ++u) {
+  auto load_keys = [&](int u, int lim) {
     const int t = u * PPP + slot;
-    const int tc = t < CL ? t : 0;                                  // position 0 stands in (always valid memory)
+    const int tc = t < lim ? t : 0;                                 // position 0 stands in (always valid memory)
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
-  }
+  };
   const int dq = tid & (DQ - 1), grp = tid / DQ;
-  auto item_pos = [&](int i) { return 64 * (i / PPB) + grp + G * (i % PPB); };   // PPB: a power of two (shifts)
-  int vbuf[2][VB];
+  auto item_pos = [&](int i) { return BLK * (i / PPB) + grp + G * (i % PPB); };   // PPB: a power of two (shifts)
+  int vbuf[VB];
+  auto load_value = [&](int u, int lim) {
+    const int t = item_pos(u);
+    vbuf[u] = *reinterpret_cast<const int*>(vc + (size_t)(t < lim ? t : 0) * D + dq * 4);
+  };
 #pragma unroll
-  for (int bb = 0; bb < 2; ++bb)
+  for (int u = 0; u < KB; ++u)
+    if ((u + 1) * PPP <= 256 || u == 0) load_keys(u, CL);
 #pragma unroll
-    for (int u = 0; u < VB; ++u) {
-      const int t = item_pos(bb * VB + u);
-      vbuf[bb][u] = *reinterpret_cast<const int*>(vc + (size_t)(t < CL ? t : 0) * D + dq * 4);
-    }
+  for (int u = 0; u < VB; ++u)
+    if (BLK * (u / PPB) + G * (u % PPB) + G <= 256 || u == 0) load_value(u, CL);
   int pos;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
   const bool live = pos >= 0 && pos < CL;                           // a step past the cache: nothing is written (the host raises first)
   const int T = live ? pos + 1 : 0;
-  const int pc = live ? pos : 0;
-  const int dr = dd < rot ? dd : 0;
-  const float cs = a.cos[(size_t)pc * rot + dr], sn = a.sin[(size_t)pc * rot + dr];
+#pragma unroll
+  for (int u = 0; u < KB; ++u)
+    if (!((u + 1) * PPP <= 256 || u == 0)) load_keys(u, T);
+#pragma unroll
+  for (int u = 0; u < VB; ++u)
+    if (!(BLK * (u / PPB) + G * (u % PPB) + G <= 256 || u == 0)) load_value(u, T);
   // ---- RoPE + the three input quantizers of the new token ---------------------------------------------------------------------------
   const Grid qa = const_grid(cv, AG_QK_A, a.qk_a), qb = const_grid(cv, AG_QK_B, a.qk_b), qo = const_grid(cv, AG_QK_OUT, a.qk_out);
   const Grid pa = const_grid(cv, AG_PV_A, a.pv_a), pb = const_grid(cv, AG_PV_B, a.pv_b), po = const_grid(cv, AG_PV_OUT, a.pv_out);
@@ -950,18 +979,20 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
     s_k8[tid] = (int8_t)sk;
     s_v8[tid] = (int8_t)sv;
     qsum_part = sq;
-    if (live && c == 0 && h % (H / a.kv_heads) == 0) {             // the group's first head (its first slice) appends to the cache
+    if (live && c == 0 && h == kvh * (H / a.kv_heads)) {           // the group's first head (its first slice) appends to the cache
       a.k_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sk;
       a.v_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sv;
     }
   }
-  {
+  if (wv < (D + 63) / 64) {                                        // (the waves that hold the D query bytes)
     const int w = wave_sum_dpp(qsum_part);
     if (lane == 0) s_redq[wv] = w;
   }
   __syncthreads();
   DG_STAMP(1);
-  const int qsum = (s_redq[0] + s_redq[1]) + (s_redq[2] + s_redq[3]);
+  int qsum = 0;
+#pragma unroll
+  for (int w = 0; w < (D + 63) / 64; ++w) qsum += s_redq[w];
   const int zq = (int)qa.o - 128, zk = (int)qb.o - 128, zv = (int)pb.o - 128, zp = (int)pa.o;
   const float alpha_qk = __fmul_rn(qa.s, qb.s), alpha_pv = __fmul_rn(pa.s, pb.s);
   const int qconst = D * zq * zk - zk * qsum;                      // sum (iq - zq)(ik - zk) = sum sq sk - zk sum sq - zq sum sk + D zq zk
@@ -1010,9 +1041,10 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
   }
   lmax = wave_max_f(lmax);
   if (lane == 0) s_redf[wv] = lmax;
-  // o_proj's weights are requested HERE, behind the scores (see the header comment); needed ~3 us from now
-  const int R = a.N / a.slices, tpr = a.tpr, cpt = (D / 16) / tpr;
-  const int orow = tid / tpr, osub = tid % tpr;
+  // o_proj's weights are requested HERE, behind the scores (see the header comment); needed ~2 us from now
+  const int tpr = a.tpr, lgt = tpr == 4 ? 2 : (tpr == 2 ? 1 : 0);
+  const int R = a.lg_slices >= 0 ? a.N >> a.lg_slices : a.N / a.slices, cpt = (D / 16) >> lgt;
+  const int orow = tid >> lgt, osub = tid & (tpr - 1);
   const bool o_ok = orow < R;
   const int n_out = c * R + (o_ok ? orow : 0);
   v4i wbuf[MAXC];
@@ -1024,20 +1056,35 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
   const int o_zp = a.o_wzp[n_out];
   __syncthreads();
   DG_STAMP(2);
-  const float mx = fmaxf(fmaxf(s_redf[0], s_redf[1]), fmaxf(s_redf[2], s_redf[3]));
+  float mx = s_redf[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mx = fmaxf(mx, s_redf[w]);
   __syncthreads();
-  float lsum = 0.f;
-  for (int t = tid; t < T; t += 256) {
-    const float e = expf(s_sc[t] - mx);
-    s_sc[t] = e;
-    lsum += e;
+  // The sum of the exponentials is a FLOAT sum: its order is part of the result -- thread j adds e[j], e[j + 256], ... in that order, DPP
+  // tree per wave, (w0 + w1) + (w2 + w3), as decode_attention_kernel's 256 threads do (with more threads: the first four waves, from LDS)
+  if constexpr (NT == 256) {
+    float lsum = 0.f;
+    for (int t = tid; t < T; t += 256) {
+      const float e = expf(s_sc[t] - mx);
+      s_sc[t] = e;
+      lsum += e;
+    }
+    lsum = wave_sum_f(lsum);
+    if (lane == 0) s_redf[wv] = lsum;
+  } else {
+    for (int t = tid; t < T; t += NT) s_sc[t] = expf(s_sc[t] - mx);
+    __syncthreads();
+    if (wv < 4) {
+      float lsum = 0.f;
+      for (int t = tid; t < T; t += 256) lsum += s_sc[t];
+      lsum = wave_sum_f(lsum);
+      if (lane == 0) s_redf[wv] = lsum;
+    }
   }
-  lsum = wave_sum_f(lsum);
-  if (lane == 0) s_redf[wv] = lsum;
   __syncthreads();
   const float tot_e = (s_redf[0] + s_redf[1]) + (s_redf[2] + s_redf[3]);
   int* s_pi = reinterpret_cast<int*>(s_sc);
-  for (int t = tid; t < T; t += 256) {
+  for (int t = tid; t < T; t += NT) {
     const float p = __fdiv_rn(s_sc[t], tot_e);
     const float ip = dq_index(p, pa.s, pa.inv_s, pa.o, pa.qmin, pa.qmax);
     s_pi[t] = (ip != ip ? 0 : (int)ip) - zp;
@@ -1047,36 +1094,31 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
   // ---- p.v over the cached positions t < pos: exact integers; the new position from registers -----------------------------------------
   long long acc[4] = {0, 0, 0, 0};
   long long psum = 0;
-  const int nblk = (pos + 63) >> 6;                                  // blocks of CACHED positions 0 .. pos - 1
+  const int nblk = (pos + BLK - 1) / BLK;                            // blocks of CACHED positions 0 .. pos - 1
   const int items = live ? nblk * PPB : 0;
-  for (int i0 = 0; i0 < items; i0 += 2 * VB) {
-    if (i0 > 0) {                                                   // later double batches (512 positions each): one exposed round trip each
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int u = 0; u < VB; ++u) {
-          const int t = item_pos(i0 + bb * VB + u);
-          vbuf[bb][u] = *reinterpret_cast<const int*>(vc + (size_t)(t < pos ? t : 0) * D + dq * 4);
-        }
-    }
-#pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      int a32[4] = {0, 0, 0, 0}, p32 = 0;                            // <= 16 positions x 65535 x 128 < 2^31
+  for (int i0 = 0; i0 < items; i0 += VB) {
+    if (i0 > 0) {                                                   // later batches (512 positions each): one exposed round trip each
 #pragma unroll
       for (int u = 0; u < VB; ++u) {
-        const int i = i0 + bb * VB + u;
-        const int t = item_pos(i);
-        const bool ok = i < items && t < pos;
-        const int pi = s_pi[ok ? t : 0];
-        const int pim = ok ? pi : 0;
-        p32 += pim;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a32[e] += (int)__builtin_amdgcn_sbfe(vbuf[bb][u], 8 * e, 8) * pim;      // (the builtin returns unsigned)
+        const int t = item_pos(i0 + u);
+        vbuf[u] = *reinterpret_cast<const int*>(vc + (size_t)(t < pos ? t : 0) * D + dq * 4);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += a32[e];
-      psum += p32;
     }
+    int a32[4] = {0, 0, 0, 0}, p32 = 0;                              // <= 32 positions x 65535 x 128 < 2^31
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int i = i0 + u;
+      const int t = item_pos(i);
+      const bool ok = i < items && t < pos;                         // (a uniform `break` at i >= items was tried: 1.9 -> 2.6 us for this sweep)
+      const int pi = s_pi[ok ? t : 0];
+      const int pim = ok ? pi : 0;
+      p32 += pim;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a32[e] += (int)__builtin_amdgcn_sbfe(vbuf[u], 8 * e, 8) * pim;      // (the builtin returns unsigned)
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += a32[e];
+    psum += p32;
   }
   if (grp == 0 && live) {                                            // the new position: group 0 adds it from registers
     const int sv4 = *reinterpret_cast<const int*>(s_v8 + dq * 4);
@@ -1091,25 +1133,52 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
   for (int e = 0; e < 4; ++e) s_acc[grp * D + dq * 4 + e] = acc[e];
   __syncthreads();
   DG_STAMP(4);
+  // the G partial sums of a dimension: NT / D threads per dimension add G D / NT of them each (exact integers: any order), then the
+  // dimension's threads meet through DPP (they are adjacent lanes: NT / D <= 16 is a power of two)
+  constexpr int TPD = NT / D >= 16 ? 16 : NT / D, GPT = G / TPD;     // threads per dimension, partial sums per thread
+  static_assert(TPD * GPT == G, "combine mapping");
   int a_byte = 0;
-  if (tid < D) {
+  {
+    const int d = tid / TPD, part_i = tid % TPD;
     long long tot = 0;
+    if (tid < D * TPD) {
 #pragma unroll
-    for (int gq = 0; gq < G; ++gq) tot += s_acc[gq * D + tid];
-    const float pre = (float)((double)tot * (double)alpha_pv);     // one rounding of the exact sum (as mq_attention.hip)
-    const float y = po.fq(pre);
-    const float qi = dq_index(y, oi.s, oi.inv_s, oi.o, oi.qmin, oi.qmax);
-    a_byte = (qi != qi ? (int)oi.qmin : (int)qi) - 128;
-    s_a8[tid] = (int8_t)a_byte;
-    if (a.out_q && c == 0 && live) a.out_q[(size_t)h * D + tid] = (int8_t)a_byte;
+      for (int gq = 0; gq < GPT; ++gq) tot += s_acc[(part_i * GPT + gq) * D + d];
+    }
+    // 64-bit sum over TPD adjacent lanes: two 32-bit DPP moves per step
+    unsigned lo = (unsigned)tot, hi = (unsigned)((unsigned long long)tot >> 32);
+#define MQ_AO_STEP(CTRL)                                                                                                   \
+  {                                                                                                                        \
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);                            \
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);                            \
+    const unsigned long long sum = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)ohi << 32) | olo);         \
+    lo = (unsigned)sum;                                                                                                    \
+    hi = (unsigned)(sum >> 32);                                                                                            \
+  }
+    if (TPD >= 2) MQ_AO_STEP(0xB1)                                  // quad_perm [1,0,3,2]
+    if (TPD >= 4) MQ_AO_STEP(0x4E)                                  // quad_perm [2,3,0,1]
+    if (TPD >= 8) MQ_AO_STEP(0x141)                                 // row_half_mirror
+    if (TPD >= 16) MQ_AO_STEP(0x140)                                // row_mirror
+#undef MQ_AO_STEP
+    tot = (long long)(((unsigned long long)hi << 32) | lo);
+    if (tid < D * TPD && part_i == 0) {
+      const float pre = (float)((double)tot * (double)alpha_pv);   // one rounding of the exact sum (as mq_attention.hip)
+      const float y = po.fq(pre);
+      const float qi = dq_index(y, oi.s, oi.inv_s, oi.o, oi.qmin, oi.qmax);
+      a_byte = (qi != qi ? (int)oi.qmin : (int)qi) - 128;
+      s_a8[d] = (int8_t)a_byte;
+      if (a.out_q && c == 0 && live) a.out_q[(size_t)h * D + d] = (int8_t)a_byte;
+    }
   }
   {
-    const int w = wave_sum_dpp(a_byte);                            // (lanes beyond D contribute 0)
+    const int w = wave_sum_dpp(a_byte);                            // (threads that hold no output byte contribute 0)
     if (lane == 0) s_redq[wv] = w;
   }
   __syncthreads();
   // ---- o_proj: rows [c R, (c + 1) R) x K-slice [h D, (h + 1) D) ---------------------------------------------------------------------
-  const int rs_h = (s_redq[0] + s_redq[1]) + (s_redq[2] + s_redq[3]);
+  int rs_h = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) rs_h += s_redq[w];
   int part = 0;
 #pragma unroll
   for (int j = 0; j < MAXC; ++j)
@@ -1124,6 +1193,25 @@ __global__ void __launch_bounds__(256) decode_attention_oproj_kernel(const mq_de
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   DG_STAMP(5);
 #endif
+}
+
+// ---- token start: embedding row + the RoPE row of this position ---------------------------------------------------------------------
+// x <- table[*tok] (embed_tokens; a scaled table carries Gemma's normalize_embed) and rope_row <- {cos[*pos][0 .. rot), sin[*pos][0 .. rot)}:
+// the one place of a token that chases *pos, so that the 22 attention launches read a FIXED address instead of a pos -> cos / sin chain
+// (two dependent round trips at the head of each: 0.8 us of 6).  A step past the table reads row 0 (the launches behind it store nothing).
+__global__ void __launch_bounds__(256) decode_embed_kernel(const float* __restrict__ table, const long long* __restrict__ tok, int hidden, long long vocab,
+                                                           const float* __restrict__ cosr, const float* __restrict__ sinr, const int* __restrict__ pos, int rot,
+                                                           int max_pos, float* __restrict__ x, float* __restrict__ rope_row) {
+  const long long tk = tok[0];
+  const long long row = (tk >= 0 && tk < vocab) ? tk : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < hidden; i += gridDim.x * 256) x[i] = table[(size_t)row * hidden + i];
+  if (blockIdx.x == 0 && rope_row) {
+    const int p = pos[0], pc = (p >= 0 && p < max_pos) ? p : 0;
+    for (int i = threadIdx.x; i < rot; i += 256) {
+      rope_row[i] = cosr[(size_t)pc * rot + i];
+      rope_row[rot + i] = sinr[(size_t)pc * rot + i];
+    }
+  }
 }
 
 // ---- final norm (floating point HFRMSNorm) + lm_head (fp32 weights) ----------------------------------------------------------------
@@ -1365,7 +1453,7 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
 int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_stream_t stream) {
   MQ_REQUIRE(args != nullptr, "mq_decode_attention_oproj: null argument block");
   const mq_decode_attention_oproj_args& a = *args;
-  MQ_REQUIRE(a.qkv && a.k_cache && a.v_cache && a.cos && a.sin && a.pos && a.consts && a.o_w && a.o_wzp && a.o_acc, "mq_decode_attention_oproj: null pointer");
+  MQ_REQUIRE(a.qkv && a.k_cache && a.v_cache && a.rope_row && a.pos && a.consts && a.o_w && a.o_wzp && a.o_acc, "mq_decode_attention_oproj: null pointer");
   MQ_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0 && (a.head_dim == 32 || a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256) &&
                  a.cache_len > 0 && a.cache_len <= 32768 && a.rot_dim > 0 && a.rot_dim <= a.head_dim && a.rot_dim % 2 == 0,
              "mq_decode_attention_oproj: heads=%d kv_heads=%d head_dim=%d (32 / 64 / 128 / 256) cache_len=%d (<= 32768) rot_dim=%d", a.heads, a.kv_heads, a.head_dim,
@@ -1376,10 +1464,13 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
   MQ_REQUIRE(a.o_in.scale && a.o_in.qmin == 0.f && a.o_in.qmax == 255.f, "mq_decode_attention_oproj: o_proj needs an 8-bit unsigned input grid (o_in)");
   const int chunks = a.head_dim / 16;
   MQ_REQUIRE(a.N > 0 && a.slices > 0 && a.N % a.slices == 0 && (a.tpr == 1 || a.tpr == 2 || a.tpr == 4) && chunks % a.tpr == 0 && chunks / a.tpr <= 8 &&
-                 (a.N / a.slices) * a.tpr <= 256 && (long long)a.heads * a.slices <= 65535,
+                 (a.N / a.slices) * a.tpr <= AO_THREADS && (long long)a.heads * a.slices <= 65535,
              "mq_decode_attention_oproj: N=%d slices=%d tpr=%d: N %% slices == 0, tpr in {1, 2, 4} dividing head_dim / 16 with <= 8 chunks per thread, "
-             "N / slices * tpr <= 256", a.N, a.slices, a.tpr);
-  MQ_REQUIRE(aligned(a.k_cache, 16) && aligned(a.v_cache, 16) && aligned(a.consts, 16) && aligned(a.qkv, 4) && aligned(a.o_w, 16),
+             "N / slices * tpr <= %d", a.N, a.slices, a.tpr, AO_THREADS);
+  MQ_REQUIRE(a.lg_slices < 0 || ((1 << a.lg_slices) == a.slices && (1 << a.lg_kv) == a.kv_heads && (a.kv_heads << a.lg_group) == a.heads &&
+                                 (a.lg_kv > 3 || a.lg_slices + a.lg_group >= 3 - a.lg_kv)),
+             "mq_decode_attention_oproj: lg_slices / lg_group / lg_kv must be the logarithms of slices, heads / kv_heads, kv_heads (or lg_slices < 0)");
+  MQ_REQUIRE(aligned(a.k_cache, 16) && aligned(a.v_cache, 16) && aligned(a.consts, 16) && aligned(a.qkv, 4) && aligned(a.o_w, 16) && aligned(a.rope_row, 4),
              "mq_decode_attention_oproj: caches / consts / o_w must be 16-byte aligned");
   MQ_REQUIRE(a.prefetch_wgs == 0 || (a.prefetch && aligned(a.prefetch, 16) && a.prefetch_bytes_per_wg % 16 == 0 && a.prefetch_wgs > 0 && a.prefetch_wgs <= 4096 &&
                                     a.prefetch_stride >= a.prefetch_bytes_per_wg && a.prefetch_stride % 16 == 0 && a.prefetch_delay >= 0 && a.prefetch_delay <= 100000),
@@ -1391,7 +1482,7 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
                                        : reinterpret_cast<const void*>(decode_attention_oproj_kernel<256>);
   static std::atomic<size_t> lds_set[kMaxDevices][4];
   const int dev = current_device(), ki = a.head_dim == 32 ? 0 : a.head_dim == 64 ? 1 : a.head_dim == 128 ? 2 : 3;
-  if (lds > 32768 && lds_set[dev][ki].load(std::memory_order_relaxed) < lds) {
+  if (lds > 16384 && lds_set[dev][ki].load(std::memory_order_relaxed) < lds) {      // (the kernel holds ~33 KB of static LDS)
     MQ_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                "mq_decode_attention_oproj: %zu bytes of dynamic LDS rejected", lds);
     lds_set[dev][ki].store(lds, std::memory_order_relaxed);
@@ -1400,12 +1491,23 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
   unsigned long long* stamps = STAMP_SLOT(4, (unsigned)(a.heads * a.slices));
   hipStream_t st = as_stream(stream);
   switch (a.head_dim) {
-    case 32: decode_attention_oproj_kernel<32><<<grid, 256, lds, st>>>(a, stamps); break;
-    case 64: decode_attention_oproj_kernel<64><<<grid, 256, lds, st>>>(a, stamps); break;
-    case 128: decode_attention_oproj_kernel<128><<<grid, 256, lds, st>>>(a, stamps); break;
-    default: decode_attention_oproj_kernel<256><<<grid, 256, lds, st>>>(a, stamps); break;
+    case 32: decode_attention_oproj_kernel<32><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
+    case 64: decode_attention_oproj_kernel<64><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
+    case 128: decode_attention_oproj_kernel<128><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
+    default: decode_attention_oproj_kernel<256><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
   }
   MQ_LAUNCH_CHECK("mq_decode_attention_oproj");
+  return MQ_OK;
+}
+
+int mq_decode_embed(const float* table, const int64_t* tok, int64_t hidden, int64_t vocab, const float* cos, const float* sin, const int* pos,
+                    int rot_dim, int max_pos, float* x, float* rope_row, mq_stream_t stream) {
+  MQ_REQUIRE(table && tok && x && hidden > 0 && vocab > 0, "mq_decode_embed: null pointer / empty table");
+  MQ_REQUIRE(!rope_row || (cos && sin && pos && rot_dim > 0 && max_pos > 0), "mq_decode_embed: rope_row needs cos / sin / pos, rot_dim and max_pos");
+  const unsigned grid = (unsigned)((hidden + 1023) / 1024 < 64 ? (hidden + 1023) / 1024 : 64);
+  decode_embed_kernel<<<grid, 256, 0, as_stream(stream)>>>(table, reinterpret_cast<const long long*>(tok), (int)hidden, (long long)vocab, cos, sin, pos, rot_dim,
+                                                          max_pos, x, rope_row);
+  MQ_LAUNCH_CHECK("mq_decode_embed");
   return MQ_OK;
 }
 

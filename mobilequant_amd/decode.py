@@ -145,6 +145,7 @@ class DecodeEngine:
         if self.launches == 4:
             self.o_acc = torch.zeros(s.hidden, dtype=torch.int32, device=dev)              # o_proj's integer sums (split-K over the heads)
             self.x_mid = torch.zeros(s.hidden, device=dev)                                 # residual stream behind the attention block
+            self.rope_row = torch.zeros(2 * self.cos.shape[1], device=dev)                 # {cos[pos], sin[pos]}, staged once per token
         self.x = torch.zeros(s.hidden, device=dev)
         self.qkv = torch.zeros((s.heads + 2 * s.kv_heads) * s.head_dim, device=dev)
         self.attn_q = torch.zeros(s.heads * s.head_dim, dtype=torch.int8, device=dev)     # pv_bmm's output as o_proj's int8 image
@@ -181,7 +182,7 @@ class DecodeEngine:
             if N % slices:
                 continue
             R = N // slices
-            for tpr in (4, 2, 1):
+            for tpr in (1, 2, 4):                              # fewest threads per row: the atomics leave in full waves
                 if chunks % tpr == 0 and chunks // tpr <= 8 and R * tpr <= 256:
                     return slices, tpr
         return None
@@ -343,7 +344,7 @@ class DecodeEngine:
         # (2) RoPE / cache append / attention + o_proj's contraction (split-K over the heads, exact integer atomics)
         at = MqDecodeAttentionOprojArgs()
         at.qkv, at.k_cache, at.v_cache = self.qkv.data_ptr(), self.k_cache[li].data_ptr(), self.v_cache[li].data_ptr()
-        at.cos, at.sin, at.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
+        at.rope_row, at.pos = self.rope_row.data_ptr(), self.pos.data_ptr()
         at.heads, at.kv_heads, at.head_dim, at.cache_len, at.rot_dim = s.heads, s.kv_heads, s.head_dim, self.cache_len, self.cos.shape[1]
         g_o = self._attention_grids(attn, at, keep)
         op = _Linear([attn.o_proj], g_o)
@@ -355,6 +356,10 @@ class DecodeEngine:
         keep.sources += op.sources
         keep.weights += op.weights
         at.o_w, at.o_wzp, at.o_acc, at.N, at.slices, at.tpr = o_w.data_ptr(), op.w_zp.data_ptr(), self.o_acc.data_ptr(), op.N, slices, tpr
+        lg = lambda n: n.bit_length() - 1 if n > 0 and n & (n - 1) == 0 else None      # noqa: E731
+        lgs, lgg, lgk = lg(slices), lg(s.heads // s.kv_heads), lg(s.kv_heads)
+        ok = None not in (lgs, lgg, lgk) and (lgk > 3 or lgs + lgg >= 3 - lgk)
+        at.lg_slices, at.lg_group, at.lg_kv = (lgs, lgg, lgk) if ok else (-1, 0, 0)
         at._mq_bytes = o_w.numel()
         self.phases.append(("attn_oproj", at))
         # (3) o_proj's epilogue + residual -> post_attention_layernorm + interleaved w1|w3 + gated activation + w2's input quantizer
@@ -443,8 +448,13 @@ class DecodeEngine:
     def _launch(self, phases=None):
         """embedding gather + 4 (or 5) launches per layer + norm / lm_head, on the current stream; reads self.tok / self.pos."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        torch.index_select(self.embed, 0, self.tok, out=self.x.view(1, -1))
-        for kind, a in (self.phases if phases is None else phases):
+        phases = self.phases if phases is None else phases
+        if phases and phases[1][0] == "attn_oproj":             # token start: embedding row + this position's cos / sin row
+            _lib.call("mq_decode_embed", self.embed.data_ptr(), self.tok.data_ptr(), self.shape.hidden, self.embed.shape[0], self.cos.data_ptr(),
+                      self.sin.data_ptr(), self.pos.data_ptr(), self.cos.shape[1], self.cos.shape[0], self.x.data_ptr(), self.rope_row.data_ptr(), st)
+        else:
+            torch.index_select(self.embed, 0, self.tok, out=self.x.view(1, -1))
+        for kind, a in phases:
             _lib.call(self._ENTRY[kind], ctypes.byref(a), st)
         _lib.call("mq_decode_head", self.x.data_ptr(), self.norm_w.data_ptr(), self.norm_b.data_ptr() if self.norm_b is not None else None,
                   int(self.norm_ln), float(self.model.norm.eps), self.lm_w.data_ptr(),

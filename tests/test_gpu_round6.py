@@ -132,6 +132,7 @@ def test_attention_oproj_launch_against_the_old_launch_pair_and_an_integer_matmu
             eng.fill_cache_random(pos, seed=pos)
             eng.x.copy_(torch.randn(s.hidden, generator=torch.Generator().manual_seed(pos)).to(dev) * 2)
         e4.o_acc.fill_(12345)                                                # must be cleared by the first launch
+        e4.rope_row.copy_(torch.cat([e4.cos[pos], e4.sin[pos]]))             # (what mq_decode_embed stages at the start of a token)
         _lib.call("mq_decode_gemv", ctypes.byref(e4.phases[0][1]), st)
         _lib.call("mq_decode_attention_oproj", ctypes.byref(at), st)
         _lib.call("mq_decode_gemv", ctypes.byref(e5.phases[0][1]), st)
@@ -173,6 +174,6 @@ def test_a_geometry_the_four_launch_kernels_do_not_serve_falls_back_to_five(dev)
     from mobilequant_amd.decode import DecodeEngine
     from mobilequant_amd.llama import LlamaShape
     assert DecodeEngine._oproj_geometry(LlamaShape.tinyllama(), 64) == (8, 1)
-    assert DecodeEngine._oproj_geometry(LlamaShape.gemma_2b(), 256) == (32, 4)
+    assert DecodeEngine._oproj_geometry(LlamaShape.gemma_2b(), 256) == (32, 2)
     assert DecodeEngine._oproj_geometry(LlamaShape.stablelm_2_1_6b(), 16) == (8, 1)
     assert DecodeEngine._oproj_geometry(LlamaShape(hidden=8192, heads=64, kv_heads=8, head_dim=128), 128) is None      # K > 4096: OPRE prologue
