@@ -451,7 +451,7 @@ def cpu_baseline():
 
 
 def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", wsym=False, wpc=None, cache_len=1024, attn_splits=None,
-                      contexts=None, also_contexts=None, launches=4, long_from=None):
+                      contexts=None, also_contexts=None, launches=4):
     """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
     model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
     one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
@@ -491,7 +491,7 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
             if "pv_bmm" in name:
                 mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    eng = DecodeEngine(model, cache_len=cache_len, attn_splits=attn_splits, launches=launches, long_from=long_from)
+    eng = DecodeEngine(model, cache_len=cache_len, attn_splits=attn_splits, launches=launches)
     for p in model.parameters():                            # the float weights of the decoder layers are no longer needed
         if p.dim() == 2 and p.shape[0] != shape.vocab:
             p.data = torch.empty(0, device=dev)

@@ -851,15 +851,20 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   // BLK positions per block, PPB stripes per block; VB stripes (<= 32 registers: 512 positions at head_dim 64) requested at the top.
   constexpr int NT = AO_THREADS, NW = NT / 64;
   constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = NT / LPP, KB = 512 / PPP >= 1 ? 512 / PPP : 1;
-  constexpr int DQ = D / 4, G = NT / DQ, BLK = G > 64 ? G : 64, PPB = BLK / G, VB = 512 / G > 32 ? 32 : (512 / G >= 1 ? 512 / G : 1);
+  // p.v: the VALUE cache is transposed ([kv head][dim][position]): thread (d = tid % D, g = tid / D) owns dimension d of the 16-position
+  // chunks g, g + NG, ...; a chunk is ONE 16-byte request and 12 v_dot4_i32_i8 against the probabilities' byte digits (below).  VC chunks
+  // per thread are requested at the top (512 positions at head_dim 64).
+  constexpr int NG = NT / D >= 1 ? NT / D : 1, VC = 32 / NG > 8 ? 8 : (32 / NG >= 1 ? 32 / NG : 1);
   constexpr int MAXC = D / 16 < 8 ? D / 16 : 8;                    // 16-byte chunks of an o_proj row slice per thread
-  static_assert(PPB * G == BLK && G * DQ == NT, "block mapping");
+  static_assert(NG * D == NT || D > NT, "p.v mapping");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_sc = reinterpret_cast<float*>(smem_raw);              // [cache_len] scores -> exp -> (p index - zp) as int
+  float* s_sc = reinterpret_cast<float*>(smem_raw);              // [cache_len] scores -> exp; behind it 3 x [cache_len] bytes: the probabilities' digits
   __shared__ __attribute__((aligned(16))) int8_t s_q8[D], s_k8[D], s_v8[D], s_a8[D];
   __shared__ float s_redf[NW];
   __shared__ int s_redq[NW];
-  __shared__ long long s_acc[G * D];                             // [G][D] partial p.v sums (32 KB)
+  __shared__ long long s_acc[NG * D];                            // [NG][D] partial p.v sums
+  __shared__ int s_pnew;                                         // the new position's (index - zero point)
+  __shared__ int s_redp[NW];                                     // per wave: sum over its positions of (probability index - zero point)
   const int H = a.heads, W = H * a.slices, rot = a.rot_dim;
   if ((int)blockIdx.x >= W) {                                      // L2 prefetch role (see decode_attention_kernel)
     const int q = (int)blockIdx.x - W;
@@ -925,7 +930,7 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   const float cs = a.rope_row[dr], sn = a.rope_row[rot + dr];
   const int CL = a.cache_len;
   const int8_t* kc = a.k_cache + (size_t)kvh * CL * D;
-  const int8_t* vc = a.v_cache + (size_t)kvh * CL * D;
+  const int8_t* vc = a.v_cache + (size_t)kvh * D * CL;             // [dim][position]
   // ---- keys and values of the first 512 positions: the first 256 before *pos is known (addresses clamped by the cache length, masked by
   // T below), the rest behind it clamped by the position (beyond it every lane reads position 0: one line) -- requesting all 512
   // unconditionally made every workgroup pull 64 KB through its L1 at the head of the launch, 0.5 us at context 256
@@ -937,19 +942,19 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
   };
-  const int dq = tid & (DQ - 1), grp = tid / DQ;
-  auto item_pos = [&](int i) { return BLK * (i / PPB) + grp + G * (i % PPB); };   // PPB: a power of two (shifts)
-  int vbuf[VB];
-  auto load_value = [&](int u, int lim) {
-    const int t = item_pos(u);
-    vbuf[u] = *reinterpret_cast<const int*>(vc + (size_t)(t < lim ? t : 0) * D + dq * 4);
+  const int vd = tid & (D - 1), vg = D >= NT ? 0 : tid / D;          // this thread's dimension and chunk stripe
+  const int8_t* vrow = vc + (size_t)vd * CL;                        // transposed value cache: [dim][position]
+  v4i vbuf[VC];
+  auto load_chunk = [&](int kk, int kbase, int lim_chunks) {         // chunk j = vg + NG (kbase + kk) of 16 positions
+    const int j = vg + NG * (kbase + kk);
+    vbuf[kk] = *reinterpret_cast<const v4i*>(vrow + 16 * (j < lim_chunks ? j : 0));
   };
 #pragma unroll
   for (int u = 0; u < KB; ++u)
     if ((u + 1) * PPP <= 256 || u == 0) load_keys(u, CL);
 #pragma unroll
-  for (int u = 0; u < VB; ++u)
-    if (BLK * (u / PPB) + G * (u % PPB) + G <= 256 || u == 0) load_value(u, CL);
+  for (int kk = 0; kk < VC; ++kk)
+    if (16 * NG * (kk + 1) <= 256 || kk == 0) load_chunk(kk, 0, CL >> 4);
   int pos;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
   const bool live = pos >= 0 && pos < CL;                           // a step past the cache: nothing is written (the host raises first)
@@ -957,9 +962,10 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
 #pragma unroll
   for (int u = 0; u < KB; ++u)
     if (!((u + 1) * PPP <= 256 || u == 0)) load_keys(u, T);
+  const int nchunk = live ? (pos + 15) >> 4 : 0;                     // 16-position chunks of CACHED positions 0 .. pos - 1
 #pragma unroll
-  for (int u = 0; u < VB; ++u)
-    if (!(BLK * (u / PPB) + G * (u % PPB) + G <= 256 || u == 0)) load_value(u, T);
+  for (int kk = 0; kk < VC; ++kk)
+    if (!(16 * NG * (kk + 1) <= 256 || kk == 0)) load_chunk(kk, 0, nchunk);
   // ---- RoPE + the three input quantizers of the new token ---------------------------------------------------------------------------
   const Grid qa = const_grid(cv, AG_QK_A, a.qk_a), qb = const_grid(cv, AG_QK_B, a.qk_b), qo = const_grid(cv, AG_QK_OUT, a.qk_out);
   const Grid pa = const_grid(cv, AG_PV_A, a.pv_a), pb = const_grid(cv, AG_PV_B, a.pv_b), po = const_grid(cv, AG_PV_OUT, a.pv_out);
@@ -981,7 +987,7 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
     qsum_part = sq;
     if (live && c == 0 && h == kvh * (H / a.kv_heads)) {           // the group's first head (its first slice) appends to the cache
       a.k_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sk;
-      a.v_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sv;
+      a.v_cache[((size_t)kvh * D + tid) * CL + pos] = (int8_t)sv;  // (transposed value cache)
     }
   }
   if (wv < (D + 63) / 64) {                                        // (the waves that hold the D query bytes)
@@ -1083,92 +1089,79 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   }
   __syncthreads();
   const float tot_e = (s_redf[0] + s_redf[1]) + (s_redf[2] + s_redf[3]);
-  int* s_pi = reinterpret_cast<int*>(s_sc);
-  for (int t = tid; t < T; t += NT) {
-    const float p = __fdiv_rn(s_sc[t], tot_e);
-    const float ip = dq_index(p, pa.s, pa.inv_s, pa.o, pa.qmin, pa.qmax);
-    s_pi[t] = (ip != ip ? 0 : (int)ip) - zp;
+  // pv_bmm's input quantizer, once per position.  The index ip (0 .. 65535) leaves as THREE signed bytes per position so that the sweep
+  // over the values is v_dot4_i32_i8 work:  ip = 256 (ph - 128) + (pl - 128) + 32896 m  with m = 1 for a cached position, and
+  // ph = pl = m = 0 (no contribution) beyond the sequence and AT the new position, whose value is not in the cache yet (another
+  // workgroup appends it in this very launch): it is added from registers below.
+  int8_t* s_ph = reinterpret_cast<int8_t*>(s_sc + CL);
+  int8_t* s_pl = s_ph + CL;
+  int8_t* s_pm = s_pl + CL;
+  int my_p = 0;                                                     // <= 128 positions per thread x 65535: int32 holds a wave's sum too
+  for (int t = tid; t < (nchunk << 4) || t < T; t += NT) {
+    int bh = 0, bl = 0, bm = 0;
+    if (t < T) {
+      const float p = __fdiv_rn(s_sc[t], tot_e);
+      const float ipf = dq_index(p, pa.s, pa.inv_s, pa.o, pa.qmin, pa.qmax);
+      const int ip = ipf != ipf ? 0 : (int)ipf;
+      my_p += ip - zp;
+      if (t == pos) s_pnew = ip - zp;
+      else bh = (ip >> 8) - 128, bl = (ip & 255) - 128, bm = 1;
+    }
+    if (t < (nchunk << 4)) {
+      s_ph[t] = (int8_t)bh;
+      s_pl[t] = (int8_t)bl;
+      s_pm[t] = (int8_t)bm;
+    }
+  }
+  {
+    const int w = wave_sum_dpp(my_p);                               // (an LDS atomic per thread was tried: 256 same-address atomics cost ~1 us)
+    if (lane == 0) s_redp[wv] = w;
   }
   __syncthreads();
   DG_STAMP(3);
-  // ---- p.v over the cached positions t < pos: exact integers; the new position from registers -----------------------------------------
-  long long acc[4] = {0, 0, 0, 0};
-  long long psum = 0;
-  const int nblk = (pos + BLK - 1) / BLK;                            // blocks of CACHED positions 0 .. pos - 1
-  const int items = live ? nblk * PPB : 0;
-  for (int i0 = 0; i0 < items; i0 += VB) {
-    if (i0 > 0) {                                                   // later batches (512 positions each): one exposed round trip each
+  // ---- p.v over the cached positions t < pos: exact integers -----------------------------------------------------------------------
+  // sum_t (ip - zp)(vs - zv) = [256 Sh + Sl + (32896 - zp) Sm] - zv P,  Sh / Sl / Sm = sum_t digit[t] vs[t][d],  P = sum_t (ip - zp)
+  int sh = 0, sl = 0, sm = 0;
+  const int my_chunks = vg < nchunk ? (nchunk - vg + NG - 1) / NG : 0;
+  for (int k0 = 0; k0 < my_chunks; k0 += VC) {
+    if (k0 > 0) {                                                   // later batches: one exposed round trip each (long caches only)
 #pragma unroll
-      for (int u = 0; u < VB; ++u) {
-        const int t = item_pos(i0 + u);
-        vbuf[u] = *reinterpret_cast<const int*>(vc + (size_t)(t < pos ? t : 0) * D + dq * 4);
+      for (int kk = 0; kk < VC; ++kk) load_chunk(kk, k0, nchunk);
+    }
+#pragma unroll
+    for (int kk = 0; kk < VC; ++kk) {
+      if (k0 + kk < my_chunks) {
+        const int j = vg + NG * (k0 + kk);
+        const v4i ph4 = *reinterpret_cast<const v4i*>(s_ph + 16 * j), pl4 = *reinterpret_cast<const v4i*>(s_pl + 16 * j);
+        const v4i pm4 = *reinterpret_cast<const v4i*>(s_pm + 16 * j);
+        sh = dot16(vbuf[kk], ph4, sh);
+        sl = dot16(vbuf[kk], pl4, sl);
+        sm = dot16(vbuf[kk], pm4, sm);
       }
     }
-    int a32[4] = {0, 0, 0, 0}, p32 = 0;                              // <= 32 positions x 65535 x 128 < 2^31
-#pragma unroll
-    for (int u = 0; u < VB; ++u) {
-      const int i = i0 + u;
-      const int t = item_pos(i);
-      const bool ok = i < items && t < pos;                         // (a uniform `break` at i >= items was tried: 1.9 -> 2.6 us for this sweep)
-      const int pi = s_pi[ok ? t : 0];
-      const int pim = ok ? pi : 0;
-      p32 += pim;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a32[e] += (int)__builtin_amdgcn_sbfe(vbuf[u], 8 * e, 8) * pim;      // (the builtin returns unsigned)
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += a32[e];
-    psum += p32;
   }
-  if (grp == 0 && live) {                                            // the new position: group 0 adds it from registers
-    const int sv4 = *reinterpret_cast<const int*>(s_v8 + dq * 4);
-    const int pi = s_pi[pos];
-    psum += pi;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += (long long)((int)__builtin_amdgcn_sbfe(sv4, 8 * e, 8) * pi);
+  {
+    long long part = 256ll * sh + sl + (long long)(32896 - zp) * sm;
+    if (vg == 0 && live) part += (long long)s_v8[vd] * (long long)s_pnew;      // the new position: stripe 0 adds it from LDS
+    if (D <= NT || tid < D) s_acc[vg * D + vd] = part;
   }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] -= (long long)zv * psum;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) s_acc[grp * D + dq * 4 + e] = acc[e];
   __syncthreads();
   DG_STAMP(4);
-  // the G partial sums of a dimension: NT / D threads per dimension add G D / NT of them each (exact integers: any order), then the
-  // dimension's threads meet through DPP (they are adjacent lanes: NT / D <= 16 is a power of two)
-  constexpr int TPD = NT / D >= 16 ? 16 : NT / D, GPT = G / TPD;     // threads per dimension, partial sums per thread
-  static_assert(TPD * GPT == G, "combine mapping");
   int a_byte = 0;
-  {
-    const int d = tid / TPD, part_i = tid % TPD;
+  if (tid < D) {
     long long tot = 0;
-    if (tid < D * TPD) {
 #pragma unroll
-      for (int gq = 0; gq < GPT; ++gq) tot += s_acc[(part_i * GPT + gq) * D + d];
-    }
-    // 64-bit sum over TPD adjacent lanes: two 32-bit DPP moves per step
-    unsigned lo = (unsigned)tot, hi = (unsigned)((unsigned long long)tot >> 32);
-#define MQ_AO_STEP(CTRL)                                                                                                   \
-  {                                                                                                                        \
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);                            \
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);                            \
-    const unsigned long long sum = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)ohi << 32) | olo);         \
-    lo = (unsigned)sum;                                                                                                    \
-    hi = (unsigned)(sum >> 32);                                                                                            \
-  }
-    if (TPD >= 2) MQ_AO_STEP(0xB1)                                  // quad_perm [1,0,3,2]
-    if (TPD >= 4) MQ_AO_STEP(0x4E)                                  // quad_perm [2,3,0,1]
-    if (TPD >= 8) MQ_AO_STEP(0x141)                                 // row_half_mirror
-    if (TPD >= 16) MQ_AO_STEP(0x140)                                // row_mirror
-#undef MQ_AO_STEP
-    tot = (long long)(((unsigned long long)hi << 32) | lo);
-    if (tid < D * TPD && part_i == 0) {
-      const float pre = (float)((double)tot * (double)alpha_pv);   // one rounding of the exact sum (as mq_attention.hip)
-      const float y = po.fq(pre);
-      const float qi = dq_index(y, oi.s, oi.inv_s, oi.o, oi.qmin, oi.qmax);
-      a_byte = (qi != qi ? (int)oi.qmin : (int)qi) - 128;
-      s_a8[d] = (int8_t)a_byte;
-      if (a.out_q && c == 0 && live) a.out_q[(size_t)h * D + d] = (int8_t)a_byte;
-    }
+    for (int g2 = 0; g2 < NG; ++g2) tot += s_acc[g2 * D + tid];
+    long long psum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) psum += s_redp[w];
+    tot -= (long long)zv * psum;
+    const float pre = (float)((double)tot * (double)alpha_pv);     // one rounding of the exact sum (as mq_attention.hip)
+    const float y = po.fq(pre);
+    const float qi = dq_index(y, oi.s, oi.inv_s, oi.o, oi.qmin, oi.qmax);
+    a_byte = (qi != qi ? (int)oi.qmin : (int)qi) - 128;
+    s_a8[tid] = (int8_t)a_byte;
+    if (a.out_q && c == 0 && live) a.out_q[(size_t)h * D + tid] = (int8_t)a_byte;
   }
   {
     const int w = wave_sum_dpp(a_byte);                            // (threads that hold no output byte contribute 0)
@@ -1475,7 +1468,8 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
   MQ_REQUIRE(a.prefetch_wgs == 0 || (a.prefetch && aligned(a.prefetch, 16) && a.prefetch_bytes_per_wg % 16 == 0 && a.prefetch_wgs > 0 && a.prefetch_wgs <= 4096 &&
                                     a.prefetch_stride >= a.prefetch_bytes_per_wg && a.prefetch_stride % 16 == 0 && a.prefetch_delay >= 0 && a.prefetch_delay <= 100000),
              "mq_decode_attention_oproj: prefetch needs a 16-byte aligned range, 1..4096 workgroups, stride >= bytes per workgroup, delay in 0..100000 (10 ns units)");
-  const size_t lds = (size_t)a.cache_len * sizeof(float);
+  MQ_REQUIRE(a.cache_len % 16 == 0, "mq_decode_attention_oproj: cache_len=%d must be a multiple of 16 (transposed value cache, 16-byte chunks)", a.cache_len);
+  const size_t lds = (size_t)a.cache_len * (sizeof(float) + 3);
   const void* fn = a.head_dim == 32 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<32>)
                    : a.head_dim == 64 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<64>)
                    : a.head_dim == 128 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<128>)

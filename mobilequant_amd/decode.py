@@ -125,11 +125,12 @@ class DecodeEngine:
     LONG_FROM, LONG_SPLITS = 768, 4
 
     def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5,
-                 launches: int = 4, long_from: Optional[int] = None):
+                 launches: int = 4):
         """launches: 4 (round 6, default) = per layer {norm + q|k|v, RoPE / cache append / attention + o_proj's contraction, o_proj's
         epilogue + norm + w1|w3 + gate, w2}; 5 = round 2-5's chain with o_proj as a launch of its own.  A geometry the 4-launch kernels
-        do not serve falls back to 5 (self.launches says which).  With launches = 4, positions from `long_from` on (None: never) replay
-        the 5-launch graph with the split attention."""
+        do not serve falls back to 5 (self.launches says which).  The 4-launch chain keeps the VALUE cache transposed
+        ([kv_heads, head_dim, cache_len]: its p.v sweep is v_dot4 work); use cached_values() / load_cached_values() to read / write it in
+        the logical [kv_heads, positions, head_dim] layout."""
         from .llama import LlamaForCausalLM
         assert isinstance(model, LlamaForCausalLM)
         assert launches in (4, 5)
@@ -139,9 +140,9 @@ class DecodeEngine:
         self.dev, self.cache_len = dev, int(cache_len)
         self._prefetch = (prefetch, prefetch_delay_us)
         self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
-        self.oproj_geom = self._oproj_geometry(s, self.cos.shape[1]) if launches == 4 else None
+        self.oproj_geom = self._oproj_geometry(s, self.cos.shape[1]) if launches == 4 and self.cache_len % 16 == 0 else None
         self.launches = 4 if self.oproj_geom is not None else 5
-        self.long_from = long_from if self.launches == 4 else None
+        self.v_transposed = self.launches == 4
         if self.launches == 4:
             self.o_acc = torch.zeros(s.hidden, dtype=torch.int32, device=dev)              # o_proj's integer sums (split-K over the heads)
             self.x_mid = torch.zeros(s.hidden, device=dev)                                 # residual stream behind the attention block
@@ -163,7 +164,8 @@ class DecodeEngine:
         self.tok = torch.zeros(1, dtype=torch.int64, device=dev)
         # keys / values as int8 indices (index - 128) on qk_bmm.input2 / pv_bmm.input2's grids
         self.k_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
-        self.v_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
+        vshape = (s.kv_heads, s.head_dim, self.cache_len) if self.v_transposed else (s.kv_heads, self.cache_len, s.head_dim)
+        self.v_cache = [torch.zeros(vshape, dtype=torch.int8, device=dev) for _ in model.layers]
         self._host_pos = 0                                   # mirror of self.pos for the cache-overflow guard (no device read-back)
         assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
         self.graph = None
@@ -211,22 +213,15 @@ class DecodeEngine:
             if isinstance(q, Q.Quantizer) and q._has_grid() and q.scale.device != dev:
                 q.scale.data, q.offset.data = q.scale.to(dev), q.offset.to(dev)
         self.oproj_images = []
-        self.phases_long = []     # launches = 4 with long_from: the 5-launch chain (split attention) for long caches
         with torch.no_grad():
             for li, layer in enumerate(model.layers):
-                if self.launches == 4:
-                    self._lower_layer4(li, layer)
-                    if self.long_from is not None:
-                        self._lower_layer(li, layer, self.phases_long)
-                else:
-                    self._lower_layer(li, layer)
+                (self._lower_layer4 if self.launches == 4 else self._lower_layer)(li, layer)
         # The attention launch of layer L pulls (a share of) layer L's w1|w3 stream into the L2s with extra workgroups: it keeps 32 of
         # 256 CUs busy and leaves the memory fabric idle, while w1|w3 is the step's biggest stream.  Measured (TinyLlama shape, context
         # 256): share 0 / 0.5 / 0.7 / 1.0 -> 0.678 / 0.656 / 0.665 / 0.690 ms per token: the attention's own dependent loads queue
         # behind the prefetch stream, so half of it, started 1.5 us into the launch, is the optimum.
         if prefetch:
             pairs = [(self.phases[i][1], self.phases[i + (1 if self.launches == 4 else 2)][1]) for i in range(1, len(self.phases), self.launches)]
-            pairs += [(self.phases_long[i][1], self.phases_long[i + 2][1]) for i in range(1, len(self.phases_long), 5)]
             for at, gate in pairs:
                 n, per, tot = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
                 _lib.call("mq_decode_gemv_geometry", ctypes.byref(gate), ctypes.byref(n), ctypes.byref(per), ctypes.byref(tot))
@@ -388,8 +383,8 @@ class DecodeEngine:
         p5.out_grid[0] = _grid(mlp.w2.output_quantizer, keep)
         self.phases.append(("gemv", self._finish_gemv(p5)))
 
-    def _lower_layer(self, li, layer, phases=None):
-        phases = self.phases if phases is None else phases
+    def _lower_layer(self, li, layer):
+        phases = self.phases
         s, keep = self.shape, self._keep
         attn, mlp = layer.self_attn, layer.mlp
         for m in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.w1, mlp.w2, mlp.w3):
@@ -467,27 +462,23 @@ class DecodeEngine:
                 a.nsplit = int(n)
 
     def _variants(self):
-        """[(phases, attention splits)]: what runs below / from self._long_threshold() positions on."""
+        """[(phases, attention splits)]: what runs below / from LONG_FROM positions on (5 launches: the split attention launch)."""
         if self.launches == 4:
-            v = [(self.phases, 1)]
-            if self.long_from is not None and self.cache_len > self.long_from:
-                v.append((self.phases_long, self.LONG_SPLITS))
-            return v
+            return [(self.phases, 1)]
         v = [(self.phases, self.attn_splits)]
         if self.auto_splits and self.cache_len > self.LONG_FROM:
             v.append((self.phases, self.LONG_SPLITS))
         return v
 
     def _long_threshold(self) -> int:
-        return self.long_from if self.launches == 4 else self.LONG_FROM
+        return self.LONG_FROM
 
     def _variant_at(self, pos: int) -> int:
         return 1 if len(self._variants()) > 1 and pos >= self._long_threshold() else 0
 
     def capture(self):
         """Record one decode step (incl. the position increment) as a hipGraph; replay it with step().  Where a second variant exists
-        (5 launches: the split attention from LONG_FROM cached positions on; 4 launches with long_from: the 5-launch chain from there on)
-        a second graph is recorded; step() picks by position.
+        (5 launches: the split attention from LONG_FROM cached positions on) a second graph is recorded; step() picks by position.
         Quantizers changed since the engine was built (recalibration, scale.copy_) are picked up here, in reset() and in prefill()."""
         if self._keep.stale():
             self._lower()
@@ -518,11 +509,29 @@ class DecodeEngine:
         self.pos.fill_(int(pos))
         self._host_pos = int(pos)
 
+    def cached_values(self, li: int, n: Optional[int] = None) -> torch.Tensor:
+        """Layer li's cached values as [kv_heads, n positions, head_dim] int8 indices (index - 128), whatever the engine's layout."""
+        n = self._host_pos if n is None else int(n)
+        c = self.v_cache[li]
+        return c[:, :, :n].transpose(1, 2) if self.v_transposed else c[:, :n]
+
+    def load_cached_values(self, li: int, values: torch.Tensor):
+        """values [kv_heads, n, head_dim] int8 -> positions 0 .. n - 1 of layer li's value cache."""
+        n = values.shape[1]
+        if self.v_transposed:
+            self.v_cache[li][:, :, :n] = values.transpose(1, 2)
+        else:
+            self.v_cache[li][:, :n] = values
+
     def fill_cache_random(self, n: int, seed: int = 0):
-        """Benchmark helper: n positions of random cached indices."""
+        """Benchmark helper: n positions of random cached indices (the same logical content for both cache layouts)."""
         g = torch.Generator(device=self.dev).manual_seed(seed)
-        for c in self.k_cache + self.v_cache:
-            c[:, :n] = torch.randint(-128, 128, c[:, :n].shape, generator=g, device=self.dev, dtype=torch.int8)
+        s = self.shape
+        rnd = lambda: torch.randint(-128, 128, (s.kv_heads, n, s.head_dim), generator=g, device=self.dev, dtype=torch.int8)      # noqa: E731
+        for c in self.k_cache:
+            c[:, :n] = rnd()
+        for li in range(len(self.v_cache)):
+            self.load_cached_values(li, rnd())
         self.set_position(n)
 
     def reset(self):
@@ -566,7 +575,7 @@ class DecodeEngine:
         for li, layer in enumerate(self.model.layers):
             att = layer.self_attn
             self.k_cache[li][:, :S] = att.qk_bmm.input2_quantizer.quantize_to_int(raw[li][0][0].contiguous())[0]
-            self.v_cache[li][:, :S] = att.pv_bmm.input2_quantizer.quantize_to_int(raw[li][1][0].contiguous())[0]
+            self.load_cached_values(li, att.pv_bmm.input2_quantizer.quantize_to_int(raw[li][1][0].contiguous())[0])
         self.set_position(S)
         self.logits.copy_(logits[0, -1])
         return self.logits

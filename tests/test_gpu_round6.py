@@ -88,7 +88,9 @@ def test_four_launch_step_is_the_five_launch_step_bit_for_bit(dev, name):
         b = e5.step(t).clone()
         assert torch.equal(a, b), (name, pos, float((a - b).abs().max()))
     for li in range(len(m.layers)):                            # the RoPE epilogue's cache append == the attention launch's
-        assert torch.equal(e4.k_cache[li], e5.k_cache[li]) and torch.equal(e4.v_cache[li], e5.v_cache[li]), (name, li)
+        n = len(ids)
+        assert e4.v_transposed and not e5.v_transposed            # [kv, dim, position] against [kv, position, dim]: compare the logical content
+        assert torch.equal(e4.k_cache[li], e5.k_cache[li]) and torch.equal(e4.cached_values(li, n), e5.cached_values(li, n)), (name, li)
     assert torch.equal(e4.x, e5.x)
     # the captured graph replays the same numbers; a second sequence after reset() too (o_proj's accumulators are cleared per step)
     e4.reset()
@@ -139,35 +141,34 @@ def test_attention_oproj_launch_against_the_old_launch_pair_and_an_integer_matmu
         _lib.call("mq_decode_attention", ctypes.byref(e5.phases[1][1]), st)
         torch.cuda.synchronize()
         assert torch.equal(out_q, e5.attn_q), pos
-        assert torch.equal(e4.k_cache[0], e5.k_cache[0]) and torch.equal(e4.v_cache[0], e5.v_cache[0]), pos
+        assert torch.equal(e4.k_cache[0], e5.k_cache[0]) and torch.equal(e4.cached_values(0, pos + 1), e5.cached_values(0, pos + 1)), pos
         a8 = out_q.cpu().numpy().astype(np.int64)
         want = w_nk @ a8
         acc = e4.o_acc.cpu().numpy().astype(np.int64)
         assert np.array_equal(acc, want - op_zp * a8.sum()), pos
 
 
-def test_four_launch_engine_hands_over_to_the_five_launch_graph_on_a_long_cache(dev):
-    """DecodeEngine(long_from=n): positions >= n replay the five-launch chain with the split attention; the two chains share the cache,
-    the residual stream and the position, so the logits are the one-chain engine's on both sides of the switch, bit for bit."""
+def test_four_launch_step_on_long_caches_and_block_boundaries(dev):
+    """The request schedule of the attention + o_proj launch changes with the position (256 positions requested before *pos is known, 512
+    before the scores, later batches inside the sweeps; 16-position chunks of the transposed value cache): at every boundary the logits
+    are the five-launch chain's, bit for bit."""
     import dataclasses
     from mobilequant_amd import llama
     from mobilequant_amd.decode import DecodeEngine
     m, ids = _model(dev, "llama_gqa")
-    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=1024))
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=1600))
     m.cos, m.sin = cos.to(dev), sin.to(dev)
-    both = DecodeEngine(m, cache_len=1024, long_from=130)
-    four = DecodeEngine(m, cache_len=1024)
-    assert both.launches == 4 and both.phases_long and not four.phases_long
-    for eng in (both, four):
-        eng.fill_cache_random(128, seed=3)
-        eng.capture()
-    assert both.graph_long is not None and four.graph_long is None
-    for t in (5, 17, 40, 3, 90):                         # two steps below long_from, three from it on
-        a = both.step(t).clone()
-        b = four.step(t).clone()
-        torch.cuda.synchronize()
-        assert torch.equal(a, b), (both._host_pos, float((a - b).abs().max()))
-    assert both._host_pos == 133
+    e4 = DecodeEngine(m, cache_len=1600)
+    e5 = DecodeEngine(m, cache_len=1600, launches=5, attn_splits=1)
+    assert e4.launches == 4
+    for start in (14, 254, 510, 766, 1022, 1278, 1534):
+        for eng in (e4, e5):
+            eng.fill_cache_random(start, seed=start)
+        for t in (5, 17, 40, 3):                          # the steps cross position start + 2 = a multiple of 16 / 256 / 512
+            a = e4.step(t).clone()
+            b = e5.step(t).clone()
+            assert torch.equal(a, b), (start, e4._host_pos, float((a - b).abs().max()))
+        assert torch.equal(e4.cached_values(0), e5.cached_values(0)) and torch.equal(e4.k_cache[0], e5.k_cache[0])
 
 
 def test_a_geometry_the_four_launch_kernels_do_not_serve_falls_back_to_five(dev):
