@@ -551,6 +551,7 @@ enum { AG_QK_A = 0, AG_QK_B = 1, AG_QK_OUT = 2, AG_PV_A = 3, AG_PV_B = 4, AG_PV_
 // sum over aligned groups of N = 2 / 4 adjacent lanes: DPP quad permutes (a __shfl_xor is an LDS round trip, ~100 cycles each)
 template <int N>
 __device__ __forceinline__ int quad_sum(int v) {
+  if (N == 1) return v;
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);                 // quad_perm [1,0,3,2]
   if (N == 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
   return v;
@@ -846,11 +847,14 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
 constexpr int AO_THREADS = 256;
 template <int D>
 __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
-  // Geometry (NT threads).  Scores: LPP lanes per cached position (CH 16-byte chunks of the key row each), PPP positions per pass, KB
-  // passes = 512 positions requested at the top.  p.v: thread (dq = dword of 4 dims, grp) owns one position of every G-position stripe;
+  // Geometry (NT threads).  PPP positions per pass, KB passes requested at the top (512 positions at head_dim 64).  p.v: thread (dq = dword of 4 dims, grp) owns one position of every G-position stripe;
   // BLK positions per block, PPB stripes per block; VB stripes (<= 32 registers: 512 positions at head_dim 64) requested at the top.
   constexpr int NT = AO_THREADS, NW = NT / 64;
-  constexpr int LPP = D >= 64 ? 4 : 2, CH = D >= 64 ? D / 64 : 1, PPP = NT / LPP, KB = 512 / PPP >= 1 ? 512 / PPP : 1;
+  // Scores: ONE lane per cached position at head_dim <= 64 (the whole key row: CH = 4 16-byte chunks per lane, LPP lanes per position
+  // beyond): with four lanes per position (rounds 3-5) a sweep over 257 positions was five passes whose epilogue ran on a quarter of the
+  // lanes -- 1.6 us of instruction issue; one lane per position is two passes and no cross-lane sum.
+  constexpr int LPP = D / 64 >= 1 ? D / 64 : 1, CH = D / 16 < 4 ? D / 16 : 4, PPP = NT / LPP;
+  constexpr int KB = (512 / PPP < 8 / CH ? 512 / PPP : 8 / CH) >= 1 ? (512 / PPP < 8 / CH ? 512 / PPP : 8 / CH) : 1;
   // p.v: the VALUE cache is transposed ([kv head][dim][position]): thread (d = tid % D, g = tid / D) owns dimension d of the 16-position
   // chunks g, g + NG, ...; a chunk is ONE 16-byte request and 12 v_dot4_i32_i8 against the probabilities' byte digits (below).  VC chunks
   // per thread are requested at the top (512 positions at head_dim 64).
@@ -1012,37 +1016,59 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   }
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   // ---- scores ----------------------------------------------------------------------------------------------------------------------
+  // The CACHED positions t < pos in passes of PPP; the first KB passes are straight-line code on the registers requested at the top (so
+  // that hipcc waits for exactly the pass it needs: a loop header with a refill inside costs a vmcnt(0), i.e. the arrival of every
+  // request in flight, incl. the passes behind *pos); the new position's score comes from the key in LDS.
   float lmax = -INFINITY;
-  for (int t0 = 0; t0 < T; t0 += KB * PPP) {
-    if (t0 > 0) {                                                   // a later batch of 512 positions (one exposed round trip each: long caches only)
+  auto score_pass = [&](int t0, int u) {
+    const int t = t0 + u * PPP + slot;
+    int dot = 0, ks = 0;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      dot = dot16(kbuf[u][ch], qf[ch], dot);
+      ks = dot16(kbuf[u][ch], ones, ks);
+    }
+    dot = quad_sum<LPP>(dot);
+    ks = quad_sum<LPP>(ks);
+    if (t < pos && sub == 0) {
+      const int ti = dot - zq * ks + qconst;
+      const float val = __fmul_rn((float)ti, alpha_qk);
+      const float qv = qo.fq(val);
+      const float sc = pow2 ? __fmul_rn(qv, inv_sqrt_d) : __fdiv_rn(qv, sqrt_d);     // qk_bmm(...) / sqrt(head_dim)  (hf_model.py:513)
+      s_sc[t] = sc;
+      lmax = fmaxf(lmax, sc);
+    }
+  };
+  if (live) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+      if (u * PPP < pos) score_pass(0, u);                          // (uniform)
+    for (int t0 = KB * PPP; t0 < pos; t0 += KB * PPP) {             // later batches (one exposed round trip each: long caches only)
 #pragma unroll
       for (int u = 0; u < KB; ++u) {
         const int t = t0 + u * PPP + slot, tc = t < pos ? t : 0;
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
       }
-    }
 #pragma unroll
-    for (int u = 0; u < KB; ++u) {
-      if (t0 + u * PPP >= T) break;                                // (uniform) the rest of the batch lies beyond the sequence
-      const int t = t0 + u * PPP + slot;
+      for (int u = 0; u < KB; ++u)
+        if (t0 + u * PPP < pos) score_pass(t0, u);
+    }
+    {                                                               // the new position (every LPP-lane group computes it; one lane stores it)
       int dot = 0, ks = 0;
 #pragma unroll
       for (int ch = 0; ch < CH; ++ch) {
-        const v4i kf = t == pos ? kn[ch] : kbuf[u][ch];
-        dot = dot16(kf, qf[ch], dot);
-        ks = dot16(kf, ones, ks);
+        dot = dot16(kn[ch], qf[ch], dot);
+        ks = dot16(kn[ch], ones, ks);
       }
       dot = quad_sum<LPP>(dot);
       ks = quad_sum<LPP>(ks);
-      if (t < T && sub == 0) {
-        const int ti = dot - zq * ks + qconst;
-        const float val = __fmul_rn((float)ti, alpha_qk);
-        const float qv = qo.fq(val);
-        const float sc = pow2 ? __fmul_rn(qv, inv_sqrt_d) : __fdiv_rn(qv, sqrt_d);     // qk_bmm(...) / sqrt(head_dim)  (hf_model.py:513)
-        s_sc[t] = sc;
-        lmax = fmaxf(lmax, sc);
-      }
+      const int ti = dot - zq * ks + qconst;
+      const float val = __fmul_rn((float)ti, alpha_qk);
+      const float qv = qo.fq(val);
+      const float sc = pow2 ? __fmul_rn(qv, inv_sqrt_d) : __fdiv_rn(qv, sqrt_d);
+      if (tid == 0) s_sc[pos] = sc;
+      lmax = fmaxf(lmax, sc);
     }
   }
   lmax = wave_max_f(lmax);
@@ -1123,22 +1149,23 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   // sum_t (ip - zp)(vs - zv) = [256 Sh + Sl + (32896 - zp) Sm] - zv P,  Sh / Sl / Sm = sum_t digit[t] vs[t][d],  P = sum_t (ip - zp)
   int sh = 0, sl = 0, sm = 0;
   const int my_chunks = vg < nchunk ? (nchunk - vg + NG - 1) / NG : 0;
-  for (int k0 = 0; k0 < my_chunks; k0 += VC) {
-    if (k0 > 0) {                                                   // later batches: one exposed round trip each (long caches only)
+  auto pv_chunk = [&](int k0, int kk) {
+    const int j = vg + NG * (k0 + kk);
+    const v4i ph4 = *reinterpret_cast<const v4i*>(s_ph + 16 * j), pl4 = *reinterpret_cast<const v4i*>(s_pl + 16 * j);
+    const v4i pm4 = *reinterpret_cast<const v4i*>(s_pm + 16 * j);
+    sh = dot16(vbuf[kk], ph4, sh);
+    sl = dot16(vbuf[kk], pl4, sl);
+    sm = dot16(vbuf[kk], pm4, sm);
+  };
 #pragma unroll
-      for (int kk = 0; kk < VC; ++kk) load_chunk(kk, k0, nchunk);
-    }
+  for (int kk = 0; kk < VC; ++kk)                                   // the chunks requested at the top: straight-line code (see the scores)
+    if (kk < my_chunks) pv_chunk(0, kk);
+  for (int k0 = VC; k0 < my_chunks; k0 += VC) {                     // later batches: one exposed round trip each (long caches only)
 #pragma unroll
-    for (int kk = 0; kk < VC; ++kk) {
-      if (k0 + kk < my_chunks) {
-        const int j = vg + NG * (k0 + kk);
-        const v4i ph4 = *reinterpret_cast<const v4i*>(s_ph + 16 * j), pl4 = *reinterpret_cast<const v4i*>(s_pl + 16 * j);
-        const v4i pm4 = *reinterpret_cast<const v4i*>(s_pm + 16 * j);
-        sh = dot16(vbuf[kk], ph4, sh);
-        sl = dot16(vbuf[kk], pl4, sl);
-        sm = dot16(vbuf[kk], pm4, sm);
-      }
-    }
+    for (int kk = 0; kk < VC; ++kk) load_chunk(kk, k0, nchunk);
+#pragma unroll
+    for (int kk = 0; kk < VC; ++kk)
+      if (k0 + kk < my_chunks) pv_chunk(k0, kk);
   }
   {
     long long part = 256ll * sh + sl + (long long)(32896 - zp) * sm;
