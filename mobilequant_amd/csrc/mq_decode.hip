@@ -944,14 +944,24 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
     const int t = u * PPP + slot;
     const int tc = t < lim ? t : 0;                                 // position 0 stands in (always valid memory)
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch) kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
+    for (int ch = 0; ch < CH; ++ch) {
+#ifdef MQ_AO_WHATIF_NOKEYS
+      kbuf[u][ch] = v4i{tc, t, u, ch};
+#else
+      kbuf[u][ch] = *reinterpret_cast<const v4i*>(kc + (size_t)tc * D + (sub * CH + ch) * 16);
+#endif
+    }
   };
   const int vd = tid & (D - 1), vg = D >= NT ? 0 : tid / D;          // this thread's dimension and chunk stripe
   const int8_t* vrow = vc + (size_t)vd * CL;                        // transposed value cache: [dim][position]
   v4i vbuf[VC];
   auto load_chunk = [&](int kk, int kbase, int lim_chunks) {         // chunk j = vg + NG (kbase + kk) of 16 positions
     const int j = vg + NG * (kbase + kk);
+#ifdef MQ_AO_WHATIF_NOVALUES
+    vbuf[kk] = v4i{j, kk, kbase, lim_chunks};
+#else
     vbuf[kk] = *reinterpret_cast<const v4i*>(vrow + 16 * (j < lim_chunks ? j : 0));
+#endif
   };
 #pragma unroll
   for (int u = 0; u < KB; ++u)
