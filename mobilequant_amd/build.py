@@ -100,7 +100,20 @@ if __name__ == "__main__":
     exp = "--experiments" in sys.argv
     if exp and not tag:
         tag = "experiments"
-    path = build(force="--force" in sys.argv, verbose=True, tag=tag, extra_flags=["-DMQ_BUILD_EXPERIMENTS"] if exp else ())
+    gen = []
+    if exp:     # the experiment-only generated programs are not committed: write them next to the others for this build, remove them after
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("gen_fr_asm", os.path.join(ROOT, "tools", "gen_fr_asm.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        for v in mod.EXPERIMENTAL:
+            mod.main(variant=v)
+            gen.append(os.path.join(CSRC, mod.VARIANTS[v][4]))
+    try:
+        path = build(force="--force" in sys.argv or exp, verbose=True, tag=tag, extra_flags=["-DMQ_BUILD_EXPERIMENTS"] if exp else ())
+    finally:
+        for f in gen:
+            os.remove(f)
     print("built", path)
     if tag:
         print("built", build_probe(tag))

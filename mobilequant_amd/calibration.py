@@ -104,7 +104,8 @@ class ActRangeCollector:
         def fn(m, xx, yy):
             x = xx[0] if isinstance(xx, tuple) else xx
             y = yy[0] if isinstance(yy, tuple) else yy
-            skip = m.__dict__.get("_mq_calib_skip", ())          # fields whose statistic the fused score chain takes (below)
+            owned = m.__dict__.get("_mq_calib_skip")             # (collector, fields) whose statistic the fused score chain takes (below)
+            skip = owned[1] if owned is not None and owned[0] is self else ()
             if "input" not in skip:
                 self._update(name, "input", x)
             if "output" not in skip:
@@ -138,6 +139,11 @@ class ActRangeCollector:
             qk, pv = getattr(m, "qk_bmm", None), getattr(m, "pv_bmm", None)
             if (getattr(m, "_mq_calibration_aware", False) and qk is not None and pv is not None
                     and (names.get(id(qk)), "output") in self.slots and (names.get(id(pv)), "input") in self.slots):
+                if m.__dict__.get("_mq_calib") is not None and m.__dict__["_mq_calib"][0] is not self:
+                    # ONE slot per module: a second collector would take the fused statistics away from the first (whose
+                    # hooks skip these fields) -- it keeps the plain hooks instead (the statistics agree within a few ulp: the fused
+                    # softmax is not torch's bit for bit)
+                    continue
                 m._mq_calib = (self, names[id(qk)], names[id(pv)])
                 self._aware.append(m)
         return self
@@ -147,7 +153,8 @@ class ActRangeCollector:
             h.remove()
         self._hooks = []
         for m in self._aware:
-            m.__dict__.pop("_mq_calib", None)
+            if m.__dict__.get("_mq_calib", (None,))[0] is self:
+                m.__dict__.pop("_mq_calib", None)
         self._aware = []
 
     # -- merge -------------------------------------------------------------------------------------

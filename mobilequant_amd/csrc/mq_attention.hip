@@ -265,6 +265,14 @@ __global__ void __launch_bounds__(256) attention_prep_kernel(const mq_attention_
       unsigned hw[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) hw[i] = pack_h2(__fsub_rn(qi[2 * i], g.o), __fsub_rn(qi[2 * i + 1], g.o));
+      // index - offset is exact in fp16 and sum_d (iq - zq)(ik - zk) < 2^24 only while |index - offset| <= 511, i.e. for an
+      // offset in [-256, 511].  compute_scale_offset_from_min_max (qmodule.py:55-62) does not force zero into the range, so a narrow
+      // range far from zero (or a loaded / trained offset) lies outside: poison the image (NaN scores -> NaN outputs, as mq_qmatmul's
+      // `sane`) instead of contracting inexactly in silence; ops.attention_quant(f16=False) serves such a grid on the int8 contraction
+      if (!(g.o >= -256.f && g.o <= 511.f)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hw[i] = 0x7e007e00u;
+      }
       if (is_q) {
         hdst += ((size_t)head * S + s) * D + col0;
         reinterpret_cast<uint4*>(hdst)[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
@@ -533,6 +541,10 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) __attribute__((amdgpu_waves_
       }
     }
     if constexpr (F16) {
+      if (!(gqa.o >= -256.f && gqa.o <= 511.f)) {                  // (see the prep kernel: a q grid the f16 contraction cannot hold exactly)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hw[i] = 0x7e007e00u;
+      }
       qh[0] = __builtin_bit_cast(v8h, v4i{(int)hw[0], (int)hw[1], (int)hw[2], (int)hw[3]});
       qh[1] = __builtin_bit_cast(v8h, v4i{(int)hw[4], (int)hw[5], (int)hw[6], (int)hw[7]});
     } else {

@@ -845,6 +845,10 @@ __global__ void __launch_bounds__(256) decode_attention_kernel(const mq_decode_a
 // every WAVE executes (grids, addresses, reductions, barriers), not by per-position work, so 1024 threads quadruple that overhead on
 // the same four SIMDs: 1 668 tok/s at 256 threads against 1 505 at 1 024 (profiles/r06/decode_stamps_L4_1024_threads.log).
 constexpr int AO_THREADS = 256;
+// (Round 6, tried and removed: a second instantiation for long caches that keeps 2 048 positions' keys / values in registers -- the
+// keys requested behind *pos, the later value chunks behind the scores -- so that the sweeps are straight-line code without an exposed
+// round trip per 512 positions.  Slower at every context: 1 500 / 1 408 / 1 159 tok/s at 512 / 1 024 / 2 048 against 1 615 / 1 455 /
+// 1 205-1 240: 200 VGPRs of unconditional requests cost the CU's memory pipe more than three round trips.)
 template <int D>
 __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
   // Geometry (NT threads).  PPP positions per pass, KB passes requested at the top (512 positions at head_dim 64).  p.v: thread (dq = dword of 4 dims, grp) owns one position of every G-position stripe;
@@ -854,11 +858,11 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   // beyond): with four lanes per position (rounds 3-5) a sweep over 257 positions was five passes whose epilogue ran on a quarter of the
   // lanes -- 1.6 us of instruction issue; one lane per position is two passes and no cross-lane sum.
   constexpr int LPP = D / 64 >= 1 ? D / 64 : 1, CH = D / 16 < 4 ? D / 16 : 4, PPP = NT / LPP;
-  constexpr int KB = (512 / PPP < 8 / CH ? 512 / PPP : 8 / CH) >= 1 ? (512 / PPP < 8 / CH ? 512 / PPP : 8 / CH) : 1;
+  constexpr int KB0 = (512 / PPP < 8 / CH ? 512 / PPP : 8 / CH) >= 1 ? (512 / PPP < 8 / CH ? 512 / PPP : 8 / CH) : 1, KB = KB0;
   // p.v: the VALUE cache is transposed ([kv head][dim][position]): thread (d = tid % D, g = tid / D) owns dimension d of the 16-position
   // chunks g, g + NG, ...; a chunk is ONE 16-byte request and 12 v_dot4_i32_i8 against the probabilities' byte digits (below).  VC chunks
   // per thread are requested at the top (512 positions at head_dim 64).
-  constexpr int NG = NT / D >= 1 ? NT / D : 1, VC = 32 / NG > 8 ? 8 : (32 / NG >= 1 ? 32 / NG : 1);
+  constexpr int NG = NT / D >= 1 ? NT / D : 1, VC0 = 32 / NG > 8 ? 8 : (32 / NG >= 1 ? 32 / NG : 1), VC = VC0;
   constexpr int MAXC = D / 16 < 8 ? D / 16 : 8;                    // 16-byte chunks of an o_proj row slice per thread
   static_assert(NG * D == NT || D > NT, "p.v mapping");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -967,7 +971,7 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   for (int u = 0; u < KB; ++u)
     if ((u + 1) * PPP <= 256 || u == 0) load_keys(u, CL);
 #pragma unroll
-  for (int kk = 0; kk < VC; ++kk)
+  for (int kk = 0; kk < VC0; ++kk)
     if (16 * NG * (kk + 1) <= 256 || kk == 0) load_chunk(kk, 0, CL >> 4);
   int pos;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
@@ -978,7 +982,7 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
     if (!((u + 1) * PPP <= 256 || u == 0)) load_keys(u, T);
   const int nchunk = live ? (pos + 15) >> 4 : 0;                     // 16-position chunks of CACHED positions 0 .. pos - 1
 #pragma unroll
-  for (int kk = 0; kk < VC; ++kk)
+  for (int kk = 0; kk < VC0; ++kk)
     if (!(16 * NG * (kk + 1) <= 256 || kk == 0)) load_chunk(kk, 0, nchunk);
   // ---- RoPE + the three input quantizers of the new token ---------------------------------------------------------------------------
   const Grid qa = const_grid(cv, AG_QK_A, a.qk_a), qb = const_grid(cv, AG_QK_B, a.qk_b), qo = const_grid(cv, AG_QK_OUT, a.qk_out);
@@ -1291,20 +1295,58 @@ __global__ void __launch_bounds__(256) decode_head_kernel(const float* __restric
   __syncthreads();
   // a wave per vocabulary row, float4 loads (16 B per lane)
   const int nvec = K >> 2;
-  for (int row = blockIdx.x * 4 + wv; row < V; row += gridDim.x * 4) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f* wr = reinterpret_cast<const v4f*>(w + (size_t)row * K);
-    float acc = 0.f;
-    for (int i = lane; i < nvec; i += 64) {
-      const v4f a = __builtin_nontemporal_load(wr + i);
-      const float4 b = reinterpret_cast<const float4*>(s_x)[i];
-      acc += a[0] * b.x;
-      acc += a[1] * b.y;
-      acc += a[2] * b.z;
-      acc += a[3] * b.w;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int stride = gridDim.x * 4;
+  if (K % 256 == 0 && K <= 2048) {
+    // Round 6: the row's <= 8 requests per lane leave together, and the NEXT row's leave before this row's sum starts (two rows in
+    // flight per wave): the stream used to issue one request per loop trip behind the previous trip's four dependent adds -- 5.8 TB/s.
+    // The sum itself is unchanged (i ascending, four adds per request): the same bits.
+    constexpr int NV = 8;
+    const int nj = nvec >> 6;                                      // requests per lane and row (uniform)
+    v4f cur[NV], nxt[NV];
+    int row = blockIdx.x * 4 + wv;
+    auto fetch = [&](v4f (&buf)[NV], int r) {
+      const v4f* wr = reinterpret_cast<const v4f*>(w + (size_t)(r < V ? r : V - 1) * K);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) buf[j] = __builtin_nontemporal_load(wr + lane + 64 * (j < nj ? j : 0));
+    };
+    auto reduce = [&](const v4f (&buf)[NV], int r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (j < nj) {
+          const float4 b = reinterpret_cast<const float4*>(s_x)[lane + 64 * j];
+          acc += buf[j][0] * b.x;
+          acc += buf[j][1] * b.y;
+          acc += buf[j][2] * b.z;
+          acc += buf[j][3] * b.w;
+        }
+      }
+      acc = wave_sum_f(acc);
+      if (lane == 0 && r < V) logits[r] = bias ? acc + bias[r] : acc;
+    };
+    fetch(cur, row);
+    for (; row < V; row += 2 * stride) {
+      fetch(nxt, row + stride);
+      reduce(cur, row);
+      fetch(cur, row + 2 * stride);
+      reduce(nxt, row + stride);
     }
-    acc = wave_sum_f(acc);
-    if (lane == 0) logits[row] = bias ? acc + bias[row] : acc;
+  } else {
+    for (int row = blockIdx.x * 4 + wv; row < V; row += stride) {
+      const v4f* wr = reinterpret_cast<const v4f*>(w + (size_t)row * K);
+      float acc = 0.f;
+      for (int i = lane; i < nvec; i += 64) {
+        const v4f a = __builtin_nontemporal_load(wr + i);
+        const float4 b = reinterpret_cast<const float4*>(s_x)[i];
+        acc += a[0] * b.x;
+        acc += a[1] * b.y;
+        acc += a[2] * b.z;
+        acc += a[3] * b.w;
+      }
+      acc = wave_sum_f(acc);
+      if (lane == 0) logits[row] = bias ? acc + bias[row] : acc;
+    }
   }
   DG_STAMP(4);
 }

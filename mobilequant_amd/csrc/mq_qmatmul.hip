@@ -268,9 +268,9 @@ extern "C" int mq_qmatmul(const float* x1, const float* x2, float* out, int64_t 
   MQ_REQUIRE(grid1->scale && grid1->offset && grid2->scale && grid2->offset, "%s: both operands need a (static per-tensor) grid", fn);
   MQ_REQUIRE(!grid_out || !grid_out->scale || grid_out->offset, "%s: output grid without an offset", fn);
   const double span1 = (double)grid1->qmax - (double)grid1->qmin, span2 = (double)grid2->qmax - (double)grid2->qmin;
-  if (!(span1 >= 1 && span1 <= 65535 && span2 >= 1 && span2 <= 255) || (!x2_k_contiguous && N % 4 != 0) || K > (1 << 20) ||
+  if (!(span1 >= 1 && span1 <= 65535 && span2 >= 1 && span2 <= 255) || (!x2_k_contiguous && N % 4 != 0) || K > 131071 ||
       M >= (1ll << 31) - 64 || N >= (1ll << 31) - 64 || batch >= (1ll << 31) || M * K >= (1ll << 40) || N * K >= (1ll << 40)) {
-    set_error("%s: not served: grids of at most 16 (x1) / 8 (x2) bits, N %% 4 == 0 for an N-contiguous x2 (pass other widths K-contiguous), K <= 2^20", fn);
+    set_error("%s: not served: grids of at most 16 (x1) / 8 (x2) bits, N %% 4 == 0 for an N-contiguous x2 (pass other widths K-contiguous), K <= 131071 (the int32 MFMA accumulators hold K x 128 x 128)", fn);
     return MQ_EUNSUPPORTED;
   }
   QmmArgs g;

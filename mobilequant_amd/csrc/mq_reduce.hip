@@ -357,7 +357,7 @@ static int launch_cols(const T* x, int64_t rows, int64_t cols, float* mn, float*
 // into pv_bmm.input's statistic and writes them over the scores.  A wave owns a row (up to 4096 keys in registers); the four
 // running statistics are committed once per workgroup through the filtered bit-pattern atomics above (NaN sticky, as torch's amin / amax).
 template <int VPT>
-__global__ void __launch_bounds__(256) calib_probs_kernel(const float* __restrict__ raw, float* __restrict__ out, const int64_t rows, const int cols,
+__global__ void __launch_bounds__(256) calib_probs_kernel(const float* raw, float* out /* may be raw: no __restrict__ */, const int64_t rows, const int cols,
                                                           const float* __restrict__ mask, const int mask_rows, const float inv_sqrt_d,
                                                           float* mn_raw, float* mx_raw, float* mn_p, float* mx_p) {
   const int lane = threadIdx.x & 63, nvec = cols >> 2;
@@ -506,7 +506,7 @@ int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64
   hipStream_t st = as_stream(stream);
   int64_t grid = (rows + 3) / 4;
   if (grid > 2048) grid = 2048;
-  const float inv = (float)(1.0 / sqrt_d);             // torch: tensor / python float == tensor * float(1 / scalar)
+  const float inv = 1.0f / (float)sqrt_d;              // torch's CUDA div-by-scalar: tensor * (accscalar_t(1) / scalar), accscalar_t = float
 #define MQ_CALIB(V) calib_probs_kernel<V><<<(unsigned)grid, 256, 0, st>>>(raw, probs, rows, (int)cols, mask, (int)(mask ? mask_rows : 1), inv, \
                                                                          raw_min, raw_max, probs_min, probs_max)
   if (cols <= 256) MQ_CALIB(1);

@@ -122,7 +122,7 @@ class _Linear:
 
 
 class DecodeEngine:
-    LONG_FROM, LONG_SPLITS = 768, 4
+    LONG_FROM, LONG_SPLITS = 768, 4      # five launches: the split attention launch from LONG_FROM cached positions on
 
     def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5,
                  launches: int = 4):

@@ -134,7 +134,8 @@ class Attention(nn.Module):
                 and calib[0].can_fuse_attention((B, s.heads, S, k.shape[-2]), q.dtype, q.device, mask)):
             # calibration: the two [heads, S, T]-sized statistics (qk_bmm.output, pv_bmm.input) are taken inside the ONE pass that turns
             # the raw scores into probabilities, in place (calibration.ActRangeCollector.attention_probs); the module hooks skip them
-            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = ("output",), ("input",)
+            # (owner, fields): only the OWNING collector's hooks skip them -- another collector on the same model keeps its plain hooks)
+            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = (calib[0], ("output",)), (calib[0], ("input",))
             try:
                 raw = self.qk_bmm(q, k.transpose(2, 3))
                 att = calib[0].attention_probs(calib[1], calib[2], raw if raw.is_contiguous() else raw.contiguous(), mask, math.sqrt(s.head_dim))

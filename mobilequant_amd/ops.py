@@ -729,7 +729,7 @@ def qmatmul_supported(x1: torch.Tensor, x2: torch.Tensor) -> bool:
         return False
     if x1.dim() < 2 or x2.dim() != x1.dim() or x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-2] or x1.numel() == 0 or x2.numel() == 0:
         return False
-    return x1.shape[-1] <= (1 << 20)
+    return x1.shape[-1] <= 131071            # the int32 MFMA accumulators hold K x 128 x 128
 
 
 def attention_image_cache(kv_heads: int, head_dim: int, max_len: int, device) -> dict:

@@ -254,3 +254,54 @@ def test_eight_rank_get_act_range_on_a_real_model_equals_the_single_process_run(
     for rank, flat, n_ar, n_other, size in res:
         assert size == 8 and n_ar == 1 and n_other == 0, (rank, n_ar, n_other, size)
         assert flat == want, (rank, [k for k in want if flat.get(k) != want[k]][:5])
+
+
+# ---- the same path on the real thing: one rank per GPU over RCCL -------------------------------------------------
+def _rccl_worker(rank, world, port, per_channel, n_samples, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from mobilequant_amd.calibration import get_act_range
+        calls = {"all_reduce": 0}
+        real = dist.all_reduce
+
+        def counting(*a, **k):
+            calls["all_reduce"] += 1
+            return real(*a, **k)
+        dist.all_reduce = counting
+        model = _toy_llama().to(torch.device("cuda", rank))
+        act = get_act_range(model, _toy_samples(n_samples), per_channel=per_channel)
+        dist.all_reduce = real
+        flat = {f"{n}|{f}": (v.cpu().numpy().tolist() if torch.is_tensor(v) else [float(v[0]), float(v[1])]) for n, d in act.items() for f, v in d.items()}
+        q.put((rank, flat, calls["all_reduce"], dist.get_world_size(), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_get_act_range_over_rccl_on_every_gpu_of_the_box(per_channel):
+    """One process per visible GPU, backend "nccl" (= RCCL over xGMI), the full get_act_range path with its HIP reductions: every rank
+    must end with the act_dict of rank 0 running ALL samples alone (min / max are exact and order independent), after exactly ONE
+    all-reduce.  `gpurun` leases one GPU, so this skips there; the first box with more than one GPU runs it without a code change."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: the multi-rank RCCL path needs at least two (covered on CPU by the gloo tests above)")
+    from mobilequant_amd.calibration import get_act_range
+    n_samples = 2 * n + 1
+    want = get_act_range(_toy_llama().to("cuda:0"), _toy_samples(n_samples), per_channel=per_channel)
+    want = {f"{k}|{f}": (v.cpu().numpy().tolist() if torch.is_tensor(v) else [float(v[0]), float(v[1])]) for k, d in want.items() for f, v in d.items()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, n, port, per_channel, n_samples, q)) for r in range(n)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, flat, n_ar, size, backend in res:
+        assert size == n and backend == "nccl" and n_ar == 1, (rank, n_ar, size, backend)
+        assert flat == want, (rank, [k for k in want if flat.get(k) != want[k]][:5])

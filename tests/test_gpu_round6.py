@@ -169,6 +169,14 @@ def test_four_launch_step_on_long_caches_and_block_boundaries(dev):
             b = e5.step(t).clone()
             assert torch.equal(a, b), (start, e4._host_pos, float((a - b).abs().max()))
         assert torch.equal(e4.cached_values(0), e5.cached_values(0)) and torch.equal(e4.k_cache[0], e5.k_cache[0])
+    # the captured graph across the 512-position batch boundary
+    for eng in (e4, e5):
+        eng.fill_cache_random(510, seed=9)
+        eng.capture()
+    for t in (5, 17, 40, 3, 90):
+        a = e4.step(t).clone()
+        b = e5.step(t).clone()
+        assert torch.equal(a, b), ("graph", e4._host_pos, float((a - b).abs().max()))
 
 
 def test_a_geometry_the_four_launch_kernels_do_not_serve_falls_back_to_five(dev):

@@ -68,6 +68,10 @@ VARIANTS = {
     "frw4x_128r": (128, 4, "f32rw4x", "MQ_FRW4X_128R", "mq_gemm_frw4x_128r_asm.inc"),
 }
 
+# Measured-negative variants (NOTES.md 9.6 / DESIGN.md 7): their .inc files are NOT committed (9 000 lines of dead
+# ISA in csrc/); `python -m mobilequant_amd.build --experiments` regenerates them into csrc/ before it compiles with -DMQ_BUILD_EXPERIMENTS
+EXPERIMENTAL = ("fr128rs", "frw4", "frw4_128")
+
 
 def configure(name):
     """binds the module-level tile constants of one variant (the emitters read them at call time)"""
@@ -2101,5 +2105,5 @@ def main(path=None, variant="fr"):
 
 if __name__ == "__main__":
     import sys
-    for v in (sys.argv[1:] or list(VARIANTS)):
+    for v in (sys.argv[1:] or [k for k in VARIANTS if k not in EXPERIMENTAL]):
         main(variant=v)

@@ -27,7 +27,7 @@ for name, mod in model.named_modules():
         if "qk_bmm" in name: mod.output_quantizer.qcfg.bitwidth = 16
         if "pv_bmm" in name: mod.input_quantizer.qcfg.bitwidth = 16
 mq.set_scale_and_offset(model, act, "buffer")
-eng = DecodeEngine(model, cache_len=1024, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '1')), prefetch_delay_us=float(os.environ.get('PFDELAY', '1.5')))
+eng = DecodeEngine(model, cache_len=1024, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '0.5')), prefetch_delay_us=float(os.environ.get('PFDELAY', '1.5')))
 eng.fill_cache_random(256); eng.tok.fill_(17)
 for _ in range(3): eng.step()
 torch.cuda.synchronize()

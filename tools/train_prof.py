@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import bench
+import bench_variants as bench
 
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
