@@ -124,7 +124,7 @@ class _Linear:
 class DecodeEngine:
     LONG_FROM, LONG_SPLITS = 768, 4      # five launches: the split attention launch from LONG_FROM cached positions on
 
-    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: float = 1.5,
+    def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: Optional[float] = None,
                  launches: int = 4):
         """launches: 4 (round 6, default) = per layer {norm + q|k|v, RoPE / cache append / attention + o_proj's contraction, o_proj's
         epilogue + norm + w1|w3 + gate, w2}; 5 = round 2-5's chain with o_proj as a launch of its own.  A geometry the 4-launch kernels
@@ -138,11 +138,16 @@ class DecodeEngine:
         s = self.shape
         dev = next(model.parameters()).device
         self.dev, self.cache_len = dev, int(cache_len)
-        self._prefetch = (prefetch, prefetch_delay_us)
+        self._prefetch = (prefetch, prefetch_delay_us)           # (delay None: by chain, once self.launches is known)
         self.cos, self.sin = model.cos.contiguous(), model.sin.contiguous()
         self.oproj_geom = self._oproj_geometry(s, self.cos.shape[1]) if launches == 4 and self.cache_len % 16 == 0 else None
         self.launches = 4 if self.oproj_geom is not None else 5
         self.v_transposed = self.launches == 4
+        if prefetch_delay_us is None:
+            # when the prefetch rows of the attention launch start streaming w1|w3 into the L2s: behind the attention's own dependent
+            # requests.  Five launches: 1.5 us (round 3).  Four launches: 2.5 us -- 0.8 / 1.5 / 2.5 -> 1 748 / 1 743 / 1 756-1 766 tok/s
+            # (the attention + o_proj launch is longer and requests o_proj's weights behind its scores: profiles/r06/decode_prefetch_ab.log)
+            self._prefetch = (prefetch, 2.5 if self.launches == 4 else 1.5)
         if self.launches == 4:
             self.o_acc = torch.zeros(s.hidden, dtype=torch.int32, device=dev)              # o_proj's integer sums (split-K over the heads)
             self.x_mid = torch.zeros(s.hidden, device=dev)                                 # residual stream behind the attention block
