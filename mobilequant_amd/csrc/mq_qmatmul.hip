@@ -64,14 +64,20 @@ __device__ __forceinline__ void quant4(const v4f x, int nlive, float s, float in
   }
 }
 
-template <bool A16, bool BKM>
+// RF: 16-row fragments per wave = 64 RF rows per workgroup (round 6).  At RF = 1 (rounds 5) the 64 x 64 tile re-read 2 B of fp32 operand
+// through the L2s per output byte: every 64-row block of pv_bmm quantised the WHOLE of x2 again (as many bytes as its own rows of
+// x1), every tile of qk_bmm read two 16-KB operand tiles for one 16-KB output tile.  RF = 2 (128 rows): half of the x2 traffic and
+// of its quantiser arithmetic per output row (RF = 4 needs 256 VGPRs: one workgroup per CU, slower again).  Wave w owns rows 64 r + 16 w + (0 .. 15), r < RF: every round r of the epilogue stages and
+// stores 64 consecutive rows.
+template <bool A16, bool BKM, int RF>
 __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   // one LDS block: the int8 operand tiles of the K loop, then (behind the loop's last barrier) the fp32 output tile, staged so that
   // the stores are whole 256-byte rows instead of the MFMA layout's 64-byte pieces of 16 different rows
   constexpr int OP = 68;                                         // output staging pitch in floats (272 B: float4 writes of 16 rows spread over the banks)
-  constexpr int A_BYTES = (A16 ? 2 : 1) * 64 * QP, SMEM = 64 * OP * 4 > A_BYTES + 64 * QP ? 64 * OP * 4 : A_BYTES + 64 * QP;
+  constexpr int MT = 64 * RF;
+  constexpr int A_BYTES = (A16 ? 2 : 1) * MT * QP, SMEM = 64 * OP * 4 > A_BYTES + 64 * QP ? 64 * OP * 4 : A_BYTES + 64 * QP;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
-  char (*sA)[64 * QP] = reinterpret_cast<char (*)[64 * QP]>(smem);
+  char (*sA)[MT * QP] = reinterpret_cast<char (*)[MT * QP]>(smem);
   char* sB = smem + A_BYTES;
   float* sO = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +88,7 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   const int tn = (int)(lb % g.tiles_n);
   const int tm = (int)((lb / g.tiles_n) % g.tiles_m);
   const int bi = (int)(lb / ((long long)g.tiles_n * g.tiles_m));
-  const int m0 = tm * 64, n0 = tn * 64;
+  const int m0 = tm * MT, n0 = tn * 64;
   const int M = g.M, N = g.N, K = g.K;
   const float* A = g.a + (long long)bi * g.a_bs;
   const float* B = g.b + (long long)bi * g.b_bs;
@@ -98,13 +104,14 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   // N-contiguous B (x2 as [K, N]): thread -> 4 k (tid / 16 * 4 ..) x 4 n ((tid % 16) * 4 ..): four 16-byte loads along n, transposed in
   // registers into four dwords of 4 consecutive k each.
   const int lr = tid >> 2, lk = (tid & 3) * 16;
-  const int am = min(m0 + lr, M - 1);
-  const float* arow = A + (long long)am * K;
+  const float* arow[RF];
+#pragma unroll
+  for (int rf = 0; rf < RF; ++rf) arow[rf] = A + (long long)min(m0 + 64 * rf + lr, M - 1) * K;
   const int bn = min(n0 + lr, N - 1);
   const int tk4 = (tid >> 4) * 4, tn4 = (tid & 15) * 4;
   const float* brow = BKM ? B + (long long)bn * K : B;
 
-  v4f xa[4], xb[4];
+  v4f xa[RF][4], xb[4];
   // rows of K floats on a 16-byte aligned base: one dwordx4 per 4 k; else element loads
   auto load_k4 = [&](const float* row, int k, bool vec) -> v4f {
     v4f r = {0.f, 0.f, 0.f, 0.f};
@@ -119,7 +126,9 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   };
   auto load_chunk = [&](int k0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xa[c] = load_k4(arow, k0 + lk + 4 * c, g.a_vec != 0);
+    for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xa[rf][c] = load_k4(arow[rf], k0 + lk + 4 * c, g.a_vec != 0);
     if constexpr (BKM) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) xb[c] = load_k4(brow, k0 + lk + 4 * c, g.b_vec != 0);
@@ -133,25 +142,36 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
     }
   };
 
-  v4i acc_lo[4], acc_hi[4], cs[4], rs_lo = {0, 0, 0, 0}, rs_hi = {0, 0, 0, 0};
+  v4i acc_lo[RF][4], acc_hi[A16 ? RF : 1][4], cs[4], rs_lo[RF], rs_hi[A16 ? RF : 1];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc_lo[j] = acc_hi[j] = cs[j] = (v4i){0, 0, 0, 0};
+  for (int j = 0; j < 4; ++j) cs[j] = (v4i){0, 0, 0, 0};
+#pragma unroll
+  for (int rf = 0; rf < RF; ++rf) {
+    rs_lo[rf] = (v4i){0, 0, 0, 0};
+    if (A16) rs_hi[rf] = (v4i){0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc_lo[rf][j] = (v4i){0, 0, 0, 0};
+      if (A16) acc_hi[rf][j] = (v4i){0, 0, 0, 0};
+    }
+  }
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
 
   load_chunk(0);
   for (int k0 = 0; k0 < K; k0 += 64) {
     // quantise the chunk held in registers and park it in the LDS; k >= K contributes zero bytes (to the products AND to both sums)
-    {
+#pragma unroll
+    for (int rf = 0; rf < RF; ++rf) {
       v4i lo, hi;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         int l1, h1 = 0;
-        quant4<A16>(xa[c], K - (k0 + lk + 4 * c), sa, inv_sa, oa, g.ga.qmin, g.ga.qmax, a_bias, l1, h1);
+        quant4<A16>(xa[rf][c], K - (k0 + lk + 4 * c), sa, inv_sa, oa, g.ga.qmin, g.ga.qmax, a_bias, l1, h1);
         lo[c] = l1;
         hi[c] = h1;
       }
-      *reinterpret_cast<v4i*>(&sA[0][lr * QP + lk]) = lo;
-      if constexpr (A16) *reinterpret_cast<v4i*>(&sA[1][lr * QP + lk]) = hi;
+      *reinterpret_cast<v4i*>(&sA[0][(64 * rf + lr) * QP + lk]) = lo;
+      if constexpr (A16) *reinterpret_cast<v4i*>(&sA[1][(64 * rf + lr) * QP + lk]) = hi;
     }
     if constexpr (BKM) {
       v4i lo;
@@ -177,16 +197,22 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
     }
     __syncthreads();
     if (k0 + 64 < K) load_chunk(k0 + 64);                    // next chunk's loads fly under this chunk's MFMAs
-    const v4i fa = *reinterpret_cast<const v4i*>(&sA[0][(16 * wave + frow) * QP + fq * 16]);
-    v4i fah = fa;
-    if constexpr (A16) fah = *reinterpret_cast<const v4i*>(&sA[1][(16 * wave + frow) * QP + fq * 16]);
-    rs_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fa, rs_lo, 0, 0, 0);
-    if constexpr (A16) rs_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fah, rs_hi, 0, 0, 0);
+    v4i fa[RF], fah[A16 ? RF : 1];
+#pragma unroll
+    for (int rf = 0; rf < RF; ++rf) {
+      fa[rf] = *reinterpret_cast<const v4i*>(&sA[0][(64 * rf + 16 * wave + frow) * QP + fq * 16]);
+      if constexpr (A16) fah[rf] = *reinterpret_cast<const v4i*>(&sA[1][(64 * rf + 16 * wave + frow) * QP + fq * 16]);
+      rs_lo[rf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fa[rf], rs_lo[rf], 0, 0, 0);
+      if constexpr (A16) rs_hi[rf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fah[rf], rs_hi[rf], 0, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const v4i fb = *reinterpret_cast<const v4i*>(&sB[(16 * j + frow) * QP + fq * 16]);
-      acc_lo[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, fa, acc_lo[j], 0, 0, 0);      // D[n][m]: lane holds n = 4 fq + e of row m = frow
-      if constexpr (A16) acc_hi[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, fah, acc_hi[j], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) {
+        acc_lo[rf][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, fa[rf], acc_lo[rf][j], 0, 0, 0);      // D[n][m]: lane holds n = 4 fq + e of row m = frow
+        if constexpr (A16) acc_hi[rf][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, fah[rf], acc_hi[rf][j], 0, 0, 0);
+      }
       cs[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, ones, cs[j], 0, 0, 0);
     }
     __syncthreads();
@@ -196,7 +222,6 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   const float zaf = rintf(oa), zbf = rintf(ob);
   const bool sane = __builtin_fabsf(zaf) < 1048576.f && __builtin_fabsf(zbf) < 1048576.f;     // else: NaN out (a grid far from zero)
   const long long ca = (long long)g.a_shift - (long long)zaf, cb = (long long)g.b_shift - (long long)zbf;
-  const long long rs = A16 ? 256ll * rs_hi[0] + rs_lo[0] : (long long)rs_lo[0];
   const float alpha = __fmul_rn(sa, sb);
   const bool has_q = g.go.scale != nullptr;
   const float so = has_q ? uniform(g.go.scale[0]) : 1.f, oo = has_q ? uniform(g.go.offset[0]) : 0.f;
@@ -207,6 +232,11 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
   // instructions of this VALU-bound epilogue (wave-uniform choice)
   const bool fits32 = __builtin_amdgcn_readfirstlane(
       (int)(!A16 && (double)K * (255.0 + (double)(ca < 0 ? -ca : ca)) * (255.0 + (double)(cb < 0 ? -cb : cb)) < 2147483648.0)) != 0;
+  float* obase = g.out + (long long)bi * g.o_bs;
+#pragma unroll
+  for (int rf = 0; rf < RF; ++rf) {
+  if (m0 + 64 * rf >= M) break;                                  // (uniform) row blocks past the matrix
+  const long long rs = A16 ? 256ll * rs_hi[A16 ? rf : 0][0] + rs_lo[rf][0] : (long long)rs_lo[rf][0];
   const int ca32 = (int)ca, row32 = (int)(cb * rs + (long long)K * ca * cb);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -215,9 +245,9 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
     for (int e = 0; e < 4; ++e) {
       float v;
       if (fits32) {
-        v = __fmul_rn((float)(acc_lo[j][e] + ca32 * cs[j][e] + row32), alpha);
+        v = __fmul_rn((float)(acc_lo[rf][j][e] + ca32 * cs[j][e] + row32), alpha);
       } else {
-        const long long p = A16 ? 256ll * acc_hi[j][e] + acc_lo[j][e] : (long long)acc_lo[j][e];
+        const long long p = A16 ? 256ll * acc_hi[A16 ? rf : 0][j][e] + acc_lo[rf][j][e] : (long long)acc_lo[rf][j][e];
         const long long t = p + cb * rs + ca * (long long)cs[j][e] + (long long)K * ca * cb;
         v = A16 ? (float)((double)t * (double)alpha) : __fmul_rn((float)(double)t, alpha);
       }
@@ -232,12 +262,11 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
     }
     *reinterpret_cast<v4f*>(&sO[(16 * wave + frow) * OP + 16 * j + 4 * fq]) = y;        // (rows of this wave only: no workgroup barrier)
   }
-  // copy-out: the wave's 16 rows x 64 columns, 16 lanes per row
-  float* obase = g.out + (long long)bi * g.o_bs;
+  // copy-out: the wave's 16 rows x 64 columns of this round, 16 lanes per row
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = lane + 64 * i, r = idx >> 4, c4 = (idx & 15) * 4;
-    const int mm = m0 + 16 * wave + r, n = n0 + c4;
+    const int mm = m0 + 64 * rf + 16 * wave + r, n = n0 + c4;
     const v4f y = *reinterpret_cast<const v4f*>(&sO[(16 * wave + r) * OP + c4]);
     if (mm < M) {
       float* orow = obase + (long long)mm * N;
@@ -249,6 +278,7 @@ __global__ void __launch_bounds__(256) qmatmul_kernel(const QmmArgs g) {
           if (n + e < N) orow[n + e] = y[e];
       }
     }
+  }
   }
 }
 
@@ -283,7 +313,12 @@ extern "C" int mq_qmatmul(const float* x1, const float* x2, float* out, int64_t 
   // stored bytes: <= 8-bit grids as index - (qmin + 128); a wider x1 as the two byte planes of index - qmin, each minus 128
   g.a_shift = a16 ? (int)grid1->qmin + 32896 : (int)grid1->qmin + 128;
   g.b_shift = (int)grid2->qmin + 128;
-  g.tiles_m = (int)((M + 63) / 64);
+  // 256-row tiles where that still gives every CU several workgroups (the x2 tile is quantised once per 256 rows instead of per 64)
+  // 128-row tiles where that still gives every CU two workgroups: the x2 tile is fetched and quantised once per 128 rows instead of per 64
+  // (S = 2048: qk_bmm 229 -> 202 us, pv_bmm 184 -> 152 us; 256-row tiles fall back to one workgroup per CU -- 256 VGPRs -- and lose it
+  // again: 236 / 187 us, profiles/r06/bench_qmatmul.log)
+  const int rf = (M >= 256 && batch * ((M + 127) / 128) * ((N + 63) / 64) >= 512) ? 2 : 1;
+  g.tiles_m = (int)((M + 64 * rf - 1) / (64 * rf));
   g.tiles_n = (int)((N + 63) / 64);
   g.nblk = (long long)batch * g.tiles_m * g.tiles_n;
   g.a_vec = K % 4 == 0 && aligned(x1, 16);
@@ -292,13 +327,19 @@ extern "C" int mq_qmatmul(const float* x1, const float* x2, float* out, int64_t 
   MQ_REQUIRE(g.nblk < (1ll << 31), "%s: too many tiles", fn);
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)g.nblk), block(256);
+#define MQ_QMM_LAUNCH(A16, BKM)                                              \
+  do {                                                                       \
+    if (rf == 2) qmatmul_kernel<A16, BKM, 2><<<grid, block, 0, st>>>(g);     \
+    else qmatmul_kernel<A16, BKM, 1><<<grid, block, 0, st>>>(g);             \
+  } while (0)
   if (a16) {
-    if (x2_k_contiguous) qmatmul_kernel<true, true><<<grid, block, 0, st>>>(g);
-    else qmatmul_kernel<true, false><<<grid, block, 0, st>>>(g);
+    if (x2_k_contiguous) MQ_QMM_LAUNCH(true, true);
+    else MQ_QMM_LAUNCH(true, false);
   } else {
-    if (x2_k_contiguous) qmatmul_kernel<false, true><<<grid, block, 0, st>>>(g);
-    else qmatmul_kernel<false, false><<<grid, block, 0, st>>>(g);
+    if (x2_k_contiguous) MQ_QMM_LAUNCH(false, true);
+    else MQ_QMM_LAUNCH(false, false);
   }
+#undef MQ_QMM_LAUNCH
   MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
 }
