@@ -486,7 +486,8 @@ int mq_decode_attention(const mq_decode_attention_args* args, mq_stream_t stream
 
 /* Round 6: the attention of one query token AND o_proj's contraction in one launch (hf_model.py:486-534 + the o_proj QLinear,
  * qmodule.py:341-358).  Inputs, cache semantics, grids and arithmetic are mq_decode_attention's (qkv fp32, RoPE at *pos, cache append,
- * exact integer qk / pv, quantizers in their divide form).  heads x slices workgroups: workgroup (h, c) computes head h's attention
+ * exact integer qk / pv, quantizers in their divide form) EXCEPT the layout of v_cache: [kv_heads][cache_len / 16][head_dim][16] (16-position
+ * chunks of all dimensions; cache_len % 16 == 0).  heads x slices workgroups: workgroup (h, c) computes head h's attention
  * (every slice repeats it: at M = 1 the arithmetic is free, a launch boundary is not; the head's first slice appends to the cache), puts
  * the head's output on o_proj's input grid (o_in) and adds ITS share of o_proj -- rows [c, c + 1) * N / slices of the K-slice
  * [h D, (h + 1) D): o_w [heads][N][D] int8 (index - 128; one byte per weight also for 4-bit weights) -- to the int32 accumulators

@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
   const float cs = a.rope_row[dr], sn = a.rope_row[rot + dr];
   const int CL = a.cache_len;
   const int8_t* kc = a.k_cache + (size_t)kvh * CL * D;
-  const int8_t* vc = a.v_cache + (size_t)kvh * D * CL;             // [dim][position]
+  const int8_t* vc = a.v_cache + (size_t)kvh * D * CL;             // [16-position chunk][dim][16 positions]
   // ---- keys and values of the first 512 positions: the first 256 before *pos is known (addresses clamped by the cache length, masked by
   // T below), the rest behind it clamped by the position (beyond it every lane reads position 0: one line) -- requesting all 512
   // unconditionally made every workgroup pull 64 KB through its L1 at the head of the launch, 0.5 us at context 256
@@ -957,14 +957,17 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
     }
   };
   const int vd = tid & (D - 1), vg = D >= NT ? 0 : tid / D;          // this thread's dimension and chunk stripe
-  const int8_t* vrow = vc + (size_t)vd * CL;                        // transposed value cache: [dim][position]
+  // value cache: [kv head][16-position chunk][dim][position in the chunk] -- a chunk of all dimensions is D x 16 contiguous bytes, so a
+  // wave's request for (chunk j, 64 dimensions) is ONE coalesced KiB (as [dim][position] rows it touched 64 cache lines per request:
+  // the p.v sweep took 6 us at 2 048 positions)
+  const int8_t* vrow = vc + (size_t)vd * 16;
   v4i vbuf[VC];
   auto load_chunk = [&](int kk, int kbase, int lim_chunks) {         // chunk j = vg + NG (kbase + kk) of 16 positions
     const int j = vg + NG * (kbase + kk);
 #ifdef MQ_AO_WHATIF_NOVALUES
     vbuf[kk] = v4i{j, kk, kbase, lim_chunks};
 #else
-    vbuf[kk] = *reinterpret_cast<const v4i*>(vrow + 16 * (j < lim_chunks ? j : 0));
+    vbuf[kk] = *reinterpret_cast<const v4i*>(vrow + (size_t)(j < lim_chunks ? j : 0) * (D * 16));
 #endif
   };
 #pragma unroll
@@ -1005,7 +1008,7 @@ __global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(cons
     qsum_part = sq;
     if (live && c == 0 && h == kvh * (H / a.kv_heads)) {           // the group's first head (its first slice) appends to the cache
       a.k_cache[((size_t)kvh * CL + pos) * D + tid] = (int8_t)sk;
-      a.v_cache[((size_t)kvh * D + tid) * CL + pos] = (int8_t)sv;  // (transposed value cache)
+      a.v_cache[(size_t)kvh * D * CL + ((size_t)(pos >> 4) * D + tid) * 16 + (pos & 15)] = (int8_t)sv;  // (chunk-blocked transposed value cache)
     }
   }
   if (wv < (D + 63) / 64) {                                        // (the waves that hold the D query bytes)

@@ -128,8 +128,8 @@ class DecodeEngine:
                  launches: int = 4):
         """launches: 4 (round 6, default) = per layer {norm + q|k|v, RoPE / cache append / attention + o_proj's contraction, o_proj's
         epilogue + norm + w1|w3 + gate, w2}; 5 = round 2-5's chain with o_proj as a launch of its own.  A geometry the 4-launch kernels
-        do not serve falls back to 5 (self.launches says which).  The 4-launch chain keeps the VALUE cache transposed
-        ([kv_heads, head_dim, cache_len]: its p.v sweep is v_dot4 work); use cached_values() / load_cached_values() to read / write it in
+        do not serve falls back to 5 (self.launches says which).  The 4-launch chain keeps the VALUE cache transposed in 16-position chunks
+        ([kv_heads, cache_len / 16, head_dim, 16]: its p.v sweep is v_dot4 work on coalesced KiB requests); use cached_values() / load_cached_values() to read / write it in
         the logical [kv_heads, positions, head_dim] layout."""
         from .llama import LlamaForCausalLM
         assert isinstance(model, LlamaForCausalLM)
@@ -169,7 +169,9 @@ class DecodeEngine:
         self.tok = torch.zeros(1, dtype=torch.int64, device=dev)
         # keys / values as int8 indices (index - 128) on qk_bmm.input2 / pv_bmm.input2's grids
         self.k_cache = [torch.zeros(s.kv_heads, self.cache_len, s.head_dim, dtype=torch.int8, device=dev) for _ in model.layers]
-        vshape = (s.kv_heads, s.head_dim, self.cache_len) if self.v_transposed else (s.kv_heads, self.cache_len, s.head_dim)
+        # four launches: [kv_heads, cache_len / 16, head_dim, 16] -- 16-position chunks of all dimensions, each dimension's 16 positions
+        # contiguous (the p.v sweep reads a chunk as one coalesced KiB and contracts it with v_dot4); five launches: [kv_heads, cache_len, head_dim]
+        vshape = (s.kv_heads, self.cache_len // 16, s.head_dim, 16) if self.v_transposed else (s.kv_heads, self.cache_len, s.head_dim)
         self.v_cache = [torch.zeros(vshape, dtype=torch.int8, device=dev) for _ in model.layers]
         self._host_pos = 0                                   # mirror of self.pos for the cache-overflow guard (no device read-back)
         assert self.cos.shape[0] >= self.cache_len, "rope tables shorter than the cache"
@@ -518,13 +520,21 @@ class DecodeEngine:
         """Layer li's cached values as [kv_heads, n positions, head_dim] int8 indices (index - 128), whatever the engine's layout."""
         n = self._host_pos if n is None else int(n)
         c = self.v_cache[li]
-        return c[:, :, :n].transpose(1, 2) if self.v_transposed else c[:, :n]
+        if not self.v_transposed:
+            return c[:, :n]
+        s = self.shape
+        return c.permute(0, 1, 3, 2).reshape(s.kv_heads, self.cache_len, s.head_dim)[:, :n]      # [kv, chunk, 16, dim] -> [kv, position, dim]
 
     def load_cached_values(self, li: int, values: torch.Tensor):
         """values [kv_heads, n, head_dim] int8 -> positions 0 .. n - 1 of layer li's value cache."""
         n = values.shape[1]
         if self.v_transposed:
-            self.v_cache[li][:, :, :n] = values.transpose(1, 2)
+            s, full = self.shape, (n + 15) // 16
+            pad = torch.zeros(s.kv_heads, full * 16, s.head_dim, dtype=torch.int8, device=self.dev)
+            pad[:, :n] = values
+            old = self.v_cache[li][:, :full].permute(0, 1, 3, 2).reshape(s.kv_heads, full * 16, s.head_dim)
+            pad[:, n:] = old[:, n:]                                  # (positions behind n in the last chunk keep what they held)
+            self.v_cache[li][:, :full] = pad.view(s.kv_heads, full, 16, s.head_dim).permute(0, 1, 3, 2)
         else:
             self.v_cache[li][:, :n] = values
 

@@ -20,8 +20,8 @@ from mobilequant_amd.llama import LlamaForCausalLM, LlamaShape  # noqa: E402
 KINDS = {0: "gemv norm (qkv)", 1: "gemv norm+gate (w1|w3)", 2: "gemv f32 in (o_proj)", 3: "gemv i8 in (w2)", 4: "attention", 5: "head"}
 
 
-def build_engine(dev, layers, wbits=8, cache_len=1024):
-    shape = LlamaShape.tinyllama(max_pos=2048, layers=layers)
+def build_engine(dev, layers, wbits=8, cache_len=int(os.environ.get("CACHE", "1024"))):
+    shape = LlamaShape.tinyllama(max_pos=max(2048, cache_len), layers=layers)
     model = LlamaForCausalLM(shape); model.reset_parameters(seed=1); model = model.to(dev).eval().requires_grad_(False)
     g = torch.Generator().manual_seed(1)
     act = get_act_range(model, [torch.randint(3, shape.vocab, (1, 256), generator=g)])
@@ -36,7 +36,7 @@ def build_engine(dev, layers, wbits=8, cache_len=1024):
             if "qk_bmm" in name: mod.output_quantizer.qcfg.bitwidth = 16
             if "pv_bmm" in name: mod.input_quantizer.qcfg.bitwidth = 16
     mq.set_scale_and_offset(model, act, "buffer")
-    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '0.5')), prefetch_delay_us=float(os.environ.get('PFDELAY', '1.5')), launches=int(os.environ.get('LAUNCHES', '4')))
+    return DecodeEngine(model, cache_len=cache_len, attn_splits=int(os.environ.get('SPLITS', '1')), prefetch=float(os.environ.get('PREFETCH', '0.5')), prefetch_delay_us=float(os.environ.get('PFDELAY', '2.5')), launches=int(os.environ.get('LAUNCHES', '4')))
 
 
 def main():
