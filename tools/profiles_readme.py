@@ -29,6 +29,17 @@ LOG_CAPTIONS = {
     "div_check_wide.log": "the same, 32 more divisors (scale clamps, all-ones significands)",
     "fr128_ab.log": "`tools/bench_fr128.py`: the 128-column generated GEMMs against the C++ tile kernels they replace",
     "decode_context_sweep.log": "`tools/decode_context_sweep.py`: ms per token against cached positions for 1 / 2 / 4 / 8 attention workgroups per head and the by-position default",
+    # round 6 (tools/evidence_r06.sh, tools/r06_decode_ab.py, tools/r06_whatif.sh)
+    "atomic_probe.log": "`tools/atomic_probe.cpp`: price of 65 536 no-return device-scope int32 atomics (32 adders per address) between two launches -- the split-K hand-off of o_proj inside the attention launch",
+    "decode_base.log": "the five-launch decode engine at the START of round 6 (tok/s at 256 / 1 024 / 2 048 cached positions)",
+    "decode_4launch_vs_5launch.log": "`bench.bench_decode_full(launches=4 | 5)` on one box: the four-launch chain against the five-launch chain",
+    "decode_stamps_L4.log": "`LAUNCHES=4 tools/decode_stamps.py` (`-DMQ_DECODE_STAMPS` build, 6 layers, context 256): per-launch gap / ramp / in-kernel stamps of the four-launch decode step",
+    "decode_stamps_L5.log": "the same for the five-launch chain (`LAUNCHES=5`) on the same box",
+    "decode_prefetch_ab.log": "`tools/r06_decode_ab.py`: share and start time of the attention launch's L2 prefetch rows",
+    "decode_whatif_kv_loads.log": "`tools/r06_whatif.sh`: what-if builds of the attention + o_proj launch without its key / value requests",
+    "bench_qmatmul.log": "`tools/bench_qmatmul.py` with 64 / 128 / 256 rows per workgroup",
+    "fuzz_and_per_sequence_ppl.log": "`pytest tests/test_gpu_fuzz.py tests/test_gpu_round5.py -k 'fuzz or perplexity' -s`: the fuzzer slices inside `-m gpu` and the per-sequence perplexity differences",
+    "bench_wall.log": "wall time of `python bench.py --steps 20 --warmup 5` (round 5: 173 s)",
     # round 4 (everything below is rewritten by tools/evidence_r04.sh)
     "boundary_probe.log": "`tools/hole_probe.py` on the stamped build (`tools/build_stamped.sh`): kernel boundary behind the headline GEMM from in-kernel `s_memrealtime` stamps, per-XCD anatomy and clock, K sweep",
     "grid_barrier_probe.log": "`tools/barrier_probe.cpp 2000`: software grid barriers among 256 resident workgroups -- single counter, round 2's hierarchy, and the microarchitecture guide's XCD-hierarchical recipe",
