@@ -186,3 +186,41 @@ def test_a_geometry_the_four_launch_kernels_do_not_serve_falls_back_to_five(dev)
     assert DecodeEngine._oproj_geometry(LlamaShape.gemma_2b(), 256) == (32, 2)
     assert DecodeEngine._oproj_geometry(LlamaShape.stablelm_2_1_6b(), 16) == (8, 1)
     assert DecodeEngine._oproj_geometry(LlamaShape(hidden=8192, heads=64, kv_heads=8, head_dim=128), 128) is None      # K > 4096: OPRE prologue
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 5632), (2048, 2048, 2048)])
+def test_residual_gemm_family_against_a_numpy_oracle_every_output(dev, M, N, K):
+    """the generated residual kernels (`fr128r` / `fr128r8`: w2 and o_proj of the fused layer, x + Q16(linear) in
+    fp32) reached the oracle only through "== the C++ kernel" tests.  Here, at the BASELINE shapes (2048, 2048 <- 5632) and (2048, 2048 <-
+    2048), every output is compared with numpy: exact int64 contraction, t = acc - w_zp rowsum + col_term, then the epilogue's documented
+    fp32 expression (one conversion, ONE fma on the pre-divided constants alpha / s_o and bias / s_o, rint, + offset, clamp to
+    the 16-bit grid, (q - o) s_o, + residual) -- the fma evaluated exactly (float64 product + sum; rational arithmetic where the float64
+    sum sits on a rounding boundary)."""
+    import test_gpu_round2 as T2
+    import test_gpu_round3 as T3
+    from mobilequant_amd import ops
+    a_q, w_q, a_rs, alpha, w_zp, col_term, b = T3._gemm_operands(dev, M, N, K, 7 * M + N + K, False, True)
+    resid = torch.randn(M, N, device=dev)
+    so_f, oo_f = np.float32(3.1e-4), np.float32(32768.0)
+    so, oo = torch.tensor([float(so_f)], device=dev), torch.tensor([float(oo_f)], device=dev)
+    got = ops.int8_linear(T3._to_tiled(a_q), w_q, a_rs, alpha, w_zp, col_term, b, resid=resid, a_tiled_rows=M,
+                          out_scale=so, out_offset=oo, out_qmin=0.0, out_qmax=65535.0).cpu().numpy()
+    F32 = np.float32
+    acc = a_q.cpu().numpy().astype(np.int64) @ w_q.cpu().numpy().astype(np.int64).T
+    t = acc - w_zp.cpu().numpy().astype(np.int64)[None, :] * a_rs.cpu().numpy().astype(np.int64)[:, None] + col_term.cpu().numpy().astype(np.int64)[None, :]
+    assert np.abs(t).max() < 2 ** 31
+    inv = F32(1.0) / so_f
+    a_p = (alpha.cpu().numpy().astype(F32) * inv).astype(F32)
+    b_p = (b.cpu().numpy().astype(F32) * inv).astype(F32)
+    tf = t.astype(F32)                                          # v_cvt_f32_i32: round to nearest even
+    v64 = tf.astype(np.float64) * a_p.astype(np.float64)[None, :] + b_p.astype(np.float64)[None, :]
+    v = v64.astype(F32)
+    frac = np.abs(v64 - np.rint(v64))
+    for m, n in zip(*np.nonzero(np.abs(frac - 0.5) < 1e-6)):     # the float64 sum (almost) on an index boundary: decide exactly
+        v[m, n] = T2._fma_f32_exact(int(tf[m, n]), a_p[n], b_p[n])
+    q = np.clip(np.rint(v) + oo_f, F32(0.0), F32(65535.0)).astype(F32)
+    y = ((q - oo_f).astype(F32) * so_f).astype(F32)
+    want = (resid.cpu().numpy() + y).astype(F32)
+    assert q.min() < 20000 and q.max() > 45000                  # the grid is exercised, not saturated
+    neq = got.view(np.uint32) != want.view(np.uint32)
+    assert not neq.any(), (int(neq.sum()), float(np.abs(got - want).max()))
