@@ -224,3 +224,33 @@ def test_residual_gemm_family_against_a_numpy_oracle_every_output(dev, M, N, K):
     assert q.min() < 20000 and q.max() > 45000                  # the grid is exercised, not saturated
     neq = got.view(np.uint32) != want.view(np.uint32)
     assert not neq.any(), (int(neq.sum()), float(np.abs(got - want).max()))
+
+
+@pytest.mark.parametrize("tag", ["w8a8", "w4a8"])
+def test_four_launch_chain_at_full_size_and_full_occupancy_bit_for_bit(dev, tag):
+    """The same identity at TinyLlama-1.1B's real geometry (22 layers, hidden 2048, 32 / 4 heads, FFN 5632: 256 workgroups = one per CU
+    in the attention + o_proj launch, 65 536 atomics per layer), from the captured hipGraphs, over 300 steps that cross the 256-position
+    batch boundary: the split-K atomics and every cross-launch hand-off (accumulators cleared by one launch, added to by the next, read by
+    the third; the chunk-blocked value cache appended while other workgroups sweep it) under the occupancy and timing the benchmark runs
+    at.  The model is the contractive one of the perplexity test (the reference's real HFForCausalLM weights)."""
+    from test_gpu_round5 import _stable_model
+    from mobilequant_amd.decode import DecodeEngine
+    import dataclasses
+    from mobilequant_amd import llama
+    m, z = _stable_model(dev, tag)
+    cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=320))
+    m.cos, m.sin = cos.to(dev), sin.to(dev)
+    e4 = DecodeEngine(m, cache_len=320)
+    e5 = DecodeEngine(m, cache_len=320, launches=5, attn_splits=1)
+    assert e4.launches == 4 and len(e4.phases) == 88
+    e4.capture()
+    e5.capture()
+    ids = np.concatenate([z["ids"], z["ids_more"][0]])[:300].tolist()
+    for pos, t in enumerate(ids):
+        a = e4.step(int(t))
+        b = e5.step(int(t))
+        if pos % 10 == 0 or pos > 250:
+            assert torch.equal(a, b), (tag, pos, float((a - b).abs().max()))
+    assert torch.equal(e4.logits, e5.logits) and torch.equal(e4.x, e5.x)
+    for li in (0, 10, 21):
+        assert torch.equal(e4.k_cache[li][:, :300], e5.k_cache[li][:, :300]) and torch.equal(e4.cached_values(li, 300), e5.cached_values(li, 300)), li
