@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(DG_THREADS) decode_gemv_kernel(const mq_decode
 
   if (wave < DG_PRO) {
     // ================================================ PROLOGUE role ====================================================================
+    // (s_setprio 3 for these waves -- the launch's critical chain, sharing SIMDs with the stream waves -- measured neutral: round 6)
     const int p = threadIdx.x;                                     // 0 .. 511
     int my_sum = 0;
     if constexpr (XMODE == XM_I8) {                                // ready int8 image (w2 after the gated epilogue): copy + row sum
