@@ -47,7 +47,7 @@ class MqDecodeAttentionOprojArgs(ctypes.Structure):
                 ("o_acc", c_void_p), ("N", c_int), ("slices", c_int), ("tpr", c_int), ("lg_slices", c_int), ("lg_group", c_int), ("lg_kv", c_int),
                 ("out_q", c_void_p), ("prefetch", c_void_p),
                 ("prefetch_bytes_per_wg", c_int64), ("prefetch_stride", c_int64), ("prefetch_total", c_int64), ("prefetch_wgs", c_int),
-                ("prefetch_delay", c_int)]
+                ("prefetch_delay", c_int), ("threads", c_int)]
 
 
 class MqDecodeAttentionArgs(ctypes.Structure):

@@ -850,11 +850,15 @@ constexpr int AO_THREADS = 256;
 // keys requested behind *pos, the later value chunks behind the scores -- so that the sweeps are straight-line code without an exposed
 // round trip per 512 positions.  Slower at every context: 1 500 / 1 408 / 1 159 tok/s at 512 / 1 024 / 2 048 against 1 615 / 1 455 /
 // 1 205-1 240: 200 VGPRs of unconditional requests cost the CU's memory pipe more than three round trips.)
-template <int D>
-__global__ void __launch_bounds__(AO_THREADS) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
+// NT_ = AO_THREADS (256) is the launch for short caches; NT_ = AO_THREADS_LONG (1024) the one DecodeEngine replays from
+// DecodeEngine.LONG4_FROM cached positions on: there the per-position arithmetic (which every slice of a head repeats) outweighs the
+// per-wave overhead, and four times the lanes take a quarter of the positions each.  No prefetch rows then (sixteen waves fill the CU).
+constexpr int AO_THREADS_LONG = 1024;
+template <int D, int NT_>
+__global__ void __launch_bounds__(NT_) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
   // Geometry (NT threads).  PPP positions per pass, KB passes requested at the top (512 positions at head_dim 64).  p.v: thread (dq = dword of 4 dims, grp) owns one position of every G-position stripe;
   // BLK positions per block, PPB stripes per block; VB stripes (<= 32 registers: 512 positions at head_dim 64) requested at the top.
-  constexpr int NT = AO_THREADS, NW = NT / 64;
+  constexpr int NT = NT_, NW = NT / 64;
   // Scores: ONE lane per cached position at head_dim <= 64 (the whole key row: CH = 4 16-byte chunks per lane, LPP lanes per position
   // beyond): with four lanes per position (rounds 3-5) a sweep over 257 positions was five passes whose epilogue ran on a quarter of the
   // lanes -- 1.6 us of instruction issue; one lane per position is two passes and no cross-lane sum.
@@ -1540,7 +1544,7 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
   MQ_REQUIRE(a.o_in.scale && a.o_in.qmin == 0.f && a.o_in.qmax == 255.f, "mq_decode_attention_oproj: o_proj needs an 8-bit unsigned input grid (o_in)");
   const int chunks = a.head_dim / 16;
   MQ_REQUIRE(a.N > 0 && a.slices > 0 && a.N % a.slices == 0 && (a.tpr == 1 || a.tpr == 2 || a.tpr == 4) && chunks % a.tpr == 0 && chunks / a.tpr <= 8 &&
-                 (a.N / a.slices) * a.tpr <= AO_THREADS && (long long)a.heads * a.slices <= 65535,
+                 (a.N / a.slices) * a.tpr <= AO_THREADS && (long long)a.heads * a.slices <= 65535 && (a.threads == 0 || a.threads == AO_THREADS || a.threads == AO_THREADS_LONG),
              "mq_decode_attention_oproj: N=%d slices=%d tpr=%d: N %% slices == 0, tpr in {1, 2, 4} dividing head_dim / 16 with <= 8 chunks per thread, "
              "N / slices * tpr <= %d", a.N, a.slices, a.tpr, AO_THREADS);
   MQ_REQUIRE(a.lg_slices < 0 || ((1 << a.lg_slices) == a.slices && (1 << a.lg_kv) == a.kv_heads && (a.kv_heads << a.lg_group) == a.heads &&
@@ -1553,12 +1557,13 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
              "mq_decode_attention_oproj: prefetch needs a 16-byte aligned range, 1..4096 workgroups, stride >= bytes per workgroup, delay in 0..100000 (10 ns units)");
   MQ_REQUIRE(a.cache_len % 16 == 0, "mq_decode_attention_oproj: cache_len=%d must be a multiple of 16 (transposed value cache, 16-byte chunks)", a.cache_len);
   const size_t lds = (size_t)a.cache_len * (sizeof(float) + 3);
-  const void* fn = a.head_dim == 32 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<32>)
-                   : a.head_dim == 64 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<64>)
-                   : a.head_dim == 128 ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<128>)
-                                       : reinterpret_cast<const void*>(decode_attention_oproj_kernel<256>);
-  static std::atomic<size_t> lds_set[kMaxDevices][4];
-  const int dev = current_device(), ki = a.head_dim == 32 ? 0 : a.head_dim == 64 ? 1 : a.head_dim == 128 ? 2 : 3;
+  const bool lng = a.threads == AO_THREADS_LONG;
+  MQ_REQUIRE(!lng || a.prefetch_wgs == 0, "mq_decode_attention_oproj: the 1024-thread launch carries no prefetch rows (prefetch_wgs = 0)");
+#define MQ_AO_FN(DD) (lng ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<DD, AO_THREADS_LONG>) : reinterpret_cast<const void*>(decode_attention_oproj_kernel<DD, AO_THREADS>))
+  const void* fn = a.head_dim == 32 ? MQ_AO_FN(32) : a.head_dim == 64 ? MQ_AO_FN(64) : a.head_dim == 128 ? MQ_AO_FN(128) : MQ_AO_FN(256);
+#undef MQ_AO_FN
+  static std::atomic<size_t> lds_set[kMaxDevices][8];
+  const int dev = current_device(), ki = (a.head_dim == 32 ? 0 : a.head_dim == 64 ? 1 : a.head_dim == 128 ? 2 : 3) + (lng ? 4 : 0);
   if (lds > 16384 && lds_set[dev][ki].load(std::memory_order_relaxed) < lds) {      // (the kernel holds ~33 KB of static LDS)
     MQ_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                "mq_decode_attention_oproj: %zu bytes of dynamic LDS rejected", lds);
@@ -1567,12 +1572,18 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
   const unsigned grid = (unsigned)(a.heads * a.slices + a.prefetch_wgs);
   unsigned long long* stamps = STAMP_SLOT(4, (unsigned)(a.heads * a.slices));
   hipStream_t st = as_stream(stream);
+#define MQ_AO_LAUNCH(DD)                                                                                              \
+  do {                                                                                                                \
+    if (lng) decode_attention_oproj_kernel<DD, AO_THREADS_LONG><<<grid, AO_THREADS_LONG, lds, st>>>(a, stamps);      \
+    else decode_attention_oproj_kernel<DD, AO_THREADS><<<grid, AO_THREADS, lds, st>>>(a, stamps);                    \
+  } while (0)
   switch (a.head_dim) {
-    case 32: decode_attention_oproj_kernel<32><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
-    case 64: decode_attention_oproj_kernel<64><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
-    case 128: decode_attention_oproj_kernel<128><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
-    default: decode_attention_oproj_kernel<256><<<grid, AO_THREADS, lds, st>>>(a, stamps); break;
+    case 32: MQ_AO_LAUNCH(32); break;
+    case 64: MQ_AO_LAUNCH(64); break;
+    case 128: MQ_AO_LAUNCH(128); break;
+    default: MQ_AO_LAUNCH(256); break;
   }
+#undef MQ_AO_LAUNCH
   MQ_LAUNCH_CHECK("mq_decode_attention_oproj");
   return MQ_OK;
 }

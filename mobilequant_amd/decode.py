@@ -123,9 +123,11 @@ class _Linear:
 
 class DecodeEngine:
     LONG_FROM, LONG_SPLITS = 768, 4      # five launches: the split attention launch from LONG_FROM cached positions on
+    LONG4_FROM = 1024                    # four launches: the 1024-thread attention + o_proj launch from here on (mq_decode_attention_oproj_args.threads):
+                                         # 256 / 1024 threads at 256 | 512 | 1024 | 2048 positions: 1768 | 1701 | 1555 | 1331 against 1640 | 1618 | 1572 | 1451 tok/s
 
     def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: Optional[float] = None,
-                 launches: int = 4):
+                 launches: int = 4, long_from: Optional[int] = None):
         """launches: 4 (round 6, default) = per layer {norm + q|k|v, RoPE / cache append / attention + o_proj's contraction, o_proj's
         epilogue + norm + w1|w3 + gate, w2}; 5 = round 2-5's chain with o_proj as a launch of its own.  A geometry the 4-launch kernels
         do not serve falls back to 5 (self.launches says which).  The 4-launch chain keeps the VALUE cache transposed in 16-position chunks
@@ -143,6 +145,7 @@ class DecodeEngine:
         self.oproj_geom = self._oproj_geometry(s, self.cos.shape[1]) if launches == 4 and self.cache_len % 16 == 0 else None
         self.launches = 4 if self.oproj_geom is not None else 5
         self.v_transposed = self.launches == 4
+        self.long_from = self.LONG4_FROM if long_from is None else int(long_from)      # (four launches) first position of the long-cache graph
         if prefetch_delay_us is None:
             # when the prefetch rows of the attention launch start streaming w1|w3 into the L2s: behind the attention's own dependent
             # requests.  Five launches: 1.5 us (round 3).  Four launches: 2.5 us -- 0.8 / 1.5 / 2.5 -> 1 748 / 1 743 / 1 756-1 766 tok/s
@@ -467,18 +470,24 @@ class DecodeEngine:
         for kind, a in phases:
             if kind == "attn":
                 a.nsplit = int(n)
+            elif kind == "attn_oproj":                            # n > 1: the long-cache launch (1024 threads, no prefetch rows)
+                if not hasattr(a, "_mq_pf"):
+                    a._mq_pf = a.prefetch_wgs
+                a.threads, a.prefetch_wgs = (1024, 0) if n > 1 else (256, a._mq_pf)
 
     def _variants(self):
         """[(phases, attention splits)]: what runs below / from LONG_FROM positions on (5 launches: the split attention launch)."""
         if self.launches == 4:
-            return [(self.phases, 1)]
+            if self.long_from <= 0:
+                return [(self.phases, 2)]
+            return [(self.phases, 1)] + ([(self.phases, 2)] if self.cache_len > self.long_from else [])
         v = [(self.phases, self.attn_splits)]
         if self.auto_splits and self.cache_len > self.LONG_FROM:
             v.append((self.phases, self.LONG_SPLITS))
         return v
 
     def _long_threshold(self) -> int:
-        return self.LONG_FROM
+        return self.long_from if self.launches == 4 else self.LONG_FROM
 
     def _variant_at(self, pos: int) -> int:
         return 1 if len(self._variants()) > 1 and pos >= self._long_threshold() else 0

@@ -79,6 +79,7 @@ def test_four_launch_step_is_the_five_launch_step_bit_for_bit(dev, name):
     m, ids = _model(dev, name)
     e4 = DecodeEngine(m, cache_len=160)
     e5 = DecodeEngine(m, cache_len=160, launches=5, attn_splits=1)
+    e4l = DecodeEngine(m, cache_len=160, long_from=0)             # the long-cache (1024-thread) attention + o_proj launch at every position
     assert e4.launches == 4 and e5.launches == 5, "the four-launch kernels must serve this geometry"
     assert len(e4.phases) == 4 * len(m.layers) and len(e5.phases) == 5 * len(m.layers)
     if FAMILIES[name][1] == 4:
@@ -86,7 +87,9 @@ def test_four_launch_step_is_the_five_launch_step_bit_for_bit(dev, name):
     for pos, t in enumerate(ids.tolist()):
         a = e4.step(t).clone()
         b = e5.step(t).clone()
+        c = e4l.step(t).clone()
         assert torch.equal(a, b), (name, pos, float((a - b).abs().max()))
+        assert torch.equal(c, b), (name, "1024 threads", pos, float((c - b).abs().max()))
     for li in range(len(m.layers)):                            # the RoPE epilogue's cache append == the attention launch's
         n = len(ids)
         assert e4.v_transposed and not e5.v_transposed            # [kv, dim, position] against [kv, position, dim]: compare the logical content
@@ -158,17 +161,32 @@ def test_four_launch_step_on_long_caches_and_block_boundaries(dev):
     m, ids = _model(dev, "llama_gqa")
     cos, sin = llama.rope_tables(dataclasses.replace(m.shape, max_pos=1600))
     m.cos, m.sin = cos.to(dev), sin.to(dev)
-    e4 = DecodeEngine(m, cache_len=1600)
+    e4 = DecodeEngine(m, cache_len=1600, long_from=10 ** 6)       # the 256-thread launch at every position
+    e4l = DecodeEngine(m, cache_len=1600, long_from=0)            # the 1024-thread launch at every position
     e5 = DecodeEngine(m, cache_len=1600, launches=5, attn_splits=1)
-    assert e4.launches == 4
+    assert e4.launches == 4 and e4l.launches == 4
     for start in (14, 254, 510, 766, 1022, 1278, 1534):
-        for eng in (e4, e5):
+        for eng in (e4, e4l, e5):
             eng.fill_cache_random(start, seed=start)
-        for t in (5, 17, 40, 3):                          # the steps cross position start + 2 = a multiple of 16 / 256 / 512
+        for t in (5, 17, 40, 3):                          # the steps cross position start + 2 = a multiple of 16 / 256 / 512 / 1024
             a = e4.step(t).clone()
+            c = e4l.step(t).clone()
             b = e5.step(t).clone()
             assert torch.equal(a, b), (start, e4._host_pos, float((a - b).abs().max()))
+            assert torch.equal(c, b), (start, "1024 threads", e4._host_pos, float((c - b).abs().max()))
         assert torch.equal(e4.cached_values(0), e5.cached_values(0)) and torch.equal(e4.k_cache[0], e5.k_cache[0])
+        assert torch.equal(e4l.cached_values(0), e5.cached_values(0)) and torch.equal(e4l.k_cache[0], e5.k_cache[0])
+    # the default engine: two captured graphs, the 1024-thread one from LONG4_FROM cached positions on
+    e4 = DecodeEngine(m, cache_len=1600)
+    assert e4._long_threshold() == DecodeEngine.LONG4_FROM
+    for eng in (e4, e5):
+        eng.fill_cache_random(DecodeEngine.LONG4_FROM - 2, seed=5)
+        eng.capture()
+    assert e4.graph_long is not None
+    for t in (5, 17, 40, 3, 90):
+        a = e4.step(t).clone()
+        b = e5.step(t).clone()
+        assert torch.equal(a, b), ("graphs", e4._host_pos, float((a - b).abs().max()))
     # the captured graph across the 512-position batch boundary
     for eng in (e4, e5):
         eng.fill_cache_random(510, seed=9)
