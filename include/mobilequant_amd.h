@@ -517,7 +517,7 @@ typedef struct mq_decode_attention_oproj_args {
   int64_t prefetch_bytes_per_wg, prefetch_stride, prefetch_total;
   int prefetch_wgs, prefetch_delay;
   int threads; /* 0 / 256: the launch for short caches; 1024: four times the lanes per workgroup (same results) -- faster from a few hundred
-                * cached positions on, slower below; needs prefetch_wgs = 0 */
+                * cached positions on, slower below; the prefetch share (<= 48 KiB per workgroup) is then requested by the attention workgroups themselves */
 } mq_decode_attention_oproj_args;
 int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_stream_t stream);
 /* Token start (sim_model.py:160-175: embed_tokens of the new token): x [hidden] <- table [vocab, hidden] row *tok, and (rope_row != NULL)

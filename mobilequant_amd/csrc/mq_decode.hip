@@ -852,7 +852,8 @@ constexpr int AO_THREADS = 256;
 // 1 205-1 240: 200 VGPRs of unconditional requests cost the CU's memory pipe more than three round trips.)
 // NT_ = AO_THREADS (256) is the launch for short caches; NT_ = AO_THREADS_LONG (1024) the one DecodeEngine replays from
 // DecodeEngine.LONG4_FROM cached positions on: there the per-position arithmetic (which every slice of a head repeats) outweighs the
-// per-wave overhead, and four times the lanes take a quarter of the positions each.  No prefetch rows then (sixteen waves fill the CU).
+// per-wave overhead, and four times the lanes take a quarter of the positions each.  No prefetch ROWS then (sixteen waves fill the CU):
+// the workgroups carry the prefetch share themselves.
 constexpr int AO_THREADS_LONG = 1024;
 template <int D, int NT_>
 __global__ void __launch_bounds__(NT_) decode_attention_oproj_kernel(const mq_decode_attention_oproj_args a, unsigned long long* stamps) {
@@ -1108,6 +1109,24 @@ __global__ void __launch_bounds__(NT_) decode_attention_oproj_kernel(const mq_de
     for (int j = 0; j < MAXC; ++j) wbuf[j] = __builtin_nontemporal_load(wp + (j < cpt ? j : 0));
   }
   const int o_zp = a.o_wzp[n_out];
+  // 1024 threads: no room for co-resident prefetch workgroups, so every workgroup pulls its own share of the later weight stream into the
+  // L2 of the XCD it runs on (piece b = what workgroup b of that launch will read): three 16-byte requests per thread, never waited for
+  // before the kernel's last instruction
+  constexpr int PFN = NT > 256 ? 3 : 0;
+  v4i pf[PFN > 0 ? PFN : 1];
+  if constexpr (PFN > 0) {
+    const int q = blockIdx.x;
+    const size_t beg = (size_t)q * a.prefetch_stride;
+    const size_t end = beg + a.prefetch_bytes_per_wg < a.prefetch_total ? beg + a.prefetch_bytes_per_wg : a.prefetch_total;
+    const bool on = q < a.prefetch_wgs && end > beg;
+    const v4i* p = on ? reinterpret_cast<const v4i*>(a.prefetch + beg) : reinterpret_cast<const v4i*>(a.o_w);
+    const size_t n = on ? (end - beg) >> 4 : 1;
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const size_t i = (size_t)tid + (size_t)u * NT;
+      pf[u] = p[i < n ? i : 0];
+    }
+  }
   __syncthreads();
   DG_STAMP(2);
   float mx = s_redf[0];
@@ -1230,6 +1249,10 @@ __global__ void __launch_bounds__(NT_) decode_attention_oproj_kernel(const mq_de
   if (o_ok && osub == 0 && live) {
     const int v = (int)((unsigned)part - (unsigned)o_zp * (unsigned)rs_h);
     __hip_atomic_fetch_add(a.o_acc + n_out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if constexpr (PFN > 0) {
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) asm volatile("" ::"v"(pf[u]));
   }
 #ifdef MQ_DECODE_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1558,7 +1581,6 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
   MQ_REQUIRE(a.cache_len % 16 == 0, "mq_decode_attention_oproj: cache_len=%d must be a multiple of 16 (transposed value cache, 16-byte chunks)", a.cache_len);
   const size_t lds = (size_t)a.cache_len * (sizeof(float) + 3);
   const bool lng = a.threads == AO_THREADS_LONG;
-  MQ_REQUIRE(!lng || a.prefetch_wgs == 0, "mq_decode_attention_oproj: the 1024-thread launch carries no prefetch rows (prefetch_wgs = 0)");
 #define MQ_AO_FN(DD) (lng ? reinterpret_cast<const void*>(decode_attention_oproj_kernel<DD, AO_THREADS_LONG>) : reinterpret_cast<const void*>(decode_attention_oproj_kernel<DD, AO_THREADS>))
   const void* fn = a.head_dim == 32 ? MQ_AO_FN(32) : a.head_dim == 64 ? MQ_AO_FN(64) : a.head_dim == 128 ? MQ_AO_FN(128) : MQ_AO_FN(256);
 #undef MQ_AO_FN
@@ -1569,7 +1591,7 @@ int mq_decode_attention_oproj(const mq_decode_attention_oproj_args* args, mq_str
                "mq_decode_attention_oproj: %zu bytes of dynamic LDS rejected", lds);
     lds_set[dev][ki].store(lds, std::memory_order_relaxed);
   }
-  const unsigned grid = (unsigned)(a.heads * a.slices + a.prefetch_wgs);
+  const unsigned grid = (unsigned)(a.heads * a.slices + (lng ? 0 : a.prefetch_wgs));      // (1024 threads: the prefetch share rides inside the workgroups)
   unsigned long long* stamps = STAMP_SLOT(4, (unsigned)(a.heads * a.slices));
   hipStream_t st = as_stream(stream);
 #define MQ_AO_LAUNCH(DD)                                                                                              \

@@ -124,7 +124,7 @@ class _Linear:
 class DecodeEngine:
     LONG_FROM, LONG_SPLITS = 768, 4      # five launches: the split attention launch from LONG_FROM cached positions on
     LONG4_FROM = 1024                    # four launches: the 1024-thread attention + o_proj launch from here on (mq_decode_attention_oproj_args.threads):
-                                         # 256 / 1024 threads at 256 | 512 | 1024 | 2048 positions: 1768 | 1701 | 1555 | 1331 against 1640 | 1618 | 1572 | 1451 tok/s
+                                         # 256 / 1024 threads at 256 | 512 | 1024 | 2048 positions: 1768 | 1701 | 1555 | 1331 against 1669 | 1646 | 1595 | 1482 tok/s
 
     def __init__(self, model, cache_len: int = 2048, attn_splits: Optional[int] = None, prefetch: float = 0.5, prefetch_delay_us: Optional[float] = None,
                  launches: int = 4, long_from: Optional[int] = None):
@@ -470,10 +470,8 @@ class DecodeEngine:
         for kind, a in phases:
             if kind == "attn":
                 a.nsplit = int(n)
-            elif kind == "attn_oproj":                            # n > 1: the long-cache launch (1024 threads, no prefetch rows)
-                if not hasattr(a, "_mq_pf"):
-                    a._mq_pf = a.prefetch_wgs
-                a.threads, a.prefetch_wgs = (1024, 0) if n > 1 else (256, a._mq_pf)
+            elif kind == "attn_oproj":                            # n > 1: the long-cache launch (1024 threads; the prefetch share inside the workgroups)
+                a.threads = 1024 if n > 1 else 256
 
     def _variants(self):
         """[(phases, attention splits)]: what runs below / from LONG_FROM positions on (5 launches: the split attention launch)."""
