@@ -459,9 +459,10 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
                       contexts=None, also_contexts=None, launches=4):
     """TinyLlama-1.1B-shaped W8A8 decode, the WHOLE step (sim_model.py:160-221 on the quantized module graph): random-init fp32
     model -> the reference's surgery (create_sim_qmodel + the mixed-precision rules of ptq/mobilequant.py:175-201) -> ranges from
-    one calibration pass of this package -> DecodeEngine: per layer 5 fused launches (norm + q|k|v stream, RoPE / cache / qk_bmm /
-    softmax / pv_bmm, o_proj + residual, norm + w1|w3 stream + QSiLU * (.) + w2 input quantizer, w2 + residual), final norm +
-    fp32 lm_head, embedding gather; one hipGraph per token, position in device memory.  Timed at a context of `context` tokens."""
+    one calibration pass of this package -> DecodeEngine: per layer 4 fused launches (launches=4, round 6: norm + q|k|v stream; RoPE / cache /
+    qk_bmm / softmax / pv_bmm + o_proj's contraction; o_proj's epilogue + residual + norm + w1|w3 stream + QSiLU * (.) + w2 input quantizer;
+    w2 + residual) or the 5 of rounds 2-5 (launches=5: o_proj + residual as a launch of its own), final norm + fp32 lm_head, embedding
+    row; one hipGraph per token, position in device memory.  Timed at a context of `context` tokens."""
     import mobilequant_amd as mq
     from mobilequant_amd.calibration import get_act_range
     from mobilequant_amd.decode import DecodeEngine
@@ -536,8 +537,11 @@ def bench_decode_full(dev, context=256, steps=64, wbits=8, family="tinyllama", w
             "weight_stream_GBps": round(eng.weight_bytes / t / 1e9, 1), "peak_GBps": 8000.0, "frac_of_hbm_peak": round(total / t / 8e12, 4),
             "kernels_per_token": len(eng.phases) + 2, "launches_per_layer": eng.launches, "decode_tok_s_by_context": by_context,
             "scope": f"FULL decode step, {family} shape, W{wbits}A8 recipe (16-bit norm inputs / o_proj / w2 / qk_bmm outputs): embedding, {shape.layers} x "
-                     "[norm+qkv, attention over the static KV cache, o_proj+residual, norm+w1|w3+SiLU*mul+quantize, w2+residual], final "
-                     "norm + fp32 lm_head; batch 1, one hipGraph per token"}
+                     + ("[norm+qkv, RoPE / cache append / attention over the static KV cache + o_proj's contraction (split-K int32 atomics), o_proj's "
+                        "epilogue+residual+norm+w1|w3+SiLU*mul+quantize, w2+residual]" if eng.launches == 4 else
+                        "[norm+qkv, attention over the static KV cache, o_proj+residual, norm+w1|w3+SiLU*mul+quantize, w2+residual]")
+                     + f", final norm + fp32 lm_head; batch 1, one hipGraph per token ({eng.launches} launches per layer; from "
+                       f"{eng._long_threshold()} cached positions on a second graph with the long-cache attention launch)"}
 
 
 def _stub_gemms(model):
