@@ -25,6 +25,8 @@ for it in range(n_cases):
     g2 = T._grid(b2, s2, float(b.min()) * clip, float(b.max()) * clip)
     fp = np.matmul(a, b)
     go = None if bo is None else T._grid(bo[0], bo[1], float(fp.min()) * 0.9, float(fp.max()) * 0.9)
+    if os.environ.get("ONLY") and it != int(os.environ["ONLY"]):
+        continue
     want = O.qmatmul_exact(a, b, g1, g2, go)
     ta = torch.from_numpy(a).to(dev)
     tb = torch.from_numpy(np.ascontiguousarray(np.swapaxes(b, -1, -2))).to(dev).transpose(-1, -2) if kt else torch.from_numpy(b).to(dev)
@@ -32,6 +34,8 @@ for it in range(n_cases):
     neq = got.view(np.uint32) != want.view(np.uint32)
     if neq.any():
         bad += 1
+        if os.environ.get("ONLY"):
+            print("where", np.argwhere(neq)[:8].tolist(), np.argwhere(neq)[-3:].tolist(), got[neq][:4], want[neq][:4])
         print("BAD", it, lead, M, N, K, kt, (b1, s1), (b2, s2), bo, int(neq.sum()), "of", neq.size, np.abs(got - want).max(), flush=True)
 print("cases", n_cases, "bad", bad)
 sys.exit(1 if bad else 0)

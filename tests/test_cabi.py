@@ -153,3 +153,19 @@ def test_argument_checks_fail_before_any_launch():
     assert lib.mq_w4a8_linear_tiled_residual(p, p, 2048, 2048, 2048, None, p, p, p, None, p, p, 0.0, 255.0, p, p, None) == 1 and b"16-bit output grid" in lib.mq_last_error()
     assert lib.mq_w4a8_linear_tiled_residual(p, p, 2048, 2000, 2048, None, p, p, p, None, p, p, 0.0, 65535.0, p, p, None) == 3
     assert lib.mq_w4a8_linear_tiled_gated(p, 2048, 2000, 2048, None, p, p, p, p, None, p, p, p, p, p, p, None, p, p, p, p, p, p, None) == 3
+
+
+def test_no_barrier_with_lds_traffic_in_flight_in_mq_qmatmul(tmp_path):
+    """Round 6: hipcc (ROCm 7.2) put the release fence's `s_waitcnt lgkmcnt(0)` BEHIND an s_barrier that opens a loop header whose latch
+    ends in LDS writes (mq_qmatmul's row-panel kernel, element-load variants): another wave read the x2 tile before the last dword had
+    landed (tests/fuzz_qmatmul.py case 85, one run in five).  The kernel now waits explicitly; tools/barrier_audit.py walks every
+    s_barrier of the compiled file backwards through the control-flow graph and must find no path with an LDS operation in flight."""
+    import subprocess, sys
+    src = os.path.join(ROOT, "mobilequant_amd", "csrc", "mq_qmatmul.hip")
+    asm = str(tmp_path / "mq_qmatmul.s")
+    from mobilequant_amd import build
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    r = subprocess.run([build.HIPCC, *flags, "-w", "--cuda-device-only", "-S", src, "-o", asm], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "barrier_audit.py"), asm], stdout=subprocess.PIPE, text=True).stdout
+    assert "PENDING" not in out and "possibly in flight 0" in out, out

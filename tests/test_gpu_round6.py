@@ -272,3 +272,46 @@ def test_four_launch_chain_at_full_size_and_full_occupancy_bit_for_bit(dev, tag)
     assert torch.equal(e4.logits, e5.logits) and torch.equal(e4.x, e5.x)
     for li in (0, 10, 21):
         assert torch.equal(e4.k_cache[li][:, :300], e5.k_cache[li][:, :300]) and torch.equal(e4.cached_values(li, 300), e5.cached_values(li, 300)), li
+
+
+# ---- mq_qmatmul, round 6: the row-panel kernel (x1 <= 8 bits, K <= 256, several column tiles) and the rotated loop orders ----------------
+QMM6_CASES = [
+    # lead, M, N, K, x2 K-contiguous, (bits, signed) x1, x2, output
+    ((2,), 130, 700, 64, True, (8, False), (8, False), (16, False)),      # panel, one 64-k chunk, three column ranges (4 + 4 + 3 tiles), ragged M and N
+    ((1,), 200, 520, 100, False, (8, True), (8, False), (8, False)),      # panel, two chunks, N-contiguous x2, K % 64 != 0
+    ((1,), 129, 300, 250, True, (6, False), (8, True), None),             # panel, four chunks, K % 4 != 0 (element loads, plain stores), no output quantizer
+    ((3,), 260, 1024, 64, True, (8, False), (8, True), (16, True)),       # panel, four column ranges per row panel, rotated tile order
+    ((2,), 150, 64, 1000, False, (16, False), (8, False), (8, False)),    # tile kernel, 16 chunks in a rotated order, the partial chunk in the middle
+    ((1,), 300, 192, 520, True, (12, True), (8, False), (16, False)),     # tile kernel, two byte planes, three column tiles, 128-row tiles
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", QMM6_CASES, ids=[f"{c[1]}x{c[2]}x{c[3]}_{'kT' if c[4] else 'kn'}_{c[5][0]}b{c[6][0]}b" for c in QMM6_CASES])
+def test_qmatmul_row_panel_and_rotated_orders_against_the_exact_integer_oracle(dev, case):
+    """mq_qmatmul after round 6 -- the row-panel kernel (a workgroup quantises 128 rows of x1 once and walks a range of column tiles in
+    an order rotated per workgroup, buffer stores) and the tile kernel's K loop started at a different chunk per workgroup -- against
+    oracle.qmatmul_exact on EVERY output, bit for bit (integer sums: any order gives the same bits)."""
+    import test_gpu_round5 as T
+    from mobilequant_amd import ops
+    from oracle import mq_oracle as O
+    lead, M, N, K, kt, (b1, s1), (b2, s2), bo = case
+    rng = np.random.default_rng(7000 * M + N + K)
+    if b1 > 8 and not s1:       # probabilities
+        a = rng.random(lead + (M, K), dtype=np.float32) ** 4
+        a /= a.sum(-1, keepdims=True)
+        g1 = T._grid(b1, s1, 0.0, float(a.max()))
+    else:
+        a = (rng.standard_normal(lead + (M, K), dtype=np.float32) * 1.3 + 0.2).astype(np.float32)
+        g1 = T._grid(b1, s1, float(a.min()) * 0.9, float(a.max()) * 0.9)
+    b = (rng.standard_normal(lead + (K, N), dtype=np.float32) * 0.8 - 0.1).astype(np.float32)
+    g2 = T._grid(b2, s2, float(b.min()) * 0.95, float(b.max()) * 0.95)
+    fp = np.matmul(a, b)
+    go = None if bo is None else T._grid(bo[0], bo[1], float(np.percentile(fp, 0.5)), float(np.percentile(fp, 99.5)))
+    want = O.qmatmul_exact(a, b, g1, g2, go)
+    ta = torch.from_numpy(a).to(dev)
+    tb = torch.from_numpy(np.ascontiguousarray(np.swapaxes(b, -1, -2))).to(dev).transpose(-1, -2) if kt else torch.from_numpy(b).to(dev)
+    got = ops.qmatmul(ta, tb, T._dev_grid(g1, dev), T._dev_grid(g2, dev), None if go is None else T._dev_grid(go, dev)).cpu().numpy()
+    assert got.shape == want.shape
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), (case, int(bad.sum()), np.argwhere(bad)[:5].tolist(), got[bad][:5].tolist(), want[bad][:5].tolist())
