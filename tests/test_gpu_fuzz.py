@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (script, case count): sized for <= ~10 s of GPU work each (plus the child's torch import)
-SLICES = [("fuzz_linear.py", 10), ("fuzz_attention.py", 16), ("fuzz_qmatmul.py", 60), ("fuzz_round3.py", 6), ("fuzz_decode.py", 10)]
+SLICES = [("fuzz_linear.py", 10), ("fuzz_attention.py", 16), ("fuzz_qmatmul.py", 100), ("fuzz_round3.py", 6), ("fuzz_decode.py", 10), ("stress_qmatmul_race.py", 20)]
 
 
 @pytest.mark.parametrize("script,cases", SLICES, ids=[s for s, _ in SLICES])
