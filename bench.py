@@ -312,7 +312,10 @@ def event_time(fn, iters):
     with torch.cuda.graph(g):
         for _ in range(iters):
             fn()
-    g.replay()
+    # pre-roll, as run_steps does: the first replays of a fresh graph read 1-2 us per launch slower than the following ones (the same
+    # library measured four times in a row: 21.2, 20.9, 20.1, 20.2 us); the timed replays start on a chip that is already in the loop
+    for _ in range(8):
+        g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     best = float("inf")
