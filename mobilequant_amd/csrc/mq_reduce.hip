@@ -372,7 +372,10 @@ __global__ void __launch_bounds__(256) calib_probs_kernel(const float* raw, floa
     for (int k = 0; k < VPT; ++k) {
       const int i = lane + 64 * k;
       const bool valid = i < nvec;
-      const float4 x4 = rr[valid ? i : nvec - 1];
+      // read once, overwritten in place: streaming hints on both sides (S = 2048, 32 heads: 220 -> 201 us)
+      typedef float v4f_ __attribute__((ext_vector_type(4)));
+      const v4f_ xv = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(rr) + (valid ? i : nvec - 1));
+      const float4 x4 = make_float4(xv.x, xv.y, xv.z, xv.w);
       float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mr) m4 = mr[valid ? i : nvec - 1];
       const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
@@ -413,7 +416,8 @@ __global__ void __launch_bounds__(256) calib_probs_kernel(const float* raw, floa
           plo = min_p(plo, y[e]);
           phi = max_p(phi, y[e]);
         }
-        orow[lane + 64 * k] = make_float4(y[0], y[1], y[2], y[3]);
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((v4f_){y[0], y[1], y[2], y[3]}, reinterpret_cast<v4f_*>(orow) + lane + 64 * k);
       }
     }
   }
