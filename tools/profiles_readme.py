@@ -38,6 +38,7 @@ LOG_CAPTIONS = {
     "decode_prefetch_ab.log": "`tools/r06_decode_ab.py`: share and start time of the attention launch's L2 prefetch rows",
     "decode_whatif_kv_loads.log": "`tools/r06_whatif.sh`: what-if builds of the attention + o_proj launch without its key / value requests",
     "bench_qmatmul.log": "`tools/bench_qmatmul.py`: mq_qmatmul step by step through round 6 (rows per workgroup, what-if builds, the row-panel kernel, branch-free loads, buffer stores, loop orders rotated against HBM channel camping); `tools/hbm_read_probe` ceilings",
+    "fuzz_full.log": "the random-shape fuzzers at full length on the final tree (`tests/fuzz_*.py`, `tests/stress_qmatmul_race.py`): every output against the oracles, 0 mismatches",
     "bench_qmatmul_final.log": "`tools/bench_qmatmul.py` and `tools/bench_calib_probs.py` on the final tree",
     "calibration_trace.summary.txt": "`rocprofv3 --kernel-trace` of `bench.py --workload calibration --calib-samples 16 --calib-stub-gemm`: kernels of the calibration pass by share of GPU time",
     "fuzz_and_per_sequence_ppl.log": "`pytest tests/test_gpu_fuzz.py tests/test_gpu_round5.py -k 'fuzz or perplexity' -s`: the fuzzer slices inside `-m gpu` and the per-sequence perplexity differences",
