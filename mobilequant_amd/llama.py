@@ -446,6 +446,22 @@ class LlamaForCausalLM(nn.Module):
             else:
                 p.fill_(1.0)
 
+    def calibration_alias_groups(self):
+        """Hooked tensors of this graph's forward that are one and the same (calibration.ActRangeCollector reduces the first member of a
+        group and mirrors the others once a first pass has confirmed them): a norm's output IS the input of the linears that read it,
+        w1's output IS the activation's input; pv_bmm's output and o_proj's input hold the same values (a transposed copy: same
+        minimum and maximum).  Keys are (module name, field) as named_modules() of THIS module spells them."""
+        out = []
+        for i in range(len(self.layers)):
+            p = f"layers.{i}"
+            out.append([(f"{p}.input_layernorm", "output"), (f"{p}.self_attn.q_proj", "input"), (f"{p}.self_attn.k_proj", "input"),
+                        (f"{p}.self_attn.v_proj", "input")])
+            out.append([(f"{p}.post_attention_layernorm", "output"), (f"{p}.mlp.w1", "input"), (f"{p}.mlp.w3", "input")])
+            out.append([(f"{p}.mlp.w1", "output"), (f"{p}.mlp.act_fn", "input")])
+            out.append([(f"{p}.self_attn.pv_bmm", "output"), (f"{p}.self_attn.o_proj", "input")])
+        out.append([("norm", "output"), ("lm_head", "input")])
+        return out
+
     def forward(self, ids, cache=None, pos: int = 0, last_logits_only: bool = False):
         """ids [B, S] token ids.  cache: list (one per layer) of (k, v) static buffers [B, KV, T, D], see Attention.forward.
         last_logits_only: final norm + lm_head on the LAST position only (logits [B, 1, vocab]) -- a context encoding that feeds

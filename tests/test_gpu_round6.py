@@ -315,3 +315,49 @@ def test_qmatmul_row_panel_and_rotated_orders_against_the_exact_integer_oracle(d
     assert got.shape == want.shape
     bad = got.view(np.uint32) != want.view(np.uint32)
     assert not bad.any(), (case, int(bad.sum()), np.argwhere(bad)[:5].tolist(), got[bad][:5].tolist(), want[bad][:5].tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["tinyllama", "stablelm_2_1_6b", "gemma_2b"])
+def test_calibration_mirrored_slots_give_the_statistics_of_the_plain_hooks(dev, family):
+    """Round 6: a tensor hooked under several names (a norm's output = the input of q / k / v, w1's output = the activation's input, pv_bmm's
+    output = o_proj's input as values) is reduced once from the second forward pass on; the other slots of a group the graph declares
+    (LlamaForCausalLM.calibration_alias_groups) mirror the first one after the first pass has confirmed them bit for bit.  The act_dict
+    is the one the plain hooks give; 7 reductions per layer + 1 fewer."""
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import ActRangeCollector, get_act_range
+    shape = getattr(llama.LlamaShape, family)(layers=2, max_pos=128, vocab=512)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=3, std=0.05)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    samples = [torch.randint(0, shape.vocab, (1, 128), generator=g).to(dev) for _ in range(4)]
+    got = {}
+    for mirror in (True, False):
+        col = ActRangeCollector(model, per_channel=False)
+        col.mirror_declared_aliases = mirror
+        col.attach()
+        with torch.no_grad():
+            for s in samples:
+                model(s)
+        col.detach()
+        got[mirror] = (col.act_dict(), col.bytes_seen, col.bytes_aliased, len(col._mirror))
+    assert got[True][0] == got[False][0]
+    assert got[False][2] == 0 and got[False][3] == 0
+    assert got[True][3] == 7 * shape.layers + 1, got[True][3]
+    assert got[True][2] > 0 and got[True][1] + got[True][2] == got[False][1]
+    assert get_act_range(model, samples) == got[False][0]
+    # a declared group whose members do NOT agree after the first pass stays on the plain hooks
+    class Wrong(llama.LlamaForCausalLM):
+        def calibration_alias_groups(self):
+            return [[("layers.0.input_layernorm", "output"), ("layers.0.mlp.w2", "output")]]
+    model.__class__ = Wrong
+    try:
+        col = ActRangeCollector(model, per_channel=False).attach()
+        with torch.no_grad():
+            for s in samples:
+                model(s)
+        col.detach()
+        assert col._mirror == {} and col.act_dict() == got[False][0]
+    finally:
+        model.__class__ = llama.LlamaForCausalLM
