@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 300 /* 0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
+#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -631,6 +631,24 @@ int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
  * as mq_minmax_tensor keeps them (initialise with mq_minmax_init; NaN is sticky). */
 int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows, double sqrt_d,
                              float* raw_min, float* raw_max, float* probs_min, float* probs_max, mq_stream_t stream);
+
+/* ---- calibration: a decoder layer's glue with its statistics (round 6) --------------------------- */
+/* The fp32 calibration forward (ptq/generate_act_range.py:49-122 over mobilellm/model/hf_model.py) hooks the input and the output of
+ * every norm / activation / linear; between the linears it runs torch elementwise launches (an HFRMSNorm, hf_model.py:183-186, is
+ * six of them) and every hooked tensor is read once more for its [min, max].  Two one-pass forms for the leaf graph of this package:
+ *
+ * mq_calib_norm: h = x (+ delta, the residual branch; h is written to h_out), running [min, max] of h (the norm's input hook),
+ *   y = weight * (h * rsqrt(mean(h^2) + eps))  (layernorm = 0; hf_model.py:183-186)  or  LayerNorm(h) * weight + bias (layernorm = 1,
+ *   biased variance), running [min, max] of y (its output hook).  x / delta / h_out / y_out [rows, cols] fp32, cols % 4 == 0,
+ *   cols <= 8192, 16-byte aligned (else MQ_EUNSUPPORTED); delta, h_out, bias may be NULL (h_out is required with a delta).
+ * mq_calib_gated: out = act(a) * b (hf_model.py:1057: w2's input) with the running [min, max] of a (w1's output = the activation's
+ *   input), act(a) (the activation's output), b (w3's output) and the product, in that order in stats[8] = {min, max} x 4.
+ *   act 0 = SiLU, 1 = GELU (erf).  numel % 4 == 0.
+ * Statistics are 1-float running values as mq_minmax_tensor keeps them (mq_minmax_init; NaN is sticky).  The row sums are taken in
+ * another order than torch's: values agree with the module chain within a few ulp (tests bound the act_dict at 1e-5 relative). */
+int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out, int64_t rows, int64_t cols, const float* weight, const float* bias,
+                  float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, mq_stream_t stream);
+int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, int act, float* const* stats, mq_stream_t stream);
 
 /* ---- QMatMul as a module: quantized batched matmul of two activations ------------------------ */
 /* Replaces QMatMul.forward (mobilellm/quantization/qmodule.py:453-466): out = Qout(matmul(Q1(x1), Q2(x2))) -- two fake-quant passes

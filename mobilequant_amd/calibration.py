@@ -86,6 +86,8 @@ class ActRangeCollector:
                 idx = [self.slots[k] for k in grp if k in self.slots]
                 if len(idx) == len(grp) and len(idx) > 1:
                     self._mirror_pending.append(idx)
+        self._forced = set()           # mirrors set by a fused pass itself (the module whose hook would fill the slot is not run)
+        self._layers = []              # decoder layers / MLPs that take their glue statistics from norm_pass / gated_pass
         self.bytes_aliased = 0         # hooked bytes NOT read again: their slot mirrors another one
         self.bytes_seen = 0            # bytes of hooked tensors reduced so far (host-side bookkeeping for the benchmark)
         self.bytes_fused = 0           # bytes of tensors whose statistics were folded into the pass that produced them
@@ -144,6 +146,43 @@ class ActRangeCollector:
         self.bytes_fused += 2 * raw.numel() * raw.element_size()
         return ops.calib_attention_probs_(raw, mask, sqrt_d, self._mn[i:i + 1], self._mx[i:i + 1], self._mn[j:j + 1], self._mx[j:j + 1])
 
+    # ... and the glue between the linears (round 6): a norm with both of its statistics in one pass (optionally with the residual add
+    # in front of it), and act(w1(x)) * w3(x) with the four statistics around it (ops.calib_norm_ / calib_gated_).  llama.DecoderLayer /
+    # MLP ask for them while ONE collector is attached (per-tensor mode); the hooks of the modules involved skip what the pass took.
+    fuse_layer_statistics = True
+
+    def can_fuse_layer(self, x: torch.Tensor) -> bool:
+        return (self.fuse_layer_statistics and not self.per_channel and x.dtype == torch.float32 and x.device == self.device
+                and x.device.type == "cuda" and x.is_contiguous() and x.shape[-1] % 4 == 0 and x.shape[-1] <= 8192)
+
+    def norm_pass(self, name: str, module: nn.Module, x: torch.Tensor, delta: Optional[torch.Tensor] = None):
+        """(h, y): h = x (+ delta), y = module(h); module's input / output statistics are taken here (its hooks are not run)."""
+        i, j = self.slots[(name, "input")], self.slots[(name, "output")]
+        nbytes = x.numel() * x.element_size()
+        self.bytes_fused += 2 * nbytes
+        return ops.calib_norm_(x, delta, module.weight, getattr(module, "bias", None), module.eps, isinstance(module, nn.LayerNorm),
+                               self._mn[i:i + 1], self._mx[i:i + 1], self._mn[j:j + 1], self._mx[j:j + 1])
+
+    @staticmethod
+    def norm_is_plain(module: nn.Module) -> bool:
+        """A norm the one-pass kernel reproduces: nn.LayerNorm over the last dim with affine parameters, or HFRMSNorm in its rsqrt form
+        without a bias."""
+        if isinstance(module, nn.LayerNorm):
+            return module.elementwise_affine and module.weight is not None and len(module.normalized_shape) == 1
+        return isinstance(module, HFRMSNorm) and not module.l2norm_as_rmsnorm and module.bias is None
+
+    def gated_pass(self, w1_name: str, w3_name: str, act_name: str, w2_name: str, a: torch.Tensor, b: torch.Tensor, act: str) -> torch.Tensor:
+        """act(a) * b with the statistics of w1.output (= act.input), act.output, w3.output and w2.input."""
+        sl = [self.slots[(w1_name, "output")], self.slots[(act_name, "output")], self.slots[(w3_name, "output")], self.slots[(w2_name, "input")]]
+        self.bytes_fused += 4 * a.numel() * a.element_size()
+        k = self.slots[(act_name, "input")]
+        self._mirror[k] = sl[0]                                        # the activation module is not run: its input IS w1's output
+        self._forced.add(k)
+        stats = []
+        for k in sl:
+            stats += [self._mn[k:k + 1], self._mx[k:k + 1]]
+        return ops.calib_gated_(a, b, act, stats)
+
     def can_fuse_attention(self, raw_shape, dtype, device, mask) -> bool:
         return (self.fuse_attention_statistics and not self.per_channel and dtype == torch.float32 and device == self.device
                 and device.type == "cuda" and raw_shape[-1] % 4 == 0 and raw_shape[-1] <= 4096
@@ -190,7 +229,31 @@ class ActRangeCollector:
                     continue
                 m._mq_calib = (self, names[id(qk)], names[id(pv)])
                 self._aware.append(m)
+            want = getattr(m, "_mq_calibration_layer_parts", None)     # llama.DecoderLayer / MLP: the submodules a fused pass stands for
+            if want is not None and not self.per_channel and self.fuse_layer_statistics:
+                parts = [getattr(m, a, None) for a in want]
+                keys = [names.get(id(q)) for q in parts]
+                if all(k is not None and (k, "input") in self.slots and (k, "output") in self.slots for k in keys):
+                    owner = m.__dict__.get("_mq_calib_layer")
+                    if owner is not None and owner[0] is not self:
+                        owner[0]._drop_layer_fusion()                  # two collectors on one model: modules a fused pass skips would never
+                        self.fuse_layer_statistics = False             # reach the other one's hooks -- both keep the plain hooks
+                        continue
+                    m._mq_calib_layer = (self, tuple(keys))
+                    self._layers.append(m)
         return self
+
+    def _drop_layer_fusion(self) -> None:
+        self.fuse_layer_statistics = False
+        for m in self._layers:
+            if m.__dict__.get("_mq_calib_layer", (None,))[0] is self:
+                m.__dict__.pop("_mq_calib_layer", None)
+        self._layers = []
+        if self._forced:
+            self._resolve()
+            for k in self._forced:
+                self._mirror.pop(k, None)
+            self._forced = set()
 
     def detach(self) -> None:
         for h in self._hooks:
@@ -200,6 +263,10 @@ class ActRangeCollector:
             if m.__dict__.get("_mq_calib", (None,))[0] is self:
                 m.__dict__.pop("_mq_calib", None)
         self._aware = []
+        for m in self._layers:
+            if m.__dict__.get("_mq_calib_layer", (None,))[0] is self:
+                m.__dict__.pop("_mq_calib_layer", None)
+        self._layers = []
 
     # -- merge -------------------------------------------------------------------------------------
     def _layout(self) -> Dict[int, int]:

@@ -426,6 +426,121 @@ __global__ void __launch_bounds__(256) calib_probs_kernel(const float* raw, floa
   block_commit(plo, phi, mn_p, mx_p);
 }
 
+
+// ---- calibration of a decoder layer's glue (round 6): statistics where the tensors are produced -------------------------------------
+// The fp32 calibration forward (generate_act_range.py:49-122 around hf_model.py) spends a third of its GPU time in torch's elementwise
+// launches between the linears -- an RMSNorm is six of them (pow, mean, + eps, rsqrt, *, * weight), each a pass over [S, hidden] -- and
+// every hooked tensor is then read again for its statistic.  Two one-pass kernels take both jobs for the leaf graph of this package
+// (llama.DecoderLayer / MLP, calibration.ActRangeCollector.norm_pass / gated_pass): the values are those of the module chain up to the
+// order of the row sums (a few ulp, like the fused score chain above; tests bound the act_dict at 1e-5 relative).
+
+// h = x (+ delta), running [min, max] of h (the norm's INPUT slot), y = norm(h) * weight (+ bias), running [min, max] of y (its OUTPUT
+// slot).  A workgroup per row, VPT float4 per thread.  RMSNorm as hf_model.py:183-186 (x * rsqrt(mean(x^2) + eps), then weight * x);
+// LayerNorm as torch.nn.functional.layer_norm (biased variance).
+template <int VPT, bool LN>
+__global__ void __launch_bounds__(256) calib_norm_kernel(const float* __restrict__ x, const float* __restrict__ delta, float* __restrict__ h_out,
+                                                         float* __restrict__ y_out, const int64_t rows, const int cols,
+                                                         const float* __restrict__ weight, const float* __restrict__ bias, const float eps,
+                                                         float* mn_h, float* mx_h, float* mn_y, float* mx_y) {
+  __shared__ float s_red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nvec = cols >> 2;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float hlo = __int_as_float(0x7f800000), hhi = __int_as_float(0xff800000), ylo = hlo, yhi = hhi;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const v4f* xr = reinterpret_cast<const v4f*>(x + row * cols);
+    const v4f* dr = delta ? reinterpret_cast<const v4f*>(delta + row * cols) : nullptr;
+    v4f h[VPT];
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int i = tid + 256 * k;
+      const bool valid = i < nvec;
+      v4f v = xr[valid ? i : nvec - 1];
+      if (dr) v += dr[valid ? i : nvec - 1];
+      h[k] = v;
+      if (valid) {
+        hlo = min_p(min_p(hlo, v[0]), min_p(v[1], min_p(v[2], v[3])));
+        hhi = max_p(max_p(hhi, v[0]), max_p(v[1], max_p(v[2], v[3])));
+        s1 += LN ? (v[0] + v[1]) + (v[2] + v[3]) : (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if (h_out) reinterpret_cast<v4f*>(h_out + row * cols)[i] = v;
+      }
+    }
+    auto block_sum = [&](float v, int slot) {
+      v = wave_sum_f32_dpp(v);
+      if (lane == 0) s_red[slot][wv] = v;
+      __syncthreads();
+      return (s_red[slot][0] + s_red[slot][1]) + (s_red[slot][2] + s_red[slot][3]);
+    };
+    float mu = 0.f, r;
+    if constexpr (LN) {
+      mu = __fdiv_rn(block_sum(s1, 0), (float)cols);
+      float s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPT; ++k)
+        if (tid + 256 * k < nvec) {
+          const v4f d = h[k] - mu;
+          s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+      r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(block_sum(s2, 1), (float)cols), eps)));
+    } else {
+      r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(block_sum(s1, 0), (float)cols), eps)));
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < nvec) {
+        const v4f w = reinterpret_cast<const v4f*>(weight)[i];
+        v4f y = LN ? (h[k] - mu) * r * w : w * (h[k] * r);
+        if (LN && bias) y += reinterpret_cast<const v4f*>(bias)[i];
+        ylo = min_p(min_p(ylo, y[0]), min_p(y[1], min_p(y[2], y[3])));
+        yhi = max_p(max_p(yhi, y[0]), max_p(y[1], max_p(y[2], y[3])));
+        reinterpret_cast<v4f*>(y_out + row * cols)[i] = y;
+      }
+    }
+    __syncthreads();                                                // (s_red is reused by the next row)
+  }
+  block_commit(hlo, hhi, mn_h, mx_h);
+  __syncthreads();
+  block_commit(ylo, yhi, mn_y, mx_y);
+}
+
+// p = act(a) * b with the running [min, max] of a (w1's output = the activation's input), act(a) (the activation's output), b (w3's
+// output) and p (w2's input): hf_model.py:1057 between four hooks.  act: 0 = SiLU (x * 1 / (1 + exp(-x)): mq_act_quant's expression),
+// 1 = GELU (erf).  stats: [mn_a, mx_a, mn_s, mx_s, mn_b, mx_b, mn_p, mx_p].
+struct CalibGatedStats {
+  float* p[8];
+};
+__global__ void __launch_bounds__(256) calib_gated_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, const int64_t numel,
+                                                          const int act, const CalibGatedStats st) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const float pinf = __int_as_float(0x7f800000), ninf = __int_as_float(0xff800000);
+  float lo[4] = {pinf, pinf, pinf, pinf}, hi[4] = {ninf, ninf, ninf, ninf};
+  auto upd = [&](int k, const v4f v) {
+    lo[k] = min_p(min_p(lo[k], v[0]), min_p(v[1], min_p(v[2], v[3])));
+    hi[k] = max_p(max_p(hi[k], v[0]), max_p(v[1], max_p(v[2], v[3])));
+  };
+  auto f = [&](float x) {
+    if (act == 0) return __fmul_rn(x, __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))));
+    return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, erff(__fmul_rn(x, 0.70710678118654752440f))));
+  };
+  const int64_t nvec = numel >> 2, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    const v4f va = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(a) + i), vb = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(b) + i);
+    const v4f vs = {f(va[0]), f(va[1]), f(va[2]), f(va[3])};
+    const v4f vp = vs * vb;
+    upd(0, va);
+    upd(1, vs);
+    upd(2, vb);
+    upd(3, vp);
+    reinterpret_cast<v4f*>(out)[i] = vp;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    block_commit(lo[k], hi[k], st.p[2 * k], st.p[2 * k + 1]);
+    __syncthreads();
+  }
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -519,6 +634,56 @@ int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64
   else if (cols <= 2048) MQ_CALIB(8);
   else MQ_CALIB(16);
 #undef MQ_CALIB
+  MQ_LAUNCH_CHECK(fn);
+  return MQ_OK;
+}
+
+
+int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out, int64_t rows, int64_t cols, const float* weight, const float* bias,
+                  float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, mq_stream_t stream) {
+  const char* fn = "mq_calib_norm";
+  MQ_REQUIRE(rows >= 0 && cols > 0, "%s: bad shape", fn);
+  if (rows == 0) return MQ_OK;
+  MQ_REQUIRE(x && y_out && weight && in_min && in_max && out_min && out_max, "%s: null pointer", fn);
+  MQ_REQUIRE(!delta || h_out, "%s: a residual needs h_out", fn);
+  if (cols % 4 != 0 || cols > 8192 || !aligned(x, 16) || !aligned(y_out, 16) || !aligned(weight, 16) || (delta && !aligned(delta, 16)) ||
+      (h_out && !aligned(h_out, 16)) || (bias && !aligned(bias, 16))) {
+    set_error("%s: not served: cols %% 4 == 0, cols <= 8192, 16-byte aligned pointers", fn);
+    return MQ_EUNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = (unsigned)(rows < 8192 ? rows : 8192);
+#define MQ_CN(V)                                                                                                                     \
+  do {                                                                                                                               \
+    if (layernorm) calib_norm_kernel<V, true><<<grid, 256, 0, st>>>(x, delta, h_out, y_out, rows, (int)cols, weight, bias, eps, in_min, in_max, out_min, out_max); \
+    else calib_norm_kernel<V, false><<<grid, 256, 0, st>>>(x, delta, h_out, y_out, rows, (int)cols, weight, bias, eps, in_min, in_max, out_min, out_max);      \
+  } while (0)
+  if (cols <= 1024) MQ_CN(1);
+  else if (cols <= 2048) MQ_CN(2);
+  else if (cols <= 4096) MQ_CN(4);
+  else MQ_CN(8);
+#undef MQ_CN
+  MQ_LAUNCH_CHECK(fn);
+  return MQ_OK;
+}
+
+int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, int act, float* const* stats, mq_stream_t stream) {
+  const char* fn = "mq_calib_gated";
+  MQ_REQUIRE(numel >= 0 && (act == 0 || act == 1), "%s: bad arguments", fn);
+  if (numel == 0) return MQ_OK;
+  MQ_REQUIRE(a && b && out && stats, "%s: null pointer", fn);
+  if (numel % 4 != 0 || !aligned(a, 16) || !aligned(b, 16) || !aligned(out, 16)) {
+    set_error("%s: not served: numel %% 4 == 0, 16-byte aligned pointers", fn);
+    return MQ_EUNSUPPORTED;
+  }
+  CalibGatedStats cs;
+  for (int k = 0; k < 8; ++k) {
+    MQ_REQUIRE(stats[k], "%s: null statistic %d", fn, k);
+    cs.p[k] = stats[k];
+  }
+  int64_t grid = (numel / 4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  calib_gated_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a, b, out, numel, act, cs);
   MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
 }

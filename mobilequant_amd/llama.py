@@ -387,7 +387,30 @@ class MLP(nn.Module):
         self.w3 = nn.Linear(s.hidden, s.ffn, bias=False)
         self.act_fn = nn.SiLU() if s.hidden_act == "silu" else nn.GELU()
 
+    _mq_calibration_layer_parts = ("w1", "w3", "act_fn", "w2")     # calibration.ActRangeCollector.attach(): see forward
+
     def forward(self, x):      # hf_model.py:1057
+        calib = self.__dict__.get("_mq_calib_layer")                # (collector, names of w1 / w3 / act_fn / w2) while ONE calibration pass runs
+        if (calib is not None and not torch.is_grad_enabled() and calib[0].can_fuse_layer(x)
+                and (isinstance(self.act_fn, nn.SiLU) or (isinstance(self.act_fn, nn.GELU) and self.act_fn.approximate == "none"))):
+            # calibration: act(w1(x)) * w3(x) and the four statistics around it (w1.output = act.input, act.output, w3.output, w2.input)
+            # in ONE pass; the linears' hooks skip those fields, the activation module is not run
+            col, (n1, n3, na, n2) = calib
+            skips = ((self.w1, ("output",)), (self.w3, ("output",)), (self.w2, ("input",)))
+            for m, f in skips:
+                m.__dict__["_mq_calib_skip"] = (col, f)
+            try:
+                a, b = self.w1(x), self.w3(x)
+                if a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 and a.numel() % 4 == 0:
+                    return self.w2(col.gated_pass(n1, n3, na, n2, a, b, "silu" if isinstance(self.act_fn, nn.SiLU) else "gelu"))
+                for m, _ in skips:                                  # (not served: the plain chain, with the hooks' own reductions)
+                    m.__dict__.pop("_mq_calib_skip", None)
+                col._update(n1, "output", a)
+                col._update(n3, "output", b)
+                return self.w2(self.act_fn(a) * b)
+            finally:
+                for m, _ in skips:
+                    m.__dict__.pop("_mq_calib_skip", None)
         return self.w2(self.act_fn(self.w1(x)) * self.w3(x))
 
 
@@ -404,7 +427,19 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = _make_norm(s)
         self.post_attention_layernorm = _make_norm(s)
 
+    _mq_calibration_layer_parts = ("input_layernorm", "post_attention_layernorm")
+
     def forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
+        calib = self.__dict__.get("_mq_calib_layer")                # (collector, names of the two norms) while ONE calibration pass runs
+        if (calib is not None and not torch.is_grad_enabled() and calib[0].can_fuse_layer(x)
+                and calib[0].norm_is_plain(self.input_layernorm) and calib[0].norm_is_plain(self.post_attention_layernorm)):
+            # calibration: each norm with its input and output statistics in one pass, the attention branch's residual add inside the
+            # second one (h = x + attn is written for the last add); the norm modules are not run
+            col, (n_in, n_post) = calib
+            _, y = col.norm_pass(n_in, self.input_layernorm, x)
+            attn = self.self_attn(y, cos, sin, mask, cache, pos)
+            h, y = col.norm_pass(n_post, self.post_attention_layernorm, x, attn if attn.is_contiguous() else attn.contiguous())
+            return h + self.mlp(y)
         x = x + self.self_attn(self.input_layernorm(x), cos, sin, mask, cache, pos)
         return x + self.mlp(self.post_attention_layernorm(x))
 

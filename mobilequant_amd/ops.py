@@ -136,6 +136,40 @@ def calib_attention_probs_(raw: torch.Tensor, mask: Optional[torch.Tensor], sqrt
     return raw
 
 
+def calib_norm_(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, layernorm: bool,
+                in_min: torch.Tensor, in_max: torch.Tensor, out_min: torch.Tensor, out_max: torch.Tensor):
+    """Calibration-mode norm (mq_calib_norm): h = x (+ delta), y = RMSNorm / LayerNorm(h) with the running [min, max] of h (the module's
+    input hook) and of y (its output hook) taken in the same pass.  Returns (h, y); h is x itself without a delta."""
+    x = _dev(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous() or (delta is not None and (delta.dtype != torch.float32 or not delta.is_contiguous()
+                                                                                        or delta.shape != x.shape)):
+        raise RuntimeError("mobilequant_amd: calib_norm_ takes contiguous float32 tensors of one shape")
+    cols = x.shape[-1]
+    rows = x.numel() // max(cols, 1)
+    y = torch.empty_like(x)
+    h = torch.empty_like(x) if delta is not None else None
+    w = _f32(weight, "weight").contiguous()
+    b = _f32(bias, "bias").contiguous() if bias is not None else None
+    with _on(x, delta, w, b, y, h, in_min, in_max, out_min, out_max):
+        _lib.call("mq_calib_norm", x.data_ptr(), delta.data_ptr() if delta is not None else None, h.data_ptr() if h is not None else None,
+                  y.data_ptr(), rows, cols, w.data_ptr(), b.data_ptr() if b is not None else None, float(eps), int(bool(layernorm)),
+                  in_min.data_ptr(), in_max.data_ptr(), out_min.data_ptr(), out_max.data_ptr(), _stream())
+    return (h if h is not None else x), y
+
+
+def calib_gated_(a: torch.Tensor, b: torch.Tensor, act: str, stats) -> torch.Tensor:
+    """Calibration-mode act(a) * b (mq_calib_gated) with the running [min, max] of a, act(a), b and the product: stats = eight 1-element
+    fp32 device tensors (min, max) x 4 in that order.  act: "silu" | "gelu" (erf).  Returns the product."""
+    a, b = _dev(a, "a"), _dev(b, "b")
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise RuntimeError("mobilequant_amd: calib_gated_ takes two contiguous float32 tensors of one shape")
+    out = torch.empty_like(a)
+    ptrs = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in stats])
+    with _on(a, b, out, *stats):
+        _lib.call("mq_calib_gated", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), {"silu": 0, "gelu": 1}[act], ptrs, _stream())
+    return out
+
+
 def minmax_tensor(x: torch.Tensor):
     """(min, max) of one tensor as 1-element device tensors: partials + fold, no atomics, no init launch."""
     x = _dev(x, "x").contiguous()

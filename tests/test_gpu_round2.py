@@ -210,6 +210,7 @@ def test_get_act_range_end_to_end_through_an_rccl_all_reduce(dev, nccl_single_ra
     # qk_bmm.output / pv_bmm.input inside their fused score chain (round 5), whose probabilities sit a few ulp from torch's softmax
     # kernel -- tests/test_gpu_round5.py holds that path to the hook path within summation-order tolerance
     C.ActRangeCollector.fuse_attention_statistics = False
+    C.ActRangeCollector.fuse_layer_statistics = False        # (round 6: the one-pass norms / gated product likewise -- tests/test_gpu_round6.py)
     try:
         forced = C.get_act_range(model, samples, per_channel=per_channel, force_collective=True)
         dist.all_reduce = real
@@ -218,6 +219,7 @@ def test_get_act_range_end_to_end_through_an_rccl_all_reduce(dev, nccl_single_ra
     finally:
         dist.all_reduce = real
         C.ActRangeCollector.fuse_attention_statistics = True
+        C.ActRangeCollector.fuse_layer_statistics = True
     # reference statistics with torch ops in hooks (generate_act_range.py:55-69)
     want = {}
 

@@ -336,6 +336,7 @@ def test_calibration_mirrored_slots_give_the_statistics_of_the_plain_hooks(dev, 
     for mirror in (True, False):
         col = ActRangeCollector(model, per_channel=False)
         col.mirror_declared_aliases = mirror
+        col.fuse_layer_statistics = False                  # (the one-pass layer glue has a test of its own below)
         col.attach()
         with torch.no_grad():
             for s in samples:
@@ -346,14 +347,17 @@ def test_calibration_mirrored_slots_give_the_statistics_of_the_plain_hooks(dev, 
     assert got[False][2] == 0 and got[False][3] == 0
     assert got[True][3] == 7 * shape.layers + 1, got[True][3]
     assert got[True][2] > 0 and got[True][1] + got[True][2] == got[False][1]
-    assert get_act_range(model, samples) == got[False][0]
+    full = get_act_range(model, samples)                    # (+ the one-pass layer glue: within round-off of the plain hooks)
+    assert set(full) == set(got[False][0])
     # a declared group whose members do NOT agree after the first pass stays on the plain hooks
     class Wrong(llama.LlamaForCausalLM):
         def calibration_alias_groups(self):
             return [[("layers.0.input_layernorm", "output"), ("layers.0.mlp.w2", "output")]]
     model.__class__ = Wrong
     try:
-        col = ActRangeCollector(model, per_channel=False).attach()
+        col = ActRangeCollector(model, per_channel=False)
+        col.fuse_layer_statistics = False
+        col.attach()
         with torch.no_grad():
             for s in samples:
                 model(s)
@@ -361,3 +365,98 @@ def test_calibration_mirrored_slots_give_the_statistics_of_the_plain_hooks(dev, 
         assert col._mirror == {} and col.act_dict() == got[False][0]
     finally:
         model.__class__ = llama.LlamaForCausalLM
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("shape", [(3, 50, 2048), (2, 7, 1000), (1, 33, 4100)])
+def test_calib_norm_and_gated_passes_against_torch(dev, shape, ln):
+    """ops.calib_norm_ / ops.calib_gated_ (mq_calib_norm / mq_calib_gated): values within a few ulp of the torch module chain
+    (hf_model.py:183-186 / torch layer_norm; silu / gelu times w3), the four running statistics EXACTLY those of the tensors the kernels
+    wrote, the residual sum bit for bit."""
+    from mobilequant_amd import ops
+    from mobilequant_amd.quantization.fp_ops import HFRMSNorm
+    g = torch.Generator().manual_seed(shape[1])
+    x = (torch.randn(*shape, generator=g) * 2 + 0.3).to(dev)
+    d = torch.randn(*shape, generator=g).to(dev)
+    C = shape[-1]
+    mod = (torch.nn.LayerNorm(C, eps=1e-5) if ln else HFRMSNorm(C, eps=1e-6)).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1)
+        if ln:
+            mod.bias.copy_(torch.randn(C, generator=g) * 0.1)
+    for delta in (None, d):
+        st = [torch.full((1,), v, device=dev) for v in (float("inf"), float("-inf"), float("inf"), float("-inf"))]
+        with torch.no_grad():
+            h, y = ops.calib_norm_(x, delta, mod.weight, getattr(mod, "bias", None), mod.eps, ln, *st)
+            hw = x if delta is None else x + delta
+            yw = mod(hw)
+        assert torch.equal(h, hw)
+        assert torch.allclose(y, yw, rtol=2e-5, atol=2e-6), float((y - yw).abs().max())
+        assert [float(s) for s in st] == [float(h.min()), float(h.max()), float(y.min()), float(y.max())]
+    a, b = x, d
+    for act, fn in (("silu", torch.nn.functional.silu), ("gelu", torch.nn.functional.gelu)):
+        st = [torch.full((1,), float("inf") if k % 2 == 0 else float("-inf"), device=dev) for k in range(8)]
+        if a.numel() % 4:
+            continue
+        p = ops.calib_gated_(a, b, act, st)
+        s = fn(a)
+        assert torch.allclose(p, s * b, rtol=2e-6, atol=1e-7), float((p - s * b).abs().max())
+        got = [float(t) for t in st]
+        assert got[0:2] == [float(a.min()), float(a.max())] and got[4:6] == [float(b.min()), float(b.max())]
+        assert got[6:8] == [float(p.min()), float(p.max())]
+        assert abs(got[2] - float(s.min())) <= 1e-6 * max(1, abs(float(s.min()))) and abs(got[3] - float(s.max())) <= 2e-6 * abs(float(s.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["tinyllama", "stablelm_2_1_6b", "gemma_2b"])
+def test_calibration_layer_passes_give_the_act_dict_of_the_plain_hooks(dev, family):
+    """Round 6: while ONE collector is attached, llama.DecoderLayer / MLP take the norms (both statistics + the residual add in one pass)
+    and act(w1) * w3 (four statistics in one pass) from mq_calib_norm / mq_calib_gated.  Same keys, values within 1e-5 relative of the
+    plain hooks (row sums in another order), the logits within fp32 round-off; a second collector on the same model sends both back to
+    the plain hooks."""
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import ActRangeCollector
+    shape = getattr(llama.LlamaShape, family)(layers=2, max_pos=128, vocab=512)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=3, std=0.05)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    samples = [torch.randint(0, shape.vocab, (1, 128), generator=g).to(dev) for _ in range(3)]
+    got, logits = {}, {}
+    for fuse in (True, False):
+        col = ActRangeCollector(model, per_channel=False)
+        col.fuse_layer_statistics = fuse
+        col.attach()
+        assert (len(col._layers) == 2 * shape.layers) == fuse
+        with torch.no_grad():
+            for s in samples:
+                logits[fuse] = model(s)
+        col.detach()
+        got[fuse] = (col.act_dict(), col.bytes_seen, col.bytes_fused)
+    assert not any("_mq_calib_layer" in m.__dict__ for m in model.modules())
+    assert set(got[True][0]) == set(got[False][0])
+    worst = 0.0
+    for name, fields in got[False][0].items():
+        assert set(fields) == set(got[True][0][name]), name
+        for f, (lo, hi) in fields.items():
+            a = got[True][0][name][f]
+            for u, v in ((a[0], lo), (a[1], hi)):
+                worst = max(worst, abs(u - v) / max(abs(v), 1e-3))
+    assert worst <= 1e-5, worst
+    assert torch.allclose(logits[True], logits[False], rtol=1e-3, atol=1e-3)
+    assert got[True][1] < 0.75 * got[False][1] and got[True][2] > got[False][2]
+    # two collectors: both on the plain hooks, both complete
+    c1 = ActRangeCollector(model, per_channel=False).attach()
+    c2 = ActRangeCollector(model, per_channel=False).attach()
+    assert not c1._layers and not c2._layers
+    with torch.no_grad():
+        for s in samples:
+            model(s)
+    c1.detach(); c2.detach()
+    d1, d2 = c1.act_dict(), c2.act_dict()
+    assert set(d1) == set(d2) == set(got[False][0])
+    for name, fields in got[False][0].items():
+        for f, (lo, hi) in fields.items():
+            for dd in (d1, d2):
+                assert abs(dd[name][f][0] - lo) <= 1e-5 * max(abs(lo), 1e-3) and abs(dd[name][f][1] - hi) <= 1e-5 * max(abs(hi), 1e-3), (name, f)
