@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
+#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated, mq_calib_rope.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -649,6 +649,13 @@ int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64
 int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out, int64_t rows, int64_t cols, const float* weight, const float* bias,
                   float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, mq_stream_t stream);
 int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, int act, float* const* stats, mq_stream_t stream);
+/* mq_calib_rope: rotary embedding of the q and k projections (hf_model.py:486-501, rotate-half; rot_dim < head_dim: partial rotary) with
+ * the running [min, max] of q_proj's output, qk_bmm's input, k_proj's output and qk_bmm's input2 (stats[8] in that order): q_in
+ * [batch, seq, heads * head_dim] and k_in [batch, seq, kv_heads * head_dim] as the linears wrote them -> q_out [batch, heads, seq,
+ * head_dim], k_out [batch, kv_heads, seq, head_dim] contiguous.  cos / sin [seq, rot_dim] (the rows of the positions).  Two rounded
+ * products and a rounded sum per element: the bits of the module chain. */
+int mq_calib_rope(const float* q_in, const float* k_in, float* q_out, float* k_out, int64_t batch, int64_t seq, int heads, int kv_heads, int head_dim,
+                  int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream);
 
 /* ---- QMatMul as a module: quantized batched matmul of two activations ------------------------ */
 /* Replaces QMatMul.forward (mobilellm/quantization/qmodule.py:453-466): out = Qout(matmul(Q1(x1), Q2(x2))) -- two fake-quant passes

@@ -131,7 +131,7 @@ class ActRangeCollector:
                 self._update(name, "input", x)
             if "output" not in skip:
                 self._update(name, "output", y)
-            if matmul:
+            if matmul and "input2" not in skip:
                 self._update(name, "input2", xx[1])
         return fn
 
@@ -182,6 +182,17 @@ class ActRangeCollector:
         for k in sl:
             stats += [self._mn[k:k + 1], self._mx[k:k + 1]]
         return ops.calib_gated_(a, b, act, stats)
+
+    def rope_pass(self, q_name: str, k_name: str, qk_name: str, q_lin: torch.Tensor, k_lin: torch.Tensor, heads: int, kv_heads: int, head_dim: int,
+                  cos: torch.Tensor, sin: torch.Tensor):
+        """(q, k) rotated, [B, heads, S, D] / [B, kv_heads, S, D], with the statistics of q_proj.output, qk_bmm.input, k_proj.output and
+        qk_bmm.input2 (the repeated k^T holds k's values) taken in the same pass (ops.calib_rope_)."""
+        sl = [self.slots[(q_name, "output")], self.slots[(qk_name, "input")], self.slots[(k_name, "output")], self.slots[(qk_name, "input2")]]
+        self.bytes_fused += 2 * (q_lin.numel() + k_lin.numel()) * q_lin.element_size()
+        stats = []
+        for k in sl:
+            stats += [self._mn[k:k + 1], self._mx[k:k + 1]]
+        return ops.calib_rope_(q_lin, k_lin, heads, kv_heads, head_dim, cos, sin, stats)
 
     def can_fuse_attention(self, raw_shape, dtype, device, mask) -> bool:
         return (self.fuse_attention_statistics and not self.per_channel and dtype == torch.float32 and device == self.device

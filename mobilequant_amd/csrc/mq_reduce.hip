@@ -541,6 +541,64 @@ __global__ void __launch_bounds__(256) calib_gated_kernel(const float* __restric
   }
 }
 
+
+// RoPE on the q and k projections of one attention block with the four statistics around it (hf_model.py:486-501 between the hooks of
+// q_proj / k_proj (outputs) and qk_bmm (input, input2)): x [B, S, heads * D] as the linear wrote it -> [B, heads, S, D] contiguous,
+// out[d] = x[d] * cos[s][d] + rot[d] * sin[s][d] for d < rot (rot[d] = -x[d + rot / 2] | x[d - rot / 2]), x[d] beyond -- two rounded
+// products and a rounded sum, as torch's three launches: the same bits.  One thread per 4 consecutive d; the partner quad is a second
+// (cached) load.  Segment 0 = q (heads[0] heads), segment 1 = k (heads[1]).
+struct CalibRopeArgs {
+  const float* x[2];
+  float* out[2];
+  int heads[2];
+  long long quads[2];            // B * S * heads * D / 4
+  int S, D, rot;
+  const float* cos;              // [S, rot]
+  const float* sin;
+  float* st[8];                  // {min, max} of x[0], out[0], x[1], out[1]
+};
+__global__ void __launch_bounds__(256) calib_rope_kernel(const CalibRopeArgs a) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const float pinf = __int_as_float(0x7f800000), ninf = __int_as_float(0xff800000);
+  float lo[4] = {pinf, pinf, pinf, pinf}, hi[4] = {ninf, ninf, ninf, ninf};
+  auto upd = [&](int k, const v4f v) {
+    lo[k] = min_p(min_p(lo[k], v[0]), min_p(v[1], min_p(v[2], v[3])));
+    hi[k] = max_p(max_p(hi[k], v[0]), max_p(v[1], max_p(v[2], v[3])));
+  };
+  const int dq = a.D >> 2, half = a.rot >> 1;
+  const long long stride = (long long)gridDim.x * 256;
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const int H = a.heads[seg];
+    const v4f* x = reinterpret_cast<const v4f*>(a.x[seg]);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.quads[seg]; i += stride) {
+      const int d = (int)(i % dq) * 4;
+      const long long r = i / dq;                      // (b * S + s) * H + h
+      const int h = (int)(r % H);
+      const long long bs = r / H;
+      const int s_ = (int)(bs % a.S);
+      const long long b = bs / a.S;
+      const v4f v = x[i];
+      upd(2 * seg, v);
+      v4f o = v;
+      if (d < a.rot) {
+        const v4f c = *reinterpret_cast<const v4f*>(a.cos + (long long)s_ * a.rot + d), sn = *reinterpret_cast<const v4f*>(a.sin + (long long)s_ * a.rot + d);
+        v4f p = x[d < half ? i + (half >> 2) : i - (half >> 2)];
+        if (d < half) p = -p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(v[e], c[e]), __fmul_rn(p[e], sn[e]));
+      }
+      upd(2 * seg + 1, o);
+      reinterpret_cast<v4f*>(a.out[seg])[(((b * H + h) * a.S + s_) * (long long)a.D + d) >> 2] = o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    block_commit(lo[k], hi[k], a.st[2 * k], a.st[2 * k + 1]);
+    __syncthreads();
+  }
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -684,6 +742,35 @@ int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, in
   int64_t grid = (numel / 4 + 255) / 256;
   if (grid > 4096) grid = 4096;
   calib_gated_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a, b, out, numel, act, cs);
+  MQ_LAUNCH_CHECK(fn);
+  return MQ_OK;
+}
+
+
+int mq_calib_rope(const float* q_in, const float* k_in, float* q_out, float* k_out, int64_t batch, int64_t seq, int heads, int kv_heads, int head_dim,
+                  int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream) {
+  const char* fn = "mq_calib_rope";
+  MQ_REQUIRE(batch >= 0 && seq >= 0 && heads > 0 && kv_heads > 0 && head_dim > 0 && rot_dim > 0, "%s: bad shape", fn);
+  if (batch == 0 || seq == 0) return MQ_OK;
+  MQ_REQUIRE(q_in && k_in && q_out && k_out && cos && sin && stats, "%s: null pointer", fn);
+  if (head_dim % 4 != 0 || rot_dim > head_dim || rot_dim % 8 != 0 || seq >= (1ll << 31) || !aligned(q_in, 16) || !aligned(k_in, 16) ||
+      !aligned(q_out, 16) || !aligned(k_out, 16) || !aligned(cos, 16) || !aligned(sin, 16)) {
+    set_error("%s: not served: head_dim %% 4 == 0, rot_dim %% 8 == 0, rot_dim <= head_dim, 16-byte aligned pointers", fn);
+    return MQ_EUNSUPPORTED;
+  }
+  CalibRopeArgs a;
+  a.x[0] = q_in; a.x[1] = k_in; a.out[0] = q_out; a.out[1] = k_out;
+  a.heads[0] = heads; a.heads[1] = kv_heads;
+  a.quads[0] = batch * seq * heads * head_dim / 4;
+  a.quads[1] = batch * seq * kv_heads * head_dim / 4;
+  a.S = (int)seq; a.D = head_dim; a.rot = rot_dim; a.cos = cos; a.sin = sin;
+  for (int k = 0; k < 8; ++k) {
+    MQ_REQUIRE(stats[k], "%s: null statistic %d", fn, k);
+    a.st[k] = stats[k];
+  }
+  long long grid = (a.quads[0] + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  calib_rope_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
   MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
 }

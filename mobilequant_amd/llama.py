@@ -96,6 +96,7 @@ def apply_rope(x, cos, sin):
 
 class Attention(nn.Module):
     _mq_calibration_aware = True        # forward() hands its score chain to an attached ActRangeCollector (calibration.py)
+    _mq_calibration_layer_parts = ("q_proj", "k_proj", "qk_bmm")      # ... and RoPE with the four statistics around it (see forward)
 
     def __init__(self, s: LlamaShape):
         super().__init__()
@@ -111,10 +112,34 @@ class Attention(nn.Module):
         written at pos .. pos+S-1 and attention runs over positions 0 .. pos+S-1 (sim_model.py:160-221's static cache)."""
         s = self.s
         B, S, _ = x.shape
-        q = self.q_proj(x).view(B, S, s.heads, s.head_dim).transpose(1, 2)
-        k = self.k_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
-        v = self.v_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
-        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+        cl = self.__dict__.get("_mq_calib_layer")                   # (collector, names of q_proj / k_proj / qk_bmm) while ONE calibration pass runs
+        rope_taken = False
+        if (cl is not None and cache is None and not torch.is_grad_enabled() and cl[0].can_fuse_layer(x) and s.head_dim % 4 == 0
+                and cos.shape[-1] % 8 == 0 and cos.dtype == torch.float32):
+            # calibration: RoPE on q and k in ONE launch that also takes the statistics of q_proj.output, k_proj.output, qk_bmm.input and
+            # qk_bmm.input2 (the bits of apply_rope; the linears' and the matmul's hooks skip those fields)
+            col, (nq, nk, nqk) = cl
+            for m in (self.q_proj, self.k_proj):
+                m.__dict__["_mq_calib_skip"] = (col, ("output",))
+            try:
+                ql, kl = self.q_proj(x), self.k_proj(x)
+            finally:
+                for m in (self.q_proj, self.k_proj):
+                    m.__dict__.pop("_mq_calib_skip", None)
+            if ql.is_contiguous() and kl.is_contiguous() and ql.dtype == torch.float32:
+                q, k = col.rope_pass(nq, nk, nqk, ql, kl, s.heads, s.kv_heads, s.head_dim, cos, sin)
+                rope_taken = True
+            else:
+                col._update(nq, "output", ql)
+                col._update(nk, "output", kl)
+                q = apply_rope(ql.view(B, S, s.heads, s.head_dim).transpose(1, 2), cos, sin)
+                k = apply_rope(kl.view(B, S, s.kv_heads, s.head_dim).transpose(1, 2), cos, sin)
+            v = self.v_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
+        else:
+            q = self.q_proj(x).view(B, S, s.heads, s.head_dim).transpose(1, 2)
+            k = self.k_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
+            v = self.v_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
+            q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
         if cache is not None:
             cache[0][:, :, pos:pos + S] = k
             cache[1][:, :, pos:pos + S] = v
@@ -135,7 +160,8 @@ class Attention(nn.Module):
             # calibration: the two [heads, S, T]-sized statistics (qk_bmm.output, pv_bmm.input) are taken inside the ONE pass that turns
             # the raw scores into probabilities, in place (calibration.ActRangeCollector.attention_probs); the module hooks skip them
             # (owner, fields): only the OWNING collector's hooks skip them -- another collector on the same model keeps its plain hooks)
-            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = (calib[0], ("output",)), (calib[0], ("input",))
+            taken = ("output", "input", "input2") if (rope_taken and cl[0] is calib[0]) else ("output",)
+            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = (calib[0], taken), (calib[0], ("input",))
             try:
                 raw = self.qk_bmm(q, k.transpose(2, 3))
                 att = calib[0].attention_probs(calib[1], calib[2], raw if raw.is_contiguous() else raw.contiguous(), mask, math.sqrt(s.head_dim))
@@ -144,7 +170,14 @@ class Attention(nn.Module):
                 self.qk_bmm.__dict__.pop("_mq_calib_skip", None)
                 self.pv_bmm.__dict__.pop("_mq_calib_skip", None)
             return self.o_proj(out.transpose(1, 2).reshape(B, S, s.heads * s.head_dim))
-        att = (fused[0] if fused is not None else self.qk_bmm(q, k.transpose(2, 3))) / math.sqrt(s.head_dim)
+        if rope_taken and fused is None:
+            self.qk_bmm.__dict__["_mq_calib_skip"] = (cl[0], ("input", "input2"))
+            try:
+                att = self.qk_bmm(q, k.transpose(2, 3)) / math.sqrt(s.head_dim)
+            finally:
+                self.qk_bmm.__dict__.pop("_mq_calib_skip", None)
+        else:
+            att = (fused[0] if fused is not None else self.qk_bmm(q, k.transpose(2, 3))) / math.sqrt(s.head_dim)
         if mask is not None:
             att = att + mask
         att = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)

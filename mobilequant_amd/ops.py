@@ -170,6 +170,25 @@ def calib_gated_(a: torch.Tensor, b: torch.Tensor, act: str, stats) -> torch.Ten
     return out
 
 
+def calib_rope_(q_lin: torch.Tensor, k_lin: torch.Tensor, heads: int, kv_heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor, stats):
+    """Calibration-mode RoPE (mq_calib_rope): q_lin [B, S, heads * D], k_lin [B, S, kv_heads * D] (the projections' outputs) -> q [B, heads,
+    S, D], k [B, kv_heads, S, D] contiguous, rotated with cos / sin [S, rot]; stats = eight 1-element fp32 device tensors: (min, max) of
+    q_lin, q, k_lin, k.  The bits of llama.apply_rope."""
+    q_lin, k_lin = _dev(q_lin, "q"), _dev(k_lin, "k")
+    B, S = q_lin.shape[0], q_lin.shape[1]
+    cos, sin = _f32(cos, "cos").contiguous(), _f32(sin, "sin").contiguous()
+    if (q_lin.dtype != torch.float32 or k_lin.dtype != torch.float32 or not q_lin.is_contiguous() or not k_lin.is_contiguous()
+            or q_lin.shape[-1] != heads * head_dim or k_lin.shape[-1] != kv_heads * head_dim or cos.shape != sin.shape or cos.shape[0] != S):
+        raise RuntimeError("mobilequant_amd: calib_rope_ takes the contiguous float32 outputs of q_proj / k_proj and cos / sin [S, rot]")
+    q = torch.empty((B, heads, S, head_dim), dtype=torch.float32, device=q_lin.device)
+    k = torch.empty((B, kv_heads, S, head_dim), dtype=torch.float32, device=q_lin.device)
+    ptrs = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in stats])
+    with _on(q_lin, k_lin, q, k, cos, sin, *stats):
+        _lib.call("mq_calib_rope", q_lin.data_ptr(), k_lin.data_ptr(), q.data_ptr(), k.data_ptr(), B, S, heads, kv_heads, head_dim, cos.shape[1],
+                  cos.data_ptr(), sin.data_ptr(), ptrs, _stream())
+    return q, k
+
+
 def minmax_tensor(x: torch.Tensor):
     """(min, max) of one tensor as 1-element device tensors: partials + fold, no atomics, no init launch."""
     x = _dev(x, "x").contiguous()

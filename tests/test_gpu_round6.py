@@ -428,7 +428,7 @@ def test_calibration_layer_passes_give_the_act_dict_of_the_plain_hooks(dev, fami
         col = ActRangeCollector(model, per_channel=False)
         col.fuse_layer_statistics = fuse
         col.attach()
-        assert (len(col._layers) == 2 * shape.layers) == fuse
+        assert (len(col._layers) == 3 * shape.layers) == fuse           # decoder layer (norms), MLP (gated product), attention (RoPE)
         with torch.no_grad():
             for s in samples:
                 logits[fuse] = model(s)
@@ -460,3 +460,28 @@ def test_calibration_layer_passes_give_the_act_dict_of_the_plain_hooks(dev, fami
         for f, (lo, hi) in fields.items():
             for dd in (d1, d2):
                 assert abs(dd[name][f][0] - lo) <= 1e-5 * max(abs(lo), 1e-3) and abs(dd[name][f][1] - hi) <= 1e-5 * max(abs(hi), 1e-3), (name, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(2, 37, 32, 4, 64, 64), (1, 50, 8, 1, 256, 256), (1, 29, 32, 32, 64, 16)])
+def test_calib_rope_pass_is_apply_rope_bit_for_bit(dev, geom):
+    """ops.calib_rope_ (mq_calib_rope): the rotated q / k of llama.apply_rope bit for bit -- full and partial rotary, GQA -- in
+    [B, heads, S, D] order, and the four statistics exactly those of the projections' outputs and of the rotated tensors."""
+    from mobilequant_amd import ops, llama
+    B, S, H, KV, D, rot = geom
+    g = torch.Generator().manual_seed(S)
+    ql = (torch.randn(B, S, H * D, generator=g) * 1.7).to(dev)
+    kl = (torch.randn(B, S, KV * D, generator=g) * 0.6 + 0.2).to(dev)
+    shape = llama.LlamaShape(hidden=64, layers=1, heads=H, kv_heads=KV, head_dim=D, ffn=64, vocab=16, max_pos=128, rot_dim=rot) if "rot_dim" in llama.LlamaShape.__dataclass_fields__ else None
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    ang = torch.outer(torch.arange(S, dtype=torch.float32) + 5, inv)
+    ang = torch.cat((ang, ang), dim=-1)
+    cos, sin = ang.cos().to(dev), ang.sin().to(dev)
+    st = [torch.full((1,), float("inf") if k % 2 == 0 else float("-inf"), device=dev) for k in range(8)]
+    q, k = ops.calib_rope_(ql, kl, H, KV, D, cos, sin, st)
+    qw = llama.apply_rope(ql.view(B, S, H, D).transpose(1, 2), cos, sin)
+    kw = llama.apply_rope(kl.view(B, S, KV, D).transpose(1, 2), cos, sin)
+    assert q.is_contiguous() and k.is_contiguous() and q.shape == qw.shape and k.shape == kw.shape
+    assert torch.equal(q, qw) and torch.equal(k, kw)
+    want = [ql.min(), ql.max(), qw.min(), qw.max(), kl.min(), kl.max(), kw.min(), kw.max()]
+    assert [float(t) for t in st] == [float(t) for t in want]
