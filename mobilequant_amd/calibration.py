@@ -160,16 +160,16 @@ class ActRangeCollector:
         i, j = self.slots[(name, "input")], self.slots[(name, "output")]
         nbytes = x.numel() * x.element_size()
         self.bytes_fused += 2 * nbytes
-        return ops.calib_norm_(x, delta, module.weight, getattr(module, "bias", None), module.eps, isinstance(module, nn.LayerNorm),
+        return ops.calib_norm_(x, delta, module.weight, getattr(module, "bias", None), module.eps, type(module) is nn.LayerNorm,
                                self._mn[i:i + 1], self._mx[i:i + 1], self._mn[j:j + 1], self._mx[j:j + 1])
 
     @staticmethod
     def norm_is_plain(module: nn.Module) -> bool:
         """A norm the one-pass kernel reproduces: nn.LayerNorm over the last dim with affine parameters, or HFRMSNorm in its rsqrt form
         without a bias."""
-        if isinstance(module, nn.LayerNorm):
+        if type(module) is nn.LayerNorm:                             # (exact types: QLayerNorm / QRMSNorm carry quantizers of their own)
             return module.elementwise_affine and module.weight is not None and len(module.normalized_shape) == 1
-        return isinstance(module, HFRMSNorm) and not module.l2norm_as_rmsnorm and module.bias is None
+        return type(module) is HFRMSNorm and not module.l2norm_as_rmsnorm and module.bias is None
 
     def gated_pass(self, w1_name: str, w3_name: str, act_name: str, w2_name: str, a: torch.Tensor, b: torch.Tensor, act: str) -> torch.Tensor:
         """act(a) * b with the statistics of w1.output (= act.input), act.output, w3.output and w2.input."""

@@ -425,7 +425,7 @@ class MLP(nn.Module):
     def forward(self, x):      # hf_model.py:1057
         calib = self.__dict__.get("_mq_calib_layer")                # (collector, names of w1 / w3 / act_fn / w2) while ONE calibration pass runs
         if (calib is not None and not torch.is_grad_enabled() and calib[0].can_fuse_layer(x)
-                and (isinstance(self.act_fn, nn.SiLU) or (isinstance(self.act_fn, nn.GELU) and self.act_fn.approximate == "none"))):
+                and (type(self.act_fn) is nn.SiLU or (type(self.act_fn) is nn.GELU and self.act_fn.approximate == "none"))):
             # calibration: act(w1(x)) * w3(x) and the four statistics around it (w1.output = act.input, act.output, w3.output, w2.input)
             # in ONE pass; the linears' hooks skip those fields, the activation module is not run
             col, (n1, n3, na, n2) = calib
@@ -435,7 +435,7 @@ class MLP(nn.Module):
             try:
                 a, b = self.w1(x), self.w3(x)
                 if a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 and a.numel() % 4 == 0:
-                    return self.w2(col.gated_pass(n1, n3, na, n2, a, b, "silu" if isinstance(self.act_fn, nn.SiLU) else "gelu"))
+                    return self.w2(col.gated_pass(n1, n3, na, n2, a, b, "silu" if type(self.act_fn) is nn.SiLU else "gelu"))
                 for m, _ in skips:                                  # (not served: the plain chain, with the hooks' own reductions)
                     m.__dict__.pop("_mq_calib_skip", None)
                 col._update(n1, "output", a)
