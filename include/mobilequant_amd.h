@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated, mq_calib_rope.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
+#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated, mq_calib_rope, mq_calib_attention_probs_causal.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -631,6 +631,13 @@ int mq_attention_quant(const mq_attention_args* args, mq_stream_t stream);
  * as mq_minmax_tensor keeps them (initialise with mq_minmax_init; NaN is sticky). */
 int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64_t cols, const float* mask, int64_t mask_rows, double sqrt_d,
                              float* raw_min, float* raw_max, float* probs_min, float* probs_max, mq_stream_t stream);
+
+/* The same pass under the causal mask of a square block (rows = n * seq rows of seq columns; row r of a block masks the columns > r):
+ * no mask is read, and with store_masked = 0 the quads wholly above the diagonal are not stored -- `probs` (!= raw) must already hold
+ * zeros there, e.g. the buffer a previous call with the same shape wrote (a quarter of the pass's bytes).  Element for element the
+ * arithmetic of mq_calib_attention_probs with the explicit -inf / 0 mask. */
+int mq_calib_attention_probs_causal(const float* raw, float* probs, int64_t rows, int64_t seq, double sqrt_d, int store_masked, float* raw_min,
+                                    float* raw_max, float* probs_min, float* probs_max, mq_stream_t stream);
 
 /* ---- calibration: a decoder layer's glue with its statistics (round 6) --------------------------- */
 /* The fp32 calibration forward (ptq/generate_act_range.py:49-122 over mobilellm/model/hf_model.py) hooks the input and the output of

@@ -356,68 +356,121 @@ static int launch_cols(const T* x, int64_t rows, int64_t cols, float* mn, float*
 // probabilities (x = raw * (1 / sqrt_d) [+ mask]; torch.softmax(dim = -1, fp32): max, exp(x - max), sum, quotient), folds THEIR min / max
 // into pv_bmm.input's statistic and writes them over the scores.  A wave owns a row (up to 4096 keys in registers); the four
 // running statistics are committed once per workgroup through the filtered bit-pattern atomics above (NaN sticky, as torch's amin / amax).
-template <int VPT>
+// CAUSAL (round 6): the mask is the causal one of a square block (row r of every [mask_rows, cols = mask_rows] matrix masks the columns
+// > r): -inf is added without reading a mask, and -- store_masked == 0 -- quads that lie wholly above the diagonal are NOT stored: the
+// caller hands a `out` buffer whose upper triangles already hold the zeros a previous call left there (calibration.ActRangeCollector keeps
+// one per shape), which takes a quarter of the pass's bytes away.  Same arithmetic on every element as with the explicit mask.
+template <int VPT, bool CAUSAL = false>
 __global__ void __launch_bounds__(256) calib_probs_kernel(const float* raw, float* out /* may be raw: no __restrict__ */, const int64_t rows, const int cols,
                                                           const float* __restrict__ mask, const int mask_rows, const float inv_sqrt_d,
-                                                          float* mn_raw, float* mx_raw, float* mn_p, float* mx_p) {
+                                                          float* mn_raw, float* mx_raw, float* mn_p, float* mx_p, const int store_masked = 1) {
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, nvec = cols >> 2;
   const int64_t nw = (int64_t)gridDim.x * 4;
-  float rlo = __int_as_float(0x7f800000), rhi = __int_as_float(0xff800000), plo = rlo, phi = rhi;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+  const float pinf = __int_as_float(0x7f800000), ninf = __int_as_float(0xff800000);
+  float rlo = pinf, rhi = ninf, plo = rlo, phi = rhi;
+  int trip = 0;
+  for (int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); lrow < rows; lrow += nw, ++trip) {
+    // CAUSAL: a row's work grows with its position in the block (see klive below) and a wave would meet the same position on every
+    // trip (the launch covers whole blocks per trip: nw % mask_rows == 0): odd trips walk their blocks bottom-up, so every wave sees
+    // light and heavy rows in turn
+    int64_t row = lrow;
+    if (CAUSAL && (trip & 1)) row = lrow - lrow % mask_rows + (mask_rows - 1 - lrow % mask_rows);
     const float4* rr = reinterpret_cast<const float4*>(raw + row * cols);
-    const float4* mr = mask ? reinterpret_cast<const float4*>(mask + (row % mask_rows) * (int64_t)cols) : nullptr;
+    const float4* mr = (!CAUSAL && mask) ? reinterpret_cast<const float4*>(mask + (row % mask_rows) * (int64_t)cols) : nullptr;
+    const int diag = CAUSAL ? (int)(row % mask_rows) : cols;      // CAUSAL: columns > diag are masked
     float v[VPT * 4];
-    float mx = __int_as_float(0xff800000);
+    float qlo = pinf, qhi = ninf;                                   // this row's raw statistic
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
       const int i = lane + 64 * k;
       const bool valid = i < nvec;
-      // read once, overwritten in place: streaming hints on both sides (S = 2048, 32 heads: 220 -> 201 us)
-      typedef float v4f_ __attribute__((ext_vector_type(4)));
+      // read once, overwritten (in place or into the kept buffer): streaming hints on both sides (S = 2048, 32 heads: 220 -> 201 us)
       const v4f_ xv = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(rr) + (valid ? i : nvec - 1));
-      const float4 x4 = make_float4(xv.x, xv.y, xv.z, xv.w);
-      float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mr) m4 = mr[valid ? i : nvec - 1];
-      const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        v[4 * k + e] = xv[e];
         if (valid) {
-          rlo = min_p(rlo, xs[e]);
-          rhi = max_p(rhi, xs[e]);
+          qlo = min_p(qlo, xv[e]);
+          qhi = max_p(qhi, xv[e]);
         }
-        float x = __fmul_rn(xs[e], inv_sqrt_d);                   // torch: tensor / python scalar == tensor * (1 / scalar)
-        if (mr) x = __fadd_rn(x, ms[e]);
-        v[4 * k + e] = x;
-        mx = valid ? max_p(mx, x) : mx;
+      }
+    }
+    rlo = min_p(rlo, qlo);
+    rhi = max_p(rhi, qhi);
+    // CAUSAL: the 256-column blocks that lie wholly above the diagonal hold -inf after the mask: no scaling, no exponential, no divide
+    // for them -- unless the row holds a NaN or an infinity somewhere (inf - inf poisons the row in the masked chain: the full pass then)
+    int klive = VPT;
+    if (CAUSAL) {
+      const bool odd = qlo != qlo || qhi != qhi || qlo == ninf || qhi == pinf;
+      if (__builtin_amdgcn_ballot_w64(odd) == 0) klive = min(VPT, (diag >> 8) + 1);
+    }
+    float mx = ninf;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      if (k < klive) {
+        const int i = lane + 64 * k;
+        const bool valid = i < nvec;
+        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mr) m4 = mr[valid ? i : nvec - 1];
+        const float ms[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = __fmul_rn(v[4 * k + e], inv_sqrt_d);           // torch: tensor / python scalar == tensor * (1 / scalar)
+          if (mr) x = __fadd_rn(x, ms[e]);
+          if (CAUSAL) x = __fadd_rn(x, 4 * i + e > diag ? ninf : 0.f);
+          v[4 * k + e] = x;
+          mx = valid ? max_p(mx, x) : mx;
+        }
       }
     }
     mx = wave_max_p(mx);
     float l = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      const bool valid = lane + 64 * k < nvec;
+      if (k < klive) {
+        const bool valid = lane + 64 * k < nvec;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float ex = expf(__fsub_rn(v[4 * k + e], mx));
-        v[4 * k + e] = ex;
-        l += valid ? ex : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const float ex = expf(__fsub_rn(v[4 * k + e], mx));
+          v[4 * k + e] = ex;
+          l += valid ? ex : 0.f;
+        }
       }
     }
     l = wave_sum_f32_dpp(l);
     float4* orow = reinterpret_cast<float4*>(out + row * cols);
+    // ex / l through RN(1 / l) and one fma correction (mq_common.h: div_by_scale, 3 instructions for the ~10 of the IEEE sequence -- this
+    // pass is VALU-bound once the masked stores are gone): l in [1, cols] is normal and its reciprocal correctly rounded, so the
+    // quotient is the IEEE one except for a divisor with an all-ones significand (wave-uniform: the true divide then) and faithfully
+    // rounded where it underflows into the denormals (probabilities below 1e-38)
+    const float inv_l = __fdiv_rn(1.0f, l);
+    const bool quick = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(l) & 0x7fffffu) != 0x7fffffu && l >= 1.0f && l <= 8192.0f)) != 0;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      float y[4];
+      if (k < klive) {
+        if (quick) {                                                // (a scalar branch: the select form computes both quotients)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = __fdiv_rn(v[4 * k + e], l);
+          for (int e = 0; e < 4; ++e) v[4 * k + e] = div_by_scale(v[4 * k + e], l, inv_l);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * k + e] = __fdiv_rn(v[4 * k + e], l);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * k + e] = 0.f;             // exp(-inf) / l
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
       if (lane + 64 * k < nvec) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          plo = min_p(plo, y[e]);
-          phi = max_p(phi, y[e]);
+          plo = min_p(plo, v[4 * k + e]);
+          phi = max_p(phi, v[4 * k + e]);
         }
-        typedef float v4f_ __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store((v4f_){y[0], y[1], y[2], y[3]}, reinterpret_cast<v4f_*>(orow) + lane + 64 * k);
+        if (!CAUSAL || store_masked || 4 * (lane + 64 * k) <= diag)
+          __builtin_nontemporal_store((v4f_){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]}, reinterpret_cast<v4f_*>(orow) + lane + 64 * k);
       }
     }
   }
@@ -426,6 +479,8 @@ __global__ void __launch_bounds__(256) calib_probs_kernel(const float* raw, floa
   block_commit(plo, phi, mn_p, mx_p);
 }
 
+}  // namespace mq
+namespace mq {
 
 // ---- calibration of a decoder layer's glue (round 6): statistics where the tensors are produced -------------------------------------
 // The fp32 calibration forward (generate_act_range.py:49-122 around hf_model.py) spends a third of its GPU time in torch's elementwise
@@ -696,6 +751,36 @@ int mq_calib_attention_probs(const float* raw, float* probs, int64_t rows, int64
   return MQ_OK;
 }
 
+int mq_calib_attention_probs_causal(const float* raw, float* probs, int64_t rows, int64_t seq, double sqrt_d, int store_masked, float* raw_min,
+                                    float* raw_max, float* probs_min, float* probs_max, mq_stream_t stream) {
+  const char* fn = "mq_calib_attention_probs_causal";
+  MQ_REQUIRE(rows >= 0 && seq >= 0, "%s: negative shape", fn);
+  if (rows == 0 || seq == 0) return MQ_OK;
+  MQ_REQUIRE(raw && probs && raw_min && raw_max && probs_min && probs_max, "%s: null pointer", fn);
+  MQ_REQUIRE(sqrt_d > 0.0 && rows % seq == 0, "%s: sqrt_d=%g, rows=%lld of square blocks of %lld", fn, sqrt_d, (long long)rows, (long long)seq);
+  MQ_REQUIRE(store_masked || raw != probs, "%s: skipping the masked stores needs an output buffer of its own", fn);
+  if (seq % 4 != 0 || seq > 4096 || !aligned(raw, 16) || !aligned(probs, 16)) {
+    set_error("%s: square blocks of up to 4096 keys, a multiple of 4, 16-byte aligned (seq=%lld)", fn, (long long)seq);
+    return MQ_EUNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  // whole blocks per trip of the grid (4 rows per workgroup, seq % 4 == 0): the kernel reverses the row order of odd trips
+  const int64_t blocks = rows / seq;
+  int64_t per_trip = 8192 / seq < 1 ? 1 : 8192 / seq;
+  if (per_trip > blocks) per_trip = blocks;
+  const int64_t grid = per_trip * seq / 4;
+  const float inv = 1.0f / (float)sqrt_d;
+#define MQ_CALIBC(V) calib_probs_kernel<V, true><<<(unsigned)grid, 256, 0, st>>>(raw, probs, rows, (int)seq, nullptr, (int)seq, inv, raw_min, raw_max, \
+                                                                                 probs_min, probs_max, store_masked)
+  if (seq <= 256) MQ_CALIBC(1);
+  else if (seq <= 512) MQ_CALIBC(2);
+  else if (seq <= 1024) MQ_CALIBC(4);
+  else if (seq <= 2048) MQ_CALIBC(8);
+  else MQ_CALIBC(16);
+#undef MQ_CALIBC
+  MQ_LAUNCH_CHECK(fn);
+  return MQ_OK;
+}
 
 int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out, int64_t rows, int64_t cols, const float* weight, const float* bias,
                   float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, mq_stream_t stream) {

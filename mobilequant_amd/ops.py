@@ -189,6 +189,22 @@ def calib_rope_(q_lin: torch.Tensor, k_lin: torch.Tensor, heads: int, kv_heads: 
     return q, k
 
 
+def calib_attention_probs_causal_(raw: torch.Tensor, out: torch.Tensor, sqrt_d: float, store_masked: bool, raw_min: torch.Tensor, raw_max: torch.Tensor,
+                                  probs_min: torch.Tensor, probs_max: torch.Tensor) -> torch.Tensor:
+    """calib_attention_probs_ under the causal mask of square [S, S] blocks (mq_calib_attention_probs_causal): no mask tensor is read;
+    store_masked = False leaves the quads above the diagonal of `out` (a buffer of raw's shape, not raw itself) untouched -- it must
+    already hold zeros there.  Returns `out`."""
+    raw, out = _dev(raw, "raw"), _dev(out, "out")
+    S = raw.shape[-1]
+    if (raw.dtype != torch.float32 or out.dtype != torch.float32 or not raw.is_contiguous() or not out.is_contiguous() or raw.shape != out.shape
+            or raw.dim() < 2 or raw.shape[-2] != S):
+        raise RuntimeError("mobilequant_amd: calib_attention_probs_causal_ takes contiguous float32 [..., S, S] tensors")
+    with _on(raw, out, raw_min, raw_max, probs_min, probs_max):
+        _lib.call("mq_calib_attention_probs_causal", raw.data_ptr(), out.data_ptr(), raw.numel() // max(S, 1), S, float(sqrt_d), int(bool(store_masked)),
+                  raw_min.data_ptr(), raw_max.data_ptr(), probs_min.data_ptr(), probs_max.data_ptr(), _stream())
+    return out
+
+
 def minmax_tensor(x: torch.Tensor):
     """(min, max) of one tensor as 1-element device tensors: partials + fold, no atomics, no init launch."""
     x = _dev(x, "x").contiguous()

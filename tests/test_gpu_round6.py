@@ -485,3 +485,51 @@ def test_calib_rope_pass_is_apply_rope_bit_for_bit(dev, geom):
     assert torch.equal(q, qw) and torch.equal(k, kw)
     want = [ql.min(), ql.max(), qw.min(), qw.max(), kl.min(), kl.max(), kw.min(), kw.max()]
     assert [float(t) for t in st] == [float(t) for t in want]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [64, 100, 2048])
+def test_causal_score_chain_without_a_mask_tensor_and_without_the_masked_stores(dev, S):
+    """ops.calib_attention_probs_causal_ (mq_calib_attention_probs_causal): the probabilities and the four statistics of
+    calib_attention_probs_ under the explicit causal mask, bit for bit; with store_masked = False the buffer's upper triangles are left
+    alone (zeros stay zeros from call to call, stale non-zeros would stay too) and the lower triangles are those of the full pass."""
+    from mobilequant_amd import ops
+    H = 3 if S < 2048 else 2
+    g = torch.Generator().manual_seed(S)
+    raws = [(torch.randn(1, H, S, S, generator=g) * 3).to(dev) for _ in range(2)]
+    mask = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    new = lambda: [torch.full((1,), float("inf") if k % 2 == 0 else float("-inf"), device=dev) for k in range(4)]
+    buf = torch.zeros_like(raws[0])
+    for raw in raws:
+        st_ref, st_c, st_k = new(), new(), new()
+        want = ops.calib_attention_probs_(raw.clone(), mask, 8.0, *st_ref)
+        full = ops.calib_attention_probs_causal_(raw, torch.empty_like(raw), 8.0, True, *st_c)
+        kept = ops.calib_attention_probs_causal_(raw, buf, 8.0, False, *st_k)
+        assert torch.equal(full, want) and torch.equal(kept, want) and kept.data_ptr() == buf.data_ptr()
+        assert [float(t) for t in st_ref] == [float(t) for t in st_c] == [float(t) for t in st_k]
+    junk = torch.full_like(raws[0], 7.0)
+    ops.calib_attention_probs_causal_(raws[0], junk, 8.0, False, *new())
+    lower = torch.ones(S, S, device=dev).tril().bool()
+    assert torch.equal(junk[..., lower], want_lower := ops.calib_attention_probs_(raws[0].clone(), mask, 8.0, *new())[..., lower])
+    q = torch.arange(S, device=dev)
+    wholly_above = (q[None, :] // 4 * 4) > q[:, None]           # quads that start beyond the diagonal were not stored
+    assert bool((junk[..., wholly_above] == 7.0).all())
+
+
+@pytest.mark.gpu
+def test_calibration_with_the_kept_causal_zeros_is_the_calibration_without(dev):
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import ActRangeCollector, get_act_range
+    shape = llama.LlamaShape.tinyllama(layers=2, max_pos=128, vocab=512)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=3, std=0.05)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    samples = [torch.randint(0, shape.vocab, (1, n), generator=g).to(dev) for n in (128, 128, 96, 128)]      # a shape change in between
+    a = get_act_range(model, samples)
+    ActRangeCollector.keep_causal_zeros = False
+    try:
+        b = get_act_range(model, samples)
+    finally:
+        ActRangeCollector.keep_causal_zeros = True
+    assert a == b

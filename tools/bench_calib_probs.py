@@ -29,3 +29,8 @@ raw = raw0.clone()
 for name, m in (("causal mask", mask), ("no mask", None)):
     us = timed(lambda: ops.calib_attention_probs_(raw, m, 8.0, *st))
     print(f"{name}: {us:.1f} us = {8 * raw.numel() / us / 1e6:.2f} TB/s of algorithmic bytes", flush=True)
+buf = torch.zeros_like(raw)
+for name, sm in (("causal, no mask tensor, all stores", True), ("causal, masked quads not stored (kept zeros)", False)):
+    src = raw0.clone()
+    us = timed(lambda: ops.calib_attention_probs_causal_(src, buf, 8.0, sm, *st))
+    print(f"{name}: {us:.1f} us = {8 * raw.numel() / us / 1e6:.2f} TB/s of the full pass's algorithmic bytes", flush=True)
