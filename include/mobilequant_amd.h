@@ -647,14 +647,17 @@ int mq_calib_attention_probs_causal(const float* raw, float* probs, int64_t rows
  * mq_calib_norm: h = x (+ delta, the residual branch; h is written to h_out), running [min, max] of h (the norm's input hook),
  *   y = weight * (h * rsqrt(mean(h^2) + eps))  (layernorm = 0; hf_model.py:183-186)  or  LayerNorm(h) * weight + bias (layernorm = 1,
  *   biased variance), running [min, max] of y (its output hook).  x / delta / h_out / y_out [rows, cols] fp32, cols % 4 == 0,
- *   cols <= 8192, 16-byte aligned (else MQ_EUNSUPPORTED); delta, h_out, bias may be NULL (h_out is required with a delta).
+ *   cols <= 8192, 16-byte aligned (else MQ_EUNSUPPORTED); delta, h_out, bias may be NULL (h_out is required with a delta);
+ *   delta_min / delta_max (both or neither; NULL without a delta): running [min, max] of delta itself -- the output hook of the linear
+ *   that produced the branch (o_proj, w2).
  * mq_calib_gated: out = act(a) * b (hf_model.py:1057: w2's input) with the running [min, max] of a (w1's output = the activation's
  *   input), act(a) (the activation's output), b (w3's output) and the product, in that order in stats[8] = {min, max} x 4.
  *   act 0 = SiLU, 1 = GELU (erf).  numel % 4 == 0.
  * Statistics are 1-float running values as mq_minmax_tensor keeps them (mq_minmax_init; NaN is sticky).  The row sums are taken in
  * another order than torch's: values agree with the module chain within a few ulp (tests bound the act_dict at 1e-5 relative). */
 int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out, int64_t rows, int64_t cols, const float* weight, const float* bias,
-                  float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, mq_stream_t stream);
+                  float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, float* delta_min, float* delta_max,
+                  mq_stream_t stream);
 int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, int act, float* const* stats, mq_stream_t stream);
 /* mq_calib_rope: rotary embedding of the q and k projections (hf_model.py:486-501, rotate-half; rot_dim < head_dim: partial rotary) with
  * the running [min, max] of q_proj's output, qk_bmm's input, k_proj's output and qk_bmm's input2 (stats[8] in that order): q_in

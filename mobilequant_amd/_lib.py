@@ -141,7 +141,7 @@ _SIGNATURES = {
     "mq_attention_quant": (c_int, [POINTER(MqAttentionArgs), _P]),
     "mq_calib_attention_probs": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, _P]),
     "mq_calib_attention_probs_causal": (c_int, [_P, _P, c_int64, c_int64, ctypes.c_double, c_int, _P, _P, _P, _P, _P]),
-    "mq_calib_norm": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P, _P, ctypes.c_float, c_int, _P, _P, _P, _P, _P]),
+    "mq_calib_norm": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P, _P, ctypes.c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mq_calib_gated": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P]),
     "mq_calib_rope": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "mq_qmatmul": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int, POINTER(MqGrid), POINTER(MqGrid), POINTER(MqGrid), _P]),

@@ -169,13 +169,20 @@ class ActRangeCollector:
         return (self.fuse_layer_statistics and not self.per_channel and x.dtype == torch.float32 and x.device == self.device
                 and x.device.type == "cuda" and x.is_contiguous() and x.shape[-1] % 4 == 0 and x.shape[-1] <= 8192)
 
-    def norm_pass(self, name: str, module: nn.Module, x: torch.Tensor, delta: Optional[torch.Tensor] = None):
-        """(h, y): h = x (+ delta), y = module(h); module's input / output statistics are taken here (its hooks are not run)."""
+    def norm_pass(self, name: str, module: nn.Module, x: torch.Tensor, delta: Optional[torch.Tensor] = None, delta_slot: Optional[tuple] = None):
+        """(h, y): h = x (+ delta), y = module(h); module's input / output statistics are taken here (its hooks are not run).
+        delta_slot = (module name, field): the branch's own statistic is taken in the same pass (the hook that would have read it is
+        told to skip the field by the caller)."""
         i, j = self.slots[(name, "input")], self.slots[(name, "output")]
         nbytes = x.numel() * x.element_size()
         self.bytes_fused += 2 * nbytes
+        dm = dx = None
+        if delta is not None and delta_slot is not None:
+            k = self.slots[delta_slot]
+            dm, dx = self._mn[k:k + 1], self._mx[k:k + 1]
+            self.bytes_fused += nbytes
         return ops.calib_norm_(x, delta, module.weight, getattr(module, "bias", None), module.eps, type(module) is nn.LayerNorm,
-                               self._mn[i:i + 1], self._mx[i:i + 1], self._mn[j:j + 1], self._mx[j:j + 1])
+                               self._mn[i:i + 1], self._mx[i:i + 1], self._mn[j:j + 1], self._mx[j:j + 1], dm, dx)
 
     @staticmethod
     def norm_is_plain(module: nn.Module) -> bool:
@@ -256,7 +263,12 @@ class ActRangeCollector:
                 self._aware.append(m)
             want = getattr(m, "_mq_calibration_layer_parts", None)     # llama.DecoderLayer / MLP: the submodules a fused pass stands for
             if want is not None and not self.per_channel and self.fuse_layer_statistics:
-                parts = [getattr(m, a, None) for a in want]
+                parts = []
+                for a in want:                                     # ("w1", ...) or dotted ("mlp.w2")
+                    q = m
+                    for piece in a.split("."):
+                        q = getattr(q, piece, None) if q is not None else None
+                    parts.append(q)
                 keys = [names.get(id(q)) for q in parts]
                 if all(k is not None and (k, "input") in self.slots and (k, "output") in self.slots for k in keys):
                     owner = m.__dict__.get("_mq_calib_layer")

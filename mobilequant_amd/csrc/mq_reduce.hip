@@ -496,11 +496,11 @@ template <int VPT, bool LN>
 __global__ void __launch_bounds__(256) calib_norm_kernel(const float* __restrict__ x, const float* __restrict__ delta, float* __restrict__ h_out,
                                                          float* __restrict__ y_out, const int64_t rows, const int cols,
                                                          const float* __restrict__ weight, const float* __restrict__ bias, const float eps,
-                                                         float* mn_h, float* mx_h, float* mn_y, float* mx_y) {
+                                                         float* mn_h, float* mx_h, float* mn_y, float* mx_y, float* mn_d, float* mx_d) {
   __shared__ float s_red[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nvec = cols >> 2;
   typedef float v4f __attribute__((ext_vector_type(4)));
-  float hlo = __int_as_float(0x7f800000), hhi = __int_as_float(0xff800000), ylo = hlo, yhi = hhi;
+  float hlo = __int_as_float(0x7f800000), hhi = __int_as_float(0xff800000), ylo = hlo, yhi = hhi, dlo = hlo, dhi = hhi;
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const v4f* xr = reinterpret_cast<const v4f*>(x + row * cols);
     const v4f* dr = delta ? reinterpret_cast<const v4f*>(delta + row * cols) : nullptr;
@@ -511,7 +511,14 @@ __global__ void __launch_bounds__(256) calib_norm_kernel(const float* __restrict
       const int i = tid + 256 * k;
       const bool valid = i < nvec;
       v4f v = xr[valid ? i : nvec - 1];
-      if (dr) v += dr[valid ? i : nvec - 1];
+      if (dr) {
+        const v4f d = dr[valid ? i : nvec - 1];
+        if (valid && mn_d) {                                        // the branch's own statistic (the producing linear's output hook)
+          dlo = min_p(min_p(dlo, d[0]), min_p(d[1], min_p(d[2], d[3])));
+          dhi = max_p(max_p(dhi, d[0]), max_p(d[1], max_p(d[2], d[3])));
+        }
+        v += d;
+      }
       h[k] = v;
       if (valid) {
         hlo = min_p(min_p(hlo, v[0]), min_p(v[1], min_p(v[2], v[3])));
@@ -557,6 +564,10 @@ __global__ void __launch_bounds__(256) calib_norm_kernel(const float* __restrict
   block_commit(hlo, hhi, mn_h, mx_h);
   __syncthreads();
   block_commit(ylo, yhi, mn_y, mx_y);
+  if (mn_d) {
+    __syncthreads();
+    block_commit(dlo, dhi, mn_d, mx_d);
+  }
 }
 
 // p = act(a) * b with the running [min, max] of a (w1's output = the activation's input), act(a) (the activation's output), b (w3's
@@ -783,12 +794,14 @@ int mq_calib_attention_probs_causal(const float* raw, float* probs, int64_t rows
 }
 
 int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out, int64_t rows, int64_t cols, const float* weight, const float* bias,
-                  float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, mq_stream_t stream) {
+                  float eps, int layernorm, float* in_min, float* in_max, float* out_min, float* out_max, float* delta_min, float* delta_max,
+                  mq_stream_t stream) {
   const char* fn = "mq_calib_norm";
   MQ_REQUIRE(rows >= 0 && cols > 0, "%s: bad shape", fn);
   if (rows == 0) return MQ_OK;
   MQ_REQUIRE(x && y_out && weight && in_min && in_max && out_min && out_max, "%s: null pointer", fn);
   MQ_REQUIRE(!delta || h_out, "%s: a residual needs h_out", fn);
+  MQ_REQUIRE((delta_min == nullptr) == (delta_max == nullptr) && (!delta_min || delta), "%s: the residual's statistic needs both slots and a residual", fn);
   if (cols % 4 != 0 || cols > 8192 || !aligned(x, 16) || !aligned(y_out, 16) || !aligned(weight, 16) || (delta && !aligned(delta, 16)) ||
       (h_out && !aligned(h_out, 16)) || (bias && !aligned(bias, 16))) {
     set_error("%s: not served: cols %% 4 == 0, cols <= 8192, 16-byte aligned pointers", fn);
@@ -798,8 +811,8 @@ int mq_calib_norm(const float* x, const float* delta, float* h_out, float* y_out
   const unsigned grid = (unsigned)(rows < 8192 ? rows : 8192);
 #define MQ_CN(V)                                                                                                                     \
   do {                                                                                                                               \
-    if (layernorm) calib_norm_kernel<V, true><<<grid, 256, 0, st>>>(x, delta, h_out, y_out, rows, (int)cols, weight, bias, eps, in_min, in_max, out_min, out_max); \
-    else calib_norm_kernel<V, false><<<grid, 256, 0, st>>>(x, delta, h_out, y_out, rows, (int)cols, weight, bias, eps, in_min, in_max, out_min, out_max);      \
+    if (layernorm) calib_norm_kernel<V, true><<<grid, 256, 0, st>>>(x, delta, h_out, y_out, rows, (int)cols, weight, bias, eps, in_min, in_max, out_min, out_max, delta_min, delta_max); \
+    else calib_norm_kernel<V, false><<<grid, 256, 0, st>>>(x, delta, h_out, y_out, rows, (int)cols, weight, bias, eps, in_min, in_max, out_min, out_max, delta_min, delta_max);      \
   } while (0)
   if (cols <= 1024) MQ_CN(1);
   else if (cols <= 2048) MQ_CN(2);

@@ -429,7 +429,8 @@ class MLP(nn.Module):
             # calibration: act(w1(x)) * w3(x) and the four statistics around it (w1.output = act.input, act.output, w3.output, w2.input)
             # in ONE pass; the linears' hooks skip those fields, the activation module is not run
             col, (n1, n3, na, n2) = calib
-            skips = ((self.w1, ("output",)), (self.w3, ("output",)), (self.w2, ("input",)))
+            w2_fields = ("input", "output") if self.__dict__.get("_mq_calib_w2_out_taken") else ("input",)      # (DecoderLayer: the next norm pass takes it)
+            skips = ((self.w1, ("output",)), (self.w3, ("output",)), (self.w2, w2_fields))
             for m, f in skips:
                 m.__dict__["_mq_calib_skip"] = (col, f)
             try:
@@ -440,6 +441,8 @@ class MLP(nn.Module):
                     m.__dict__.pop("_mq_calib_skip", None)
                 col._update(n1, "output", a)
                 col._update(n3, "output", b)
+                if len(w2_fields) == 2:
+                    self.w2.__dict__["_mq_calib_skip"] = (col, ("output",))
                 return self.w2(self.act_fn(a) * b)
             finally:
                 for m, _ in skips:
@@ -460,19 +463,47 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = _make_norm(s)
         self.post_attention_layernorm = _make_norm(s)
 
-    _mq_calibration_layer_parts = ("input_layernorm", "post_attention_layernorm")
+    _mq_calibration_layer_parts = ("input_layernorm", "post_attention_layernorm", "self_attn.o_proj", "mlp.w2")
 
-    def forward(self, x, cos, sin, mask, cache=None, pos: int = 0):
-        calib = self.__dict__.get("_mq_calib_layer")                # (collector, names of the two norms) while ONE calibration pass runs
+    def forward(self, x, cos, sin, mask, cache=None, pos: int = 0, pending=None, defer: bool = False):
+        """pending = (tensor, slot key): a residual branch the previous layer left unadded (calibration only, see below); defer: this
+        layer may do the same -- it then returns (h, (mlp output, slot key)) instead of h + mlp output."""
+        calib = self.__dict__.get("_mq_calib_layer")                # (collector, names of the two norms, o_proj, w2) while ONE calibration pass runs
         if (calib is not None and not torch.is_grad_enabled() and calib[0].can_fuse_layer(x)
                 and calib[0].norm_is_plain(self.input_layernorm) and calib[0].norm_is_plain(self.post_attention_layernorm)):
-            # calibration: each norm with its input and output statistics in one pass, the attention branch's residual add inside the
-            # second one (h = x + attn is written for the last add); the norm modules are not run
-            col, (n_in, n_post) = calib
-            _, y = col.norm_pass(n_in, self.input_layernorm, x)
-            attn = self.self_attn(y, cos, sin, mask, cache, pos)
-            h, y = col.norm_pass(n_post, self.post_attention_layernorm, x, attn if attn.is_contiguous() else attn.contiguous())
-            return h + self.mlp(y)
+            # calibration: each norm with its input and output statistics in one pass, the residual add in front of it inside (h = x +
+            # branch is written for the next add) together with the branch's own statistic (o_proj's / w2's output hook skips it); the
+            # norm modules are not run.  The layer's last add is left to the next layer's first pass (defer).
+            col, (n_in, n_post, n_o, n_w2) = calib
+            if pending is not None and pending[2] is col:
+                x, y = col.norm_pass(n_in, self.input_layernorm, x, pending[0], pending[1])
+            elif pending is not None:
+                pending[2]._update(pending[1][0], pending[1][1], pending[0])
+                x = x + pending[0]
+                _, y = col.norm_pass(n_in, self.input_layernorm, x)
+            else:
+                _, y = col.norm_pass(n_in, self.input_layernorm, x)
+            o = self.self_attn.o_proj
+            o.__dict__["_mq_calib_skip"] = (col, ("output",))
+            try:
+                attn = self.self_attn(y, cos, sin, mask, cache, pos)
+            finally:
+                o.__dict__.pop("_mq_calib_skip", None)
+            h, y = col.norm_pass(n_post, self.post_attention_layernorm, x, attn if attn.is_contiguous() else attn.contiguous(), (n_o, "output"))
+            if not defer:
+                return h + self.mlp(y)
+            self.mlp.__dict__["_mq_calib_w2_out_taken"] = True
+            try:
+                m = self.mlp(y)
+            finally:
+                self.mlp.__dict__.pop("_mq_calib_w2_out_taken", None)
+            if not m.is_contiguous() or m.dtype != torch.float32:
+                col._update(n_w2, "output", m)
+                return h + m
+            return h, (m, (n_w2, "output"), col)
+        if pending is not None:                                     # (a deferred add meets a layer on the plain path: its statistic, then the add)
+            pending[2]._update(pending[1][0], pending[1][1], pending[0])
+            x = x + pending[0]
         x = x + self.self_attn(self.input_layernorm(x), cos, sin, mask, cache, pos)
         return x + self.mlp(self.post_attention_layernorm(x))
 
@@ -488,6 +519,8 @@ class ImageCache:
 class LlamaForCausalLM(nn.Module):
     """embed -> layers -> norm -> lm_head.  `layers`, final `norm` and `lm_head` carry the names the surgery rules skip
     (qmodule.py:843)."""
+
+    _mq_calibration_layer_parts = ("norm",)        # calibration.ActRangeCollector.attach(): the final norm takes the last deferred add (forward)
 
     def __init__(self, shape: LlamaShape, std: float = 0.02):
         super().__init__()
@@ -543,8 +576,22 @@ class LlamaForCausalLM(nn.Module):
         if S > 1:
             mask = torch.full((S, pos + S), float("-inf"), device=x.device, dtype=x.dtype).triu(pos + 1)
             mask._mq_causal = True          # lets a fused attention skip the masked key blocks instead of reading the mask
+        pend = None                 # calibration: a layer's last residual add, left to the next norm pass (DecoderLayer.forward)
         for i, layer in enumerate(self.layers):
-            x = layer(x, cos, sin, mask, None if cache is None else cache[i], pos)
+            c = None if cache is None else cache[i]
+            if pend is not None or layer.__dict__.get("_mq_calib_layer") is not None:
+                out = layer(x, cos, sin, mask, c, pos, pending=pend, defer=True)
+                x, pend = out if isinstance(out, tuple) else (out, None)
+            else:
+                x = layer(x, cos, sin, mask, c, pos)
+        if pend is not None:
+            calib = self.__dict__.get("_mq_calib_layer")            # (collector, ("norm",)): the final norm takes the last add like a layer's
+            if (calib is not None and calib[0] is pend[2] and not last_logits_only and calib[0].can_fuse_layer(x)
+                    and calib[0].norm_is_plain(self.norm)):
+                _, y = calib[0].norm_pass(calib[1][0], self.norm, x, pend[0], pend[1])
+                return self.lm_head(y)
+            pend[2]._update(pend[1][0], pend[1][1], pend[0])
+            x = x + pend[0]
         if last_logits_only:
             from .quantization import qmodule as Q
             x = Q._materialize(x)[:, -1:].contiguous()

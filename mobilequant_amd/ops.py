@@ -137,9 +137,11 @@ def calib_attention_probs_(raw: torch.Tensor, mask: Optional[torch.Tensor], sqrt
 
 
 def calib_norm_(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, layernorm: bool,
-                in_min: torch.Tensor, in_max: torch.Tensor, out_min: torch.Tensor, out_max: torch.Tensor):
+                in_min: torch.Tensor, in_max: torch.Tensor, out_min: torch.Tensor, out_max: torch.Tensor,
+                delta_min: Optional[torch.Tensor] = None, delta_max: Optional[torch.Tensor] = None):
     """Calibration-mode norm (mq_calib_norm): h = x (+ delta), y = RMSNorm / LayerNorm(h) with the running [min, max] of h (the module's
-    input hook) and of y (its output hook) taken in the same pass.  Returns (h, y); h is x itself without a delta."""
+    input hook) and of y (its output hook) taken in the same pass; delta_min / delta_max: also that of delta itself.  Returns (h, y); h is x
+    itself without a delta."""
     x = _dev(x, "x")
     if x.dtype != torch.float32 or not x.is_contiguous() or (delta is not None and (delta.dtype != torch.float32 or not delta.is_contiguous()
                                                                                         or delta.shape != x.shape)):
@@ -150,10 +152,11 @@ def calib_norm_(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Te
     h = torch.empty_like(x) if delta is not None else None
     w = _f32(weight, "weight").contiguous()
     b = _f32(bias, "bias").contiguous() if bias is not None else None
-    with _on(x, delta, w, b, y, h, in_min, in_max, out_min, out_max):
+    with _on(x, delta, w, b, y, h, in_min, in_max, out_min, out_max, delta_min, delta_max):
         _lib.call("mq_calib_norm", x.data_ptr(), delta.data_ptr() if delta is not None else None, h.data_ptr() if h is not None else None,
                   y.data_ptr(), rows, cols, w.data_ptr(), b.data_ptr() if b is not None else None, float(eps), int(bool(layernorm)),
-                  in_min.data_ptr(), in_max.data_ptr(), out_min.data_ptr(), out_max.data_ptr(), _stream())
+                  in_min.data_ptr(), in_max.data_ptr(), out_min.data_ptr(), out_max.data_ptr(),
+                  delta_min.data_ptr() if delta_min is not None else None, delta_max.data_ptr() if delta_max is not None else None, _stream())
     return (h if h is not None else x), y
 
 

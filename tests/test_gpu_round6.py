@@ -428,7 +428,7 @@ def test_calibration_layer_passes_give_the_act_dict_of_the_plain_hooks(dev, fami
         col = ActRangeCollector(model, per_channel=False)
         col.fuse_layer_statistics = fuse
         col.attach()
-        assert (len(col._layers) == 3 * shape.layers) == fuse           # decoder layer (norms), MLP (gated product), attention (RoPE)
+        assert (len(col._layers) == 3 * shape.layers + 1) == fuse       # decoder layer (norms), MLP (gated product), attention (RoPE); the model (final norm)
         with torch.no_grad():
             for s in samples:
                 logits[fuse] = model(s)
