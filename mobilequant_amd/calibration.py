@@ -81,7 +81,7 @@ class ActRangeCollector:
         self._mirror: Dict[int, int] = {}              # slot -> the slot whose statistic it mirrors (verified groups)
         self._mirror_pending: List[List[int]] = []     # declared groups, not yet compared
         groups = getattr(model, "calibration_alias_groups", None)
-        if not per_channel and callable(groups):
+        if callable(groups):                                        # (per-channel mode: a group survives the check only if its members are one tensor)
             for grp in groups():
                 idx = [self.slots[k] for k in grp if k in self.slots]
                 if len(idx) == len(grp) and len(idx) > 1:
@@ -228,6 +228,14 @@ class ActRangeCollector:
         pending, self._mirror_pending = self._mirror_pending, []
         if not self.mirror_declared_aliases:
             return
+        if self.per_channel:
+            for idx in pending:
+                r = self._pc[idx[0]]
+                if r is not None and all(self._pc[i] is not None and self._pc[i][0].shape == r[0].shape and torch.equal(self._pc[i][0], r[0])
+                                         and torch.equal(self._pc[i][1], r[1]) for i in idx[1:]):
+                    for i in idx[1:]:
+                        self._mirror[i] = idx[0]
+            return
         mn, mx = self._mn.tolist(), self._mx.tolist()
         for idx in pending:
             root = idx[0]
@@ -237,7 +245,12 @@ class ActRangeCollector:
 
     def _resolve(self) -> None:
         """Mirrored slots read the statistic of the slot that took their reductions."""
-        if self.per_channel or not self._mirror:
+        if not self._mirror:
+            return
+        if self.per_channel:
+            for i, j in self._mirror.items():
+                if self._pc[j] is not None:
+                    self._pc[i] = (self._pc[j][0].clone(), self._pc[j][1].clone())
             return
         ii = torch.tensor(list(self._mirror.keys()), device=self._mn.device)
         jj = torch.tensor(list(self._mirror.values()), device=self._mn.device)
@@ -309,6 +322,7 @@ class ActRangeCollector:
     # -- merge -------------------------------------------------------------------------------------
     def _layout(self) -> Dict[int, int]:
         """Per-channel mode: {slot: channels} of what THIS rank observed."""
+        self._resolve()
         return {i: int(s[0].numel()) for i, s in enumerate(self._pc) if s is not None}
 
     @staticmethod
@@ -391,6 +405,7 @@ class ActRangeCollector:
         whole run) or ``{module: {field: Tensor[2, C]}}`` on the CPU (per-channel)."""
         out: Dict[str, dict] = {}
         if self.per_channel:
+            self._resolve()
             for (name, field), i in self.slots.items():
                 if self._pc[i] is not None:
                     out.setdefault(name, {})[field] = torch.stack(self._pc[i], dim=0).cpu()
@@ -406,6 +421,7 @@ class ActRangeCollector:
         """SmoothQuant statistics: per-channel absmax keyed ``"<module>_<field>"`` for Linear / Norm
         leaves (generate_act_scale_shift.py:47-71); absmax = max(|min|, |max|) of the same running stats."""
         assert self.per_channel, "act_scales needs per-channel statistics"
+        self._resolve()
         out = {}
         mods = dict(self.model.named_modules())
         for (name, field), i in self.slots.items():

@@ -533,3 +533,36 @@ def test_calibration_with_the_kept_causal_zeros_is_the_calibration_without(dev):
     finally:
         ActRangeCollector.keep_causal_zeros = True
     assert a == b
+
+
+@pytest.mark.gpu
+def test_per_channel_calibration_mirrors_the_groups_that_are_one_tensor(dev):
+    """Per-channel mode (act ranges per feature, SmoothQuant's absmax): the declared alias groups whose members are ONE tensor are
+    mirrored after the first pass as in per-tensor mode; the value-only group (pv_bmm.output / o_proj.input: other channel counts) fails
+    the check and keeps its hooks.  Same act_dict and act_scales as without mirroring."""
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import ActRangeCollector
+    shape = llama.LlamaShape.tinyllama(layers=2, max_pos=128, vocab=512)
+    model = llama.LlamaForCausalLM(shape)
+    model.reset_parameters(seed=3, std=0.05)
+    model = model.to(dev).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    samples = [torch.randint(0, shape.vocab, (1, 128), generator=g).to(dev) for _ in range(3)]
+    got = {}
+    for mirror in (True, False):
+        col = ActRangeCollector(model, per_channel=True)
+        col.mirror_declared_aliases = mirror
+        col.attach()
+        with torch.no_grad():
+            for s in samples:
+                model(s)
+        col.detach()
+        got[mirror] = (col.act_dict(), col.act_scales(), len(col._mirror), col.bytes_aliased)
+    assert got[True][2] == 6 * shape.layers + 1 and got[False][2] == 0 and got[True][3] > 0
+    a, b = got[True][0], got[False][0]
+    assert a.keys() == b.keys()
+    for name in a:
+        assert a[name].keys() == b[name].keys()
+        for f in a[name]:
+            assert torch.equal(a[name][f], b[name][f]), (name, f)
+    assert got[True][1].keys() == got[False][1].keys() and all(torch.equal(got[True][1][k], got[False][1][k]) for k in got[True][1])
