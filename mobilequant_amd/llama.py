@@ -579,10 +579,14 @@ class LlamaForCausalLM(nn.Module):
         pend = None                 # calibration: a layer's last residual add, left to the next norm pass (DecoderLayer.forward)
         for i, layer in enumerate(self.layers):
             c = None if cache is None else cache[i]
-            if pend is not None or layer.__dict__.get("_mq_calib_layer") is not None:
+            own = "forward" not in layer.__dict__ and type(layer).forward is DecoderLayer.forward      # (not a fused / patched layer)
+            if own and (pend is not None or layer.__dict__.get("_mq_calib_layer") is not None):
                 out = layer(x, cos, sin, mask, c, pos, pending=pend, defer=True)
                 x, pend = out if isinstance(out, tuple) else (out, None)
             else:
+                if pend is not None:                                # a deferred add in front of a layer that does not take one
+                    pend[2]._update(pend[1][0], pend[1][1], pend[0])
+                    x, pend = x + pend[0], None
                 x = layer(x, cos, sin, mask, c, pos)
         if pend is not None:
             calib = self.__dict__.get("_mq_calib_layer")            # (collector, ("norm",)): the final norm takes the last add like a layer's
