@@ -99,8 +99,16 @@ class ActRangeCollector:
         i = self.slots[(name, field)]
         t = t.detach()
         if i in self._mirror:
-            self.bytes_aliased += t.numel() * t.element_size()
-            return
+            if i not in self._forced:
+                self.bytes_aliased += t.numel() * t.element_size()
+                return
+            # a fused pass used to vouch for this slot and skip its hook; this time the hook ran: the slot takes over the mirrored history
+            # (equal to its own so far) and goes on alone
+            j = self._mirror.pop(i)
+            self._forced.discard(i)
+            if not self.per_channel:
+                self._mn[i:i + 1].copy_(self._mn[j:j + 1])
+                self._mx[i:i + 1].copy_(self._mx[j:j + 1])
         self.bytes_seen += t.numel() * t.element_size()
         if t.device != self.device:
             raise RuntimeError(f"calibration of {name}.{field}: tensor on {t.device}, statistics on {self.device} -- run one "
@@ -214,6 +222,16 @@ class ActRangeCollector:
         for k in sl:
             stats += [self._mn[k:k + 1], self._mx[k:k + 1]]
         return ops.calib_rope_(q_lin, k_lin, heads, kv_heads, head_dim, cos, sin, stats)
+
+    def mirror_values(self, name: str, field: str, src_name: str, src_field: str) -> bool:
+        """The caller vouches that (name, field)'s tensor holds exactly the values of (src_name, src_field)'s in this pass and skips the
+        hook: the slot mirrors the source from now on (per-tensor mode).  False: keep the hook."""
+        if self.per_channel or (name, field) not in self.slots or (src_name, src_field) not in self.slots:
+            return False
+        k = self.slots[(name, field)]
+        self._mirror[k] = self.slots[(src_name, src_field)]
+        self._forced.add(k)
+        return True
 
     def can_fuse_attention(self, raw_shape, dtype, device, mask) -> bool:
         return (self.fuse_attention_statistics and not self.per_channel and dtype == torch.float32 and device == self.device

@@ -96,7 +96,7 @@ def apply_rope(x, cos, sin):
 
 class Attention(nn.Module):
     _mq_calibration_aware = True        # forward() hands its score chain to an attached ActRangeCollector (calibration.py)
-    _mq_calibration_layer_parts = ("q_proj", "k_proj", "qk_bmm")      # ... and RoPE with the four statistics around it (see forward)
+    _mq_calibration_layer_parts = ("q_proj", "k_proj", "qk_bmm", "v_proj")      # ... and RoPE with the four statistics around it (see forward)
 
     def __init__(self, s: LlamaShape):
         super().__init__()
@@ -118,7 +118,7 @@ class Attention(nn.Module):
                 and cos.shape[-1] % 8 == 0 and cos.dtype == torch.float32):
             # calibration: RoPE on q and k in ONE launch that also takes the statistics of q_proj.output, k_proj.output, qk_bmm.input and
             # qk_bmm.input2 (the bits of apply_rope; the linears' and the matmul's hooks skip those fields)
-            col, (nq, nk, nqk) = cl
+            col, (nq, nk, nqk, _) = cl
             for m in (self.q_proj, self.k_proj):
                 m.__dict__["_mq_calib_skip"] = (col, ("output",))
             try:
@@ -161,7 +161,9 @@ class Attention(nn.Module):
             # the raw scores into probabilities, in place (calibration.ActRangeCollector.attention_probs); the module hooks skip them
             # (owner, fields): only the OWNING collector's hooks skip them -- another collector on the same model keeps its plain hooks)
             taken = ("output", "input", "input2") if (rope_taken and cl[0] is calib[0]) else ("output",)
-            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = (calib[0], taken), (calib[0], ("input",))
+            # (rope_taken implies cache is None: the repeated v holds exactly v_proj's output values -- pv_bmm.input2 mirrors that slot)
+            pv_taken = ("input", "input2") if (rope_taken and cl[0] is calib[0] and cl[0].mirror_values(calib[2], "input2", cl[1][3], "output")) else ("input",)
+            self.qk_bmm.__dict__["_mq_calib_skip"], self.pv_bmm.__dict__["_mq_calib_skip"] = (calib[0], taken), (calib[0], pv_taken)
             try:
                 raw = self.qk_bmm(q, k.transpose(2, 3))
                 att = calib[0].attention_probs(calib[1], calib[2], raw if raw.is_contiguous() else raw.contiguous(), mask, math.sqrt(s.head_dim))
