@@ -40,7 +40,7 @@ LOG_CAPTIONS = {
     "bench_qmatmul.log": "`tools/bench_qmatmul.py`: mq_qmatmul step by step through round 6 (rows per workgroup, what-if builds, the row-panel kernel, branch-free loads, buffer stores, loop orders rotated against HBM channel camping); `tools/hbm_read_probe` ceilings",
     "fuzz_full.log": "the random-shape fuzzers at full length on the final tree (`tests/fuzz_*.py`, `tests/stress_qmatmul_race.py`): every output against the oracles, 0 mismatches",
     "bench_qmatmul_final.log": "`tools/bench_qmatmul.py` and `tools/bench_calib_probs.py` on the final tree",
-    "calibration_trace_after.summary.txt": "the same trace on the final tree (alias groups, `mq_calib_norm` / `mq_calib_gated` / `mq_calib_rope`): 333 -> 205 ms of kernels for the same passes",
+    "calibration_trace_after.summary.txt": "the same trace on the final tree (alias groups, `mq_calib_norm` / `mq_calib_gated` / `mq_calib_rope`): 333 -> 200 ms of kernels for the same passes",
     "calibration_trace.summary.txt": "`rocprofv3 --kernel-trace` of `bench.py --workload calibration --calib-samples 16 --calib-stub-gemm`: kernels of the calibration pass by share of GPU time, BEFORE the round-6 calibration changes",
     "fuzz_and_per_sequence_ppl.log": "`pytest tests/test_gpu_fuzz.py tests/test_gpu_round5.py -k 'fuzz or perplexity' -s`: the fuzzer slices inside `-m gpu` and the per-sequence perplexity differences",
     "bench_wall.log": "wall time of `python bench.py --steps 20 --warmup 5` (round 5: 173 s)",
