@@ -468,8 +468,8 @@ class DecoderLayer(nn.Module):
     _mq_calibration_layer_parts = ("input_layernorm", "post_attention_layernorm", "self_attn.o_proj", "mlp.w2")
 
     def forward(self, x, cos, sin, mask, cache=None, pos: int = 0, pending=None, defer: bool = False):
-        """pending = (tensor, slot key): a residual branch the previous layer left unadded (calibration only, see below); defer: this
-        layer may do the same -- it then returns (h, (mlp output, slot key)) instead of h + mlp output."""
+        """pending = (tensor, slot key, collector): a residual branch the previous layer left unadded (calibration only, see below);
+        defer: this layer may do the same -- it then returns (h, (mlp output, slot key, collector)) instead of h + mlp output."""
         calib = self.__dict__.get("_mq_calib_layer")                # (collector, names of the two norms, o_proj, w2) while ONE calibration pass runs
         if (calib is not None and not torch.is_grad_enabled() and calib[0].can_fuse_layer(x)
                 and calib[0].norm_is_plain(self.input_layernorm) and calib[0].norm_is_plain(self.post_attention_layernorm)):
