@@ -105,3 +105,29 @@ def test_other_model_families_equal_the_reference_hf_model(tag):
     names = dict(m.named_modules())
     assert isinstance(names["layers.0.input_layernorm"], torch.nn.LayerNorm) == (tag == "stablelm")
     assert (names["layers.0.self_attn.q_proj"].bias is not None) == (tag == "stablelm") and names["layers.0.self_attn.o_proj"].bias is None
+
+
+def test_declared_calibration_alias_groups_name_real_slots():
+    """LlamaForCausalLM.calibration_alias_groups() (round 6: tensors hooked under several names are reduced once) must name hooked
+    (module, field) pairs of the graph as named_modules() spells them -- a renamed submodule would silently switch the mirroring off --
+    and so must the parts the one-pass calibration kernels stand for (_mq_calibration_layer_parts)."""
+    import torch
+    from mobilequant_amd import llama
+    from mobilequant_amd.calibration import ActRangeCollector
+    for fam in ("tinyllama", "stablelm_2_1_6b", "gemma_2b"):
+        shape = getattr(llama.LlamaShape, fam)(layers=2, max_pos=32, vocab=64)
+        model = llama.LlamaForCausalLM(shape)
+        col = ActRangeCollector(model, per_channel=False, device="cpu")
+        groups = model.calibration_alias_groups()
+        assert len(groups) == 4 * shape.layers + 1
+        for grp in groups:
+            assert len(grp) >= 2 and all(k in col.slots for k in grp), (fam, grp)
+        assert len(col._mirror_pending) == len(groups)
+        names = dict(model.named_modules())
+        for name, m in names.items():
+            for part in getattr(m, "_mq_calibration_layer_parts", ()):
+                q = m
+                for piece in part.split("."):
+                    q = getattr(q, piece)
+                key = next(n for n, mm in names.items() if mm is q)
+                assert (key, "input") in col.slots and (key, "output") in col.slots, (fam, name, part)
