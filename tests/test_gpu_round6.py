@@ -463,7 +463,7 @@ def test_calibration_layer_passes_give_the_act_dict_of_the_plain_hooks(dev, fami
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geom", [(2, 37, 32, 4, 64, 64), (1, 50, 8, 1, 256, 256), (1, 29, 32, 32, 64, 16)])
+@pytest.mark.parametrize("geom", [(2, 37, 32, 4, 64, 64), (1, 50, 8, 1, 256, 256), (1, 29, 32, 32, 64, 16), (2, 21, 6, 2, 80, 32)])
 def test_calib_rope_pass_is_apply_rope_bit_for_bit(dev, geom):
     """ops.calib_rope_ (mq_calib_rope): the rotated q / k of llama.apply_rope bit for bit -- full and partial rotary, GQA -- in
     [B, heads, S, D] order, and the four statistics exactly those of the projections' outputs and of the rotated tensors."""
