@@ -40,6 +40,7 @@ LOG_CAPTIONS = {
     "bench_qmatmul.log": "`tools/bench_qmatmul.py`: mq_qmatmul step by step through round 6 (rows per workgroup, what-if builds, the row-panel kernel, branch-free loads, buffer stores, loop orders rotated against HBM channel camping); `tools/hbm_read_probe` ceilings",
     "fuzz_full.log": "the random-shape fuzzers at full length on the final tree (`tests/fuzz_*.py`, `tests/stress_qmatmul_race.py`): every output against the oracles, 0 mismatches",
     "bench_qmatmul_final.log": "`tools/bench_qmatmul.py` and `tools/bench_calib_probs.py` on the final tree",
+    "calibration_full_size_check.log": "`tools/r06_calib_full_size_check.py`: the act_dict with every round-6 calibration change on against the plain hooks, full-width 2-layer graphs of three families: worst relative deviation 1.8e-6 ... 2.6e-6",
     "calibration512_stub_gemm.json": "`python bench.py --workload calibration --calib-samples 512 --calib-stub-gemm`: BASELINE.json configs[4] at its full size on one GPU, final tree (171 samples/s; round 5: 81)",
     "calibration64.json": "`python bench.py --workload calibration --calib-samples 64`: the same graph with the fp32 library GEMMs in (22.5 samples/s)",
     "calibration64_per_channel_stub_gemm.json": "`... --calib-samples 64 --calib-stub-gemm --per-channel`: per-channel statistics (38 samples/s: the one-pass layer kernels are per-tensor only)",
