@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated, mq_calib_rope, mq_calib_attention_probs_causal.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
+#define MQ_VERSION 301 /* 0.3.1: + mq_calib_norm, mq_calib_gated, mq_calib_rope(_qkv), mq_calib_attention_probs_causal.  0.3.0: ABI BREAK -- argument structs grew at their tails (mq_decode_gemv_args in 0.3.0, mq_attention_args in 0.2.x): a caller MUST compare mq_version() / 100 with MQ_VERSION / 100 of the header it was built against (mobilequant_amd/_lib.py does) before passing a struct; + mq_decode_attention_oproj.  0.2.1: + mq_qmatmul, mq_calib_attention_probs (0.2.0: chan_scale in mq_quantize / mq_quantize_tiled; tuning knobs moved to mobilequant_amd_tuning.h) */
 
 typedef void* mq_stream_t;
 
@@ -666,6 +666,11 @@ int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, in
  * products and a rounded sum per element: the bits of the module chain. */
 int mq_calib_rope(const float* q_in, const float* k_in, float* q_out, float* k_out, int64_t batch, int64_t seq, int heads, int kv_heads, int head_dim,
                   int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream);
+/* mq_calib_rope_qkv: the same with v carried along (no rotation) and repeat_kv (hf_model.py:509-510) inside: k_out and v_out are
+ * [batch, heads, seq, head_dim] with every kv head written heads / kv_heads times.  stats[12] = {min, max} of q_in, q_out, k_in, k_out,
+ * v_in and (v_out: both NULL or both given -- v_out holds v_in's values).  */
+int mq_calib_rope_qkv(const float* q_in, const float* k_in, const float* v_in, float* q_out, float* k_out, float* v_out, int64_t batch, int64_t seq, int heads,
+                      int kv_heads, int head_dim, int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream);
 
 /* ---- QMatMul as a module: quantized batched matmul of two activations ------------------------ */
 /* Replaces QMatMul.forward (mobilellm/quantization/qmodule.py:453-466): out = Qout(matmul(Q1(x1), Q2(x2))) -- two fake-quant passes

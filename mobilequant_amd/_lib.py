@@ -144,6 +144,7 @@ _SIGNATURES = {
     "mq_calib_norm": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P, _P, ctypes.c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mq_calib_gated": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P]),
     "mq_calib_rope": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "mq_calib_rope_qkv": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "mq_qmatmul": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int, POINTER(MqGrid), POINTER(MqGrid), POINTER(MqGrid), _P]),
     "mq_gemm_set_variant": (c_int, [c_int]),
     "mq_gemm_variant_name": (c_char_p, [c_int]),

@@ -223,6 +223,16 @@ class ActRangeCollector:
             stats += [self._mn[k:k + 1], self._mx[k:k + 1]]
         return ops.calib_rope_(q_lin, k_lin, heads, kv_heads, head_dim, cos, sin, stats)
 
+    def rope_qkv_pass(self, q_name: str, k_name: str, v_name: str, qk_name: str, q_lin, k_lin, v_lin, heads: int, kv_heads: int, head_dim: int, cos, sin):
+        """rope_pass with v carried along and repeat_kv inside: (q, k, v) all [B, heads, S, D]; + the statistic of v_proj.output."""
+        sl = [self.slots[(q_name, "output")], self.slots[(qk_name, "input")], self.slots[(k_name, "output")], self.slots[(qk_name, "input2")],
+              self.slots[(v_name, "output")]]
+        self.bytes_fused += (2 * q_lin.numel() + 2 * k_lin.numel() + v_lin.numel()) * q_lin.element_size()
+        stats = []
+        for k in sl:
+            stats += [self._mn[k:k + 1], self._mx[k:k + 1]]
+        return ops.calib_rope_qkv_(q_lin, k_lin, v_lin, heads, kv_heads, head_dim, cos, sin, stats)
+
     def mirror_values(self, name: str, field: str, src_name: str, src_field: str) -> bool:
         """The caller vouches that (name, field)'s tensor holds exactly the values of (src_name, src_field)'s in this pass and skips the
         hook: the slot mirrors the source from now on (per-tensor mode).  False: keep the hook."""

@@ -614,24 +614,27 @@ __global__ void __launch_bounds__(256) calib_gated_kernel(const float* __restric
 // products and a rounded sum, as torch's three launches: the same bits.  One thread per 4 consecutive d; the partner quad is a second
 // (cached) load.  Segment 0 = q (heads[0] heads), segment 1 = k (heads[1]).
 struct CalibRopeArgs {
-  const float* x[2];
-  float* out[2];
-  int heads[2];
-  long long quads[2];            // B * S * heads * D / 4
+  const float* x[3];
+  float* out[3];
+  int heads[3];                  // heads of the INPUT of a segment (q: heads, k / v: kv_heads)
+  int rep[3];                    // every input head is written to `rep` consecutive output heads (repeat_kv, hf_model.py:509-510)
+  int rotate[3];                 // 0: the segment passes through (v)
+  int nseg;
+  long long quads[3];            // B * S * heads * D / 4
   int S, D, rot, dq_shift;       // dq_shift: log2(D / 4) or -1
   const float* cos;              // [S, rot]
   const float* sin;
-  float* st[8];                  // {min, max} of x[0], out[0], x[1], out[1]
+  float* st[12];                 // {min, max} of x[s], out[s] per segment (an out pair may be NULL)
 };
 __global__ void __launch_bounds__(256) calib_rope_kernel(const CalibRopeArgs a) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   const float pinf = __int_as_float(0x7f800000), ninf = __int_as_float(0xff800000);
-  float lo[4] = {pinf, pinf, pinf, pinf}, hi[4] = {ninf, ninf, ninf, ninf};
+  float lo[6] = {pinf, pinf, pinf, pinf, pinf, pinf}, hi[6] = {ninf, ninf, ninf, ninf, ninf, ninf};
   auto upd = [&](int k, const v4f v) {
     lo[k] = min_p(min_p(lo[k], v[0]), min_p(v[1], min_p(v[2], v[3])));
     hi[k] = max_p(max_p(hi[k], v[0]), max_p(v[1], max_p(v[2], v[3])));
   };
-  // a workgroup per (batch, position) row of both projections; thread -> (head slot threadIdx.x / dq, quad threadIdx.x % dq) with dq = D / 4
+  // a workgroup per (batch, position) row of the projections; thread -> (head slot threadIdx.x / dq, quad threadIdx.x % dq) with dq = D / 4
   // a launch constant the host passes as a shift when it is a power of two (no integer division per quad: 14 -> 9 us)
   const int dq = a.D >> 2, half = a.rot >> 1;
   const int tq = a.dq_shift >= 0 ? (int)(threadIdx.x & (dq - 1)) : (int)(threadIdx.x % dq);
@@ -648,8 +651,9 @@ __global__ void __launch_bounds__(256) calib_rope_kernel(const CalibRopeArgs a) 
       sn = *reinterpret_cast<const v4f*>(a.sin + (long long)s_ * a.rot + d);
     }
 #pragma unroll
-    for (int seg = 0; seg < 2; ++seg) {
-      const int H = a.heads[seg];
+    for (int seg = 0; seg < 3; ++seg) {
+      if (seg >= a.nseg) break;
+      const int H = a.heads[seg], rep = a.rep[seg], HO = H * rep;
       const v4f* x = reinterpret_cast<const v4f*>(a.x[seg]) + bs * H * dq;
       for (int h = th; h < H; h += hstep) {
         if (th >= hstep) break;                                     // (256 % dq != 0: the last partial head slot idles)
@@ -657,20 +661,21 @@ __global__ void __launch_bounds__(256) calib_rope_kernel(const CalibRopeArgs a) 
         const v4f v = x[i];
         upd(2 * seg, v);
         v4f o = v;
-        if (d < a.rot) {
+        if (a.rotate[seg] && d < a.rot) {
           v4f p = x[d < half ? i + (half >> 2) : i - (half >> 2)];
           if (d < half) p = -p;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(v[e], c[e]), __fmul_rn(p[e], sn[e]));
         }
         upd(2 * seg + 1, o);
-        reinterpret_cast<v4f*>(a.out[seg])[(((b * H + h) * a.S + s_) * (long long)a.D + d) >> 2] = o;
+        for (int j = 0; j < rep; ++j)
+          reinterpret_cast<v4f*>(a.out[seg])[(((b * HO + h * rep + j) * a.S + s_) * (long long)a.D + d) >> 2] = o;
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    block_commit(lo[k], hi[k], a.st[2 * k], a.st[2 * k + 1]);
+  for (int k = 0; k < 6; ++k) {
+    if (k < 2 * a.nseg && a.st[2 * k]) block_commit(lo[k], hi[k], a.st[2 * k], a.st[2 * k + 1]);
     __syncthreads();
   }
 }
@@ -855,27 +860,34 @@ int mq_calib_gated(const float* a, const float* b, float* out, int64_t numel, in
 }
 
 
-int mq_calib_rope(const float* q_in, const float* k_in, float* q_out, float* k_out, int64_t batch, int64_t seq, int heads, int kv_heads, int head_dim,
-                  int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream) {
-  const char* fn = "mq_calib_rope";
-  MQ_REQUIRE(batch >= 0 && seq >= 0 && heads > 0 && kv_heads > 0 && head_dim > 0 && rot_dim > 0, "%s: bad shape", fn);
+static int launch_calib_rope(const char* fn, const float* const* in, float* const* out, int nseg, int64_t batch, int64_t seq, int heads, int kv_heads,
+                             int head_dim, int rot_dim, int expand, const float* cos, const float* sin, float* const* stats, mq_stream_t stream) {
+  MQ_REQUIRE(batch >= 0 && seq >= 0 && heads > 0 && kv_heads > 0 && head_dim > 0 && rot_dim > 0 && heads % kv_heads == 0, "%s: bad shape", fn);
   if (batch == 0 || seq == 0) return MQ_OK;
-  MQ_REQUIRE(q_in && k_in && q_out && k_out && cos && sin && stats, "%s: null pointer", fn);
-  if (head_dim % 4 != 0 || head_dim > 1024 || rot_dim > head_dim || rot_dim % 8 != 0 || seq >= (1ll << 31) || !aligned(q_in, 16) || !aligned(k_in, 16) ||
-      !aligned(q_out, 16) || !aligned(k_out, 16) || !aligned(cos, 16) || !aligned(sin, 16)) {
+  MQ_REQUIRE(cos && sin && stats, "%s: null pointer", fn);
+  bool ok = head_dim % 4 == 0 && head_dim <= 1024 && rot_dim <= head_dim && rot_dim % 8 == 0 && seq < (1ll << 31) && aligned(cos, 16) && aligned(sin, 16);
+  for (int k = 0; k < nseg; ++k) {
+    MQ_REQUIRE(in[k] && out[k], "%s: null pointer", fn);
+    ok = ok && aligned(in[k], 16) && aligned(out[k], 16);
+  }
+  if (!ok) {
     set_error("%s: not served: head_dim %% 4 == 0, head_dim <= 1024, rot_dim %% 8 == 0, rot_dim <= head_dim, 16-byte aligned pointers", fn);
     return MQ_EUNSUPPORTED;
   }
   CalibRopeArgs a;
-  a.x[0] = q_in; a.x[1] = k_in; a.out[0] = q_out; a.out[1] = k_out;
-  a.heads[0] = heads; a.heads[1] = kv_heads;
-  a.quads[0] = batch * seq * heads * head_dim / 4;
-  a.quads[1] = batch * seq * kv_heads * head_dim / 4;
-  a.S = (int)seq; a.D = head_dim; a.rot = rot_dim; a.cos = cos; a.sin = sin;
-  for (int k = 0; k < 8; ++k) {
-    MQ_REQUIRE(stats[k], "%s: null statistic %d", fn, k);
-    a.st[k] = stats[k];
+  a.nseg = nseg;
+  for (int k = 0; k < 3; ++k) {
+    a.x[k] = k < nseg ? in[k] : nullptr;
+    a.out[k] = k < nseg ? out[k] : nullptr;
+    a.heads[k] = k == 0 ? heads : kv_heads;
+    a.rep[k] = (k == 0 || !expand) ? 1 : heads / kv_heads;
+    a.rotate[k] = k < 2;
+    a.quads[k] = batch * seq * a.heads[k] * head_dim / 4;
   }
+  a.S = (int)seq; a.D = head_dim; a.rot = rot_dim; a.cos = cos; a.sin = sin;
+  for (int k = 0; k < 12; ++k) a.st[k] = nullptr;
+  for (int k = 0; k < 4 * nseg; ++k) a.st[k] = stats[k];
+  for (int k = 0; k < nseg; ++k) MQ_REQUIRE(a.st[4 * k] && a.st[4 * k + 1] && (a.st[4 * k + 2] == nullptr) == (a.st[4 * k + 3] == nullptr), "%s: statistics of segment %d", fn, k);
   const int dq = head_dim / 4;
   a.dq_shift = (dq & (dq - 1)) == 0 ? __builtin_ctz((unsigned)dq) : -1;
   long long grid = batch * seq;
@@ -883,6 +895,21 @@ int mq_calib_rope(const float* q_in, const float* k_in, float* q_out, float* k_o
   calib_rope_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
   MQ_LAUNCH_CHECK(fn);
   return MQ_OK;
+}
+
+int mq_calib_rope(const float* q_in, const float* k_in, float* q_out, float* k_out, int64_t batch, int64_t seq, int heads, int kv_heads, int head_dim,
+                  int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream) {
+  const float* in[2] = {q_in, k_in};
+  float* out[2] = {q_out, k_out};
+  if (stats) for (int k = 0; k < 8; ++k) MQ_REQUIRE(stats[k], "mq_calib_rope: null statistic %d", k);
+  return launch_calib_rope("mq_calib_rope", in, out, 2, batch, seq, heads, kv_heads, head_dim, rot_dim, 0, cos, sin, stats, stream);
+}
+
+int mq_calib_rope_qkv(const float* q_in, const float* k_in, const float* v_in, float* q_out, float* k_out, float* v_out, int64_t batch, int64_t seq, int heads,
+                      int kv_heads, int head_dim, int rot_dim, const float* cos, const float* sin, float* const* stats, mq_stream_t stream) {
+  const float* in[3] = {q_in, k_in, v_in};
+  float* out[3] = {q_out, k_out, v_out};
+  return launch_calib_rope("mq_calib_rope_qkv", in, out, 3, batch, seq, heads, kv_heads, head_dim, rot_dim, 1, cos, sin, stats, stream);
 }
 
 }  // extern "C"

@@ -113,28 +113,29 @@ class Attention(nn.Module):
         s = self.s
         B, S, _ = x.shape
         cl = self.__dict__.get("_mq_calib_layer")                   # (collector, names of q_proj / k_proj / qk_bmm) while ONE calibration pass runs
-        rope_taken = False
+        rope_taken = kv_repeated = False
         if (cl is not None and cache is None and not torch.is_grad_enabled() and cl[0].can_fuse_layer(x) and s.head_dim % 4 == 0
                 and cos.shape[-1] % 8 == 0 and cos.dtype == torch.float32):
             # calibration: RoPE on q and k in ONE launch that also takes the statistics of q_proj.output, k_proj.output, qk_bmm.input and
             # qk_bmm.input2 (the bits of apply_rope; the linears' and the matmul's hooks skip those fields)
-            col, (nq, nk, nqk, _) = cl
-            for m in (self.q_proj, self.k_proj):
+            col, (nq, nk, nqk, nv) = cl
+            for m in (self.q_proj, self.k_proj, self.v_proj):
                 m.__dict__["_mq_calib_skip"] = (col, ("output",))
             try:
-                ql, kl = self.q_proj(x), self.k_proj(x)
+                ql, kl, vl = self.q_proj(x), self.k_proj(x), self.v_proj(x)
             finally:
-                for m in (self.q_proj, self.k_proj):
+                for m in (self.q_proj, self.k_proj, self.v_proj):
                     m.__dict__.pop("_mq_calib_skip", None)
-            if ql.is_contiguous() and kl.is_contiguous() and ql.dtype == torch.float32:
-                q, k = col.rope_pass(nq, nk, nqk, ql, kl, s.heads, s.kv_heads, s.head_dim, cos, sin)
-                rope_taken = True
+            if all(t.is_contiguous() and t.dtype == torch.float32 for t in (ql, kl, vl)):
+                # (+ v carried along and repeat_kv inside: k, v come back with every kv head repeated -- [B, heads, S, D])
+                q, k, v = col.rope_qkv_pass(nq, nk, nv, nqk, ql, kl, vl, s.heads, s.kv_heads, s.head_dim, cos, sin)
+                rope_taken = kv_repeated = True
             else:
-                col._update(nq, "output", ql)
-                col._update(nk, "output", kl)
+                for n_, t_ in ((nq, ql), (nk, kl), (nv, vl)):
+                    col._update(n_, "output", t_)
                 q = apply_rope(ql.view(B, S, s.heads, s.head_dim).transpose(1, 2), cos, sin)
                 k = apply_rope(kl.view(B, S, s.kv_heads, s.head_dim).transpose(1, 2), cos, sin)
-            v = self.v_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
+                v = vl.view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
         else:
             q = self.q_proj(x).view(B, S, s.heads, s.head_dim).transpose(1, 2)
             k = self.k_proj(x).view(B, S, s.kv_heads, s.head_dim).transpose(1, 2)
@@ -145,7 +146,7 @@ class Attention(nn.Module):
             cache[1][:, :, pos:pos + S] = v
             k, v = cache[0][:, :, :pos + S], cache[1][:, :, :pos + S]
         rep = s.heads // s.kv_heads
-        if rep > 1:   # repeat_kv (hf_model.py:509-510)
+        if rep > 1 and not kv_repeated:   # repeat_kv (hf_model.py:509-510)
             k = k[:, :, None].expand(B, s.kv_heads, rep, k.shape[-2], s.head_dim).reshape(B, s.heads, -1, s.head_dim)
             v = v[:, :, None].expand(B, s.kv_heads, rep, v.shape[-2], s.head_dim).reshape(B, s.heads, -1, s.head_dim)
         from .quantization import qmodule as Q

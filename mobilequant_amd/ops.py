@@ -192,6 +192,24 @@ def calib_rope_(q_lin: torch.Tensor, k_lin: torch.Tensor, heads: int, kv_heads: 
     return q, k
 
 
+def calib_rope_qkv_(q_lin: torch.Tensor, k_lin: torch.Tensor, v_lin: torch.Tensor, heads: int, kv_heads: int, head_dim: int, cos: torch.Tensor,
+                    sin: torch.Tensor, stats):
+    """calib_rope_ with v carried along and repeat_kv inside (mq_calib_rope_qkv): returns q [B, heads, S, D] and k, v [B, heads, S, D]
+    with every kv head repeated heads / kv_heads times; stats = ten 1-element fp32 device tensors: (min, max) of q_lin, q, k_lin, k, v_lin."""
+    q_lin, k_lin, v_lin = _dev(q_lin, "q"), _dev(k_lin, "k"), _dev(v_lin, "v")
+    B, S = q_lin.shape[0], q_lin.shape[1]
+    cos, sin = _f32(cos, "cos").contiguous(), _f32(sin, "sin").contiguous()
+    if (any(t.dtype != torch.float32 or not t.is_contiguous() for t in (q_lin, k_lin, v_lin)) or q_lin.shape[-1] != heads * head_dim
+            or k_lin.shape[-1] != kv_heads * head_dim or v_lin.shape != k_lin.shape or cos.shape != sin.shape or cos.shape[0] != S):
+        raise RuntimeError("mobilequant_amd: calib_rope_qkv_ takes the contiguous float32 outputs of q_proj / k_proj / v_proj and cos / sin [S, rot]")
+    q, k, v = (torch.empty((B, heads, S, head_dim), dtype=torch.float32, device=q_lin.device) for _ in range(3))
+    ptrs = (ctypes.c_void_p * 12)(*([t.data_ptr() for t in stats] + [None, None]))
+    with _on(q_lin, k_lin, v_lin, q, k, v, cos, sin, *stats):
+        _lib.call("mq_calib_rope_qkv", q_lin.data_ptr(), k_lin.data_ptr(), v_lin.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, S, heads,
+                  kv_heads, head_dim, cos.shape[1], cos.data_ptr(), sin.data_ptr(), ptrs, _stream())
+    return q, k, v
+
+
 def calib_attention_probs_causal_(raw: torch.Tensor, out: torch.Tensor, sqrt_d: float, store_masked: bool, raw_min: torch.Tensor, raw_max: torch.Tensor,
                                   probs_min: torch.Tensor, probs_max: torch.Tensor) -> torch.Tensor:
     """calib_attention_probs_ under the causal mask of square [S, S] blocks (mq_calib_attention_probs_causal): no mask tensor is read;

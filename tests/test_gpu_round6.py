@@ -566,3 +566,28 @@ def test_per_channel_calibration_mirrors_the_groups_that_are_one_tensor(dev):
         for f in a[name]:
             assert torch.equal(a[name][f], b[name][f]), (name, f)
     assert got[True][1].keys() == got[False][1].keys() and all(torch.equal(got[True][1][k], got[False][1][k]) for k in got[True][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(2, 37, 32, 4, 64, 64), (1, 29, 8, 8, 64, 16), (1, 19, 6, 2, 80, 32)])
+def test_calib_rope_qkv_pass_is_apply_rope_and_repeat_kv_bit_for_bit(dev, geom):
+    from mobilequant_amd import ops, llama
+    B, S, H, KV, D, rot = geom
+    g = torch.Generator().manual_seed(S)
+    ql = (torch.randn(B, S, H * D, generator=g) * 1.7).to(dev)
+    kl = (torch.randn(B, S, KV * D, generator=g) * 0.6 + 0.2).to(dev)
+    vl = (torch.randn(B, S, KV * D, generator=g) * 2.5 - 0.4).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    ang = torch.outer(torch.arange(S, dtype=torch.float32) + 3, inv)
+    ang = torch.cat((ang, ang), dim=-1)
+    cos, sin = ang.cos().to(dev), ang.sin().to(dev)
+    st = [torch.full((1,), float("inf") if k % 2 == 0 else float("-inf"), device=dev) for k in range(10)]
+    q, k, v = ops.calib_rope_qkv_(ql, kl, vl, H, KV, D, cos, sin, st)
+    rep = H // KV
+    expand = lambda t: t[:, :, None].expand(B, KV, rep, S, D).reshape(B, H, S, D)
+    qw = llama.apply_rope(ql.view(B, S, H, D).transpose(1, 2), cos, sin)
+    kw = expand(llama.apply_rope(kl.view(B, S, KV, D).transpose(1, 2), cos, sin))
+    vw = expand(vl.view(B, S, KV, D).transpose(1, 2))
+    assert torch.equal(q, qw) and torch.equal(k, kw) and torch.equal(v, vw)
+    want = [ql.min(), ql.max(), qw.min(), qw.max(), kl.min(), kl.max(), kw.min(), kw.max(), vl.min(), vl.max()]
+    assert [float(t) for t in st] == [float(t) for t in want]
