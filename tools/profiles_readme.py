@@ -41,10 +41,10 @@ LOG_CAPTIONS = {
     "fuzz_full.log": "the random-shape fuzzers at full length on the final tree (`tests/fuzz_*.py`, `tests/stress_qmatmul_race.py`): every output against the oracles, 0 mismatches",
     "bench_qmatmul_final.log": "`tools/bench_qmatmul.py` and `tools/bench_calib_probs.py` on the final tree",
     "calibration_full_size_check.log": "`tools/r06_calib_full_size_check.py`: the act_dict with every round-6 calibration change on against the plain hooks, full-width 2-layer graphs of three families: worst relative deviation 1.8e-6 ... 2.6e-6",
-    "calibration512_stub_gemm.json": "`python bench.py --workload calibration --calib-samples 512 --calib-stub-gemm`: BASELINE.json configs[4] at its full size on one GPU, final tree (171 samples/s; round 5: 81)",
+    "calibration512_stub_gemm.json": "`python bench.py --workload calibration --calib-samples 512 --calib-stub-gemm`: BASELINE.json configs[4] at its full size on one GPU, final tree (180 samples/s; round 5: 81)",
     "calibration64.json": "`python bench.py --workload calibration --calib-samples 64`: the same graph with the fp32 library GEMMs in (22.5 samples/s)",
     "calibration64_per_channel_stub_gemm.json": "`... --calib-samples 64 --calib-stub-gemm --per-channel`: per-channel statistics (38 samples/s: the one-pass layer kernels are per-tensor only)",
-    "calibration_trace_after.summary.txt": "the same trace on the final tree (alias groups, `mq_calib_norm` / `mq_calib_gated` / `mq_calib_rope`): 333 -> 200 ms of kernels for the same passes",
+    "calibration_trace_after.summary.txt": "the same trace on the final tree (alias groups, `mq_calib_norm` / `mq_calib_gated` / `mq_calib_rope`): 333 -> 195 ms of kernels for the same passes",
     "calibration_trace.summary.txt": "`rocprofv3 --kernel-trace` of `bench.py --workload calibration --calib-samples 16 --calib-stub-gemm`: kernels of the calibration pass by share of GPU time, BEFORE the round-6 calibration changes",
     "fuzz_and_per_sequence_ppl.log": "`pytest tests/test_gpu_fuzz.py tests/test_gpu_round5.py -k 'fuzz or perplexity' -s`: the fuzzer slices inside `-m gpu` and the per-sequence perplexity differences",
     "bench_wall.log": "wall time of `python bench.py --steps 20 --warmup 5` (round 5: 173 s)",
